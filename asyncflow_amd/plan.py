@@ -1,0 +1,374 @@
+"""Lower a normalised payload to the flat device plan (``af_plan_t``).
+
+This is the batched analogue of the reference's per-run build/wire phase
+(/root/reference/src/asyncflow/runtime/simulation_runner.py:127-294): it is done
+ONCE per sweep, the plan is shared by every scenario, and per-scenario
+parameters travel as override columns (``af_sweep_t``).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import Any
+
+import numpy as np
+
+from . import _abi
+from .payload import CPU_STEP_KINDS, IO_STEP_KINDS, RAM_STEP_KINDS, normalize_payload
+
+
+def _ptr(arr: np.ndarray, ctype: Any) -> Any:
+    return arr.ctypes.data_as(C.POINTER(ctype))
+
+
+@dataclass
+class DevicePlan:
+    """Flat SoA description of one topology + workload + event timelines."""
+
+    payload: dict
+    total_time: float
+    sample_period: float
+    metrics_mask: int
+    gen_users_dist: int
+    gen_users_mean: float
+    gen_users_sigma: float
+    gen_rpm_mean: float
+    gen_window_s: float
+    gen_out_edge: int
+    client_out_edge: int
+    has_lb: bool
+    lb_algo: int
+    lb_edges: np.ndarray
+    edge_target_kind: np.ndarray
+    edge_target_idx: np.ndarray
+    edge_dist: np.ndarray
+    edge_mean: np.ndarray
+    edge_sigma: np.ndarray
+    edge_dropout: np.ndarray
+    srv_cores: np.ndarray
+    srv_ram_mb: np.ndarray
+    srv_out_edge: np.ndarray
+    srv_ep_begin: np.ndarray
+    ep_step_begin: np.ndarray
+    ep_ram: np.ndarray
+    step_kind: np.ndarray
+    step_time: np.ndarray
+    emark_time: np.ndarray
+    emark_edge: np.ndarray
+    emark_delta: np.ndarray
+    smark_time: np.ndarray
+    smark_lb_edge: np.ndarray
+    smark_down: np.ndarray
+    edge_ids: list[str] = field(default_factory=list)
+    server_ids: list[str] = field(default_factory=list)
+    #: payload step (server, endpoint, step) -> flat step index (RAM steps: -1)
+    step_index: dict[tuple[int, int, int], int] = field(default_factory=dict)
+
+    @property
+    def n_edges(self) -> int:
+        return len(self.edge_ids)
+
+    @property
+    def n_servers(self) -> int:
+        return len(self.server_ids)
+
+    @property
+    def n_series(self) -> int:
+        return self.n_edges + 3 * self.n_servers
+
+    @property
+    def tick_count(self) -> int:
+        """Ticks ``env.run(until=T)`` takes (metrics/collector.py:50-53).
+
+        The collector's clock is ``0 + p + p + ...`` in f64 and the stop event
+        is URGENT at T, so the count follows repeated addition, not ``T/p``.
+        """
+        n, t = 0, 0.0 + self.sample_period
+        while t < self.total_time:
+            n += 1
+            t = t + self.sample_period
+        return n
+
+    def as_ctypes(self) -> _abi.AfPlan:
+        p = _abi.AfPlan()
+        p.abi_version = _abi.AF_ABI_VERSION
+        p.struct_size = C.sizeof(_abi.AfPlan)
+        p.total_time = self.total_time
+        p.sample_period = self.sample_period
+        p.metrics_mask = self.metrics_mask
+        p.gen_users_dist = self.gen_users_dist
+        p.gen_users_mean = self.gen_users_mean
+        p.gen_users_sigma = self.gen_users_sigma
+        p.gen_rpm_mean = self.gen_rpm_mean
+        p.gen_window_s = self.gen_window_s
+        p.gen_out_edge = self.gen_out_edge
+        p.n_edges = self.n_edges
+        p.n_servers = self.n_servers
+        p.client_out_edge = self.client_out_edge
+        p.has_lb = int(self.has_lb)
+        p.lb_algo = self.lb_algo
+        p.n_lb_edges = len(self.lb_edges)
+        p.lb_edges = _ptr(self.lb_edges, C.c_int32)
+        p.edge_target_kind = _ptr(self.edge_target_kind, C.c_uint8)
+        p.edge_target_idx = _ptr(self.edge_target_idx, C.c_int32)
+        p.edge_dist = _ptr(self.edge_dist, C.c_uint8)
+        p.edge_mean = _ptr(self.edge_mean, C.c_double)
+        p.edge_sigma = _ptr(self.edge_sigma, C.c_double)
+        p.edge_dropout = _ptr(self.edge_dropout, C.c_double)
+        p.srv_cores = _ptr(self.srv_cores, C.c_uint32)
+        p.srv_ram_mb = _ptr(self.srv_ram_mb, C.c_double)
+        p.srv_out_edge = _ptr(self.srv_out_edge, C.c_int32)
+        p.srv_ep_begin = _ptr(self.srv_ep_begin, C.c_uint32)
+        p.n_endpoints = len(self.ep_ram)
+        p.ep_step_begin = _ptr(self.ep_step_begin, C.c_uint32)
+        p.ep_ram = _ptr(self.ep_ram, C.c_double)
+        p.n_steps = len(self.step_kind)
+        p.step_kind = _ptr(self.step_kind, C.c_uint8)
+        p.step_time = _ptr(self.step_time, C.c_double)
+        p.n_edge_marks = len(self.emark_time)
+        p.emark_time = _ptr(self.emark_time, C.c_double)
+        p.emark_edge = _ptr(self.emark_edge, C.c_int32)
+        p.emark_delta = _ptr(self.emark_delta, C.c_double)
+        p.n_srv_marks = len(self.smark_time)
+        p.smark_time = _ptr(self.smark_time, C.c_double)
+        p.smark_lb_edge = _ptr(self.smark_lb_edge, C.c_int32)
+        p.smark_down = _ptr(self.smark_down, C.c_uint8)
+        p._keepalive = self  # noqa: SLF001 - arrays must outlive the struct
+        return p
+
+    # ------------------------------------------------------------------ #
+    # sizing helpers                                                      #
+    # ------------------------------------------------------------------ #
+    def expected_arrivals(self, users_mean: float | None = None, rpm: float | None = None) -> tuple[float, float]:
+        """(mean, std) of the number of generated requests over the horizon.
+
+        Compound process of samplers/poisson_poisson.py:20-82: per window W,
+        N | U ~ Poisson(U r W), so Var N = E[U] r W + Var(U) (r W)^2.
+        """
+        u = self.gen_users_mean if users_mean is None else users_mean
+        r = (self.gen_rpm_mean if rpm is None else rpm) / 60.0
+        w = min(self.gen_window_s, self.total_time)
+        n_win = self.total_time / w
+        var_u = u if self.gen_users_dist == _abi.DIST_CODES["poisson"] else self.gen_users_sigma**2
+        mean = u * r * self.total_time
+        var = n_win * (u * r * w + var_u * (r * w) ** 2)
+        return mean, math.sqrt(max(var, 0.0))
+
+    def clock_capacity(self, users_mean: float | None = None, rpm: float | None = None) -> int:
+        mean, std = self.expected_arrivals(users_mean, rpm)
+        return int(mean + 8.0 * std + 64.0)
+
+
+def _edge_latency_scale(lat: dict) -> float:
+    """A rough typical transit time, only used to size request pools."""
+    d, m, s = lat["distribution"], lat["mean"], lat["variance"] or 0.0
+    if d == "log_normal":
+        return math.exp(min(m + 2.0 * s, 50.0))
+    if d == "normal":
+        return max(m, 0.0) + 2.0 * s
+    if d == "uniform":
+        return 1.0
+    if d == "poisson":
+        return m + 3.0 * math.sqrt(m) + 1.0
+    return 3.0 * m
+
+
+def lower(payload: Any) -> DevicePlan:  # noqa: C901, PLR0912, PLR0915
+    """``SimulationPayload`` | dict  ->  :class:`DevicePlan`.
+
+    Mirrors the wiring of ``SimulationRunner._build_edges``
+    (simulation_runner.py:205-260) and the timelines of
+    ``EventInjectionRuntime.__init__`` (runtime/events/injection.py:119-163).
+    """
+    p = normalize_payload(payload)
+    rqs, tg, st = p["rqs_input"], p["topology_graph"], p["sim_settings"]
+    nodes = tg["nodes"]
+    servers, client, lb = nodes["servers"], nodes["client"], nodes["load_balancer"]
+    edges = tg["edges"]
+    server_ids = [s["id"] for s in servers]
+    srv_index = {sid: i for i, sid in enumerate(server_ids)}
+    edge_ids = [e["id"] for e in edges]
+    edge_index = {eid: i for i, eid in enumerate(edge_ids)}
+
+    # ---- wiring (simulation_runner.py:205-260); later edges win, as the dict
+    # assignment `source_object.out_edge = ...` does.
+    gen_out, client_out = -1, -1
+    srv_out = [-1] * len(servers)
+    lb_edges: list[int] = []
+    tkind, tidx = [], []
+    for i, e in enumerate(edges):
+        if e["target"] in srv_index:
+            tkind.append(_abi.NODE_SERVER)
+            tidx.append(srv_index[e["target"]])
+        elif e["target"] == client["id"]:
+            tkind.append(_abi.NODE_CLIENT)
+            tidx.append(0)
+        elif lb is not None and e["target"] == lb["id"]:
+            tkind.append(_abi.NODE_LB)
+            tidx.append(0)
+        else:  # unreachable after validation; the runner raises TypeError here
+            msg = f"Unknown runtime for {e['target']!r}"
+            raise TypeError(msg)
+        src = e["source"]
+        if src in srv_index:
+            srv_out[srv_index[src]] = i
+        elif src == client["id"]:
+            client_out = i
+        elif src == rqs["id"]:
+            gen_out = i
+        elif lb is not None and src == lb["id"]:
+            lb_edges.append(i)
+        else:  # all_nodes[edge.source] -> KeyError in the reference
+            msg = f"edge '{e['id']}': unknown source node '{src}'"
+            raise ValueError(msg)
+    if gen_out < 0:
+        msg = "the request generator has no outgoing edge"  # assert at rqs_generator.py:99
+        raise ValueError(msg)
+    if client_out < 0:
+        msg = "the client has no outgoing edge"  # assert at client.py:45
+        raise ValueError(msg)
+    for i, o in enumerate(srv_out):
+        if o < 0:
+            msg = f"server '{server_ids[i]}' has no outgoing edge"  # assert at server.py:275
+            raise ValueError(msg)
+    if lb is not None and not lb_edges:
+        msg = "the load balancer has no outgoing edge"
+        raise ValueError(msg)
+
+    # ---- servers / endpoints / steps (server.py:95-110: RAM summed up front)
+    srv_ep_begin, ep_step_begin, ep_ram = [0], [0], []
+    step_kind, step_time = [], []
+    step_index: dict[tuple[int, int, int], int] = {}
+    for si, s in enumerate(servers):
+        if not s["endpoints"]:
+            # rng.integers(low=0, high=0) raises ValueError in the reference (server.py:101)
+            msg = f"server '{s['id']}' has no endpoints"
+            raise ValueError(msg)
+        for ei, ep in enumerate(s["endpoints"]):
+            ram = 0
+            for ki, stp in enumerate(ep["steps"]):
+                (op, val), = stp["step_operation"].items()
+                if stp["kind"] in RAM_STEP_KINDS:
+                    ram = ram + val  # same left-to-right sum as server.py:106-110
+                    step_index[(si, ei, ki)] = -1
+                elif stp["kind"] in CPU_STEP_KINDS:
+                    step_index[(si, ei, ki)] = len(step_kind)
+                    step_kind.append(_abi.STEP_CPU)
+                    step_time.append(float(val))
+                elif stp["kind"] in IO_STEP_KINDS:
+                    step_index[(si, ei, ki)] = len(step_kind)
+                    step_kind.append(_abi.STEP_IO)
+                    step_time.append(float(val))
+            ep_ram.append(float(ram))
+            ep_step_begin.append(len(step_kind))
+        srv_ep_begin.append(len(ep_ram))
+
+    # ---- event timelines (injection.py:119-163)
+    emarks: list[tuple[float, int, str, str, float]] = []
+    smarks: list[tuple[float, int, str, str]] = []
+    edge_by_server: dict[str, int] = {}
+    for ei in lb_edges:  # injection.py:158-163: last LB edge per server wins
+        edge_by_server[edges[ei]["target"]] = ei
+    for ev in p["events"] or []:
+        tgt = ev["target_id"]
+        if tgt in edge_index:
+            spike = float(ev["start"]["spike_s"])
+            emarks.append((ev["start"]["t_start"], 1, ev["event_id"], tgt, spike))
+            emarks.append((ev["end"]["t_end"], 0, ev["event_id"], tgt, spike))
+        elif tgt in srv_index:
+            smarks.append((ev["start"]["t_start"], 1, ev["event_id"], tgt))
+            smarks.append((ev["end"]["t_end"], 0, ev["event_id"], tgt))
+    # sort key (time, mark == start, event_id, target_id): END before START at equal t
+    emarks.sort(key=lambda m: (m[0], m[1] == 1, m[2], m[3]))
+    smarks.sort(key=lambda m: (m[0], m[1] == 1, m[2], m[3]))
+
+    def _env_times(ts: list[float]) -> list[float]:
+        # injection.py:181-188: `dt = t - last_t; if dt > 0: yield timeout(dt)`;
+        # the clock after the wait is now + dt, which is what we store.
+        out, now, last = [], 0.0, 0.0
+        for t in ts:
+            dt = t - last
+            if dt > 0.0:
+                now = now + dt
+            last = t
+            out.append(now)
+        return out
+
+    emark_time = _env_times([m[0] for m in emarks])
+    smark_time = _env_times([m[0] for m in smarks])
+
+    mask = 0
+    for m in st["enabled_sample_metrics"]:
+        mask |= _abi.METRIC_BITS[m]
+
+    users = rqs["avg_active_users"]
+    f64 = np.float64
+    plan = DevicePlan(
+        payload=p,
+        total_time=float(st["total_simulation_time"]),
+        sample_period=float(st["sample_period_s"]),
+        metrics_mask=mask,
+        gen_users_dist=_abi.DIST_CODES[users["distribution"]],
+        gen_users_mean=float(users["mean"]),
+        gen_users_sigma=float(users["variance"] if users["variance"] is not None else 0.0),
+        gen_rpm_mean=float(rqs["avg_request_per_minute_per_user"]["mean"]),
+        gen_window_s=float(rqs["user_sampling_window"]),
+        gen_out_edge=gen_out,
+        client_out_edge=client_out,
+        has_lb=lb is not None,
+        lb_algo=_abi.LB_CODES[lb["algorithms"]] if lb else 0,
+        lb_edges=np.asarray(lb_edges, dtype=np.int32).reshape(-1),
+        edge_target_kind=np.asarray(tkind, dtype=np.uint8),
+        edge_target_idx=np.asarray(tidx, dtype=np.int32),
+        edge_dist=np.asarray([_abi.DIST_CODES[e["latency"]["distribution"]] for e in edges], dtype=np.uint8),
+        edge_mean=np.asarray([e["latency"]["mean"] for e in edges], dtype=f64),
+        edge_sigma=np.asarray(
+            [e["latency"]["variance"] if e["latency"]["variance"] is not None else 0.0 for e in edges], dtype=f64
+        ),
+        edge_dropout=np.asarray([e["dropout_rate"] for e in edges], dtype=f64),
+        srv_cores=np.asarray([s["server_resources"]["cpu_cores"] for s in servers], dtype=np.uint32),
+        srv_ram_mb=np.asarray([s["server_resources"]["ram_mb"] for s in servers], dtype=f64),
+        srv_out_edge=np.asarray(srv_out, dtype=np.int32),
+        srv_ep_begin=np.asarray(srv_ep_begin, dtype=np.uint32),
+        ep_step_begin=np.asarray(ep_step_begin, dtype=np.uint32),
+        ep_ram=np.asarray(ep_ram, dtype=f64),
+        step_kind=np.asarray(step_kind, dtype=np.uint8),
+        step_time=np.asarray(step_time, dtype=f64),
+        emark_time=np.asarray(emark_time, dtype=f64),
+        emark_edge=np.asarray([edge_index[m[3]] for m in emarks], dtype=np.int32),
+        emark_delta=np.asarray([m[4] if m[1] == 1 else -m[4] for m in emarks], dtype=f64),
+        smark_time=np.asarray(smark_time, dtype=f64),
+        smark_lb_edge=np.asarray([edge_by_server.get(m[3], -1) for m in smarks], dtype=np.int32),
+        smark_down=np.asarray([m[1] for m in smarks], dtype=np.uint8),
+        edge_ids=edge_ids,
+        server_ids=server_ids,
+        step_index=step_index,
+    )
+    return plan
+
+
+def estimate_capacities(plan: DevicePlan, users_max: float | None = None, latency_scale: float = 1.0) -> tuple[int, int]:
+    """(request_capacity, fifo_capacity) heuristics for the engine.
+
+    Live requests ~ arrival rate x time in system (Little); time in system is
+    bounded by the sum of typical edge transits along the longest path + spikes
+    + service.  Overflow is detected and reported by the engine, never silent.
+    """
+    payload = plan.payload
+    users = plan.gen_users_mean if users_max is None else users_max
+    sd = math.sqrt(users) if plan.gen_users_dist == _abi.DIST_CODES["poisson"] else plan.gen_users_sigma
+    rate = (users + 6.0 * sd) * plan.gen_rpm_mean / 60.0
+    lat = sorted((_edge_latency_scale(e["latency"]) * latency_scale for e in payload["topology_graph"]["edges"]), reverse=True)
+    path = sum(lat[: 4 + max(0, plan.n_servers - 2)])
+    spike = sum(abs(float(d)) for d in plan.emark_delta[plan.emark_delta > 0]) if len(plan.emark_delta) else 0.0
+    service = 0.0
+    for ep in range(len(plan.ep_ram)):
+        b, e = plan.ep_step_begin[ep], plan.ep_step_begin[ep + 1]
+        service = max(service, float(plan.step_time[b:e].sum()))
+    live = rate * (path + spike + 4.0 * service)
+    cap = int(max(16, 8 + 4.0 * live + 10.0 * math.sqrt(max(live, 1.0))))
+    cap = 1 << max(4, (cap - 1).bit_length())
+    fifo = max(8, min(cap, 1 << max(3, (cap // 2 - 1).bit_length())))
+    return cap, fifo

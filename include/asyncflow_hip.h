@@ -1,0 +1,251 @@
+/* asyncflow_hip.h -- C ABI of the MI355X batched discrete-event engine.
+ *
+ * Drop-in boundary for ONE hot path of AsyncFlow (reference @ /root/reference):
+ *
+ *     SimulationRunner.run()  ->  simpy.Environment.run(until=T)
+ *     (src/asyncflow/runtime/simulation_runner.py:349-376)
+ *
+ * executed over n independent scenarios (seed replicas / parameter-grid points)
+ * on one MI355X.  The reference has NO FFI/plugin boundary for this path
+ * (pure Python): the only seam is the Python call
+ * `SimulationRunner(env=..., simulation_input=SimulationPayload).run()`.
+ * The host-side mirror of that call is asyncflow_amd.SimulationRunner
+ * (asyncflow_amd/runner.py); it lowers the validated payload to `af_plan_t`
+ * and calls the entry points below through ctypes (INTEGRATION.md shows the
+ * stub a reference maintainer would add).
+ *
+ * Conventions
+ *  - plain C, no torch / HIP types in signatures; pointers + sizes only;
+ *  - every `const T*` inside af_plan_t / af_sweep_t is HOST memory, borrowed for
+ *    the duration of the call (the engine copies what it needs to the device);
+ *  - every pointer inside af_outputs_t is DEVICE memory owned by the caller
+ *    (e.g. torch tensors); the engine never allocates or frees output buffers;
+ *  - all entry points return 0 on success, a negative af_status otherwise, and
+ *    leave a thread-local message retrievable through af_last_error();
+ *  - one host thread per engine; calls are synchronous with respect to the
+ *    returned buffers (one internal HIP stream, synchronised before return);
+ *  - capacity overflow is reported per scenario in counts[AF_CNT_FLAGS] and is
+ *    never a silent drop.
+ */
+#ifndef ASYNCFLOW_HIP_H
+#define ASYNCFLOW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AF_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------ */
+enum af_status {
+    AF_OK = 0,
+    AF_ERR_INVALID = -1,     /* malformed plan / sweep / outputs            */
+    AF_ERR_NO_DEVICE = -2,   /* no HIP device, or device index out of range */
+    AF_ERR_HIP = -3,         /* a HIP runtime call failed                   */
+    AF_ERR_CAPACITY = -4,    /* requested capacities exceed what a wave can hold */
+    AF_ERR_ABI = -5          /* caller built against another AF_ABI_VERSION */
+};
+
+/* ---- enumerations mirrored from src/asyncflow/config/constants.py ------- */
+/* Distribution (constants.py:39-52) */
+enum af_dist {
+    AF_DIST_POISSON = 0,
+    AF_DIST_NORMAL = 1,
+    AF_DIST_LOG_NORMAL = 2,
+    AF_DIST_EXPONENTIAL = 3,
+    AF_DIST_UNIFORM = 4
+};
+/* SystemNodes that can be an edge target (constants.py:155-166) */
+enum af_node_kind { AF_NODE_CLIENT = 0, AF_NODE_LB = 1, AF_NODE_SERVER = 2 };
+/* LbAlgorithmsName (constants.py:144-148) */
+enum af_lb_algo { AF_LB_ROUND_ROBIN = 0, AF_LB_LEAST_CONNECTIONS = 1 };
+/* EndpointStepCPU / EndpointStepIO (constants.py:58-89); RAM steps are folded
+ * into ep_ram at lowering time (server.py:106-110 sums them up front). */
+enum af_step_kind { AF_STEP_CPU = 0, AF_STEP_IO = 1 };
+/* SampledMetricName (constants.py:195-205) as a bit mask */
+enum af_metric_bit {
+    AF_METRIC_READY_QUEUE_LEN = 1u << 0,
+    AF_METRIC_EVENT_LOOP_IO_SLEEP = 1u << 1,
+    AF_METRIC_RAM_IN_USE = 1u << 2,
+    AF_METRIC_EDGE_CONCURRENT_CONNECTION = 1u << 3
+};
+
+/* ---- the lowered scenario (shared by every scenario of a sweep) -------- */
+typedef struct af_plan {
+    uint32_t abi_version;  /* = AF_ABI_VERSION                                   */
+    uint32_t struct_size;  /* = sizeof(af_plan_t)                                */
+
+    /* SimulationSettings (schemas/settings/simulation.py:13-44) */
+    double total_time;     /* total_simulation_time (s)                          */
+    double sample_period;  /* sample_period_s (s)                                */
+    uint32_t metrics_mask; /* af_metric_bit                                      */
+
+    /* RqsGenerator (schemas/workload/rqs_generator.py:10-59) */
+    uint32_t gen_users_dist;   /* AF_DIST_POISSON | AF_DIST_NORMAL               */
+    double gen_users_mean;     /* avg_active_users.mean                          */
+    double gen_users_sigma;    /* avg_active_users.variance (used AS sigma)      */
+    double gen_rpm_mean;       /* avg_request_per_minute_per_user.mean           */
+    double gen_window_s;       /* user_sampling_window                           */
+    int32_t gen_out_edge;      /* edge index leaving the generator               */
+
+    /* topology (schemas/topology/{nodes,edges,graph}.py) */
+    uint32_t n_edges;
+    uint32_t n_servers;
+    int32_t client_out_edge;   /* edge index leaving the client                  */
+    uint32_t has_lb;
+    uint32_t lb_algo;          /* af_lb_algo                                     */
+    uint32_t n_lb_edges;
+    const int32_t* lb_edges;   /* [n_lb_edges] LB out-edges in payload order     */
+
+    const uint8_t* edge_target_kind;  /* [n_edges] af_node_kind                  */
+    const int32_t* edge_target_idx;   /* [n_edges] server index (or 0)           */
+    const uint8_t* edge_dist;         /* [n_edges] af_dist of latency            */
+    const double* edge_mean;          /* [n_edges] latency.mean                  */
+    const double* edge_sigma;         /* [n_edges] latency.variance (AS sigma)   */
+    const double* edge_dropout;       /* [n_edges] dropout_rate                  */
+
+    const uint32_t* srv_cores;        /* [n_servers] cpu_cores                   */
+    const double* srv_ram_mb;         /* [n_servers] ram_mb                      */
+    const int32_t* srv_out_edge;      /* [n_servers] edge leaving the server     */
+    const uint32_t* srv_ep_begin;     /* [n_servers+1] CSR into endpoints        */
+
+    uint32_t n_endpoints;
+    const uint32_t* ep_step_begin;    /* [n_endpoints+1] CSR into steps          */
+    const double* ep_ram;             /* [n_endpoints] sum of necessary_ram      */
+
+    uint32_t n_steps;
+    const uint8_t* step_kind;         /* [n_steps] af_step_kind                  */
+    const double* step_time;          /* [n_steps] cpu_time | io_waiting_time    */
+
+    /* EventInjection timelines, pre-sorted exactly like
+     * runtime/events/injection.py:142-151; *_time is the simulation clock at
+     * which the mark is applied (relative waits re-accumulated, :181-188). */
+    uint32_t n_edge_marks;
+    const double* emark_time;         /* [n_edge_marks]                          */
+    const int32_t* emark_edge;        /* [n_edge_marks] edge index               */
+    const double* emark_delta;        /* [n_edge_marks] +spike_s start / -spike_s end */
+    uint32_t n_srv_marks;
+    const double* smark_time;         /* [n_srv_marks]                           */
+    const int32_t* smark_lb_edge;     /* [n_srv_marks] LB out-edge index, -1 = not behind LB */
+    const uint8_t* smark_down;        /* [n_srv_marks] 1 = SERVER_DOWN, 0 = SERVER_UP */
+} af_plan_t;
+
+/* ---- per-scenario inputs ------------------------------------------------ */
+enum af_param {
+    AF_PARAM_GEN_USERS_MEAN = 0,
+    AF_PARAM_GEN_USERS_SIGMA = 1,
+    AF_PARAM_GEN_RPM_MEAN = 2,
+    AF_PARAM_EDGE_MEAN = 3,     /* index = edge  */
+    AF_PARAM_EDGE_SIGMA = 4,    /* index = edge  */
+    AF_PARAM_EDGE_DROPOUT = 5,  /* index = edge  */
+    AF_PARAM_STEP_TIME = 6,     /* index = step  */
+    AF_PARAM_COUNT_ = 7
+};
+
+typedef struct af_override {
+    uint32_t param;        /* af_param                                         */
+    uint32_t index;        /* entity index for the indexed params, else 0      */
+    const double* values;  /* HOST [n_scenarios]                               */
+} af_override_t;
+
+typedef struct af_sweep {
+    uint32_t n_scenarios;
+    const uint64_t* seeds;            /* HOST [n_scenarios] Philox keys          */
+    uint32_t n_overrides;
+    const af_override_t* overrides;   /* HOST [n_overrides]                      */
+} af_sweep_t;
+
+/* ---- outputs ------------------------------------------------------------- */
+/* counts[scenario][AF_CNT_*] */
+enum af_count_slot {
+    AF_CNT_GENERATED = 0,  /* RqsGeneratorRuntime.id_counter                     */
+    AF_CNT_COMPLETED = 1,  /* len(ClientRuntime.rqs_clock)                       */
+    AF_CNT_DROPPED = 2,    /* messages lost on edges (edge.py:78-86)             */
+    AF_CNT_EVENTS = 3,     /* request-events: arrivals + deliveries + cpu/io step ends */
+    AF_CNT_TICKS = 4,      /* sampler ticks taken (collector.py:50-66)           */
+    AF_CNT_FLAGS = 5,      /* af_flag bits                                       */
+    AF_CNT_MAX_LIVE = 6,   /* high-water mark of live requests                   */
+    AF_CNT_MARKS = 7,      /* injection marks applied                            */
+    AF_CNT_SLOTS = 8
+};
+enum af_flag {
+    AF_FLAG_POOL_OVERFLOW = 1u << 0,   /* more live requests than request_capacity */
+    AF_FLAG_FIFO_OVERFLOW = 1u << 1,   /* a CPU/RAM wait queue exceeded fifo_capacity */
+    AF_FLAG_CLOCK_OVERFLOW = 1u << 2,  /* more completions than clock_capacity     */
+    AF_FLAG_TICK_OVERFLOW = 1u << 3,   /* more ticks than tick_capacity            */
+    AF_FLAG_RAM_STARVED = 1u << 4      /* a request needs more RAM than ram_mb: that
+                                          server's RAM queue is blocked for good
+                                          (same as the reference; informational) */
+};
+
+typedef struct af_outputs {
+    /* RqsClock list (metrics/client.py:9-18): (start, finish) per completion,
+     * in completion order.  DEVICE [n_scenarios][clock_capacity][2] f64. */
+    uint32_t clock_capacity;
+    double* clock;
+    /* Sampled series (metrics/collector.py:50-66).
+     * DEVICE [n_scenarios][n_series][tick_capacity] 4-byte words, series order:
+     *   e in [0,n_edges):            edge_concurrent_connection (int32)
+     *   n_edges + 3*s + 0:           ready_queue_len   of server s (int32)
+     *   n_edges + 3*s + 1:           event_loop_io_sleep of server s (int32)
+     *   n_edges + 3*s + 2:           ram_in_use        of server s (float32)
+     * May be NULL (series not stored; ticks still counted). */
+    uint32_t tick_capacity;
+    uint32_t* samples;
+    /* DEVICE [n_scenarios][AF_CNT_SLOTS] u32 */
+    uint32_t* counts;
+} af_outputs_t;
+
+typedef struct af_engine_options {
+    uint32_t request_capacity;  /* live requests per scenario (0 = engine default) */
+    uint32_t fifo_capacity;     /* waiters per server queue   (0 = engine default) */
+    uint32_t force_global_state;/* 1 = keep per-scenario state in HBM even if it fits LDS */
+} af_engine_options_t;
+
+typedef struct af_stats {
+    double kernel_ms;           /* HIP-event time of the last af_engine_run kernel */
+    double h2d_ms;              /* seeds/overrides upload                          */
+    uint64_t state_bytes_per_scenario;
+    uint32_t state_in_lds;      /* 1 = LDS-resident state, 0 = HBM-resident        */
+    uint32_t lds_bytes_per_wave;
+    uint32_t waves;             /* workgroups launched (one wave of 64 scenarios)  */
+    uint32_t request_capacity;
+    uint32_t fifo_capacity;
+} af_stats_t;
+
+typedef struct af_engine af_engine_t;
+
+/* Replaces: SimulationRunner.__init__ + _build_* (simulation_runner.py:52-294). */
+int af_engine_create(const af_plan_t* plan, int device, const af_engine_options_t* opts,
+                     af_engine_t** out);
+/* Replaces: _start_* + env.run(until=T) (simulation_runner.py:301-369) for
+ * sweep->n_scenarios independent scenarios. */
+int af_engine_run(af_engine_t* eng, const af_sweep_t* sweep, const af_outputs_t* out);
+int af_engine_stats(const af_engine_t* eng, af_stats_t* stats);
+void af_engine_destroy(af_engine_t* eng);
+
+/* Number of sampler ticks env.run(until=T) takes for (period, T): repeated f64
+ * addition from 0, tick at t < T only (collector.py:50-53). */
+uint32_t af_tick_count(double sample_period, double total_time);
+uint32_t af_series_count(const af_plan_t* plan);  /* n_edges + 3*n_servers */
+
+const char* af_last_error(void);
+int af_abi_version(void);
+
+/* Spec probes (device): evaluate the engine's own RNG/math on the GPU so the
+ * parity tests can pin them against the oracle bit for bit.
+ *   kind 0: uniform(seed,stream,index,j)
+ *   kind 1: log(x)   kind 2: exp(x)   kind 3: norminv(x)   kind 4: sqrt(x)
+ *   kind 5: x / y (x = in[i], y = in2[i])
+ * `in`, `in2`, `out` are HOST arrays of n doubles (kind 0: in[i] = index,
+ * in2[i] = stream * 65536 + j, both exact small integers). */
+int af_probe_math(int device, int kind, uint64_t seed, const double* in, const double* in2,
+                  double* out, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASYNCFLOW_HIP_H */
