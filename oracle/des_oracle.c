@@ -6,11 +6,18 @@
  *     SimulationRunner.run() -> env.run(until=T)
  *     (/root/reference/src/asyncflow/runtime/simulation_runner.py:349-376)
  *
- * i.e. the reference actors + the SimPy 4.1.1 scheduling rules they rely on,
- * reduced to the TIMED events (SimPy `Timeout`s); every zero-time SimPy step
- * (Initialize, Store put/get, Container put/get, process end) is executed
- * inline, in the order SimPy would run it.  Random variates come from the
- * counter-based spec in oracle_rng.h (see there for why not numpy's PCG64).
+ * i.e. the reference actors AND the SimPy 4.1.1 scheduling rules they run on.
+ * Every SimPy event the reference creates -- Timeouts, but also the zero-time
+ * Initialize / Store put+get / Container put+get events -- is an entry of ONE
+ * heap keyed (time, priority, eid) exactly like simpy.Environment's, and each
+ * reference generator is a small state machine resumed at its `yield` points.
+ * (Events nobody waits on -- process-termination events -- are not created:
+ * dropping an eid does not change the relative order of the others.)
+ * This matters: with deterministic step times, queued requests finish at
+ * EXACTLY equal timestamps and SimPy then interleaves the zero-time steps of the
+ * tied cascades breadth-first; tests/golden/overload_t30 pins that behaviour.
+ * Random variates come from the counter-based spec in oracle_rng.h (see there
+ * for why not numpy's PCG64).
  *
  * Pinning: tests/test_oracle_golden.py checks this file bit for bit against
  * tests/golden/ (npz files), which oracle/make_golden.py produced by running the
@@ -20,10 +27,10 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use
  * this library; asyncflow_amd never links or loads it.
  *
- * Tie rule: pending timed events are ordered by (time, push sequence), the
- * analogue of SimPy's (time, priority=NORMAL, eid).  Exact ties between
- * independent timed events have probability zero under continuous latency
- * distributions; see DESIGN.md "Ties".
+ * counts[AF_CNT_MARKS+...]: see orc_simulate; `ties` (returned through
+ * orc_last_ties) counts timed events popped at the timestamp of the previous
+ * one, i.e. the situations in which an engine that runs zero-time cascades
+ * atomically may legally differ from SimPy's interleaving (DESIGN.md "Ties").
  */
 #include <math.h>
 #include <stdint.h>
@@ -34,31 +41,60 @@
 #include "oracle_rng.h"
 
 /* ---------------------------------------------------------------- events */
-enum { EV_ARRIVAL, EV_TICK, EV_EMARK, EV_SMARK, EV_DELIVER, EV_CPU_DONE, EV_IO_DONE };
+#define PRIO_URGENT 0
+#define PRIO_NORMAL 1
+
+enum {
+    /* timed (simpy.Timeout) */
+    EV_GEN_TIMEOUT,   /* rqs_generator.py:104  yield env.timeout(gap)           */
+    EV_TICK,          /* collector.py:53       yield env.timeout(period)        */
+    EV_EMARK,         /* injection.py:187      yield env.timeout(dt)            */
+    EV_SMARK,         /* injection.py:210                                       */
+    EV_EDGE_TIMEOUT,  /* edge.py:107           yield env.timeout(effective)     */
+    EV_STEP_TIMEOUT,  /* server.py:231,255     yield env.timeout(cpu|io time)   */
+    /* zero-time */
+    EV_EDGE_INIT,     /* edge.py:124           env.process(_deliver) Initialize, URGENT */
+    EV_SRV_INIT,      /* server.py:313         env.process(_handle_request) Initialize, URGENT */
+    EV_STORE_PUT,     /* edge.py:116           yield target_box.put(state)      */
+    EV_STORE_GET,     /* client.py:48 / load_balancer.py:63 / server.py:310  yield box.get() */
+    EV_CBOX_PUT,      /* client.py:69          yield completed_box.put(state)   */
+    EV_RAM_GOT,       /* server.py:148         yield RAM.get(total_ram)         */
+    EV_CPU_GOT,       /* server.py:220         yield cpu_req                    */
+    EV_CPU_PUT_IO,    /* server.py:241         yield CPU.put(1)  (before an I/O step) */
+    EV_CPU_PUT_END,   /* server.py:258         yield CPU.put(1)  (endpoint finished)  */
+    EV_RAM_PUT        /* server.py:273         yield RAM.put(total_ram)         */
+};
+
+static int is_timed(int kind) { return kind <= EV_STEP_TIMEOUT; }
 
 typedef struct {
     double t;
-    uint64_t seq;
+    uint64_t eid;
+    int prio;
     int kind;
-    int req;
+    int a; /* request id, or node id for store events */
+    int b; /* node id for EV_STORE_GET */
 } ev_t;
 
 typedef struct {
     ev_t* a;
     size_t n, cap;
-    uint64_t next_seq;
+    uint64_t next_eid;
 } heap_t;
 
+/* simpy.Environment heap order: (time, priority, eid) */
 static int ev_less(const ev_t* x, const ev_t* y) {
-    return x->t < y->t || (x->t == y->t && x->seq < y->seq);
+    if (x->t != y->t) return x->t < y->t;
+    if (x->prio != y->prio) return x->prio < y->prio;
+    return x->eid < y->eid;
 }
 
-static void heap_push(heap_t* h, double t, int kind, int req) {
+static void heap_push(heap_t* h, double t, int prio, int kind, int a, int b) {
     if (h->n == h->cap) {
         h->cap = h->cap ? 2 * h->cap : 64;
         h->a = (ev_t*)realloc(h->a, h->cap * sizeof(ev_t));
     }
-    ev_t e = {t, h->next_seq++, kind, req};
+    ev_t e = {t, h->next_eid++, prio, kind, a, b};
     size_t i = h->n++;
     while (i > 0) {
         size_t p = (i - 1) / 2;
@@ -92,8 +128,9 @@ typedef struct { /* RequestState (runtime/rqs_state.py:21-51) + _handle_request 
     int hops;        /* len(history)                                  */
     int edge;        /* edge currently carrying the message           */
     int server, ep;  /* server / endpoint being executed              */
-    uint32_t step;   /* absolute index of the next/current step       */
-    int core_locked, in_io;
+    uint32_t step;   /* absolute index of the current step            */
+    int core_locked, in_io, waiting_cpu;
+    int got;         /* scratch: "get event triggered" marker         */
     int next_free;
 } req_t;
 
@@ -114,12 +151,18 @@ static void fifo_push(fifo_t* f, int v) {
 static int fifo_pop(fifo_t* f) { f->n--; return f->a[f->head++]; }
 static int fifo_front(const fifo_t* f) { return f->a[f->head]; }
 
+/* simpy.Store used as a node inbox + the single forwarder process reading it */
+typedef struct {
+    fifo_t items;
+    int getter_waiting; /* forwarder is blocked in `yield box.get()` */
+} box_t;
+
 typedef struct { /* ServerRuntime + ServerContainers (server.py, server_containers.py:34-68) */
-    int cpu_free;        /* CPU container level      */
-    double ram_free;     /* RAM container level      */
+    int cpu_level;       /* CPU container level      */
+    double ram_level;    /* RAM container level      */
     int ready, io;       /* _el_ready_queue_len, _el_io_queue_len */
     double ram_in_use;   /* _ram_in_use              */
-    fifo_t cpu_wait, ram_wait;
+    fifo_t cpu_q, ram_q; /* Container.get_queue      */
     uint32_t arrivals;
 } srv_t;
 
@@ -133,15 +176,21 @@ typedef struct {
     req_t* reqs; int n_reqs, cap_reqs, free_head, live, max_live;
     srv_t* srv;
     edge_t* edge;
+    box_t* box;          /* [0]=client, [1]=lb, [2+s]=server s */
     int* lb_order; int lb_n;
     /* generator: poisson_poisson.py:51-82 / gaussian_poisson.py:63-94 */
     double g_now, g_window_end, g_lam; uint32_t g_draws;
     uint32_t emark_i, smark_i;
     /* outputs */
     uint64_t n_generated, n_completed, n_dropped, n_events, n_ticks, n_marks, flags;
+    uint64_t n_heap_events, n_ties;
     double* clock; uint64_t clock_cap;
     uint32_t* samples; uint64_t tick_cap; uint32_t n_series;
 } sim_t;
+
+#define BOX_CLIENT 0
+#define BOX_LB 1
+#define BOX_SERVER(s) (2 + (s))
 
 static int req_alloc(sim_t* s) {
     int r;
@@ -164,6 +213,18 @@ static void req_free(sim_t* s, int r) {
     s->reqs[r].next_free = s->free_head;
     s->free_head = r;
     s->live -= 1;
+}
+
+static void sched(sim_t* s, double delay, int prio, int kind, int a, int b) {
+    heap_push(&s->heap, s->now + delay, prio, kind, a, b); /* Environment.schedule */
+    s->n_heap_events += 1;
+}
+
+/* Timeline marks: the plan already holds the clock value `now + dt` the
+ * reference's relative wait lands on (asyncflow_amd/plan.py::_env_times). */
+static void sched_abs(sim_t* s, double t, int kind) {
+    heap_push(&s->heap, t, PRIO_NORMAL, kind, -1, 0);
+    s->n_heap_events += 1;
 }
 
 /* ------------------------------------------------ generator (samplers/) */
@@ -208,10 +269,30 @@ static double next_gap(sim_t* s) {
     return -1.0;
 }
 
+/* ------------------------------------------------ simpy.Store (node inbox) */
+/* StoreGet.__init__ -> _trigger_get: succeed at once if an item is queued */
+static void forwarder_get(sim_t* s, int node) {
+    box_t* B = &s->box[node];
+    if (B->items.n > 0) {
+        int item = fifo_pop(&B->items);
+        B->getter_waiting = 0;
+        sched(s, 0.0, PRIO_NORMAL, EV_STORE_GET, item, node);
+    } else {
+        B->getter_waiting = 1;
+    }
+}
+
 /* -------------------------------------------------- edge (actors/edge.py) */
-/* EdgeRuntime.transport/_deliver up to the `yield env.timeout` (edge.py:73-107) */
-static void edge_send(sim_t* s, int r, int e) {
+/* EdgeRuntime.transport (edge.py:119-124): spawn the _deliver process */
+static void transport(sim_t* s, int r, int e) {
+    s->reqs[r].edge = e;
+    sched(s, 0.0, PRIO_URGENT, EV_EDGE_INIT, r, 0);
+}
+
+/* _deliver up to its first yield (edge.py:73-107) */
+static void edge_init(sim_t* s, int r) {
     const af_plan_t* p = s->p;
+    const int e = s->reqs[r].edge;
     edge_t* ed = &s->edge[e];
     uint32_t idx = ed->sends++;
     double u = orc_uniform(s->seed, ORC_STREAM_EDGE(e), idx, 0);
@@ -224,38 +305,86 @@ static void edge_send(sim_t* s, int r, int e) {
     double transit = orc_variate(p->edge_dist[e], p->edge_mean[e], p->edge_sigma[e], s->seed,
                                  ORC_STREAM_EDGE(e), idx, 1);
     double effective = transit + ed->spike; /* edge.py:94-106, spike read at SEND time */
-    s->reqs[r].edge = e;
-    heap_push(&s->heap, s->now + effective, EV_DELIVER, r);
+    sched(s, effective, PRIO_NORMAL, EV_EDGE_TIMEOUT, r, 0);
+}
+
+/* _deliver after the timeout (edge.py:110-116) */
+static void edge_timeout(sim_t* s, int r) {
+    const af_plan_t* p = s->p;
+    req_t* R = &s->reqs[r];
+    const int e = R->edge;
+    R->hops += 1; /* record_hop(NETWORK_CONNECTION) */
+    s->edge[e].conn -= 1;
+    int node = p->edge_target_kind[e] == AF_NODE_CLIENT ? BOX_CLIENT
+             : p->edge_target_kind[e] == AF_NODE_LB     ? BOX_LB
+                                                        : BOX_SERVER(p->edge_target_idx[e]);
+    /* StorePut.__init__: unbounded store -> append + succeed immediately */
+    fifo_push(&s->box[node].items, r);
+    sched(s, 0.0, PRIO_NORMAL, EV_STORE_PUT, node, 0);
+}
+
+/* the put event is processed: its first callback is Store._trigger_get */
+static void store_put_processed(sim_t* s, int node) {
+    box_t* B = &s->box[node];
+    if (B->getter_waiting && B->items.n > 0) {
+        int item = fifo_pop(&B->items);
+        B->getter_waiting = 0;
+        sched(s, 0.0, PRIO_NORMAL, EV_STORE_GET, item, node);
+    }
+    /* then the edge process resumes and terminates (nobody waits on it) */
 }
 
 /* ----------------------------------------------- server (actors/server.py) */
-static void run_steps(sim_t* s, int r);
-
-/* A CPU token became free: hand it to the first waiter (Container FIFO).
- * Returns the waiter (its Timeout is scheduled by the caller, AFTER the
- * releasing request's own, see the ordering note in run_steps) or -1. */
-static int cpu_release(sim_t* s, int sv) {
+/* Container._trigger_get for the CPU container (amount is always 1) */
+static void cpu_trigger_get(sim_t* s, int sv) {
     srv_t* S = &s->srv[sv];
-    S->cpu_free += 1;
-    if (S->cpu_wait.n > 0) {
-        int w = fifo_pop(&S->cpu_wait);
-        S->cpu_free -= 1;
-        return w;
+    while (S->cpu_q.n > 0) {
+        if (S->cpu_level < 1) break; /* _do_get fails: head-of-line blocking */
+        int w = fifo_pop(&S->cpu_q);
+        S->cpu_level -= 1;
+        s->reqs[w].got = 1;
+        sched(s, 0.0, PRIO_NORMAL, EV_CPU_GOT, w, 0);
     }
-    return -1;
 }
 
-/* server.py:220-231: the waiter's `yield cpu_req` returns */
-static void cpu_granted(sim_t* s, int w) {
-    req_t* W = &s->reqs[w];
-    srv_t* S = &s->srv[W->server];
-    S->ready -= 1; /* waiting_cpu -> False */
-    W->core_locked = 1;
-    heap_push(&s->heap, s->now + s->p->step_time[W->step], EV_CPU_DONE, w);
+/* Container._trigger_get for the RAM container */
+static void ram_trigger_get(sim_t* s, int sv) {
+    srv_t* S = &s->srv[sv];
+    while (S->ram_q.n > 0) {
+        int w = fifo_front(&S->ram_q);
+        double need = s->reqs[w].ram;
+        if (S->ram_level < need) break;
+        fifo_pop(&S->ram_q);
+        S->ram_level -= need;
+        s->reqs[w].got = 1;
+        sched(s, 0.0, PRIO_NORMAL, EV_RAM_GOT, w, 0);
+    }
 }
 
-/* The for-loop of _handle_request (server.py:197-276) from step `req.step`. */
-static void run_steps(sim_t* s, int r) {
+/* tail of _handle_request after the core was given back (server.py:261-276) */
+static void srv_finish(sim_t* s, int r) {
+    req_t* R = &s->reqs[r];
+    srv_t* S = &s->srv[R->server];
+    if (R->in_io) {
+        R->in_io = 0;
+        S->io -= 1;
+    }
+    if (R->waiting_cpu) { /* defensive branch of the reference, never taken */
+        R->waiting_cpu = 0;
+        S->ready -= 1;
+    }
+    if (R->ram > 0.0) { /* `if total_ram:` */
+        S->ram_in_use -= R->ram;
+        S->ram_level += R->ram; /* ContainerPut.__init__ -> _do_put succeeds at once */
+        sched(s, 0.0, PRIO_NORMAL, EV_RAM_PUT, r, 0);
+        return;
+    }
+    transport(s, r, s->p->srv_out_edge[R->server]);
+}
+
+/* The for-loop of _handle_request (server.py:197-255) from step `R->step`,
+ * run until the generator yields. */
+static void srv_continue(sim_t* s, int r) {
     const af_plan_t* p = s->p;
     req_t* R = &s->reqs[r];
     const int sv = R->server;
@@ -269,78 +398,47 @@ static void run_steps(sim_t* s, int r) {
                 S->io -= 1;
             }
             if (!R->core_locked) {
-                if (S->cpu_wait.n == 0 && S->cpu_free > 0) {
-                    S->cpu_free -= 1; /* cpu_req.triggered: not counted in ready */
-                    R->core_locked = 1;
-                } else {
-                    fifo_push(&S->cpu_wait, r); /* waiting_cpu = True */
+                /* cpu_req = CPU.get(1): ContainerGet.__init__ appends + triggers */
+                R->got = 0;
+                fifo_push(&S->cpu_q, r);
+                cpu_trigger_get(s, sv);
+                if (!R->got) { /* `if not cpu_req.triggered` */
+                    R->waiting_cpu = 1;
                     S->ready += 1;
-                    return;
                 }
+                return; /* yield cpu_req */
             }
-            heap_push(&s->heap, s->now + p->step_time[R->step], EV_CPU_DONE, r);
+            sched(s, p->step_time[R->step], PRIO_NORMAL, EV_STEP_TIMEOUT, r, 0);
             return;
         }
         /* I/O step, server.py:235-255 */
-        int granted = -1;
         if (R->core_locked) {
-            granted = cpu_release(s, sv);
-            R->core_locked = 0;
-            if (!R->in_io) {
-                R->in_io = 1;
-                S->io += 1;
-            }
-        } else if (!R->in_io) {
+            S->cpu_level += 1; /* CPU.put(1) succeeds at once */
+            sched(s, 0.0, PRIO_NORMAL, EV_CPU_PUT_IO, r, 0);
+            return; /* yield CPU.put(1) */
+        }
+        if (!R->in_io) {
             R->in_io = 1;
             S->io += 1;
         }
-        /* SimPy order: the put event's first callback grants the waiter (its get
-         * event is only *scheduled*), then this process resumes and creates its
-         * own Timeout; the waiter's Timeout is created later. */
-        heap_push(&s->heap, s->now + p->step_time[R->step], EV_IO_DONE, r);
-        if (granted >= 0) cpu_granted(s, granted);
+        sched(s, p->step_time[R->step], PRIO_NORMAL, EV_STEP_TIMEOUT, r, 0);
         return;
     }
-
-    /* endpoint finished, server.py:257-276 */
+    /* endpoint finished, server.py:257-259 */
     if (R->core_locked) {
-        int granted = cpu_release(s, sv);
-        R->core_locked = 0;
-        /* here the waiter's get event is processed BEFORE the RAM put below is,
-         * hence before this request's transport(): waiter first. */
-        if (granted >= 0) cpu_granted(s, granted);
+        S->cpu_level += 1;
+        sched(s, 0.0, PRIO_NORMAL, EV_CPU_PUT_END, r, 0);
+        return;
     }
-    if (R->in_io) {
-        R->in_io = 0;
-        S->io -= 1;
-    }
-    const double ram = R->ram;
-    if (ram > 0.0) { /* `if total_ram:` */
-        S->ram_in_use -= ram;
-        S->ram_free += ram;
-    }
-    /* transport() -> Initialize is URGENT: runs before the RAM waiters' get events */
-    edge_send(s, r, p->srv_out_edge[sv]);
-    if (ram > 0.0) {
-        /* Container._trigger_get: FIFO with head-of-line blocking */
-        while (S->ram_wait.n > 0) {
-            int w = fifo_front(&S->ram_wait);
-            double need = s->reqs[w].ram;
-            if (S->ram_free < need) break;
-            fifo_pop(&S->ram_wait);
-            S->ram_free -= need;
-            S->ram_in_use += need; /* server.py:149 */
-            run_steps(s, w);
-            S = &s->srv[sv];
-        }
-    }
+    srv_finish(s, r);
 }
 
-/* _dispatcher + head of _handle_request (server.py:303-313, 79-149) */
-static void server_arrival(sim_t* s, int r, int sv) {
+/* head of _handle_request (server.py:79-149), run by its Initialize event */
+static void srv_init(sim_t* s, int r) {
     const af_plan_t* p = s->p;
-    srv_t* S = &s->srv[sv];
     req_t* R = &s->reqs[r];
+    const int sv = R->server;
+    srv_t* S = &s->srv[sv];
     R->hops += 1; /* record_hop(SERVER) */
     uint32_t n_ep = p->srv_ep_begin[sv + 1] - p->srv_ep_begin[sv];
     uint32_t idx = S->arrivals++;
@@ -348,67 +446,66 @@ static void server_arrival(sim_t* s, int r, int sv) {
     if (n_ep > 1) { /* rng.integers(0, n_ep), server.py:101 */
         pick = (uint32_t)(((uint64_t)orc_word0(s->seed, ORC_STREAM_SERVER(sv), idx) * n_ep) >> 32);
     }
-    R->server = sv;
     R->ep = (int)(p->srv_ep_begin[sv] + pick);
     R->ram = p->ep_ram[R->ep];
     R->step = p->ep_step_begin[R->ep];
     R->core_locked = 0;
     R->in_io = 0;
+    R->waiting_cpu = 0;
     if (R->ram > 0.0) { /* server.py:146-149 */
         if (R->ram > p->srv_ram_mb[sv]) s->flags |= AF_FLAG_RAM_STARVED;
-        if (S->ram_wait.n == 0 && S->ram_free >= R->ram) {
-            S->ram_free -= R->ram;
-            S->ram_in_use += R->ram;
-        } else {
-            fifo_push(&S->ram_wait, r); /* blocked on RAM: in neither queue */
-            return;
-        }
+        fifo_push(&S->ram_q, r); /* ContainerGet.__init__ */
+        ram_trigger_get(s, sv);
+        return; /* yield RAM.get(total_ram): resumes at EV_RAM_GOT */
     }
-    run_steps(s, r);
+    srv_continue(s, r);
 }
 
-/* EdgeRuntime._deliver after the timeout (edge.py:110-116) + the target node */
-static void deliver(sim_t* s, int r) {
+/* a forwarder process resumes with `state` (its box.get() event is processed) */
+static void store_get_processed(sim_t* s, int r, int node) {
     const af_plan_t* p = s->p;
     req_t* R = &s->reqs[r];
-    const int e = R->edge;
-    R->hops += 1; /* record_hop(NETWORK_CONNECTION) */
-    s->edge[e].conn -= 1;
-    switch (p->edge_target_kind[e]) {
-        case AF_NODE_CLIENT: /* ClientRuntime._forwarder, client.py:46-71 */
-            R->hops += 1;
-            if (R->hops > 3) {
-                if (s->n_completed < s->clock_cap) {
-                    s->clock[2 * s->n_completed] = R->t0;
-                    s->clock[2 * s->n_completed + 1] = s->now;
-                } else {
-                    s->flags |= AF_FLAG_CLOCK_OVERFLOW;
-                }
-                s->n_completed += 1;
-                req_free(s, r);
-            } else {
-                edge_send(s, r, p->client_out_edge);
+    if (node == BOX_CLIENT) { /* ClientRuntime._forwarder, client.py:46-71 */
+        R->hops += 1;
+        if (R->hops > 3) {
+            if (s->n_completed < s->clock_cap) {
+                s->clock[2 * s->n_completed] = R->t0;
+                s->clock[2 * s->n_completed + 1] = s->now;
+            } else if (s->clock) {
+                s->flags |= AF_FLAG_CLOCK_OVERFLOW;
             }
-            break;
-        case AF_NODE_LB: { /* LoadBalancerRuntime._forwarder, load_balancer.py:60-72 */
-            R->hops += 1;
-            int out;
-            if (p->lb_algo == AF_LB_LEAST_CONNECTIONS) { /* lb_algorithms.py:10-20 */
-                int best = 0;
-                for (int i = 1; i < s->lb_n; ++i)
-                    if (s->edge[s->lb_order[i]].conn < s->edge[s->lb_order[best]].conn) best = i;
-                out = s->lb_order[best];
-            } else { /* round_robin, lb_algorithms.py:22-36: first key, move_to_end */
-                out = s->lb_order[0];
-                for (int i = 1; i < s->lb_n; ++i) s->lb_order[i - 1] = s->lb_order[i];
-                s->lb_order[s->lb_n - 1] = out;
-            }
-            edge_send(s, r, out);
-            break;
+            s->n_completed += 1;
+            req_free(s, r);
+            /* yield completed_box.put(state): the client only asks for the next
+             * message once that put event has been processed */
+            sched(s, 0.0, PRIO_NORMAL, EV_CBOX_PUT, 0, 0);
+            return;
         }
-        default:
-            server_arrival(s, r, p->edge_target_idx[e]);
+        transport(s, r, p->client_out_edge);
+        forwarder_get(s, BOX_CLIENT);
+        return;
     }
+    if (node == BOX_LB) { /* LoadBalancerRuntime._forwarder, load_balancer.py:60-72 */
+        R->hops += 1;
+        int out;
+        if (p->lb_algo == AF_LB_LEAST_CONNECTIONS) { /* lb_algorithms.py:10-20 */
+            int best = 0;
+            for (int i = 1; i < s->lb_n; ++i)
+                if (s->edge[s->lb_order[i]].conn < s->edge[s->lb_order[best]].conn) best = i;
+            out = s->lb_order[best];
+        } else { /* round_robin, lb_algorithms.py:22-36: first key, move_to_end */
+            out = s->lb_order[0];
+            for (int i = 1; i < s->lb_n; ++i) s->lb_order[i - 1] = s->lb_order[i];
+            s->lb_order[s->lb_n - 1] = out;
+        }
+        transport(s, r, out);
+        forwarder_get(s, BOX_LB);
+        return;
+    }
+    /* ServerRuntime._dispatcher, server.py:303-313 */
+    R->server = node - 2;
+    sched(s, 0.0, PRIO_URGENT, EV_SRV_INIT, r, 0);
+    forwarder_get(s, node);
 }
 
 /* ------------------------------------- event injection (events/injection.py) */
@@ -421,7 +518,7 @@ static void apply_emarks(sim_t* s) { /* _assign_edges_spike, injection.py:167-19
         if (s->emark_i >= p->n_edge_marks) return;
         if (p->emark_time[s->emark_i] > s->now) break; /* dt > 0: new Timeout */
     }
-    heap_push(&s->heap, p->emark_time[s->emark_i], EV_EMARK, -1);
+    sched_abs(s, p->emark_time[s->emark_i], EV_EMARK);
 }
 
 static void apply_smarks(sim_t* s) { /* _assign_server_state, injection.py:201-226 */
@@ -451,7 +548,7 @@ static void apply_smarks(sim_t* s) { /* _assign_server_state, injection.py:201-2
         if (s->smark_i >= p->n_srv_marks) return;
         if (p->smark_time[s->smark_i] > s->now) break;
     }
-    heap_push(&s->heap, p->smark_time[s->smark_i], EV_SMARK, -1);
+    sched_abs(s, p->smark_time[s->smark_i], EV_SMARK);
 }
 
 /* ----------------------------- sampler tick (metrics/collector.py:50-66) */
@@ -481,6 +578,10 @@ static void sample_tick(sim_t* s) {
 }
 
 /* ------------------------------------------------------------- top level */
+static uint64_t g_last_ties, g_last_heap_events;
+uint64_t orc_last_ties(void) { return g_last_ties; }
+uint64_t orc_last_heap_events(void) { return g_last_heap_events; }
+
 /* counts: uint64[8] indexed by af_count_slot.  clock: [clock_cap][2] f64 or
  * NULL.  samples: [n_series][tick_cap] 4-byte words or NULL.  Returns 0. */
 int orc_simulate(const af_plan_t* plan, uint64_t seed, uint64_t clock_cap, double* clock,
@@ -500,68 +601,116 @@ int orc_simulate(const af_plan_t* plan, uint64_t seed, uint64_t clock_cap, doubl
     s->n_series = plan->n_edges + 3 * plan->n_servers;
     s->srv = (srv_t*)calloc(plan->n_servers ? plan->n_servers : 1, sizeof(srv_t));
     s->edge = (edge_t*)calloc(plan->n_edges ? plan->n_edges : 1, sizeof(edge_t));
+    s->box = (box_t*)calloc(2 + plan->n_servers, sizeof(box_t));
     s->lb_order = (int*)calloc(plan->n_lb_edges ? plan->n_lb_edges : 1, sizeof(int));
     for (uint32_t v = 0; v < plan->n_servers; ++v) { /* build_containers: init full */
-        s->srv[v].cpu_free = (int)plan->srv_cores[v];
-        s->srv[v].ram_free = plan->srv_ram_mb[v];
+        s->srv[v].cpu_level = (int)plan->srv_cores[v];
+        s->srv[v].ram_level = plan->srv_ram_mb[v];
     }
     s->lb_n = (int)plan->n_lb_edges;
     for (int i = 0; i < s->lb_n; ++i) s->lb_order[i] = plan->lb_edges[i];
 
-    /* process start order (simulation_runner.py:364-366): events, generator,
-     * ..., collector.  Marks at t == 0 are applied inside the Initialize. */
+    /* Initialize events run in process start order (simulation_runner.py:364-366):
+     * edge timeline, server timeline, generator, client, servers, LB, collector.
+     * Marks at t == 0 are applied inside the Initialize (dt == 0). */
     if (plan->n_edge_marks) {
-        if (plan->emark_time[0] > 0.0) heap_push(&s->heap, plan->emark_time[0], EV_EMARK, -1);
+        if (plan->emark_time[0] > 0.0) sched_abs(s, plan->emark_time[0], EV_EMARK);
         else apply_emarks(s);
     }
     if (plan->n_srv_marks) {
-        if (plan->smark_time[0] > 0.0) heap_push(&s->heap, plan->smark_time[0], EV_SMARK, -1);
+        if (plan->smark_time[0] > 0.0) sched_abs(s, plan->smark_time[0], EV_SMARK);
         else apply_smarks(s);
     }
     {
         double gap = next_gap(s);
-        if (gap >= 0.0) heap_push(&s->heap, 0.0 + gap, EV_ARRIVAL, -1);
+        if (gap >= 0.0) sched(s, gap, PRIO_NORMAL, EV_GEN_TIMEOUT, -1, 0);
     }
-    heap_push(&s->heap, 0.0 + plan->sample_period, EV_TICK, -1);
+    for (uint32_t b = 0; b < 2 + plan->n_servers; ++b) s->box[b].getter_waiting = 1;
+    sched(s, plan->sample_period, PRIO_NORMAL, EV_TICK, -1, 0);
 
     const double T = plan->total_time;
+    int have_prev_timed = 0;
     while (s->heap.n > 0) {
-        if (!(s->heap.a[0].t < T)) break; /* stop event is URGENT at T */
+        if (!(s->heap.a[0].t < T)) break; /* stop event: URGENT at T, scheduled first */
         ev_t ev = heap_pop(&s->heap);
+        if (is_timed(ev.kind)) {
+            if (have_prev_timed && ev.t == s->now) s->n_ties += 1;
+            have_prev_timed = 1;
+        }
         s->now = ev.t;
         switch (ev.kind) {
-            case EV_ARRIVAL: { /* RqsGeneratorRuntime._event_arrival, rqs_generator.py:101-119 */
+            case EV_GEN_TIMEOUT: { /* RqsGeneratorRuntime._event_arrival, rqs_generator.py:101-119 */
                 s->n_generated += 1;
                 s->n_events += 1;
                 int r = req_alloc(s);
                 s->reqs[r].t0 = s->now;
                 s->reqs[r].hops = 1; /* record_hop(GENERATOR) */
-                /* the generator's next Timeout is created before the edge process starts */
-                double gap = next_gap(s);
-                if (gap >= 0.0) heap_push(&s->heap, s->now + gap, EV_ARRIVAL, -1);
-                edge_send(s, r, plan->gen_out_edge);
+                transport(s, r, plan->gen_out_edge);
+                double gap = next_gap(s); /* next(time_gaps) runs before the edge process starts */
+                if (gap >= 0.0) sched(s, gap, PRIO_NORMAL, EV_GEN_TIMEOUT, -1, 0);
                 break;
             }
             case EV_TICK:
                 sample_tick(s);
-                heap_push(&s->heap, s->now + plan->sample_period, EV_TICK, -1);
+                sched(s, plan->sample_period, PRIO_NORMAL, EV_TICK, -1, 0);
                 break;
             case EV_EMARK: apply_emarks(s); break;
             case EV_SMARK: apply_smarks(s); break;
-            case EV_DELIVER:
+            case EV_EDGE_INIT: edge_init(s, ev.a); break;
+            case EV_EDGE_TIMEOUT:
                 s->n_events += 1;
-                deliver(s, ev.req);
+                edge_timeout(s, ev.a);
                 break;
-            case EV_CPU_DONE:
+            case EV_STORE_PUT: store_put_processed(s, ev.a); break;
+            case EV_STORE_GET: store_get_processed(s, ev.a, ev.b); break;
+            case EV_CBOX_PUT: forwarder_get(s, BOX_CLIENT); break; /* client.py:46-48 loop */
+            case EV_SRV_INIT: srv_init(s, ev.a); break;
+            case EV_RAM_GOT: { /* server.py:149 */
+                req_t* R = &s->reqs[ev.a];
+                s->srv[R->server].ram_in_use += R->ram;
+                srv_continue(s, ev.a);
+                break;
+            }
+            case EV_CPU_GOT: { /* server.py:220-231 */
+                req_t* R = &s->reqs[ev.a];
+                if (R->waiting_cpu) {
+                    R->waiting_cpu = 0;
+                    s->srv[R->server].ready -= 1;
+                }
+                R->core_locked = 1;
+                sched(s, plan->step_time[R->step], PRIO_NORMAL, EV_STEP_TIMEOUT, ev.a, 0);
+                break;
+            }
+            case EV_STEP_TIMEOUT: /* the for-loop moves on to the next step */
                 s->n_events += 1;
-                s->reqs[ev.req].step += 1;
-                run_steps(s, ev.req);
+                s->reqs[ev.a].step += 1;
+                srv_continue(s, ev.a);
                 break;
-            case EV_IO_DONE:
-                s->n_events += 1;
-                s->reqs[ev.req].step += 1;
-                run_steps(s, ev.req);
+            case EV_CPU_PUT_IO: { /* server.py:241-255: put processed -> grants, then resume */
+                req_t* R = &s->reqs[ev.a];
+                srv_t* Sv = &s->srv[R->server];
+                cpu_trigger_get(s, R->server);
+                R->core_locked = 0;
+                if (!R->in_io) {
+                    R->in_io = 1;
+                    Sv->io += 1;
+                }
+                sched(s, plan->step_time[R->step], PRIO_NORMAL, EV_STEP_TIMEOUT, ev.a, 0);
                 break;
+            }
+            case EV_CPU_PUT_END: { /* server.py:258-259 */
+                req_t* R = &s->reqs[ev.a];
+                cpu_trigger_get(s, R->server);
+                R->core_locked = 0;
+                srv_finish(s, ev.a);
+                break;
+            }
+            case EV_RAM_PUT: { /* server.py:273-276 */
+                req_t* R = &s->reqs[ev.a];
+                ram_trigger_get(s, R->server);
+                transport(s, ev.a, plan->srv_out_edge[R->server]);
+                break;
+            }
         }
     }
 
@@ -575,10 +724,14 @@ int orc_simulate(const af_plan_t* plan, uint64_t seed, uint64_t clock_cap, doubl
         counts[AF_CNT_MAX_LIVE] = (uint64_t)s->max_live;
         counts[AF_CNT_MARKS] = s->n_marks;
     }
+    g_last_ties = s->n_ties;
+    g_last_heap_events = s->n_heap_events;
     for (uint32_t v = 0; v < plan->n_servers; ++v) {
-        free(s->srv[v].cpu_wait.a);
-        free(s->srv[v].ram_wait.a);
+        free(s->srv[v].cpu_q.a);
+        free(s->srv[v].ram_q.a);
     }
+    for (uint32_t b = 0; b < 2 + plan->n_servers; ++b) free(s->box[b].items.a);
+    free(s->box);
     free(s->srv);
     free(s->edge);
     free(s->lb_order);

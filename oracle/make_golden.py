@@ -1,0 +1,100 @@
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference here.
+
+ORACLE / TEST INFRASTRUCTURE ONLY.  Build-container only (needs /root/reference):
+
+    python oracle/make_golden.py            # (re)write every fixture
+    python oracle/make_golden.py --check    # regenerate in memory, compare with committed files
+
+Each fixture holds, for one (payload, seed) of oracle/scenarios.py::GOLDEN:
+
+* ``payload_json``   the exact input dict (so the fixture is self-contained);
+* ``seed``           Philox key of the scenario;
+* ``generated / completed / dropped / ticks / heap_events``;
+* ``clock``          float64 [completed, 2] = ClientRuntime.rqs_clock (start, finish);
+* ``samples``        uint32 [n_series, ticks] sampled series (ram rows: float32 bits);
+* ``latency_stats``  the 8 numbers of ResultsAnalyzer.get_latency_stats();
+* ``rps``            ResultsAnalyzer.get_throughput_series()[1];
+* ``glibc_log_*``    the same run WITHOUT the math.log substitution (see
+                     oracle/reference_runner.py::_DeterministicMath): counts and the
+                     max |delta| of (start, finish) -- documents the <= 1 ulp/log effect.
+
+The reference ran on: the SimPy stand-in (oracle/simpy_standin) unless a real
+SimPy is importable -- recorded in ``simpy_flavour``.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+from oracle import ref_env  # noqa: E402
+from oracle.scenarios import GOLDEN  # noqa: E402
+
+GOLDEN_DIR = ROOT / "tests" / "golden"
+STAT_KEYS = ("total_requests", "mean", "median", "std_dev", "p95", "p99", "min", "max")
+
+
+def build_fixture(name: str) -> dict[str, np.ndarray]:
+    from oracle.reference_runner import run_reference
+
+    builder, seed = GOLDEN[name]
+    payload = builder()
+    res = run_reference(payload, seed, patch_log=True)
+    raw = run_reference(payload, seed, patch_log=False)
+    n = min(len(res.clock), len(raw.clock))
+    delta = float(np.max(np.abs(res.clock[:n] - raw.clock[:n]))) if n else 0.0
+    return {
+        "payload_json": np.array(json.dumps(payload, sort_keys=True)),
+        "seed": np.uint64(seed),
+        "generated": np.int64(res.generated),
+        "completed": np.int64(res.completed),
+        "dropped": np.int64(res.dropped),
+        "ticks": np.int64(res.ticks),
+        "heap_events": np.int64(res.heap_events),
+        "clock": res.clock,
+        "samples": res.samples,
+        "latency_stats": np.asarray([res.latency_stats.get(k, np.nan) for k in STAT_KEYS], dtype=np.float64),
+        "rps": np.asarray(res.throughput[1], dtype=np.float64),
+        "edge_ids": np.array(json.dumps(res.edge_ids)),
+        "server_ids": np.array(json.dumps(res.server_ids)),
+        "simpy_flavour": np.array(res.simpy_flavour),
+        "glibc_log_counts": np.asarray([raw.generated, raw.completed, raw.dropped, raw.ticks], dtype=np.int64),
+        "glibc_log_max_abs_delta": np.float64(delta),
+    }
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--check", action="store_true")
+    ap.add_argument("names", nargs="*")
+    args = ap.parse_args()
+    ref_env.install()
+    GOLDEN_DIR.mkdir(parents=True, exist_ok=True)
+    rc = 0
+    for name in args.names or list(GOLDEN):
+        fx = build_fixture(name)
+        path = GOLDEN_DIR / f"{name}.npz"
+        if args.check:
+            old = np.load(path, allow_pickle=False)
+            same = all(np.array_equal(old[k], fx[k]) for k in fx)
+            print(f"{name}: {'identical' if same else 'DIFFERENT'}")
+            rc |= 0 if same else 1
+        else:
+            np.savez_compressed(path, **fx)
+            print(
+                f"{name}: generated={int(fx['generated'])} completed={int(fx['completed'])} "
+                f"dropped={int(fx['dropped'])} ticks={int(fx['ticks'])} heap_events={int(fx['heap_events'])} "
+                f"glibc-log delta={float(fx['glibc_log_max_abs_delta']):.3e} -> {path.name} ({path.stat().st_size} B)"
+            )
+    return rc
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

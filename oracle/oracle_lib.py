@@ -52,6 +52,10 @@ def lib() -> C.CDLL:
         L.orc_x_poisson.restype = C.c_int64
         L.orc_x_variate.argtypes = [C.c_int, C.c_double, C.c_double, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
         L.orc_x_variate.restype = C.c_double
+        L.orc_last_ties.argtypes = []
+        L.orc_last_ties.restype = C.c_uint64
+        L.orc_last_heap_events.argtypes = []
+        L.orc_last_heap_events.restype = C.c_uint64
         L.orc_tick_count.argtypes = [C.c_double, C.c_double]
         L.orc_tick_count.restype = C.c_uint32
         _lib = L
@@ -76,6 +80,8 @@ class OracleResult:
     counts: np.ndarray   # uint64[8], af_count_slot order
     clock: np.ndarray    # float64[n_completed, 2]  (start, finish)
     samples: np.ndarray  # uint32[n_series, n_ticks] raw words (ram rows are float32 bits)
+    ties: int = 0        # timed events popped at the timestamp of the previous one
+    heap_events: int = 0 # SimPy-equivalent heap pushes
 
     @property
     def generated(self) -> int:
@@ -153,4 +159,6 @@ def simulate(
         counts=counts,
         clock=clock[: min(n, cap)].copy() if clock is not None else np.zeros((0, 2)),
         samples=samples[:, : int(counts[_abi.CNT_TICKS])].copy() if samples is not None else np.zeros((0, 0), np.uint32),
+        ties=int(L.orc_last_ties()),
+        heap_events=int(L.orc_last_heap_events()),
     )

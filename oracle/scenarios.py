@@ -1,0 +1,315 @@
+"""Scenario library shared by the golden generator, the tests and bench.py.
+
+ORACLE / TEST INFRASTRUCTURE (bench.py only uses the two builders that restate
+BASELINE.json's configs; they contain no reference code, only the YAML values of
+/root/reference/examples/yaml_input/data/*.yml re-typed as Python dicts).
+"""
+
+from __future__ import annotations
+
+import copy
+import random
+from typing import Any
+
+
+def _server(sid: str, cores: int = 1, ram: int = 2048, endpoints: list | None = None) -> dict:
+    if endpoints is None:
+        endpoints = [_endpoint("/api", [("initial_parsing", 0.002), ("ram", 128), ("io_wait", 0.012)])]
+    return {"id": sid, "server_resources": {"cpu_cores": cores, "ram_mb": ram}, "endpoints": endpoints}
+
+
+def _endpoint(name: str, steps: list[tuple[str, float]]) -> dict:
+    out = []
+    for kind, val in steps:
+        key = "necessary_ram" if kind == "ram" else ("cpu_time" if kind in ("initial_parsing", "cpu_bound_operation") else "io_waiting_time")
+        out.append({"kind": kind, "step_operation": {key: val}})
+    return {"endpoint_name": name, "steps": out}
+
+
+def _edge(eid: str, src: str, tgt: str, mean: float, dist: str = "exponential", variance: float | None = None, dropout: float | None = None) -> dict:
+    lat: dict[str, Any] = {"mean": mean, "distribution": dist}
+    if variance is not None:
+        lat["variance"] = variance
+    e: dict[str, Any] = {"id": eid, "source": src, "target": tgt, "latency": lat}
+    if dropout is not None:
+        e["dropout_rate"] = dropout
+    return e
+
+
+def single_server(users: float = 100, rpm: float = 20, horizon: int = 300, period: float = 0.05) -> dict:
+    """examples/yaml_input/data/single_server.yml (BASELINE config 1; the file says T=500)."""
+    return {
+        "rqs_input": {
+            "id": "rqs-1",
+            "avg_active_users": {"mean": users},
+            "avg_request_per_minute_per_user": {"mean": rpm},
+            "user_sampling_window": 60,
+        },
+        "topology_graph": {
+            "nodes": {
+                "client": {"id": "client-1"},
+                "servers": [_server("srv-1", 1, 2048, [_endpoint("ep-1", [("initial_parsing", 0.001), ("ram", 100), ("io_wait", 0.1)])])],
+            },
+            "edges": [
+                _edge("gen-to-client", "rqs-1", "client-1", 0.003),
+                _edge("client-to-server", "client-1", "srv-1", 0.003),
+                _edge("server-to-client", "srv-1", "client-1", 0.003),
+            ],
+        },
+        "sim_settings": {"total_simulation_time": horizon, "sample_period_s": period},
+    }
+
+
+def lb_two_servers(users: float = 400, rpm: float = 20, horizon: int = 600, period: float = 0.05, algo: str = "round_robin") -> dict:
+    """examples/yaml_input/data/two_servers_lb.yml:14-71 (BASELINE config 2, "LB-2")."""
+    return {
+        "rqs_input": {
+            "id": "rqs-1",
+            "avg_active_users": {"mean": users},
+            "avg_request_per_minute_per_user": {"mean": rpm},
+            "user_sampling_window": 60,
+        },
+        "topology_graph": {
+            "nodes": {
+                "client": {"id": "client-1"},
+                "load_balancer": {"id": "lb-1", "algorithms": algo, "server_covered": ["srv-1", "srv-2"]},
+                "servers": [_server("srv-1"), _server("srv-2")],
+            },
+            "edges": [
+                _edge("gen-client", "rqs-1", "client-1", 0.003),
+                _edge("client-lb", "client-1", "lb-1", 0.002),
+                _edge("lb-srv1", "lb-1", "srv-1", 0.002),
+                _edge("lb-srv2", "lb-1", "srv-2", 0.002),
+                _edge("srv1-client", "srv-1", "client-1", 0.003),
+                _edge("srv2-client", "srv-2", "client-1", 0.003),
+            ],
+        },
+        "sim_settings": {
+            "total_simulation_time": horizon,
+            "sample_period_s": period,
+            "enabled_sample_metrics": ["ready_queue_len", "event_loop_io_sleep", "ram_in_use", "edge_concurrent_connection"],
+            "enabled_event_metrics": ["rqs_clock"],
+        },
+    }
+
+
+def lb_with_events(users: float = 120, horizon: int = 600, scale: float = 1.0) -> dict:
+    """examples/yaml_input/data/event_inj_lb.yml:73-102 (BASELINE config 4's events).
+
+    ``scale`` compresses the event times so short-horizon fixtures still see them.
+    """
+    p = lb_two_servers(users=users, horizon=horizon)
+    s = scale
+    p["events"] = [
+        {"event_id": "ev-spike-1", "target_id": "client-lb",
+         "start": {"kind": "network_spike_start", "t_start": 100.0 * s, "spike_s": 0.015}, "end": {"kind": "network_spike_end", "t_end": 160.0 * s}},
+        {"event_id": "ev-srv1-down", "target_id": "srv-1",
+         "start": {"kind": "server_down", "t_start": 180.0 * s}, "end": {"kind": "server_up", "t_end": 240.0 * s}},
+        {"event_id": "ev-spike-2", "target_id": "lb-srv2",
+         "start": {"kind": "network_spike_start", "t_start": 300.0 * s, "spike_s": 0.020}, "end": {"kind": "network_spike_end", "t_end": 360.0 * s}},
+        {"event_id": "ev-srv2-down", "target_id": "srv-2",
+         "start": {"kind": "server_down", "t_start": 360.0 * s}, "end": {"kind": "server_up", "t_end": 420.0 * s}},
+        {"event_id": "ev-spike-3", "target_id": "gen-client",
+         "start": {"kind": "network_spike_start", "t_start": 480.0 * s, "spike_s": 0.010}, "end": {"kind": "network_spike_end", "t_end": 540.0 * s}},
+    ]
+    return p
+
+
+def fanout8(users: float = 120, horizon: int = 600, period: float = 0.05) -> dict:
+    """BASELINE config 5: LB -> 8 identical servers, log-normal edges."""
+    servers = [_server(f"srv-{i}") for i in range(1, 9)]
+    edges = [
+        _edge("gen-client", "rqs-1", "client-1", 0.001, "log_normal", 0.25),
+        _edge("client-lb", "client-1", "lb-1", 0.001, "log_normal", 0.25),
+    ]
+    for i in range(1, 9):
+        edges.append(_edge(f"lb-srv{i}", "lb-1", f"srv-{i}", 0.001, "log_normal", 0.25))
+        edges.append(_edge(f"srv{i}-client", f"srv-{i}", "client-1", 0.001, "log_normal", 0.25))
+    return {
+        "rqs_input": {"id": "rqs-1", "avg_active_users": {"mean": users}, "avg_request_per_minute_per_user": {"mean": 20}, "user_sampling_window": 60},
+        "topology_graph": {
+            "nodes": {
+                "client": {"id": "client-1"},
+                "load_balancer": {"id": "lb-1", "algorithms": "round_robin", "server_covered": [f"srv-{i}" for i in range(1, 9)]},
+                "servers": servers,
+            },
+            "edges": edges,
+        },
+        "sim_settings": {"total_simulation_time": horizon, "sample_period_s": period},
+    }
+
+
+def stress_mixed(horizon: int = 40) -> dict:
+    """Everything the schema allows in one payload (generality row).
+
+    Gaussian users, least-connection LB, 3 heterogeneous servers (multi-core,
+    multi-endpoint, CPU bursts, first-step I/O, RAM contention with different
+    working sets), all five latency distributions, overlapping spikes, outage.
+    """
+    eps_a = [
+        _endpoint("/fast", [("initial_parsing", 0.001), ("ram", 64), ("io_cache", 0.004), ("cpu_bound_operation", 0.002)]),
+        _endpoint("/burst", [("initial_parsing", 0.002), ("cpu_bound_operation", 0.003), ("ram", 300), ("io_db", 0.02), ("io_wait", 0.01)]),
+    ]
+    eps_b = [
+        _endpoint("/io-first", [("io_wait", 0.005), ("ram", 200), ("initial_parsing", 0.004), ("io_llm", 0.03), ("cpu_bound_operation", 0.001)]),
+    ]
+    eps_c = [
+        _endpoint("/noram", [("initial_parsing", 0.003), ("io_task_spawn", 0.006)]),
+        _endpoint("/big", [("initial_parsing", 0.002), ("ram", 400.5), ("io_wait", 0.05)]),
+        _endpoint("/small", [("ram", 32), ("initial_parsing", 0.001)]),
+    ]
+    p = {
+        "rqs_input": {
+            "id": "gen",
+            "avg_active_users": {"mean": 90, "distribution": "normal", "variance": 25},
+            "avg_request_per_minute_per_user": {"mean": 120},
+            "user_sampling_window": 7,
+        },
+        "topology_graph": {
+            "nodes": {
+                "client": {"id": "cli"},
+                "load_balancer": {"id": "lb", "algorithms": "least_connection", "server_covered": ["a", "b", "c"]},
+                "servers": [_server("a", 2, 1024, eps_a), _server("b", 1, 512, eps_b), _server("c", 3, 900, eps_c)],
+            },
+            "edges": [
+                _edge("g-c", "gen", "cli", 0.004, "exponential", dropout=0.02),
+                _edge("c-lb", "cli", "lb", 0.003, "normal", 0.002, dropout=0.0),
+                _edge("lb-a", "lb", "a", 0.01, "uniform", dropout=0.005),
+                _edge("lb-b", "lb", "b", 0.002, "log_normal", 0.5),
+                _edge("lb-c", "lb", "c", 0.006, "exponential"),
+                _edge("a-c", "a", "cli", 0.3, "poisson", dropout=0.03),
+                _edge("b-c", "b", "cli", 0.005, "normal", 0.01),
+                _edge("c-c", "c", "cli", 0.002, "exponential", dropout=0.0),
+            ],
+        },
+        "sim_settings": {"total_simulation_time": horizon, "sample_period_s": 0.01},
+        "events": [
+            {"event_id": "s1", "target_id": "c-lb", "start": {"kind": "network_spike_start", "t_start": 3.0, "spike_s": 0.3},
+             "end": {"kind": "network_spike_end", "t_end": 9.0}},
+            {"event_id": "s2", "target_id": "c-lb", "start": {"kind": "network_spike_start", "t_start": 5.0, "spike_s": 0.2},
+             "end": {"kind": "network_spike_end", "t_end": 11.0}},
+            {"event_id": "o1", "target_id": "b", "start": {"kind": "server_down", "t_start": 12.0}, "end": {"kind": "server_up", "t_end": 20.0}},
+            {"event_id": "o2", "target_id": "a", "start": {"kind": "server_down", "t_start": 20.0}, "end": {"kind": "server_up", "t_end": 26.5}},
+            {"event_id": "s3", "target_id": "lb-c", "start": {"kind": "network_spike_start", "t_start": 0.0, "spike_s": 0.05},
+             "end": {"kind": "network_spike_end", "t_end": 2.0}},
+        ],
+    }
+    return p
+
+
+def overload(horizon: int = 30) -> dict:
+    """CPU + RAM contention: ready queue and RAM FIFO (head-of-line) are busy."""
+    eps = [
+        _endpoint("/a", [("initial_parsing", 0.006), ("ram", 500), ("io_wait", 0.03), ("cpu_bound_operation", 0.004)]),
+        _endpoint("/b", [("initial_parsing", 0.003), ("ram", 900), ("io_wait", 0.08)]),
+    ]
+    p = single_server(users=60, rpm=120, horizon=horizon, period=0.02)
+    p["topology_graph"]["nodes"]["servers"] = [_server("srv-1", 1, 1500, eps)]
+    return p
+
+
+def random_payload(rng: random.Random, horizon: int = 12) -> dict:
+    """Random valid payload for differential fuzzing (reference vs oracle vs engine)."""
+    n_srv = rng.randint(1, 4)
+    use_lb = n_srv > 1 or rng.random() < 0.3
+    cpu_kinds = ["initial_parsing", "cpu_bound_operation"]
+    io_kinds = ["io_task_spawn", "io_llm", "io_wait", "io_db", "io_cache"]
+
+    def rnd_latency() -> tuple[float, str, float | None]:
+        d = rng.choice(["exponential", "exponential", "exponential", "normal", "log_normal", "uniform", "poisson"])
+        if d == "exponential":
+            return rng.uniform(0.001, 0.02), d, None
+        if d == "normal":
+            return rng.uniform(0.002, 0.02), d, rng.uniform(0.0, 0.01)
+        if d == "log_normal":
+            return rng.uniform(0.001, 0.2), d, rng.uniform(0.05, 0.6)
+        if d == "uniform":
+            return rng.uniform(0.1, 1.0), d, None
+        return rng.uniform(0.05, 0.6), d, None
+
+    servers = []
+    for i in range(n_srv):
+        eps = []
+        for j in range(rng.randint(1, 3)):
+            steps = []
+            for _ in range(rng.randint(1, 5)):
+                r = rng.random()
+                if r < 0.4:
+                    steps.append((rng.choice(cpu_kinds), round(rng.uniform(0.0005, 0.008), 5)))
+                elif r < 0.8:
+                    steps.append((rng.choice(io_kinds), round(rng.uniform(0.001, 0.06), 5)))
+                else:
+                    steps.append(("ram", rng.choice([16, 64, 128, 200, 333, 100.25])))
+            eps.append(_endpoint(f"/e{j}", steps))
+        servers.append(_server(f"s{i}", rng.randint(1, 3), rng.choice([256, 300, 512, 1024]), eps))
+    edges = []
+    m, d, v = rnd_latency()
+    edges.append(_edge("g-c", "gen", "cli", m, d, v, rng.choice([None, 0.0, 0.05])))
+    if use_lb:
+        m, d, v = rnd_latency()
+        edges.append(_edge("c-lb", "cli", "lb", m, d, v, rng.choice([None, 0.0, 0.02])))
+        for i in range(n_srv):
+            m, d, v = rnd_latency()
+            edges.append(_edge(f"lb-s{i}", "lb", f"s{i}", m, d, v, rng.choice([None, 0.0, 0.1])))
+    else:
+        m, d, v = rnd_latency()
+        edges.append(_edge("c-s0", "cli", "s0", m, d, v, rng.choice([None, 0.0])))
+    for i in range(n_srv):
+        m, d, v = rnd_latency()
+        edges.append(_edge(f"s{i}-c", f"s{i}", "cli", m, d, v, rng.choice([None, 0.0, 0.03])))
+    users_dist = rng.choice(["poisson", "normal"])
+    users: dict[str, Any] = {"mean": rng.choice([5, 20, 60, 150])}
+    if users_dist == "normal":
+        users.update(distribution="normal", variance=rng.choice([1, 10, 40]))
+    nodes: dict[str, Any] = {"client": {"id": "cli"}, "servers": servers}
+    if use_lb:
+        nodes["load_balancer"] = {
+            "id": "lb",
+            "algorithms": rng.choice(["round_robin", "least_connection"]),
+            "server_covered": [f"s{i}" for i in range(n_srv)],
+        }
+    p: dict[str, Any] = {
+        "rqs_input": {
+            "id": "gen",
+            "avg_active_users": users,
+            "avg_request_per_minute_per_user": {"mean": rng.choice([30, 60, 240])},
+            "user_sampling_window": rng.choice([1, 3, 60]),
+        },
+        "topology_graph": {"nodes": nodes, "edges": edges},
+        "sim_settings": {"total_simulation_time": horizon, "sample_period_s": rng.choice([0.01, 0.05, 0.1, 0.003])},
+    }
+    events = []
+    T = float(horizon)
+    for k in range(rng.randint(0, 3)):
+        e = rng.choice(edges)
+        a = rng.uniform(0, T * 0.8)
+        b = rng.uniform(a + 0.1, T)
+        events.append({"event_id": f"sp{k}", "target_id": e["id"],
+                       "start": {"kind": "network_spike_start", "t_start": round(a, 3), "spike_s": round(rng.uniform(0.005, 0.3), 4)},
+                       "end": {"kind": "network_spike_end", "t_end": round(b, 3)}})
+    if use_lb and n_srv > 1 and rng.random() < 0.7:
+        # non-overlapping outages, one server at a time
+        t = rng.uniform(0.5, 3.0)
+        for k in range(rng.randint(1, 3)):
+            sid = f"s{rng.randrange(n_srv)}"
+            dur = rng.uniform(0.5, 3.0)
+            if t + dur >= T:
+                break
+            events.append({"event_id": f"out{k}", "target_id": sid,
+                           "start": {"kind": "server_down", "t_start": round(t, 3)}, "end": {"kind": "server_up", "t_end": round(t + dur, 3)}})
+            t += dur + rng.choice([0.0, 0.7])
+    if events:
+        p["events"] = events
+    return copy.deepcopy(p)
+
+
+#: name -> (payload builder, seed) for the committed golden fixtures
+GOLDEN = {
+    "single_server_t30": (lambda: single_server(horizon=30), 0),
+    "lb2_rr_t30": (lambda: lb_two_servers(horizon=30), 0x5EED0000),
+    "lb2_lc_t20": (lambda: lb_two_servers(horizon=20, algo="least_connection"), 7),
+    "lb2_events_t60": (lambda: lb_with_events(users=200, horizon=60, scale=0.1), 42),
+    "fanout8_t20": (lambda: fanout8(users=120, horizon=20), 11),
+    "stress_mixed_t40": (lambda: stress_mixed(40), 3),
+    "overload_t30": (lambda: overload(30), 5),
+}

@@ -1,0 +1,23 @@
+"""pytest configuration: `gpu` marker + repo root on sys.path."""
+
+from __future__ import annotations
+
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+GOLDEN_DIR = ROOT / "tests" / "golden"
+
+
+def pytest_configure(config: pytest.Config) -> None:
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "reference: needs /root/reference (build container only)")
+
+
+def golden_names() -> list[str]:
+    return sorted(p.stem for p in GOLDEN_DIR.glob("*.npz"))
