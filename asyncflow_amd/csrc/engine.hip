@@ -1,0 +1,547 @@
+// engine.hip -- MI355X (gfx950) batched discrete-event engine: kernel + C ABI.
+//
+// One scenario per lane, one wavefront (64 scenarios) per workgroup, one
+// workgroup per CU-resident LDS allocation.  Each wave free-runs its 64
+// scenarios through af::Lane<Mem>::round() (af_core.hpp) until every lane has
+// reached the horizon (`__any` wave vote); there is no inter-wave communication.
+//
+// Memory plan
+//   LDS  : [plan blob (read-only, shared by the 64 lanes)]
+//          [per-lane state, SoA [index][lane]: f64 region, then u32 region]
+//          -> any per-lane index pattern is bank-conflict free
+//             (ds_read_b64: bank = 2*lane mod 64 per 32-lane group;
+//              ds_read_b32: bank = lane mod 32).
+//   HBM  : outputs only (rqs_clock, sampled series, counts); per-lane state too
+//          when 64 * bytes_per_lane exceeds the 160 KiB LDS of a CU ("global
+//          state" mode, same [index][lane] layout => coalesced for equal indices).
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see build.py).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/asyncflow_hip.h"
+#include "af_core.hpp"
+
+#define LDS_AS __attribute__((address_space(3)))
+
+namespace {
+
+constexpr uint32_t kLdsLimit = 160u * 1024u;  // bytes per workgroup on gfx950
+constexpr uint32_t kWave = 64u;
+
+enum BlobArray : uint32_t {
+    B_E_MEAN, B_E_SIGMA, B_E_DROP, B_S_RAM, B_EP_RAM, B_ST_TIME, B_EM_TIME, B_EM_DELTA, B_SM_TIME,
+    B_LB_EDGES, B_E_TKIND, B_E_TIDX, B_E_DIST, B_S_CORES, B_S_OUT, B_S_EPB, B_EP_STEPB, B_ST_KIND,
+    B_EM_EDGE, B_SM_EDGE, B_SM_DOWN, B_COUNT
+};
+
+struct KArgs {
+    double total_time, sample_period, gen_users_mean, gen_users_sigma, gen_rpm_mean, gen_window_s;
+    uint32_t metrics_mask, gen_users_dist;
+    int32_t gen_out_edge, client_out_edge;
+    uint32_t n_edges, n_servers, lb_algo, n_lb_edges, n_endpoints, n_steps, n_edge_marks, n_srv_marks;
+    uint32_t off[B_COUNT];  // byte offsets of the arrays inside the blob
+    uint32_t blob_bytes;    // multiple of 16
+    const unsigned char* blob;
+    af::Layout L;
+    uint32_t n_scen;
+    const uint64_t* seeds;
+    uint32_t n_ovr;
+    const uint32_t* ovr_param;
+    const uint32_t* ovr_index;
+    const double* ovr_values;  // [n_ovr][n_scen]
+    double* clock;
+    uint32_t clock_cap;
+    uint32_t* samples;
+    uint32_t tick_cap, n_series;
+    uint32_t* counts;
+    unsigned char* state;  // HBM-resident lane state (global-state mode only)
+    uint64_t state_bytes_per_wave;
+};
+
+struct MemLds {
+    LDS_AS double* d;    // already offset by the lane
+    LDS_AS uint32_t* w;
+    __device__ __forceinline__ double ld64(uint32_t i) const { return d[i * kWave]; }
+    __device__ __forceinline__ void st64(uint32_t i, double v) const { d[i * kWave] = v; }
+    __device__ __forceinline__ uint32_t ld32(uint32_t i) const { return w[i * kWave]; }
+    __device__ __forceinline__ void st32(uint32_t i, uint32_t v) const { w[i * kWave] = v; }
+};
+
+struct MemGlobal {
+    double* d;
+    uint32_t* w;
+    __device__ __forceinline__ double ld64(uint32_t i) const { return d[i * kWave]; }
+    __device__ __forceinline__ void st64(uint32_t i, double v) const { d[i * kWave] = v; }
+    __device__ __forceinline__ uint32_t ld32(uint32_t i) const { return w[i * kWave]; }
+    __device__ __forceinline__ void st32(uint32_t i, uint32_t v) const { w[i * kWave] = v; }
+};
+
+template <class T>
+__device__ __forceinline__ const LDS_AS T* lds_arr(unsigned char* smem, uint32_t off) {
+    return (const LDS_AS T*)(smem + off);
+}
+
+template <bool kLdsState>
+__global__ void __launch_bounds__(64) af_des_kernel(const KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t lane = threadIdx.x;
+
+    // stage the read-only plan into LDS (shared by the 64 scenarios of the wave)
+    for (uint32_t i = lane * 16u; i < a.blob_bytes; i += kWave * 16u)
+        *reinterpret_cast<uint4*>(smem + i) = *reinterpret_cast<const uint4*>(a.blob + i);
+    __syncthreads();
+
+    af::PlanView P;
+    P.total_time = a.total_time;
+    P.sample_period = a.sample_period;
+    P.gen_users_mean = a.gen_users_mean;
+    P.gen_users_sigma = a.gen_users_sigma;
+    P.gen_rpm_mean = a.gen_rpm_mean;
+    P.gen_window_s = a.gen_window_s;
+    P.metrics_mask = a.metrics_mask;
+    P.gen_users_dist = a.gen_users_dist;
+    P.gen_out_edge = a.gen_out_edge;
+    P.client_out_edge = a.client_out_edge;
+    P.n_edges = a.n_edges;
+    P.n_servers = a.n_servers;
+    P.lb_algo = a.lb_algo;
+    P.n_lb_edges = a.n_lb_edges;
+    P.n_endpoints = a.n_endpoints;
+    P.n_steps = a.n_steps;
+    P.n_edge_marks = a.n_edge_marks;
+    P.n_srv_marks = a.n_srv_marks;
+    P.e_mean = lds_arr<double>(smem, a.off[B_E_MEAN]);
+    P.e_sigma = lds_arr<double>(smem, a.off[B_E_SIGMA]);
+    P.e_drop = lds_arr<double>(smem, a.off[B_E_DROP]);
+    P.s_ram = lds_arr<double>(smem, a.off[B_S_RAM]);
+    P.ep_ram = lds_arr<double>(smem, a.off[B_EP_RAM]);
+    P.st_time = lds_arr<double>(smem, a.off[B_ST_TIME]);
+    P.em_time = lds_arr<double>(smem, a.off[B_EM_TIME]);
+    P.em_delta = lds_arr<double>(smem, a.off[B_EM_DELTA]);
+    P.sm_time = lds_arr<double>(smem, a.off[B_SM_TIME]);
+    P.lb_edges = lds_arr<int32_t>(smem, a.off[B_LB_EDGES]);
+    P.e_tkind = lds_arr<uint32_t>(smem, a.off[B_E_TKIND]);
+    P.e_tidx = lds_arr<int32_t>(smem, a.off[B_E_TIDX]);
+    P.e_dist = lds_arr<uint32_t>(smem, a.off[B_E_DIST]);
+    P.s_cores = lds_arr<uint32_t>(smem, a.off[B_S_CORES]);
+    P.s_out = lds_arr<int32_t>(smem, a.off[B_S_OUT]);
+    P.s_epb = lds_arr<uint32_t>(smem, a.off[B_S_EPB]);
+    P.ep_stepb = lds_arr<uint32_t>(smem, a.off[B_EP_STEPB]);
+    P.st_kind = lds_arr<uint32_t>(smem, a.off[B_ST_KIND]);
+    P.em_edge = lds_arr<int32_t>(smem, a.off[B_EM_EDGE]);
+    P.sm_edge = lds_arr<int32_t>(smem, a.off[B_SM_EDGE]);
+    P.sm_down = lds_arr<uint32_t>(smem, a.off[B_SM_DOWN]);
+
+    const uint32_t scen = blockIdx.x * kWave + lane;
+    const bool active = scen < a.n_scen;
+    const uint32_t sc = active ? scen : 0u;
+
+    af::LaneOut O;
+    O.clock = a.clock ? a.clock + (size_t)sc * a.clock_cap * 2u : nullptr;
+    O.samples = a.samples ? a.samples + (size_t)sc * a.n_series * a.tick_cap : nullptr;
+    O.counts = a.counts + (size_t)sc * af::CNT_SLOTS;
+    O.clock_cap = a.clock_cap;
+    O.tick_cap = a.tick_cap;
+
+    const uint64_t seed = a.seeds[sc];
+    auto ovr = [&](uint32_t k) { return a.ovr_values[(size_t)k * a.n_scen + sc]; };
+
+    if constexpr (kLdsState) {
+        MemLds M;
+        M.d = (LDS_AS double*)(smem + a.blob_bytes) + lane;
+        M.w = (LDS_AS uint32_t*)(smem + a.blob_bytes + (size_t)a.L.n_d * kWave * 8u) + lane;
+        af::Lane<MemLds> S(P, a.L, M, O, seed);
+        bool run = active;
+        if (active) S.init(a.ovr_param, a.ovr_index, a.n_ovr, ovr);
+        while (__any(run)) {
+            if (run) run = S.round();
+        }
+        if (active) S.write_counts();
+    } else {
+        unsigned char* base = a.state + (size_t)blockIdx.x * a.state_bytes_per_wave;
+        MemGlobal M;
+        M.d = reinterpret_cast<double*>(base) + lane;
+        M.w = reinterpret_cast<uint32_t*>(base + (size_t)a.L.n_d * kWave * 8u) + lane;
+        af::Lane<MemGlobal> S(P, a.L, M, O, seed);
+        bool run = active;
+        if (active) S.init(a.ovr_param, a.ovr_index, a.n_ovr, ovr);
+        while (__any(run)) {
+            if (run) run = S.round();
+        }
+        if (active) S.write_counts();
+    }
+}
+
+__global__ void af_probe_kernel(int kind, uint64_t seed, const double* in, const double* in2, double* out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = in[i];
+    const double y = in2 ? in2[i] : 0.0;
+    double r;
+    switch (kind) {
+        case 0: {
+            const uint32_t packed = (uint32_t)y;
+            r = af::uniform_j(seed, packed >> 16, (uint32_t)x, packed & 0xFFFFu);
+            break;
+        }
+        case 1: r = af::af_log(x); break;
+        case 2: r = af::af_exp(x); break;
+        case 3: r = af::af_norminv(x); break;
+        case 4: r = af::af_sqrt(x); break;
+        case 5: r = x / y; break;
+        case 6: r = (double)af::af_poisson(x, seed, (uint32_t)y >> 16, (uint32_t)y & 0xFFFFu, 0u); break;
+        default: r = 0.0;
+    }
+    out[i] = r;
+}
+
+// ---- host side ---------------------------------------------------------------
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(AF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));            \
+    } while (0)
+
+uint32_t pow2_at_least(uint32_t v) {
+    uint32_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+}  // namespace
+
+struct af_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    KArgs args{};
+    unsigned char* d_blob = nullptr;
+    unsigned char* d_state = nullptr;
+    size_t state_cap = 0;
+    void* d_sweep = nullptr;  // seeds + override tables
+    size_t sweep_cap = 0;
+    uint32_t request_capacity = 0, fifo_capacity = 0, force_global = 0;
+    uint32_t n_lb_edges = 0;
+    af_stats_t stats{};
+};
+
+namespace {
+
+template <class T>
+void put_array(std::vector<unsigned char>& blob, uint32_t* off, const T* src, size_t n) {
+    while (blob.size() % 8) blob.push_back(0);
+    *off = (uint32_t)blob.size();
+    const size_t bytes = (n ? n : 1) * sizeof(T);
+    blob.resize(blob.size() + bytes, 0);
+    if (n && src) std::memcpy(blob.data() + *off, src, n * sizeof(T));
+}
+
+template <class T>
+void put_widened(std::vector<unsigned char>& blob, uint32_t* off, const T* src, size_t n) {
+    std::vector<uint32_t> w(n ? n : 1, 0u);
+    for (size_t i = 0; i < n; ++i) w[i] = (uint32_t)src[i];
+    put_array<uint32_t>(blob, off, w.data(), n);
+}
+
+int validate_plan(const af_plan_t* p) {
+    if (!p) return fail(AF_ERR_INVALID, "plan is NULL");
+    if (p->abi_version != AF_ABI_VERSION || p->struct_size != sizeof(af_plan_t))
+        return fail(AF_ERR_ABI, "af_plan_t ABI mismatch (version or size)");
+    if (!(p->total_time > 0.0) || !(p->sample_period > 0.0)) return fail(AF_ERR_INVALID, "bad horizon or sample period");
+    if (p->n_edges == 0 || p->n_edges > 255 || p->n_servers > 255) return fail(AF_ERR_INVALID, "edge/server count out of range (1..255 edges, <=255 servers)");
+    if (p->n_endpoints > 65535 || p->n_steps > 65535) return fail(AF_ERR_INVALID, "too many endpoints/steps (<= 65535)");
+    if (p->gen_out_edge < 0 || (uint32_t)p->gen_out_edge >= p->n_edges) return fail(AF_ERR_INVALID, "generator out edge invalid");
+    if (p->client_out_edge < 0 || (uint32_t)p->client_out_edge >= p->n_edges) return fail(AF_ERR_INVALID, "client out edge invalid");
+    if (p->has_lb && p->n_lb_edges == 0) return fail(AF_ERR_INVALID, "load balancer without out edges");
+    for (uint32_t e = 0; e < p->n_edges; ++e) {
+        if (p->edge_target_kind[e] > AF_NODE_SERVER) return fail(AF_ERR_INVALID, "edge target kind invalid");
+        if (p->edge_target_kind[e] == AF_NODE_SERVER &&
+            (p->edge_target_idx[e] < 0 || (uint32_t)p->edge_target_idx[e] >= p->n_servers))
+            return fail(AF_ERR_INVALID, "edge targets unknown server");
+        if (p->edge_target_kind[e] == AF_NODE_LB && !p->has_lb) return fail(AF_ERR_INVALID, "edge targets missing LB");
+        if (p->edge_dist[e] > AF_DIST_UNIFORM) return fail(AF_ERR_INVALID, "edge distribution invalid");
+    }
+    for (uint32_t s = 0; s < p->n_servers; ++s) {
+        if (p->srv_out_edge[s] < 0 || (uint32_t)p->srv_out_edge[s] >= p->n_edges) return fail(AF_ERR_INVALID, "server out edge invalid");
+        if (p->srv_ep_begin[s + 1] <= p->srv_ep_begin[s]) return fail(AF_ERR_INVALID, "server without endpoints");
+    }
+    for (uint32_t i = 0; i < p->n_lb_edges; ++i)
+        if (p->lb_edges[i] < 0 || (uint32_t)p->lb_edges[i] >= p->n_edges) return fail(AF_ERR_INVALID, "LB edge invalid");
+    for (uint32_t i = 0; i < p->n_edge_marks; ++i)
+        if (p->emark_edge[i] < 0 || (uint32_t)p->emark_edge[i] >= p->n_edges) return fail(AF_ERR_INVALID, "edge mark invalid");
+    for (uint32_t i = 0; i < p->n_srv_marks; ++i)
+        if (p->smark_lb_edge[i] >= (int32_t)p->n_edges) return fail(AF_ERR_INVALID, "server mark invalid");
+    return AF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int af_abi_version(void) { return AF_ABI_VERSION; }
+
+const char* af_last_error(void) { return g_err.c_str(); }
+
+uint32_t af_tick_count(double sample_period, double total_time) {
+    if (!(sample_period > 0.0)) return 0;
+    uint32_t n = 0;
+    double t = 0.0 + sample_period;
+    while (t < total_time) {
+        n += 1;
+        t = t + sample_period;
+    }
+    return n;
+}
+
+uint32_t af_series_count(const af_plan_t* plan) { return plan ? plan->n_edges + 3u * plan->n_servers : 0u; }
+
+int af_engine_create(const af_plan_t* plan, int device, const af_engine_options_t* opts, af_engine_t** out) {
+    if (!out) return fail(AF_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (int rc = validate_plan(plan)) return rc;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return fail(AF_ERR_NO_DEVICE, "no HIP device visible: the asyncflow_amd engine has no CPU fallback");
+    if (device < 0 || device >= n_dev) return fail(AF_ERR_NO_DEVICE, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+
+    af_engine* e = new af_engine();
+    e->device = device;
+    KArgs& a = e->args;
+    a.total_time = plan->total_time;
+    a.sample_period = plan->sample_period;
+    a.gen_users_mean = plan->gen_users_mean;
+    a.gen_users_sigma = plan->gen_users_sigma;
+    a.gen_rpm_mean = plan->gen_rpm_mean;
+    a.gen_window_s = plan->gen_window_s;
+    a.metrics_mask = plan->metrics_mask;
+    a.gen_users_dist = plan->gen_users_dist;
+    a.gen_out_edge = plan->gen_out_edge;
+    a.client_out_edge = plan->client_out_edge;
+    a.n_edges = plan->n_edges;
+    a.n_servers = plan->n_servers;
+    a.lb_algo = plan->lb_algo;
+    a.n_lb_edges = plan->n_lb_edges;
+    a.n_endpoints = plan->n_endpoints;
+    a.n_steps = plan->n_steps;
+    a.n_edge_marks = plan->n_edge_marks;
+    a.n_srv_marks = plan->n_srv_marks;
+    a.n_series = plan->n_edges + 3u * plan->n_servers;
+
+    std::vector<unsigned char> blob;
+    put_array(blob, &a.off[B_E_MEAN], plan->edge_mean, plan->n_edges);
+    put_array(blob, &a.off[B_E_SIGMA], plan->edge_sigma, plan->n_edges);
+    put_array(blob, &a.off[B_E_DROP], plan->edge_dropout, plan->n_edges);
+    put_array(blob, &a.off[B_S_RAM], plan->srv_ram_mb, plan->n_servers);
+    put_array(blob, &a.off[B_EP_RAM], plan->ep_ram, plan->n_endpoints);
+    put_array(blob, &a.off[B_ST_TIME], plan->step_time, plan->n_steps);
+    put_array(blob, &a.off[B_EM_TIME], plan->emark_time, plan->n_edge_marks);
+    put_array(blob, &a.off[B_EM_DELTA], plan->emark_delta, plan->n_edge_marks);
+    put_array(blob, &a.off[B_SM_TIME], plan->smark_time, plan->n_srv_marks);
+    put_array(blob, &a.off[B_LB_EDGES], plan->lb_edges, plan->n_lb_edges);
+    put_widened(blob, &a.off[B_E_TKIND], plan->edge_target_kind, plan->n_edges);
+    put_array(blob, &a.off[B_E_TIDX], plan->edge_target_idx, plan->n_edges);
+    put_widened(blob, &a.off[B_E_DIST], plan->edge_dist, plan->n_edges);
+    put_array(blob, &a.off[B_S_CORES], plan->srv_cores, plan->n_servers);
+    put_array(blob, &a.off[B_S_OUT], plan->srv_out_edge, plan->n_servers);
+    put_array(blob, &a.off[B_S_EPB], plan->srv_ep_begin, (size_t)plan->n_servers + 1);
+    put_array(blob, &a.off[B_EP_STEPB], plan->ep_step_begin, (size_t)plan->n_endpoints + 1);
+    put_widened(blob, &a.off[B_ST_KIND], plan->step_kind, plan->n_steps);
+    put_array(blob, &a.off[B_EM_EDGE], plan->emark_edge, plan->n_edge_marks);
+    put_array(blob, &a.off[B_SM_EDGE], plan->smark_lb_edge, plan->n_srv_marks);
+    put_widened(blob, &a.off[B_SM_DOWN], plan->smark_down, plan->n_srv_marks);
+    while (blob.size() % 16) blob.push_back(0);
+    a.blob_bytes = (uint32_t)blob.size();
+
+    e->request_capacity = opts && opts->request_capacity ? opts->request_capacity : 64u;
+    e->fifo_capacity = pow2_at_least(opts && opts->fifo_capacity ? opts->fifo_capacity : 32u);
+    e->force_global = opts ? opts->force_global_state : 0u;
+    if (e->request_capacity > 65535u || e->fifo_capacity > 65536u) {
+        delete e;
+        return fail(AF_ERR_CAPACITY, "request_capacity must be <= 65535 and fifo_capacity <= 65536");
+    }
+    if (a.blob_bytes > kLdsLimit / 2) {
+        delete e;
+        return fail(AF_ERR_CAPACITY, "plan too large for the LDS-resident plan blob");
+    }
+
+    hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (err == hipSuccess) err = hipEventCreate(&e->ev0);
+    if (err == hipSuccess) err = hipEventCreate(&e->ev1);
+    if (err == hipSuccess) err = hipEventCreate(&e->ev2);
+    if (err == hipSuccess) err = hipMalloc((void**)&e->d_blob, blob.size());
+    if (err == hipSuccess) err = hipMemcpy(e->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice);
+    if (err != hipSuccess) {
+        af_engine_destroy(e);
+        return fail(AF_ERR_HIP, std::string("engine setup: ") + hipGetErrorString(err));
+    }
+    a.blob = e->d_blob;
+    *out = e;
+    return AF_OK;
+}
+
+int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* out) {
+    if (!e || !sweep || !out) return fail(AF_ERR_INVALID, "NULL argument");
+    if (sweep->n_scenarios == 0 || !sweep->seeds) return fail(AF_ERR_INVALID, "empty sweep");
+    if (!out->counts) return fail(AF_ERR_INVALID, "outputs.counts is required");
+    if (out->clock && out->clock_capacity == 0) return fail(AF_ERR_INVALID, "clock buffer with zero capacity");
+    if (out->samples && out->tick_capacity == 0) return fail(AF_ERR_INVALID, "samples buffer with zero capacity");
+    HIP_TRY(hipSetDevice(e->device));
+    KArgs a = e->args;
+    const uint32_t n = sweep->n_scenarios;
+
+    uint32_t mask = 0;
+    for (uint32_t k = 0; k < sweep->n_overrides; ++k) {
+        const af_override_t& o = sweep->overrides[k];
+        if (o.param >= AF_PARAM_COUNT_ || !o.values) return fail(AF_ERR_INVALID, "bad override");
+        const uint32_t lim = (o.param >= AF_PARAM_EDGE_MEAN && o.param <= AF_PARAM_EDGE_DROPOUT) ? a.n_edges
+                             : (o.param == AF_PARAM_STEP_TIME)                                   ? a.n_steps
+                                                                                                 : 1u;
+        if (o.index >= lim) return fail(AF_ERR_INVALID, "override index out of range");
+        mask |= 1u << o.param;
+    }
+    a.L = af::make_layout(e->request_capacity, e->fifo_capacity, a.n_edges, a.n_servers, a.n_lb_edges, a.n_steps, mask);
+    const uint64_t bytes_per_lane = af::layout_bytes_per_lane(a.L);
+    const uint64_t state_per_wave = bytes_per_lane * kWave;
+    const bool lds_state = !e->force_global && (uint64_t)a.blob_bytes + state_per_wave <= kLdsLimit;
+    const uint32_t waves = (n + kWave - 1) / kWave;
+    const uint32_t lds_bytes = lds_state ? (uint32_t)(a.blob_bytes + state_per_wave) : a.blob_bytes;
+
+    // ---- upload seeds + override tables (one staging buffer) -------------------
+    const size_t seeds_b = (size_t)n * 8;
+    const size_t vals_b = (size_t)sweep->n_overrides * n * 8;
+    const size_t tab_b = (size_t)(sweep->n_overrides ? sweep->n_overrides : 1) * 4;
+    const size_t total = seeds_b + vals_b + 2 * ((tab_b + 7) & ~size_t(7));
+    if (total > e->sweep_cap) {
+        if (e->d_sweep) HIP_TRY(hipFree(e->d_sweep));
+        e->d_sweep = nullptr;
+        e->sweep_cap = 0;
+        HIP_TRY(hipMalloc(&e->d_sweep, total));
+        e->sweep_cap = total;
+    }
+    unsigned char* ds = static_cast<unsigned char*>(e->d_sweep);
+    HIP_TRY(hipEventRecord(e->ev0, e->stream));
+    HIP_TRY(hipMemcpyAsync(ds, sweep->seeds, seeds_b, hipMemcpyHostToDevice, e->stream));
+    std::vector<uint32_t> params(sweep->n_overrides ? sweep->n_overrides : 1, 0u), idxs(params.size(), 0u);
+    for (uint32_t k = 0; k < sweep->n_overrides; ++k) {
+        params[k] = sweep->overrides[k].param;
+        idxs[k] = sweep->overrides[k].index;
+        HIP_TRY(hipMemcpyAsync(ds + seeds_b + (size_t)k * n * 8, sweep->overrides[k].values, (size_t)n * 8,
+                               hipMemcpyHostToDevice, e->stream));
+    }
+    unsigned char* d_params = ds + seeds_b + vals_b;
+    unsigned char* d_idxs = d_params + ((tab_b + 7) & ~size_t(7));
+    HIP_TRY(hipMemcpyAsync(d_params, params.data(), tab_b, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(d_idxs, idxs.data(), tab_b, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));  // host staging vectors go out of scope below
+
+    a.n_scen = n;
+    a.seeds = reinterpret_cast<const uint64_t*>(ds);
+    a.n_ovr = sweep->n_overrides;
+    a.ovr_values = reinterpret_cast<const double*>(ds + seeds_b);
+    a.ovr_param = reinterpret_cast<const uint32_t*>(d_params);
+    a.ovr_index = reinterpret_cast<const uint32_t*>(d_idxs);
+    a.clock = out->clock;
+    a.clock_cap = out->clock_capacity;
+    a.samples = out->samples;
+    a.tick_cap = out->tick_capacity;
+    a.counts = out->counts;
+    a.state = nullptr;
+    a.state_bytes_per_wave = state_per_wave;
+
+    if (!lds_state) {
+        const size_t need = (size_t)state_per_wave * waves;
+        if (need > e->state_cap) {
+            if (e->d_state) HIP_TRY(hipFree(e->d_state));
+            e->d_state = nullptr;
+            e->state_cap = 0;
+            HIP_TRY(hipMalloc((void**)&e->d_state, need));
+            e->state_cap = need;
+        }
+        a.state = e->d_state;
+    }
+
+    HIP_TRY(hipEventRecord(e->ev1, e->stream));
+    if (lds_state) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(af_des_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL(af_des_kernel<true>, dim3(waves), dim3(kWave), lds_bytes, e->stream, a);
+    } else {
+        hipLaunchKernelGGL(af_des_kernel<false>, dim3(waves), dim3(kWave), lds_bytes, e->stream, a);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e->ev2, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+
+    float ms_h2d = 0.f, ms_k = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms_h2d, e->ev0, e->ev1));
+    HIP_TRY(hipEventElapsedTime(&ms_k, e->ev1, e->ev2));
+    e->stats.kernel_ms = ms_k;
+    e->stats.h2d_ms = ms_h2d;
+    e->stats.state_bytes_per_scenario = bytes_per_lane;
+    e->stats.state_in_lds = lds_state ? 1u : 0u;
+    e->stats.lds_bytes_per_wave = lds_bytes;
+    e->stats.waves = waves;
+    e->stats.request_capacity = e->request_capacity;
+    e->stats.fifo_capacity = e->fifo_capacity;
+    return AF_OK;
+}
+
+int af_engine_stats(const af_engine_t* e, af_stats_t* stats) {
+    if (!e || !stats) return fail(AF_ERR_INVALID, "NULL argument");
+    *stats = e->stats;
+    return AF_OK;
+}
+
+void af_engine_destroy(af_engine_t* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->d_blob) (void)hipFree(e->d_blob);
+    if (e->d_state) (void)hipFree(e->d_state);
+    if (e->d_sweep) (void)hipFree(e->d_sweep);
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->ev2) (void)hipEventDestroy(e->ev2);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int af_probe_math(int device, int kind, uint64_t seed, const double* in, const double* in2, double* out, size_t n) {
+    if (!in || !out || n == 0) return fail(AF_ERR_INVALID, "NULL argument");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return fail(AF_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= n_dev) return fail(AF_ERR_NO_DEVICE, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    double *d_in = nullptr, *d_in2 = nullptr, *d_out = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_in, n * 8));
+    HIP_TRY(hipMalloc((void**)&d_out, n * 8));
+    HIP_TRY(hipMemcpy(d_in, in, n * 8, hipMemcpyHostToDevice));
+    if (in2) {
+        HIP_TRY(hipMalloc((void**)&d_in2, n * 8));
+        HIP_TRY(hipMemcpy(d_in2, in2, n * 8, hipMemcpyHostToDevice));
+    }
+    hipLaunchKernelGGL(af_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, kind, seed, d_in, d_in2,
+                       d_out, n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, d_out, n * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    if (d_in2) (void)hipFree(d_in2);
+    return AF_OK;
+}
+
+}  // extern "C"

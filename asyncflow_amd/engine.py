@@ -1,0 +1,126 @@
+"""ctypes binding of the HIP engine (include/asyncflow_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or no MI355X is
+visible, :class:`EngineUnavailableError` is raised.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+from typing import Sequence
+
+import numpy as np
+
+from . import _abi
+from .build import LIB_PATH
+from .plan import DevicePlan
+
+
+class EngineUnavailableError(RuntimeError):
+    """The HIP library or the GPU is missing (the engine never falls back to the CPU)."""
+
+
+class EngineError(RuntimeError):
+    """A C-ABI call failed; the message is ``af_last_error()``."""
+
+
+_lib: C.CDLL | None = None
+
+
+def load_library(path: str | Path | None = None) -> C.CDLL:
+    global _lib  # noqa: PLW0603
+    if _lib is None:
+        p = Path(path) if path else LIB_PATH
+        if not p.exists():
+            msg = (
+                f"{p} not found: build it with `python -m asyncflow_amd.build` "
+                "(hipcc --offload-arch=gfx950). asyncflow_amd has no CPU fallback."
+            )
+            raise EngineUnavailableError(msg)
+        try:
+            lib = C.CDLL(str(p))
+        except OSError as exc:
+            msg = f"cannot load {p}: {exc}"
+            raise EngineUnavailableError(msg) from exc
+        if lib.af_abi_version() != _abi.AF_ABI_VERSION:
+            msg = "libasyncflow_hip.so was built against another ABI version; rebuild it"
+            raise EngineUnavailableError(msg)
+        _lib = _abi.declare(lib)
+    return _lib
+
+
+def _check(lib: C.CDLL, rc: int, what: str) -> None:
+    if rc == _abi.AF_OK:
+        return
+    text = (lib.af_last_error() or b"").decode(errors="replace")
+    if rc == _abi.AF_ERR_NO_DEVICE:
+        raise EngineUnavailableError(f"{what}: {text}")
+    raise EngineError(f"{what} failed ({rc}): {text}")
+
+
+class Engine:
+    """One ``af_engine_t``: a lowered plan resident on one GPU."""
+
+    def __init__(self, plan: DevicePlan, device: int = 0, *, request_capacity: int = 0,
+                 fifo_capacity: int = 0, force_global_state: bool = False) -> None:
+        self._lib = load_library()
+        self.plan = plan
+        self.device = device
+        self._cplan = plan.as_ctypes()
+        opts = _abi.AfEngineOptions(request_capacity, fifo_capacity, int(force_global_state))
+        handle = C.c_void_p()
+        _check(self._lib, self._lib.af_engine_create(C.byref(self._cplan), device, C.byref(opts), C.byref(handle)),
+               "af_engine_create")
+        self._h = handle
+
+    def run(self, seeds: np.ndarray, overrides: Sequence[tuple[int, int, np.ndarray]], *,
+            clock_ptr: int, clock_capacity: int, samples_ptr: int, tick_capacity: int, counts_ptr: int) -> _abi.AfStats:
+        """Launch the sweep; output pointers are DEVICE addresses owned by the caller."""
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        n = int(seeds.shape[0])
+        cols = [np.ascontiguousarray(v, dtype=np.float64) for _, _, v in overrides]
+        for c in cols:
+            if c.shape != (n,):
+                msg = f"override column has shape {c.shape}, expected ({n},)"
+                raise ValueError(msg)
+        ov = (_abi.AfOverride * max(len(cols), 1))()
+        for k, (param, index, _) in enumerate(overrides):
+            ov[k].param, ov[k].index = int(param), int(index)
+            ov[k].values = cols[k].ctypes.data_as(C.POINTER(C.c_double))
+        sweep = _abi.AfSweep(n, seeds.ctypes.data_as(C.POINTER(C.c_uint64)), len(cols), ov)
+        out = _abi.AfOutputs(int(clock_capacity), C.c_void_p(clock_ptr or None), int(tick_capacity),
+                             C.c_void_p(samples_ptr or None), C.c_void_p(counts_ptr))
+        _check(self._lib, self._lib.af_engine_run(self._h, C.byref(sweep), C.byref(out)), "af_engine_run")
+        return self.stats()
+
+    def stats(self) -> _abi.AfStats:
+        st = _abi.AfStats()
+        _check(self._lib, self._lib.af_engine_stats(self._h, C.byref(st)), "af_engine_stats")
+        return st
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.af_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self) -> None:  # pragma: no cover - best effort
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def probe_math(kind: int, x: np.ndarray, y: np.ndarray | None = None, seed: int = 0, device: int = 0) -> np.ndarray:
+    """Evaluate the engine's own RNG/math on the GPU (spec pinning, tests only)."""
+    lib = load_library()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    pd = C.POINTER(C.c_double)
+    yp = None
+    if y is not None:
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        yp = y.ctypes.data_as(pd)
+    _check(lib, lib.af_probe_math(device, kind, C.c_uint64(seed), x.ctypes.data_as(pd), yp, out.ctypes.data_as(pd), x.size),
+           "af_probe_math")
+    return out

@@ -161,18 +161,16 @@ class DevicePlan:
         return int(mean + 8.0 * std + 64.0)
 
 
-def _edge_latency_scale(lat: dict) -> float:
-    """A rough typical transit time, only used to size request pools."""
-    d, m, s = lat["distribution"], lat["mean"], lat["variance"] or 0.0
-    if d == "log_normal":
-        return math.exp(min(m + 2.0 * s, 50.0))
-    if d == "normal":
-        return max(m, 0.0) + 2.0 * s
-    if d == "uniform":
-        return 1.0
-    if d == "poisson":
-        return m + 3.0 * math.sqrt(m) + 1.0
-    return 3.0 * m
+def _edge_latency_mean(dist: str, m: float, s: float) -> float:
+    """Mean transit time of one edge under the reference's variate semantics
+    (samplers/common_helpers.py:49-89); only used to size request pools."""
+    if dist == "log_normal":
+        return math.exp(min(m + 0.5 * s * s, 50.0))
+    if dist == "normal":
+        return max(m, 0.0) + 0.4 * s
+    if dist == "uniform":
+        return 0.5
+    return m  # exponential, poisson
 
 
 def lower(payload: Any) -> DevicePlan:  # noqa: C901, PLR0912, PLR0915
@@ -349,26 +347,61 @@ def lower(payload: Any) -> DevicePlan:  # noqa: C901, PLR0912, PLR0915
     return plan
 
 
-def estimate_capacities(plan: DevicePlan, users_max: float | None = None, latency_scale: float = 1.0) -> tuple[int, int]:
+def estimate_capacities(
+    plan: DevicePlan,
+    users_max: float | None = None,
+    latency_scale: float = 1.0,
+    rpm_max: float | None = None,
+) -> tuple[int, int]:
     """(request_capacity, fifo_capacity) heuristics for the engine.
 
-    Live requests ~ arrival rate x time in system (Little); time in system is
-    bounded by the sum of typical edge transits along the longest path + spikes
-    + service.  Overflow is detected and reported by the engine, never silent.
+    Little's law: live requests ~ arrival rate x time in system, where the time
+    in system is the mean transit along generator -> client -> (LB ->) server ->
+    client plus the service time, M/D/1 waiting for the CPU, and every injected
+    spike.  The number in system is roughly Poisson, so mean + 8 sigma + slack.
+    A saturated server (CPU or RAM bound) accumulates a backlog proportional to
+    the horizon.  Overflow is detected and reported by the engine, never silent;
+    the runner retries with a larger pool.
     """
     payload = plan.payload
-    users = plan.gen_users_mean if users_max is None else users_max
-    sd = math.sqrt(users) if plan.gen_users_dist == _abi.DIST_CODES["poisson"] else plan.gen_users_sigma
-    rate = (users + 6.0 * sd) * plan.gen_rpm_mean / 60.0
-    lat = sorted((_edge_latency_scale(e["latency"]) * latency_scale for e in payload["topology_graph"]["edges"]), reverse=True)
-    path = sum(lat[: 4 + max(0, plan.n_servers - 2)])
-    spike = sum(abs(float(d)) for d in plan.emark_delta[plan.emark_delta > 0]) if len(plan.emark_delta) else 0.0
-    service = 0.0
+    edges = payload["topology_graph"]["edges"]
+    users = plan.gen_users_mean if users_max is None else float(users_max)
+    rpm = plan.gen_rpm_mean if rpm_max is None else float(rpm_max)
+    sd = math.sqrt(max(users, 0.0)) if plan.gen_users_dist == _abi.DIST_CODES["poisson"] else plan.gen_users_sigma
+    rate = max(users + 5.0 * sd, 0.0) * rpm / 60.0
+
+    def lat(i: int) -> float:
+        e = edges[i]["latency"]
+        return _edge_latency_mean(e["distribution"], e["mean"], e["variance"] or 0.0) * latency_scale
+
+    path = lat(plan.gen_out_edge) + lat(plan.client_out_edge)
+    if plan.has_lb:
+        path += max(lat(int(i)) for i in plan.lb_edges)
+    if plan.n_servers:
+        path += max(lat(int(i)) for i in plan.srv_out_edge)
+    spike = float(plan.emark_delta[plan.emark_delta > 0].sum()) if len(plan.emark_delta) else 0.0
+
+    service = cpu = ram = 0.0
     for ep in range(len(plan.ep_ram)):
-        b, e = plan.ep_step_begin[ep], plan.ep_step_begin[ep + 1]
+        b, e = int(plan.ep_step_begin[ep]), int(plan.ep_step_begin[ep + 1])
         service = max(service, float(plan.step_time[b:e].sum()))
-    live = rate * (path + spike + 4.0 * service)
-    cap = int(max(16, 8 + 4.0 * live + 10.0 * math.sqrt(max(live, 1.0))))
-    cap = 1 << max(4, (cap - 1).bit_length())
-    fifo = max(8, min(cap, 1 << max(3, (cap // 2 - 1).bit_length())))
+        cpu = max(cpu, float(plan.step_time[b:e][plan.step_kind[b:e] == _abi.STEP_CPU].sum()))
+        ram = max(ram, float(plan.ep_ram[ep]))
+    n_active = max(1, (len(plan.lb_edges) if plan.has_lb else 1) - (1 if len(plan.smark_time) else 0))
+    srv_rate = rate / n_active
+    cores = float(plan.srv_cores.min()) if plan.n_servers else 1.0
+    rho = srv_rate * cpu / cores
+    saturated = rho >= 0.9
+    wait = 0.0 if saturated else rho * cpu / (2.0 * (1.0 - rho))
+    if ram > 0.0 and plan.n_servers:
+        slots = math.floor(float(plan.srv_ram_mb.min()) / ram)
+        saturated = saturated or srv_rate * (service + wait) >= 0.8 * slots
+    live = rate * (path + spike + service + wait)
+    if saturated:
+        live += rate * plan.total_time
+    cap = int(live + 8.0 * math.sqrt(max(live, 1.0)) + 8.0)
+    cap = min(65535, max(16, (cap + 7) // 8 * 8))
+    fifo = 8
+    while fifo < (cap if saturated else min(cap, max(8, cap // 2))):
+        fifo *= 2
     return cap, fifo

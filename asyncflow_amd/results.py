@@ -1,0 +1,297 @@
+"""Results of a batched run, with the reference analyzer's accessors per scenario.
+
+``ScenarioResults`` restates the compute part of the reference's
+``ResultsAnalyzer`` (/root/reference/src/asyncflow/metrics/analyzer.py:75-244)
+on the arrays the engine wrote: same numpy calls, same bucket rule, same keys,
+so a user of ``SimulationRunner(...).run()`` can keep calling
+``get_latency_stats / get_throughput_series / get_sampled_metrics / get_series``.
+Plotting (analyzer.py:249-589) is presentation and out of scope: the reference's
+own plot helpers accept these objects through ``to_reference_analyzer``.
+"""
+
+from __future__ import annotations
+
+from collections import defaultdict
+from typing import Any, Iterator
+
+import numpy as np
+
+from . import _abi
+from .plan import DevicePlan
+
+LATENCY_KEYS = ("total_requests", "mean", "median", "std_dev", "p95", "p99", "min", "max")
+Series = tuple[list[float], list[float]]
+
+
+class ScenarioResults:
+    """One scenario of a sweep; API of the reference's ``ResultsAnalyzer``."""
+
+    _WINDOW_SIZE_S: float = 1.0
+
+    def __init__(self, plan: DevicePlan, counts: np.ndarray, clock: np.ndarray, samples: np.ndarray | None) -> None:
+        self._plan = plan
+        self.counts = counts
+        self.rqs_clock = clock            # float64 [completed, 2] (start, finish)
+        self._samples = samples           # uint32 [n_series, ticks] raw words or None
+        self.latencies: np.ndarray | None = None
+        self.latency_stats: dict[str, float] | None = None
+        self.throughput_series: Series | None = None
+        self.sampled_metrics: dict[str, dict[str, list[float]]] | None = None
+
+    # ---- counters -------------------------------------------------------------
+    @property
+    def total_generated(self) -> int:
+        return int(self.counts[_abi.CNT_GENERATED])
+
+    @property
+    def total_completed(self) -> int:
+        return int(self.counts[_abi.CNT_COMPLETED])
+
+    @property
+    def total_dropped(self) -> int:
+        return int(self.counts[_abi.CNT_DROPPED])
+
+    @property
+    def request_events(self) -> int:
+        return int(self.counts[_abi.CNT_EVENTS])
+
+    @property
+    def flags(self) -> int:
+        return int(self.counts[_abi.CNT_FLAGS])
+
+    # ---- analyzer.py:75-142 -----------------------------------------------------
+    def process_all_metrics(self) -> None:
+        if self.latency_stats is None and len(self.rqs_clock):
+            self._process_event_metrics()
+        if self.sampled_metrics is None:
+            self._extract_sampled_metrics()
+
+    def _process_event_metrics(self) -> None:
+        start, finish = self.rqs_clock[:, 0], self.rqs_clock[:, 1]
+        arr = finish - start
+        self.latencies = arr
+        if arr.size:
+            self.latency_stats = {
+                "total_requests": float(arr.size),
+                "mean": float(np.mean(arr)),
+                "median": float(np.median(arr)),
+                "std_dev": float(np.std(arr)),
+                "p95": float(np.percentile(arr, 95)),
+                "p99": float(np.percentile(arr, 99)),
+                "min": float(np.min(arr)),
+                "max": float(np.max(arr)),
+            }
+        else:
+            self.latency_stats = {}
+        self.throughput_series = self._throughput(self._WINDOW_SIZE_S)
+
+    def _throughput(self, window_s: float) -> Series:
+        """Buckets (k-1, k]*window counting ``finish <= k*window`` (analyzer.py:107-125)."""
+        completion = np.sort(self.rqs_clock[:, 1])
+        end_time = self._plan.total_time
+        timestamps: list[float] = []
+        current_end = float(window_s)
+        while current_end <= end_time:  # same float accumulation as the reference
+            timestamps.append(current_end)
+            current_end += float(window_s)
+        edges = np.searchsorted(completion, np.asarray(timestamps), side="right")
+        counts = np.diff(np.concatenate([[0], edges]))
+        return timestamps, [float(c) / float(window_s) for c in counts]
+
+    def _extract_sampled_metrics(self) -> None:
+        metrics: dict[str, dict[str, list[float]]] = defaultdict(dict)
+        plan, s = self._plan, self._samples
+        enabled = set(plan.payload["sim_settings"]["enabled_sample_metrics"])
+        servers_sampled = {"ready_queue_len", "event_loop_io_sleep", "ram_in_use"} <= enabled
+        E = plan.n_edges
+        for v, sid in enumerate(plan.server_ids):
+            rows = {
+                "ready_queue_len": (E + 3 * v, False),
+                "event_loop_io_sleep": (E + 3 * v + 1, False),
+                "ram_in_use": (E + 3 * v + 2, True),
+            }
+            for name, (row, is_float) in rows.items():
+                if name not in enabled:
+                    continue
+                if s is None or not servers_sampled:
+                    metrics[name][sid] = []
+                elif is_float:
+                    metrics[name][sid] = s[row].view(np.float32).astype(np.float64).tolist()
+                else:
+                    metrics[name][sid] = s[row].view(np.int32).tolist()
+        if "edge_concurrent_connection" in enabled:
+            for e, eid in enumerate(plan.edge_ids):
+                metrics["edge_concurrent_connection"][eid] = [] if s is None else s[e].view(np.int32).tolist()
+        self.sampled_metrics = metrics
+
+    # ---- analyzer.py:147-244 (public accessors) -----------------------------------
+    def list_server_ids(self) -> list[str]:
+        return list(self._plan.server_ids)
+
+    def get_latency_stats(self) -> dict[str, float]:
+        self.process_all_metrics()
+        return self.latency_stats or {}
+
+    def format_latency_stats(self) -> str:
+        stats = self.get_latency_stats()
+        if not stats:
+            return "Latency stats: (empty)"
+        lines = ["════════ LATENCY STATS ════════"]
+        lines.extend(f"{k.upper():<20} = {stats[k]:.6f}" for k in LATENCY_KEYS if k in stats)
+        return "\n".join(lines)
+
+    def get_throughput_series(self, window_s: float | None = None) -> Series:
+        self.process_all_metrics()
+        if window_s is None or window_s == self._WINDOW_SIZE_S:
+            return self.throughput_series or ([], [])
+        return self._throughput(float(window_s))
+
+    def get_sampled_metrics(self) -> dict[str, dict[str, list[float]]]:
+        self.process_all_metrics()
+        assert self.sampled_metrics is not None
+        return self.sampled_metrics
+
+    def get_metric_map(self, key: Any) -> dict[str, list[float]]:
+        self.process_all_metrics()
+        assert self.sampled_metrics is not None
+        name = getattr(key, "value", key)
+        return self.sampled_metrics.get(name, {}) or {}
+
+    def get_series(self, key: Any, entity_id: str) -> Series:
+        vals = self.get_metric_map(key).get(entity_id, [])
+        times = (np.arange(len(vals)) * self._plan.sample_period).tolist()
+        return times, vals
+
+    # ---- bridge to the reference's own analyzer / plots ----------------------------
+    def to_reference_analyzer(self) -> Any:
+        """Hydrate the reference's ``ResultsAnalyzer`` via duck-typed shims (needs `asyncflow`).
+
+        Same trick as the reference's tests/unit/metrics/test_analyzer.py:34-95.
+        """
+        from types import SimpleNamespace
+
+        from asyncflow.config.constants import SampledMetricName  # type: ignore[import-not-found]
+        from asyncflow.metrics.analyzer import ResultsAnalyzer  # type: ignore[import-not-found]
+
+        sm = self.get_sampled_metrics()
+        client = SimpleNamespace(rqs_clock=[SimpleNamespace(start=float(a), finish=float(b)) for a, b in self.rqs_clock])
+        servers = [
+            SimpleNamespace(
+                server_config=SimpleNamespace(id=sid),
+                enabled_metrics={SampledMetricName(k): v[sid] for k, v in sm.items() if sid in v},
+            )
+            for sid in self._plan.server_ids
+        ]
+        edges = [
+            SimpleNamespace(
+                edge_config=SimpleNamespace(id=eid),
+                enabled_metrics={SampledMetricName(k): v[eid] for k, v in sm.items() if eid in v},
+            )
+            for eid in self._plan.edge_ids
+        ]
+        settings = SimpleNamespace(
+            total_simulation_time=int(self._plan.total_time), sample_period_s=self._plan.sample_period
+        )
+        return ResultsAnalyzer(client=client, servers=servers, edges=edges, settings=settings)
+
+
+class BatchedResults:
+    """All scenarios of a sweep; device-resident until a scenario is read."""
+
+    def __init__(self, plan: DevicePlan, seeds: np.ndarray, counts: Any, clock: Any, samples: Any,
+                 stats: _abi.AfStats, wall_s: float, overrides: dict[str, np.ndarray] | None = None) -> None:
+        self.plan = plan
+        self.seeds = seeds
+        self._counts_t, self._clock_t, self._samples_t = counts, clock, samples
+        self.counts = counts.cpu().numpy().view(np.uint32)
+        self.kernel_ms = float(stats.kernel_ms)
+        self.engine_stats = stats
+        self.wall_s = wall_s
+        self.overrides = overrides or {}
+
+    def __len__(self) -> int:
+        return int(self.counts.shape[0])
+
+    @property
+    def flags(self) -> np.ndarray:
+        return self.counts[:, _abi.CNT_FLAGS]
+
+    @property
+    def request_events(self) -> np.ndarray:
+        return self.counts[:, _abi.CNT_EVENTS].astype(np.int64)
+
+    def raise_on_overflow(self) -> None:
+        bad = np.nonzero(self.flags & _abi.FATAL_FLAGS)[0]
+        if len(bad):
+            f = int(np.bitwise_or.reduce(self.flags[bad]))
+            why = "; ".join(v for k, v in _abi.FLAG_NAMES.items() if f & k & _abi.FATAL_FLAGS)
+            msg = f"{len(bad)} scenario(s) overflowed an engine capacity (first: #{int(bad[0])}): {why}"
+            raise OverflowError(msg)
+
+    def __getitem__(self, i: int) -> ScenarioResults:
+        i = int(i)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        counts = self.counts[i]
+        n = min(int(counts[_abi.CNT_COMPLETED]), int(self._clock_t.shape[1])) if self._clock_t is not None else 0
+        clock = self._clock_t[i, :n].cpu().numpy() if self._clock_t is not None else np.zeros((0, 2))
+        samples = None
+        if self._samples_t is not None:
+            k = min(int(counts[_abi.CNT_TICKS]), int(self._samples_t.shape[2]))
+            samples = self._samples_t[i, :, :k].cpu().numpy().view(np.uint32)
+        return ScenarioResults(self.plan, counts, clock, samples)
+
+    def __iter__(self) -> Iterator[ScenarioResults]:
+        return (self[i] for i in range(len(self)))
+
+    # ---- device-side reduction of every scenario at once ---------------------------
+    def summary(self, rps: bool = True) -> dict[str, Any]:
+        """Per-scenario latency stats (+ 1-s RPS series) computed on the GPU.
+
+        Returns torch tensors on the run's device: ``stats`` float64 [n, 8] in
+        LATENCY_KEYS order and ``rps`` float32 [n, T].  Percentiles use numpy's
+        linear-interpolation rule; sums are not pairwise like numpy's, so values
+        agree with ``ScenarioResults`` to ~1e-12 relative, not bit for bit.
+        """
+        import torch
+
+        if self._clock_t is None:
+            msg = "run(collect_clock=False) kept no rqs_clock"
+            raise RuntimeError(msg)
+        clock = self._clock_t
+        n, cap = int(clock.shape[0]), int(clock.shape[1])
+        dev = clock.device
+        cnt = torch.as_tensor(self.counts[:, _abi.CNT_COMPLETED].astype(np.int64), device=dev).clamp(max=cap)
+        idx = torch.arange(cap, device=dev).unsqueeze(0)
+        valid = idx < cnt.unsqueeze(1)
+        lat = torch.where(valid, clock[:, :, 1] - clock[:, :, 0], torch.full((), float("inf"), dtype=clock.dtype, device=dev))
+        lat_sorted, _ = torch.sort(lat, dim=1)
+        cf = cnt.clamp(min=1).to(torch.float64)
+        zero = torch.zeros((), dtype=torch.float64, device=dev)
+        lat0 = torch.where(valid, lat, zero)
+        mean = lat0.sum(dim=1) / cf
+        var = (torch.where(valid, (lat - mean.unsqueeze(1)) ** 2, zero)).sum(dim=1) / cf
+
+        def pct(q: float) -> Any:
+            pos = (cnt.clamp(min=1) - 1).to(torch.float64) * (q / 100.0)
+            lo = pos.floor().long()
+            hi = (lo + 1).clamp(max=(cnt.clamp(min=1) - 1))
+            frac = pos - lo.to(torch.float64)
+            a = lat_sorted.gather(1, lo.unsqueeze(1)).squeeze(1)
+            b = lat_sorted.gather(1, hi.unsqueeze(1)).squeeze(1)
+            return a + (b - a) * frac
+
+        stats = torch.stack(
+            [cnt.to(torch.float64), mean, pct(50.0), var.sqrt(), pct(95.0), pct(99.0), lat_sorted[:, 0],
+             lat_sorted.gather(1, (cnt.clamp(min=1) - 1).unsqueeze(1)).squeeze(1)], dim=1)
+        stats = torch.where((cnt > 0).unsqueeze(1), stats, torch.full_like(stats, float("nan")))
+        out: dict[str, Any] = {"stats": stats, "keys": LATENCY_KEYS}
+        if rps:
+            T = int(self.plan.total_time)
+            fin = torch.where(valid, clock[:, :, 1], torch.full((), float("inf"), dtype=clock.dtype, device=dev))
+            bucket = torch.ceil(fin).clamp(min=1.0)  # finish in (k-1, k] -> bucket k
+            bucket = torch.where(valid & (bucket <= T), bucket, torch.zeros((), dtype=clock.dtype, device=dev)).long()
+            hist = torch.zeros((n, T + 1), dtype=torch.float32, device=dev)
+            hist.scatter_add_(1, bucket, torch.ones_like(bucket, dtype=torch.float32))
+            out["rps"] = hist[:, 1:]
+        return out

@@ -1,0 +1,205 @@
+"""``SimulationRunner``: host-side mirror of the reference's entry point.
+
+Reference seam (the ONLY boundary this path has):
+
+    SimulationRunner(env=simpy.Environment(), simulation_input=payload).run() -> ResultsAnalyzer
+    SimulationRunner.from_yaml(env=..., yaml_path=...)
+    (/root/reference/src/asyncflow/runtime/simulation_runner.py:52-57, 349-398)
+
+Same constructor keywords, same ``run()`` / ``from_yaml`` names.  Differences,
+all additive: ``env`` is accepted and ignored (there is no SimPy environment:
+the HIP kernel owns the clock); ``replicas`` / ``seeds`` / ``sweep`` describe
+the batch; ``run()`` returns :class:`BatchedResults`, whose items expose the
+reference analyzer's accessors.  With the defaults (1 replica) ``run()`` returns
+a single :class:`ScenarioResults`, i.e. a drop-in for the reference call.
+"""
+
+from __future__ import annotations
+
+import re
+import time
+import warnings
+from pathlib import Path
+from typing import Any, Mapping, Sequence
+
+import numpy as np
+
+from . import _abi
+from .engine import Engine
+from .payload import load_yaml, normalize_payload
+from .plan import DevicePlan, estimate_capacities, lower
+from .results import BatchedResults, ScenarioResults
+
+DEFAULT_SEED_BASE = 0x5EED0000  # BASELINE config 2: scenario i uses Philox key 0x5EED0000 + i
+
+_EDGE_RE = re.compile(r"^topology_graph\.edges\[(?P<id>[^\]]+)\]\.(?P<f>latency\.mean|latency\.variance|dropout_rate)$")
+_STEP_RE = re.compile(
+    r"^topology_graph\.nodes\.servers\[(?P<sid>[^\]]+)\]\.endpoints\[(?P<ep>\d+)\]\.steps\[(?P<k>\d+)\]\.(cpu_time|io_waiting_time)$"
+)
+
+
+def resolve_sweep(plan: DevicePlan, sweep: Mapping[str, Any] | None, n: int) -> list[tuple[int, int, np.ndarray, str]]:
+    """Map YAML-style paths to ``af_override_t`` columns.
+
+    Accepted keys (values: one float per scenario):
+      rqs_input.avg_active_users.mean | .variance
+      rqs_input.avg_request_per_minute_per_user.mean
+      topology_graph.edges[<edge id>|*].latency.mean | .latency.variance | .dropout_rate
+      topology_graph.nodes.servers[<id>].endpoints[<j>].steps[<k>].cpu_time | .io_waiting_time
+    """
+    out: list[tuple[int, int, np.ndarray, str]] = []
+    for key, values in (sweep or {}).items():
+        col = np.ascontiguousarray(np.broadcast_to(np.asarray(values, dtype=np.float64), (n,)))
+        if key == "rqs_input.avg_active_users.mean":
+            out.append((_abi.PARAM_CODES["gen_users_mean"], 0, col, key))
+        elif key == "rqs_input.avg_active_users.variance":
+            out.append((_abi.PARAM_CODES["gen_users_sigma"], 0, col, key))
+        elif key == "rqs_input.avg_request_per_minute_per_user.mean":
+            out.append((_abi.PARAM_CODES["gen_rpm_mean"], 0, col, key))
+        elif m := _EDGE_RE.match(key):
+            code = {"latency.mean": "edge_mean", "latency.variance": "edge_sigma", "dropout_rate": "edge_dropout"}[m["f"]]
+            ids = plan.edge_ids if m["id"] == "*" else [m["id"]]
+            for eid in ids:
+                if eid not in plan.edge_ids:
+                    msg = f"sweep key {key!r}: unknown edge id {eid!r}"
+                    raise ValueError(msg)
+                out.append((_abi.PARAM_CODES[code], plan.edge_ids.index(eid), col, key))
+            if code == "edge_mean" and np.any(col <= 0):
+                msg = f"sweep key {key!r}: edge latency mean must be positive"  # edges.py:79-81
+                raise ValueError(msg)
+        elif m := _STEP_RE.match(key):
+            if m["sid"] not in plan.server_ids:
+                msg = f"sweep key {key!r}: unknown server id"
+                raise ValueError(msg)
+            idx = plan.step_index.get((plan.server_ids.index(m["sid"]), int(m["ep"]), int(m["k"])), -1)
+            if idx < 0:
+                msg = f"sweep key {key!r}: not a CPU or I/O step"
+                raise ValueError(msg)
+            out.append((_abi.PARAM_CODES["step_time"], idx, col, key))
+        else:
+            msg = f"unsupported sweep key {key!r}"
+            raise ValueError(msg)
+    return out
+
+
+class SimulationRunner:
+    """Build -> lower -> run the batched HIP engine -> results."""
+
+    def __init__(
+        self,
+        *,
+        env: Any = None,
+        simulation_input: Any,
+        replicas: int = 1,
+        seeds: Sequence[int] | np.ndarray | None = None,
+        sweep: Mapping[str, Any] | None = None,
+        device: int | None = None,
+        request_capacity: int | None = None,
+        fifo_capacity: int | None = None,
+        clock_capacity: int | None = None,
+        collect_clock: bool = True,
+        collect_samples: bool = True,
+        force_global_state: bool = False,
+        auto_grow: bool = True,
+    ) -> None:
+        self.env = env  # accepted for signature compatibility; unused
+        self.simulation_input = simulation_input
+        self.payload = normalize_payload(simulation_input)
+        self.plan: DevicePlan = lower(self.payload)
+        if seeds is not None:
+            self.seeds = np.asarray(seeds, dtype=np.uint64).reshape(-1)
+        else:
+            self.seeds = (DEFAULT_SEED_BASE + np.arange(int(replicas), dtype=np.uint64)).astype(np.uint64)
+        if self.seeds.size == 0:
+            msg = "at least one scenario is required"
+            raise ValueError(msg)
+        self.sweep = dict(sweep or {})
+        self.device = device
+        self.request_capacity = request_capacity
+        self.fifo_capacity = fifo_capacity
+        self.clock_capacity = clock_capacity
+        self.collect_clock = collect_clock
+        self.collect_samples = collect_samples
+        self.force_global_state = force_global_state
+        self.auto_grow = auto_grow
+        self._single = seeds is None and int(replicas) == 1 and not self.sweep
+        self._engine: Engine | None = None
+
+    # ------------------------------------------------------------------ #
+    def _capacities(self, overrides: list[tuple[int, int, np.ndarray, str]]) -> tuple[int, int, int]:
+        users_max, rpm_max, lat_scale = None, None, 1.0
+        for code, _idx, col, _ in overrides:
+            if code == _abi.PARAM_CODES["gen_users_mean"]:
+                users_max = float(col.max())
+            elif code == _abi.PARAM_CODES["gen_rpm_mean"]:
+                rpm_max = float(col.max())
+            elif code == _abi.PARAM_CODES["edge_mean"]:
+                base = float(self.plan.edge_mean[_idx]) or 1.0
+                lat_scale = max(lat_scale, float(col.max()) / base)
+        cap, fifo = estimate_capacities(self.plan, users_max, lat_scale, rpm_max)
+        cap = int(self.request_capacity or min(cap, 65535))
+        fifo = int(self.fifo_capacity or min(fifo, cap))
+        clock_cap = int(self.clock_capacity or self.plan.clock_capacity(users_max, rpm_max))
+        return cap, fifo, clock_cap
+
+    def run(self) -> BatchedResults | ScenarioResults:
+        """Lower once, launch the HIP kernel over every scenario, return results."""
+        import torch
+
+        if not torch.cuda.is_available():
+            from .engine import EngineUnavailableError
+
+            msg = "no GPU visible (torch.cuda.is_available() is False): asyncflow_amd has no CPU fallback"
+            raise EngineUnavailableError(msg)
+        device = torch.cuda.current_device() if self.device is None else int(self.device)
+        n = int(self.seeds.size)
+        overrides = resolve_sweep(self.plan, self.sweep, n)
+        cap, fifo, clock_cap = self._capacities(overrides)
+        dev = torch.device("cuda", device)
+        ticks = max(self.plan.tick_count, 1)
+        t0 = time.perf_counter()
+        for attempt in range(4):
+            eng = Engine(self.plan, device, request_capacity=cap, fifo_capacity=fifo,
+                         force_global_state=self.force_global_state)
+            self._engine = eng
+            counts = torch.zeros((n, _abi.CNT_SLOTS), dtype=torch.int32, device=dev)
+            clock = torch.empty((n, clock_cap, 2), dtype=torch.float64, device=dev) if self.collect_clock else None
+            samples = (
+                torch.zeros((n, self.plan.n_series, ticks), dtype=torch.int32, device=dev)
+                if self.collect_samples else None
+            )
+            torch.cuda.synchronize(dev)
+            stats = eng.run(
+                self.seeds,
+                [(c, i, v) for c, i, v, _ in overrides],
+                clock_ptr=clock.data_ptr() if clock is not None else 0,
+                clock_capacity=clock_cap,
+                samples_ptr=samples.data_ptr() if samples is not None else 0,
+                tick_capacity=ticks,
+                counts_ptr=counts.data_ptr(),
+            )
+            eng.close()
+            res = BatchedResults(self.plan, self.seeds, counts, clock, samples, stats,
+                                 time.perf_counter() - t0, {k: v for _, _, v, k in overrides})
+            over = int(np.bitwise_or.reduce(res.flags)) & _abi.FATAL_FLAGS
+            if not over or attempt == 3 or not self.auto_grow:
+                break
+            # capacities are estimates (Little's law); overflow is flagged by the
+            # kernel, never silent -> grow the overflowing pool and run again.
+            if over & (_abi.FLAG_POOL_OVERFLOW | _abi.FLAG_FIFO_OVERFLOW):
+                if cap >= 65535 and fifo >= 65536:
+                    break
+                cap, fifo = min(65535, cap * 4), min(65536, fifo * 4)
+            if over & _abi.FLAG_CLOCK_OVERFLOW:
+                clock_cap *= 2
+            warnings.warn(
+                f"engine capacity overflow (flags={over:#x}); retrying with request_capacity={cap}, "
+                f"fifo_capacity={fifo}, clock_capacity={clock_cap}", RuntimeWarning, stacklevel=2)
+            del counts, clock, samples, res
+        res.raise_on_overflow()
+        return res[0] if self._single else res
+
+    @classmethod
+    def from_yaml(cls, *, env: Any = None, yaml_path: str | Path, **kwargs: Any) -> "SimulationRunner":
+        """``SimulationRunner.from_yaml`` (simulation_runner.py:381-398)."""
+        return cls(env=env, simulation_input=load_yaml(yaml_path), **kwargs)

@@ -1,0 +1,284 @@
+"""Benchmark of the hot path: batched `env.run(until=T)` on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--replicas R]
+
+Workload (BASELINE.json configs[1], the one the metric is quoted on): the
+2-server + load-balancer topology of examples/yaml_input/data/two_servers_lb.yml
+(400 users x 20 rpm, T = 600 s, 0.05 s sampling), 10 000 seed replicas per GPU,
+scenario i uses Philox key 0x5EED0000 + i, full-fidelity outputs (every
+(start, finish) pair and all 12 sampled series written to HBM).
+
+A "step" is ONE pass of the hot path over that batch: af_engine_run() = seed
+upload + the HIP next-event kernel + stream sync, inputs/outputs resident in HBM.
+K steps are timed between barrier + torch.cuda.synchronize() on both sides, MAX
+over ranks; rank 0 prints ONE JSON line.  value = request-events simulated by all
+ranks / that time (request-event = one timed state transition of a request:
+arrival, edge delivery, CPU-step end, I/O-step end).
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), scenarios
+sharded by rank with NO data-path collective (weak scaling: R replicas per GPU);
+ONE all_gather of the per-scenario summaries over xGMI after the timed region
+(reported as gather_ms).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured-achievable
+HBM_ACHIEVABLE_GBS = 6290.0
+SEED_BASE = 0x5EED0000
+
+
+def lb2_payload(horizon: int = 600) -> dict:
+    from oracle.scenarios import lb_two_servers  # pure dict builder (the YAML's values), no oracle code
+
+    return lb_two_servers(horizon=horizon)
+
+
+def algorithmic_bytes(counts: np.ndarray, n_series: int, plan_bytes: int) -> float:
+    """B = 80 N_events + 16 N_completed + 4 n_series N_ticks + plan_bytes, per scenario."""
+    ev = counts[:, 3].astype(np.float64).sum()
+    comp = counts[:, 1].astype(np.float64).sum()
+    ticks = counts[:, 4].astype(np.float64).sum()
+    return 80.0 * ev + 16.0 * comp + 4.0 * n_series * ticks + float(plan_bytes) * counts.shape[0]
+
+
+# --------------------------------------------------------------------------- #
+# CPU baseline: the SimPy-faithful C restatement (oracle/des_oracle.c), "port"  #
+# --------------------------------------------------------------------------- #
+def _cpu_worker(args: tuple[dict, list[int]]) -> tuple[int, int, float]:
+    payload, seeds = args
+    from asyncflow_amd.plan import lower
+    from oracle import oracle_lib as ol
+
+    plan = lower(payload)
+    ol.simulate(plan, 1, want_clock=True, want_samples=True)  # warm
+    t0 = time.perf_counter()
+    ev = heap = 0
+    for s in seeds:
+        r = ol.simulate(plan, s)
+        ev += r.events
+        heap += r.heap_events
+    return ev, heap, time.perf_counter() - t0
+
+
+def cpu_baseline(payload: dict, budget_s: float = 12.0) -> dict:
+    """Time the oracle on the host cores over a bounded sample of the same workload."""
+    import multiprocessing as mp
+
+    from asyncflow_amd.plan import lower
+    from oracle import oracle_lib as ol
+
+    ol.build()
+    plan = lower(payload)
+    t0 = time.perf_counter()
+    ol.simulate(plan, SEED_BASE)
+    one = max(time.perf_counter() - t0, 1e-3)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    per_core = max(2, min(64, int(budget_s / one)))
+    jobs = [(payload, [SEED_BASE + c * per_core + k for k in range(per_core)]) for c in range(cores)]
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(cores) as pool:
+        parts = pool.map(_cpu_worker, jobs)
+    wall = time.perf_counter() - t0
+    ev = sum(p[0] for p in parts)
+    heap = sum(p[1] for p in parts)
+    busy = max(p[2] for p in parts)
+    return {
+        "value": ev / busy,
+        "unit": "request-events/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{cores * per_core} LB-2 replicas (T=600 s) of the same workload, {per_core} per core, "
+                  f"C restatement of the reference actors + SimPy heap (oracle/des_oracle.c), "
+                  f"{heap / max(ev, 1):.1f} SimPy heap events per request-event, wall {wall:.1f} s",
+        "replicas_per_s": cores * per_core / busy,
+        "python_reference_events_per_s_per_core": 4.5e4,  # measured in the build container
+    }
+
+
+# --------------------------------------------------------------------------- #
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--replicas", type=int, default=10_000, help="scenarios per GPU")
+    ap.add_argument("--horizon", type=int, default=600)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-series", action="store_true", help="do not store the sampled series")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    payload = lb2_payload(args.horizon)
+
+    base = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        base = cpu_baseline(payload)  # before CUDA is initialised (fork-safe)
+
+    import torch
+
+    from asyncflow_amd import _abi
+    from asyncflow_amd.engine import Engine
+    from asyncflow_amd.plan import estimate_capacities, lower
+
+    if not torch.cuda.is_available():
+        print("bench.py needs an MI355X: the engine has no CPU fallback", file=sys.stderr)
+        return 2
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # type: ignore[no-redef]
+
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    plan = lower(payload)
+    n = args.replicas
+    seeds = (SEED_BASE + rank * n + np.arange(n, dtype=np.uint64)).astype(np.uint64)
+    cap, fifo = estimate_capacities(plan)
+    clock_cap = plan.clock_capacity()
+    ticks = max(plan.tick_count, 1)
+    eng = Engine(plan, local_rank, request_capacity=cap, fifo_capacity=fifo)
+    counts = torch.zeros((n, _abi.CNT_SLOTS), dtype=torch.int32, device=dev)
+    clock = torch.empty((n, clock_cap, 2), dtype=torch.float64, device=dev)
+    samples = None if args.no_series else torch.zeros((n, plan.n_series, ticks), dtype=torch.int32, device=dev)
+
+    def step():
+        return eng.run(seeds, [], clock_ptr=clock.data_ptr(), clock_capacity=clock_cap,
+                       samples_ptr=samples.data_ptr() if samples is not None else 0, tick_capacity=ticks,
+                       counts_ptr=counts.data_ptr())
+
+    def barrier() -> None:
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for _ in range(args.steps):
+        st = step()
+        kernel_ms.append(st.kernel_ms)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    c = counts.cpu().numpy().view(np.uint32)
+    flags = int(np.bitwise_or.reduce(c[:, _abi.CNT_FLAGS]))
+    if flags & _abi.FATAL_FLAGS:
+        print(f"capacity overflow flags={flags:#x}: result invalid", file=sys.stderr)
+        return 3
+    events_rank = float(c[:, _abi.CNT_EVENTS].astype(np.float64).sum())
+
+    # ---- the single collective: gather per-scenario summaries (after the timed region)
+    from asyncflow_amd.results import BatchedResults
+
+    t1 = time.perf_counter()
+    res = BatchedResults(plan, seeds, counts, clock, samples, st, elapsed)
+    summ = res.summary()
+    torch.cuda.synchronize(dev)
+    summary_ms = (time.perf_counter() - t1) * 1e3
+    gather_ms = 0.0
+    stats_all = summ["stats"]
+    if dist is not None:
+        t2 = time.perf_counter()
+        packed = torch.cat([summ["stats"].to(torch.float32), summ["rps"]], dim=1).contiguous()
+        out = torch.empty((world * n, packed.shape[1]), dtype=packed.dtype, device=dev)
+        dist.all_gather_into_tensor(out, packed)
+        torch.cuda.synchronize(dev)
+        gather_ms = (time.perf_counter() - t2) * 1e3
+        stats_all = out[:, :8]
+        tot = torch.tensor([elapsed, events_rank], dtype=torch.float64, device=dev)
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tot.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed = float(mx[0])
+        events_total = float(sm[1])
+    else:
+        events_total = events_rank
+
+    if rank == 0:
+        total_events = events_total * args.steps
+        k_ms = float(np.mean(kernel_ms))
+        alg_bytes = algorithmic_bytes(c, plan.n_series, int(st.lds_bytes_per_wave - 64 * st.state_bytes_per_scenario)
+                                      if st.state_in_lds else 0)
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        sa = stats_all.double().cpu().numpy()
+        line = {
+            "metric": "simulated request-events/sec (2-server LB scenario, 10k replicas/GPU)",
+            "value": total_events / elapsed,
+            "unit": "request-events/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"two_servers_lb.yml (2 servers + LB, 400 users x 20 rpm, T={args.horizon} s, dt=0.05 s), "
+                            f"{n} seed replicas per GPU, seeds 0x5EED0000+i, full outputs"
+                            + (" without sampled series" if args.no_series else ""),
+                "scenarios_per_gpu": n,
+                "parallelism": f"scenario-sharded x{world}, no data-path collective",
+                "state": "LDS" if st.state_in_lds else "HBM",
+                "request_capacity": int(st.request_capacity),
+                "lds_bytes_per_wave": int(st.lds_bytes_per_wave),
+            },
+            "events_per_step": events_total,
+            "per_gpu_value": total_events / elapsed / world,
+            "sweep_wall_s_per_10k": elapsed / args.steps * (10_000 / n),
+            "kernel_ms": k_ms,
+            "summary_ms": summary_ms,
+            "gather_ms": gather_ms,
+            "p95_ms_mean": float(np.nanmean(sa[:, 4]) * 1e3),
+            "p50_ms_mean": float(np.nanmean(sa[:, 2]) * 1e3),
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "frac_of_achievable_6290": achieved / HBM_ACHIEVABLE_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "bytes_per_event": alg_bytes / max(events_rank, 1.0),
+                "kernel": "af_des_kernel",
+            },
+        }
+        if base is not None:
+            line["cpu_baseline"] = base
+            line["gpu_over_cpu_port_all_cores"] = (total_events / elapsed) / base["value"]
+        traffic = os.environ.get("AF_BENCH_TRAFFIC_BYTES")
+        if traffic:
+            line["roofline"]["traffic"] = float(traffic)
+        print(json.dumps(line))
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -1,0 +1,73 @@
+"""Build + load the TEST-ONLY host instantiation of the engine core (see hostcheck.cpp)."""
+
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+from asyncflow_amd import _abi
+from asyncflow_amd.plan import DevicePlan
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parent.parent
+LIB = HERE / "libaf_hostcheck.so"
+_lib = None
+
+
+def build(force: bool = False) -> Path:
+    srcs = [HERE / "hostcheck.cpp", ROOT / "asyncflow_amd/csrc/af_core.hpp", ROOT / "asyncflow_amd/csrc/af_math.hpp"]
+    newest = max(p.stat().st_mtime for p in srcs)
+    if force or not LIB.exists() or LIB.stat().st_mtime < newest:
+        subprocess.run(
+            ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+             "-Wall", "-o", str(LIB), str(srcs[0])],
+            check=True, capture_output=True, text=True,
+        )
+    return LIB
+
+
+def lib() -> C.CDLL:
+    global _lib  # noqa: PLW0603
+    if _lib is None:
+        build()
+        L = C.CDLL(str(LIB))
+        L.hc_simulate.argtypes = [
+            C.POINTER(_abi.AfPlan), C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+            C.POINTER(C.c_double), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double), C.c_uint32,
+            C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+        ]
+        L.hc_simulate.restype = C.c_int
+        L.hc_bytes_per_lane.argtypes = [C.c_uint32] * 7
+        L.hc_bytes_per_lane.restype = C.c_uint64
+        _lib = L
+    return _lib
+
+
+def simulate(plan: DevicePlan, seed: int, *, cap: int = 4096, fcap: int = 4096,
+             overrides: list[tuple[str, int, float]] | None = None, clock_capacity: int | None = None):
+    """Run one scenario through the engine core on the host. Returns (counts, clock, samples)."""
+    L = lib()
+    cplan = plan.as_ctypes()
+    ov = overrides or []
+    params = np.asarray([_abi.PARAM_CODES[o[0]] for o in ov], dtype=np.uint32)
+    idxs = np.asarray([o[1] for o in ov], dtype=np.uint32)
+    vals = np.asarray([o[2] for o in ov], dtype=np.float64)
+    ccap = int(clock_capacity if clock_capacity is not None else plan.clock_capacity())
+    clock = np.zeros((ccap, 2), dtype=np.float64)
+    ticks = max(plan.tick_count, 1)
+    samples = np.zeros((plan.n_series, ticks), dtype=np.uint32)
+    counts = np.zeros(_abi.CNT_SLOTS, dtype=np.uint32)
+    u32p, f64p = C.POINTER(C.c_uint32), C.POINTER(C.c_double)
+    rc = L.hc_simulate(
+        C.byref(cplan), C.c_uint64(seed), len(ov), params.ctypes.data_as(u32p), idxs.ctypes.data_as(u32p),
+        vals.ctypes.data_as(f64p), cap, fcap, ccap, clock.ctypes.data_as(f64p), ticks,
+        samples.ctypes.data_as(u32p), counts.ctypes.data_as(u32p),
+    )
+    if rc != 0:
+        msg = f"hc_simulate failed: {rc}"
+        raise RuntimeError(msg)
+    n = int(counts[_abi.CNT_COMPLETED])
+    return counts, clock[: min(n, ccap)].copy(), samples[:, : int(counts[_abi.CNT_TICKS])].copy()

@@ -1,0 +1,222 @@
+"""Parity tests proper: the HIP engine (through the C ABI) vs the oracle, on a real MI355X."""
+
+from __future__ import annotations
+
+import json
+import random
+
+import numpy as np
+import pytest
+
+from asyncflow_amd import _abi
+from asyncflow_amd.plan import lower
+from oracle import oracle_lib as ol
+from oracle.scenarios import fanout8, lb_two_servers, lb_with_events, overload, random_payload, single_server
+from tests.conftest import GOLDEN_DIR, golden_names
+
+pytestmark = pytest.mark.gpu
+
+
+def _runner(payload, **kw):
+    from asyncflow_amd.runner import SimulationRunner
+
+    return SimulationRunner(simulation_input=payload, **kw)
+
+
+def _assert_scenario(got, want):
+    assert np.array_equal(got.counts[:5].astype(np.uint64), want.counts[:5]), (got.counts, want.counts)
+    assert np.array_equal(got.rqs_clock.view(np.uint64), want.clock.view(np.uint64)), "rqs_clock differs"
+    assert np.array_equal(got._samples, want.samples), "sampled series differ"  # noqa: SLF001
+
+
+# ---------------------------------------------------------------- spec pinning
+def test_device_math_matches_oracle_bit_for_bit():
+    from asyncflow_amd.engine import probe_math
+
+    L = ol.lib()
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.random(20000), 1.0 - rng.random(2000) * 1e-9, np.exp(rng.uniform(-300, 300, 4000))])
+    assert np.array_equal(probe_math(1, x), np.array([L.orc_x_log(float(v)) for v in x]))
+    e = np.concatenate([rng.uniform(-30, 30, 20000), rng.uniform(-700, 700, 2000)])
+    assert np.array_equal(probe_math(2, e), np.array([L.orc_x_exp(float(v)) for v in e]))
+    p = np.concatenate([rng.random(20000), rng.random(2000) * 1e-12])
+    p = p[(p > 0) & (p < 1)]
+    assert np.array_equal(probe_math(3, p), np.array([L.orc_x_norminv(float(v)) for v in p]))
+    s = np.exp(rng.uniform(-50, 50, 20000))
+    assert np.array_equal(probe_math(4, s), np.sqrt(s))            # IEEE sqrt
+    a, b = rng.normal(size=20000), np.exp(rng.uniform(-20, 20, 20000))
+    assert np.array_equal(probe_math(5, a, b), a / b)              # IEEE division
+    idx = np.arange(5000, dtype=np.float64)
+    for stream, j in ((0, 0), (3, 1), (0x1001, 5)):
+        got = probe_math(0, idx, np.full_like(idx, stream * 65536 + j), seed=0x5EED0007)
+        want = np.array([L.orc_x_uniform(0x5EED0007, stream, int(i), j) for i in idx])
+        assert np.array_equal(got, want)
+    means = np.array([0.003, 0.7, 5.0, 16.0, 33.0, 400.0, 1000.0] * 50)
+    got = probe_math(6, means, np.arange(len(means), dtype=np.float64) + 7 * 65536, seed=11)
+    want = np.array([L.orc_x_poisson(float(m), 11, 7, i, 0) for i, m in enumerate(means)], dtype=np.float64)
+    assert np.array_equal(got, want)
+
+
+# ------------------------------------------------------------- golden fixtures
+@pytest.mark.parametrize("name", golden_names())
+def test_engine_reproduces_reference_fixtures(name):
+    fx = np.load(GOLDEN_DIR / f"{name}.npz", allow_pickle=False)
+    payload = json.loads(str(fx["payload_json"]))
+    seed = int(fx["seed"])
+    res = _runner(payload, seeds=[seed, seed + 1, seed]).run()
+    plan = lower(payload)
+    want = ol.simulate(plan, seed, atomic=True)
+    _assert_scenario(res[0], want)
+    _assert_scenario(res[2], want)                      # same seed -> same result, any lane
+    _assert_scenario(res[1], ol.simulate(plan, seed + 1, atomic=True))
+    if ol.simulate(plan, seed).ties == 0:               # tie-free: identical to the reference itself
+        got = res[0]
+        assert np.array_equal(got.rqs_clock, fx["clock"]) and np.array_equal(got._samples, fx["samples"])  # noqa: SLF001
+        assert (got.total_generated, got.total_completed, got.total_dropped) == (
+            int(fx["generated"]), int(fx["completed"]), int(fx["dropped"]))
+        stats = got.get_latency_stats()
+        keys = ("total_requests", "mean", "median", "std_dev", "p95", "p99", "min", "max")
+        assert [stats[k] for k in keys] == list(fx["latency_stats"])   # same numpy calls as the analyzer
+        assert got.get_throughput_series()[1] == list(fx["rps"])
+
+
+# --------------------------------------------------------------------- batches
+def test_lb2_batch_matches_oracle_everywhere_sampled():
+    payload = lb_two_servers(horizon=30)
+    seeds = 0x5EED0000 + np.arange(200, dtype=np.uint64)     # not a multiple of 64: ragged last wave
+    res = _runner(payload, seeds=seeds).run()
+    assert res.engine_stats.state_in_lds == 1 and res.engine_stats.waves == 4
+    plan = lower(payload)
+    for i in (0, 1, 63, 64, 127, 199):
+        _assert_scenario(res[i], ol.simulate(plan, int(seeds[i]), atomic=True))
+    want_counts = np.array([ol.simulate(plan, int(s), atomic=True, want_clock=False, want_samples=False).counts[:5] for s in seeds])
+    assert np.array_equal(res.counts[:, :5].astype(np.uint64), want_counts)
+
+
+def test_global_state_mode_is_bit_identical_to_lds_mode():
+    payload = lb_with_events(users=150, horizon=30, scale=0.05)
+    seeds = np.arange(70, dtype=np.uint64) + 5
+    a = _runner(payload, seeds=seeds).run()
+    b = _runner(payload, seeds=seeds, force_global_state=True).run()
+    assert a.engine_stats.state_in_lds == 1 and b.engine_stats.state_in_lds == 0
+    assert np.array_equal(a.counts, b.counts)
+    for i in (0, 69):
+        assert np.array_equal(a[i].rqs_clock, b[i].rqs_clock) and np.array_equal(a[i]._samples, b[i]._samples)  # noqa: SLF001
+
+
+def test_large_state_falls_back_to_hbm_and_still_matches():
+    payload = fanout8(horizon=20)                           # ~200 requests in flight: does not fit LDS
+    seeds = np.arange(64, dtype=np.uint64) + 11
+    res = _runner(payload, seeds=seeds).run()
+    assert res.engine_stats.state_in_lds == 0
+    plan = lower(payload)
+    for i in (0, 33):
+        _assert_scenario(res[i], ol.simulate(plan, int(seeds[i]), atomic=True))
+
+
+def test_parameter_sweep_columns():
+    payload = lb_two_servers(horizon=20)
+    n = 96
+    users = np.repeat([10.0, 200.0, 480.0], n // 3)
+    lat = np.tile([0.0005, 0.004, 0.02, 0.05], n // 4)
+    seeds = 0xC0F30000 + np.arange(n, dtype=np.uint64)
+    sweep = {"rqs_input.avg_active_users.mean": users, "topology_graph.edges[*].latency.mean": lat}
+    res = _runner(payload, seeds=seeds, sweep=sweep).run()
+    for i in (0, 17, 50, 95):
+        plan = lower(payload)
+        ol.apply_overrides(plan, {("gen_users_mean", 0): users[i], **{("edge_mean", e): lat[i] for e in range(6)}})
+        _assert_scenario(res[i], ol.simulate(plan, int(seeds[i]), atomic=True))
+    gen = res.counts[:, _abi.CNT_GENERATED].astype(np.float64)
+    assert gen[users == 480.0].mean() > 30 * gen[users == 10.0].mean()
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_fuzzed_payloads(case):
+    rng = random.Random(9000 + case)
+    payload = random_payload(rng, horizon=8)
+    seeds = np.arange(3, dtype=np.uint64) + 100 * case
+    res = _runner(payload, seeds=seeds).run()
+    plan = lower(payload)
+    for i in range(3):
+        _assert_scenario(res[i], ol.simulate(plan, int(seeds[i]), atomic=True))
+
+
+def test_exact_tie_scenarios_match_engine_semantics_and_are_flagged():
+    payload = overload(horizon=12)
+    res = _runner(payload, seeds=[5]).run()
+    plan = lower(payload)
+    _assert_scenario(res[0], ol.simulate(plan, 5, atomic=True))
+    assert res[0].flags & 32          # AF_FLAG_TIME_TIE: SimPy may interleave differently here
+    assert ol.simulate(plan, 5).ties > 0
+
+
+# ------------------------------------------------------------------ edge cases
+def test_overflow_is_reported_and_auto_grow_recovers():
+    payload = overload(horizon=8)
+    with pytest.raises(OverflowError):
+        _runner(payload, seeds=[1, 2], request_capacity=16, fifo_capacity=8, auto_grow=False).run()
+    with pytest.warns(RuntimeWarning):
+        res = _runner(payload, seeds=[1, 2], request_capacity=64, fifo_capacity=16).run()
+    _assert_scenario(res[1], ol.simulate(lower(payload), 2, atomic=True))
+
+
+def test_single_run_is_a_drop_in_for_the_reference_call(tmp_path):
+    import yaml
+
+    from asyncflow_amd.runner import SimulationRunner
+
+    path = tmp_path / "scenario.yml"
+    path.write_text(yaml.safe_dump(single_server(horizon=10)))
+    results = SimulationRunner.from_yaml(env=None, yaml_path=path).run()
+    stats = results.get_latency_stats()
+    assert set(stats) == {"total_requests", "mean", "median", "std_dev", "p95", "p99", "min", "max"}
+    ts, rps = results.get_throughput_series()
+    assert ts == [float(k) for k in range(1, 11)] and sum(rps) == stats["total_requests"]
+    sm = results.get_sampled_metrics()
+    assert set(sm) == {"ready_queue_len", "event_loop_io_sleep", "ram_in_use", "edge_concurrent_connection"}
+    t, v = results.get_series("ram_in_use", "srv-1")
+    assert len(t) == len(v) == lower(single_server(horizon=10)).tick_count
+    assert results.list_server_ids() == ["srv-1"]
+
+
+def test_zero_load_and_disabled_metrics():
+    payload = lb_two_servers(users=0, horizon=6)
+    payload["sim_settings"]["enabled_sample_metrics"] = ["edge_concurrent_connection"]
+    res = _runner(payload, seeds=[1, 2]).run()
+    assert res.counts[:, _abi.CNT_GENERATED].sum() == 0
+    assert res[0].get_latency_stats() == {}
+    assert set(res[0].get_sampled_metrics()) == {"edge_concurrent_connection"}
+
+
+# ------------------------------------------------- full-size, size-independent
+def test_full_horizon_properties_and_statistical_parity_with_simpy():
+    """BASELINE config 2 at the full 600 s horizon (fewer replicas than 10 000: the
+    bench runs those).  Invariants + the pooled p50/p95 of the stock numpy-seeded
+    SimPy reference (mean 24.04 ms, p50 23.18, p95 33.65, p99 39.68)."""
+    payload = lb_two_servers()
+    n = 256
+    res = _runner(payload, replicas=n).run()
+    c = res.counts.astype(np.int64)
+    gen, comp, drop, ev, ticks = (c[:, k] for k in range(5))
+    assert np.all(ticks == 11999)
+    assert np.all(comp + drop <= gen) and np.all(gen - comp - drop <= 64)     # the rest is in flight at T
+    assert abs(gen.mean() - 80000) < 4 * 1300 / np.sqrt(n) + 200
+    assert abs(ev.sum() / gen.sum() - 6.84) < 0.05                              # request-events per request
+    summ = res.summary()
+    stats = summ["stats"].cpu().numpy()
+    mean, p50, p95, p99 = stats[:, 1].mean(), stats[:, 2].mean(), stats[:, 4].mean(), stats[:, 5].mean()
+    assert abs(mean - 24.04e-3) / 24.04e-3 < 0.01
+    assert abs(p50 - 23.18e-3) / 23.18e-3 < 0.01
+    assert abs(p95 - 33.65e-3) / 33.65e-3 < 0.01
+    assert abs(p99 - 39.68e-3) / 39.68e-3 < 0.02
+    assert abs(summ["rps"].sum(dim=1).cpu().numpy() - comp).max() == 0
+    for i in (0, n - 1):
+        s = res[i]
+        clock = s.rqs_clock
+        assert np.all(np.diff(clock[:, 1]) >= 0) and np.all(clock[:, 1] >= clock[:, 0]) and clock[:, 1].max() < 600.0
+        host = s.get_latency_stats()
+        assert np.allclose([host[k] for k in ("mean", "median", "std_dev", "p95", "p99", "min", "max")],
+                           stats[i, 1:], rtol=1e-9, atol=0)
+        sm = s.get_sampled_metrics()
+        assert max(sm["ram_in_use"]["srv-1"]) <= 2048 and min(sm["edge_concurrent_connection"]["lb-srv1"]) >= 0
+        assert np.array_equal(clock, ol.simulate(lower(payload), int(res.seeds[i]), atomic=True).clock)

@@ -1,0 +1,110 @@
+"""CPU differential tests of the ENGINE CORE (asyncflow_amd/csrc/af_core.hpp).
+
+tests/hostcheck/ compiles the very state machine the HIP kernel runs for one
+lane with g++ (test-only, never shipped).  It must reproduce the oracle's
+engine-semantics restatement (oracle/des_oracle_atomic.c) bit for bit, and
+thereby -- on tie-free scenarios -- the reference itself (tests/golden/).
+"""
+
+from __future__ import annotations
+
+import json
+import random
+
+import numpy as np
+import pytest
+
+from asyncflow_amd import _abi
+from asyncflow_amd.plan import lower
+from oracle import oracle_lib as ol
+from oracle.scenarios import lb_two_servers, overload, random_payload, stress_mixed
+from tests.conftest import GOLDEN_DIR, golden_names
+from tests.hostcheck import build as hc
+
+
+def _assert_same(plan, seed, **kw):
+    a = ol.simulate(plan, seed, atomic=True)
+    counts, clock, samples = hc.simulate(plan, seed, **kw)
+    assert np.array_equal(a.counts[:5].astype(np.uint32), counts[:5])
+    assert int(counts[_abi.CNT_MARKS]) == int(a.counts[_abi.CNT_MARKS])
+    assert np.array_equal(a.clock.view(np.uint64), clock.view(np.uint64))
+    assert np.array_equal(a.samples, samples)
+    assert (int(counts[_abi.CNT_FLAGS]) & _abi.FATAL_FLAGS) == 0
+    return a, counts
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_core_matches_engine_semantics_oracle_on_golden_inputs(name):
+    fx = np.load(GOLDEN_DIR / f"{name}.npz", allow_pickle=False)
+    plan = lower(json.loads(str(fx["payload_json"])))
+    a, counts = _assert_same(plan, int(fx["seed"]))
+    assert int(counts[_abi.CNT_MAX_LIVE]) == int(a.counts[_abi.CNT_MAX_LIVE])
+    faithful = ol.simulate(plan, int(fx["seed"]))
+    if faithful.ties == 0:  # no exact timestamp ties -> identical to the reference
+        assert np.array_equal(a.clock, fx["clock"]) and np.array_equal(a.samples, fx["samples"])
+        assert (int(counts[_abi.CNT_FLAGS]) & 32) == 0
+
+
+@pytest.mark.parametrize("case", range(40))
+def test_core_matches_oracle_on_fuzzed_payloads(case):
+    rng = random.Random(4000 + case)
+    _assert_same(lower(random_payload(rng, horizon=8)), 77 + case)
+
+
+def test_atomic_semantics_equal_simpy_semantics_without_ties():
+    rng = random.Random(99)
+    checked = 0
+    for i in range(60):
+        plan = lower(random_payload(rng, horizon=6))
+        f = ol.simulate(plan, i)
+        if f.ties:
+            continue
+        a = ol.simulate(plan, i, atomic=True)
+        assert np.array_equal(f.clock, a.clock) and np.array_equal(f.samples, a.samples)
+        assert np.array_equal(f.counts[:5], a.counts[:5])
+        checked += 1
+    assert checked >= 5
+
+
+def test_overrides_are_applied_per_scenario():
+    payload = lb_two_servers(horizon=8)
+    plan = lower(payload)
+    ov = [("gen_users_mean", 0, 150.0), ("edge_mean", 2, 0.02), ("edge_dropout", 0, 0.2), ("step_time", 1, 0.03),
+          ("gen_rpm_mean", 0, 35.0), ("edge_sigma", 1, 0.5)]
+    ref_plan = lower(payload)
+    ol.apply_overrides(ref_plan, {(k, i): v for k, i, v in ov})
+    a = ol.simulate(ref_plan, 9, atomic=True)
+    counts, clock, samples = hc.simulate(plan, 9, overrides=ov)
+    assert np.array_equal(a.counts[:5].astype(np.uint32), counts[:5])
+    assert np.array_equal(a.clock, clock) and np.array_equal(a.samples, samples)
+    base = ol.simulate(plan, 9, atomic=True)
+    assert not np.array_equal(base.counts[:3], a.counts[:3])
+
+
+def test_capacity_overflow_is_flagged_never_silent():
+    plan = lower(overload(horizon=8))
+    counts, _, _ = hc.simulate(plan, 5, cap=16, fcap=8)
+    assert int(counts[_abi.CNT_FLAGS]) & (_abi.FLAG_POOL_OVERFLOW | _abi.FLAG_FIFO_OVERFLOW)
+    counts, _, _ = hc.simulate(lower(lb_two_servers(horizon=8)), 5, clock_capacity=10)
+    assert int(counts[_abi.CNT_FLAGS]) & _abi.FLAG_CLOCK_OVERFLOW
+
+
+def test_ram_starved_endpoint_blocks_like_the_reference():
+    """A request needing more RAM than ram_mb blocks that server's RAM queue for good (SURVEY trap 6)."""
+    payload = stress_mixed(30)
+    payload["topology_graph"]["nodes"]["servers"][2]["endpoints"][1]["steps"][1]["step_operation"]["necessary_ram"] = 5000
+    plan = lower(payload)
+    a = ol.simulate(plan, 1, atomic=True)
+    counts, clock, samples = hc.simulate(plan, 1)
+    assert int(a.counts[_abi.CNT_FLAGS]) & _abi.FLAG_RAM_STARVED
+    assert int(counts[_abi.CNT_FLAGS]) & _abi.FLAG_RAM_STARVED
+    assert np.array_equal(a.counts[:5].astype(np.uint32), counts[:5])
+    assert np.array_equal(a.clock, clock) and np.array_equal(a.samples, samples)
+
+
+def test_zero_users_produces_ticks_only():
+    payload = lb_two_servers(users=0.0, horizon=6)
+    plan = lower(payload)
+    counts, clock, samples = hc.simulate(plan, 3)
+    assert counts[_abi.CNT_GENERATED] == 0 and len(clock) == 0
+    assert counts[_abi.CNT_TICKS] == plan.tick_count and not samples.any()
