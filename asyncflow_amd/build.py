@@ -24,6 +24,10 @@ ARCH = "gfx950"
 HIPCC_FLAGS = (
     f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
     "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+    # Do NOT record a dependency on a particular libamdhip64: the HIP runtime is
+    # resolved at load time from the one already in the process (PyTorch bundles
+    # its own copy; two HIP/HSA runtimes in one process do not coexist reliably).
+    "-no-hip-rt",
 )
 
 

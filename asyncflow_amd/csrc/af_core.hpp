@@ -34,7 +34,7 @@
 #define AF_PLAN_AS __attribute__((address_space(3)))
 #else
 #define AF_CORE inline
-#define AF_CORE_NOINLINE inline
+#define AF_CORE_NOINLINE __attribute__((noinline))
 #define AF_PLAN_AS
 #endif
 
@@ -162,6 +162,25 @@ struct LaneOut {
 };
 
 constexpr double AF_INF = __builtin_huge_val();
+constexpr uint32_t NONE32 = 0xFFFFFFFFu;
+
+// Cold helpers kept out of line so that the hot loop stays small (the gfx950
+// instruction cache is shared by two CUs; the round body must fit in it).
+AF_CORE_NOINLINE double cold_variate(uint32_t dist, double mean, double sigma, double u1, uint64_t seed,
+                                     uint32_t stream, uint32_t index) {
+    return variate_from_u1(dist, mean, sigma, u1, seed, stream, index);
+}
+AF_CORE_NOINLINE double cold_users_draw(uint32_t dist, double mean, double sigma, uint64_t seed, uint32_t idx) {
+    if (dist == DIST_NORMAL) {  // gaussian_poisson.py:72-76 + common_helpers.py:32-33
+        const double v = mean + sigma * af_norminv(uniform_j(seed, STREAM_GENERATOR, idx, 0u));
+        return v > 0.0 ? v : 0.0;
+    }
+    return (double)af_poisson(mean, seed, STREAM_GENERATOR, idx, 0u);  // poisson_poisson.py:60
+}
+AF_CORE_NOINLINE uint32_t cold_endpoint_pick(uint64_t seed, uint32_t sv, uint32_t idx, uint32_t n_ep) {
+    const U4 r = draw_block(seed, stream_server(sv), idx, 0u);  // rng.integers(0, n_ep), server.py:101
+    return (uint32_t)(((uint64_t)r.x * n_ep) >> 32);
+}
 
 template <class Mem>
 struct Lane {
@@ -172,12 +191,25 @@ struct Lane {
     uint64_t seed;
 
     // register-resident scalars
-    double now, t_gen, g_now, g_wend, g_lam, t_tick;
+    double now, t_gen, g_now, g_wend, g_lam, t_tick, t_emark, t_smark;
     double users_mean, users_sigma, rpm;
     uint32_t g_draws, heap_n, seq, bump, free_top, live, max_live, lb_n, emark_i, smark_i;
     uint32_t n_gen, n_comp, n_drop, n_events, n_ticks, n_marks, flags, rounds;
-    int32_t pending_grant_sv;
-    bool hole;
+
+    // per-round work registers ("follow-ups" of the timed event being handled)
+    bool hole;            // the popped event left the heap root free
+    uint32_t pend_count;  // pushes buffered this pass (<= 2): the heap code exists once
+    double pend_t0, pend_t1;
+    uint32_t pend_slot0, pend_slot1;
+    bool gen_first;       // the generator's Initialize has not run yet
+    uint32_t fu_grant;  // waiter that received a CPU token (NONE32 = none)
+    uint32_t fu_grant_sv;
+    bool fu_send;       // a message has to be put on an edge
+    uint32_t send_slot, send_edge, send_hops;
+    bool fu_adv;        // a request (re)enters the endpoint step loop
+    uint32_t adv_slot, adv_sv, adv_ep, adv_step, adv_hops;
+    bool adv_core, adv_io;
+    int32_t fu_ram_sv;  // RAM was released on this server: serve its wait queue
 
     AF_CORE Lane(const PlanView& p, const Layout& l, Mem m, LaneOut o, uint64_t s) : P(p), L(l), M(m), O(o), seed(s) {}
 
@@ -236,24 +268,41 @@ struct Lane {
         M.st64(L.d_hk + pos, key);
         M.st32(L.w_hs + pos, slot);
     }
-    // schedule the (single) pending timed event of request `slot`
-    AF_CORE void push(double t, uint32_t slot) {
-        M.st32(L.w_rseq + slot, seq++);
-        if (hole) {  // the event popped this round left the root free: replace-top
+    // Apply the buffered pushes of this pass: the first one takes the root when the
+    // popped event left it free (replace-top), otherwise they are appended; if
+    // nothing replaced the popped event the root is removed.  ONE sift_down and ONE
+    // sift_up instance serve every case.
+    AF_CORE void heap_commit(bool final_pass) {
+        uint32_t k = 0u;
+        if (hole && (pend_count > 0u || final_pass)) {
+            double key;
+            uint32_t slot;
+            if (pend_count > 0u) {
+                key = pend_t0;
+                slot = pend_slot0;
+                k = 1u;
+            } else {
+                heap_n -= 1u;
+                key = M.ld64(L.d_hk + heap_n);
+                slot = M.ld32(L.w_hs + heap_n);
+            }
             hole = false;
-            sift_down(0u, t, slot, heap_n);
-        } else {
-            sift_up(heap_n++, t, slot);
+            if (heap_n > 0u && (k == 1u || heap_n > 0u)) sift_down(0u, key, slot, heap_n);
         }
+        for (; k < pend_count; ++k) sift_up(heap_n++, k == 0u ? pend_t0 : pend_t1, k == 0u ? pend_slot0 : pend_slot1);
+        pend_count = 0u;
     }
-    AF_CORE void remove_root() {
-        hole = false;
-        heap_n -= 1u;
-        if (heap_n > 0u) {
-            const double k = M.ld64(L.d_hk + heap_n);
-            const uint32_t s = M.ld32(L.w_hs + heap_n);
-            sift_down(0u, k, s, heap_n);
+    // schedule the (single) pending timed event of request `slot` (caller guarantees room)
+    AF_CORE void emit(double t, uint32_t slot) {
+        M.st32(L.w_rseq + slot, seq++);
+        if (pend_count == 0u) {
+            pend_t0 = t;
+            pend_slot0 = slot;
+        } else {
+            pend_t1 = t;
+            pend_slot1 = slot;
         }
+        pend_count += 1u;
     }
 
     // ---- request pool ----------------------------------------------------------
@@ -265,7 +314,7 @@ struct Lane {
             s = bump++;
         } else {
             flags |= FLAG_POOL_OVERFLOW;
-            return 0xFFFFFFFFu;
+            return NONE32;
         }
         live += 1u;
         if (live > max_live) max_live = live;
@@ -306,21 +355,14 @@ struct Lane {
         while (g_now < T) {
             if (g_now >= g_wend) {
                 g_wend = g_now + P.gen_window_s;
-                const uint32_t idx = g_draws++;
-                double users;
-                if (P.gen_users_dist == DIST_NORMAL) {
-                    const double v = users_mean + users_sigma * af_norminv(uniform_j(seed, STREAM_GENERATOR, idx, 0u));
-                    users = v > 0.0 ? v : 0.0;
-                } else {
-                    users = (double)af_poisson(users_mean, seed, STREAM_GENERATOR, idx, 0u);
-                }
-                g_lam = users * rps_per_user;
+                g_lam = cold_users_draw(P.gen_users_dist, users_mean, users_sigma, seed, g_draws++) * rps_per_user;
             }
             if (g_lam <= 0.0) {
                 g_now = g_wend;
                 continue;
             }
-            double u = uniform_j(seed, STREAM_GENERATOR, g_draws++, 0u);
+            const U4 r = draw_block(seed, STREAM_GENERATOR, g_draws++, 0u);
+            double u = u53(r.x, r.y);
             if (u < 1e-15) u = 1e-15;
             const double dt = -af_log(1.0 - u) / g_lam;
             if (g_now + dt > T) break;
@@ -335,7 +377,7 @@ struct Lane {
         return -1.0;
     }
 
-    // ---- edge: EdgeRuntime.transport/_deliver up to the timeout (edge.py:73-107) ----
+    // ---- SEND stage: EdgeRuntime.transport/_deliver up to the timeout (edge.py:73-107) ----
     AF_CORE void edge_send(uint32_t slot, uint32_t e, uint32_t hops) {
         const uint32_t idx = M.ld32(L.w_sends + e);
         M.st32(L.w_sends + e, idx + 1u);
@@ -347,41 +389,48 @@ struct Lane {
             return;
         }
         M.st32(L.w_conn + e, M.ld32(L.w_conn + e) + 1u);
-        const double transit = variate_from_u1(P.e_dist[e], edge_mean(e), edge_sigma(e), u53(r.z, r.w), seed, stream, idx);
+        const double u1 = u53(r.z, r.w);
+        const uint32_t dist = P.e_dist[e];
+        const double mean = edge_mean(e);
+        double transit;
+        if (dist == DIST_EXPONENTIAL) {
+            transit = -(mean * af_log(1.0 - u1));
+        } else {
+            transit = cold_variate(dist, mean, edge_sigma(e), u1, seed, stream, idx);
+        }
         const double effective = transit + M.ld64(L.d_spike + e);  // spike read at SEND time (edge.py:94-106)
         M.st32(L.w_rst + slot, rst_pack(RK_TRANSIT, e, hops, 0u));
-        push(now + effective, slot);
+        emit(now + effective, slot);
     }
 
-    // ---- server: ServerRuntime._handle_request (server.py:79-276) ----------------
-    // a CPU token became free: first waiter (Container FIFO) or 0xFFFFFFFF
-    AF_CORE uint32_t cpu_release(uint32_t sv) {
-        if (M.ld32(L.w_cqn + sv) > 0u) return q_pop(L.w_cq, L.w_cqh, L.w_cqn, sv);  // token handed over
-        M.st32(L.w_cpufree + sv, M.ld32(L.w_cpufree + sv) + 1u);
-        return 0xFFFFFFFFu;
-    }
-    // the waiter's `yield cpu_req` returns (server.py:220-231)
+    // ---- GRANT stage: the waiter's `yield cpu_req` returns (server.py:220-231) ----
     AF_CORE void cpu_granted(uint32_t w, uint32_t sv) {
         M.st32(L.w_ready + sv, M.ld32(L.w_ready + sv) - 1u);
         const uint32_t st = M.ld32(L.w_rst + w);
         const uint32_t step = M.ld32(L.w_rst2 + w) >> 16;
         M.st32(L.w_rst + w, (st & ~7u) | RK_CPU);
-        push(now + step_time(step), w);
+        emit(now + step_time(step), w);
+    }
+    // a CPU token became free: hand it to the first waiter (Container FIFO)
+    AF_CORE void cpu_release(uint32_t sv) {
+        if (M.ld32(L.w_cqn + sv) > 0u) {
+            fu_grant = q_pop(L.w_cq, L.w_cqh, L.w_cqn, sv);
+            fu_grant_sv = sv;
+        } else {
+            M.st32(L.w_cpufree + sv, M.ld32(L.w_cpufree + sv) + 1u);
+        }
     }
 
-    // The for-loop of _handle_request from `step` until the next timed event,
-    // a wait, or the end of the endpoint.  Non-recursive: RAM grants caused by a
-    // finishing request are left to the caller via pending_grant_sv.
+    // ---- ADV stage: the for-loop of _handle_request (server.py:197-276) from `step`
+    // until the next timed event, a wait, or the end of the endpoint.
     AF_CORE void advance(uint32_t slot, uint32_t sv, uint32_t ep, uint32_t step, uint32_t hops, bool core_locked,
                          bool in_io) {
         const uint32_t end = P.ep_stepb[ep + 1u];
         const uint32_t rst2 = ep | (step << 16);
         if (step < end) {
+            uint32_t kind_bits;
             if (P.st_kind[step] == STEP_CPU) {  // server.py:199-231
-                if (in_io) {
-                    in_io = false;
-                    M.st32(L.w_io + sv, M.ld32(L.w_io + sv) - 1u);
-                }
+                if (in_io) M.st32(L.w_io + sv, M.ld32(L.w_io + sv) - 1u);
                 if (!core_locked) {
                     const uint32_t cf = M.ld32(L.w_cpufree + sv);
                     if (M.ld32(L.w_cqn + sv) == 0u && cf > 0u) {
@@ -397,63 +446,59 @@ struct Lane {
                         return;
                     }
                 }
-                M.st32(L.w_rst + slot, rst_pack(RK_CPU, sv, hops, 0u));
-                M.st32(L.w_rst2 + slot, rst2);
-                push(now + step_time(step), slot);
-                return;
+                kind_bits = rst_pack(RK_CPU, sv, hops, 0u);
+            } else {  // I/O step, server.py:235-255
+                if (core_locked) cpu_release(sv);  // the waiter's Timeout is created AFTER this one
+                if (!in_io) M.st32(L.w_io + sv, M.ld32(L.w_io + sv) + 1u);
+                kind_bits = rst_pack(RK_IO, sv, hops, 1u);
             }
-            // I/O step, server.py:235-255
-            uint32_t granted = 0xFFFFFFFFu;
-            if (core_locked) {
-                granted = cpu_release(sv);
-                if (!in_io) {
-                    in_io = true;
-                    M.st32(L.w_io + sv, M.ld32(L.w_io + sv) + 1u);
-                }
-            } else if (!in_io) {
-                in_io = true;
-                M.st32(L.w_io + sv, M.ld32(L.w_io + sv) + 1u);
-            }
-            M.st32(L.w_rst + slot, rst_pack(RK_IO, sv, hops, 1u));
+            M.st32(L.w_rst + slot, kind_bits);
             M.st32(L.w_rst2 + slot, rst2);
-            push(now + step_time(step), slot);                     // own Timeout first ...
-            if (granted != 0xFFFFFFFFu) cpu_granted(granted, sv);  // ... then the waiter's
+            emit(now + step_time(step), slot);
             return;
         }
-        // endpoint finished, server.py:257-276
-        if (core_locked) {
-            const uint32_t granted = cpu_release(sv);
-            if (granted != 0xFFFFFFFFu) cpu_granted(granted, sv);  // waiter's get is processed first
-        }
+        // endpoint finished, server.py:257-276: waiter's grant, then transport(), then RAM waiters
+        if (core_locked) cpu_release(sv);
         if (in_io) M.st32(L.w_io + sv, M.ld32(L.w_io + sv) - 1u);
         const double ram = P.ep_ram[ep];
         if (ram > 0.0) {
             M.st64(L.d_ramuse + sv, M.ld64(L.d_ramuse + sv) - ram);
             M.st64(L.d_ramfree + sv, M.ld64(L.d_ramfree + sv) + ram);
-            pending_grant_sv = (int32_t)sv;
+            if (M.ld32(L.w_rqn + sv) > 0u) fu_ram_sv = (int32_t)sv;
         }
-        edge_send(slot, (uint32_t)P.s_out[sv], hops);
+        fu_send = true;
+        send_slot = slot;
+        send_edge = (uint32_t)P.s_out[sv];
+        send_hops = hops;
     }
 
-    // Container._trigger_get on the RAM container: FIFO, head-of-line blocking
-    AF_CORE void drain_ram_grants() {
-        while (pending_grant_sv >= 0) {
-            const uint32_t sv = (uint32_t)pending_grant_sv;
-            pending_grant_sv = -1;
-            while (M.ld32(L.w_rqn + sv) > 0u) {
-                const uint32_t w = q_front(L.w_rq, L.w_rqh, sv);
-                const uint32_t rst2 = M.ld32(L.w_rst2 + w);
-                const uint32_t ep = rst2 & 0xFFFFu;
-                const double need = P.ep_ram[ep];
-                const double free_ram = M.ld64(L.d_ramfree + sv);
-                if (free_ram < need) break;
-                q_pop(L.w_rq, L.w_rqh, L.w_rqn, sv);
-                M.st64(L.d_ramfree + sv, free_ram - need);
-                M.st64(L.d_ramuse + sv, M.ld64(L.d_ramuse + sv) + need);
-                const uint32_t hops = (M.ld32(L.w_rst + w) >> 11) & 0xFFu;
-                advance(w, sv, ep, rst2 >> 16, hops, false, false);
-            }
+    // ---- RAM stage: Container._trigger_get, FIFO with head-of-line blocking ------
+    AF_CORE void ram_stage() {
+        const uint32_t sv = (uint32_t)fu_ram_sv;
+        if (M.ld32(L.w_rqn + sv) == 0u) {
+            fu_ram_sv = -1;
+            return;
         }
+        const uint32_t w = q_front(L.w_rq, L.w_rqh, sv);
+        const uint32_t rst2 = M.ld32(L.w_rst2 + w);
+        const uint32_t ep = rst2 & 0xFFFFu;
+        const double need = P.ep_ram[ep];
+        const double free_ram = M.ld64(L.d_ramfree + sv);
+        if (free_ram < need) {
+            fu_ram_sv = -1;
+            return;
+        }
+        q_pop(L.w_rq, L.w_rqh, L.w_rqn, sv);
+        M.st64(L.d_ramfree + sv, free_ram - need);
+        M.st64(L.d_ramuse + sv, M.ld64(L.d_ramuse + sv) + need);
+        fu_adv = true;  // keep fu_ram_sv: the queue is looked at again after this waiter
+        adv_slot = w;
+        adv_sv = sv;
+        adv_ep = ep;
+        adv_step = rst2 >> 16;
+        adv_hops = (M.ld32(L.w_rst + w) >> 11) & 0xFFu;
+        adv_core = false;
+        adv_io = false;
     }
 
     // _dispatcher + head of _handle_request (server.py:303-313, 79-149)
@@ -463,11 +508,7 @@ struct Lane {
         const uint32_t n_ep = P.s_epb[sv + 1u] - epb;
         const uint32_t idx = M.ld32(L.w_arr + sv);
         M.st32(L.w_arr + sv, idx + 1u);
-        uint32_t pick = 0u;
-        if (n_ep > 1u) {  // rng.integers(0, n_ep), server.py:101
-            const U4 r = draw_block(seed, stream_server(sv), idx, 0u);
-            pick = (uint32_t)(((uint64_t)r.x * n_ep) >> 32);
-        }
+        const uint32_t pick = n_ep > 1u ? cold_endpoint_pick(seed, sv, idx, n_ep) : 0u;
         const uint32_t ep = epb + pick;
         const uint32_t step0 = P.ep_stepb[ep];
         const double ram = P.ep_ram[ep];
@@ -491,7 +532,14 @@ struct Lane {
                 return;
             }
         }
-        advance(slot, sv, ep, step0, hops, false, false);
+        fu_adv = true;
+        adv_slot = slot;
+        adv_sv = sv;
+        adv_ep = ep;
+        adv_step = step0;
+        adv_hops = hops;
+        adv_core = false;
+        adv_io = false;
     }
 
     // EdgeRuntime._deliver after the timeout (edge.py:110-116) + the target node
@@ -513,13 +561,15 @@ struct Lane {
                 n_comp += 1u;
                 free_slot(slot);
             } else {
-                edge_send(slot, (uint32_t)P.client_out_edge, hops);
+                fu_send = true;
+                send_slot = slot;
+                send_edge = (uint32_t)P.client_out_edge;
+                send_hops = hops;
             }
         } else if (tk == NODE_LB) {  // LoadBalancerRuntime._forwarder, load_balancer.py:60-72
             hops += 1u;
-            uint32_t out;
+            uint32_t out = M.ld32(L.w_lb);
             if (P.lb_algo == LB_LEAST_CONNECTIONS) {  // lb_algorithms.py:10-20
-                out = M.ld32(L.w_lb);
                 uint32_t best = M.ld32(L.w_conn + out);
                 for (uint32_t i = 1u; i < lb_n; ++i) {
                     const uint32_t cand = M.ld32(L.w_lb + i);
@@ -530,11 +580,13 @@ struct Lane {
                     }
                 }
             } else {  // round_robin: first key, move_to_end (lb_algorithms.py:22-36)
-                out = M.ld32(L.w_lb);
                 for (uint32_t i = 1u; i < lb_n; ++i) M.st32(L.w_lb + i - 1u, M.ld32(L.w_lb + i));
                 M.st32(L.w_lb + lb_n - 1u, out);
             }
-            edge_send(slot, out, hops);
+            fu_send = true;
+            send_slot = slot;
+            send_edge = out;
+            send_hops = hops;
         } else {
             server_arrival(slot, (uint32_t)P.e_tidx[e], hops);
         }
@@ -549,6 +601,7 @@ struct Lane {
             n_marks += 1u;
             if (emark_i >= P.n_edge_marks || P.em_time[emark_i] > now) break;
         }
+        t_emark = emark_i < P.n_edge_marks ? P.em_time[emark_i] : AF_INF;
     }
     AF_CORE void apply_smarks() {
         for (;;) {
@@ -556,16 +609,16 @@ struct Lane {
             const int32_t e = P.sm_edge[i];
             n_marks += 1u;
             if (e >= 0) {
-                uint32_t pos = 0xFFFFFFFFu;
+                uint32_t pos = NONE32;
                 for (uint32_t k = 0u; k < lb_n; ++k)
                     if (M.ld32(L.w_lb + k) == (uint32_t)e) pos = k;
                 if (P.sm_down[i]) {  // lb_out_edges.pop(edge_id, None)
-                    if (pos != 0xFFFFFFFFu) {
+                    if (pos != NONE32) {
                         for (uint32_t k = pos + 1u; k < lb_n; ++k) M.st32(L.w_lb + k - 1u, M.ld32(L.w_lb + k));
                         lb_n -= 1u;
                     }
                 } else {  // re-insert + move_to_end
-                    if (pos != 0xFFFFFFFFu) {
+                    if (pos != NONE32) {
                         for (uint32_t k = pos + 1u; k < lb_n; ++k) M.st32(L.w_lb + k - 1u, M.ld32(L.w_lb + k));
                         M.st32(L.w_lb + lb_n - 1u, (uint32_t)e);
                     } else {
@@ -576,6 +629,7 @@ struct Lane {
             }
             if (smark_i >= P.n_srv_marks || P.sm_time[smark_i] > now) break;
         }
+        t_smark = smark_i < P.n_srv_marks ? P.sm_time[smark_i] : AF_INF;
     }
 
     // ---- sampler tick (metrics/collector.py:50-66) --------------------------------
@@ -610,8 +664,11 @@ struct Lane {
         g_lam = 0.0;
         g_draws = heap_n = seq = bump = free_top = live = max_live = emark_i = smark_i = 0u;
         n_gen = n_comp = n_drop = n_events = n_ticks = n_marks = flags = rounds = 0u;
-        pending_grant_sv = -1;
-        hole = false;
+        hole = fu_send = fu_adv = false;
+        pend_count = 0u;
+        gen_first = true;
+        fu_grant = NONE32;
+        fu_ram_sv = -1;
         users_mean = P.gen_users_mean;
         users_sigma = P.gen_users_sigma;
         rpm = P.gen_rpm_mean;
@@ -654,12 +711,20 @@ struct Lane {
                 default: break;
             }
         }
-        const double gap = next_gap();
-        t_gen = gap >= 0.0 ? 0.0 + gap : AF_INF;
+        t_gen = 0.0;  // the generator's Initialize runs as the first "arrival" round (gen_first)
         t_tick = 0.0 + P.sample_period;
+        t_emark = P.n_edge_marks ? P.em_time[0] : AF_INF;
+        t_smark = P.n_srv_marks ? P.sm_time[0] : AF_INF;
     }
 
     // One next-event round.  Returns false once the scenario reached the horizon.
+    //
+    // Structure (every heavy block appears ONCE so the code stays I-cache sized and
+    // lanes re-converge at each stage):
+    //   select -> decode (light, per event kind) -> [ADV -> GRANT -> SEND -> RAM]* -> heap commit
+    // The stage order is the order SimPy creates the corresponding Timeouts in
+    // (server.py:235-276): own I/O timer before the CPU waiter's; on endpoint end
+    // the CPU waiter's timer, then transport(), then the RAM waiters.
     AF_CORE bool round() {
         // next event among {heap, arrival, tick, server marks, edge marks}; on equal
         // times the LATER test wins: edge marks < server marks < tick < arrival < heap.
@@ -667,14 +732,8 @@ struct Lane {
         double t = heap_n > 0u ? M.ld64(L.d_hk) : AF_INF;
         if (t_gen <= t) { cls = 3u; t = t_gen; }
         if (t_tick <= t) { cls = 2u; t = t_tick; }
-        if (smark_i < P.n_srv_marks) {
-            const double ts = P.sm_time[smark_i];
-            if (ts <= t) { cls = 1u; t = ts; }
-        }
-        if (emark_i < P.n_edge_marks) {
-            const double te = P.em_time[emark_i];
-            if (te <= t) { cls = 0u; t = te; }
-        }
+        if (t_smark <= t) { cls = 1u; t = t_smark; }
+        if (t_emark <= t) { cls = 0u; t = t_emark; }
         if (!(t < P.total_time)) return false;  // the stop event is URGENT at T
         if (rounds > 0u && t == now) flags |= FLAG_TIME_TIE;
         rounds += 1u;
@@ -692,20 +751,33 @@ struct Lane {
                 deliver(slot, idx, hops);
             } else {  // CPU or I/O step finished: the for-loop moves to the next step
                 const uint32_t rst2 = M.ld32(L.w_rst2 + slot);
-                advance(slot, idx, rst2 & 0xFFFFu, (rst2 >> 16) + 1u, hops, kind == RK_CPU, (st >> 19) & 1u);
+                fu_adv = true;
+                adv_slot = slot;
+                adv_sv = idx;
+                adv_ep = rst2 & 0xFFFFu;
+                adv_step = (rst2 >> 16) + 1u;
+                adv_hops = hops;
+                adv_core = kind == RK_CPU;
+                adv_io = (st >> 19) & 1u;
             }
-            drain_ram_grants();
-            if (hole) remove_root();
         } else if (cls == 3u) {  // RqsGeneratorRuntime._event_arrival (rqs_generator.py:101-119)
-            n_gen += 1u;
-            n_events += 1u;
-            const double gap = next_gap();
+            const bool first = gen_first;  // Initialize: only draws the first gap
+            gen_first = false;
             const double t_arrival = now;
+            const double gap = next_gap();
             t_gen = gap >= 0.0 ? now + gap : AF_INF;
-            const uint32_t slot = alloc_slot();
-            if (slot != 0xFFFFFFFFu) {
+            uint32_t slot = NONE32;
+            if (!first) {
+                n_gen += 1u;
+                n_events += 1u;
+                slot = alloc_slot();
+            }
+            if (slot != NONE32) {
                 M.st64(L.d_t0 + slot, t_arrival);
-                edge_send(slot, (uint32_t)P.gen_out_edge, 1u);  // hops = 1: record_hop(GENERATOR)
+                fu_send = true;
+                send_slot = slot;
+                send_edge = (uint32_t)P.gen_out_edge;
+                send_hops = 1u;  // record_hop(GENERATOR)
             }
         } else if (cls == 2u) {
             sample_tick();
@@ -714,6 +786,30 @@ struct Lane {
             apply_smarks();
         } else {
             apply_emarks();
+        }
+
+        for (;;) {
+            // each stage pushes at most one event; the buffer holds two, so a pass
+            // stops early (stage order preserved) when it is full -- rare.
+            if (fu_adv) {
+                fu_adv = false;
+                advance(adv_slot, adv_sv, adv_ep, adv_step, adv_hops, adv_core, adv_io);
+            }
+            bool room = pend_count < 2u;
+            if (fu_grant != NONE32 && room) {
+                const uint32_t w = fu_grant;
+                fu_grant = NONE32;
+                cpu_granted(w, fu_grant_sv);
+                room = pend_count < 2u;
+            }
+            if (fu_send && fu_grant == NONE32 && room) {
+                fu_send = false;
+                edge_send(send_slot, send_edge, send_hops);
+            }
+            if (fu_ram_sv >= 0 && fu_grant == NONE32 && !fu_send) ram_stage();
+            const bool more = fu_adv || fu_grant != NONE32 || fu_send || fu_ram_sv >= 0;
+            heap_commit(!more);
+            if (!more) break;
         }
         return true;
     }

@@ -28,6 +28,36 @@ class EngineError(RuntimeError):
 _lib: C.CDLL | None = None
 
 
+def _load_hip_runtime() -> None:
+    """Make ONE HIP runtime globally visible before dlopen()ing the engine.
+
+    libasyncflow_hip.so is linked with --no-hip-rt: its hip* symbols bind to the
+    runtime already in the process.  Under PyTorch that must be the copy torch
+    bundles (torch/lib/libamdhip64.so), otherwise torch tensors and the engine
+    would live in two different HIP/HSA runtimes.  Without torch, the system ROCm
+    runtime is used; a C/C++ host links its own.
+    """
+    candidates: list[str] = []
+    try:
+        import torch
+
+        candidates.append(str(Path(torch.__file__).resolve().parent / "lib" / "libamdhip64.so"))
+    except Exception:  # noqa: BLE001 - torch is plumbing, not a requirement of the C ABI
+        pass
+    candidates += ["libamdhip64.so.7", "/opt/rocm/lib/libamdhip64.so", "libamdhip64.so"]
+    for cand in candidates:
+        if cand.startswith("/") and not Path(cand).exists():
+            continue
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            continue
+        else:
+            return
+    msg = "no HIP runtime (libamdhip64) could be loaded"
+    raise EngineUnavailableError(msg)
+
+
 def load_library(path: str | Path | None = None) -> C.CDLL:
     global _lib  # noqa: PLW0603
     if _lib is None:
@@ -38,6 +68,7 @@ def load_library(path: str | Path | None = None) -> C.CDLL:
                 "(hipcc --offload-arch=gfx950). asyncflow_amd has no CPU fallback."
             )
             raise EngineUnavailableError(msg)
+        _load_hip_runtime()
         try:
             lib = C.CDLL(str(p))
         except OSError as exc:
