@@ -8,7 +8,17 @@ executed over thousands of independent scenarios by a hand-written HIP kernel
 
 from .payload import load_yaml, normalize_payload
 from .plan import DevicePlan, lower
+from .results import BatchedResults, ScenarioResults
+from .runner import SimulationRunner
 
-__all__ = ["DevicePlan", "load_yaml", "lower", "normalize_payload"]
+__all__ = [
+    "BatchedResults",
+    "DevicePlan",
+    "ScenarioResults",
+    "SimulationRunner",
+    "load_yaml",
+    "lower",
+    "normalize_payload",
+]
 
 __version__ = "0.1.0"

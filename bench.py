@@ -200,9 +200,10 @@ def main() -> int:
     stats_all = summ["stats"]
     if dist is not None:
         t2 = time.perf_counter()
+        from asyncflow_amd.distributed import gather_summaries
+
         packed = torch.cat([summ["stats"].to(torch.float32), summ["rps"]], dim=1).contiguous()
-        out = torch.empty((world * n, packed.shape[1]), dtype=packed.dtype, device=dev)
-        dist.all_gather_into_tensor(out, packed)
+        out = gather_summaries(packed, [n] * world)   # ONE all_gather over xGMI (RCCL)
         torch.cuda.synchronize(dev)
         gather_ms = (time.perf_counter() - t2) * 1e3
         stats_all = out[:, :8]

@@ -1,0 +1,81 @@
+"""N > 1 path on CPU: 2 processes, gloo backend, the same sharding + gather code bench.py uses."""
+
+from __future__ import annotations
+
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from asyncflow_amd.distributed import interleave_by_load, shard_bounds, shard_seeds
+
+
+def test_shards_partition_the_seed_range():
+    seeds = 0x5EED0000 + np.arange(1003, dtype=np.uint64)
+    for world in (1, 2, 3, 8):
+        parts = [shard_seeds(seeds, r, world) for r in range(world)]
+        assert np.array_equal(np.concatenate(parts), seeds)
+        sizes = [len(p) for p in parts]
+        assert max(sizes) - min(sizes) <= 1
+        assert [shard_bounds(1003, r, world) for r in range(world)][0][0] == 0
+
+
+def test_interleave_balances_expected_load():
+    users = np.repeat(np.arange(1, 101) * 10.0, 100)       # config 3: events ~ users
+    parts = interleave_by_load(users, 8)
+    loads = [users[p].sum() for p in parts]
+    assert sorted(np.concatenate(parts).tolist()) == list(range(10_000))
+    assert (max(loads) - min(loads)) / np.mean(loads) < 0.01
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank: int, world: int, port: int, n_total: int) -> None:
+    import torch
+    import torch.distributed as dist
+
+    from asyncflow_amd import _abi
+    from asyncflow_amd.distributed import gather_summaries, shard_seeds
+    from asyncflow_amd.plan import lower
+    from oracle.scenarios import lb_two_servers
+    from tests.hostcheck import build as hc
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        plan = lower(lb_two_servers(horizon=5))
+        seeds = 0x5EED0000 + np.arange(n_total, dtype=np.uint64)
+        mine = shard_seeds(seeds, rank, world)
+
+        def summary(seed: int) -> list[float]:
+            counts, clock, _ = hc.simulate(plan, int(seed))      # engine core, one lane, on the host
+            lat = clock[:, 1] - clock[:, 0]
+            return [float(seed), float(counts[_abi.CNT_GENERATED]), float(counts[_abi.CNT_COMPLETED]),
+                    float(np.percentile(lat, 95)) if len(lat) else float("nan")]
+
+        local = torch.tensor([summary(s) for s in mine], dtype=torch.float64).reshape(len(mine), 4)
+        full = gather_summaries(local)                            # the single collective
+        assert full.shape == (n_total, 4)
+        assert np.array_equal(full[:, 0].numpy().astype(np.uint64), seeds)      # rank order == seed order
+        want = torch.tensor([summary(s) for s in seeds], dtype=torch.float64)
+        assert torch.equal(torch.nan_to_num(full), torch.nan_to_num(want))
+        total = torch.tensor([local[:, 2].sum()], dtype=torch.float64)
+        dist.all_reduce(total)
+        assert float(total) == float(want[:, 2].sum())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [6, 7])   # equal and ragged shards
+def test_two_rank_gloo_gather_matches_serial(n_total):
+    import torch.multiprocessing as mp
+
+    from tests.hostcheck import build as hc
+
+    hc.build()
+    mp.spawn(_worker, args=(2, _free_port(), n_total), nprocs=2, join=True)
