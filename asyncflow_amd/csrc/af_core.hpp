@@ -9,15 +9,18 @@
 //
 // Execution model ("atomic cascades"):
 //   * only TIMED events live in the per-scenario priority queue -- a binary heap
-//     of (time f64, request slot), ties broken by a per-scenario push sequence;
-//     the generator, sampler and injection timers are register-resident
-//     "special" sources with fixed class order on ties;
+//     whose entries carry the whole request: (time, start time, seq|state); there
+//     is no request pool and no dependent state lookup after a pop;
+//     ties are broken by a per-scenario push sequence; the generator, sampler and
+//     injection timers are register-resident "special" sources with a fixed class
+//     order on ties;
 //   * every zero-time SimPy step following a timed event is executed inline in
 //     the order SimPy runs it when no other timed event shares the timestamp.
 //
-// State lives in `Mem`, a word-addressed per-lane memory laid out [index][lane]
-// (SoA across the 64 lanes of a wave): LDS when it fits (bank-conflict-free for
-// arbitrary per-lane indices), HBM otherwise (coalesced for equal indices).
+// State lives in `Mem`, a per-lane memory of 64-bit words laid out [index][lane]
+// (SoA across the 64 lanes of a wave): LDS when it fits (ds_read_b64 of
+// [i][lane] is bank-conflict free for ANY per-lane index), HBM otherwise
+// (coalesced for equal indices).
 //
 // This header is device code under hipcc and plain C++ under g++: the latter is
 // the TEST-ONLY host instantiation built by tests/hostcheck/ (never shipped,
@@ -43,7 +46,6 @@ namespace af {
 // ---- must match include/asyncflow_hip.h ---------------------------------
 enum : uint32_t { NODE_CLIENT = 0, NODE_LB = 1, NODE_SERVER = 2 };
 enum : uint32_t { LB_ROUND_ROBIN = 0, LB_LEAST_CONNECTIONS = 1 };
-enum : uint32_t { STEP_CPU = 0, STEP_IO = 1 };
 enum : uint32_t { METRIC_READY = 1, METRIC_IO = 2, METRIC_RAM = 4, METRIC_EDGE = 8 };
 enum : uint32_t {
     FLAG_POOL_OVERFLOW = 1u << 0,
@@ -61,97 +63,84 @@ enum : uint32_t {
     PARAM_EDGE_DROPOUT, PARAM_STEP_TIME, PARAM_COUNT
 };
 
-// ---- request state word ----------------------------------------------------
-// RST : kind[0:2] | idx8[3:10] (edge when in transit, server otherwise) | hops[11:18] | in_io[19]
-// RST2: endpoint[0:15] | absolute step index[16:31]
-enum : uint32_t { RK_TRANSIT = 0, RK_CPU = 1, RK_IO = 2, RK_WAIT_RAM = 3, RK_WAIT_CPU = 4 };
-AF_HD uint32_t rst_pack(uint32_t kind, uint32_t idx, uint32_t hops, uint32_t in_io) {
-    return kind | (idx << 3) | ((hops > 255u ? 255u : hops) << 11) | (in_io << 19);
+// ---- request state (low 32 bits of a heap / queue entry's B word) -----------
+//   kind[0:1] | idx[2:9] (edge while in transit, server otherwise) | hops[10:12] (saturating:
+//   only `len(history) > 3` is ever tested, client.py:62) | in_io[13] | step row[14:29]
+enum : uint32_t { RK_TRANSIT = 0, RK_CPU = 1, RK_IO = 2, RK_WAIT = 3 };
+AF_HD uint32_t st_pack(uint32_t kind, uint32_t idx, uint32_t hops, uint32_t in_io, uint32_t step) {
+    return kind | (idx << 2) | ((hops > 7u ? 7u : hops) << 10) | (in_io << 13) | (step << 14);
 }
+AF_HD uint32_t st_kind(uint32_t s) { return s & 3u; }
+AF_HD uint32_t st_idx(uint32_t s) { return (s >> 2) & 0xFFu; }
+AF_HD uint32_t st_hops(uint32_t s) { return (s >> 10) & 7u; }
+AF_HD uint32_t st_io(uint32_t s) { return (s >> 13) & 1u; }
+AF_HD uint32_t st_step(uint32_t s) { return (s >> 14) & 0xFFFFu; }
 
-// ---- the lowered plan as seen by device code (LDS-resident copy) -----------
+// ---- the lowered plan as seen by device code: arrays of 64-bit records -------
+// (LDS-resident copy under hipcc; packed on the host by af_plan_pack.hpp)
+//   edge  record [4]: mean, sigma, dropout, meta = tkind | tidx<<8 | dist<<16
+//   server record[2]: ram_mb, meta = cores | out_edge<<16 | first_endpoint<<32 | n_endpoints<<48
+//   endpoint rec [2]: ram, first step row
+//   step row     [3]: time, ram of its endpoint, kind (STEP_CPU | STEP_IO | STEP_END);
+//                     every endpoint's rows end with one STEP_END row
+//   edge mark    [3]: time, delta, edge ; server mark [2]: time, meta = (lb_edge+1) | down<<32
+enum : uint32_t { STEP_CPU = 0, STEP_IO = 1, STEP_END = 2 };
+enum : uint32_t { EREC = 4, SREC = 2, PREC = 2, TREC = 3, MREC = 3, NREC = 2 };
+
 struct PlanView {
     double total_time, sample_period;
     double gen_users_mean, gen_users_sigma, gen_rpm_mean, gen_window_s;
     uint32_t metrics_mask, gen_users_dist;
-    int32_t gen_out_edge, client_out_edge;
-    uint32_t n_edges, n_servers, lb_algo, n_lb_edges, n_endpoints, n_steps, n_edge_marks, n_srv_marks;
-    const AF_PLAN_AS double* e_mean;
-    const AF_PLAN_AS double* e_sigma;
-    const AF_PLAN_AS double* e_drop;
-    const AF_PLAN_AS double* s_ram;
-    const AF_PLAN_AS double* ep_ram;
-    const AF_PLAN_AS double* st_time;
-    const AF_PLAN_AS double* em_time;
-    const AF_PLAN_AS double* em_delta;
-    const AF_PLAN_AS double* sm_time;
-    const AF_PLAN_AS int32_t* lb_edges;
-    const AF_PLAN_AS uint32_t* e_tkind;
-    const AF_PLAN_AS int32_t* e_tidx;
-    const AF_PLAN_AS uint32_t* e_dist;
-    const AF_PLAN_AS uint32_t* s_cores;
-    const AF_PLAN_AS int32_t* s_out;
-    const AF_PLAN_AS uint32_t* s_epb;
-    const AF_PLAN_AS uint32_t* ep_stepb;
-    const AF_PLAN_AS uint32_t* st_kind;
-    const AF_PLAN_AS int32_t* em_edge;
-    const AF_PLAN_AS int32_t* sm_edge;
-    const AF_PLAN_AS uint32_t* sm_down;
+    uint32_t gen_out_edge, client_out_edge;
+    uint32_t n_edges, n_servers, lb_algo, n_lb_edges, n_rows, n_edge_marks, n_srv_marks;
+    const AF_PLAN_AS uint64_t* edge;
+    const AF_PLAN_AS uint64_t* srv;
+    const AF_PLAN_AS uint64_t* ep;
+    const AF_PLAN_AS uint64_t* row;
+    const AF_PLAN_AS uint64_t* emark;
+    const AF_PLAN_AS uint64_t* smark;
+    const AF_PLAN_AS uint64_t* lb;  // [n_lb_edges] out-edge indices in payload order
 };
 
-// ---- per-lane state layout (word offsets; computed by the host) -------------
+AF_HD double u2d(uint64_t u) { return __builtin_bit_cast(double, u); }
+AF_HD uint64_t d2u(double d) { return __builtin_bit_cast(uint64_t, d); }
+
+// ---- per-lane state layout (offsets in 64-bit words; computed by the host) ----
+//   heap K/A/B [cap] each; edge [E][2] = {conn | sends<<32, spike}; optional per-scenario
+//   parameter columns; server [S][5] = {cpu_free | ready<<32, io | arrivals<<32, ram_free,
+//   ram_in_use, cq_head | cq_n<<16 | rq_head<<32 | rq_n<<48 | blocked<<63}; wait queues
+//   [S][fcap][2] = {start time, state}; LB order [n_lb] (only used when n_lb > 8).
 struct Layout {
-    uint32_t cap;       // live requests == heap capacity
-    uint32_t fcap;      // per-server wait-queue capacity (power of two)
+    uint32_t cap;       // pending timed events (== requests in flight) per scenario
+    uint32_t fcap;      // per-server wait-queue capacity (power of two, <= 32768)
     uint32_t ovr_mask;  // bit p set: af_param class p has a per-lane column
-    // f64 region, offsets in doubles
-    uint32_t d_hk, d_t0, d_spike, d_ramfree, d_ramuse, d_emean, d_esig, d_edrop, d_stime, n_d;
-    // u32 region, offsets in words
-    uint32_t w_hs, w_rst, w_rst2, w_rseq, w_free, w_conn, w_sends, w_cpufree, w_ready, w_io, w_arr, w_rblk;
-    uint32_t w_cqh, w_cqn, w_rqh, w_rqn, w_cq, w_rq, w_lb, n_w;
+    uint32_t hk, ha, hb, edge, emean, esig, edrop, stime, srv, cq, rq, lb, n_words;
 };
+enum : uint32_t { LEDGE = 2, LSRV = 5 };
 
 AF_HD Layout make_layout(uint32_t cap, uint32_t fcap, uint32_t n_edges, uint32_t n_servers, uint32_t n_lb,
-                         uint32_t n_steps, uint32_t ovr_mask) {
+                         uint32_t n_rows, uint32_t ovr_mask) {
     Layout L{};
     L.cap = cap;
     L.fcap = fcap;
     L.ovr_mask = ovr_mask;
-    uint32_t d = 0;
-    L.d_hk = d; d += cap;
-    L.d_t0 = d; d += cap;
-    L.d_spike = d; d += n_edges;
-    L.d_ramfree = d; d += n_servers;
-    L.d_ramuse = d; d += n_servers;
-    L.d_emean = d; if (ovr_mask & (1u << PARAM_EDGE_MEAN)) d += n_edges;
-    L.d_esig = d; if (ovr_mask & (1u << PARAM_EDGE_SIGMA)) d += n_edges;
-    L.d_edrop = d; if (ovr_mask & (1u << PARAM_EDGE_DROPOUT)) d += n_edges;
-    L.d_stime = d; if (ovr_mask & (1u << PARAM_STEP_TIME)) d += n_steps;
-    L.n_d = d;
     uint32_t w = 0;
-    L.w_hs = w; w += cap;
-    L.w_rst = w; w += cap;
-    L.w_rst2 = w; w += cap;
-    L.w_rseq = w; w += cap;
-    L.w_free = w; w += cap;
-    L.w_conn = w; w += n_edges;
-    L.w_sends = w; w += n_edges;
-    L.w_cpufree = w; w += n_servers;
-    L.w_ready = w; w += n_servers;
-    L.w_io = w; w += n_servers;
-    L.w_arr = w; w += n_servers;
-    L.w_rblk = w; w += n_servers;
-    L.w_cqh = w; w += n_servers;
-    L.w_cqn = w; w += n_servers;
-    L.w_rqh = w; w += n_servers;
-    L.w_rqn = w; w += n_servers;
-    L.w_cq = w; w += n_servers * fcap;
-    L.w_rq = w; w += n_servers * fcap;
-    L.w_lb = w; w += n_lb;
-    L.n_w = w;
+    L.hk = w; w += cap;
+    L.ha = w; w += cap;
+    L.hb = w; w += cap;
+    L.edge = w; w += LEDGE * n_edges;
+    L.emean = w; if (ovr_mask & (1u << PARAM_EDGE_MEAN)) w += n_edges;
+    L.esig = w; if (ovr_mask & (1u << PARAM_EDGE_SIGMA)) w += n_edges;
+    L.edrop = w; if (ovr_mask & (1u << PARAM_EDGE_DROPOUT)) w += n_edges;
+    L.stime = w; if (ovr_mask & (1u << PARAM_STEP_TIME)) w += n_rows;
+    L.srv = w; w += LSRV * n_servers;
+    L.cq = w; w += 2u * n_servers * fcap;
+    L.rq = w; w += 2u * n_servers * fcap;
+    L.lb = w; w += n_lb > 8u ? n_lb : 0u;
+    L.n_words = w;
     return L;
 }
-AF_HD uint64_t layout_bytes_per_lane(const Layout& L) { return 8ull * L.n_d + 4ull * L.n_w; }
+AF_HD uint64_t layout_bytes_per_lane(const Layout& L) { return 8ull * L.n_words; }
 
 // ---- outputs of one scenario -------------------------------------------------
 struct LaneOut {
@@ -162,7 +151,6 @@ struct LaneOut {
 };
 
 constexpr double AF_INF = __builtin_huge_val();
-constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 
 // Cold helpers kept out of line so that the hot loop stays small (the gfx950
 // instruction cache is shared by two CUs; the round body must fit in it).
@@ -193,21 +181,25 @@ struct Lane {
     // register-resident scalars
     double now, t_gen, g_now, g_wend, g_lam, t_tick, t_emark, t_smark;
     double users_mean, users_sigma, rpm;
-    uint32_t g_draws, heap_n, seq, bump, free_top, live, max_live, lb_n, emark_i, smark_i;
+    uint64_t lb_list;  // LB out-edge order, 8 bits per entry (n_lb_edges <= 8), else in Mem
+    uint32_t g_draws, heap_n, seq, live, max_live, lb_n, emark_i, smark_i;
     uint32_t n_gen, n_comp, n_drop, n_events, n_ticks, n_marks, flags, rounds;
 
     // per-round work registers ("follow-ups" of the timed event being handled)
     bool hole;            // the popped event left the heap root free
-    uint32_t pend_count;  // pushes buffered this pass (<= 2): the heap code exists once
-    double pend_t0, pend_t1;
-    uint32_t pend_slot0, pend_slot1;
     bool gen_first;       // the generator's Initialize has not run yet
-    uint32_t fu_grant;  // waiter that received a CPU token (NONE32 = none)
-    uint32_t fu_grant_sv;
-    bool fu_send;       // a message has to be put on an edge
-    uint32_t send_slot, send_edge, send_hops;
-    bool fu_adv;        // a request (re)enters the endpoint step loop
-    uint32_t adv_slot, adv_sv, adv_ep, adv_step, adv_hops;
+    uint32_t pend_count;  // pushes buffered this pass (<= 2): the heap code exists once
+    double pend_k0, pend_k1;
+    uint64_t pend_a0, pend_a1, pend_b0, pend_b1;
+    bool fu_grant;  // a waiter received a CPU token
+    uint64_t grant_a;
+    uint32_t grant_st;
+    bool fu_send;   // a message has to be put on an edge
+    uint64_t send_a;
+    uint32_t send_edge, send_hops;
+    bool fu_adv;    // a request (re)enters the endpoint step loop
+    uint64_t adv_a;
+    uint32_t adv_sv, adv_step, adv_hops;
     bool adv_core, adv_io;
     int32_t fu_ram_sv;  // RAM was released on this server: serve its wait queue
 
@@ -215,58 +207,66 @@ struct Lane {
 
     // ---- parameter accessors (plan value or per-scenario column) -------------
     AF_CORE double edge_mean(uint32_t e) const {
-        return (L.ovr_mask & (1u << PARAM_EDGE_MEAN)) ? M.ld64(L.d_emean + e) : P.e_mean[e];
+        return (L.ovr_mask & (1u << PARAM_EDGE_MEAN)) ? u2d(M.ld(L.emean + e)) : u2d(P.edge[EREC * e]);
     }
     AF_CORE double edge_sigma(uint32_t e) const {
-        return (L.ovr_mask & (1u << PARAM_EDGE_SIGMA)) ? M.ld64(L.d_esig + e) : P.e_sigma[e];
+        return (L.ovr_mask & (1u << PARAM_EDGE_SIGMA)) ? u2d(M.ld(L.esig + e)) : u2d(P.edge[EREC * e + 1u]);
     }
     AF_CORE double edge_dropout(uint32_t e) const {
-        return (L.ovr_mask & (1u << PARAM_EDGE_DROPOUT)) ? M.ld64(L.d_edrop + e) : P.e_drop[e];
+        return (L.ovr_mask & (1u << PARAM_EDGE_DROPOUT)) ? u2d(M.ld(L.edrop + e)) : u2d(P.edge[EREC * e + 2u]);
     }
-    AF_CORE double step_time(uint32_t i) const {
-        return (L.ovr_mask & (1u << PARAM_STEP_TIME)) ? M.ld64(L.d_stime + i) : P.st_time[i];
+    AF_CORE double row_time(uint32_t r) const {
+        return (L.ovr_mask & (1u << PARAM_STEP_TIME)) ? u2d(M.ld(L.stime + r)) : u2d(P.row[TREC * r]);
     }
 
-    // ---- priority queue: binary heap of (time, slot), ties by push sequence ----
-    AF_CORE bool ev_less(double ka, uint32_t sa, double kb, uint32_t sb) const {
-        if (ka != kb) return ka < kb;
-        return M.ld32(L.w_rseq + sa) < M.ld32(L.w_rseq + sb);
+    // ---- priority queue: binary heap of (time, start, seq|state) ------------------
+    // (time, push sequence) order; the sequence sits in the high half of B
+    AF_CORE static bool ev_less(double ka, uint64_t ba, double kb, uint64_t bb) {
+        return ka < kb || (ka == kb && (ba >> 32) < (bb >> 32));
     }
-    AF_CORE void sift_down(uint32_t pos, double key, uint32_t slot, uint32_t n) {
+    AF_CORE void sift_down(uint32_t pos, double key, uint64_t a, uint64_t b, uint32_t n) {
         for (;;) {
             uint32_t c = 2u * pos + 1u;
             if (c >= n) break;
-            double kc = M.ld64(L.d_hk + c);
-            uint32_t sc = M.ld32(L.w_hs + c);
+            // both children are fetched in full (6 independent LDS reads, one latency)
+            double kc = u2d(M.ld(L.hk + c));
+            uint64_t ac = M.ld(L.ha + c);
+            uint64_t bc = M.ld(L.hb + c);
             if (c + 1u < n) {
-                const double k2 = M.ld64(L.d_hk + c + 1u);
-                const uint32_t s2 = M.ld32(L.w_hs + c + 1u);
-                if (ev_less(k2, s2, kc, sc)) {
+                const double k2 = u2d(M.ld(L.hk + c + 1u));
+                const uint64_t a2 = M.ld(L.ha + c + 1u);
+                const uint64_t b2 = M.ld(L.hb + c + 1u);
+                if (ev_less(k2, b2, kc, bc)) {
                     c += 1u;
                     kc = k2;
-                    sc = s2;
+                    ac = a2;
+                    bc = b2;
                 }
             }
-            if (!ev_less(kc, sc, key, slot)) break;
-            M.st64(L.d_hk + pos, kc);
-            M.st32(L.w_hs + pos, sc);
+            if (!ev_less(kc, bc, key, b)) break;
+            M.st(L.hk + pos, d2u(kc));
+            M.st(L.ha + pos, ac);
+            M.st(L.hb + pos, bc);
             pos = c;
         }
-        M.st64(L.d_hk + pos, key);
-        M.st32(L.w_hs + pos, slot);
+        M.st(L.hk + pos, d2u(key));
+        M.st(L.ha + pos, a);
+        M.st(L.hb + pos, b);
     }
-    AF_CORE void sift_up(uint32_t pos, double key, uint32_t slot) {
+    AF_CORE void sift_up(uint32_t pos, double key, uint64_t a, uint64_t b) {
         while (pos > 0u) {
             const uint32_t p = (pos - 1u) >> 1;
-            const double kp = M.ld64(L.d_hk + p);
-            const uint32_t sp = M.ld32(L.w_hs + p);
-            if (!ev_less(key, slot, kp, sp)) break;
-            M.st64(L.d_hk + pos, kp);
-            M.st32(L.w_hs + pos, sp);
+            const double kp = u2d(M.ld(L.hk + p));
+            const uint64_t bp = M.ld(L.hb + p);
+            if (!ev_less(key, b, kp, bp)) break;
+            M.st(L.hk + pos, d2u(kp));
+            M.st(L.ha + pos, M.ld(L.ha + p));
+            M.st(L.hb + pos, bp);
             pos = p;
         }
-        M.st64(L.d_hk + pos, key);
-        M.st32(L.w_hs + pos, slot);
+        M.st(L.hk + pos, d2u(key));
+        M.st(L.ha + pos, a);
+        M.st(L.hb + pos, b);
     }
     // Apply the buffered pushes of this pass: the first one takes the root when the
     // popped event left it free (replace-top), otherwise they are appended; if
@@ -276,76 +276,58 @@ struct Lane {
         uint32_t k = 0u;
         if (hole && (pend_count > 0u || final_pass)) {
             double key;
-            uint32_t slot;
+            uint64_t a, b;
             if (pend_count > 0u) {
-                key = pend_t0;
-                slot = pend_slot0;
+                key = pend_k0;
+                a = pend_a0;
+                b = pend_b0;
                 k = 1u;
             } else {
                 heap_n -= 1u;
-                key = M.ld64(L.d_hk + heap_n);
-                slot = M.ld32(L.w_hs + heap_n);
+                key = u2d(M.ld(L.hk + heap_n));
+                a = M.ld(L.ha + heap_n);
+                b = M.ld(L.hb + heap_n);
             }
             hole = false;
-            if (heap_n > 0u && (k == 1u || heap_n > 0u)) sift_down(0u, key, slot, heap_n);
+            if (heap_n > 0u) sift_down(0u, key, a, b, heap_n);
         }
-        for (; k < pend_count; ++k) sift_up(heap_n++, k == 0u ? pend_t0 : pend_t1, k == 0u ? pend_slot0 : pend_slot1);
+        for (; k < pend_count; ++k) {
+            if (heap_n >= L.cap) {  // more requests in flight than request_capacity
+                flags |= FLAG_POOL_OVERFLOW;
+                live -= 1u;
+                continue;
+            }
+            sift_up(heap_n++, k == 0u ? pend_k0 : pend_k1, k == 0u ? pend_a0 : pend_a1, k == 0u ? pend_b0 : pend_b1);
+        }
         pend_count = 0u;
     }
-    // schedule the (single) pending timed event of request `slot` (caller guarantees room)
-    AF_CORE void emit(double t, uint32_t slot) {
-        M.st32(L.w_rseq + slot, seq++);
+    // schedule the (single) pending timed event of a request (caller guarantees room)
+    AF_CORE void emit(double t, uint64_t a, uint32_t state) {
+        const uint64_t b = ((uint64_t)(seq++) << 32) | state;
         if (pend_count == 0u) {
-            pend_t0 = t;
-            pend_slot0 = slot;
+            pend_k0 = t;
+            pend_a0 = a;
+            pend_b0 = b;
         } else {
-            pend_t1 = t;
-            pend_slot1 = slot;
+            pend_k1 = t;
+            pend_a1 = a;
+            pend_b1 = b;
         }
         pend_count += 1u;
     }
 
-    // ---- request pool ----------------------------------------------------------
-    AF_CORE uint32_t alloc_slot() {
-        uint32_t s;
-        if (free_top > 0u) {
-            s = M.ld32(L.w_free + --free_top);
-        } else if (bump < L.cap) {
-            s = bump++;
-        } else {
-            flags |= FLAG_POOL_OVERFLOW;
-            return NONE32;
-        }
-        live += 1u;
-        if (live > max_live) max_live = live;
-        return s;
-    }
-    AF_CORE void free_slot(uint32_t s) {
-        M.st32(L.w_free + free_top++, s);
-        live -= 1u;
-    }
-
-    // ---- server wait queues (rings) ---------------------------------------------
-    AF_CORE bool q_push(uint32_t w_q, uint32_t w_h, uint32_t w_n, uint32_t sv, uint32_t slot) {
-        const uint32_t n = M.ld32(w_n + sv);
+    // ---- server wait queues: rings of (start time, state) ---------------------------
+    // q word: cq_head[0:15] | cq_n[16:31] | rq_head[32:47] | rq_n[48:62] | ram_blocked[63]
+    AF_CORE bool q_push(uint32_t base, uint32_t sv, uint32_t head, uint32_t n, uint64_t a, uint32_t state) {
         if (n >= L.fcap) {
             flags |= FLAG_FIFO_OVERFLOW;
+            live -= 1u;
             return false;
         }
-        const uint32_t h = M.ld32(w_h + sv);
-        M.st32(w_q + sv * L.fcap + ((h + n) & (L.fcap - 1u)), slot);
-        M.st32(w_n + sv, n + 1u);
+        const uint32_t at = base + 2u * (sv * L.fcap + ((head + n) & (L.fcap - 1u)));
+        M.st(at, a);
+        M.st(at + 1u, (uint64_t)state);
         return true;
-    }
-    AF_CORE uint32_t q_front(uint32_t w_q, uint32_t w_h, uint32_t sv) const {
-        return M.ld32(w_q + sv * L.fcap + M.ld32(w_h + sv));
-    }
-    AF_CORE uint32_t q_pop(uint32_t w_q, uint32_t w_h, uint32_t w_n, uint32_t sv) {
-        const uint32_t h = M.ld32(w_h + sv);
-        const uint32_t slot = M.ld32(w_q + sv * L.fcap + h);
-        M.st32(w_h + sv, (h + 1u) & (L.fcap - 1u));
-        M.st32(w_n + sv, M.ld32(w_n + sv) - 1u);
-        return slot;
     }
 
     // ---- generator: samplers/poisson_poisson.py:51-82, gaussian_poisson.py:63-94 ----
@@ -378,217 +360,249 @@ struct Lane {
     }
 
     // ---- SEND stage: EdgeRuntime.transport/_deliver up to the timeout (edge.py:73-107) ----
-    AF_CORE void edge_send(uint32_t slot, uint32_t e, uint32_t hops) {
-        const uint32_t idx = M.ld32(L.w_sends + e);
-        M.st32(L.w_sends + e, idx + 1u);
+    AF_CORE void edge_send(uint64_t a, uint32_t e, uint32_t hops) {
+        const uint32_t at = L.edge + LEDGE * e;
+        const uint64_t cs = M.ld(at);  // conn | sends<<32
+        const double spike = u2d(M.ld(at + 1u));
+        const double mean = edge_mean(e);
+        const double dropout = edge_dropout(e);
+        const uint32_t dist = (uint32_t)(P.edge[EREC * e + 3u] >> 16) & 0xFFu;
+        const uint32_t idx = (uint32_t)(cs >> 32);
         const uint32_t stream = stream_edge(e);
         const U4 r = draw_block(seed, stream, idx, 0u);
-        if (u53(r.x, r.y) < edge_dropout(e)) {  // dropped: no latency draw (edge.py:78-86)
+        if (u53(r.x, r.y) < dropout) {  // dropped: no latency draw (edge.py:78-86)
+            M.st(at, cs + (1ull << 32));
             n_drop += 1u;
-            free_slot(slot);
+            live -= 1u;
             return;
         }
-        M.st32(L.w_conn + e, M.ld32(L.w_conn + e) + 1u);
+        M.st(at, cs + (1ull << 32) + 1ull);  // sends += 1, conn += 1
         const double u1 = u53(r.z, r.w);
-        const uint32_t dist = P.e_dist[e];
-        const double mean = edge_mean(e);
         double transit;
         if (dist == DIST_EXPONENTIAL) {
             transit = -(mean * af_log(1.0 - u1));
         } else {
             transit = cold_variate(dist, mean, edge_sigma(e), u1, seed, stream, idx);
         }
-        const double effective = transit + M.ld64(L.d_spike + e);  // spike read at SEND time (edge.py:94-106)
-        M.st32(L.w_rst + slot, rst_pack(RK_TRANSIT, e, hops, 0u));
-        emit(now + effective, slot);
+        const double effective = transit + spike;  // spike read at SEND time (edge.py:94-106)
+        emit(now + effective, a, st_pack(RK_TRANSIT, e, hops, 0u, 0u));
     }
 
     // ---- GRANT stage: the waiter's `yield cpu_req` returns (server.py:220-231) ----
-    AF_CORE void cpu_granted(uint32_t w, uint32_t sv) {
-        M.st32(L.w_ready + sv, M.ld32(L.w_ready + sv) - 1u);
-        const uint32_t st = M.ld32(L.w_rst + w);
-        const uint32_t step = M.ld32(L.w_rst2 + w) >> 16;
-        M.st32(L.w_rst + w, (st & ~7u) | RK_CPU);
-        emit(now + step_time(step), w);
+    AF_CORE void cpu_granted() {
+        const uint32_t sv = st_idx(grant_st);
+        const uint32_t at = L.srv + LSRV * sv;
+        M.st(at, M.ld(at) - (1ull << 32));  // ready -= 1
+        const uint32_t step = st_step(grant_st);
+        emit(now + row_time(step), grant_a, st_pack(RK_CPU, sv, st_hops(grant_st), 0u, step));
     }
     // a CPU token became free: hand it to the first waiter (Container FIFO)
     AF_CORE void cpu_release(uint32_t sv) {
-        if (M.ld32(L.w_cqn + sv) > 0u) {
-            fu_grant = q_pop(L.w_cq, L.w_cqh, L.w_cqn, sv);
-            fu_grant_sv = sv;
+        const uint32_t at = L.srv + LSRV * sv;
+        const uint64_t q = M.ld(at + 4u);
+        const uint32_t cqn = (uint32_t)(q >> 16) & 0xFFFFu;
+        if (cqn > 0u) {
+            const uint32_t head = (uint32_t)q & 0xFFFFu;
+            const uint32_t from = L.cq + 2u * (sv * L.fcap + head);
+            grant_a = M.ld(from);
+            grant_st = (uint32_t)M.ld(from + 1u);
+            fu_grant = true;
+            const uint64_t nq = (q & ~0xFFFFFFFFull) | ((head + 1u) & (L.fcap - 1u)) | ((uint64_t)(cqn - 1u) << 16);
+            M.st(at + 4u, nq);
         } else {
-            M.st32(L.w_cpufree + sv, M.ld32(L.w_cpufree + sv) + 1u);
+            M.st(at, M.ld(at) + 1ull);  // cpu_free += 1
         }
     }
 
-    // ---- ADV stage: the for-loop of _handle_request (server.py:197-276) from `step`
-    // until the next timed event, a wait, or the end of the endpoint.
-    AF_CORE void advance(uint32_t slot, uint32_t sv, uint32_t ep, uint32_t step, uint32_t hops, bool core_locked,
-                         bool in_io) {
-        const uint32_t end = P.ep_stepb[ep + 1u];
-        const uint32_t rst2 = ep | (step << 16);
-        if (step < end) {
-            uint32_t kind_bits;
-            if (P.st_kind[step] == STEP_CPU) {  // server.py:199-231
-                if (in_io) M.st32(L.w_io + sv, M.ld32(L.w_io + sv) - 1u);
-                if (!core_locked) {
-                    const uint32_t cf = M.ld32(L.w_cpufree + sv);
-                    if (M.ld32(L.w_cqn + sv) == 0u && cf > 0u) {
-                        M.st32(L.w_cpufree + sv, cf - 1u);  // granted at once: not in the ready queue
-                    } else {
-                        M.st32(L.w_rst + slot, rst_pack(RK_WAIT_CPU, sv, hops, 0u));
-                        M.st32(L.w_rst2 + slot, rst2);
-                        if (q_push(L.w_cq, L.w_cqh, L.w_cqn, sv, slot)) {
-                            M.st32(L.w_ready + sv, M.ld32(L.w_ready + sv) + 1u);
-                        } else {
-                            free_slot(slot);
-                        }
-                        return;
+    // ---- ADV stage: the for-loop of _handle_request (server.py:197-276) at step row
+    // `step`: a CPU step, an I/O step, or the END row of the endpoint.
+    AF_CORE void advance(uint64_t a, uint32_t sv, uint32_t step, uint32_t hops, bool core_locked, bool in_io) {
+        const uint32_t at = L.srv + LSRV * sv;
+        const uint32_t kind = (uint32_t)P.row[TREC * step + 2u];
+        if (kind == STEP_CPU) {  // server.py:199-231
+            if (in_io) M.st(at + 1u, M.ld(at + 1u) - 1ull);  // io -= 1
+            if (!core_locked) {
+                const uint64_t w0 = M.ld(at);  // cpu_free | ready<<32
+                const uint64_t q = M.ld(at + 4u);
+                const uint32_t cqn = (uint32_t)(q >> 16) & 0xFFFFu;
+                if (cqn == 0u && (uint32_t)w0 > 0u) {
+                    M.st(at, w0 - 1ull);  // granted at once: not in the ready queue
+                } else {
+                    if (q_push(L.cq, sv, (uint32_t)q & 0xFFFFu, cqn, a, st_pack(RK_WAIT, sv, hops, 0u, step))) {
+                        M.st(at + 4u, q + (1ull << 16));
+                        M.st(at, w0 + (1ull << 32));  // ready += 1
                     }
+                    return;
                 }
-                kind_bits = rst_pack(RK_CPU, sv, hops, 0u);
-            } else {  // I/O step, server.py:235-255
-                if (core_locked) cpu_release(sv);  // the waiter's Timeout is created AFTER this one
-                if (!in_io) M.st32(L.w_io + sv, M.ld32(L.w_io + sv) + 1u);
-                kind_bits = rst_pack(RK_IO, sv, hops, 1u);
             }
-            M.st32(L.w_rst + slot, kind_bits);
-            M.st32(L.w_rst2 + slot, rst2);
-            emit(now + step_time(step), slot);
+            emit(now + row_time(step), a, st_pack(RK_CPU, sv, hops, 0u, step));
+            return;
+        }
+        if (kind == STEP_IO) {  // server.py:235-255
+            if (core_locked) cpu_release(sv);  // the waiter's Timeout is created AFTER this one
+            if (!in_io) M.st(at + 1u, M.ld(at + 1u) + 1ull);  // io += 1
+            emit(now + row_time(step), a, st_pack(RK_IO, sv, hops, 1u, step));
             return;
         }
         // endpoint finished, server.py:257-276: waiter's grant, then transport(), then RAM waiters
         if (core_locked) cpu_release(sv);
-        if (in_io) M.st32(L.w_io + sv, M.ld32(L.w_io + sv) - 1u);
-        const double ram = P.ep_ram[ep];
+        if (in_io) M.st(at + 1u, M.ld(at + 1u) - 1ull);
+        const double ram = u2d(P.row[TREC * step + 1u]);
         if (ram > 0.0) {
-            M.st64(L.d_ramuse + sv, M.ld64(L.d_ramuse + sv) - ram);
-            M.st64(L.d_ramfree + sv, M.ld64(L.d_ramfree + sv) + ram);
-            if (M.ld32(L.w_rqn + sv) > 0u) fu_ram_sv = (int32_t)sv;
+            M.st(at + 3u, d2u(u2d(M.ld(at + 3u)) - ram));  // ram_in_use
+            M.st(at + 2u, d2u(u2d(M.ld(at + 2u)) + ram));  // ram container level
+            if (((M.ld(at + 4u) >> 48) & 0x7FFFu) > 0u) fu_ram_sv = (int32_t)sv;
         }
         fu_send = true;
-        send_slot = slot;
-        send_edge = (uint32_t)P.s_out[sv];
+        send_a = a;
+        send_edge = (uint32_t)(P.srv[SREC * sv + 1u] >> 16) & 0xFFFFu;
         send_hops = hops;
     }
 
     // ---- RAM stage: Container._trigger_get, FIFO with head-of-line blocking ------
     AF_CORE void ram_stage() {
         const uint32_t sv = (uint32_t)fu_ram_sv;
-        if (M.ld32(L.w_rqn + sv) == 0u) {
+        const uint32_t at = L.srv + LSRV * sv;
+        const uint64_t q = M.ld(at + 4u);
+        const uint32_t rqn = (uint32_t)(q >> 48) & 0x7FFFu;
+        if (rqn == 0u) {
             fu_ram_sv = -1;
             return;
         }
-        const uint32_t w = q_front(L.w_rq, L.w_rqh, sv);
-        const uint32_t rst2 = M.ld32(L.w_rst2 + w);
-        const uint32_t ep = rst2 & 0xFFFFu;
-        const double need = P.ep_ram[ep];
-        const double free_ram = M.ld64(L.d_ramfree + sv);
+        const uint32_t head = (uint32_t)(q >> 32) & 0xFFFFu;
+        const uint32_t from = L.rq + 2u * (sv * L.fcap + head);
+        const uint64_t a = M.ld(from);
+        const uint32_t st = (uint32_t)M.ld(from + 1u);
+        const uint32_t step = st_step(st);
+        const double need = u2d(P.row[TREC * step + 1u]);
+        const double free_ram = u2d(M.ld(at + 2u));
         if (free_ram < need) {
             fu_ram_sv = -1;
             return;
         }
-        q_pop(L.w_rq, L.w_rqh, L.w_rqn, sv);
-        M.st64(L.d_ramfree + sv, free_ram - need);
-        M.st64(L.d_ramuse + sv, M.ld64(L.d_ramuse + sv) + need);
+        const uint64_t nq = (q & ~(0x7FFFFFFFull << 32)) | ((uint64_t)((head + 1u) & (L.fcap - 1u)) << 32) |
+                            ((uint64_t)(rqn - 1u) << 48);
+        M.st(at + 4u, nq);
+        M.st(at + 2u, d2u(free_ram - need));
+        M.st(at + 3u, d2u(u2d(M.ld(at + 3u)) + need));
         fu_adv = true;  // keep fu_ram_sv: the queue is looked at again after this waiter
-        adv_slot = w;
+        adv_a = a;
         adv_sv = sv;
-        adv_ep = ep;
-        adv_step = rst2 >> 16;
-        adv_hops = (M.ld32(L.w_rst + w) >> 11) & 0xFFu;
+        adv_step = step;
+        adv_hops = st_hops(st);
         adv_core = false;
         adv_io = false;
     }
 
     // _dispatcher + head of _handle_request (server.py:303-313, 79-149)
-    AF_CORE void server_arrival(uint32_t slot, uint32_t sv, uint32_t hops) {
+    AF_CORE void server_arrival(uint64_t a, uint32_t sv, uint32_t hops) {
         hops += 1u;  // record_hop(SERVER)
-        const uint32_t epb = P.s_epb[sv];
-        const uint32_t n_ep = P.s_epb[sv + 1u] - epb;
-        const uint32_t idx = M.ld32(L.w_arr + sv);
-        M.st32(L.w_arr + sv, idx + 1u);
-        const uint32_t pick = n_ep > 1u ? cold_endpoint_pick(seed, sv, idx, n_ep) : 0u;
+        const uint32_t at = L.srv + LSRV * sv;
+        const uint64_t meta = P.srv[SREC * sv + 1u];
+        const uint32_t epb = (uint32_t)(meta >> 32) & 0xFFFFu;
+        const uint32_t n_ep = (uint32_t)(meta >> 48);
+        const uint64_t w1 = M.ld(at + 1u);  // io | arrivals<<32
+        M.st(at + 1u, w1 + (1ull << 32));
+        const uint32_t pick = n_ep > 1u ? cold_endpoint_pick(seed, sv, (uint32_t)(w1 >> 32), n_ep) : 0u;
         const uint32_t ep = epb + pick;
-        const uint32_t step0 = P.ep_stepb[ep];
-        const double ram = P.ep_ram[ep];
+        const double ram = u2d(P.ep[PREC * ep]);
+        const uint32_t step0 = (uint32_t)P.ep[PREC * ep + 1u];
         if (ram > 0.0) {  // server.py:146-149
-            if (ram > P.s_ram[sv] || M.ld32(L.w_rblk + sv)) {
+            const uint64_t q = M.ld(at + 4u);
+            if (ram > u2d(P.srv[SREC * sv]) || (q >> 63)) {
                 // can never be served: it (and everything queued behind it) waits
                 // forever in the reference, observable nowhere -> dropped here.
                 flags |= FLAG_RAM_STARVED;
-                M.st32(L.w_rblk + sv, 1u);
-                free_slot(slot);
+                M.st(at + 4u, q | (1ull << 63));
+                live -= 1u;
                 return;
             }
-            const double free_ram = M.ld64(L.d_ramfree + sv);
-            if (M.ld32(L.w_rqn + sv) == 0u && free_ram >= ram) {
-                M.st64(L.d_ramfree + sv, free_ram - ram);
-                M.st64(L.d_ramuse + sv, M.ld64(L.d_ramuse + sv) + ram);
+            const double free_ram = u2d(M.ld(at + 2u));
+            const uint32_t rqn = (uint32_t)(q >> 48) & 0x7FFFu;
+            if (rqn == 0u && free_ram >= ram) {
+                M.st(at + 2u, d2u(free_ram - ram));
+                M.st(at + 3u, d2u(u2d(M.ld(at + 3u)) + ram));
             } else {
-                M.st32(L.w_rst + slot, rst_pack(RK_WAIT_RAM, sv, hops, 0u));
-                M.st32(L.w_rst2 + slot, ep | (step0 << 16));
-                if (!q_push(L.w_rq, L.w_rqh, L.w_rqn, sv, slot)) free_slot(slot);
+                if (q_push(L.rq, sv, (uint32_t)(q >> 32) & 0xFFFFu, rqn, a, st_pack(RK_WAIT, sv, hops, 0u, step0)))
+                    M.st(at + 4u, q + (1ull << 48));
                 return;
             }
         }
         fu_adv = true;
-        adv_slot = slot;
+        adv_a = a;
         adv_sv = sv;
-        adv_ep = ep;
         adv_step = step0;
         adv_hops = hops;
         adv_core = false;
         adv_io = false;
     }
 
+    // ---- load balancer order list (lb_algorithms.py, injection.py:201-226) ----------
+    AF_CORE uint32_t lb_get(uint32_t i) const {
+        return P.n_lb_edges <= 8u ? (uint32_t)(lb_list >> (8u * i)) & 0xFFu : (uint32_t)M.ld(L.lb + i);
+    }
+    AF_CORE void lb_set(uint32_t i, uint32_t e) {
+        if (P.n_lb_edges <= 8u) {
+            lb_list = (lb_list & ~(0xFFull << (8u * i))) | ((uint64_t)e << (8u * i));
+        } else {
+            M.st(L.lb + i, (uint64_t)e);
+        }
+    }
+    AF_CORE uint32_t lb_pick() {
+        uint32_t out = lb_get(0u);
+        if (P.lb_algo == LB_LEAST_CONNECTIONS) {  // lb_algorithms.py:10-20: first minimum in current order
+            uint32_t best = (uint32_t)M.ld(L.edge + LEDGE * out);
+            for (uint32_t i = 1u; i < lb_n; ++i) {
+                const uint32_t cand = lb_get(i);
+                const uint32_t c = (uint32_t)M.ld(L.edge + LEDGE * cand);
+                if ((int32_t)c < (int32_t)best) {
+                    best = c;
+                    out = cand;
+                }
+            }
+        } else if (P.n_lb_edges <= 8u) {  // round_robin: first key, move_to_end (lb_algorithms.py:22-36)
+            const uint32_t sh = 8u * (lb_n - 1u);  // bytes above the live entries may be stale: mask them
+            lb_list = ((lb_list >> 8) & ((1ull << sh) - 1ull)) | ((uint64_t)out << sh);
+        } else {
+            for (uint32_t i = 1u; i < lb_n; ++i) lb_set(i - 1u, lb_get(i));
+            lb_set(lb_n - 1u, out);
+        }
+        return out;
+    }
+
     // EdgeRuntime._deliver after the timeout (edge.py:110-116) + the target node
-    AF_CORE void deliver(uint32_t slot, uint32_t e, uint32_t hops) {
+    AF_CORE void deliver(uint64_t a, uint32_t e, uint32_t hops) {
         hops += 1u;  // record_hop(NETWORK_CONNECTION)
-        M.st32(L.w_conn + e, M.ld32(L.w_conn + e) - 1u);
-        const uint32_t tk = P.e_tkind[e];
+        const uint32_t at = L.edge + LEDGE * e;
+        M.st(at, M.ld(at) - 1ull);  // conn -= 1
+        const uint32_t meta = (uint32_t)P.edge[EREC * e + 3u];
+        const uint32_t tk = meta & 0xFFu;
         if (tk == NODE_CLIENT) {  // ClientRuntime._forwarder, client.py:46-71
             hops += 1u;
             if (hops > 3u) {
                 if (O.clock != nullptr) {
                     if (n_comp < O.clock_cap) {
-                        O.clock[2u * n_comp] = M.ld64(L.d_t0 + slot);
+                        O.clock[2u * n_comp] = u2d(a);
                         O.clock[2u * n_comp + 1u] = now;
                     } else {
                         flags |= FLAG_CLOCK_OVERFLOW;
                     }
                 }
                 n_comp += 1u;
-                free_slot(slot);
+                live -= 1u;
             } else {
                 fu_send = true;
-                send_slot = slot;
-                send_edge = (uint32_t)P.client_out_edge;
+                send_a = a;
+                send_edge = P.client_out_edge;
                 send_hops = hops;
             }
         } else if (tk == NODE_LB) {  // LoadBalancerRuntime._forwarder, load_balancer.py:60-72
-            hops += 1u;
-            uint32_t out = M.ld32(L.w_lb);
-            if (P.lb_algo == LB_LEAST_CONNECTIONS) {  // lb_algorithms.py:10-20
-                uint32_t best = M.ld32(L.w_conn + out);
-                for (uint32_t i = 1u; i < lb_n; ++i) {
-                    const uint32_t cand = M.ld32(L.w_lb + i);
-                    const uint32_t c = M.ld32(L.w_conn + cand);
-                    if ((int32_t)c < (int32_t)best) {
-                        best = c;
-                        out = cand;
-                    }
-                }
-            } else {  // round_robin: first key, move_to_end (lb_algorithms.py:22-36)
-                for (uint32_t i = 1u; i < lb_n; ++i) M.st32(L.w_lb + i - 1u, M.ld32(L.w_lb + i));
-                M.st32(L.w_lb + lb_n - 1u, out);
-            }
             fu_send = true;
-            send_slot = slot;
-            send_edge = out;
-            send_hops = hops;
+            send_a = a;
+            send_edge = lb_pick();
+            send_hops = hops + 1u;
         } else {
-            server_arrival(slot, (uint32_t)P.e_tidx[e], hops);
+            server_arrival(a, (meta >> 8) & 0xFFu, hops);
         }
     }
 
@@ -596,40 +610,36 @@ struct Lane {
     AF_CORE void apply_emarks() {
         for (;;) {
             const uint32_t i = emark_i++;
-            const uint32_t e = (uint32_t)P.em_edge[i];
-            M.st64(L.d_spike + e, M.ld64(L.d_spike + e) + P.em_delta[i]);
+            const uint32_t at = L.edge + LEDGE * (uint32_t)P.emark[MREC * i + 2u] + 1u;
+            M.st(at, d2u(u2d(M.ld(at)) + u2d(P.emark[MREC * i + 1u])));
             n_marks += 1u;
-            if (emark_i >= P.n_edge_marks || P.em_time[emark_i] > now) break;
+            if (emark_i >= P.n_edge_marks || u2d(P.emark[MREC * emark_i]) > now) break;
         }
-        t_emark = emark_i < P.n_edge_marks ? P.em_time[emark_i] : AF_INF;
+        t_emark = emark_i < P.n_edge_marks ? u2d(P.emark[MREC * emark_i]) : AF_INF;
     }
     AF_CORE void apply_smarks() {
         for (;;) {
             const uint32_t i = smark_i++;
-            const int32_t e = P.sm_edge[i];
+            const uint64_t meta = P.smark[NREC * i + 1u];
+            const uint32_t e1 = (uint32_t)meta;  // lb edge + 1, 0 = server not behind the LB
             n_marks += 1u;
-            if (e >= 0) {
-                uint32_t pos = NONE32;
+            if (e1 != 0u) {
+                const uint32_t e = e1 - 1u;
+                uint32_t pos = 0xFFFFFFFFu;
                 for (uint32_t k = 0u; k < lb_n; ++k)
-                    if (M.ld32(L.w_lb + k) == (uint32_t)e) pos = k;
-                if (P.sm_down[i]) {  // lb_out_edges.pop(edge_id, None)
-                    if (pos != NONE32) {
-                        for (uint32_t k = pos + 1u; k < lb_n; ++k) M.st32(L.w_lb + k - 1u, M.ld32(L.w_lb + k));
-                        lb_n -= 1u;
-                    }
-                } else {  // re-insert + move_to_end
-                    if (pos != NONE32) {
-                        for (uint32_t k = pos + 1u; k < lb_n; ++k) M.st32(L.w_lb + k - 1u, M.ld32(L.w_lb + k));
-                        M.st32(L.w_lb + lb_n - 1u, (uint32_t)e);
-                    } else {
-                        M.st32(L.w_lb + lb_n, (uint32_t)e);
-                        lb_n += 1u;
-                    }
+                    if (lb_get(k) == e) pos = k;
+                if (pos != 0xFFFFFFFFu) {  // remove (pop() and the re-insert both start by removing)
+                    for (uint32_t k = pos + 1u; k < lb_n; ++k) lb_set(k - 1u, lb_get(k));
+                    lb_n -= 1u;
+                }
+                if (!(meta >> 32)) {  // SERVER_UP: append at the end (move_to_end)
+                    lb_set(lb_n, e);
+                    lb_n += 1u;
                 }
             }
-            if (smark_i >= P.n_srv_marks || P.sm_time[smark_i] > now) break;
+            if (smark_i >= P.n_srv_marks || u2d(P.smark[NREC * smark_i]) > now) break;
         }
-        t_smark = smark_i < P.n_srv_marks ? P.sm_time[smark_i] : AF_INF;
+        t_smark = smark_i < P.n_srv_marks ? u2d(P.smark[NREC * smark_i]) : AF_INF;
     }
 
     // ---- sampler tick (metrics/collector.py:50-66) --------------------------------
@@ -638,14 +648,16 @@ struct Lane {
             if (n_ticks < O.tick_cap) {
                 const uint32_t k = n_ticks;
                 if (P.metrics_mask & METRIC_EDGE)
-                    for (uint32_t e = 0u; e < P.n_edges; ++e) O.samples[e * O.tick_cap + k] = M.ld32(L.w_conn + e);
+                    for (uint32_t e = 0u; e < P.n_edges; ++e)
+                        O.samples[e * O.tick_cap + k] = (uint32_t)M.ld(L.edge + LEDGE * e);
                 constexpr uint32_t all = METRIC_READY | METRIC_IO | METRIC_RAM;
                 if ((P.metrics_mask & all) == all)
                     for (uint32_t v = 0u; v < P.n_servers; ++v) {
+                        const uint32_t at = L.srv + LSRV * v;
                         const uint32_t base = (P.n_edges + 3u * v) * O.tick_cap + k;
-                        O.samples[base] = M.ld32(L.w_ready + v);
-                        O.samples[base + O.tick_cap] = M.ld32(L.w_io + v);
-                        O.samples[base + 2u * O.tick_cap] = __builtin_bit_cast(uint32_t, (float)M.ld64(L.d_ramuse + v));
+                        O.samples[base] = (uint32_t)(M.ld(at) >> 32);
+                        O.samples[base + O.tick_cap] = (uint32_t)M.ld(at + 1u);
+                        O.samples[base + 2u * O.tick_cap] = __builtin_bit_cast(uint32_t, (float)u2d(M.ld(at + 3u)));
                     }
             } else {
                 flags |= FLAG_TICK_OVERFLOW;
@@ -655,48 +667,43 @@ struct Lane {
     }
 
     // ---- life cycle -----------------------------------------------------------------
-    // `ovr` : per-lane reader of the override columns, ovr(k) -> double, k-th column
+    // `ovr` : per-lane reader of the override columns, ovr(k) -> double, k-th column;
+    // ovr_index of a STEP_TIME column is a step ROW.
     template <class OvrFn>
     AF_CORE void init(const uint32_t* ovr_param, const uint32_t* ovr_index, uint32_t n_ovr, OvrFn ovr) {
         now = 0.0;
         g_now = 0.0;
         g_wend = 0.0;
         g_lam = 0.0;
-        g_draws = heap_n = seq = bump = free_top = live = max_live = emark_i = smark_i = 0u;
+        g_draws = heap_n = seq = live = max_live = emark_i = smark_i = 0u;
         n_gen = n_comp = n_drop = n_events = n_ticks = n_marks = flags = rounds = 0u;
-        hole = fu_send = fu_adv = false;
+        hole = fu_send = fu_adv = fu_grant = false;
         pend_count = 0u;
         gen_first = true;
-        fu_grant = NONE32;
         fu_ram_sv = -1;
         users_mean = P.gen_users_mean;
         users_sigma = P.gen_users_sigma;
         rpm = P.gen_rpm_mean;
         for (uint32_t e = 0u; e < P.n_edges; ++e) {
-            M.st64(L.d_spike + e, 0.0);
-            M.st32(L.w_conn + e, 0u);
-            M.st32(L.w_sends + e, 0u);
-            if (L.ovr_mask & (1u << PARAM_EDGE_MEAN)) M.st64(L.d_emean + e, P.e_mean[e]);
-            if (L.ovr_mask & (1u << PARAM_EDGE_SIGMA)) M.st64(L.d_esig + e, P.e_sigma[e]);
-            if (L.ovr_mask & (1u << PARAM_EDGE_DROPOUT)) M.st64(L.d_edrop + e, P.e_drop[e]);
+            M.st(L.edge + LEDGE * e, 0ull);
+            M.st(L.edge + LEDGE * e + 1u, d2u(0.0));
+            if (L.ovr_mask & (1u << PARAM_EDGE_MEAN)) M.st(L.emean + e, P.edge[EREC * e]);
+            if (L.ovr_mask & (1u << PARAM_EDGE_SIGMA)) M.st(L.esig + e, P.edge[EREC * e + 1u]);
+            if (L.ovr_mask & (1u << PARAM_EDGE_DROPOUT)) M.st(L.edrop + e, P.edge[EREC * e + 2u]);
         }
         if (L.ovr_mask & (1u << PARAM_STEP_TIME))
-            for (uint32_t i = 0u; i < P.n_steps; ++i) M.st64(L.d_stime + i, P.st_time[i]);
+            for (uint32_t r = 0u; r < P.n_rows; ++r) M.st(L.stime + r, P.row[TREC * r]);
         for (uint32_t v = 0u; v < P.n_servers; ++v) {  // build_containers: init full
-            M.st64(L.d_ramfree + v, P.s_ram[v]);
-            M.st64(L.d_ramuse + v, 0.0);
-            M.st32(L.w_cpufree + v, P.s_cores[v]);
-            M.st32(L.w_ready + v, 0u);
-            M.st32(L.w_io + v, 0u);
-            M.st32(L.w_arr + v, 0u);
-            M.st32(L.w_rblk + v, 0u);
-            M.st32(L.w_cqh + v, 0u);
-            M.st32(L.w_cqn + v, 0u);
-            M.st32(L.w_rqh + v, 0u);
-            M.st32(L.w_rqn + v, 0u);
+            const uint32_t at = L.srv + LSRV * v;
+            M.st(at, P.srv[SREC * v + 1u] & 0xFFFFull);  // cpu_free = cores, ready = 0
+            M.st(at + 1u, 0ull);
+            M.st(at + 2u, P.srv[SREC * v]);  // RAM level = ram_mb
+            M.st(at + 3u, d2u(0.0));
+            M.st(at + 4u, 0ull);
         }
         lb_n = P.n_lb_edges;
-        for (uint32_t i = 0u; i < lb_n; ++i) M.st32(L.w_lb + i, (uint32_t)P.lb_edges[i]);
+        lb_list = 0ull;
+        for (uint32_t i = 0u; i < lb_n; ++i) lb_set(i, (uint32_t)P.lb[i]);
         for (uint32_t k = 0u; k < n_ovr; ++k) {
             const double v = ovr(k);
             const uint32_t idx = ovr_index[k];
@@ -704,17 +711,17 @@ struct Lane {
                 case PARAM_GEN_USERS_MEAN: users_mean = v; break;
                 case PARAM_GEN_USERS_SIGMA: users_sigma = v; break;
                 case PARAM_GEN_RPM_MEAN: rpm = v; break;
-                case PARAM_EDGE_MEAN: M.st64(L.d_emean + idx, v); break;
-                case PARAM_EDGE_SIGMA: M.st64(L.d_esig + idx, v); break;
-                case PARAM_EDGE_DROPOUT: M.st64(L.d_edrop + idx, v); break;
-                case PARAM_STEP_TIME: M.st64(L.d_stime + idx, v); break;
+                case PARAM_EDGE_MEAN: M.st(L.emean + idx, d2u(v)); break;
+                case PARAM_EDGE_SIGMA: M.st(L.esig + idx, d2u(v)); break;
+                case PARAM_EDGE_DROPOUT: M.st(L.edrop + idx, d2u(v)); break;
+                case PARAM_STEP_TIME: M.st(L.stime + idx, d2u(v)); break;
                 default: break;
             }
         }
         t_gen = 0.0;  // the generator's Initialize runs as the first "arrival" round (gen_first)
         t_tick = 0.0 + P.sample_period;
-        t_emark = P.n_edge_marks ? P.em_time[0] : AF_INF;
-        t_smark = P.n_srv_marks ? P.sm_time[0] : AF_INF;
+        t_emark = P.n_edge_marks ? u2d(P.emark[0]) : AF_INF;
+        t_smark = P.n_srv_marks ? u2d(P.smark[0]) : AF_INF;
     }
 
     // One next-event round.  Returns false once the scenario reached the horizon.
@@ -726,10 +733,14 @@ struct Lane {
     // (server.py:235-276): own I/O timer before the CPU waiter's; on endpoint end
     // the CPU waiter's timer, then transport(), then the RAM waiters.
     AF_CORE bool round() {
+        // the root entry is fetched in full up front: three independent LDS reads
+        const double t_heap = heap_n > 0u ? u2d(M.ld(L.hk)) : AF_INF;
+        const uint64_t root_a = M.ld(L.ha);
+        const uint32_t root_st = (uint32_t)M.ld(L.hb);
         // next event among {heap, arrival, tick, server marks, edge marks}; on equal
         // times the LATER test wins: edge marks < server marks < tick < arrival < heap.
         uint32_t cls = 4u;
-        double t = heap_n > 0u ? M.ld64(L.d_hk) : AF_INF;
+        double t = t_heap;
         if (t_gen <= t) { cls = 3u; t = t_gen; }
         if (t_tick <= t) { cls = 2u; t = t_tick; }
         if (t_smark <= t) { cls = 1u; t = t_smark; }
@@ -740,25 +751,19 @@ struct Lane {
         now = t;
 
         if (cls == 4u) {
-            const uint32_t slot = M.ld32(L.w_hs);
             hole = true;
-            const uint32_t st = M.ld32(L.w_rst + slot);
-            const uint32_t kind = st & 7u;
-            const uint32_t idx = (st >> 3) & 0xFFu;
-            const uint32_t hops = (st >> 11) & 0xFFu;
             n_events += 1u;
+            const uint32_t kind = st_kind(root_st);
             if (kind == RK_TRANSIT) {
-                deliver(slot, idx, hops);
-            } else {  // CPU or I/O step finished: the for-loop moves to the next step
-                const uint32_t rst2 = M.ld32(L.w_rst2 + slot);
+                deliver(root_a, st_idx(root_st), st_hops(root_st));
+            } else {  // CPU or I/O step finished: the for-loop moves to the next step row
                 fu_adv = true;
-                adv_slot = slot;
-                adv_sv = idx;
-                adv_ep = rst2 & 0xFFFFu;
-                adv_step = (rst2 >> 16) + 1u;
-                adv_hops = hops;
+                adv_a = root_a;
+                adv_sv = st_idx(root_st);
+                adv_step = st_step(root_st) + 1u;
+                adv_hops = st_hops(root_st);
                 adv_core = kind == RK_CPU;
-                adv_io = (st >> 19) & 1u;
+                adv_io = st_io(root_st) != 0u;
             }
         } else if (cls == 3u) {  // RqsGeneratorRuntime._event_arrival (rqs_generator.py:101-119)
             const bool first = gen_first;  // Initialize: only draws the first gap
@@ -766,17 +771,14 @@ struct Lane {
             const double t_arrival = now;
             const double gap = next_gap();
             t_gen = gap >= 0.0 ? now + gap : AF_INF;
-            uint32_t slot = NONE32;
             if (!first) {
                 n_gen += 1u;
                 n_events += 1u;
-                slot = alloc_slot();
-            }
-            if (slot != NONE32) {
-                M.st64(L.d_t0 + slot, t_arrival);
+                live += 1u;
+                if (live > max_live) max_live = live;
                 fu_send = true;
-                send_slot = slot;
-                send_edge = (uint32_t)P.gen_out_edge;
+                send_a = d2u(t_arrival);
+                send_edge = P.gen_out_edge;
                 send_hops = 1u;  // record_hop(GENERATOR)
             }
         } else if (cls == 2u) {
@@ -793,21 +795,20 @@ struct Lane {
             // stops early (stage order preserved) when it is full -- rare.
             if (fu_adv) {
                 fu_adv = false;
-                advance(adv_slot, adv_sv, adv_ep, adv_step, adv_hops, adv_core, adv_io);
+                advance(adv_a, adv_sv, adv_step, adv_hops, adv_core, adv_io);
             }
             bool room = pend_count < 2u;
-            if (fu_grant != NONE32 && room) {
-                const uint32_t w = fu_grant;
-                fu_grant = NONE32;
-                cpu_granted(w, fu_grant_sv);
+            if (fu_grant && room) {
+                fu_grant = false;
+                cpu_granted();
                 room = pend_count < 2u;
             }
-            if (fu_send && fu_grant == NONE32 && room) {
+            if (fu_send && !fu_grant && room) {
                 fu_send = false;
-                edge_send(send_slot, send_edge, send_hops);
+                edge_send(send_a, send_edge, send_hops);
             }
-            if (fu_ram_sv >= 0 && fu_grant == NONE32 && !fu_send) ram_stage();
-            const bool more = fu_adv || fu_grant != NONE32 || fu_send || fu_ram_sv >= 0;
+            if (fu_ram_sv >= 0 && !fu_grant && !fu_send) ram_stage();
+            const bool more = fu_adv || fu_grant || fu_send || fu_ram_sv >= 0;
             heap_commit(!more);
             if (!more) break;
         }

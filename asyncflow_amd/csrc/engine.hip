@@ -7,10 +7,9 @@
 //
 // Memory plan
 //   LDS  : [plan blob (read-only, shared by the 64 lanes)]
-//          [per-lane state, SoA [index][lane]: f64 region, then u32 region]
+//          [per-lane state: 64-bit words, SoA [index][lane]]
 //          -> any per-lane index pattern is bank-conflict free
-//             (ds_read_b64: bank = 2*lane mod 64 per 32-lane group;
-//              ds_read_b32: bank = lane mod 32).
+//             (ds_read_b64: bank pair = 2*lane mod 64 within each 32-lane group).
 //   HBM  : outputs only (rqs_clock, sampled series, counts); per-lane state too
 //          when 64 * bytes_per_lane exceeds the 160 KiB LDS of a CU ("global
 //          state" mode, same [index][lane] layout => coalesced for equal indices).
@@ -25,6 +24,7 @@
 
 #include "../../include/asyncflow_hip.h"
 #include "af_core.hpp"
+#include "af_plan_pack.hpp"
 
 #define LDS_AS __attribute__((address_space(3)))
 
@@ -33,19 +33,12 @@ namespace {
 constexpr uint32_t kLdsLimit = 160u * 1024u;  // bytes per workgroup on gfx950
 constexpr uint32_t kWave = 64u;
 
-enum BlobArray : uint32_t {
-    B_E_MEAN, B_E_SIGMA, B_E_DROP, B_S_RAM, B_EP_RAM, B_ST_TIME, B_EM_TIME, B_EM_DELTA, B_SM_TIME,
-    B_LB_EDGES, B_E_TKIND, B_E_TIDX, B_E_DIST, B_S_CORES, B_S_OUT, B_S_EPB, B_EP_STEPB, B_ST_KIND,
-    B_EM_EDGE, B_SM_EDGE, B_SM_DOWN, B_COUNT
-};
-
 struct KArgs {
     double total_time, sample_period, gen_users_mean, gen_users_sigma, gen_rpm_mean, gen_window_s;
-    uint32_t metrics_mask, gen_users_dist;
-    int32_t gen_out_edge, client_out_edge;
-    uint32_t n_edges, n_servers, lb_algo, n_lb_edges, n_endpoints, n_steps, n_edge_marks, n_srv_marks;
-    uint32_t off[B_COUNT];  // byte offsets of the arrays inside the blob
-    uint32_t blob_bytes;    // multiple of 16
+    uint32_t metrics_mask, gen_users_dist, gen_out_edge, client_out_edge;
+    uint32_t n_edges, n_servers, lb_algo, n_lb_edges, n_rows, n_edge_marks, n_srv_marks;
+    uint32_t off_edge, off_srv, off_ep, off_row, off_emark, off_smark, off_lb;  // word offsets in the blob
+    uint32_t blob_bytes;  // multiple of 16
     const unsigned char* blob;
     af::Layout L;
     uint32_t n_scen;
@@ -64,26 +57,19 @@ struct KArgs {
 };
 
 struct MemLds {
-    LDS_AS double* d;    // already offset by the lane
-    LDS_AS uint32_t* w;
-    __device__ __forceinline__ double ld64(uint32_t i) const { return d[i * kWave]; }
-    __device__ __forceinline__ void st64(uint32_t i, double v) const { d[i * kWave] = v; }
-    __device__ __forceinline__ uint32_t ld32(uint32_t i) const { return w[i * kWave]; }
-    __device__ __forceinline__ void st32(uint32_t i, uint32_t v) const { w[i * kWave] = v; }
+    LDS_AS uint64_t* w;  // already offset by the lane
+    __device__ __forceinline__ uint64_t ld(uint32_t i) const { return w[i * kWave]; }
+    __device__ __forceinline__ void st(uint32_t i, uint64_t v) const { w[i * kWave] = v; }
 };
 
 struct MemGlobal {
-    double* d;
-    uint32_t* w;
-    __device__ __forceinline__ double ld64(uint32_t i) const { return d[i * kWave]; }
-    __device__ __forceinline__ void st64(uint32_t i, double v) const { d[i * kWave] = v; }
-    __device__ __forceinline__ uint32_t ld32(uint32_t i) const { return w[i * kWave]; }
-    __device__ __forceinline__ void st32(uint32_t i, uint32_t v) const { w[i * kWave] = v; }
+    uint64_t* w;
+    __device__ __forceinline__ uint64_t ld(uint32_t i) const { return w[i * kWave]; }
+    __device__ __forceinline__ void st(uint32_t i, uint64_t v) const { w[i * kWave] = v; }
 };
 
-template <class T>
-__device__ __forceinline__ const LDS_AS T* lds_arr(unsigned char* smem, uint32_t off) {
-    return (const LDS_AS T*)(smem + off);
+__device__ __forceinline__ const LDS_AS uint64_t* lds_words(unsigned char* smem, uint32_t word_off) {
+    return (const LDS_AS uint64_t*)smem + word_off;
 }
 
 template <bool kLdsState>
@@ -111,31 +97,16 @@ __global__ void __launch_bounds__(64) af_des_kernel(const KArgs a) {
     P.n_servers = a.n_servers;
     P.lb_algo = a.lb_algo;
     P.n_lb_edges = a.n_lb_edges;
-    P.n_endpoints = a.n_endpoints;
-    P.n_steps = a.n_steps;
+    P.n_rows = a.n_rows;
     P.n_edge_marks = a.n_edge_marks;
     P.n_srv_marks = a.n_srv_marks;
-    P.e_mean = lds_arr<double>(smem, a.off[B_E_MEAN]);
-    P.e_sigma = lds_arr<double>(smem, a.off[B_E_SIGMA]);
-    P.e_drop = lds_arr<double>(smem, a.off[B_E_DROP]);
-    P.s_ram = lds_arr<double>(smem, a.off[B_S_RAM]);
-    P.ep_ram = lds_arr<double>(smem, a.off[B_EP_RAM]);
-    P.st_time = lds_arr<double>(smem, a.off[B_ST_TIME]);
-    P.em_time = lds_arr<double>(smem, a.off[B_EM_TIME]);
-    P.em_delta = lds_arr<double>(smem, a.off[B_EM_DELTA]);
-    P.sm_time = lds_arr<double>(smem, a.off[B_SM_TIME]);
-    P.lb_edges = lds_arr<int32_t>(smem, a.off[B_LB_EDGES]);
-    P.e_tkind = lds_arr<uint32_t>(smem, a.off[B_E_TKIND]);
-    P.e_tidx = lds_arr<int32_t>(smem, a.off[B_E_TIDX]);
-    P.e_dist = lds_arr<uint32_t>(smem, a.off[B_E_DIST]);
-    P.s_cores = lds_arr<uint32_t>(smem, a.off[B_S_CORES]);
-    P.s_out = lds_arr<int32_t>(smem, a.off[B_S_OUT]);
-    P.s_epb = lds_arr<uint32_t>(smem, a.off[B_S_EPB]);
-    P.ep_stepb = lds_arr<uint32_t>(smem, a.off[B_EP_STEPB]);
-    P.st_kind = lds_arr<uint32_t>(smem, a.off[B_ST_KIND]);
-    P.em_edge = lds_arr<int32_t>(smem, a.off[B_EM_EDGE]);
-    P.sm_edge = lds_arr<int32_t>(smem, a.off[B_SM_EDGE]);
-    P.sm_down = lds_arr<uint32_t>(smem, a.off[B_SM_DOWN]);
+    P.edge = lds_words(smem, a.off_edge);
+    P.srv = lds_words(smem, a.off_srv);
+    P.ep = lds_words(smem, a.off_ep);
+    P.row = lds_words(smem, a.off_row);
+    P.emark = lds_words(smem, a.off_emark);
+    P.smark = lds_words(smem, a.off_smark);
+    P.lb = lds_words(smem, a.off_lb);
 
     const uint32_t scen = blockIdx.x * kWave + lane;
     const bool active = scen < a.n_scen;
@@ -153,8 +124,7 @@ __global__ void __launch_bounds__(64) af_des_kernel(const KArgs a) {
 
     if constexpr (kLdsState) {
         MemLds M;
-        M.d = (LDS_AS double*)(smem + a.blob_bytes) + lane;
-        M.w = (LDS_AS uint32_t*)(smem + a.blob_bytes + (size_t)a.L.n_d * kWave * 8u) + lane;
+        M.w = (LDS_AS uint64_t*)(smem + a.blob_bytes) + lane;
         af::Lane<MemLds> S(P, a.L, M, O, seed);
         bool run = active;
         if (active) S.init(a.ovr_param, a.ovr_index, a.n_ovr, ovr);
@@ -165,8 +135,7 @@ __global__ void __launch_bounds__(64) af_des_kernel(const KArgs a) {
     } else {
         unsigned char* base = a.state + (size_t)blockIdx.x * a.state_bytes_per_wave;
         MemGlobal M;
-        M.d = reinterpret_cast<double*>(base) + lane;
-        M.w = reinterpret_cast<uint32_t*>(base + (size_t)a.L.n_d * kWave * 8u) + lane;
+        M.w = reinterpret_cast<uint64_t*>(base) + lane;
         af::Lane<MemGlobal> S(P, a.L, M, O, seed);
         bool run = active;
         if (active) S.init(a.ovr_param, a.ovr_index, a.n_ovr, ovr);
@@ -235,26 +204,11 @@ struct af_engine {
     size_t sweep_cap = 0;
     uint32_t request_capacity = 0, fifo_capacity = 0, force_global = 0;
     uint32_t n_lb_edges = 0;
+    std::vector<uint32_t> row_of_step;
     af_stats_t stats{};
 };
 
 namespace {
-
-template <class T>
-void put_array(std::vector<unsigned char>& blob, uint32_t* off, const T* src, size_t n) {
-    while (blob.size() % 8) blob.push_back(0);
-    *off = (uint32_t)blob.size();
-    const size_t bytes = (n ? n : 1) * sizeof(T);
-    blob.resize(blob.size() + bytes, 0);
-    if (n && src) std::memcpy(blob.data() + *off, src, n * sizeof(T));
-}
-
-template <class T>
-void put_widened(std::vector<unsigned char>& blob, uint32_t* off, const T* src, size_t n) {
-    std::vector<uint32_t> w(n ? n : 1, 0u);
-    for (size_t i = 0; i < n; ++i) w[i] = (uint32_t)src[i];
-    put_array<uint32_t>(blob, off, w.data(), n);
-}
 
 int validate_plan(const af_plan_t* p) {
     if (!p) return fail(AF_ERR_INVALID, "plan is NULL");
@@ -262,7 +216,6 @@ int validate_plan(const af_plan_t* p) {
         return fail(AF_ERR_ABI, "af_plan_t ABI mismatch (version or size)");
     if (!(p->total_time > 0.0) || !(p->sample_period > 0.0)) return fail(AF_ERR_INVALID, "bad horizon or sample period");
     if (p->n_edges == 0 || p->n_edges > 255 || p->n_servers > 255) return fail(AF_ERR_INVALID, "edge/server count out of range (1..255 edges, <=255 servers)");
-    if (p->n_endpoints > 65535 || p->n_steps > 65535) return fail(AF_ERR_INVALID, "too many endpoints/steps (<= 65535)");
     if (p->gen_out_edge < 0 || (uint32_t)p->gen_out_edge >= p->n_edges) return fail(AF_ERR_INVALID, "generator out edge invalid");
     if (p->client_out_edge < 0 || (uint32_t)p->client_out_edge >= p->n_edges) return fail(AF_ERR_INVALID, "client out edge invalid");
     if (p->has_lb && p->n_lb_edges == 0) return fail(AF_ERR_INVALID, "load balancer without out edges");
@@ -335,43 +288,34 @@ int af_engine_create(const af_plan_t* plan, int device, const af_engine_options_
     a.n_servers = plan->n_servers;
     a.lb_algo = plan->lb_algo;
     a.n_lb_edges = plan->n_lb_edges;
-    a.n_endpoints = plan->n_endpoints;
-    a.n_steps = plan->n_steps;
     a.n_edge_marks = plan->n_edge_marks;
     a.n_srv_marks = plan->n_srv_marks;
     a.n_series = plan->n_edges + 3u * plan->n_servers;
 
-    std::vector<unsigned char> blob;
-    put_array(blob, &a.off[B_E_MEAN], plan->edge_mean, plan->n_edges);
-    put_array(blob, &a.off[B_E_SIGMA], plan->edge_sigma, plan->n_edges);
-    put_array(blob, &a.off[B_E_DROP], plan->edge_dropout, plan->n_edges);
-    put_array(blob, &a.off[B_S_RAM], plan->srv_ram_mb, plan->n_servers);
-    put_array(blob, &a.off[B_EP_RAM], plan->ep_ram, plan->n_endpoints);
-    put_array(blob, &a.off[B_ST_TIME], plan->step_time, plan->n_steps);
-    put_array(blob, &a.off[B_EM_TIME], plan->emark_time, plan->n_edge_marks);
-    put_array(blob, &a.off[B_EM_DELTA], plan->emark_delta, plan->n_edge_marks);
-    put_array(blob, &a.off[B_SM_TIME], plan->smark_time, plan->n_srv_marks);
-    put_array(blob, &a.off[B_LB_EDGES], plan->lb_edges, plan->n_lb_edges);
-    put_widened(blob, &a.off[B_E_TKIND], plan->edge_target_kind, plan->n_edges);
-    put_array(blob, &a.off[B_E_TIDX], plan->edge_target_idx, plan->n_edges);
-    put_widened(blob, &a.off[B_E_DIST], plan->edge_dist, plan->n_edges);
-    put_array(blob, &a.off[B_S_CORES], plan->srv_cores, plan->n_servers);
-    put_array(blob, &a.off[B_S_OUT], plan->srv_out_edge, plan->n_servers);
-    put_array(blob, &a.off[B_S_EPB], plan->srv_ep_begin, (size_t)plan->n_servers + 1);
-    put_array(blob, &a.off[B_EP_STEPB], plan->ep_step_begin, (size_t)plan->n_endpoints + 1);
-    put_widened(blob, &a.off[B_ST_KIND], plan->step_kind, plan->n_steps);
-    put_array(blob, &a.off[B_EM_EDGE], plan->emark_edge, plan->n_edge_marks);
-    put_array(blob, &a.off[B_SM_EDGE], plan->smark_lb_edge, plan->n_srv_marks);
-    put_widened(blob, &a.off[B_SM_DOWN], plan->smark_down, plan->n_srv_marks);
-    while (blob.size() % 16) blob.push_back(0);
-    a.blob_bytes = (uint32_t)blob.size();
+    af::PackedPlan pk;
+    const std::string why = af::pack_plan(*plan, pk);
+    if (!why.empty()) {
+        delete e;
+        return fail(AF_ERR_INVALID, why);
+    }
+    a.n_rows = pk.n_rows;
+    a.off_edge = pk.off_edge;
+    a.off_srv = pk.off_srv;
+    a.off_ep = pk.off_ep;
+    a.off_row = pk.off_row;
+    a.off_emark = pk.off_emark;
+    a.off_smark = pk.off_smark;
+    a.off_lb = pk.off_lb;
+    a.blob_bytes = (uint32_t)(pk.words.size() * 8u);
+    e->row_of_step = pk.row_of_step;
+    const std::vector<uint64_t>& blob = pk.words;
 
     e->request_capacity = opts && opts->request_capacity ? opts->request_capacity : 64u;
     e->fifo_capacity = pow2_at_least(opts && opts->fifo_capacity ? opts->fifo_capacity : 32u);
     e->force_global = opts ? opts->force_global_state : 0u;
-    if (e->request_capacity > 65535u || e->fifo_capacity > 65536u) {
+    if (e->request_capacity > 65535u || e->fifo_capacity > 32768u) {
         delete e;
-        return fail(AF_ERR_CAPACITY, "request_capacity must be <= 65535 and fifo_capacity <= 65536");
+        return fail(AF_ERR_CAPACITY, "request_capacity must be <= 65535 and fifo_capacity <= 32768");
     }
     if (a.blob_bytes > kLdsLimit / 2) {
         delete e;
@@ -382,8 +326,8 @@ int af_engine_create(const af_plan_t* plan, int device, const af_engine_options_
     if (err == hipSuccess) err = hipEventCreate(&e->ev0);
     if (err == hipSuccess) err = hipEventCreate(&e->ev1);
     if (err == hipSuccess) err = hipEventCreate(&e->ev2);
-    if (err == hipSuccess) err = hipMalloc((void**)&e->d_blob, blob.size());
-    if (err == hipSuccess) err = hipMemcpy(e->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMalloc((void**)&e->d_blob, blob.size() * 8u);
+    if (err == hipSuccess) err = hipMemcpy(e->d_blob, blob.data(), blob.size() * 8u, hipMemcpyHostToDevice);
     if (err != hipSuccess) {
         af_engine_destroy(e);
         return fail(AF_ERR_HIP, std::string("engine setup: ") + hipGetErrorString(err));
@@ -408,12 +352,12 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
         const af_override_t& o = sweep->overrides[k];
         if (o.param >= AF_PARAM_COUNT_ || !o.values) return fail(AF_ERR_INVALID, "bad override");
         const uint32_t lim = (o.param >= AF_PARAM_EDGE_MEAN && o.param <= AF_PARAM_EDGE_DROPOUT) ? a.n_edges
-                             : (o.param == AF_PARAM_STEP_TIME)                                   ? a.n_steps
+                             : (o.param == AF_PARAM_STEP_TIME)                                   ? (uint32_t)e->row_of_step.size()
                                                                                                  : 1u;
         if (o.index >= lim) return fail(AF_ERR_INVALID, "override index out of range");
         mask |= 1u << o.param;
     }
-    a.L = af::make_layout(e->request_capacity, e->fifo_capacity, a.n_edges, a.n_servers, a.n_lb_edges, a.n_steps, mask);
+    a.L = af::make_layout(e->request_capacity, e->fifo_capacity, a.n_edges, a.n_servers, a.n_lb_edges, a.n_rows, mask);
     const uint64_t bytes_per_lane = af::layout_bytes_per_lane(a.L);
     const uint64_t state_per_wave = bytes_per_lane * kWave;
     const bool lds_state = !e->force_global && (uint64_t)a.blob_bytes + state_per_wave <= kLdsLimit;
@@ -438,7 +382,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     std::vector<uint32_t> params(sweep->n_overrides ? sweep->n_overrides : 1, 0u), idxs(params.size(), 0u);
     for (uint32_t k = 0; k < sweep->n_overrides; ++k) {
         params[k] = sweep->overrides[k].param;
-        idxs[k] = sweep->overrides[k].index;
+        idxs[k] = params[k] == AF_PARAM_STEP_TIME ? e->row_of_step[sweep->overrides[k].index] : sweep->overrides[k].index;
         HIP_TRY(hipMemcpyAsync(ds + seeds_b + (size_t)k * n * 8, sweep->overrides[k].values, (size_t)n * 8,
                                hipMemcpyHostToDevice, e->stream));
     }

@@ -18,7 +18,8 @@ _lib = None
 
 
 def build(force: bool = False) -> Path:
-    srcs = [HERE / "hostcheck.cpp", ROOT / "asyncflow_amd/csrc/af_core.hpp", ROOT / "asyncflow_amd/csrc/af_math.hpp"]
+    srcs = [HERE / "hostcheck.cpp", ROOT / "asyncflow_amd/csrc/af_core.hpp", ROOT / "asyncflow_amd/csrc/af_math.hpp",
+            ROOT / "asyncflow_amd/csrc/af_plan_pack.hpp"]
     newest = max(p.stat().st_mtime for p in srcs)
     if force or not LIB.exists() or LIB.stat().st_mtime < newest:
         subprocess.run(

@@ -10,26 +10,15 @@
 #include <cstring>
 #include <vector>
 
-#include "../../asyncflow_amd/csrc/af_core.hpp"
-#include "../../include/asyncflow_hip.h"
+#include "../../asyncflow_amd/csrc/af_plan_pack.hpp"
 
 namespace {
 
 struct MemHost {
-    double* d;
-    uint32_t* w;
-    double ld64(uint32_t i) const { return d[i]; }
-    void st64(uint32_t i, double v) const { d[i] = v; }
-    uint32_t ld32(uint32_t i) const { return w[i]; }
-    void st32(uint32_t i, uint32_t v) const { w[i] = v; }
+    uint64_t* w;
+    uint64_t ld(uint32_t i) const { return w[i]; }
+    void st(uint32_t i, uint64_t v) const { w[i] = v; }
 };
-
-template <class T>
-std::vector<uint32_t> widen(const T* p, size_t n) {
-    std::vector<uint32_t> v(n ? n : 1);
-    for (size_t i = 0; i < n; ++i) v[i] = (uint32_t)p[i];
-    return v;
-}
 
 }  // namespace
 
@@ -38,61 +27,30 @@ extern "C" int hc_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ovr, co
                            uint32_t clock_cap, double* clock, uint32_t tick_cap, uint32_t* samples,
                            uint32_t* counts) {
     if (!p || p->abi_version != AF_ABI_VERSION || p->struct_size != sizeof(af_plan_t)) return AF_ERR_ABI;
-    if (fcap == 0 || (fcap & (fcap - 1)) != 0) return AF_ERR_INVALID;
-    auto tk = widen(p->edge_target_kind, p->n_edges);
-    auto ed = widen(p->edge_dist, p->n_edges);
-    auto sk = widen(p->step_kind, p->n_steps);
-    auto sd = widen(p->smark_down, p->n_srv_marks);
-
+    if (fcap == 0 || (fcap & (fcap - 1)) != 0 || fcap > 32768) return AF_ERR_INVALID;
+    af::PackedPlan pk;
+    if (!af::pack_plan(*p, pk).empty()) return AF_ERR_INVALID;
     af::PlanView V{};
-    V.total_time = p->total_time;
-    V.sample_period = p->sample_period;
-    V.gen_users_mean = p->gen_users_mean;
-    V.gen_users_sigma = p->gen_users_sigma;
-    V.gen_rpm_mean = p->gen_rpm_mean;
-    V.gen_window_s = p->gen_window_s;
-    V.metrics_mask = p->metrics_mask;
-    V.gen_users_dist = p->gen_users_dist;
-    V.gen_out_edge = p->gen_out_edge;
-    V.client_out_edge = p->client_out_edge;
-    V.n_edges = p->n_edges;
-    V.n_servers = p->n_servers;
-    V.lb_algo = p->lb_algo;
-    V.n_lb_edges = p->n_lb_edges;
-    V.n_endpoints = p->n_endpoints;
-    V.n_steps = p->n_steps;
-    V.n_edge_marks = p->n_edge_marks;
-    V.n_srv_marks = p->n_srv_marks;
-    V.e_mean = p->edge_mean;
-    V.e_sigma = p->edge_sigma;
-    V.e_drop = p->edge_dropout;
-    V.s_ram = p->srv_ram_mb;
-    V.ep_ram = p->ep_ram;
-    V.st_time = p->step_time;
-    V.em_time = p->emark_time;
-    V.em_delta = p->emark_delta;
-    V.sm_time = p->smark_time;
-    V.lb_edges = p->lb_edges;
-    V.e_tkind = tk.data();
-    V.e_tidx = p->edge_target_idx;
-    V.e_dist = ed.data();
-    V.s_cores = p->srv_cores;
-    V.s_out = p->srv_out_edge;
-    V.s_epb = p->srv_ep_begin;
-    V.ep_stepb = p->ep_step_begin;
-    V.st_kind = sk.data();
-    V.em_edge = p->emark_edge;
-    V.sm_edge = p->smark_lb_edge;
-    V.sm_down = sd.data();
+    af::fill_view_scalars(*p, pk, V);
+    V.edge = pk.words.data() + pk.off_edge;
+    V.srv = pk.words.data() + pk.off_srv;
+    V.ep = pk.words.data() + pk.off_ep;
+    V.row = pk.words.data() + pk.off_row;
+    V.emark = pk.words.data() + pk.off_emark;
+    V.smark = pk.words.data() + pk.off_smark;
+    V.lb = pk.words.data() + pk.off_lb;
 
     uint32_t mask = 0;
-    for (uint32_t k = 0; k < n_ovr; ++k) mask |= 1u << ovr_param[k];
-    const af::Layout L = af::make_layout(cap, fcap, p->n_edges, p->n_servers, p->n_lb_edges, p->n_steps, mask);
-    std::vector<double> d(L.n_d ? L.n_d : 1, 0.0);
-    std::vector<uint32_t> w(L.n_w ? L.n_w : 1, 0u);
+    std::vector<uint32_t> idx(n_ovr ? n_ovr : 1, 0u);
+    for (uint32_t k = 0; k < n_ovr; ++k) {
+        mask |= 1u << ovr_param[k];
+        idx[k] = ovr_param[k] == AF_PARAM_STEP_TIME ? pk.row_of_step[ovr_index[k]] : ovr_index[k];
+    }
+    const af::Layout L = af::make_layout(cap, fcap, p->n_edges, p->n_servers, p->n_lb_edges, pk.n_rows, mask);
+    std::vector<uint64_t> w(L.n_words ? L.n_words : 1, 0ull);
     af::LaneOut O{clock, samples, counts, clock_cap, tick_cap};
-    af::Lane<MemHost> lane(V, L, MemHost{d.data(), w.data()}, O, seed);
-    lane.init(ovr_param, ovr_index, n_ovr, [&](uint32_t k) { return ovr_value[k]; });
+    af::Lane<MemHost> lane(V, L, MemHost{w.data()}, O, seed);
+    lane.init(ovr_param, idx.data(), n_ovr, [&](uint32_t k) { return ovr_value[k]; });
     while (lane.round()) {
     }
     lane.write_counts();
@@ -100,6 +58,6 @@ extern "C" int hc_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ovr, co
 }
 
 extern "C" uint64_t hc_bytes_per_lane(uint32_t cap, uint32_t fcap, uint32_t n_edges, uint32_t n_servers,
-                                      uint32_t n_lb, uint32_t n_steps, uint32_t mask) {
-    return af::layout_bytes_per_lane(af::make_layout(cap, fcap, n_edges, n_servers, n_lb, n_steps, mask));
+                                      uint32_t n_lb, uint32_t n_rows, uint32_t mask) {
+    return af::layout_bytes_per_lane(af::make_layout(cap, fcap, n_edges, n_servers, n_lb, n_rows, mask));
 }
