@@ -53,14 +53,20 @@ FLAG_FIFO_OVERFLOW = 2
 FLAG_CLOCK_OVERFLOW = 4
 FLAG_TICK_OVERFLOW = 8
 FLAG_RAM_STARVED = 16
+FLAG_TIME_TIE = 32
+FLAG_DRAW_OVERFLOW = 64
 FLAG_NAMES = {
     FLAG_POOL_OVERFLOW: "request pool overflow (raise request_capacity)",
     FLAG_FIFO_OVERFLOW: "server wait-queue overflow (raise fifo_capacity)",
     FLAG_CLOCK_OVERFLOW: "rqs_clock capacity overflow (raise clock_capacity)",
     FLAG_TICK_OVERFLOW: "sample capacity overflow",
     FLAG_RAM_STARVED: "a request needs more RAM than the server owns (queue blocked, as in the reference)",
+    FLAG_TIME_TIE: "two timed events shared a timestamp (SimPy may interleave their zero-time steps differently)",
+    FLAG_DRAW_OVERFLOW: "more arrivals than draw_capacity (raise clock_capacity)",
 }
-FATAL_FLAGS = FLAG_POOL_OVERFLOW | FLAG_FIFO_OVERFLOW | FLAG_CLOCK_OVERFLOW | FLAG_TICK_OVERFLOW
+FATAL_FLAGS = (
+    FLAG_POOL_OVERFLOW | FLAG_FIFO_OVERFLOW | FLAG_CLOCK_OVERFLOW | FLAG_TICK_OVERFLOW | FLAG_DRAW_OVERFLOW
+)
 
 _pd = C.POINTER(C.c_double)
 _pi32 = C.POINTER(C.c_int32)
@@ -126,6 +132,7 @@ class AfSweep(C.Structure):
         ("seeds", _pu64),
         ("n_overrides", C.c_uint32),
         ("overrides", C.POINTER(AfOverride)),
+        ("draw_capacity", C.c_uint32),
     ]
 
 
@@ -150,7 +157,9 @@ class AfEngineOptions(C.Structure):
 class AfStats(C.Structure):
     _fields_ = [
         ("kernel_ms", C.c_double),
+        ("pregen_ms", C.c_double),
         ("h2d_ms", C.c_double),
+        ("draw_bytes", C.c_uint64),
         ("state_bytes_per_scenario", C.c_uint64),
         ("state_in_lds", C.c_uint32),
         ("lds_bytes_per_wave", C.c_uint32),

@@ -54,6 +54,7 @@ enum : uint32_t {
     FLAG_TICK_OVERFLOW = 1u << 3,
     FLAG_RAM_STARVED = 1u << 4,
     FLAG_TIME_TIE = 1u << 5,
+    FLAG_DRAW_OVERFLOW = 1u << 6,
 };
 enum : uint32_t {
     CNT_GENERATED = 0, CNT_COMPLETED, CNT_DROPPED, CNT_EVENTS, CNT_TICKS, CNT_FLAGS, CNT_MAX_LIVE, CNT_MARKS, CNT_SLOTS
@@ -106,17 +107,19 @@ AF_HD double u2d(uint64_t u) { return __builtin_bit_cast(double, u); }
 AF_HD uint64_t d2u(double d) { return __builtin_bit_cast(uint64_t, d); }
 
 // ---- per-lane state layout (offsets in 64-bit words; computed by the host) ----
-//   heap K/A/B [cap] each; edge [E][2] = {conn | sends<<32, spike}; optional per-scenario
-//   parameter columns; server [S][5] = {cpu_free | ready<<32, io | arrivals<<32, ram_free,
-//   ram_in_use, cq_head | cq_n<<16 | rq_head<<32 | rq_n<<48 | blocked<<63}; wait queues
+//   heap K/A/B [cap] each; edge [E][2] = {conn[0:15] | ring_ahead[16:23] | sends<<32, spike};
+//   draw rings [1+E][RING] (stream 0 = arrival times, 1+e = edge e transit times, staged
+//   from the pre-generated HBM arrays); optional per-scenario step-time column; server
+//   [S][5] = {cpu_free | ready<<32, io | arrivals<<32, ram_free, ram_in_use,
+//   cq_head | cq_n<<16 | rq_head<<32 | rq_n<<48 | blocked<<63}; wait queues
 //   [S][fcap][2] = {start time, state}; LB order [n_lb] (only used when n_lb > 8).
 struct Layout {
     uint32_t cap;       // pending timed events (== requests in flight) per scenario
     uint32_t fcap;      // per-server wait-queue capacity (power of two, <= 32768)
-    uint32_t ovr_mask;  // bit p set: af_param class p has a per-lane column
-    uint32_t hk, ha, hb, edge, emean, esig, edrop, stime, srv, cq, rq, lb, n_words;
+    uint32_t ovr_mask;  // bit p set: af_param class p is overridden per scenario
+    uint32_t hk, ha, hb, edge, ring, stime, srv, cq, rq, lb, n_words;
 };
-enum : uint32_t { LEDGE = 2, LSRV = 5 };
+enum : uint32_t { LEDGE = 2, LSRV = 5, RING = 4 };
 
 AF_HD Layout make_layout(uint32_t cap, uint32_t fcap, uint32_t n_edges, uint32_t n_servers, uint32_t n_lb,
                          uint32_t n_rows, uint32_t ovr_mask) {
@@ -129,9 +132,7 @@ AF_HD Layout make_layout(uint32_t cap, uint32_t fcap, uint32_t n_edges, uint32_t
     L.ha = w; w += cap;
     L.hb = w; w += cap;
     L.edge = w; w += LEDGE * n_edges;
-    L.emean = w; if (ovr_mask & (1u << PARAM_EDGE_MEAN)) w += n_edges;
-    L.esig = w; if (ovr_mask & (1u << PARAM_EDGE_SIGMA)) w += n_edges;
-    L.edrop = w; if (ovr_mask & (1u << PARAM_EDGE_DROPOUT)) w += n_edges;
+    L.ring = w; w += RING * (1u + n_edges);
     L.stime = w; if (ovr_mask & (1u << PARAM_STEP_TIME)) w += n_rows;
     L.srv = w; w += LSRV * n_servers;
     L.cq = w; w += 2u * n_servers * fcap;
@@ -152,19 +153,77 @@ struct LaneOut {
 
 constexpr double AF_INF = __builtin_huge_val();
 
-// Cold helpers kept out of line so that the hot loop stays small (the gfx950
-// instruction cache is shared by two CUs; the round body must fit in it).
-AF_CORE_NOINLINE double cold_variate(uint32_t dist, double mean, double sigma, double u1, uint64_t seed,
-                                     uint32_t stream, uint32_t index) {
-    return variate_from_u1(dist, mean, sigma, u1, seed, stream, index);
-}
-AF_CORE_NOINLINE double cold_users_draw(uint32_t dist, double mean, double sigma, uint64_t seed, uint32_t idx) {
-    if (dist == DIST_NORMAL) {  // gaussian_poisson.py:72-76 + common_helpers.py:32-33
-        const double v = mean + sigma * af_norminv(uniform_j(seed, STREAM_GENERATOR, idx, 0u));
-        return v > 0.0 ? v : 0.0;
+// ---- pre-generated random draws --------------------------------------------------
+// Every random variate of a scenario is a pure function of (seed, stream, draw index)
+// and of the scenario's parameters -- never of the simulation state.  They are therefore
+// produced up front by fully parallel kernels (engine.hip: af_pregen_*), at full GPU
+// occupancy, into HBM:  draws[stream][index][scenario]  (f64)
+//   stream 0     : absolute arrival times of the generator (AF_INF after the last one)
+//   stream 1 + e : transit time of the index-th message sent on edge e, or -1.0 if that
+//                  message is dropped (edge.py:78-86)
+// The sequential next-event kernel only stages them through small LDS rings.
+struct PreDraws {
+    const double* base;
+    uint32_t n_per_stream;  // entries per stream and scenario
+    uint32_t n_scen;        // scenarios in the launch (stride between consecutive indices)
+    uint32_t scen;          // this lane's scenario
+    uint32_t flags_in;      // AF_FLAG_DRAW_OVERFLOW if the arrival stream did not fit
+    AF_HD double entry(uint32_t stream, uint32_t index) const {
+        return base[((size_t)stream * n_per_stream + index) * n_scen + scen];
     }
-    return (double)af_poisson(mean, seed, STREAM_GENERATOR, idx, 0u);  // poisson_poisson.py:60
+};
+
+// One message on one edge: EdgeRuntime._deliver's dropout test + latency draw
+// (edge.py:78-90, samplers/common_helpers.py:49-89).
+AF_HD double pre_edge_draw(uint64_t seed, uint32_t e, uint32_t idx, uint32_t dist, double mean, double sigma,
+                           double dropout) {
+    const uint32_t stream = stream_edge(e);
+    const U4 r = draw_block(seed, stream, idx, 0u);
+    if (u53(r.x, r.y) < dropout) return -1.0;  // dropped: no latency draw
+    return variate_from_u1(dist, mean, sigma, u53(r.z, r.w), seed, stream, idx);
 }
+
+// The windowed arrival sampler: samplers/poisson_poisson.py:51-82, gaussian_poisson.py:63-94.
+struct GenState {
+    double g_now = 0.0, g_wend = 0.0, g_lam = 0.0;
+    uint32_t draws = 0;
+};
+AF_HD double gen_next_gap(GenState& g, uint64_t seed, uint32_t users_dist, double users_mean, double users_sigma,
+                          double rpm, double window_s, double T) {
+    const double rps_per_user = rpm / 60.0;
+    while (g.g_now < T) {
+        if (g.g_now >= g.g_wend) {
+            g.g_wend = g.g_now + window_s;
+            const uint32_t idx = g.draws++;
+            double users;
+            if (users_dist == DIST_NORMAL) {  // gaussian_poisson.py:72-76 + common_helpers.py:32-33
+                const double v = users_mean + users_sigma * af_norminv(uniform_j(seed, STREAM_GENERATOR, idx, 0u));
+                users = v > 0.0 ? v : 0.0;
+            } else {  // poisson_poisson.py:60
+                users = (double)af_poisson(users_mean, seed, STREAM_GENERATOR, idx, 0u);
+            }
+            g.g_lam = users * rps_per_user;
+        }
+        if (g.g_lam <= 0.0) {
+            g.g_now = g.g_wend;
+            continue;
+        }
+        const U4 r = draw_block(seed, STREAM_GENERATOR, g.draws++, 0u);
+        double u = u53(r.x, r.y);
+        if (u < 1e-15) u = 1e-15;
+        const double dt = -af_log(1.0 - u) / g.g_lam;
+        if (g.g_now + dt > T) break;
+        if (g.g_now + dt >= g.g_wend) {
+            g.g_now = g.g_wend;
+            continue;
+        }
+        g.g_now += dt;
+        return dt;
+    }
+    g.g_now = T + 1.0;
+    return -1.0;
+}
+
 AF_CORE_NOINLINE uint32_t cold_endpoint_pick(uint64_t seed, uint32_t sv, uint32_t idx, uint32_t n_ep) {
     const U4 r = draw_block(seed, stream_server(sv), idx, 0u);  // rng.integers(0, n_ep), server.py:101
     return (uint32_t)(((uint64_t)r.x * n_ep) >> 32);
@@ -176,18 +235,19 @@ struct Lane {
     const Layout& L;
     Mem M;
     LaneOut O;
+    PreDraws D;
     uint64_t seed;
 
     // register-resident scalars
-    double now, t_gen, g_now, g_wend, g_lam, t_tick, t_emark, t_smark;
-    double users_mean, users_sigma, rpm;
+    double now, t_gen, t_tick, t_emark, t_smark;
     uint64_t lb_list;  // LB out-edge order, 8 bits per entry (n_lb_edges <= 8), else in Mem
-    uint32_t g_draws, heap_n, seq, live, max_live, lb_n, emark_i, smark_i;
+    uint32_t arr_ahead;  // arrival times staged in the ring beyond the next one
+    bool want_refill;    // a draw ring ran low: the wave restages all rings before the next round
+    uint32_t heap_n, seq, live, max_live, lb_n, emark_i, smark_i;
     uint32_t n_gen, n_comp, n_drop, n_events, n_ticks, n_marks, flags, rounds;
 
     // per-round work registers ("follow-ups" of the timed event being handled)
     bool hole;            // the popped event left the heap root free
-    bool gen_first;       // the generator's Initialize has not run yet
     uint32_t pend_count;  // pushes buffered this pass (<= 2): the heap code exists once
     double pend_k0, pend_k1;
     uint64_t pend_a0, pend_a1, pend_b0, pend_b1;
@@ -203,18 +263,10 @@ struct Lane {
     bool adv_core, adv_io;
     int32_t fu_ram_sv;  // RAM was released on this server: serve its wait queue
 
-    AF_CORE Lane(const PlanView& p, const Layout& l, Mem m, LaneOut o, uint64_t s) : P(p), L(l), M(m), O(o), seed(s) {}
+    AF_CORE Lane(const PlanView& p, const Layout& l, Mem m, LaneOut o, PreDraws d, uint64_t s)
+        : P(p), L(l), M(m), O(o), D(d), seed(s) {}
 
-    // ---- parameter accessors (plan value or per-scenario column) -------------
-    AF_CORE double edge_mean(uint32_t e) const {
-        return (L.ovr_mask & (1u << PARAM_EDGE_MEAN)) ? u2d(M.ld(L.emean + e)) : u2d(P.edge[EREC * e]);
-    }
-    AF_CORE double edge_sigma(uint32_t e) const {
-        return (L.ovr_mask & (1u << PARAM_EDGE_SIGMA)) ? u2d(M.ld(L.esig + e)) : u2d(P.edge[EREC * e + 1u]);
-    }
-    AF_CORE double edge_dropout(uint32_t e) const {
-        return (L.ovr_mask & (1u << PARAM_EDGE_DROPOUT)) ? u2d(M.ld(L.edrop + e)) : u2d(P.edge[EREC * e + 2u]);
-    }
+    // ---- parameter accessor (plan value or per-scenario column) ---------------
     AF_CORE double row_time(uint32_t r) const {
         return (L.ovr_mask & (1u << PARAM_STEP_TIME)) ? u2d(M.ld(L.stime + r)) : u2d(P.row[TREC * r]);
     }
@@ -330,60 +382,59 @@ struct Lane {
         return true;
     }
 
-    // ---- generator: samplers/poisson_poisson.py:51-82, gaussian_poisson.py:63-94 ----
-    AF_CORE double next_gap() {
-        const double T = P.total_time;
-        const double rps_per_user = rpm / 60.0;
-        while (g_now < T) {
-            if (g_now >= g_wend) {
-                g_wend = g_now + P.gen_window_s;
-                g_lam = cold_users_draw(P.gen_users_dist, users_mean, users_sigma, seed, g_draws++) * rps_per_user;
+    // ---- draw rings: stage the pre-generated draws of every stream into LDS ------------
+    // Runs for the whole wave (all lanes active) whenever some lane's ring ran low: 4 x (1+E)
+    // independent global loads per lane, one wait.
+    AF_CORE void refill() {
+        want_refill = false;
+        const uint32_t n = D.n_per_stream;
+        {   // stream 0: arrival times; t_gen is entry n_gen
+#pragma unroll
+            for (uint32_t k = 0u; k < RING; ++k) {
+                const uint32_t i = n_gen + k;
+                M.st(L.ring + (i & (RING - 1u)), d2u(i < n ? D.entry(0u, i) : AF_INF));
             }
-            if (g_lam <= 0.0) {
-                g_now = g_wend;
-                continue;
-            }
-            const U4 r = draw_block(seed, STREAM_GENERATOR, g_draws++, 0u);
-            double u = u53(r.x, r.y);
-            if (u < 1e-15) u = 1e-15;
-            const double dt = -af_log(1.0 - u) / g_lam;
-            if (g_now + dt > T) break;
-            if (g_now + dt >= g_wend) {
-                g_now = g_wend;
-                continue;
-            }
-            g_now += dt;
-            return dt;
+            arr_ahead = RING - 1u;
+            t_gen = u2d(M.ld(L.ring + (n_gen & (RING - 1u))));
         }
-        g_now = T + 1.0;
-        return -1.0;
+        for (uint32_t e = 0u; e < P.n_edges; ++e) {
+            const uint32_t at = L.edge + LEDGE * e;
+            const uint64_t cs = M.ld(at);
+            const uint32_t sends = (uint32_t)(cs >> 32);
+#pragma unroll
+            for (uint32_t k = 0u; k < RING; ++k) {
+                const uint32_t i = sends + k;
+                M.st(L.ring + RING * (1u + e) + (i & (RING - 1u)), d2u(i < n ? D.entry(1u + e, i) : -1.0));
+            }
+            M.st(at, (cs & ~(0xFFull << 16)) | ((uint64_t)RING << 16));
+        }
     }
 
     // ---- SEND stage: EdgeRuntime.transport/_deliver up to the timeout (edge.py:73-107) ----
     AF_CORE void edge_send(uint64_t a, uint32_t e, uint32_t hops) {
         const uint32_t at = L.edge + LEDGE * e;
-        const uint64_t cs = M.ld(at);  // conn | sends<<32
+        const uint64_t cs = M.ld(at);  // conn[0:15] | ring_ahead[16:23] | sends<<32
         const double spike = u2d(M.ld(at + 1u));
-        const double mean = edge_mean(e);
-        const double dropout = edge_dropout(e);
-        const uint32_t dist = (uint32_t)(P.edge[EREC * e + 3u] >> 16) & 0xFFu;
         const uint32_t idx = (uint32_t)(cs >> 32);
-        const uint32_t stream = stream_edge(e);
-        const U4 r = draw_block(seed, stream, idx, 0u);
-        if (u53(r.x, r.y) < dropout) {  // dropped: no latency draw (edge.py:78-86)
-            M.st(at, cs + (1ull << 32));
+        const uint32_t ahead = (uint32_t)(cs >> 16) & 0xFFu;
+        // transit time of this edge's idx-th message (pre-drawn; -1 = dropped, edge.py:78-86)
+        double transit;
+        uint64_t ncs = cs + (1ull << 32);  // sends += 1
+        if (ahead > 0u) {
+            transit = u2d(M.ld(L.ring + RING * (1u + e) + (idx & (RING - 1u))));
+            ncs -= 1ull << 16;
+        } else {
+            transit = idx < D.n_per_stream ? D.entry(1u + e, idx) : -1.0;  // ring empty: straight from HBM (rare)
+            if (idx >= D.n_per_stream) flags |= FLAG_DRAW_OVERFLOW;
+        }
+        if (ahead <= 1u) want_refill = true;
+        if (transit < 0.0) {
+            M.st(at, ncs);
             n_drop += 1u;
             live -= 1u;
             return;
         }
-        M.st(at, cs + (1ull << 32) + 1ull);  // sends += 1, conn += 1
-        const double u1 = u53(r.z, r.w);
-        double transit;
-        if (dist == DIST_EXPONENTIAL) {
-            transit = -(mean * af_log(1.0 - u1));
-        } else {
-            transit = cold_variate(dist, mean, edge_sigma(e), u1, seed, stream, idx);
-        }
+        M.st(at, ncs + 1ull);  // conn += 1 (edge.py:88)
         const double effective = transit + spike;  // spike read at SEND time (edge.py:94-106)
         emit(now + effective, a, st_pack(RK_TRANSIT, e, hops, 0u, 0u));
     }
@@ -551,11 +602,11 @@ struct Lane {
     AF_CORE uint32_t lb_pick() {
         uint32_t out = lb_get(0u);
         if (P.lb_algo == LB_LEAST_CONNECTIONS) {  // lb_algorithms.py:10-20: first minimum in current order
-            uint32_t best = (uint32_t)M.ld(L.edge + LEDGE * out);
+            uint32_t best = (uint32_t)M.ld(L.edge + LEDGE * out) & 0xFFFFu;
             for (uint32_t i = 1u; i < lb_n; ++i) {
                 const uint32_t cand = lb_get(i);
-                const uint32_t c = (uint32_t)M.ld(L.edge + LEDGE * cand);
-                if ((int32_t)c < (int32_t)best) {
+                const uint32_t c = (uint32_t)M.ld(L.edge + LEDGE * cand) & 0xFFFFu;
+                if (c < best) {
                     best = c;
                     out = cand;
                 }
@@ -649,7 +700,7 @@ struct Lane {
                 const uint32_t k = n_ticks;
                 if (P.metrics_mask & METRIC_EDGE)
                     for (uint32_t e = 0u; e < P.n_edges; ++e)
-                        O.samples[e * O.tick_cap + k] = (uint32_t)M.ld(L.edge + LEDGE * e);
+                        O.samples[e * O.tick_cap + k] = (uint32_t)M.ld(L.edge + LEDGE * e) & 0xFFFFu;
                 constexpr uint32_t all = METRIC_READY | METRIC_IO | METRIC_RAM;
                 if ((P.metrics_mask & all) == all)
                     for (uint32_t v = 0u; v < P.n_servers; ++v) {
@@ -668,28 +719,20 @@ struct Lane {
 
     // ---- life cycle -----------------------------------------------------------------
     // `ovr` : per-lane reader of the override columns, ovr(k) -> double, k-th column;
-    // ovr_index of a STEP_TIME column is a step ROW.
+    // ovr_index of a STEP_TIME column is a step ROW.  Must be called with the whole wave
+    // active (it stages the draw rings).
     template <class OvrFn>
     AF_CORE void init(const uint32_t* ovr_param, const uint32_t* ovr_index, uint32_t n_ovr, OvrFn ovr) {
         now = 0.0;
-        g_now = 0.0;
-        g_wend = 0.0;
-        g_lam = 0.0;
-        g_draws = heap_n = seq = live = max_live = emark_i = smark_i = 0u;
-        n_gen = n_comp = n_drop = n_events = n_ticks = n_marks = flags = rounds = 0u;
+        heap_n = seq = live = max_live = emark_i = smark_i = 0u;
+        n_gen = n_comp = n_drop = n_events = n_ticks = n_marks = rounds = 0u;
+        flags = D.flags_in;
         hole = fu_send = fu_adv = fu_grant = false;
         pend_count = 0u;
-        gen_first = true;
         fu_ram_sv = -1;
-        users_mean = P.gen_users_mean;
-        users_sigma = P.gen_users_sigma;
-        rpm = P.gen_rpm_mean;
         for (uint32_t e = 0u; e < P.n_edges; ++e) {
             M.st(L.edge + LEDGE * e, 0ull);
             M.st(L.edge + LEDGE * e + 1u, d2u(0.0));
-            if (L.ovr_mask & (1u << PARAM_EDGE_MEAN)) M.st(L.emean + e, P.edge[EREC * e]);
-            if (L.ovr_mask & (1u << PARAM_EDGE_SIGMA)) M.st(L.esig + e, P.edge[EREC * e + 1u]);
-            if (L.ovr_mask & (1u << PARAM_EDGE_DROPOUT)) M.st(L.edrop + e, P.edge[EREC * e + 2u]);
         }
         if (L.ovr_mask & (1u << PARAM_STEP_TIME))
             for (uint32_t r = 0u; r < P.n_rows; ++r) M.st(L.stime + r, P.row[TREC * r]);
@@ -707,18 +750,9 @@ struct Lane {
         for (uint32_t k = 0u; k < n_ovr; ++k) {
             const double v = ovr(k);
             const uint32_t idx = ovr_index[k];
-            switch (ovr_param[k]) {
-                case PARAM_GEN_USERS_MEAN: users_mean = v; break;
-                case PARAM_GEN_USERS_SIGMA: users_sigma = v; break;
-                case PARAM_GEN_RPM_MEAN: rpm = v; break;
-                case PARAM_EDGE_MEAN: M.st(L.emean + idx, d2u(v)); break;
-                case PARAM_EDGE_SIGMA: M.st(L.esig + idx, d2u(v)); break;
-                case PARAM_EDGE_DROPOUT: M.st(L.edrop + idx, d2u(v)); break;
-                case PARAM_STEP_TIME: M.st(L.stime + idx, d2u(v)); break;
-                default: break;
-            }
+            if (ovr_param[k] == PARAM_STEP_TIME) M.st(L.stime + idx, d2u(v));  // the others only shape the draws
         }
-        t_gen = 0.0;  // the generator's Initialize runs as the first "arrival" round (gen_first)
+        refill();  // also sets t_gen = first arrival
         t_tick = 0.0 + P.sample_period;
         t_emark = P.n_edge_marks ? u2d(P.emark[0]) : AF_INF;
         t_smark = P.n_srv_marks ? u2d(P.smark[0]) : AF_INF;
@@ -766,21 +800,22 @@ struct Lane {
                 adv_io = st_io(root_st) != 0u;
             }
         } else if (cls == 3u) {  // RqsGeneratorRuntime._event_arrival (rqs_generator.py:101-119)
-            const bool first = gen_first;  // Initialize: only draws the first gap
-            gen_first = false;
-            const double t_arrival = now;
-            const double gap = next_gap();
-            t_gen = gap >= 0.0 ? now + gap : AF_INF;
-            if (!first) {
-                n_gen += 1u;
-                n_events += 1u;
-                live += 1u;
-                if (live > max_live) max_live = live;
-                fu_send = true;
-                send_a = d2u(t_arrival);
-                send_edge = P.gen_out_edge;
-                send_hops = 1u;  // record_hop(GENERATOR)
+            n_gen += 1u;
+            n_events += 1u;
+            live += 1u;
+            if (live > max_live) max_live = live;
+            fu_send = true;
+            send_a = d2u(now);
+            send_edge = P.gen_out_edge;
+            send_hops = 1u;  // record_hop(GENERATOR)
+            // next arrival time: pre-generated (the sampler never looks at the simulation state)
+            if (arr_ahead > 0u) {
+                arr_ahead -= 1u;
+                t_gen = u2d(M.ld(L.ring + (n_gen & (RING - 1u))));
+            } else {
+                t_gen = n_gen < D.n_per_stream ? D.entry(0u, n_gen) : AF_INF;
             }
+            if (arr_ahead == 0u) want_refill = true;
         } else if (cls == 2u) {
             sample_tick();
             t_tick = now + P.sample_period;

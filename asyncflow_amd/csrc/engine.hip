@@ -54,6 +54,10 @@ struct KArgs {
     uint32_t* counts;
     unsigned char* state;  // HBM-resident lane state (global-state mode only)
     uint64_t state_bytes_per_wave;
+    double* draws;          // pre-generated draws [1 + n_edges][n_draw][n_scen]
+    uint32_t n_draw;
+    uint32_t* pre_flags;    // [n_scen] AF_FLAG_DRAW_OVERFLOW from the arrival pre-generation
+    uint32_t pregen_chunk;  // draw indices handled by one thread of af_pregen_edges
 };
 
 struct MemLds {
@@ -121,14 +125,21 @@ __global__ void __launch_bounds__(64) af_des_kernel(const KArgs a) {
 
     const uint64_t seed = a.seeds[sc];
     auto ovr = [&](uint32_t k) { return a.ovr_values[(size_t)k * a.n_scen + sc]; };
+    af::PreDraws D;
+    D.base = a.draws;
+    D.n_per_stream = a.n_draw;
+    D.n_scen = a.n_scen;
+    D.scen = sc;
+    D.flags_in = a.pre_flags[sc];
 
     if constexpr (kLdsState) {
         MemLds M;
         M.w = (LDS_AS uint64_t*)(smem + a.blob_bytes) + lane;
-        af::Lane<MemLds> S(P, a.L, M, O, seed);
+        af::Lane<MemLds> S(P, a.L, M, O, D, seed);
         bool run = active;
-        if (active) S.init(a.ovr_param, a.ovr_index, a.n_ovr, ovr);
+        S.init(a.ovr_param, a.ovr_index, a.n_ovr, ovr);  // whole wave (inactive lanes shadow scenario 0)
         while (__any(run)) {
+            if (__any(run && S.want_refill)) S.refill();  // wave-wide: every lane restages its rings
             if (run) run = S.round();
         }
         if (active) S.write_counts();
@@ -136,14 +147,67 @@ __global__ void __launch_bounds__(64) af_des_kernel(const KArgs a) {
         unsigned char* base = a.state + (size_t)blockIdx.x * a.state_bytes_per_wave;
         MemGlobal M;
         M.w = reinterpret_cast<uint64_t*>(base) + lane;
-        af::Lane<MemGlobal> S(P, a.L, M, O, seed);
+        af::Lane<MemGlobal> S(P, a.L, M, O, D, seed);
         bool run = active;
-        if (active) S.init(a.ovr_param, a.ovr_index, a.n_ovr, ovr);
+        S.init(a.ovr_param, a.ovr_index, a.n_ovr, ovr);  // whole wave (inactive lanes shadow scenario 0)
         while (__any(run)) {
+            if (__any(run && S.want_refill)) S.refill();  // wave-wide: every lane restages its rings
             if (run) run = S.round();
         }
         if (active) S.write_counts();
     }
+}
+
+// ---- draw pre-generation (fully parallel, full occupancy) ---------------------------
+__device__ __forceinline__ double ovr_or(const KArgs& a, uint32_t param, uint32_t index, uint32_t scen, double dflt) {
+    for (uint32_t k = 0; k < a.n_ovr; ++k)
+        if (a.ovr_param[k] == param && a.ovr_index[k] == index) dflt = a.ovr_values[(size_t)k * a.n_scen + scen];
+    return dflt;
+}
+
+// Stream 0: one thread per scenario walks the (sequential) windowed arrival sampler and
+// stores the absolute arrival times: t_k = t_{k-1} + gap_k (env.now + gap, rqs_generator.py:104).
+__global__ void __launch_bounds__(64) af_pregen_arrivals(const KArgs a) {
+    const uint32_t scen = blockIdx.x * blockDim.x + threadIdx.x;
+    if (scen >= a.n_scen) return;
+    const uint64_t seed = a.seeds[scen];
+    const double users_mean = ovr_or(a, af::PARAM_GEN_USERS_MEAN, 0u, scen, a.gen_users_mean);
+    const double users_sigma = ovr_or(a, af::PARAM_GEN_USERS_SIGMA, 0u, scen, a.gen_users_sigma);
+    const double rpm = ovr_or(a, af::PARAM_GEN_RPM_MEAN, 0u, scen, a.gen_rpm_mean);
+    af::GenState g;
+    double t = 0.0;
+    uint32_t k = 0;
+    uint32_t flags = 0;
+    for (; k < a.n_draw; ++k) {
+        const double gap = af::gen_next_gap(g, seed, a.gen_users_dist, users_mean, users_sigma, rpm, a.gen_window_s,
+                                            a.total_time);
+        if (gap < 0.0) break;
+        t = t + gap;
+        a.draws[(size_t)k * a.n_scen + scen] = t;
+    }
+    if (k == a.n_draw &&
+        af::gen_next_gap(g, seed, a.gen_users_dist, users_mean, users_sigma, rpm, a.gen_window_s, a.total_time) >= 0.0)
+        flags = AF_FLAG_DRAW_OVERFLOW;
+    for (; k < a.n_draw; ++k) a.draws[(size_t)k * a.n_scen + scen] = af::AF_INF;
+    a.pre_flags[scen] = flags;
+}
+
+// Streams 1 + e: thread (scenario, chunk) of edge blockIdx.z draws `pregen_chunk` messages.
+__global__ void __launch_bounds__(256) af_pregen_edges(const KArgs a) {
+    const uint32_t scen = blockIdx.x * blockDim.x + threadIdx.x;
+    if (scen >= a.n_scen) return;
+    const uint32_t e = blockIdx.z;
+    const uint64_t* rec = reinterpret_cast<const uint64_t*>(a.blob) + a.off_edge + af::EREC * e;
+    const double mean = ovr_or(a, af::PARAM_EDGE_MEAN, e, scen, af::u2d(rec[0]));
+    const double sigma = ovr_or(a, af::PARAM_EDGE_SIGMA, e, scen, af::u2d(rec[1]));
+    const double dropout = ovr_or(a, af::PARAM_EDGE_DROPOUT, e, scen, af::u2d(rec[2]));
+    const uint32_t dist = (uint32_t)(rec[3] >> 16) & 0xFFu;
+    const uint64_t seed = a.seeds[scen];
+    const uint32_t lo = blockIdx.y * a.pregen_chunk;
+    const uint32_t hi = lo + a.pregen_chunk < a.n_draw ? lo + a.pregen_chunk : a.n_draw;
+    double* out = a.draws + ((size_t)(1u + e) * a.n_draw) * a.n_scen + scen;
+    for (uint32_t i = lo; i < hi; ++i)
+        out[(size_t)i * a.n_scen] = af::pre_edge_draw(seed, e, i, dist, mean, sigma, dropout);
 }
 
 __global__ void af_probe_kernel(int kind, uint64_t seed, const double* in, const double* in2, double* out, size_t n) {
@@ -202,6 +266,11 @@ struct af_engine {
     size_t state_cap = 0;
     void* d_sweep = nullptr;  // seeds + override tables
     size_t sweep_cap = 0;
+    double* d_draws = nullptr;  // pre-generated draws
+    size_t draws_cap = 0;
+    uint32_t* d_pre_flags = nullptr;
+    size_t pre_flags_cap = 0;
+    hipEvent_t ev3 = nullptr;
     uint32_t request_capacity = 0, fifo_capacity = 0, force_global = 0;
     uint32_t n_lb_edges = 0;
     std::vector<uint32_t> row_of_step;
@@ -326,6 +395,7 @@ int af_engine_create(const af_plan_t* plan, int device, const af_engine_options_
     if (err == hipSuccess) err = hipEventCreate(&e->ev0);
     if (err == hipSuccess) err = hipEventCreate(&e->ev1);
     if (err == hipSuccess) err = hipEventCreate(&e->ev2);
+    if (err == hipSuccess) err = hipEventCreate(&e->ev3);
     if (err == hipSuccess) err = hipMalloc((void**)&e->d_blob, blob.size() * 8u);
     if (err == hipSuccess) err = hipMemcpy(e->d_blob, blob.data(), blob.size() * 8u, hipMemcpyHostToDevice);
     if (err != hipSuccess) {
@@ -418,7 +488,35 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
         a.state = e->d_state;
     }
 
+    // ---- pre-generate every random draw of every scenario (HBM) ----------------------
+    const uint32_t n_draw = sweep->draw_capacity ? sweep->draw_capacity : out->clock_capacity;
+    if (n_draw == 0) return fail(AF_ERR_INVALID, "draw_capacity (or clock_capacity) must be > 0");
+    const size_t draw_bytes = (size_t)(1u + a.n_edges) * n_draw * n * sizeof(double);
+    if (draw_bytes > e->draws_cap) {
+        if (e->d_draws) HIP_TRY(hipFree(e->d_draws));
+        e->d_draws = nullptr;
+        e->draws_cap = 0;
+        HIP_TRY(hipMalloc((void**)&e->d_draws, draw_bytes));
+        e->draws_cap = draw_bytes;
+    }
+    if ((size_t)n * 4 > e->pre_flags_cap) {
+        if (e->d_pre_flags) HIP_TRY(hipFree(e->d_pre_flags));
+        e->d_pre_flags = nullptr;
+        e->pre_flags_cap = 0;
+        HIP_TRY(hipMalloc((void**)&e->d_pre_flags, (size_t)n * 4));
+        e->pre_flags_cap = (size_t)n * 4;
+    }
+    a.draws = e->d_draws;
+    a.n_draw = n_draw;
+    a.pre_flags = e->d_pre_flags;
+    a.pregen_chunk = 128u;
+
     HIP_TRY(hipEventRecord(e->ev1, e->stream));
+    hipLaunchKernelGGL(af_pregen_arrivals, dim3((n + 63u) / 64u), dim3(64), 0, e->stream, a);
+    hipLaunchKernelGGL(af_pregen_edges, dim3((n + 255u) / 256u, (n_draw + a.pregen_chunk - 1u) / a.pregen_chunk, a.n_edges),
+                       dim3(256), 0, e->stream, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e->ev3, e->stream));
     if (lds_state) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(af_des_kernel<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -430,11 +528,14 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     HIP_TRY(hipEventRecord(e->ev2, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
 
-    float ms_h2d = 0.f, ms_k = 0.f;
+    float ms_h2d = 0.f, ms_k = 0.f, ms_p = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms_h2d, e->ev0, e->ev1));
-    HIP_TRY(hipEventElapsedTime(&ms_k, e->ev1, e->ev2));
+    HIP_TRY(hipEventElapsedTime(&ms_p, e->ev1, e->ev3));
+    HIP_TRY(hipEventElapsedTime(&ms_k, e->ev3, e->ev2));
     e->stats.kernel_ms = ms_k;
+    e->stats.pregen_ms = ms_p;
     e->stats.h2d_ms = ms_h2d;
+    e->stats.draw_bytes = draw_bytes;
     e->stats.state_bytes_per_scenario = bytes_per_lane;
     e->stats.state_in_lds = lds_state ? 1u : 0u;
     e->stats.lds_bytes_per_wave = lds_bytes;
@@ -459,6 +560,9 @@ void af_engine_destroy(af_engine_t* e) {
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->ev2) (void)hipEventDestroy(e->ev2);
+    if (e->ev3) (void)hipEventDestroy(e->ev3);
+    if (e->d_draws) (void)hipFree(e->d_draws);
+    if (e->d_pre_flags) (void)hipFree(e->d_pre_flags);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }

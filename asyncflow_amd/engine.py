@@ -106,7 +106,8 @@ class Engine:
         self._h = handle
 
     def run(self, seeds: np.ndarray, overrides: Sequence[tuple[int, int, np.ndarray]], *,
-            clock_ptr: int, clock_capacity: int, samples_ptr: int, tick_capacity: int, counts_ptr: int) -> _abi.AfStats:
+            clock_ptr: int, clock_capacity: int, samples_ptr: int, tick_capacity: int, counts_ptr: int,
+            draw_capacity: int = 0) -> _abi.AfStats:
         """Launch the sweep; output pointers are DEVICE addresses owned by the caller."""
         seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
         n = int(seeds.shape[0])
@@ -119,7 +120,7 @@ class Engine:
         for k, (param, index, _) in enumerate(overrides):
             ov[k].param, ov[k].index = int(param), int(index)
             ov[k].values = cols[k].ctypes.data_as(C.POINTER(C.c_double))
-        sweep = _abi.AfSweep(n, seeds.ctypes.data_as(C.POINTER(C.c_uint64)), len(cols), ov)
+        sweep = _abi.AfSweep(n, seeds.ctypes.data_as(C.POINTER(C.c_uint64)), len(cols), ov, int(draw_capacity))
         out = _abi.AfOutputs(int(clock_capacity), C.c_void_p(clock_ptr or None), int(tick_capacity),
                              C.c_void_p(samples_ptr or None), C.c_void_p(counts_ptr))
         _check(self._lib, self._lib.af_engine_run(self._h, C.byref(sweep), C.byref(out)), "af_engine_run")

@@ -177,6 +177,7 @@ class SimulationRunner:
                 samples_ptr=samples.data_ptr() if samples is not None else 0,
                 tick_capacity=ticks,
                 counts_ptr=counts.data_ptr(),
+                draw_capacity=clock_cap,
             )
             eng.close()
             res = BatchedResults(self.plan, self.seeds, counts, clock, samples, stats,
@@ -190,7 +191,7 @@ class SimulationRunner:
                 if cap >= 65535 and fifo >= 65536:
                     break
                 cap, fifo = min(65535, cap * 4), min(65536, fifo * 4)
-            if over & _abi.FLAG_CLOCK_OVERFLOW:
+            if over & (_abi.FLAG_CLOCK_OVERFLOW | _abi.FLAG_DRAW_OVERFLOW):
                 clock_cap *= 2
             warnings.warn(
                 f"engine capacity overflow (flags={over:#x}); retrying with request_capacity={cap}, "

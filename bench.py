@@ -119,6 +119,9 @@ def main() -> int:
     ap.add_argument("--horizon", type=int, default=600)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-series", action="store_true", help="do not store the sampled series")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
+                    help="BASELINE.json config: 2 = 10k LB-2 seed replicas (the metric's config, default); "
+                         "3 = users x RTT 100x100 grid; 4 = grid + injected spikes/outages; 5 = 8-server fan-out")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -127,6 +130,19 @@ def main() -> int:
     if world != args.gpus and world > 1:
         args.gpus = world
     payload = lb2_payload(args.horizon)
+    sweep: dict = {}
+    label = "two_servers_lb.yml (2 servers + LB, 400 users x 20 rpm"
+    if args.config in (3, 4):
+        from oracle.scenarios import lb_with_events
+
+        if args.config == 4:
+            payload = lb_with_events(users=400, horizon=args.horizon, scale=args.horizon / 600.0)
+        label = "LB-2 grid avg_active_users x RTT" + (" + event_inj_lb.yml spikes/outages" if args.config == 4 else "")
+    if args.config == 5:
+        from oracle.scenarios import fanout8
+
+        payload = fanout8(horizon=args.horizon)
+        label = "8-server fan-out, log-normal edges (120 users x 20 rpm"
 
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -152,8 +168,26 @@ def main() -> int:
     plan = lower(payload)
     n = args.replicas
     seeds = (SEED_BASE + rank * n + np.arange(n, dtype=np.uint64)).astype(np.uint64)
-    cap, fifo = estimate_capacities(plan)
-    clock_cap = plan.clock_capacity()
+    overrides = []
+    users_max = None
+    lat_scale = 1.0
+    if args.config in (3, 4):
+        # users = 10 a (a = 1..100), per-hop latency mean = 0.5 ms b (b = 1..100);
+        # scenarios are dealt to lanes by expected load so that a wave holds similar scenarios
+        from asyncflow_amd.runner import resolve_sweep
+
+        side = int(round(n ** 0.5))
+        n = side * side
+        a = np.repeat(np.arange(1, side + 1), side) * (1000.0 / side)
+        b = np.tile(np.arange(1, side + 1), side) * (0.05 / side)
+        order = np.argsort(-a, kind="stable")
+        a, b = a[order], b[order]
+        seeds = (0xC0F30000 + rank * n + np.arange(n, dtype=np.uint64)).astype(np.uint64)
+        overrides = [(c, i, v) for c, i, v, _ in resolve_sweep(plan, {
+            "rqs_input.avg_active_users.mean": a, "topology_graph.edges[*].latency.mean": b}, n)]
+        users_max, lat_scale = float(a.max()), float(b.max() / plan.edge_mean.min())
+    cap, fifo = estimate_capacities(plan, users_max, lat_scale)
+    clock_cap = plan.clock_capacity(users_max)
     ticks = max(plan.tick_count, 1)
     eng = Engine(plan, local_rank, request_capacity=cap, fifo_capacity=fifo)
     counts = torch.zeros((n, _abi.CNT_SLOTS), dtype=torch.int32, device=dev)
@@ -161,9 +195,9 @@ def main() -> int:
     samples = None if args.no_series else torch.zeros((n, plan.n_series, ticks), dtype=torch.int32, device=dev)
 
     def step():
-        return eng.run(seeds, [], clock_ptr=clock.data_ptr(), clock_capacity=clock_cap,
+        return eng.run(seeds, overrides, clock_ptr=clock.data_ptr(), clock_capacity=clock_cap,
                        samples_ptr=samples.data_ptr() if samples is not None else 0, tick_capacity=ticks,
-                       counts_ptr=counts.data_ptr())
+                       counts_ptr=counts.data_ptr(), draw_capacity=clock_cap)
 
     def barrier() -> None:
         if dist is not None:
@@ -225,7 +259,8 @@ def main() -> int:
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         sa = stats_all.double().cpu().numpy()
         line = {
-            "metric": "simulated request-events/sec (2-server LB scenario, 10k replicas/GPU)",
+            "metric": "simulated request-events/sec (2-server LB scenario, 10k replicas/GPU)" if args.config == 2
+                      else f"simulated request-events/sec (BASELINE config {args.config})",
             "value": total_events / elapsed,
             "unit": "request-events/s",
             "n_gpus": world,
@@ -238,8 +273,8 @@ def main() -> int:
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"two_servers_lb.yml (2 servers + LB, 400 users x 20 rpm, T={args.horizon} s, dt=0.05 s), "
-                            f"{n} seed replicas per GPU, seeds 0x5EED0000+i, full outputs"
+                "workload": f"{label}, T={args.horizon} s, dt=0.05 s), "
+                            f"{n} scenarios per GPU, full outputs"
                             + (" without sampled series" if args.no_series else ""),
                 "scenarios_per_gpu": n,
                 "parallelism": f"scenario-sharded x{world}, no data-path collective",
@@ -251,6 +286,8 @@ def main() -> int:
             "per_gpu_value": total_events / elapsed / world,
             "sweep_wall_s_per_10k": elapsed / args.steps * (10_000 / n),
             "kernel_ms": k_ms,
+            "pregen_ms": float(st.pregen_ms),
+            "draw_bytes": int(st.draw_bytes),
             "summary_ms": summary_ms,
             "gather_ms": gather_ms,
             "p95_ms_mean": float(np.nanmean(sa[:, 4]) * 1e3),

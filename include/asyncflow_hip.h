@@ -156,6 +156,9 @@ typedef struct af_sweep {
     const uint64_t* seeds;            /* HOST [n_scenarios] Philox keys          */
     uint32_t n_overrides;
     const af_override_t* overrides;   /* HOST [n_overrides]                      */
+    uint32_t draw_capacity;           /* upper bound on generated requests per scenario: the
+                                         engine pre-generates that many random draws per
+                                         stream (0 = outputs.clock_capacity)          */
 } af_sweep_t;
 
 /* ---- outputs ------------------------------------------------------------- */
@@ -176,9 +179,13 @@ enum af_flag {
     AF_FLAG_FIFO_OVERFLOW = 1u << 1,   /* a CPU/RAM wait queue exceeded fifo_capacity */
     AF_FLAG_CLOCK_OVERFLOW = 1u << 2,  /* more completions than clock_capacity     */
     AF_FLAG_TICK_OVERFLOW = 1u << 3,   /* more ticks than tick_capacity            */
-    AF_FLAG_RAM_STARVED = 1u << 4      /* a request needs more RAM than ram_mb: that
+    AF_FLAG_RAM_STARVED = 1u << 4,     /* a request needs more RAM than ram_mb: that
                                           server's RAM queue is blocked for good
                                           (same as the reference; informational) */
+    AF_FLAG_TIME_TIE = 1u << 5,        /* two timed events shared a timestamp: SimPy may
+                                          interleave their zero-time steps differently
+                                          (DESIGN.md "Ties"; informational) */
+    AF_FLAG_DRAW_OVERFLOW = 1u << 6    /* more arrivals than draw_capacity            */
 };
 
 typedef struct af_outputs {
@@ -206,8 +213,10 @@ typedef struct af_engine_options {
 } af_engine_options_t;
 
 typedef struct af_stats {
-    double kernel_ms;           /* HIP-event time of the last af_engine_run kernel */
+    double kernel_ms;           /* HIP-event time of the next-event kernel (af_des_kernel) */
+    double pregen_ms;           /* HIP-event time of the draw pre-generation kernels       */
     double h2d_ms;              /* seeds/overrides upload                          */
+    uint64_t draw_bytes;        /* size of the pre-generated draw arrays (HBM)     */
     uint64_t state_bytes_per_scenario;
     uint32_t state_in_lds;      /* 1 = LDS-resident state, 0 = HBM-resident        */
     uint32_t lds_bytes_per_wave;

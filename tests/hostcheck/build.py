@@ -38,7 +38,7 @@ def lib() -> C.CDLL:
         L.hc_simulate.argtypes = [
             C.POINTER(_abi.AfPlan), C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
             C.POINTER(C.c_double), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double), C.c_uint32,
-            C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+            C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32,
         ]
         L.hc_simulate.restype = C.c_int
         L.hc_bytes_per_lane.argtypes = [C.c_uint32] * 7
@@ -48,7 +48,8 @@ def lib() -> C.CDLL:
 
 
 def simulate(plan: DevicePlan, seed: int, *, cap: int = 4096, fcap: int = 4096,
-             overrides: list[tuple[str, int, float]] | None = None, clock_capacity: int | None = None):
+             overrides: list[tuple[str, int, float]] | None = None, clock_capacity: int | None = None,
+             draw_capacity: int | None = None):
     """Run one scenario through the engine core on the host. Returns (counts, clock, samples)."""
     L = lib()
     cplan = plan.as_ctypes()
@@ -66,6 +67,7 @@ def simulate(plan: DevicePlan, seed: int, *, cap: int = 4096, fcap: int = 4096,
         C.byref(cplan), C.c_uint64(seed), len(ov), params.ctypes.data_as(u32p), idxs.ctypes.data_as(u32p),
         vals.ctypes.data_as(f64p), cap, fcap, ccap, clock.ctypes.data_as(f64p), ticks,
         samples.ctypes.data_as(u32p), counts.ctypes.data_as(u32p),
+        int(draw_capacity if draw_capacity is not None else plan.clock_capacity()),
     )
     if rc != 0:
         msg = f"hc_simulate failed: {rc}"

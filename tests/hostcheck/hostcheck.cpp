@@ -25,7 +25,7 @@ struct MemHost {
 extern "C" int hc_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ovr, const uint32_t* ovr_param,
                            const uint32_t* ovr_index, const double* ovr_value, uint32_t cap, uint32_t fcap,
                            uint32_t clock_cap, double* clock, uint32_t tick_cap, uint32_t* samples,
-                           uint32_t* counts) {
+                           uint32_t* counts, uint32_t draw_cap) {
     if (!p || p->abi_version != AF_ABI_VERSION || p->struct_size != sizeof(af_plan_t)) return AF_ERR_ABI;
     if (fcap == 0 || (fcap & (fcap - 1)) != 0 || fcap > 32768) return AF_ERR_INVALID;
     af::PackedPlan pk;
@@ -42,16 +42,57 @@ extern "C" int hc_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ovr, co
 
     uint32_t mask = 0;
     std::vector<uint32_t> idx(n_ovr ? n_ovr : 1, 0u);
+    double users_mean = p->gen_users_mean, users_sigma = p->gen_users_sigma, rpm = p->gen_rpm_mean;
+    std::vector<double> e_mean(p->edge_mean, p->edge_mean + p->n_edges), e_sig(p->edge_sigma, p->edge_sigma + p->n_edges),
+        e_drop(p->edge_dropout, p->edge_dropout + p->n_edges);
     for (uint32_t k = 0; k < n_ovr; ++k) {
         mask |= 1u << ovr_param[k];
         idx[k] = ovr_param[k] == AF_PARAM_STEP_TIME ? pk.row_of_step[ovr_index[k]] : ovr_index[k];
+        switch (ovr_param[k]) {
+            case AF_PARAM_GEN_USERS_MEAN: users_mean = ovr_value[k]; break;
+            case AF_PARAM_GEN_USERS_SIGMA: users_sigma = ovr_value[k]; break;
+            case AF_PARAM_GEN_RPM_MEAN: rpm = ovr_value[k]; break;
+            case AF_PARAM_EDGE_MEAN: e_mean[ovr_index[k]] = ovr_value[k]; break;
+            case AF_PARAM_EDGE_SIGMA: e_sig[ovr_index[k]] = ovr_value[k]; break;
+            case AF_PARAM_EDGE_DROPOUT: e_drop[ovr_index[k]] = ovr_value[k]; break;
+            default: break;
+        }
     }
+    // pre-generation, exactly what af_pregen_arrivals / af_pregen_edges do on the GPU
+    const uint32_t n_draw = draw_cap;
+    std::vector<double> draws((size_t)(1 + p->n_edges) * (n_draw ? n_draw : 1), 0.0);
+    uint32_t flags_in = 0;
+    {
+        af::GenState g;
+        double t = 0.0;
+        uint32_t k = 0;
+        for (; k < n_draw; ++k) {
+            const double gap = af::gen_next_gap(g, seed, p->gen_users_dist, users_mean, users_sigma, rpm,
+                                                p->gen_window_s, p->total_time);
+            if (gap < 0.0) break;
+            t = t + gap;
+            draws[k] = t;
+        }
+        if (k == n_draw) {
+            if (af::gen_next_gap(g, seed, p->gen_users_dist, users_mean, users_sigma, rpm, p->gen_window_s,
+                                 p->total_time) >= 0.0)
+                flags_in |= AF_FLAG_DRAW_OVERFLOW;
+        }
+        for (; k < n_draw; ++k) draws[k] = af::AF_INF;
+    }
+    for (uint32_t e = 0; e < p->n_edges; ++e)
+        for (uint32_t i = 0; i < n_draw; ++i)
+            draws[(size_t)(1 + e) * n_draw + i] = af::pre_edge_draw(seed, e, i, p->edge_dist[e], e_mean[e], e_sig[e], e_drop[e]);
+
     const af::Layout L = af::make_layout(cap, fcap, p->n_edges, p->n_servers, p->n_lb_edges, pk.n_rows, mask);
     std::vector<uint64_t> w(L.n_words ? L.n_words : 1, 0ull);
     af::LaneOut O{clock, samples, counts, clock_cap, tick_cap};
-    af::Lane<MemHost> lane(V, L, MemHost{w.data()}, O, seed);
+    af::PreDraws D{draws.data(), n_draw, 1u, 0u, flags_in};
+    af::Lane<MemHost> lane(V, L, MemHost{w.data()}, O, D, seed);
     lane.init(ovr_param, idx.data(), n_ovr, [&](uint32_t k) { return ovr_value[k]; });
-    while (lane.round()) {
+    for (;;) {
+        if (lane.want_refill) lane.refill();
+        if (!lane.round()) break;
     }
     lane.write_counts();
     return 0;

@@ -108,3 +108,12 @@ def test_zero_users_produces_ticks_only():
     counts, clock, samples = hc.simulate(plan, 3)
     assert counts[_abi.CNT_GENERATED] == 0 and len(clock) == 0
     assert counts[_abi.CNT_TICKS] == plan.tick_count and not samples.any()
+
+
+def test_draw_capacity_overflow_is_flagged():
+    plan = lower(lb_two_servers(horizon=8))
+    counts, _, _ = hc.simulate(plan, 5, draw_capacity=100)
+    assert int(counts[_abi.CNT_FLAGS]) & _abi.FLAG_DRAW_OVERFLOW
+    assert int(counts[_abi.CNT_GENERATED]) == 100            # the arrival stream stops at the capacity
+    counts, _, _ = hc.simulate(plan, 5)
+    assert not int(counts[_abi.CNT_FLAGS]) & _abi.FLAG_DRAW_OVERFLOW
