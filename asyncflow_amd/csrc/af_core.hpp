@@ -157,19 +157,20 @@ constexpr double AF_INF = __builtin_huge_val();
 // Every random variate of a scenario is a pure function of (seed, stream, draw index)
 // and of the scenario's parameters -- never of the simulation state.  They are therefore
 // produced up front by fully parallel kernels (engine.hip: af_pregen_*), at full GPU
-// occupancy, into HBM:  draws[stream][index][scenario]  (f64)
+// occupancy, into HBM:  draws[scenario][stream][index]  (f64; a scenario's next draws of a
+// stream are contiguous, so the 4-entry top-ups below touch one or two 32 B sectors)
 //   stream 0     : absolute arrival times of the generator (AF_INF after the last one)
 //   stream 1 + e : transit time of the index-th message sent on edge e, or -1.0 if that
 //                  message is dropped (edge.py:78-86)
-// The sequential next-event kernel only stages them through small LDS rings.
+// The sequential next-event kernel only stages them through small LDS rings: a ring is
+// topped up (4 loads issued at the start of a round, stored at its end -- never waited
+// for) in the round after one of its entries was consumed.
 struct PreDraws {
-    const double* base;
-    uint32_t n_per_stream;  // entries per stream and scenario
-    uint32_t n_scen;        // scenarios in the launch (stride between consecutive indices)
-    uint32_t scen;          // this lane's scenario
+    const double* base;     // this scenario's block: [1 + n_edges][n_per_stream]
+    uint32_t n_per_stream;  // entries per stream
     uint32_t flags_in;      // AF_FLAG_DRAW_OVERFLOW if the arrival stream did not fit
     AF_HD double entry(uint32_t stream, uint32_t index) const {
-        return base[((size_t)stream * n_per_stream + index) * n_scen + scen];
+        return base[(size_t)stream * n_per_stream + index];
     }
 };
 
@@ -242,7 +243,8 @@ struct Lane {
     double now, t_gen, t_tick, t_emark, t_smark;
     uint64_t lb_list;  // LB out-edge order, 8 bits per entry (n_lb_edges <= 8), else in Mem
     uint32_t arr_ahead;  // arrival times staged in the ring beyond the next one
-    bool want_refill;    // a draw ring ran low: the wave restages all rings before the next round
+    bool dirty_arr;      // an arrival time was consumed: top its ring up next round
+    int32_t dirty_edge;  // edge whose ring was consumed from last (-1 = none): idem
     uint32_t heap_n, seq, live, max_live, lb_n, emark_i, smark_i;
     uint32_t n_gen, n_comp, n_drop, n_events, n_ticks, n_marks, flags, rounds;
 
@@ -382,32 +384,51 @@ struct Lane {
         return true;
     }
 
-    // ---- draw rings: stage the pre-generated draws of every stream into LDS ------------
-    // Runs for the whole wave (all lanes active) whenever some lane's ring ran low: 4 x (1+E)
-    // independent global loads per lane, one wait.
-    AF_CORE void refill() {
-        want_refill = false;
-        const uint32_t n = D.n_per_stream;
-        {   // stream 0: arrival times; t_gen is entry n_gen
-#pragma unroll
-            for (uint32_t k = 0u; k < RING; ++k) {
-                const uint32_t i = n_gen + k;
-                M.st(L.ring + (i & (RING - 1u)), d2u(i < n ? D.entry(0u, i) : AF_INF));
-            }
-            arr_ahead = RING - 1u;
-            t_gen = u2d(M.ld(L.ring + (n_gen & (RING - 1u))));
+    // ---- draw rings: stage the pre-generated draws through LDS ---------------------------
+    // ring row of stream s, draw index i: L.ring + RING * s + (i & (RING - 1))
+    struct TopUp {  // four draws in flight between the start and the end of a round
+        double v0, v1, v2, v3;
+        uint32_t stream, c0;
+        bool active;
+    };
+    AF_CORE double draw_or(uint32_t stream, uint32_t i, double none) const {
+        return i < D.n_per_stream ? D.entry(stream, i) : none;
+    }
+    AF_CORE TopUp topup_begin(bool want, uint32_t stream, uint32_t c0) const {
+        TopUp t;
+        t.active = want;
+        t.stream = stream;
+        t.c0 = c0;
+        const double none = stream == 0u ? AF_INF : -1.0;
+        t.v0 = t.v1 = t.v2 = t.v3 = none;
+        if (want) {  // four independent global loads; nobody waits for them until topup_end
+            t.v0 = draw_or(stream, c0, none);
+            t.v1 = draw_or(stream, c0 + 1u, none);
+            t.v2 = draw_or(stream, c0 + 2u, none);
+            t.v3 = draw_or(stream, c0 + 3u, none);
         }
-        for (uint32_t e = 0u; e < P.n_edges; ++e) {
-            const uint32_t at = L.edge + LEDGE * e;
-            const uint64_t cs = M.ld(at);
-            const uint32_t sends = (uint32_t)(cs >> 32);
-#pragma unroll
-            for (uint32_t k = 0u; k < RING; ++k) {
-                const uint32_t i = sends + k;
-                M.st(L.ring + RING * (1u + e) + (i & (RING - 1u)), d2u(i < n ? D.entry(1u + e, i) : -1.0));
-            }
-            M.st(at, (cs & ~(0xFFull << 16)) | ((uint64_t)RING << 16));
-        }
+        return t;
+    }
+    AF_CORE void topup_store(const TopUp& t) {
+        const uint32_t row = L.ring + RING * t.stream;
+        M.st(row + (t.c0 & (RING - 1u)), d2u(t.v0));
+        M.st(row + ((t.c0 + 1u) & (RING - 1u)), d2u(t.v1));
+        M.st(row + ((t.c0 + 2u) & (RING - 1u)), d2u(t.v2));
+        M.st(row + ((t.c0 + 3u) & (RING - 1u)), d2u(t.v3));
+    }
+    AF_CORE void topup_end_arrivals(const TopUp& t) {
+        if (!t.active) return;
+        topup_store(t);
+        arr_ahead = t.c0 + RING - 1u - n_gen;  // ring now holds [c0, c0 + RING); t_gen is entry n_gen
+    }
+    AF_CORE void topup_end_edge(const TopUp& t) {
+        if (!t.active) return;
+        topup_store(t);
+        const uint32_t at = L.edge + LEDGE * (t.stream - 1u);
+        const uint64_t cs = M.ld(at);
+        const uint32_t sends = (uint32_t)(cs >> 32);  // may have advanced past the staged window in a burst
+        const uint32_t ahead = t.c0 + RING > sends ? t.c0 + RING - sends : 0u;
+        M.st(at, (cs & ~(0xFFull << 16)) | ((uint64_t)ahead << 16));
     }
 
     // ---- SEND stage: EdgeRuntime.transport/_deliver up to the timeout (edge.py:73-107) ----
@@ -424,10 +445,10 @@ struct Lane {
             transit = u2d(M.ld(L.ring + RING * (1u + e) + (idx & (RING - 1u))));
             ncs -= 1ull << 16;
         } else {
-            transit = idx < D.n_per_stream ? D.entry(1u + e, idx) : -1.0;  // ring empty: straight from HBM (rare)
+            transit = draw_or(1u + e, idx, -1.0);  // ring empty: straight from HBM (rare)
             if (idx >= D.n_per_stream) flags |= FLAG_DRAW_OVERFLOW;
         }
-        if (ahead <= 1u) want_refill = true;
+        dirty_edge = (int32_t)e;
         if (transit < 0.0) {
             M.st(at, ncs);
             n_drop += 1u;
@@ -719,8 +740,7 @@ struct Lane {
 
     // ---- life cycle -----------------------------------------------------------------
     // `ovr` : per-lane reader of the override columns, ovr(k) -> double, k-th column;
-    // ovr_index of a STEP_TIME column is a step ROW.  Must be called with the whole wave
-    // active (it stages the draw rings).
+    // ovr_index of a STEP_TIME column is a step ROW.
     template <class OvrFn>
     AF_CORE void init(const uint32_t* ovr_param, const uint32_t* ovr_index, uint32_t n_ovr, OvrFn ovr) {
         now = 0.0;
@@ -752,7 +772,14 @@ struct Lane {
             const uint32_t idx = ovr_index[k];
             if (ovr_param[k] == PARAM_STEP_TIME) M.st(L.stime + idx, d2u(v));  // the others only shape the draws
         }
-        refill();  // also sets t_gen = first arrival
+        dirty_arr = false;
+        dirty_edge = -1;
+        {   // blocking first fill of every ring (once per scenario)
+            const TopUp t = topup_begin(true, 0u, 0u);
+            topup_end_arrivals(t);
+            t_gen = u2d(M.ld(L.ring));
+            for (uint32_t e = 0u; e < P.n_edges; ++e) topup_end_edge(topup_begin(true, 1u + e, 0u));
+        }
         t_tick = 0.0 + P.sample_period;
         t_emark = P.n_edge_marks ? u2d(P.emark[0]) : AF_INF;
         t_smark = P.n_srv_marks ? u2d(P.smark[0]) : AF_INF;
@@ -767,6 +794,16 @@ struct Lane {
     // (server.py:235-276): own I/O timer before the CPU waiter's; on endpoint end
     // the CPU waiter's timer, then transport(), then the RAM waiters.
     AF_CORE bool round() {
+        // top up the rings consumed from in the previous round: loads are issued now and
+        // stored at the end of this round, so their HBM latency hides behind the round
+        const bool want_arr = dirty_arr;
+        const bool want_edge = dirty_edge >= 0;
+        const uint32_t tu_e = want_edge ? (uint32_t)dirty_edge : 0u;
+        dirty_arr = false;
+        dirty_edge = -1;
+        const TopUp tu_arr = topup_begin(want_arr, 0u, n_gen);
+        const TopUp tu_edge =
+            topup_begin(want_edge, 1u + tu_e, want_edge ? (uint32_t)(M.ld(L.edge + LEDGE * tu_e) >> 32) : 0u);
         // the root entry is fetched in full up front: three independent LDS reads
         const double t_heap = heap_n > 0u ? u2d(M.ld(L.hk)) : AF_INF;
         const uint64_t root_a = M.ld(L.ha);
@@ -779,7 +816,7 @@ struct Lane {
         if (t_tick <= t) { cls = 2u; t = t_tick; }
         if (t_smark <= t) { cls = 1u; t = t_smark; }
         if (t_emark <= t) { cls = 0u; t = t_emark; }
-        if (!(t < P.total_time)) return false;  // the stop event is URGENT at T
+        if (!(t < P.total_time)) return false;  // the stop event is URGENT at T (pending top-ups are moot)
         if (rounds > 0u && t == now) flags |= FLAG_TIME_TIE;
         rounds += 1u;
         now = t;
@@ -813,9 +850,9 @@ struct Lane {
                 arr_ahead -= 1u;
                 t_gen = u2d(M.ld(L.ring + (n_gen & (RING - 1u))));
             } else {
-                t_gen = n_gen < D.n_per_stream ? D.entry(0u, n_gen) : AF_INF;
+                t_gen = draw_or(0u, n_gen, AF_INF);  // ring empty: straight from HBM (rare)
             }
-            if (arr_ahead == 0u) want_refill = true;
+            dirty_arr = true;
         } else if (cls == 2u) {
             sample_tick();
             t_tick = now + P.sample_period;
@@ -847,6 +884,8 @@ struct Lane {
             heap_commit(!more);
             if (!more) break;
         }
+        topup_end_arrivals(tu_arr);
+        topup_end_edge(tu_edge);
         return true;
     }
 

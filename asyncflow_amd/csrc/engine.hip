@@ -54,10 +54,9 @@ struct KArgs {
     uint32_t* counts;
     unsigned char* state;  // HBM-resident lane state (global-state mode only)
     uint64_t state_bytes_per_wave;
-    double* draws;          // pre-generated draws [1 + n_edges][n_draw][n_scen]
+    double* draws;          // pre-generated draws [n_scen][1 + n_edges][n_draw]
     uint32_t n_draw;
     uint32_t* pre_flags;    // [n_scen] AF_FLAG_DRAW_OVERFLOW from the arrival pre-generation
-    uint32_t pregen_chunk;  // draw indices handled by one thread of af_pregen_edges
 };
 
 struct MemLds {
@@ -126,10 +125,8 @@ __global__ void __launch_bounds__(64) af_des_kernel(const KArgs a) {
     const uint64_t seed = a.seeds[sc];
     auto ovr = [&](uint32_t k) { return a.ovr_values[(size_t)k * a.n_scen + sc]; };
     af::PreDraws D;
-    D.base = a.draws;
+    D.base = a.draws + (size_t)sc * (1u + a.n_edges) * a.n_draw;
     D.n_per_stream = a.n_draw;
-    D.n_scen = a.n_scen;
-    D.scen = sc;
     D.flags_in = a.pre_flags[sc];
 
     if constexpr (kLdsState) {
@@ -137,9 +134,8 @@ __global__ void __launch_bounds__(64) af_des_kernel(const KArgs a) {
         M.w = (LDS_AS uint64_t*)(smem + a.blob_bytes) + lane;
         af::Lane<MemLds> S(P, a.L, M, O, D, seed);
         bool run = active;
-        S.init(a.ovr_param, a.ovr_index, a.n_ovr, ovr);  // whole wave (inactive lanes shadow scenario 0)
+        if (active) S.init(a.ovr_param, a.ovr_index, a.n_ovr, ovr);
         while (__any(run)) {
-            if (__any(run && S.want_refill)) S.refill();  // wave-wide: every lane restages its rings
             if (run) run = S.round();
         }
         if (active) S.write_counts();
@@ -149,9 +145,8 @@ __global__ void __launch_bounds__(64) af_des_kernel(const KArgs a) {
         M.w = reinterpret_cast<uint64_t*>(base) + lane;
         af::Lane<MemGlobal> S(P, a.L, M, O, D, seed);
         bool run = active;
-        S.init(a.ovr_param, a.ovr_index, a.n_ovr, ovr);  // whole wave (inactive lanes shadow scenario 0)
+        if (active) S.init(a.ovr_param, a.ovr_index, a.n_ovr, ovr);
         while (__any(run)) {
-            if (__any(run && S.want_refill)) S.refill();  // wave-wide: every lane restages its rings
             if (run) run = S.round();
         }
         if (active) S.write_counts();
@@ -175,6 +170,7 @@ __global__ void __launch_bounds__(64) af_pregen_arrivals(const KArgs a) {
     const double users_sigma = ovr_or(a, af::PARAM_GEN_USERS_SIGMA, 0u, scen, a.gen_users_sigma);
     const double rpm = ovr_or(a, af::PARAM_GEN_RPM_MEAN, 0u, scen, a.gen_rpm_mean);
     af::GenState g;
+    double* out = a.draws + (size_t)scen * (1u + a.n_edges) * a.n_draw;  // stream 0 of this scenario
     double t = 0.0;
     uint32_t k = 0;
     uint32_t flags = 0;
@@ -183,31 +179,28 @@ __global__ void __launch_bounds__(64) af_pregen_arrivals(const KArgs a) {
                                             a.total_time);
         if (gap < 0.0) break;
         t = t + gap;
-        a.draws[(size_t)k * a.n_scen + scen] = t;
+        out[k] = t;
     }
     if (k == a.n_draw &&
         af::gen_next_gap(g, seed, a.gen_users_dist, users_mean, users_sigma, rpm, a.gen_window_s, a.total_time) >= 0.0)
         flags = AF_FLAG_DRAW_OVERFLOW;
-    for (; k < a.n_draw; ++k) a.draws[(size_t)k * a.n_scen + scen] = af::AF_INF;
+    for (; k < a.n_draw; ++k) out[k] = af::AF_INF;
     a.pre_flags[scen] = flags;
 }
 
-// Streams 1 + e: thread (scenario, chunk) of edge blockIdx.z draws `pregen_chunk` messages.
+// Streams 1 + e: block (x, scenario, edge) draws 256 consecutive messages (coalesced stores).
 __global__ void __launch_bounds__(256) af_pregen_edges(const KArgs a) {
-    const uint32_t scen = blockIdx.x * blockDim.x + threadIdx.x;
-    if (scen >= a.n_scen) return;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_draw) return;
+    const uint32_t scen = blockIdx.y;
     const uint32_t e = blockIdx.z;
     const uint64_t* rec = reinterpret_cast<const uint64_t*>(a.blob) + a.off_edge + af::EREC * e;
     const double mean = ovr_or(a, af::PARAM_EDGE_MEAN, e, scen, af::u2d(rec[0]));
     const double sigma = ovr_or(a, af::PARAM_EDGE_SIGMA, e, scen, af::u2d(rec[1]));
     const double dropout = ovr_or(a, af::PARAM_EDGE_DROPOUT, e, scen, af::u2d(rec[2]));
     const uint32_t dist = (uint32_t)(rec[3] >> 16) & 0xFFu;
-    const uint64_t seed = a.seeds[scen];
-    const uint32_t lo = blockIdx.y * a.pregen_chunk;
-    const uint32_t hi = lo + a.pregen_chunk < a.n_draw ? lo + a.pregen_chunk : a.n_draw;
-    double* out = a.draws + ((size_t)(1u + e) * a.n_draw) * a.n_scen + scen;
-    for (uint32_t i = lo; i < hi; ++i)
-        out[(size_t)i * a.n_scen] = af::pre_edge_draw(seed, e, i, dist, mean, sigma, dropout);
+    a.draws[((size_t)scen * (1u + a.n_edges) + 1u + e) * a.n_draw + i] =
+        af::pre_edge_draw(a.seeds[scen], e, i, dist, mean, sigma, dropout);
 }
 
 __global__ void af_probe_kernel(int kind, uint64_t seed, const double* in, const double* in2, double* out, size_t n) {
@@ -509,12 +502,11 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     a.draws = e->d_draws;
     a.n_draw = n_draw;
     a.pre_flags = e->d_pre_flags;
-    a.pregen_chunk = 128u;
 
     HIP_TRY(hipEventRecord(e->ev1, e->stream));
     hipLaunchKernelGGL(af_pregen_arrivals, dim3((n + 63u) / 64u), dim3(64), 0, e->stream, a);
-    hipLaunchKernelGGL(af_pregen_edges, dim3((n + 255u) / 256u, (n_draw + a.pregen_chunk - 1u) / a.pregen_chunk, a.n_edges),
-                       dim3(256), 0, e->stream, a);
+    if (n > 65535u) return fail(AF_ERR_CAPACITY, "at most 65535 scenarios per af_engine_run (shard the sweep)");
+    hipLaunchKernelGGL(af_pregen_edges, dim3((n_draw + 255u) / 256u, n, a.n_edges), dim3(256), 0, e->stream, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e->ev3, e->stream));
     if (lds_state) {
