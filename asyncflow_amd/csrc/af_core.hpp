@@ -243,26 +243,32 @@ struct Lane {
     double now, t_gen, t_tick, t_emark, t_smark;
     uint64_t lb_list;  // LB out-edge order, 8 bits per entry (n_lb_edges <= 8), else in Mem
     uint32_t arr_ahead;  // arrival times staged in the ring beyond the next one
-    bool dirty_arr;      // an arrival time was consumed: top its ring up next round
-    int32_t dirty_edge;  // edge whose ring was consumed from last (-1 = none): idem
+    int32_t dirty_edge;  // edge whose ring was consumed from last (-1 = none): topped up next round
+    // Per-lane boolean state lives in ONE register (a bool per lane costs a 64-bit
+    // lane mask in scalar registers and a pile of mask arithmetic at every branch).
+    uint32_t fl;
+    enum : uint32_t {
+        F_HOLE = 1u,       // the popped event left the heap root free
+        F_GRANT = 2u,      // a waiter received a CPU token
+        F_SEND = 4u,       // a message has to be put on an edge
+        F_ADV = 8u,        // a request (re)enters the endpoint step loop
+        F_ADV_CORE = 16u,  // ... holding a CPU core
+        F_ADV_IO = 32u,    // ... counted in the I/O queue
+        F_DIRTY_ARR = 64u  // an arrival time was consumed: top its ring up next round
+    };
     uint32_t heap_n, seq, live, max_live, lb_n, emark_i, smark_i;
     uint32_t n_gen, n_comp, n_drop, n_events, n_ticks, n_marks, flags, rounds;
 
     // per-round work registers ("follow-ups" of the timed event being handled)
-    bool hole;            // the popped event left the heap root free
     uint32_t pend_count;  // pushes buffered this pass (<= 2): the heap code exists once
     double pend_k0, pend_k1;
     uint64_t pend_a0, pend_a1, pend_b0, pend_b1;
-    bool fu_grant;  // a waiter received a CPU token
     uint64_t grant_a;
     uint32_t grant_st;
-    bool fu_send;   // a message has to be put on an edge
     uint64_t send_a;
     uint32_t send_edge, send_hops;
-    bool fu_adv;    // a request (re)enters the endpoint step loop
     uint64_t adv_a;
     uint32_t adv_sv, adv_step, adv_hops;
-    bool adv_core, adv_io;
     int32_t fu_ram_sv;  // RAM was released on this server: serve its wait queue
 
     AF_CORE Lane(const PlanView& p, const Layout& l, Mem m, LaneOut o, PreDraws d, uint64_t s)
@@ -328,7 +334,7 @@ struct Lane {
     // sift_up instance serve every case.
     AF_CORE void heap_commit(bool final_pass) {
         uint32_t k = 0u;
-        if (hole && (pend_count > 0u || final_pass)) {
+        if ((fl & F_HOLE) && (pend_count > 0u || final_pass)) {
             double key;
             uint64_t a, b;
             if (pend_count > 0u) {
@@ -342,7 +348,7 @@ struct Lane {
                 a = M.ld(L.ha + heap_n);
                 b = M.ld(L.hb + heap_n);
             }
-            hole = false;
+            fl &= ~F_HOLE;
             if (heap_n > 0u) sift_down(0u, key, a, b, heap_n);
         }
         for (; k < pend_count; ++k) {
@@ -478,7 +484,7 @@ struct Lane {
             const uint32_t from = L.cq + 2u * (sv * L.fcap + head);
             grant_a = M.ld(from);
             grant_st = (uint32_t)M.ld(from + 1u);
-            fu_grant = true;
+            fl |= F_GRANT;
             const uint64_t nq = (q & ~0xFFFFFFFFull) | ((head + 1u) & (L.fcap - 1u)) | ((uint64_t)(cqn - 1u) << 16);
             M.st(at + 4u, nq);
         } else {
@@ -525,7 +531,7 @@ struct Lane {
             M.st(at + 2u, d2u(u2d(M.ld(at + 2u)) + ram));  // ram container level
             if (((M.ld(at + 4u) >> 48) & 0x7FFFu) > 0u) fu_ram_sv = (int32_t)sv;
         }
-        fu_send = true;
+        fl |= F_SEND;
         send_a = a;
         send_edge = (uint32_t)(P.srv[SREC * sv + 1u] >> 16) & 0xFFFFu;
         send_hops = hops;
@@ -557,13 +563,11 @@ struct Lane {
         M.st(at + 4u, nq);
         M.st(at + 2u, d2u(free_ram - need));
         M.st(at + 3u, d2u(u2d(M.ld(at + 3u)) + need));
-        fu_adv = true;  // keep fu_ram_sv: the queue is looked at again after this waiter
+        fl = (fl & ~(F_ADV_CORE | F_ADV_IO)) | F_ADV;  // keep fu_ram_sv: the queue is looked at again after this waiter
         adv_a = a;
         adv_sv = sv;
         adv_step = step;
         adv_hops = st_hops(st);
-        adv_core = false;
-        adv_io = false;
     }
 
     // _dispatcher + head of _handle_request (server.py:303-313, 79-149)
@@ -600,13 +604,11 @@ struct Lane {
                 return;
             }
         }
-        fu_adv = true;
+        fl = (fl & ~(F_ADV_CORE | F_ADV_IO)) | F_ADV;
         adv_a = a;
         adv_sv = sv;
         adv_step = step0;
         adv_hops = hops;
-        adv_core = false;
-        adv_io = false;
     }
 
     // ---- load balancer order list (lb_algorithms.py, injection.py:201-226) ----------
@@ -663,13 +665,13 @@ struct Lane {
                 n_comp += 1u;
                 live -= 1u;
             } else {
-                fu_send = true;
+                fl |= F_SEND;
                 send_a = a;
                 send_edge = P.client_out_edge;
                 send_hops = hops;
             }
         } else if (tk == NODE_LB) {  // LoadBalancerRuntime._forwarder, load_balancer.py:60-72
-            fu_send = true;
+            fl |= F_SEND;
             send_a = a;
             send_edge = lb_pick();
             send_hops = hops + 1u;
@@ -747,7 +749,7 @@ struct Lane {
         heap_n = seq = live = max_live = emark_i = smark_i = 0u;
         n_gen = n_comp = n_drop = n_events = n_ticks = n_marks = rounds = 0u;
         flags = D.flags_in;
-        hole = fu_send = fu_adv = fu_grant = false;
+        fl = 0u;
         pend_count = 0u;
         fu_ram_sv = -1;
         for (uint32_t e = 0u; e < P.n_edges; ++e) {
@@ -772,7 +774,6 @@ struct Lane {
             const uint32_t idx = ovr_index[k];
             if (ovr_param[k] == PARAM_STEP_TIME) M.st(L.stime + idx, d2u(v));  // the others only shape the draws
         }
-        dirty_arr = false;
         dirty_edge = -1;
         {   // blocking first fill of every ring (once per scenario)
             const TopUp t = topup_begin(true, 0u, 0u);
@@ -796,10 +797,10 @@ struct Lane {
     AF_CORE bool round() {
         // top up the rings consumed from in the previous round: loads are issued now and
         // stored at the end of this round, so their HBM latency hides behind the round
-        const bool want_arr = dirty_arr;
+        const bool want_arr = (fl & F_DIRTY_ARR) != 0u;
         const bool want_edge = dirty_edge >= 0;
         const uint32_t tu_e = want_edge ? (uint32_t)dirty_edge : 0u;
-        dirty_arr = false;
+        fl &= ~F_DIRTY_ARR;
         dirty_edge = -1;
         const TopUp tu_arr = topup_begin(want_arr, 0u, n_gen);
         const TopUp tu_edge =
@@ -822,26 +823,24 @@ struct Lane {
         now = t;
 
         if (cls == 4u) {
-            hole = true;
+            fl |= F_HOLE;
             n_events += 1u;
             const uint32_t kind = st_kind(root_st);
             if (kind == RK_TRANSIT) {
                 deliver(root_a, st_idx(root_st), st_hops(root_st));
             } else {  // CPU or I/O step finished: the for-loop moves to the next step row
-                fu_adv = true;
+                fl |= F_ADV | (kind == RK_CPU ? F_ADV_CORE : 0u) | (st_io(root_st) ? F_ADV_IO : 0u);
                 adv_a = root_a;
                 adv_sv = st_idx(root_st);
                 adv_step = st_step(root_st) + 1u;
                 adv_hops = st_hops(root_st);
-                adv_core = kind == RK_CPU;
-                adv_io = st_io(root_st) != 0u;
             }
         } else if (cls == 3u) {  // RqsGeneratorRuntime._event_arrival (rqs_generator.py:101-119)
             n_gen += 1u;
             n_events += 1u;
             live += 1u;
             if (live > max_live) max_live = live;
-            fu_send = true;
+            fl |= F_SEND;
             send_a = d2u(now);
             send_edge = P.gen_out_edge;
             send_hops = 1u;  // record_hop(GENERATOR)
@@ -852,7 +851,7 @@ struct Lane {
             } else {
                 t_gen = draw_or(0u, n_gen, AF_INF);  // ring empty: straight from HBM (rare)
             }
-            dirty_arr = true;
+            fl |= F_DIRTY_ARR;
         } else if (cls == 2u) {
             sample_tick();
             t_tick = now + P.sample_period;
@@ -865,22 +864,21 @@ struct Lane {
         for (;;) {
             // each stage pushes at most one event; the buffer holds two, so a pass
             // stops early (stage order preserved) when it is full -- rare.
-            if (fu_adv) {
-                fu_adv = false;
-                advance(adv_a, adv_sv, adv_step, adv_hops, adv_core, adv_io);
+            if (fl & F_ADV) {
+                const uint32_t f = fl;
+                fl &= ~(F_ADV | F_ADV_CORE | F_ADV_IO);
+                advance(adv_a, adv_sv, adv_step, adv_hops, (f & F_ADV_CORE) != 0u, (f & F_ADV_IO) != 0u);
             }
-            bool room = pend_count < 2u;
-            if (fu_grant && room) {
-                fu_grant = false;
+            if ((fl & F_GRANT) && pend_count < 2u) {
+                fl &= ~F_GRANT;
                 cpu_granted();
-                room = pend_count < 2u;
             }
-            if (fu_send && !fu_grant && room) {
-                fu_send = false;
+            if ((fl & (F_SEND | F_GRANT)) == F_SEND && pend_count < 2u) {
+                fl &= ~F_SEND;
                 edge_send(send_a, send_edge, send_hops);
             }
-            if (fu_ram_sv >= 0 && !fu_grant && !fu_send) ram_stage();
-            const bool more = fu_adv || fu_grant || fu_send || fu_ram_sv >= 0;
+            if (fu_ram_sv >= 0 && !(fl & (F_GRANT | F_SEND))) ram_stage();
+            const bool more = (fl & (F_ADV | F_GRANT | F_SEND)) != 0u || fu_ram_sv >= 0;
             heap_commit(!more);
             if (!more) break;
         }
