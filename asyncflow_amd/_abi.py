@@ -151,6 +151,7 @@ class AfEngineOptions(C.Structure):
         ("request_capacity", C.c_uint32),
         ("fifo_capacity", C.c_uint32),
         ("force_global_state", C.c_uint32),
+        ("lanes_per_wave", C.c_uint32),
     ]
 
 
@@ -164,6 +165,7 @@ class AfStats(C.Structure):
         ("state_in_lds", C.c_uint32),
         ("lds_bytes_per_wave", C.c_uint32),
         ("waves", C.c_uint32),
+        ("lanes_per_wave", C.c_uint32),
         ("request_capacity", C.c_uint32),
         ("fifo_capacity", C.c_uint32),
     ]

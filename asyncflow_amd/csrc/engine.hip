@@ -57,18 +57,22 @@ struct KArgs {
     double* draws;          // pre-generated draws [n_scen][1 + n_edges][n_draw]
     uint32_t n_draw;
     uint32_t* pre_flags;    // [n_scen] AF_FLAG_DRAW_OVERFLOW from the arrival pre-generation
+    uint32_t klog;          // log2(scenario lanes per wave)
 };
 
+// Per-lane state memory, [index][lane] with 2^klog scenario lanes per wave.
 struct MemLds {
     LDS_AS uint64_t* w;  // already offset by the lane
-    __device__ __forceinline__ uint64_t ld(uint32_t i) const { return w[i * kWave]; }
-    __device__ __forceinline__ void st(uint32_t i, uint64_t v) const { w[i * kWave] = v; }
+    uint32_t klog;
+    __device__ __forceinline__ uint64_t ld(uint32_t i) const { return w[i << klog]; }
+    __device__ __forceinline__ void st(uint32_t i, uint64_t v) const { w[i << klog] = v; }
 };
 
 struct MemGlobal {
     uint64_t* w;
-    __device__ __forceinline__ uint64_t ld(uint32_t i) const { return w[i * kWave]; }
-    __device__ __forceinline__ void st(uint32_t i, uint64_t v) const { w[i * kWave] = v; }
+    uint32_t klog;
+    __device__ __forceinline__ uint64_t ld(uint32_t i) const { return w[i << klog]; }
+    __device__ __forceinline__ void st(uint32_t i, uint64_t v) const { w[i << klog] = v; }
 };
 
 __device__ __forceinline__ const LDS_AS uint64_t* lds_words(unsigned char* smem, uint32_t word_off) {
@@ -111,8 +115,12 @@ __global__ void __launch_bounds__(64) af_des_kernel(const KArgs a) {
     P.smark = lds_words(smem, a.off_smark);
     P.lb = lds_words(smem, a.off_lb);
 
-    const uint32_t scen = blockIdx.x * kWave + lane;
-    const bool active = scen < a.n_scen;
+    // Only the first 2^klog lanes of a wave carry scenarios.  With few scenarios per GPU the
+    // sweep is spread over MANY narrow waves: fewer event kinds per round in each wave (less
+    // divergence), every SIMD of the chip busy, several waves per SIMD hiding LDS latency.
+    const uint32_t kl = 1u << a.klog;
+    const uint32_t scen = (blockIdx.x << a.klog) + lane;
+    const bool active = lane < kl && scen < a.n_scen;
     const uint32_t sc = active ? scen : 0u;
 
     af::LaneOut O;
@@ -131,7 +139,8 @@ __global__ void __launch_bounds__(64) af_des_kernel(const KArgs a) {
 
     if constexpr (kLdsState) {
         MemLds M;
-        M.w = (LDS_AS uint64_t*)(smem + a.blob_bytes) + lane;
+        M.w = (LDS_AS uint64_t*)(smem + a.blob_bytes) + (lane & (kl - 1u));
+        M.klog = a.klog;
         af::Lane<MemLds> S(P, a.L, M, O, D, seed);
         bool run = active;
         if (active) S.init(a.ovr_param, a.ovr_index, a.n_ovr, ovr);
@@ -142,7 +151,8 @@ __global__ void __launch_bounds__(64) af_des_kernel(const KArgs a) {
     } else {
         unsigned char* base = a.state + (size_t)blockIdx.x * a.state_bytes_per_wave;
         MemGlobal M;
-        M.w = reinterpret_cast<uint64_t*>(base) + lane;
+        M.w = reinterpret_cast<uint64_t*>(base) + (lane & (kl - 1u));
+        M.klog = a.klog;
         af::Lane<MemGlobal> S(P, a.L, M, O, D, seed);
         bool run = active;
         if (active) S.init(a.ovr_param, a.ovr_index, a.n_ovr, ovr);
@@ -264,7 +274,7 @@ struct af_engine {
     uint32_t* d_pre_flags = nullptr;
     size_t pre_flags_cap = 0;
     hipEvent_t ev3 = nullptr;
-    uint32_t request_capacity = 0, fifo_capacity = 0, force_global = 0;
+    uint32_t request_capacity = 0, fifo_capacity = 0, force_global = 0, lanes_per_wave = 0;
     uint32_t n_lb_edges = 0;
     std::vector<uint32_t> row_of_step;
     af_stats_t stats{};
@@ -375,6 +385,12 @@ int af_engine_create(const af_plan_t* plan, int device, const af_engine_options_
     e->request_capacity = opts && opts->request_capacity ? opts->request_capacity : 64u;
     e->fifo_capacity = pow2_at_least(opts && opts->fifo_capacity ? opts->fifo_capacity : 32u);
     e->force_global = opts ? opts->force_global_state : 0u;
+    e->lanes_per_wave = opts ? opts->lanes_per_wave : 0u;
+    if (e->lanes_per_wave & (e->lanes_per_wave - 1u)) {
+        delete e;
+        return fail(AF_ERR_INVALID, "lanes_per_wave must be 0 (auto) or a power of two <= 64");
+    }
+    if (e->lanes_per_wave > 64u) e->lanes_per_wave = 64u;
     if (e->request_capacity > 65535u || e->fifo_capacity > 32768u) {
         delete e;
         return fail(AF_ERR_CAPACITY, "request_capacity must be <= 65535 and fifo_capacity <= 32768");
@@ -422,9 +438,18 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     }
     a.L = af::make_layout(e->request_capacity, e->fifo_capacity, a.n_edges, a.n_servers, a.n_lb_edges, a.n_rows, mask);
     const uint64_t bytes_per_lane = af::layout_bytes_per_lane(a.L);
-    const uint64_t state_per_wave = bytes_per_lane * kWave;
+    // scenario lanes per wave: few scenarios -> many narrow waves (see af_des_kernel)
+    uint32_t kl = e->lanes_per_wave;
+    if (kl == 0u) {
+        kl = kWave;
+        while (kl > 4u && (n + kl - 1u) / kl < 2048u) kl >>= 1;
+    }
+    uint32_t klog = 0;
+    while ((1u << klog) < kl) ++klog;
+    a.klog = klog;
+    const uint64_t state_per_wave = bytes_per_lane * kl;
     const bool lds_state = !e->force_global && (uint64_t)a.blob_bytes + state_per_wave <= kLdsLimit;
-    const uint32_t waves = (n + kWave - 1) / kWave;
+    const uint32_t waves = (n + kl - 1) / kl;
     const uint32_t lds_bytes = lds_state ? (uint32_t)(a.blob_bytes + state_per_wave) : a.blob_bytes;
 
     // ---- upload seeds + override tables (one staging buffer) -------------------
@@ -532,6 +557,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     e->stats.state_in_lds = lds_state ? 1u : 0u;
     e->stats.lds_bytes_per_wave = lds_bytes;
     e->stats.waves = waves;
+    e->stats.lanes_per_wave = kl;
     e->stats.request_capacity = e->request_capacity;
     e->stats.fifo_capacity = e->fifo_capacity;
     return AF_OK;

@@ -210,6 +210,8 @@ typedef struct af_engine_options {
     uint32_t request_capacity;  /* live requests per scenario (0 = engine default) */
     uint32_t fifo_capacity;     /* waiters per server queue   (0 = engine default) */
     uint32_t force_global_state;/* 1 = keep per-scenario state in HBM even if it fits LDS */
+    uint32_t lanes_per_wave;    /* scenarios per wavefront: power of two <= 64, 0 = auto
+                                   (few scenarios are spread over many narrow waves)    */
 } af_engine_options_t;
 
 typedef struct af_stats {
@@ -220,7 +222,8 @@ typedef struct af_stats {
     uint64_t state_bytes_per_scenario;
     uint32_t state_in_lds;      /* 1 = LDS-resident state, 0 = HBM-resident        */
     uint32_t lds_bytes_per_wave;
-    uint32_t waves;             /* workgroups launched (one wave of 64 scenarios)  */
+    uint32_t waves;             /* workgroups launched (one wavefront each)        */
+    uint32_t lanes_per_wave;    /* scenarios carried by each wavefront             */
     uint32_t request_capacity;
     uint32_t fifo_capacity;
 } af_stats_t;

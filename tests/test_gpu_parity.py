@@ -84,7 +84,7 @@ def test_engine_reproduces_reference_fixtures(name):
 def test_lb2_batch_matches_oracle_everywhere_sampled():
     payload = lb_two_servers(horizon=30)
     seeds = 0x5EED0000 + np.arange(200, dtype=np.uint64)     # not a multiple of 64: ragged last wave
-    res = _runner(payload, seeds=seeds).run()
+    res = _runner(payload, seeds=seeds, lanes_per_wave=64).run()
     assert res.engine_stats.state_in_lds == 1 and res.engine_stats.waves == 4
     plan = lower(payload)
     for i in (0, 1, 63, 64, 127, 199):
@@ -107,11 +107,27 @@ def test_global_state_mode_is_bit_identical_to_lds_mode():
 def test_large_state_falls_back_to_hbm_and_still_matches():
     payload = fanout8(horizon=20)                           # ~200 requests in flight: does not fit LDS
     seeds = np.arange(64, dtype=np.uint64) + 11
-    res = _runner(payload, seeds=seeds).run()
+    res = _runner(payload, seeds=seeds, lanes_per_wave=64).run()
     assert res.engine_stats.state_in_lds == 0
     plan = lower(payload)
     for i in (0, 33):
         _assert_scenario(res[i], ol.simulate(plan, int(seeds[i]), atomic=True))
+    narrow = _runner(payload, seeds=seeds).run()            # few scenarios -> narrow waves -> fits LDS
+    assert narrow.engine_stats.state_in_lds == 1 and narrow.engine_stats.lanes_per_wave < 64
+    assert np.array_equal(narrow.counts, res.counts)
+    assert np.array_equal(narrow[33].rqs_clock, res[33].rqs_clock)
+
+
+@pytest.mark.parametrize("lanes", [1, 2, 8, 32, 64])
+def test_lanes_per_wave_does_not_change_results(lanes):
+    payload = lb_with_events(users=150, horizon=20, scale=0.03)
+    seeds = np.arange(77, dtype=np.uint64) + 900
+    ref = _runner(payload, seeds=seeds, lanes_per_wave=4).run()
+    res = _runner(payload, seeds=seeds, lanes_per_wave=lanes).run()
+    assert res.engine_stats.lanes_per_wave == lanes
+    assert np.array_equal(ref.counts, res.counts)
+    for i in (0, 40, 76):
+        assert np.array_equal(ref[i].rqs_clock, res[i].rqs_clock) and np.array_equal(ref[i]._samples, res[i]._samples)  # noqa: SLF001
 
 
 def test_parameter_sweep_columns():
