@@ -401,7 +401,10 @@ def estimate_capacities(
         live += rate * plan.total_time
     cap = int(live + 8.0 * math.sqrt(max(live, 1.0)) + 8.0)
     cap = min(65535, max(16, (cap + 7) // 8 * 8))
+    # waiters per server queue: everything when saturated, else the M/D/1 queue length + slack
+    lq = 0.0 if saturated else rho * rho / (2.0 * (1.0 - rho))
+    want = cap if saturated else min(cap, int(lq + 10.0 * math.sqrt(lq + 1.0)) + 1)
     fifo = 8
-    while fifo < (cap if saturated else min(cap, max(8, cap // 2))):
+    while fifo < want:
         fifo *= 2
     return cap, fifo
