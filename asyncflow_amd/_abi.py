@@ -152,7 +152,6 @@ class AfEngineOptions(C.Structure):
         ("fifo_capacity", C.c_uint32),
         ("force_global_state", C.c_uint32),
         ("lanes_per_wave", C.c_uint32),
-        ("waves_per_simd", C.c_uint32),
     ]
 
 

@@ -79,10 +79,10 @@ __device__ __forceinline__ const LDS_AS uint64_t* lds_words(unsigned char* smem,
     return (const LDS_AS uint64_t*)smem + word_off;
 }
 
-// kOcc = waves per SIMD the register allocator must leave room for (launch bound): more
-// resident narrow waves per SIMD hide LDS latency, at the price of a few spilled registers.
-template <bool kLdsState, int kOcc>
-__global__ void __launch_bounds__(64, kOcc) af_des_kernel(const KArgs a) {
+// (Measured on MI355X, profiles/r01: forcing more than the natural 3 waves/SIMD with a
+// launch bound spills registers and is 1.5-3x slower; the kernel keeps its ~144 VGPRs.)
+template <bool kLdsState>
+__global__ void __launch_bounds__(64) af_des_kernel(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lane = threadIdx.x;
 
@@ -276,7 +276,7 @@ struct af_engine {
     uint32_t* d_pre_flags = nullptr;
     size_t pre_flags_cap = 0;
     hipEvent_t ev3 = nullptr;
-    uint32_t request_capacity = 0, fifo_capacity = 0, force_global = 0, lanes_per_wave = 0, waves_per_simd = 3;
+    uint32_t request_capacity = 0, fifo_capacity = 0, force_global = 0, lanes_per_wave = 0;
     uint32_t n_lb_edges = 0;
     std::vector<uint32_t> row_of_step;
     af_stats_t stats{};
@@ -388,7 +388,6 @@ int af_engine_create(const af_plan_t* plan, int device, const af_engine_options_
     e->fifo_capacity = pow2_at_least(opts && opts->fifo_capacity ? opts->fifo_capacity : 32u);
     e->force_global = opts ? opts->force_global_state : 0u;
     e->lanes_per_wave = opts ? opts->lanes_per_wave : 0u;
-    e->waves_per_simd = opts && opts->waves_per_simd ? opts->waves_per_simd : 3u;
     if (e->lanes_per_wave & (e->lanes_per_wave - 1u)) {
         delete e;
         return fail(AF_ERR_INVALID, "lanes_per_wave must be 0 (auto) or a power of two <= 64");
@@ -442,10 +441,13 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     a.L = af::make_layout(e->request_capacity, e->fifo_capacity, a.n_edges, a.n_servers, a.n_lb_edges, a.n_rows, mask);
     const uint64_t bytes_per_lane = af::layout_bytes_per_lane(a.L);
     // scenario lanes per wave: few scenarios -> many narrow waves (see af_des_kernel)
+    // The kernel's ~144 VGPRs admit 3 waves per SIMD = 3072 resident waves on 256 CUs: use the
+    // narrowest waves that still keep the whole sweep resident (measured at 10 000 LB-2 scenarios:
+    // 64 lanes 2.83 s, 16: 3.21 s, 8: 2.83 s, 4: 2.10 s, 2: 2.91 s [1.6 residency batches]).
     uint32_t kl = e->lanes_per_wave;
     if (kl == 0u) {
-        kl = kWave;
-        while (kl > 4u && (n + kl - 1u) / kl < 2048u) kl >>= 1;
+        kl = 1u;
+        while (kl < kWave && (n + kl - 1u) / kl > 2560u) kl <<= 1;
     }
     uint32_t klog = 0;
     while ((1u << klog) < kl) ++klog;
@@ -537,19 +539,12 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     hipLaunchKernelGGL(af_pregen_edges, dim3((n_draw + 255u) / 256u, n, a.n_edges), dim3(256), 0, e->stream, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e->ev3, e->stream));
-    {
-        using Kern = void (*)(const KArgs);
-        const uint32_t occ = e->waves_per_simd;
-        Kern k;
-        if (lds_state)
-            k = occ >= 6 ? af_des_kernel<true, 6> : occ == 5 ? af_des_kernel<true, 5> : occ == 4 ? af_des_kernel<true, 4>
-                                                                                                 : af_des_kernel<true, 3>;
-        else
-            k = occ >= 6 ? af_des_kernel<false, 6> : occ == 5 ? af_des_kernel<false, 5> : occ == 4 ? af_des_kernel<false, 4>
-                                                                                                    : af_des_kernel<false, 3>;
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds_bytes));
-        hipLaunchKernelGGL(k, dim3(waves), dim3(kWave), lds_bytes, e->stream, a);
+    if (lds_state) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(af_des_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL(af_des_kernel<true>, dim3(waves), dim3(kWave), lds_bytes, e->stream, a);
+    } else {
+        hipLaunchKernelGGL(af_des_kernel<false>, dim3(waves), dim3(kWave), lds_bytes, e->stream, a);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e->ev2, e->stream));

@@ -212,7 +212,6 @@ typedef struct af_engine_options {
     uint32_t force_global_state;/* 1 = keep per-scenario state in HBM even if it fits LDS */
     uint32_t lanes_per_wave;    /* scenarios per wavefront: power of two <= 64, 0 = auto
                                    (few scenarios are spread over many narrow waves)    */
-    uint32_t waves_per_simd;    /* occupancy the kernel variant is compiled for: 3..6, 0 = auto */
 } af_engine_options_t;
 
 typedef struct af_stats {
