@@ -441,19 +441,49 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     a.L = af::make_layout(e->request_capacity, e->fifo_capacity, a.n_edges, a.n_servers, a.n_lb_edges, a.n_rows, mask);
     const uint64_t bytes_per_lane = af::layout_bytes_per_lane(a.L);
     // scenario lanes per wave: few scenarios -> many narrow waves (see af_des_kernel)
-    // The kernel's ~144 VGPRs admit 3 waves per SIMD = 3072 resident waves on 256 CUs: use the
-    // narrowest waves that still keep the whole sweep resident (measured at 10 000 LB-2 scenarios:
-    // 64 lanes 2.83 s, 16: 3.21 s, 8: 2.83 s, 4: 2.10 s, 2: 2.91 s [1.6 residency batches]).
+    // Scenario lanes per wave and state placement.  The kernel is latency bound, so few
+    // scenarios are best spread over MANY narrow waves: fewer event kinds per round in a
+    // wave, every SIMD busy, several waves per SIMD hiding LDS latency.  Limits: ~144 VGPRs
+    // -> 3 waves/SIMD = 12 per CU; LDS-resident state -> 160 KiB per CU.  Cost model fitted
+    // to MI355X measurements (profiles/r01/lanes_sweep.md): relative time of one wave-round
+    // f(lanes), x 2.3 when the state lives in HBM, x the number of residency batches.
     uint32_t kl = e->lanes_per_wave;
-    if (kl == 0u) {
-        kl = 1u;
-        while (kl < kWave && (n + kl - 1u) / kl > 2560u) kl <<= 1;
+    bool lds_state;
+    {
+        static const double f_lanes[7] = {1.0, 1.4, 1.65, 2.2, 2.5, 2.4, 2.25};  // 1,2,4,...,64 lanes
+        const double n_cu = 256.0, vgpr_waves_per_cu = 12.0;
+        double best = 1e300;
+        uint32_t best_kl = 4;
+        bool best_lds = false;
+        for (uint32_t k = 0; k < 7; ++k) {
+            const uint32_t cand = 1u << k;
+            if (kl != 0u && cand != kl) continue;
+            const double waves_needed = (double)((n + cand - 1u) / cand);
+            for (int lds = 1; lds >= 0; --lds) {
+                if (lds && e->force_global) continue;
+                double per_cu = vgpr_waves_per_cu;
+                if (lds) {
+                    const uint64_t wg_bytes = (uint64_t)a.blob_bytes + bytes_per_lane * cand;
+                    if (wg_bytes > kLdsLimit) continue;
+                    const double fit = (double)(kLdsLimit / wg_bytes);
+                    per_cu = fit < per_cu ? fit : per_cu;
+                }
+                const double batches = waves_needed / (n_cu * per_cu);
+                const double cost = (batches < 1.0 ? 1.0 : batches) * f_lanes[k] * (lds ? 1.0 : 2.3);
+                if (cost < best) {
+                    best = cost;
+                    best_kl = cand;
+                    best_lds = lds != 0;
+                }
+            }
+        }
+        kl = best_kl;
+        lds_state = best_lds;
     }
     uint32_t klog = 0;
     while ((1u << klog) < kl) ++klog;
     a.klog = klog;
     const uint64_t state_per_wave = bytes_per_lane * kl;
-    const bool lds_state = !e->force_global && (uint64_t)a.blob_bytes + state_per_wave <= kLdsLimit;
     const uint32_t waves = (n + kl - 1) / kl;
     const uint32_t lds_bytes = lds_state ? (uint32_t)(a.blob_bytes + state_per_wave) : a.blob_bytes;
 
