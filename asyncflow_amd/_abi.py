@@ -179,6 +179,7 @@ EXPORTED_SYMBOLS = (
     "af_engine_destroy",
     "af_tick_count",
     "af_series_count",
+    "af_series_pitch",
     "af_last_error",
     "af_abi_version",
     "af_probe_math",
@@ -201,6 +202,8 @@ def declare(lib: C.CDLL) -> C.CDLL:
     lib.af_tick_count.restype = C.c_uint32
     lib.af_series_count.argtypes = [C.POINTER(AfPlan)]
     lib.af_series_count.restype = C.c_uint32
+    lib.af_series_pitch.argtypes = [C.POINTER(AfPlan)]
+    lib.af_series_pitch.restype = C.c_uint32
     lib.af_last_error.argtypes = []
     lib.af_last_error.restype = C.c_char_p
     lib.af_abi_version.argtypes = []

@@ -146,10 +146,19 @@ AF_HD uint64_t layout_bytes_per_lane(const Layout& L) { return 8ull * L.n_words;
 // ---- outputs of one scenario -------------------------------------------------
 struct LaneOut {
     double* clock;      // [clock_cap][2] or nullptr
-    uint32_t* samples;  // [n_series][tick_cap] or nullptr
+    uint32_t* samples;  // [tick_cap][series_pitch] or nullptr (16-byte aligned rows)
     uint32_t* counts;   // [CNT_SLOTS]
-    uint32_t clock_cap, tick_cap;
+    uint32_t clock_cap, tick_cap, series_pitch;
 };
+
+// one 16-byte store (rows of the sample array are 16-byte aligned)
+AF_HD void store4(uint32_t* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    *reinterpret_cast<uint4*>(p) = make_uint4(a, b, c, d);
+#else
+    p[0] = a; p[1] = b; p[2] = c; p[3] = d;
+#endif
+}
 
 constexpr double AF_INF = __builtin_huge_val();
 
@@ -717,22 +726,37 @@ struct Lane {
     }
 
     // ---- sampler tick (metrics/collector.py:50-66) --------------------------------
+    // One tick = one contiguous row [series_pitch] of 4-byte words (series order: edges,
+    // then ready / io / ram per server), written with 16-byte stores: a row is 1-2 HBM
+    // sectors instead of one partial write per series.
     AF_CORE void sample_tick() {
         if (O.samples != nullptr) {
             if (n_ticks < O.tick_cap) {
-                const uint32_t k = n_ticks;
-                if (P.metrics_mask & METRIC_EDGE)
-                    for (uint32_t e = 0u; e < P.n_edges; ++e)
-                        O.samples[e * O.tick_cap + k] = (uint32_t)M.ld(L.edge + LEDGE * e) & 0xFFFFu;
+                const uint32_t n_series = P.n_edges + 3u * P.n_servers;
+                uint32_t* row = O.samples + (size_t)n_ticks * O.series_pitch;
+                const bool edges_on = (P.metrics_mask & METRIC_EDGE) != 0u;
                 constexpr uint32_t all = METRIC_READY | METRIC_IO | METRIC_RAM;
-                if ((P.metrics_mask & all) == all)
-                    for (uint32_t v = 0u; v < P.n_servers; ++v) {
-                        const uint32_t at = L.srv + LSRV * v;
-                        const uint32_t base = (P.n_edges + 3u * v) * O.tick_cap + k;
-                        O.samples[base] = (uint32_t)(M.ld(at) >> 32);
-                        O.samples[base + O.tick_cap] = (uint32_t)M.ld(at + 1u);
-                        O.samples[base + 2u * O.tick_cap] = __builtin_bit_cast(uint32_t, (float)u2d(M.ld(at + 3u)));
+                const bool servers_on = (P.metrics_mask & all) == all;
+                for (uint32_t s0 = 0u; s0 < n_series; s0 += 4u) {
+                    uint32_t v[4];
+#pragma unroll
+                    for (uint32_t k = 0u; k < 4u; ++k) {
+                        const uint32_t sidx = s0 + k;
+                        uint32_t val = 0u;
+                        if (sidx < P.n_edges) {
+                            if (edges_on) val = (uint32_t)M.ld(L.edge + LEDGE * sidx) & 0xFFFFu;
+                        } else if (sidx < n_series && servers_on) {
+                            const uint32_t r = sidx - P.n_edges;
+                            const uint32_t sv = r / 3u, which = r - 3u * sv;
+                            const uint32_t at = L.srv + LSRV * sv;
+                            if (which == 0u) val = (uint32_t)(M.ld(at) >> 32);            // ready_queue_len
+                            else if (which == 1u) val = (uint32_t)M.ld(at + 1u);          // event_loop_io_sleep
+                            else val = __builtin_bit_cast(uint32_t, (float)u2d(M.ld(at + 3u)));  // ram_in_use
+                        }
+                        v[k] = val;
                     }
+                    store4(row + s0, v[0], v[1], v[2], v[3]);
+                }
             } else {
                 flags |= FLAG_TICK_OVERFLOW;
             }

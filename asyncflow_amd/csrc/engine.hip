@@ -50,7 +50,7 @@ struct KArgs {
     double* clock;
     uint32_t clock_cap;
     uint32_t* samples;
-    uint32_t tick_cap, n_series;
+    uint32_t tick_cap, n_series, series_pitch;
     uint32_t* counts;
     unsigned char* state;  // HBM-resident lane state (global-state mode only)
     uint64_t state_bytes_per_wave;
@@ -127,10 +127,11 @@ __global__ void __launch_bounds__(64) af_des_kernel(const KArgs a) {
 
     af::LaneOut O;
     O.clock = a.clock ? a.clock + (size_t)sc * a.clock_cap * 2u : nullptr;
-    O.samples = a.samples ? a.samples + (size_t)sc * a.n_series * a.tick_cap : nullptr;
+    O.samples = a.samples ? a.samples + (size_t)sc * a.series_pitch * a.tick_cap : nullptr;
     O.counts = a.counts + (size_t)sc * af::CNT_SLOTS;
     O.clock_cap = a.clock_cap;
     O.tick_cap = a.tick_cap;
+    O.series_pitch = a.series_pitch;
 
     const uint64_t seed = a.seeds[sc];
     auto ovr = [&](uint32_t k) { return a.ovr_values[(size_t)k * a.n_scen + sc]; };
@@ -335,6 +336,8 @@ uint32_t af_tick_count(double sample_period, double total_time) {
 
 uint32_t af_series_count(const af_plan_t* plan) { return plan ? plan->n_edges + 3u * plan->n_servers : 0u; }
 
+uint32_t af_series_pitch(const af_plan_t* plan) { return (af_series_count(plan) + 3u) & ~3u; }
+
 int af_engine_create(const af_plan_t* plan, int device, const af_engine_options_t* opts, af_engine_t** out) {
     if (!out) return fail(AF_ERR_INVALID, "out is NULL");
     *out = nullptr;
@@ -365,6 +368,7 @@ int af_engine_create(const af_plan_t* plan, int device, const af_engine_options_
     a.n_edge_marks = plan->n_edge_marks;
     a.n_srv_marks = plan->n_srv_marks;
     a.n_series = plan->n_edges + 3u * plan->n_servers;
+    a.series_pitch = (a.n_series + 3u) & ~3u;
 
     af::PackedPlan pk;
     const std::string why = af::pack_plan(*plan, pk);

@@ -79,6 +79,11 @@ class DevicePlan:
         return self.n_edges + 3 * self.n_servers
 
     @property
+    def series_pitch(self) -> int:
+        """Row length of the device sample array: ``n_series`` rounded up to a multiple of 4."""
+        return (self.n_series + 3) & ~3
+
+    @property
     def tick_count(self) -> int:
         """Ticks ``env.run(until=T)`` takes (metrics/collector.py:50-53).
 

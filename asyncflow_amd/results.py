@@ -236,9 +236,10 @@ class BatchedResults:
         n = min(int(counts[_abi.CNT_COMPLETED]), int(self._clock_t.shape[1])) if self._clock_t is not None else 0
         clock = self._clock_t[i, :n].cpu().numpy() if self._clock_t is not None else np.zeros((0, 2))
         samples = None
-        if self._samples_t is not None:
-            k = min(int(counts[_abi.CNT_TICKS]), int(self._samples_t.shape[2]))
-            samples = self._samples_t[i, :, :k].cpu().numpy().view(np.uint32)
+        if self._samples_t is not None:  # device layout [tick][series_pitch] -> [series][tick]
+            k = min(int(counts[_abi.CNT_TICKS]), int(self._samples_t.shape[1]))
+            rows = self._samples_t[i, :k, : self.plan.n_series].cpu().numpy().view(np.uint32)
+            samples = np.ascontiguousarray(rows.T)
         return ScenarioResults(self.plan, counts, clock, samples)
 
     def __iter__(self) -> Iterator[ScenarioResults]:

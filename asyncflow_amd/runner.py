@@ -167,7 +167,7 @@ class SimulationRunner:
             counts = torch.zeros((n, _abi.CNT_SLOTS), dtype=torch.int32, device=dev)
             clock = torch.empty((n, clock_cap, 2), dtype=torch.float64, device=dev) if self.collect_clock else None
             samples = (
-                torch.zeros((n, self.plan.n_series, ticks), dtype=torch.int32, device=dev)
+                torch.zeros((n, ticks, self.plan.series_pitch), dtype=torch.int32, device=dev)
                 if self.collect_samples else None
             )
             torch.cuda.synchronize(dev)

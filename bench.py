@@ -195,7 +195,7 @@ def main() -> int:
                  force_global_state=args.global_state)
     counts = torch.zeros((n, _abi.CNT_SLOTS), dtype=torch.int32, device=dev)
     clock = torch.empty((n, clock_cap, 2), dtype=torch.float64, device=dev)
-    samples = None if args.no_series else torch.zeros((n, plan.n_series, ticks), dtype=torch.int32, device=dev)
+    samples = None if args.no_series else torch.zeros((n, ticks, plan.series_pitch), dtype=torch.int32, device=dev)
 
     def step():
         return eng.run(seeds, overrides, clock_ptr=clock.data_ptr(), clock_capacity=clock_cap,

@@ -194,7 +194,8 @@ typedef struct af_outputs {
     uint32_t clock_capacity;
     double* clock;
     /* Sampled series (metrics/collector.py:50-66).
-     * DEVICE [n_scenarios][n_series][tick_capacity] 4-byte words, series order:
+     * DEVICE [n_scenarios][tick_capacity][af_series_pitch(plan)] 4-byte words (one
+     * 16-byte aligned row per tick; pitch = n_series rounded up to 4), series order:
      *   e in [0,n_edges):            edge_concurrent_connection (int32)
      *   n_edges + 3*s + 0:           ready_queue_len   of server s (int32)
      *   n_edges + 3*s + 1:           event_loop_io_sleep of server s (int32)
@@ -243,6 +244,7 @@ void af_engine_destroy(af_engine_t* eng);
  * addition from 0, tick at t < T only (collector.py:50-53). */
 uint32_t af_tick_count(double sample_period, double total_time);
 uint32_t af_series_count(const af_plan_t* plan);  /* n_edges + 3*n_servers */
+uint32_t af_series_pitch(const af_plan_t* plan);  /* row length of outputs.samples (multiple of 4) */
 
 const char* af_last_error(void);
 int af_abi_version(void);

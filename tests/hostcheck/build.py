@@ -60,7 +60,7 @@ def simulate(plan: DevicePlan, seed: int, *, cap: int = 4096, fcap: int = 4096,
     ccap = int(clock_capacity if clock_capacity is not None else plan.clock_capacity())
     clock = np.zeros((ccap, 2), dtype=np.float64)
     ticks = max(plan.tick_count, 1)
-    samples = np.zeros((plan.n_series, ticks), dtype=np.uint32)
+    samples = np.zeros((ticks, plan.series_pitch), dtype=np.uint32)  # device layout [tick][pitch]
     counts = np.zeros(_abi.CNT_SLOTS, dtype=np.uint32)
     u32p, f64p = C.POINTER(C.c_uint32), C.POINTER(C.c_double)
     rc = L.hc_simulate(
@@ -73,4 +73,5 @@ def simulate(plan: DevicePlan, seed: int, *, cap: int = 4096, fcap: int = 4096,
         msg = f"hc_simulate failed: {rc}"
         raise RuntimeError(msg)
     n = int(counts[_abi.CNT_COMPLETED])
-    return counts, clock[: min(n, ccap)].copy(), samples[:, : int(counts[_abi.CNT_TICKS])].copy()
+    k = int(counts[_abi.CNT_TICKS])
+    return counts, clock[: min(n, ccap)].copy(), np.ascontiguousarray(samples[:k, : plan.n_series].T)

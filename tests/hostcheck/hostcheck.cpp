@@ -86,7 +86,8 @@ extern "C" int hc_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ovr, co
 
     const af::Layout L = af::make_layout(cap, fcap, p->n_edges, p->n_servers, p->n_lb_edges, pk.n_rows, mask);
     std::vector<uint64_t> w(L.n_words ? L.n_words : 1, 0ull);
-    af::LaneOut O{clock, samples, counts, clock_cap, tick_cap};
+    const uint32_t pitch = (p->n_edges + 3u * p->n_servers + 3u) & ~3u;
+    af::LaneOut O{clock, samples, counts, clock_cap, tick_cap, pitch};
     af::PreDraws D{draws.data(), n_draw, flags_in};
     af::Lane<MemHost> lane(V, L, MemHost{w.data()}, O, D, seed);
     lane.init(ovr_param, idx.data(), n_ovr, [&](uint32_t k) { return ovr_value[k]; });
