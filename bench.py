@@ -313,9 +313,13 @@ def main() -> int:
         if base is not None:
             line["cpu_baseline"] = base
             line["gpu_over_cpu_port_all_cores"] = (total_events / elapsed) / base["value"]
-        traffic = os.environ.get("AF_BENCH_TRAFFIC_BYTES")
-        if traffic:
-            line["roofline"]["traffic"] = float(traffic)
+        # HBM bytes per launch of the dominant kernel, from the committed PMC passes of THIS
+        # command (rocprofv3 cannot run inside the timed bench): profiles/r01/final/traffic.json
+        tpath = ROOT / "profiles" / "r01" / "final" / "traffic.json"
+        if args.config == 2 and n == 10_000 and not args.no_series and args.horizon == 600 and tpath.exists():
+            tj = json.loads(tpath.read_text())
+            line["roofline"]["traffic"] = tj["bytes_per_launch"]
+            line["roofline"]["traffic_source"] = "profiles/r01/final/traffic.json (2 x FETCH_SIZE + WRITE_SIZE, KB=1024 B)"
         print(json.dumps(line))
     eng.close()
     if dist is not None:
