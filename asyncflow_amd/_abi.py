@@ -152,6 +152,7 @@ class AfEngineOptions(C.Structure):
         ("fifo_capacity", C.c_uint32),
         ("force_global_state", C.c_uint32),
         ("lanes_per_wave", C.c_uint32),
+        ("draw_memory_mb", C.c_uint32),
     ]
 
 
@@ -166,6 +167,7 @@ class AfStats(C.Structure):
         ("lds_bytes_per_wave", C.c_uint32),
         ("waves", C.c_uint32),
         ("lanes_per_wave", C.c_uint32),
+        ("chunks", C.c_uint32),
         ("request_capacity", C.c_uint32),
         ("fifo_capacity", C.c_uint32),
     ]

@@ -46,7 +46,8 @@ struct KArgs {
     uint32_t n_ovr;
     const uint32_t* ovr_param;
     const uint32_t* ovr_index;
-    const double* ovr_values;  // [n_ovr][n_scen]
+    const double* ovr_values;  // [n_ovr][ovr_stride], already offset to this chunk's first scenario
+    uint32_t ovr_stride;       // scenarios in the whole sweep
     double* clock;
     uint32_t clock_cap;
     uint32_t* samples;
@@ -134,7 +135,7 @@ __global__ void __launch_bounds__(64) af_des_kernel(const KArgs a) {
     O.series_pitch = a.series_pitch;
 
     const uint64_t seed = a.seeds[sc];
-    auto ovr = [&](uint32_t k) { return a.ovr_values[(size_t)k * a.n_scen + sc]; };
+    auto ovr = [&](uint32_t k) { return a.ovr_values[(size_t)k * a.ovr_stride + sc]; };
     af::PreDraws D;
     D.base = a.draws + (size_t)sc * (1u + a.n_edges) * a.n_draw;
     D.n_per_stream = a.n_draw;
@@ -169,7 +170,7 @@ __global__ void __launch_bounds__(64) af_des_kernel(const KArgs a) {
 // ---- draw pre-generation (fully parallel, full occupancy) ---------------------------
 __device__ __forceinline__ double ovr_or(const KArgs& a, uint32_t param, uint32_t index, uint32_t scen, double dflt) {
     for (uint32_t k = 0; k < a.n_ovr; ++k)
-        if (a.ovr_param[k] == param && a.ovr_index[k] == index) dflt = a.ovr_values[(size_t)k * a.n_scen + scen];
+        if (a.ovr_param[k] == param && a.ovr_index[k] == index) dflt = a.ovr_values[(size_t)k * a.ovr_stride + scen];
     return dflt;
 }
 
@@ -276,7 +277,8 @@ struct af_engine {
     size_t draws_cap = 0;
     uint32_t* d_pre_flags = nullptr;
     size_t pre_flags_cap = 0;
-    hipEvent_t ev3 = nullptr;
+    hipEvent_t ev3 = nullptr, ev4 = nullptr;
+    size_t draw_memory_bytes = 0;
     uint32_t request_capacity = 0, fifo_capacity = 0, force_global = 0, lanes_per_wave = 0;
     uint32_t n_lb_edges = 0;
     std::vector<uint32_t> row_of_step;
@@ -392,6 +394,7 @@ int af_engine_create(const af_plan_t* plan, int device, const af_engine_options_
     e->fifo_capacity = pow2_at_least(opts && opts->fifo_capacity ? opts->fifo_capacity : 32u);
     e->force_global = opts ? opts->force_global_state : 0u;
     e->lanes_per_wave = opts ? opts->lanes_per_wave : 0u;
+    e->draw_memory_bytes = opts ? (size_t)opts->draw_memory_mb << 20 : 0;
     if (e->lanes_per_wave & (e->lanes_per_wave - 1u)) {
         delete e;
         return fail(AF_ERR_INVALID, "lanes_per_wave must be 0 (auto) or a power of two <= 64");
@@ -411,6 +414,7 @@ int af_engine_create(const af_plan_t* plan, int device, const af_engine_options_
     if (err == hipSuccess) err = hipEventCreate(&e->ev1);
     if (err == hipSuccess) err = hipEventCreate(&e->ev2);
     if (err == hipSuccess) err = hipEventCreate(&e->ev3);
+    if (err == hipSuccess) err = hipEventCreate(&e->ev4);
     if (err == hipSuccess) err = hipMalloc((void**)&e->d_blob, blob.size() * 8u);
     if (err == hipSuccess) err = hipMemcpy(e->d_blob, blob.data(), blob.size() * 8u, hipMemcpyHostToDevice);
     if (err != hipSuccess) {
@@ -444,52 +448,6 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     }
     a.L = af::make_layout(e->request_capacity, e->fifo_capacity, a.n_edges, a.n_servers, a.n_lb_edges, a.n_rows, mask);
     const uint64_t bytes_per_lane = af::layout_bytes_per_lane(a.L);
-    // scenario lanes per wave: few scenarios -> many narrow waves (see af_des_kernel)
-    // Scenario lanes per wave and state placement.  The kernel is latency bound, so few
-    // scenarios are best spread over MANY narrow waves: fewer event kinds per round in a
-    // wave, every SIMD busy, several waves per SIMD hiding LDS latency.  Limits: ~144 VGPRs
-    // -> 3 waves/SIMD = 12 per CU; LDS-resident state -> 160 KiB per CU.  Cost model fitted
-    // to MI355X measurements (profiles/r01/lanes_sweep.md): relative time of one wave-round
-    // f(lanes), x 2.3 when the state lives in HBM, x the number of residency batches.
-    uint32_t kl = e->lanes_per_wave;
-    bool lds_state;
-    {
-        static const double f_lanes[7] = {1.0, 1.4, 1.65, 2.2, 2.5, 2.4, 2.25};  // 1,2,4,...,64 lanes
-        const double n_cu = 256.0, vgpr_waves_per_cu = 12.0;
-        double best = 1e300;
-        uint32_t best_kl = 4;
-        bool best_lds = false;
-        for (uint32_t k = 0; k < 7; ++k) {
-            const uint32_t cand = 1u << k;
-            if (kl != 0u && cand != kl) continue;
-            const double waves_needed = (double)((n + cand - 1u) / cand);
-            for (int lds = 1; lds >= 0; --lds) {
-                if (lds && e->force_global) continue;
-                double per_cu = vgpr_waves_per_cu;
-                if (lds) {
-                    const uint64_t wg_bytes = (uint64_t)a.blob_bytes + bytes_per_lane * cand;
-                    if (wg_bytes > kLdsLimit) continue;
-                    const double fit = (double)(kLdsLimit / wg_bytes);
-                    per_cu = fit < per_cu ? fit : per_cu;
-                }
-                const double batches = waves_needed / (n_cu * per_cu);
-                const double cost = (batches < 1.0 ? 1.0 : batches) * f_lanes[k] * (lds ? 1.0 : 2.3);
-                if (cost < best) {
-                    best = cost;
-                    best_kl = cand;
-                    best_lds = lds != 0;
-                }
-            }
-        }
-        kl = best_kl;
-        lds_state = best_lds;
-    }
-    uint32_t klog = 0;
-    while ((1u << klog) < kl) ++klog;
-    a.klog = klog;
-    const uint64_t state_per_wave = bytes_per_lane * kl;
-    const uint32_t waves = (n + kl - 1) / kl;
-    const uint32_t lds_bytes = lds_state ? (uint32_t)(a.blob_bytes + state_per_wave) : a.blob_bytes;
 
     // ---- upload seeds + override tables (one staging buffer) -------------------
     const size_t seeds_b = (size_t)n * 8;
@@ -518,37 +476,27 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     HIP_TRY(hipMemcpyAsync(d_params, params.data(), tab_b, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(d_idxs, idxs.data(), tab_b, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));  // host staging vectors go out of scope below
+    HIP_TRY(hipEventRecord(e->ev1, e->stream));
 
-    a.n_scen = n;
-    a.seeds = reinterpret_cast<const uint64_t*>(ds);
     a.n_ovr = sweep->n_overrides;
-    a.ovr_values = reinterpret_cast<const double*>(ds + seeds_b);
     a.ovr_param = reinterpret_cast<const uint32_t*>(d_params);
     a.ovr_index = reinterpret_cast<const uint32_t*>(d_idxs);
-    a.clock = out->clock;
+    a.ovr_stride = n;
     a.clock_cap = out->clock_capacity;
-    a.samples = out->samples;
     a.tick_cap = out->tick_capacity;
-    a.counts = out->counts;
-    a.state = nullptr;
-    a.state_bytes_per_wave = state_per_wave;
 
-    if (!lds_state) {
-        const size_t need = (size_t)state_per_wave * waves;
-        if (need > e->state_cap) {
-            if (e->d_state) HIP_TRY(hipFree(e->d_state));
-            e->d_state = nullptr;
-            e->state_cap = 0;
-            HIP_TRY(hipMalloc((void**)&e->d_state, need));
-            e->state_cap = need;
-        }
-        a.state = e->d_state;
-    }
-
-    // ---- pre-generate every random draw of every scenario (HBM) ----------------------
+    // ---- chunking: the pre-generated draws of a chunk must fit the draw budget --------
     const uint32_t n_draw = sweep->draw_capacity ? sweep->draw_capacity : out->clock_capacity;
     if (n_draw == 0) return fail(AF_ERR_INVALID, "draw_capacity (or clock_capacity) must be > 0");
-    const size_t draw_bytes = (size_t)(1u + a.n_edges) * n_draw * n * sizeof(double);
+    const size_t draw_bytes_per_scen = (size_t)(1u + a.n_edges) * n_draw * sizeof(double);
+    size_t mem_free = 0, mem_total = 0;
+    HIP_TRY(hipMemGetInfo(&mem_free, &mem_total));
+    size_t budget = e->draw_memory_bytes ? e->draw_memory_bytes : (size_t)64 << 30;
+    if (budget > mem_free / 2 + e->draws_cap) budget = mem_free / 2 + e->draws_cap;
+    uint32_t chunk = (uint32_t)(budget / draw_bytes_per_scen < 65535u ? budget / draw_bytes_per_scen : 65535u);
+    if (chunk == 0) return fail(AF_ERR_CAPACITY, "draw_capacity too large for the device memory budget");
+    if (chunk > n) chunk = n;
+    const size_t draw_bytes = draw_bytes_per_scen * chunk;
     if (draw_bytes > e->draws_cap) {
         if (e->d_draws) HIP_TRY(hipFree(e->d_draws));
         e->d_draws = nullptr;
@@ -556,40 +504,115 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
         HIP_TRY(hipMalloc((void**)&e->d_draws, draw_bytes));
         e->draws_cap = draw_bytes;
     }
-    if ((size_t)n * 4 > e->pre_flags_cap) {
+    if ((size_t)chunk * 4 > e->pre_flags_cap) {
         if (e->d_pre_flags) HIP_TRY(hipFree(e->d_pre_flags));
         e->d_pre_flags = nullptr;
         e->pre_flags_cap = 0;
-        HIP_TRY(hipMalloc((void**)&e->d_pre_flags, (size_t)n * 4));
-        e->pre_flags_cap = (size_t)n * 4;
+        HIP_TRY(hipMalloc((void**)&e->d_pre_flags, (size_t)chunk * 4));
+        e->pre_flags_cap = (size_t)chunk * 4;
     }
     a.draws = e->d_draws;
     a.n_draw = n_draw;
     a.pre_flags = e->d_pre_flags;
 
-    HIP_TRY(hipEventRecord(e->ev1, e->stream));
-    hipLaunchKernelGGL(af_pregen_arrivals, dim3((n + 63u) / 64u), dim3(64), 0, e->stream, a);
-    if (n > 65535u) return fail(AF_ERR_CAPACITY, "at most 65535 scenarios per af_engine_run (shard the sweep)");
-    hipLaunchKernelGGL(af_pregen_edges, dim3((n_draw + 255u) / 256u, n, a.n_edges), dim3(256), 0, e->stream, a);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(e->ev3, e->stream));
-    if (lds_state) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(af_des_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL(af_des_kernel<true>, dim3(waves), dim3(kWave), lds_bytes, e->stream, a);
-    } else {
-        hipLaunchKernelGGL(af_des_kernel<false>, dim3(waves), dim3(kWave), lds_bytes, e->stream, a);
-    }
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(e->ev2, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    double ms_pregen = 0.0, ms_kernel = 0.0;
+    uint32_t kl = 0, waves = 0, lds_bytes = 0, n_chunks = 0;
+    bool lds_state = false;
+    for (uint32_t lo = 0; lo < n; lo += chunk) {
+        const uint32_t nc = n - lo < chunk ? n - lo : chunk;
+        n_chunks += 1u;
+        a.n_scen = nc;
+        a.seeds = reinterpret_cast<const uint64_t*>(ds) + lo;
+        a.ovr_values = reinterpret_cast<const double*>(ds + seeds_b) + lo;
+        a.clock = out->clock ? out->clock + (size_t)lo * out->clock_capacity * 2u : nullptr;
+        a.samples = out->samples ? out->samples + (size_t)lo * a.series_pitch * out->tick_capacity : nullptr;
+        a.counts = out->counts + (size_t)lo * AF_CNT_SLOTS;
 
-    float ms_h2d = 0.f, ms_k = 0.f, ms_p = 0.f;
+        // Scenario lanes per wave and state placement.  The kernel is latency bound, so few
+        // scenarios are best spread over MANY narrow waves: fewer event kinds per round in a
+        // wave, every SIMD busy, several waves per SIMD hiding LDS latency.  Limits: ~144 VGPRs
+        // -> 3 waves/SIMD = 12 per CU; LDS-resident state -> 160 KiB per CU.  Cost model fitted
+        // to MI355X measurements (profiles/r01/lanes_sweep.md): relative time of one wave-round
+        // f(lanes), x 2.3 when the state lives in HBM, x the number of residency batches.
+        kl = e->lanes_per_wave;
+        {
+            static const double f_lanes[7] = {1.0, 1.4, 1.65, 2.2, 2.5, 2.4, 2.25};  // 1,2,4,...,64 lanes
+            const double n_cu = 256.0, vgpr_waves_per_cu = 12.0;
+            double best = 1e300;
+            uint32_t best_kl = 4;
+            bool best_lds = false;
+            for (uint32_t k = 0; k < 7; ++k) {
+                const uint32_t cand = 1u << k;
+                if (kl != 0u && cand != kl) continue;
+                const double waves_needed = (double)((nc + cand - 1u) / cand);
+                for (int lds = 1; lds >= 0; --lds) {
+                    if (lds && e->force_global) continue;
+                    double per_cu = vgpr_waves_per_cu;
+                    if (lds) {
+                        const uint64_t wg_bytes = (uint64_t)a.blob_bytes + bytes_per_lane * cand;
+                        if (wg_bytes > kLdsLimit) continue;
+                        const double fit = (double)(kLdsLimit / wg_bytes);
+                        per_cu = fit < per_cu ? fit : per_cu;
+                    }
+                    const double batches = waves_needed / (n_cu * per_cu);
+                    const double cost = (batches < 1.0 ? 1.0 : batches) * f_lanes[k] * (lds ? 1.0 : 2.3);
+                    if (cost < best) {
+                        best = cost;
+                        best_kl = cand;
+                        best_lds = lds != 0;
+                    }
+                }
+            }
+            kl = best_kl;
+            lds_state = best_lds;
+        }
+        uint32_t klog = 0;
+        while ((1u << klog) < kl) ++klog;
+        a.klog = klog;
+        const uint64_t state_per_wave = bytes_per_lane * kl;
+        waves = (nc + kl - 1) / kl;
+        lds_bytes = lds_state ? (uint32_t)(a.blob_bytes + state_per_wave) : a.blob_bytes;
+        a.state = nullptr;
+        a.state_bytes_per_wave = state_per_wave;
+        if (!lds_state) {
+            const size_t need = (size_t)state_per_wave * waves;
+            if (need > e->state_cap) {
+                if (e->d_state) HIP_TRY(hipFree(e->d_state));
+                e->d_state = nullptr;
+                e->state_cap = 0;
+                HIP_TRY(hipMalloc((void**)&e->d_state, need));
+                e->state_cap = need;
+            }
+            a.state = e->d_state;
+        }
+
+        // pre-generate every random draw of the chunk (HBM), then simulate
+        HIP_TRY(hipEventRecord(e->ev2, e->stream));
+        hipLaunchKernelGGL(af_pregen_arrivals, dim3((nc + 63u) / 64u), dim3(64), 0, e->stream, a);
+        hipLaunchKernelGGL(af_pregen_edges, dim3((n_draw + 255u) / 256u, nc, a.n_edges), dim3(256), 0, e->stream, a);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(e->ev3, e->stream));
+        if (lds_state) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(af_des_kernel<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            hipLaunchKernelGGL(af_des_kernel<true>, dim3(waves), dim3(kWave), lds_bytes, e->stream, a);
+        } else {
+            hipLaunchKernelGGL(af_des_kernel<false>, dim3(waves), dim3(kWave), lds_bytes, e->stream, a);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(e->ev4, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        float ms_p = 0.f, ms_k = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms_p, e->ev2, e->ev3));
+        HIP_TRY(hipEventElapsedTime(&ms_k, e->ev3, e->ev4));
+        ms_pregen += ms_p;
+        ms_kernel += ms_k;
+    }
+
+    float ms_h2d = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms_h2d, e->ev0, e->ev1));
-    HIP_TRY(hipEventElapsedTime(&ms_p, e->ev1, e->ev3));
-    HIP_TRY(hipEventElapsedTime(&ms_k, e->ev3, e->ev2));
-    e->stats.kernel_ms = ms_k;
-    e->stats.pregen_ms = ms_p;
+    e->stats.kernel_ms = ms_kernel;
+    e->stats.pregen_ms = ms_pregen;
     e->stats.h2d_ms = ms_h2d;
     e->stats.draw_bytes = draw_bytes;
     e->stats.state_bytes_per_scenario = bytes_per_lane;
@@ -597,6 +620,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     e->stats.lds_bytes_per_wave = lds_bytes;
     e->stats.waves = waves;
     e->stats.lanes_per_wave = kl;
+    e->stats.chunks = n_chunks;
     e->stats.request_capacity = e->request_capacity;
     e->stats.fifo_capacity = e->fifo_capacity;
     return AF_OK;
@@ -618,6 +642,7 @@ void af_engine_destroy(af_engine_t* e) {
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->ev2) (void)hipEventDestroy(e->ev2);
     if (e->ev3) (void)hipEventDestroy(e->ev3);
+    if (e->ev4) (void)hipEventDestroy(e->ev4);
     if (e->d_draws) (void)hipFree(e->d_draws);
     if (e->d_pre_flags) (void)hipFree(e->d_pre_flags);
     if (e->stream) (void)hipStreamDestroy(e->stream);

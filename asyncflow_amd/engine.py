@@ -94,12 +94,14 @@ class Engine:
     """One ``af_engine_t``: a lowered plan resident on one GPU."""
 
     def __init__(self, plan: DevicePlan, device: int = 0, *, request_capacity: int = 0,
-                 fifo_capacity: int = 0, force_global_state: bool = False, lanes_per_wave: int = 0) -> None:
+                 fifo_capacity: int = 0, force_global_state: bool = False, lanes_per_wave: int = 0,
+                 draw_memory_mb: int = 0) -> None:
         self._lib = load_library()
         self.plan = plan
         self.device = device
         self._cplan = plan.as_ctypes()
-        opts = _abi.AfEngineOptions(request_capacity, fifo_capacity, int(force_global_state), int(lanes_per_wave))
+        opts = _abi.AfEngineOptions(request_capacity, fifo_capacity, int(force_global_state), int(lanes_per_wave),
+                                    int(draw_memory_mb))
         handle = C.c_void_p()
         _check(self._lib, self._lib.af_engine_create(C.byref(self._cplan), device, C.byref(opts), C.byref(handle)),
                "af_engine_create")

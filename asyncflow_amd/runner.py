@@ -102,6 +102,7 @@ class SimulationRunner:
         force_global_state: bool = False,
         auto_grow: bool = True,
         lanes_per_wave: int = 0,
+        draw_memory_mb: int = 0,
     ) -> None:
         self.env = env  # accepted for signature compatibility; unused
         self.simulation_input = simulation_input
@@ -124,6 +125,7 @@ class SimulationRunner:
         self.force_global_state = force_global_state
         self.auto_grow = auto_grow
         self.lanes_per_wave = lanes_per_wave
+        self.draw_memory_mb = draw_memory_mb
         self._single = seeds is None and int(replicas) == 1 and not self.sweep
         self._engine: Engine | None = None
 
@@ -162,7 +164,8 @@ class SimulationRunner:
         t0 = time.perf_counter()
         for attempt in range(4):
             eng = Engine(self.plan, device, request_capacity=cap, fifo_capacity=fifo,
-                         force_global_state=self.force_global_state, lanes_per_wave=self.lanes_per_wave)
+                         force_global_state=self.force_global_state, lanes_per_wave=self.lanes_per_wave,
+                         draw_memory_mb=self.draw_memory_mb)
             self._engine = eng
             counts = torch.zeros((n, _abi.CNT_SLOTS), dtype=torch.int32, device=dev)
             clock = torch.empty((n, clock_cap, 2), dtype=torch.float64, device=dev) if self.collect_clock else None

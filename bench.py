@@ -162,7 +162,7 @@ def main() -> int:
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("AF_BENCH_FORCE_DIST") == "1":  # the env flag exercises the RCCL path on 1 GPU
         import torch.distributed as dist  # type: ignore[no-redef]
 
         dist.init_process_group(backend="nccl", device_id=dev)

@@ -213,6 +213,9 @@ typedef struct af_engine_options {
     uint32_t force_global_state;/* 1 = keep per-scenario state in HBM even if it fits LDS */
     uint32_t lanes_per_wave;    /* scenarios per wavefront: power of two <= 64, 0 = auto
                                    (few scenarios are spread over many narrow waves)    */
+    uint32_t draw_memory_mb;    /* HBM budget for the pre-generated draws of one chunk of the
+                                   sweep, MiB (0 = min(64 GiB, half of the free memory));
+                                   larger sweeps run as several chunks                   */
 } af_engine_options_t;
 
 typedef struct af_stats {
@@ -225,6 +228,7 @@ typedef struct af_stats {
     uint32_t lds_bytes_per_wave;
     uint32_t waves;             /* workgroups launched (one wavefront each)        */
     uint32_t lanes_per_wave;    /* scenarios carried by each wavefront             */
+    uint32_t chunks;            /* sub-launches the sweep was split into           */
     uint32_t request_capacity;
     uint32_t fifo_capacity;
 } af_stats_t;

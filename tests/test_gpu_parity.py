@@ -146,6 +146,23 @@ def test_parameter_sweep_columns():
     assert gen[users == 480.0].mean() > 30 * gen[users == 10.0].mean()
 
 
+def test_sweep_larger_than_the_draw_budget_runs_in_chunks_with_identical_results():
+    payload = lb_two_servers(horizon=20)
+    n = 150
+    users = np.linspace(20.0, 400.0, n)
+    seeds = 0xABCD0000 + np.arange(n, dtype=np.uint64)
+    sweep = {"rqs_input.avg_active_users.mean": users}
+    whole = _runner(payload, seeds=seeds, sweep=sweep).run()
+    # 1 MiB of draws per chunk: (1 + 6 edges) * clock_capacity * 8 B per scenario -> a handful of scenarios
+    parts = _runner(payload, seeds=seeds, sweep=sweep, draw_memory_mb=1,
+                    clock_capacity=whole._clock_t.shape[1]).run()  # noqa: SLF001
+    assert whole.engine_stats.chunks == 1 and parts.engine_stats.chunks > 3
+    assert np.array_equal(whole.counts, parts.counts)
+    for i in range(n):
+        assert np.array_equal(whole[i].rqs_clock, parts[i].rqs_clock)
+    assert np.array_equal(whole._samples_t.cpu().numpy(), parts._samples_t.cpu().numpy())  # noqa: SLF001
+
+
 @pytest.mark.parametrize("case", range(6))
 def test_fuzzed_payloads(case):
     rng = random.Random(9000 + case)
