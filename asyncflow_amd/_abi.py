@@ -161,6 +161,7 @@ class AfStats(C.Structure):
         ("kernel_ms", C.c_double),
         ("pregen_ms", C.c_double),
         ("h2d_ms", C.c_double),
+        ("summary_ms", C.c_double),
         ("draw_bytes", C.c_uint64),
         ("state_bytes_per_scenario", C.c_uint64),
         ("state_in_lds", C.c_uint32),
@@ -173,10 +174,25 @@ class AfStats(C.Structure):
     ]
 
 
+class AfSummary(C.Structure):
+    _fields_ = [
+        ("n_scenarios", C.c_uint32),
+        ("rps_buckets", C.c_uint32),
+        ("hist_bins", C.c_uint32),
+        ("hist_max", C.c_double),
+        ("stats", C.c_void_p),
+        ("rps", C.c_void_p),
+        ("hist", C.c_void_p),
+        ("series_mean", C.c_void_p),
+        ("series_max", C.c_void_p),
+    ]
+
+
 #: every symbol include/asyncflow_hip.h declares
 EXPORTED_SYMBOLS = (
     "af_engine_create",
     "af_engine_run",
+    "af_engine_summarize",
     "af_engine_stats",
     "af_engine_destroy",
     "af_tick_count",
@@ -196,6 +212,8 @@ def declare(lib: C.CDLL) -> C.CDLL:
     lib.af_engine_create.restype = C.c_int
     lib.af_engine_run.argtypes = [C.c_void_p, C.POINTER(AfSweep), C.POINTER(AfOutputs)]
     lib.af_engine_run.restype = C.c_int
+    lib.af_engine_summarize.argtypes = [C.c_void_p, C.POINTER(AfOutputs), C.POINTER(AfSummary)]
+    lib.af_engine_summarize.restype = C.c_int
     lib.af_engine_stats.argtypes = [C.c_void_p, C.POINTER(AfStats)]
     lib.af_engine_stats.restype = C.c_int
     lib.af_engine_destroy.argtypes = [C.c_void_p]

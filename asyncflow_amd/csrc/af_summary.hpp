@@ -1,0 +1,391 @@
+// Batched analyzer on the device: per-scenario latency statistics, 1-s throughput buckets,
+// an optional latency histogram and per-series mean/max of the sampled metrics.
+//
+// Replaces, for n scenarios at once, ResultsAnalyzer._process_event_metrics
+// (/root/reference src/asyncflow/metrics/analyzer.py:83-126):
+//   latencies = finish - start;  total, np.mean, np.median, np.std, np.percentile(95 / 99),
+//   np.min, np.max;  RPS windows (k-1, k] for k = 1..floor(total_simulation_time).
+// Order statistics are EXACT (bit-equal to numpy's partition + linear interpolation, including
+// its "t >= 0.5" lerp branch); mean/std are deterministic tree sums (numpy sums pairwise, so those
+// two agree to ~1e-13 relative, not bit for bit).
+//
+// HBM-bound: one workgroup per scenario streams that scenario's rqs_clock rows (16 B per
+// completed request) 3 times in the common case:
+//   pass 1  sum / min / max / RPS buckets / histogram of the f64 exponent field
+//   pass 2+ (only while a wanted rank still has > kCand candidates) 10 more key bits per pass,
+//           MSB-first radix select, all wanted ranks at once
+//   last    gather the <= kCand candidates of every wanted rank into LDS, accumulate the squared
+//           deviations, then select by counting
+// No sort, no scratch memory in HBM, no atomics on floating point (results are run-to-run
+// deterministic).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace afs {
+
+constexpr int kThreads = 512;
+constexpr int kWaves = kThreads / 64;
+constexpr int kRanks = 6;       // median lo/hi, p95 lo/hi, p99 lo/hi
+constexpr int kCand = 512;      // candidates per rank resolved in LDS
+constexpr int kExpBins = 2048;  // level 0: bits 62..52 (latencies are >= +0.0, the sign bit is clear)
+constexpr int kDigBits = 10;    // deeper levels: 10 key bits each
+constexpr int kDigBins = 1 << kDigBits;
+
+struct SumArgs {
+    const double* clock;     // [n][clock_cap][2]  (start, finish)
+    const uint32_t* counts;  // [n][8]
+    uint32_t clock_cap;
+    uint32_t cnt_completed_slot;
+    double* stats;  // [n][8]  total, mean, median, std, p95, p99, min, max
+    float* rps;     // [n][rps_buckets] or null
+    uint32_t rps_buckets;
+    uint32_t* hist;  // [n][hist_bins] or null
+    uint32_t hist_bins;
+    double hist_scale;  // hist_bins / hist_max
+};
+
+__device__ inline double wave_sum(double v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ inline double wave_min(double v) {
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_down(v, off, 64));
+    return v;
+}
+__device__ inline double wave_max(double v) {
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+    return v;
+}
+
+// Deterministic block sum: per-thread partials -> wave tree -> the 8 wave results in lane order.
+__device__ inline double block_sum(double v, double* scratch /* [kWaves] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    double r = 0.0;
+    for (int w = 0; w < kWaves; ++w) r += scratch[w];
+    return r;
+}
+
+// One wave finds the bin holding rank k of a histogram: bin, #elements below it, its count.
+__device__ inline void wave_select(const uint32_t* hist, int nbins, uint32_t k, uint32_t& bin, uint32_t& below,
+                                   uint32_t& count) {
+    const int lane = threadIdx.x & 63;
+    const int per = nbins / 64;
+    uint32_t mine = 0;
+    for (int j = 0; j < per; ++j) mine += hist[lane * per + j];
+    uint32_t incl = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
+    }
+    const uint32_t excl = incl - mine;
+    const bool owner = excl <= k && k < incl;
+    uint32_t b = 0, bl = 0, c = 0;
+    if (owner) {
+        uint32_t run = excl;
+        for (int j = 0; j < per; ++j) {
+            const uint32_t h = hist[lane * per + j];
+            if (k < run + h) {
+                b = (uint32_t)(lane * per + j);
+                bl = run;
+                c = h;
+                break;
+            }
+            run += h;
+        }
+    }
+    const unsigned long long m = __ballot(owner);
+    const int src = m ? __ffsll((long long)m) - 1 : 0;
+    bin = __shfl(b, src, 64);
+    below = __shfl(bl, src, 64);
+    count = __shfl(c, src, 64);
+}
+
+__global__ __launch_bounds__(kThreads) void af_summary_kernel(SumArgs a) {
+    extern __shared__ uint32_t dyn[];  // [rps_buckets] then [hist_bins]
+    __shared__ uint32_t exp_hist[kExpBins];
+    __shared__ uint32_t dig_hist[kRanks][kDigBins];
+    __shared__ double cand[kRanks][kCand];
+    __shared__ uint32_t cand_n[kRanks];
+    __shared__ double scratch[kWaves];
+    __shared__ unsigned long long pfx[kRanks];       // key >> shift of the bin holding rank r
+    __shared__ unsigned long long slot_pfx[kRanks];  // distinct prefixes
+    __shared__ uint32_t rank_in[kRanks];             // rank r relative to its bin
+    __shared__ uint32_t cnt[kRanks];                 // elements in that bin
+    __shared__ uint32_t slot_of[kRanks];
+    __shared__ uint32_t n_slots, more;
+    __shared__ double val[kRanks];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t sc = blockIdx.x;
+    uint32_t n = a.counts[(size_t)sc * 8u + a.cnt_completed_slot];
+    if (n > a.clock_cap) n = a.clock_cap;
+    const double2* ck = reinterpret_cast<const double2*>(a.clock) + (size_t)sc * a.clock_cap;
+    uint32_t* rps_l = dyn;
+    uint32_t* hist_l = dyn + a.rps_buckets;
+
+    for (int i = tid; i < kExpBins; i += kThreads) exp_hist[i] = 0u;
+    for (uint32_t i = tid; i < a.rps_buckets + (a.hist ? a.hist_bins : 0u); i += kThreads) dyn[i] = 0u;
+    __syncthreads();
+
+    // ---- pass 1 -----------------------------------------------------------------------------
+    double s = 0.0, mn = __builtin_inf(), mx = -__builtin_inf();
+    for (uint32_t base = 0; base < n; base += kThreads * 4u) {
+        double2 c4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // four 16-byte loads in flight per thread
+            const uint32_t i = base + (uint32_t)u * kThreads + tid;
+            c4[u] = i < n ? ck[i] : double2{0.0, 0.0};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = base + (uint32_t)u * kThreads + tid;
+            if (i >= n) continue;
+            const double2 c = c4[u];
+            const double lat = c.y - c.x;
+            s += lat;
+            mn = fmin(mn, lat);
+            mx = fmax(mx, lat);
+            const unsigned long long key = (unsigned long long)__double_as_longlong(lat);
+            atomicAdd(&exp_hist[(key >> 52) & (kExpBins - 1)], 1u);
+            if (a.rps) {
+                // window (k-1, k]; a finish at exactly 0 belongs to the first window (analyzer.py:112-121)
+                const double kf = ceil(c.y);
+                const uint32_t k = kf < 1.0 ? 1u : (kf > 4.0e9 ? 0xFFFFFFFFu : (uint32_t)kf);
+                if (k <= a.rps_buckets) atomicAdd(&rps_l[k - 1u], 1u);
+            }
+            if (a.hist) {
+                const double bf = lat * a.hist_scale;
+                const uint32_t b = bf >= (double)(a.hist_bins - 1u) ? a.hist_bins - 1u : (uint32_t)bf;
+                atomicAdd(&hist_l[b], 1u);
+            }
+        }
+    }
+    const double total = block_sum(s, scratch);
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    __syncthreads();
+    if (lane == 0) scratch[wave] = mn;
+    __syncthreads();
+    double vmin = scratch[0];
+    for (int w = 1; w < kWaves; ++w) vmin = fmin(vmin, scratch[w]);
+    __syncthreads();
+    if (lane == 0) scratch[wave] = mx;
+    __syncthreads();
+    double vmax = scratch[0];
+    for (int w = 1; w < kWaves; ++w) vmax = fmax(vmax, scratch[w]);
+    __syncthreads();
+
+    if (a.rps)
+        for (uint32_t i = tid; i < a.rps_buckets; i += kThreads) a.rps[(size_t)sc * a.rps_buckets + i] = (float)rps_l[i];
+    if (a.hist)
+        for (uint32_t i = tid; i < a.hist_bins; i += kThreads) a.hist[(size_t)sc * a.hist_bins + i] = hist_l[i];
+
+    double* st = a.stats + (size_t)sc * 8u;
+    if (n == 0u) {  // the reference leaves latency_stats empty (analyzer.py:105-106)
+        if (tid < 8) st[tid] = tid == 0 ? 0.0 : __builtin_nan("");
+        return;
+    }
+    const double mean = total / (double)n;
+
+    // ---- wanted ranks (numpy: median = mean of the middle pair; percentile 'linear') ---------
+    __shared__ uint32_t want[kRanks];
+    __shared__ double tfrac[2];
+    if (tid == 0) {
+        want[0] = (n & 1u) ? n / 2u : n / 2u - 1u;
+        want[1] = n / 2u;
+        const double q[2] = {95.0 / 100.0, 99.0 / 100.0};
+        for (int p = 0; p < 2; ++p) {
+            const double v = (double)(n - 1u) * q[p];
+            if (v >= (double)(n - 1u)) {
+                want[2 + 2 * p] = want[3 + 2 * p] = n - 1u;
+                tfrac[p] = 0.0;
+            } else {
+                const double f = floor(v);
+                want[2 + 2 * p] = (uint32_t)f;
+                want[3 + 2 * p] = (uint32_t)f + 1u;
+                tfrac[p] = v - f;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- level 0: exponent bin of every wanted rank ---------------------------------------------
+    if (wave < kRanks) {
+        uint32_t bin, below, count;
+        wave_select(exp_hist, kExpBins, want[wave], bin, below, count);
+        if (lane == 0) {
+            pfx[wave] = bin;
+            rank_in[wave] = want[wave] - below;
+            cnt[wave] = count;
+        }
+    }
+    int shift = 52;
+
+    // ---- deeper levels while some rank still has too many candidates ------------------------------
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t ns = 0, m = 0;
+            for (int r = 0; r < kRanks; ++r) {
+                uint32_t sidx = ns;
+                for (uint32_t q = 0; q < ns; ++q)
+                    if (slot_pfx[q] == pfx[r]) sidx = q;
+                if (sidx == ns) slot_pfx[ns++] = pfx[r];
+                slot_of[r] = sidx;
+                if (cnt[r] > (uint32_t)kCand && shift > 0) m = 1u;
+            }
+            n_slots = ns;
+            more = m;
+        }
+        __syncthreads();
+        if (!more) break;
+        const int bits = shift >= kDigBits ? kDigBits : shift;
+        const int new_shift = shift - bits;
+        const uint32_t ns = n_slots;
+        for (uint32_t i = tid; i < ns * (uint32_t)kDigBins; i += kThreads) (&dig_hist[0][0])[i] = 0u;
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += kThreads) {
+            const double2 c = ck[i];
+            const unsigned long long key = (unsigned long long)__double_as_longlong(c.y - c.x);
+            const unsigned long long hi = key >> shift;
+            for (uint32_t q = 0; q < ns; ++q)
+                if (hi == slot_pfx[q]) atomicAdd(&dig_hist[q][(key >> new_shift) & ((1u << bits) - 1u)], 1u);
+        }
+        __syncthreads();
+        if (wave < kRanks) {
+            uint32_t bin, below, count;
+            wave_select(dig_hist[slot_of[wave]], kDigBins, rank_in[wave], bin, below, count);
+            if (lane == 0) {
+                pfx[wave] = (pfx[wave] << bits) | bin;
+                rank_in[wave] -= below;
+                cnt[wave] = count;
+            }
+        }
+        shift = new_shift;
+    }
+
+    // ---- last pass: gather candidates + squared deviations -----------------------------------------
+    if (tid < kRanks) cand_n[tid] = 0u;
+    __syncthreads();
+    const uint32_t ns = n_slots;
+    double sq = 0.0;
+    for (uint32_t base = 0; base < n; base += kThreads * 4u) {
+        double2 c4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = base + (uint32_t)u * kThreads + tid;
+            c4[u] = i < n ? ck[i] : double2{0.0, 0.0};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = base + (uint32_t)u * kThreads + tid;
+            if (i >= n) continue;
+            const double lat = c4[u].y - c4[u].x;
+            const double d = lat - mean;
+            sq += d * d;
+            const unsigned long long hi = (unsigned long long)__double_as_longlong(lat) >> shift;
+            for (uint32_t q = 0; q < ns; ++q)
+                if (hi == slot_pfx[q]) {
+                    const uint32_t pos = atomicAdd(&cand_n[q], 1u);
+                    if (pos < (uint32_t)kCand) cand[q][pos] = lat;
+                }
+        }
+    }
+    const double sq_total = block_sum(sq, scratch);
+    __syncthreads();
+    for (int r = 0; r < kRanks; ++r) {
+        const uint32_t q = slot_of[r];
+        if (shift == 0) {  // the whole key is known: every candidate has this value
+            if (tid == 0) val[r] = __longlong_as_double((long long)pfx[r]);
+            continue;
+        }
+        const uint32_t m = cand_n[q] < (uint32_t)kCand ? cand_n[q] : (uint32_t)kCand;
+        const uint32_t k = rank_in[r];
+        if ((uint32_t)tid < m) {
+            const double x = cand[q][tid];
+            uint32_t less = 0, leq = 0;
+            for (uint32_t j = 0; j < m; ++j) {
+                const double y = cand[q][j];
+                less += y < x ? 1u : 0u;
+                leq += y <= x ? 1u : 0u;
+            }
+            if (less <= k && k < leq) val[r] = x;
+        }
+    }
+    __syncthreads();
+
+    if (tid == 0) {
+        auto lerp = [](double lo, double hi, double t) {  // numpy _lerp
+            const double d = hi - lo;
+            return t >= 0.5 ? hi - d * (1.0 - t) : lo + d * t;
+        };
+        st[0] = (double)n;
+        st[1] = mean;
+        st[2] = (n & 1u) ? val[1] : (val[0] + val[1]) / 2.0;
+        st[3] = sqrt(sq_total / (double)n);
+        st[4] = lerp(val[2], val[3], tfrac[0]);
+        st[5] = lerp(val[4], val[5], tfrac[1]);
+        st[6] = vmin;
+        st[7] = vmax;
+    }
+}
+
+// Per-series mean and maximum of the sampled metrics of every scenario
+// (samples [n][tick_cap][pitch] u32; only the first counts[CNT_TICKS] rows are valid).
+struct SeriesArgs {
+    const uint32_t* samples;
+    const uint32_t* counts;
+    uint32_t tick_cap, pitch, n_series, cnt_ticks_slot;
+    double* mean;    // [n][n_series]
+    uint32_t* maxv;  // [n][n_series]
+};
+
+constexpr int kSeriesThreads = 256;
+
+__global__ __launch_bounds__(kSeriesThreads) void af_series_kernel(SeriesArgs a) {
+    extern __shared__ unsigned long long sdyn[];  // [pitch] sums, then [pitch] u32 maxima
+    unsigned long long* sum_l = sdyn;
+    uint32_t* max_l = reinterpret_cast<uint32_t*>(sdyn + a.pitch);
+    const int tid = threadIdx.x;
+    const uint32_t sc = blockIdx.x;
+    uint32_t ticks = a.counts[(size_t)sc * 8u + a.cnt_ticks_slot];
+    if (ticks > a.tick_cap) ticks = a.tick_cap;
+    for (uint32_t i = tid; i < a.pitch; i += kSeriesThreads) {
+        sum_l[i] = 0ull;
+        max_l[i] = 0u;
+    }
+    __syncthreads();
+    const uint32_t pq = a.pitch / 4u;                       // 16-byte groups per row
+    const uint32_t stride = (kSeriesThreads / pq) * pq;     // keeps a thread on one column group
+    const uint4* rows = reinterpret_cast<const uint4*>(a.samples + (size_t)sc * a.tick_cap * a.pitch);
+    const uint32_t total = ticks * pq;
+    if ((uint32_t)tid < stride) {
+        unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+        for (uint32_t i = tid; i < total; i += stride) {
+            const uint4 v = rows[i];
+            s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+            m0 = v.x > m0 ? v.x : m0; m1 = v.y > m1 ? v.y : m1;
+            m2 = v.z > m2 ? v.z : m2; m3 = v.w > m3 ? v.w : m3;
+        }
+        const uint32_t col = ((uint32_t)tid % pq) * 4u;
+        atomicAdd(&sum_l[col + 0], s0); atomicAdd(&sum_l[col + 1], s1);
+        atomicAdd(&sum_l[col + 2], s2); atomicAdd(&sum_l[col + 3], s3);
+        atomicMax(&max_l[col + 0], m0); atomicMax(&max_l[col + 1], m1);
+        atomicMax(&max_l[col + 2], m2); atomicMax(&max_l[col + 3], m3);
+    }
+    __syncthreads();
+    for (uint32_t j = tid; j < a.n_series; j += kSeriesThreads) {
+        if (a.mean) a.mean[(size_t)sc * a.n_series + j] = ticks ? (double)sum_l[j] / (double)ticks : __builtin_nan("");
+        if (a.maxv) a.maxv[(size_t)sc * a.n_series + j] = max_l[j];
+    }
+}
+
+}  // namespace afs

@@ -25,6 +25,7 @@
 #include "../../include/asyncflow_hip.h"
 #include "af_core.hpp"
 #include "af_plan_pack.hpp"
+#include "af_summary.hpp"
 
 #define LDS_AS __attribute__((address_space(3)))
 
@@ -623,6 +624,62 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     e->stats.chunks = n_chunks;
     e->stats.request_capacity = e->request_capacity;
     e->stats.fifo_capacity = e->fifo_capacity;
+    return AF_OK;
+}
+
+int af_engine_summarize(af_engine_t* e, const af_outputs_t* out, const af_summary_t* sum) {
+    if (!e || !out || !sum) return fail(AF_ERR_INVALID, "NULL argument");
+    if (sum->n_scenarios == 0) return fail(AF_ERR_INVALID, "empty summary request");
+    if (!out->counts) return fail(AF_ERR_INVALID, "outputs.counts is required");
+    const bool want_lat = sum->stats || sum->rps || sum->hist;
+    const bool want_series = sum->series_mean || sum->series_max;
+    if (want_lat && !sum->stats) return fail(AF_ERR_INVALID, "summary.stats is required with rps/hist");
+    if (want_lat && (!out->clock || out->clock_capacity == 0)) return fail(AF_ERR_INVALID, "summary needs outputs.clock");
+    if (want_series && (!out->samples || out->tick_capacity == 0)) return fail(AF_ERR_INVALID, "series summary needs outputs.samples");
+    if (sum->hist && (sum->hist_bins == 0 || sum->hist_bins > 8192u || !(sum->hist_max > 0.0)))
+        return fail(AF_ERR_INVALID, "hist_bins must be 1..8192 and hist_max > 0");
+    if (sum->rps && sum->rps_buckets == 0) return fail(AF_ERR_INVALID, "rps buffer with zero buckets");
+    const uint32_t rps_buckets = sum->rps ? sum->rps_buckets : 0u;
+    const size_t dyn_bytes = ((size_t)rps_buckets + (sum->hist ? sum->hist_bins : 0u)) * 4u;
+    if (dyn_bytes > 96u * 1024u) return fail(AF_ERR_CAPACITY, "rps_buckets + hist_bins exceed the LDS budget (24576 words)");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipEventRecord(e->ev0, e->stream));
+    if (want_lat) {
+        afs::SumArgs s{};
+        s.clock = out->clock;
+        s.counts = out->counts;
+        s.clock_cap = out->clock_capacity;
+        s.cnt_completed_slot = AF_CNT_COMPLETED;
+        s.stats = sum->stats;
+        s.rps = sum->rps;
+        s.rps_buckets = rps_buckets;
+        s.hist = sum->hist;
+        s.hist_bins = sum->hist ? sum->hist_bins : 0u;
+        s.hist_scale = sum->hist ? (double)sum->hist_bins / sum->hist_max : 0.0;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(afs::af_summary_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes));
+        hipLaunchKernelGGL(afs::af_summary_kernel, dim3(sum->n_scenarios), dim3(afs::kThreads), dyn_bytes, e->stream, s);
+        HIP_TRY(hipGetLastError());
+    }
+    if (want_series) {
+        afs::SeriesArgs s{};
+        s.samples = out->samples;
+        s.counts = out->counts;
+        s.tick_cap = out->tick_capacity;
+        s.pitch = e->args.series_pitch;
+        s.n_series = e->args.n_edges + 3u * e->args.n_servers;
+        s.cnt_ticks_slot = AF_CNT_TICKS;
+        s.mean = sum->series_mean;
+        s.maxv = sum->series_max;
+        const size_t lds = (size_t)s.pitch * 12u;
+        hipLaunchKernelGGL(afs::af_series_kernel, dim3(sum->n_scenarios), dim3(afs::kSeriesThreads), lds, e->stream, s);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(e->ev1, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    e->stats.summary_ms = ms;
     return AF_OK;
 }
 

@@ -128,6 +128,19 @@ class Engine:
         _check(self._lib, self._lib.af_engine_run(self._h, C.byref(sweep), C.byref(out)), "af_engine_run")
         return self.stats()
 
+    def summarize(self, n: int, *, clock_ptr: int, clock_capacity: int, samples_ptr: int, tick_capacity: int,
+                  counts_ptr: int, stats_ptr: int = 0, rps_ptr: int = 0, rps_buckets: int = 0, hist_ptr: int = 0,
+                  hist_bins: int = 0, hist_max: float = 0.0, series_mean_ptr: int = 0,
+                  series_max_ptr: int = 0) -> _abi.AfStats:
+        """Batched analyzer on the device over the outputs of a finished run (DEVICE pointers)."""
+        out = _abi.AfOutputs(int(clock_capacity), C.c_void_p(clock_ptr or None), int(tick_capacity),
+                             C.c_void_p(samples_ptr or None), C.c_void_p(counts_ptr))
+        summ = _abi.AfSummary(int(n), int(rps_buckets), int(hist_bins), float(hist_max),
+                              C.c_void_p(stats_ptr or None), C.c_void_p(rps_ptr or None), C.c_void_p(hist_ptr or None),
+                              C.c_void_p(series_mean_ptr or None), C.c_void_p(series_max_ptr or None))
+        _check(self._lib, self._lib.af_engine_summarize(self._h, C.byref(out), C.byref(summ)), "af_engine_summarize")
+        return self.stats()
+
     def stats(self) -> _abi.AfStats:
         st = _abi.AfStats()
         _check(self._lib, self._lib.af_engine_stats(self._h, C.byref(st)), "af_engine_stats")

@@ -246,53 +246,88 @@ class BatchedResults:
         return (self[i] for i in range(len(self)))
 
     # ---- device-side reduction of every scenario at once ---------------------------
-    def summary(self, rps: bool = True) -> dict[str, Any]:
-        """Per-scenario latency stats (+ 1-s RPS series) computed on the GPU.
+    def summary(self, rps: bool = True, hist_bins: int = 0, hist_max: float = 0.0,
+                series: bool = False) -> dict[str, Any]:
+        """Per-scenario latency stats, 1-s RPS series, optional latency histogram and
+        per-series mean/max, computed by the HIP analyzer (``af_engine_summarize``).
 
         Returns torch tensors on the run's device: ``stats`` float64 [n, 8] in
-        LATENCY_KEYS order and ``rps`` float32 [n, T].  Percentiles use numpy's
-        linear-interpolation rule; sums are not pairwise like numpy's, so values
-        agree with ``ScenarioResults`` to ~1e-12 relative, not bit for bit.
+        LATENCY_KEYS order (= ``ResultsAnalyzer.get_latency_stats`` per scenario,
+        metrics/analyzer.py:83-104), ``rps`` float32 [n, floor(T)] (analyzer.py:108-126),
+        ``hist`` int32 [n, hist_bins], ``series_mean`` float64 / ``series_max`` int32
+        [n, n_series].  Order statistics (median, p95, p99, min, max) are bit-equal to
+        numpy's; mean/std agree to ~1e-13 relative (different summation order).
         """
         import torch
+
+        from .engine import Engine
 
         if self._clock_t is None:
             msg = "run(collect_clock=False) kept no rqs_clock"
             raise RuntimeError(msg)
+        if series and self._samples_t is None:
+            msg = "run(collect_samples=False) kept no sampled series"
+            raise RuntimeError(msg)
         clock = self._clock_t
         n, cap = int(clock.shape[0]), int(clock.shape[1])
         dev = clock.device
-        cnt = torch.as_tensor(self.counts[:, _abi.CNT_COMPLETED].astype(np.int64), device=dev).clamp(max=cap)
-        idx = torch.arange(cap, device=dev).unsqueeze(0)
-        valid = idx < cnt.unsqueeze(1)
-        lat = torch.where(valid, clock[:, :, 1] - clock[:, :, 0], torch.full((), float("inf"), dtype=clock.dtype, device=dev))
-        lat_sorted, _ = torch.sort(lat, dim=1)
-        cf = cnt.clamp(min=1).to(torch.float64)
-        zero = torch.zeros((), dtype=torch.float64, device=dev)
-        lat0 = torch.where(valid, lat, zero)
-        mean = lat0.sum(dim=1) / cf
-        var = (torch.where(valid, (lat - mean.unsqueeze(1)) ** 2, zero)).sum(dim=1) / cf
+        T = int(self.plan.total_time)
+        stats = torch.empty((n, 8), dtype=torch.float64, device=dev)
+        rps_t = torch.empty((n, T), dtype=torch.float32, device=dev) if rps and T > 0 else None
+        hist_t = torch.empty((n, hist_bins), dtype=torch.int32, device=dev) if hist_bins else None
+        smean = torch.empty((n, self.plan.n_series), dtype=torch.float64, device=dev) if series else None
+        smax = torch.empty((n, self.plan.n_series), dtype=torch.int32, device=dev) if series else None
+        torch.cuda.synchronize(dev)
+        eng = Engine(self.plan, dev.index if dev.index is not None else torch.cuda.current_device())
+        try:
+            st = eng.summarize(
+                n,
+                clock_ptr=clock.data_ptr(), clock_capacity=cap,
+                samples_ptr=self._samples_t.data_ptr() if self._samples_t is not None else 0,
+                tick_capacity=int(self._samples_t.shape[1]) if self._samples_t is not None else 0,
+                counts_ptr=self._counts_t.data_ptr(),
+                stats_ptr=stats.data_ptr(),
+                rps_ptr=rps_t.data_ptr() if rps_t is not None else 0, rps_buckets=T if rps_t is not None else 0,
+                hist_ptr=hist_t.data_ptr() if hist_t is not None else 0, hist_bins=hist_bins, hist_max=hist_max,
+                series_mean_ptr=smean.data_ptr() if smean is not None else 0,
+                series_max_ptr=smax.data_ptr() if smax is not None else 0,
+            )
+        finally:
+            eng.close()
+        out: dict[str, Any] = {"stats": stats, "keys": LATENCY_KEYS, "summary_ms": float(st.summary_ms)}
+        if rps_t is not None:
+            out["rps"] = rps_t
+        if hist_t is not None:
+            out["hist"] = hist_t
+        if series:
+            out["series_mean"], out["series_max"] = smean, smax
+        return out
 
-        def pct(q: float) -> Any:
-            pos = (cnt.clamp(min=1) - 1).to(torch.float64) * (q / 100.0)
-            lo = pos.floor().long()
-            hi = (lo + 1).clamp(max=(cnt.clamp(min=1) - 1))
-            frac = pos - lo.to(torch.float64)
-            a = lat_sorted.gather(1, lo.unsqueeze(1)).squeeze(1)
-            b = lat_sorted.gather(1, hi.unsqueeze(1)).squeeze(1)
-            return a + (b - a) * frac
+    def aggregate(self, level: float = 0.95) -> dict[str, Any]:
+        """Monte-Carlo aggregation over the scenarios of the sweep (the reference's roadmap
+        item, ROADMAP.md:23-29): mean, standard deviation and normal-approximation confidence
+        half-width of every latency statistic, plus the mean RPS band (5th/95th percentile
+        across scenarios per 1-s window)."""
+        from statistics import NormalDist
 
-        stats = torch.stack(
-            [cnt.to(torch.float64), mean, pct(50.0), var.sqrt(), pct(95.0), pct(99.0), lat_sorted[:, 0],
-             lat_sorted.gather(1, (cnt.clamp(min=1) - 1).unsqueeze(1)).squeeze(1)], dim=1)
-        stats = torch.where((cnt > 0).unsqueeze(1), stats, torch.full_like(stats, float("nan")))
-        out: dict[str, Any] = {"stats": stats, "keys": LATENCY_KEYS}
-        if rps:
-            T = int(self.plan.total_time)
-            fin = torch.where(valid, clock[:, :, 1], torch.full((), float("inf"), dtype=clock.dtype, device=dev))
-            bucket = torch.ceil(fin).clamp(min=1.0)  # finish in (k-1, k] -> bucket k
-            bucket = torch.where(valid & (bucket <= T), bucket, torch.zeros((), dtype=clock.dtype, device=dev)).long()
-            hist = torch.zeros((n, T + 1), dtype=torch.float32, device=dev)
-            hist.scatter_add_(1, bucket, torch.ones_like(bucket, dtype=torch.float32))
-            out["rps"] = hist[:, 1:]
+        summ = self.summary(rps=True)
+        stats = summ["stats"].cpu().numpy()
+        ok = stats[:, 0] > 0
+        z = NormalDist().inv_cdf(0.5 + level / 2.0)
+        k = int(ok.sum())
+        body = stats[ok]
+        mean = body.mean(axis=0) if k else np.full(8, np.nan)
+        sd = body.std(axis=0, ddof=1) if k > 1 else np.full(8, np.nan)
+        out: dict[str, Any] = {
+            "n": k,
+            "keys": LATENCY_KEYS,
+            "mean": dict(zip(LATENCY_KEYS, mean.tolist())),
+            "std": dict(zip(LATENCY_KEYS, sd.tolist())),
+            "ci_halfwidth": dict(zip(LATENCY_KEYS, (z * sd / np.sqrt(max(k, 1))).tolist())),
+            "level": level,
+        }
+        if "rps" in summ:
+            r = summ["rps"].cpu().numpy().astype(np.float64)
+            out["rps_mean"] = r.mean(axis=0)
+            out["rps_p05"], out["rps_p95"] = np.percentile(r, [5.0, 95.0], axis=0)
         return out

@@ -222,6 +222,7 @@ typedef struct af_stats {
     double kernel_ms;           /* HIP-event time of the next-event kernel (af_des_kernel) */
     double pregen_ms;           /* HIP-event time of the draw pre-generation kernels       */
     double h2d_ms;              /* seeds/overrides upload                          */
+    double summary_ms;          /* last af_engine_summarize (both kernels)         */
     uint64_t draw_bytes;        /* size of the pre-generated draw arrays (HBM)     */
     uint64_t state_bytes_per_scenario;
     uint32_t state_in_lds;      /* 1 = LDS-resident state, 0 = HBM-resident        */
@@ -238,6 +239,30 @@ typedef struct af_engine af_engine_t;
 /* Replaces: SimulationRunner.__init__ + _build_* (simulation_runner.py:52-294). */
 int af_engine_create(const af_plan_t* plan, int device, const af_engine_options_t* opts,
                      af_engine_t** out);
+/* Batched analyzer on the device (replaces ResultsAnalyzer._process_event_metrics,
+ * src/asyncflow/metrics/analyzer.py:83-126, for every scenario of a finished af_engine_run):
+ * per-scenario latency statistics in LatencyKey order
+ *   {total_requests, mean, median, std_dev, p95, p99, min, max}
+ * (order statistics exact, numpy 'linear' interpolation; scenarios without completions: total 0,
+ * the rest NaN), the 1-s throughput windows (k-1, k], k = 1..rps_buckets, an optional linear latency
+ * histogram over [0, hist_max) whose last bin also takes the overflow, and the mean / maximum of
+ * every sampled series.  All buffers are DEVICE memory owned by the caller; NULL skips an output. */
+typedef struct af_summary_t {
+    uint32_t n_scenarios;
+    uint32_t rps_buckets;   /* floor(total_time)                                        */
+    uint32_t hist_bins;     /* <= 8192                                                  */
+    double hist_max;        /* seconds                                                  */
+    double* stats;          /* [n][8] f64                                               */
+    float* rps;             /* [n][rps_buckets] f32                                     */
+    uint32_t* hist;         /* [n][hist_bins] u32                                       */
+    double* series_mean;    /* [n][af_series_count] f64 (needs outputs.samples)         */
+    uint32_t* series_max;   /* [n][af_series_count] u32                                 */
+} af_summary_t;
+
+/* `out` is the af_outputs_t the run filled (clock + counts are required, samples only for the
+ * series outputs).  Synchronous like af_engine_run. */
+int af_engine_summarize(af_engine_t* engine, const af_outputs_t* out, const af_summary_t* summary);
+
 /* Replaces: _start_* + env.run(until=T) (simulation_runner.py:301-369) for
  * sweep->n_scenarios independent scenarios. */
 int af_engine_run(af_engine_t* eng, const af_sweep_t* sweep, const af_outputs_t* out);

@@ -1,0 +1,145 @@
+"""The HIP analyzer (af_engine_summarize, through the C ABI) vs the analyzer oracle on a real MI355X.
+
+Bar: total, median, p95, p99, min, max, RPS windows, histogram, series mean/max bit-exact;
+mean within 1e-12 relative and std_dev within 1e-12 relative + 1e-13 x max latency absolute (the
+kernel sums in a fixed tree order, numpy pairwise; for near-constant data std_dev is pure rounding
+noise of the mean, hence the absolute term).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from asyncflow_amd import _abi
+from asyncflow_amd.plan import lower
+from oracle import analyzer_oracle as ao
+from oracle.scenarios import lb_two_servers, lb_with_events, single_server
+
+pytestmark = pytest.mark.gpu
+
+EXACT = [0, 2, 4, 5, 6, 7]      # total, median, p95, p99, min, max
+CLOSE = [1, 3]                  # mean, std_dev
+RTOL = 1e-12
+
+
+def _check_stats(got: np.ndarray, want: np.ndarray, what=""):
+    assert np.array_equal(got[EXACT].view(np.uint64), want[EXACT].view(np.uint64)), (what, got, want)
+    if want[0] > 0:
+        assert np.allclose(got[1], want[1], rtol=RTOL, atol=0.0), (what, got, want)
+        assert np.allclose(got[3], want[3], rtol=RTOL, atol=1e-13 * want[7]), (what, got, want)
+    else:
+        assert np.isnan(got[1:]).all()
+
+
+def _summarize_synthetic(lats_list, starts_list=None, total_time=50, hist_bins=0, hist_max=0.0, cap_limit=None,
+                         random_starts=()):
+    """Feed hand-made rqs_clock rows straight to af_engine_summarize."""
+    import torch
+
+    from asyncflow_amd.engine import Engine
+
+    plan = lower(single_server(horizon=total_time))
+    n = len(lats_list)
+    cap = max(max((len(x) for x in lats_list), default=1), 1)
+    if cap_limit:
+        cap = cap_limit
+    rng = np.random.default_rng(7)
+    clock = np.full((n, cap, 2), np.nan)
+    counts = np.zeros((n, _abi.CNT_SLOTS), dtype=np.uint32)
+    clocks = []
+    for i, lat in enumerate(lats_list):
+        lat = np.asarray(lat, dtype=np.float64)
+        if starts_list is not None:
+            start = np.asarray(starts_list[i], dtype=np.float64)
+        elif i in random_starts:                               # finish - start then differs from lat by rounding
+            start = rng.uniform(0.0, total_time - 1.0, size=lat.size)
+        else:                                                   # finish - 0 == lat exactly: ties stay ties
+            start = np.zeros(lat.size)
+        fin = start + lat
+        rows = np.stack([start, fin], axis=1) if lat.size else np.zeros((0, 2))
+        counts[i, _abi.CNT_COMPLETED] = lat.size           # may exceed cap: the kernel clamps
+        keep = rows[:cap]
+        clock[i, : keep.shape[0]] = keep
+        clocks.append(keep)
+    dev = torch.device("cuda", 0)
+    clock_t = torch.as_tensor(clock, device=dev)
+    counts_t = torch.as_tensor(counts.view(np.int32), device=dev)
+    stats = torch.empty((n, 8), dtype=torch.float64, device=dev)
+    rps = torch.empty((n, total_time), dtype=torch.float32, device=dev)
+    hist = torch.empty((n, max(hist_bins, 1)), dtype=torch.int32, device=dev)
+    eng = Engine(plan, 0)
+    eng.summarize(n, clock_ptr=clock_t.data_ptr(), clock_capacity=cap, samples_ptr=0, tick_capacity=0,
+                  counts_ptr=counts_t.data_ptr(), stats_ptr=stats.data_ptr(), rps_ptr=rps.data_ptr(),
+                  rps_buckets=total_time, hist_ptr=hist.data_ptr() if hist_bins else 0, hist_bins=hist_bins,
+                  hist_max=hist_max)
+    eng.close()
+    return clocks, stats.cpu().numpy(), rps.cpu().numpy(), hist.cpu().numpy().view(np.uint32)
+
+
+def test_order_statistics_are_exact_on_adversarial_latency_sets():
+    rng = np.random.default_rng(2026)
+    cases = [
+        [],                                                     # no completion at all
+        [0.25],                                                 # n = 1
+        [0.5, 0.125],                                           # n = 2
+        [3.0, 1.0, 2.0],
+        rng.exponential(0.02, 511), rng.exponential(0.02, 512), rng.exponential(0.02, 513),
+        rng.exponential(0.02, 20_001),
+        np.full(5_000, 0.0625),                                 # every latency equal: radix runs to the last bit
+        rng.choice([0.001, 0.002, 0.004], 30_000),              # three values, > kCand ties each
+        np.concatenate([np.full(4_000, 0.01), 0.01 + rng.uniform(0, 1e-15, 4_000)]),   # split only by the last mantissa bits
+        10.0 ** rng.uniform(-300, 300, 10_000),                 # the whole exponent range
+        np.concatenate([np.zeros(700), rng.uniform(0, 1, 701)]),  # many exact zeros
+        rng.lognormal(-4.0, 0.5, 75_861),                       # LB-2 sized
+        np.arange(1, 101) * 0.001,                              # n = 100: p95 / p99 interpolate with t < 0.5 and t >= 0.5
+        np.arange(1, 34) * 0.5,
+    ]
+    clocks, stats, rps, _ = _summarize_synthetic(cases, random_starts=(4, 5, 6, 7, 13))
+    for i, ck in enumerate(clocks):
+        _check_stats(stats[i], ao.latency_stats(ck), f"case {i}")
+        assert np.array_equal(rps[i].astype(np.float64), ao.throughput_series(ck, 50)[1]), f"rps case {i}"
+
+
+def test_window_edges_histogram_and_capacity_clamp():
+    starts = [np.zeros(6)]
+    lats = [np.array([0.0, 1.0, 1.0000000000000002, 2.0, 49.99, 50.0])]
+    clocks, stats, rps, hist = _summarize_synthetic(lats, starts, hist_bins=8, hist_max=4.0)
+    want = ao.throughput_series(clocks[0], 50)[1]
+    assert np.array_equal(rps[0].astype(np.float64), want) and want[0] == 2.0 and want[49] == 2.0
+    assert np.array_equal(hist[0], ao.latency_histogram(clocks[0], 8, 4.0))
+    # counts says 1000 completions, the clock buffer holds 300: only the stored rows are analysed
+    rng = np.random.default_rng(5)
+    clocks, stats, _, _ = _summarize_synthetic([rng.exponential(0.03, 1000)], cap_limit=300, random_starts=(0,))
+    assert clocks[0].shape[0] == 300
+    _check_stats(stats[0], ao.latency_stats(clocks[0]))
+
+
+@pytest.mark.parametrize("payload_fn", [lambda: lb_two_servers(horizon=30), lambda: lb_with_events(users=150, horizon=40, scale=0.05)])
+def test_summary_of_a_simulated_batch_matches_the_oracle(payload_fn):
+    from asyncflow_amd.runner import SimulationRunner
+
+    payload = payload_fn()
+    seeds = 0x5EED0000 + np.arange(40, dtype=np.uint64)
+    res = SimulationRunner(simulation_input=payload, seeds=seeds).run()
+    summ = res.summary(rps=True, hist_bins=64, hist_max=0.128, series=True)
+    stats = summ["stats"].cpu().numpy()
+    rps = summ["rps"].cpu().numpy()
+    hist = summ["hist"].cpu().numpy().view(np.uint32)
+    smean = summ["series_mean"].cpu().numpy()
+    smax = summ["series_max"].cpu().numpy().view(np.uint32)
+    T = int(res.plan.total_time)
+    for i in range(len(res)):
+        sc = res[i]
+        _check_stats(stats[i], ao.latency_stats(sc.rqs_clock), f"scenario {i}")
+        assert np.array_equal(rps[i].astype(np.float64), ao.throughput_series(sc.rqs_clock, T)[1])
+        assert np.array_equal(hist[i], ao.latency_histogram(sc.rqs_clock, 64, 0.128))
+        m, x = ao.series_mean_max(sc._samples)  # noqa: SLF001
+        assert np.array_equal(smean[i].view(np.uint64), m.view(np.uint64)) and np.array_equal(smax[i], x)
+        # the drop-in accessor of one scenario agrees with the batched row
+        one = sc.get_latency_stats()
+        assert one["p95"] == stats[i][4] and one["total_requests"] == stats[i][0]
+    agg = res.aggregate()
+    assert agg["n"] == 40 and agg["ci_halfwidth"]["p95"] > 0.0
+    assert abs(agg["mean"]["p95"] - stats[:, 4].mean()) < 1e-15
+    assert agg["rps_mean"].shape == (T,)
