@@ -61,7 +61,7 @@ FLAG_NAMES = {
     FLAG_CLOCK_OVERFLOW: "rqs_clock capacity overflow (raise clock_capacity)",
     FLAG_TICK_OVERFLOW: "sample capacity overflow",
     FLAG_RAM_STARVED: "a request needs more RAM than the server owns (queue blocked, as in the reference)",
-    FLAG_TIME_TIE: "two timed events shared a timestamp (SimPy may interleave their zero-time steps differently)",
+    FLAG_TIME_TIE: "a zero-delay timeout was created in the middle of a zero-time cascade (SimPy may order the pending steps differently)",
     FLAG_DRAW_OVERFLOW: "more arrivals than draw_capacity (raise clock_capacity)",
 }
 FATAL_FLAGS = (
@@ -153,6 +153,7 @@ class AfEngineOptions(C.Structure):
         ("force_global_state", C.c_uint32),
         ("lanes_per_wave", C.c_uint32),
         ("draw_memory_mb", C.c_uint32),
+        ("expect_shared_instants", C.c_uint32),
     ]
 
 
@@ -169,6 +170,7 @@ class AfStats(C.Structure):
         ("waves", C.c_uint32),
         ("lanes_per_wave", C.c_uint32),
         ("chunks", C.c_uint32),
+        ("shared_instant_scenarios", C.c_uint32),
         ("request_capacity", C.c_uint32),
         ("fifo_capacity", C.c_uint32),
     ]

@@ -15,7 +15,13 @@
 //     injection timers are register-resident "special" sources with a fixed class
 //     order on ties;
 //   * every zero-time SimPy step following a timed event is executed inline in
-//     the order SimPy runs it when no other timed event shares the timestamp.
+//     the order SimPy runs it when no other timed event shares the timestamp;
+//   * when two or more timed events DO share a timestamp, SimPy interleaves their
+//     zero-time steps breadth-first (every step is a NORMAL heap event behind the
+//     other timed events of that instant, process Initialize events are URGENT).
+//     Such instants are detected before anything is processed and run through
+//     `micro_mode`, a cold path that replays SimPy's event-by-event order on the
+//     same state (FIFO of zero-time events in a per-scenario HBM scratch).
 //
 // State lives in `Mem`, a per-lane memory of 64-bit words laid out [index][lane]
 // (SoA across the 64 lanes of a wave): LDS when it fits (ds_read_b64 of
@@ -55,6 +61,7 @@ enum : uint32_t {
     FLAG_RAM_STARVED = 1u << 4,
     FLAG_TIME_TIE = 1u << 5,
     FLAG_DRAW_OVERFLOW = 1u << 6,
+    FLAG_SHARED_INSTANT = 1u << 7,  // internal: never visible in the outputs of af_engine_run
 };
 enum : uint32_t {
     CNT_GENERATED = 0, CNT_COMPLETED, CNT_DROPPED, CNT_EVENTS, CNT_TICKS, CNT_FLAGS, CNT_MAX_LIVE, CNT_MARKS, CNT_SLOTS
@@ -118,6 +125,9 @@ struct Layout {
     uint32_t fcap;      // per-server wait-queue capacity (power of two, <= 32768)
     uint32_t ovr_mask;  // bit p set: af_param class p is overridden per scenario
     uint32_t hk, ha, hb, edge, ring, stime, srv, cq, rq, lb, n_words;
+    // per-scenario HBM scratch of the shared-timestamp path (64-bit words, plain array):
+    //   zero-time event FIFO [tcap][2] | node inbox items [tcap][2] | forwarder-busy bits
+    uint32_t tcap, tie_words;
 };
 enum : uint32_t { LEDGE = 2, LSRV = 5, RING = 4 };
 
@@ -139,6 +149,10 @@ AF_HD Layout make_layout(uint32_t cap, uint32_t fcap, uint32_t n_edges, uint32_t
     L.rq = w; w += 2u * n_servers * fcap;
     L.lb = w; w += n_lb > 8u ? n_lb : 0u;
     L.n_words = w;
+    uint32_t tc = 16u;
+    while (tc < 2u * cap + 8u) tc <<= 1;
+    L.tcap = tc;
+    L.tie_words = 4u * tc + (2u + n_servers + 63u) / 64u;
     return L;
 }
 AF_HD uint64_t layout_bytes_per_lane(const Layout& L) { return 8ull * L.n_words; }
@@ -178,6 +192,7 @@ struct PreDraws {
     const double* base;     // this scenario's block: [1 + n_edges][n_per_stream]
     uint32_t n_per_stream;  // entries per stream
     uint32_t flags_in;      // AF_FLAG_DRAW_OVERFLOW if the arrival stream did not fit
+    uint64_t* tie;          // this scenario's scratch for shared timestamps: [Layout::tie_words]
     AF_HD double entry(uint32_t stream, uint32_t index) const {
         return base[(size_t)stream * n_per_stream + index];
     }
@@ -239,8 +254,25 @@ AF_CORE_NOINLINE uint32_t cold_endpoint_pick(uint64_t seed, uint32_t sv, uint32_
     return (uint32_t)(((uint64_t)r.x * n_ep) >> 32);
 }
 
-template <class Mem>
-struct Lane {
+// Every scalar of a scenario that survives from one round to the next.
+struct LaneRegs {
+    double now, t_gen, t_tick, t_emark, t_smark;
+    uint64_t lb_list;    // LB out-edge order, 8 bits per entry (n_lb_edges <= 8), else in Mem
+    // creation sequence of the pending generator / sampler / timeline timers: together with the
+    // sequence in every heap entry this is SimPy's event-id order among TIMED events
+    uint32_t q_gen, q_tick, q_emark, q_smark;
+    uint32_t arr_ahead;  // arrival times staged in the ring beyond the next one
+    int32_t dirty_edge;  // edge whose ring was consumed from last (-1 = none): topped up next round
+    uint32_t fl;
+    uint32_t heap_n, seq, live, max_live, lb_n, emark_i, smark_i;
+    uint32_t n_gen, n_comp, n_drop, n_events, n_ticks, n_marks, flags;
+};
+
+// kFaithful = false builds the lean variant used for the first pass of a sweep: it has no
+// SimPy-order path; a scenario that meets a shared instant stops with FLAG_SHARED_INSTANT and
+// is simulated again, from the start, by the kFaithful = true variant (engine.hip).
+template <class Mem, bool kFaithful = true>
+struct Lane : LaneRegs {
     const PlanView& P;
     const Layout& L;
     Mem M;
@@ -248,14 +280,8 @@ struct Lane {
     PreDraws D;
     uint64_t seed;
 
-    // register-resident scalars
-    double now, t_gen, t_tick, t_emark, t_smark;
-    uint64_t lb_list;  // LB out-edge order, 8 bits per entry (n_lb_edges <= 8), else in Mem
-    uint32_t arr_ahead;  // arrival times staged in the ring beyond the next one
-    int32_t dirty_edge;  // edge whose ring was consumed from last (-1 = none): topped up next round
-    // Per-lane boolean state lives in ONE register (a bool per lane costs a 64-bit
+    // Per-lane boolean state lives in ONE register `fl` (a bool per lane costs a 64-bit
     // lane mask in scalar registers and a pile of mask arithmetic at every branch).
-    uint32_t fl;
     enum : uint32_t {
         F_HOLE = 1u,       // the popped event left the heap root free
         F_GRANT = 2u,      // a waiter received a CPU token
@@ -263,10 +289,9 @@ struct Lane {
         F_ADV = 8u,        // a request (re)enters the endpoint step loop
         F_ADV_CORE = 16u,  // ... holding a CPU core
         F_ADV_IO = 32u,    // ... counted in the I/O queue
-        F_DIRTY_ARR = 64u  // an arrival time was consumed: top its ring up next round
+        F_DIRTY_ARR = 64u,   // an arrival time was consumed: top its ring up next round
+        F_SEND_FIRST = 128u  // this pass: the message leaves before the CPU waiter resumes
     };
-    uint32_t heap_n, seq, live, max_live, lb_n, emark_i, smark_i;
-    uint32_t n_gen, n_comp, n_drop, n_events, n_ticks, n_marks, flags, rounds;
 
     // per-round work registers ("follow-ups" of the timed event being handled)
     uint32_t pend_count;  // pushes buffered this pass (<= 2): the heap code exists once
@@ -372,6 +397,16 @@ struct Lane {
     }
     // schedule the (single) pending timed event of a request (caller guarantees room)
     AF_CORE void emit(double t, uint64_t a, uint32_t state) {
+        // A zero-delay Timeout belongs BEHIND the zero-time steps still queued at this instant and
+        // AHEAD of the steps those trigger (SimPy FIFO).  The inline cascade runs all of them first.
+        // That is the same thing when nothing else is pending, and it commutes when the event is a
+        // delivery to the client (completion bookkeeping only); anything else is reported.
+        if (t == now) {
+            const bool pending = (fl & (F_ADV | F_GRANT | F_SEND)) != 0u || fu_ram_sv >= 0;
+            const bool to_client =
+                st_kind(state) == RK_TRANSIT && ((uint32_t)P.edge[EREC * st_idx(state) + 3u] & 0xFFu) == NODE_CLIENT;
+            if (pending && !to_client) flags |= FLAG_TIME_TIE;
+        }
         const uint64_t b = ((uint64_t)(seq++) << 32) | state;
         if (pend_count == 0u) {
             pend_k0 = t;
@@ -447,6 +482,7 @@ struct Lane {
     }
 
     // ---- SEND stage: EdgeRuntime.transport/_deliver up to the timeout (edge.py:73-107) ----
+    template <bool kMicro = false>
     AF_CORE void edge_send(uint64_t a, uint32_t e, uint32_t hops) {
         const uint32_t at = L.edge + LEDGE * e;
         const uint64_t cs = M.ld(at);  // conn[0:15] | ring_ahead[16:23] | sends<<32
@@ -472,7 +508,8 @@ struct Lane {
         }
         M.st(at, ncs + 1ull);  // conn += 1 (edge.py:88)
         const double effective = transit + spike;  // spike read at SEND time (edge.py:94-106)
-        emit(now + effective, a, st_pack(RK_TRANSIT, e, hops, 0u, 0u));
+        if constexpr (kMicro) m_emit(now + effective, a, st_pack(RK_TRANSIT, e, hops, 0u, 0u), MK_EDGE_TIMEOUT);
+        else emit(now + effective, a, st_pack(RK_TRANSIT, e, hops, 0u, 0u));
     }
 
     // ---- GRANT stage: the waiter's `yield cpu_req` returns (server.py:220-231) ----
@@ -540,7 +577,9 @@ struct Lane {
             M.st(at + 2u, d2u(u2d(M.ld(at + 2u)) + ram));  // ram container level
             if (((M.ld(at + 4u) >> 48) & 0x7FFFu) > 0u) fu_ram_sv = (int32_t)sv;
         }
-        fl |= F_SEND;
+        // with RAM to give back, `yield RAM.put` lets the CPU waiter resume first (server.py:273-276);
+        // without, transport() runs in the same step and its Timeout is created first
+        fl |= ram > 0.0 ? F_SEND : (F_SEND | F_SEND_FIRST);
         send_a = a;
         send_edge = (uint32_t)(P.srv[SREC * sv + 1u] >> 16) & 0xFFFFu;
         send_hops = hops;
@@ -699,6 +738,7 @@ struct Lane {
             if (emark_i >= P.n_edge_marks || u2d(P.emark[MREC * emark_i]) > now) break;
         }
         t_emark = emark_i < P.n_edge_marks ? u2d(P.emark[MREC * emark_i]) : AF_INF;
+        q_emark = seq++;
     }
     AF_CORE void apply_smarks() {
         for (;;) {
@@ -723,6 +763,7 @@ struct Lane {
             if (smark_i >= P.n_srv_marks || u2d(P.smark[NREC * smark_i]) > now) break;
         }
         t_smark = smark_i < P.n_srv_marks ? u2d(P.smark[NREC * smark_i]) : AF_INF;
+        q_smark = seq++;
     }
 
     // ---- sampler tick (metrics/collector.py:50-66) --------------------------------
@@ -764,14 +805,400 @@ struct Lane {
         n_ticks += 1u;
     }
 
+
+    // =====================================================================================
+    // Shared timestamps: SimPy's own event-by-event order (cold path, see DESIGN.md "Ties").
+    //
+    // At an instant `now` SimPy's heap order (time, priority, event id) means: the TIMED events
+    // already scheduled for `now` run first, by creation order; every zero-time step they
+    // trigger is a NORMAL event appended behind them (FIFO); a process Initialize (edge
+    // `_deliver`, server `_handle_request`) is URGENT and runs right after the step that
+    // spawned it.  The handlers below are the reference's coroutine fragments between two
+    // yields, keyed by the SimPy event whose processing resumes them:
+    //   EDGE_TIMEOUT  edge.py:110-116          STORE_PUT / STORE_GET  simpy.Store + the forwarders
+    //   STEP_TIMEOUT  server.py:231,255        (client.py:46-71, load_balancer.py:60-72, server.py:303-313)
+    //   CPU_GOT       server.py:220-231        CBOX_PUT   client.py:69 (completed_box.put)
+    //   CPU_PUT_IO    server.py:241-255        RAM_GOT    server.py:149
+    //   CPU_PUT_END   server.py:258-259        RAM_PUT    server.py:273-276
+    // A request waiting in a node inbox (simpy.Store) or as a FIFO entry carries its whole state
+    // (start time, hops, server, in_io, step row), like a heap entry does.
+    enum : uint32_t {
+        MK_NONE = 0, MK_EDGE_TIMEOUT, MK_STEP_TIMEOUT, MK_STORE_PUT, MK_STORE_GET, MK_CBOX_PUT,
+        MK_RAM_GOT, MK_CPU_GOT, MK_CPU_PUT_IO, MK_CPU_PUT_END, MK_RAM_PUT
+    };
+    enum : uint32_t { UK_NONE = 0, UK_EDGE_INIT, UK_SRV_INIT };
+    uint32_t mq_head, mq_n, bx_n;  // FIFO ring / inbox items in the HBM scratch D.tie
+    uint32_t uk, u_idx, u_hops;    // the (single) pending URGENT event
+    uint64_t ua;
+
+    AF_CORE void mq_push(uint32_t mk, uint64_t a, uint32_t st, uint32_t node = 0u, uint32_t waiting = 0u) {
+        if (mq_n >= L.tcap) {
+            flags |= FLAG_POOL_OVERFLOW;
+            return;
+        }
+        const uint32_t at = 2u * ((mq_head + mq_n) & (L.tcap - 1u));
+        D.tie[at] = a;
+        D.tie[at + 1u] = (uint64_t)st | ((uint64_t)mk << 32) | ((uint64_t)node << 40) | ((uint64_t)waiting << 56);
+        mq_n += 1u;
+    }
+    AF_CORE void bx_push(uint32_t node, uint64_t a, uint32_t st) {  // StorePut: append (unbounded store)
+        if (bx_n >= L.tcap) {
+            flags |= FLAG_POOL_OVERFLOW;
+            return;
+        }
+        const uint32_t at = 2u * L.tcap + 2u * bx_n;
+        D.tie[at] = a;
+        D.tie[at + 1u] = (uint64_t)st | ((uint64_t)node << 40);
+        bx_n += 1u;
+    }
+    AF_CORE bool bx_pop(uint32_t node, uint64_t& a, uint32_t& st) {  // first item of this node's inbox
+        const uint32_t base = 2u * L.tcap;
+        for (uint32_t i = 0u; i < bx_n; ++i) {
+            const uint64_t b = D.tie[base + 2u * i + 1u];
+            if ((uint32_t)(b >> 40) != node) continue;
+            a = D.tie[base + 2u * i];
+            st = (uint32_t)b;
+            for (uint32_t k = i + 1u; k < bx_n; ++k) {
+                D.tie[base + 2u * (k - 1u)] = D.tie[base + 2u * k];
+                D.tie[base + 2u * (k - 1u) + 1u] = D.tie[base + 2u * k + 1u];
+            }
+            bx_n -= 1u;
+            return true;
+        }
+        return false;
+    }
+    // forwarder of a node is between `box.get()` succeeding and its next `box.get()`
+    AF_CORE bool busy(uint32_t node) const { return (D.tie[4u * L.tcap + (node >> 6)] >> (node & 63u)) & 1ull; }
+    AF_CORE void set_busy(uint32_t node, bool v) {
+        uint64_t& w = D.tie[4u * L.tcap + (node >> 6)];
+        w = v ? (w | (1ull << (node & 63u))) : (w & ~(1ull << (node & 63u)));
+    }
+    AF_CORE void m_urgent(uint32_t k, uint64_t a, uint32_t idx, uint32_t hops) {
+        uk = k;
+        ua = a;
+        u_idx = idx;
+        u_hops = hops;
+    }
+    // a Timeout: into the heap, or -- zero delay -- behind the steps queued at this instant
+    AF_CORE void m_emit(double t, uint64_t a, uint32_t state, uint32_t mk) {
+        const uint32_t sq = seq++;
+        if (t == now) {
+            mq_push(mk, a, state);
+            return;
+        }
+        if (heap_n >= L.cap) {
+            flags |= FLAG_POOL_OVERFLOW;
+            live -= 1u;
+            return;
+        }
+        sift_up(heap_n++, t, a, ((uint64_t)sq << 32) | state);
+    }
+    AF_CORE void m_heap_pop() {
+        heap_n -= 1u;
+        if (heap_n > 0u) {
+            const double key = u2d(M.ld(L.hk + heap_n));
+            const uint64_t a = M.ld(L.ha + heap_n);
+            const uint64_t b = M.ld(L.hb + heap_n);
+            sift_down(0u, key, a, b, heap_n);
+        }
+    }
+    // StoreGet.__init__ -> _trigger_get: the forwarder asks for its next message
+    AF_CORE void m_forwarder_get(uint32_t node) {
+        uint64_t a;
+        uint32_t st;
+        if (bx_pop(node, a, st)) {
+            set_busy(node, true);
+            mq_push(MK_STORE_GET, a, st, node);
+        } else {
+            set_busy(node, false);
+        }
+    }
+    // Container._trigger_get of the CPU container; entries beyond `n_old` were appended by the
+    // caller's own get() and have not been counted in the ready queue.  Returns #grants.
+    AF_CORE uint32_t m_cpu_trigger(uint32_t sv, uint32_t n_old) {
+        const uint32_t at = L.srv + LSRV * sv;
+        uint64_t w0 = M.ld(at);
+        uint64_t q = M.ld(at + 4u);
+        uint32_t g = 0u;
+        while (((uint32_t)(q >> 16) & 0xFFFFu) > 0u && (uint32_t)w0 > 0u) {
+            const uint32_t head = (uint32_t)q & 0xFFFFu;
+            const uint32_t cqn = (uint32_t)(q >> 16) & 0xFFFFu;
+            const uint32_t from = L.cq + 2u * (sv * L.fcap + head);
+            mq_push(MK_CPU_GOT, M.ld(from), (uint32_t)M.ld(from + 1u), 0u, g < n_old ? 1u : 0u);
+            q = (q & ~0xFFFFFFFFull) | ((head + 1u) & (L.fcap - 1u)) | ((uint64_t)(cqn - 1u) << 16);
+            w0 -= 1ull;  // level -= 1
+            g += 1u;
+        }
+        M.st(at, w0);
+        M.st(at + 4u, q);
+        return g;
+    }
+    AF_CORE void m_ram_trigger(uint32_t sv) {  // head-of-line blocking FIFO
+        const uint32_t at = L.srv + LSRV * sv;
+        for (;;) {
+            const uint64_t q = M.ld(at + 4u);
+            const uint32_t rqn = (uint32_t)(q >> 48) & 0x7FFFu;
+            if (rqn == 0u) break;
+            const uint32_t head = (uint32_t)(q >> 32) & 0xFFFFu;
+            const uint32_t from = L.rq + 2u * (sv * L.fcap + head);
+            const uint64_t a = M.ld(from);
+            const uint32_t st = (uint32_t)M.ld(from + 1u);
+            const double need = u2d(P.row[TREC * st_step(st) + 1u]);
+            const double free_ram = u2d(M.ld(at + 2u));
+            if (free_ram < need) break;
+            M.st(at + 4u, (q & ~(0x7FFFFFFFull << 32)) | ((uint64_t)((head + 1u) & (L.fcap - 1u)) << 32) |
+                              ((uint64_t)(rqn - 1u) << 48));
+            M.st(at + 2u, d2u(free_ram - need));
+            mq_push(MK_RAM_GOT, a, st);
+        }
+    }
+    // tail of _handle_request once the core is back (server.py:261-276)
+    AF_CORE void m_srv_finish(uint64_t a, uint32_t sv, uint32_t step, uint32_t hops, bool in_io) {
+        const uint32_t at = L.srv + LSRV * sv;
+        if (in_io) M.st(at + 1u, M.ld(at + 1u) - 1ull);
+        const double ram = u2d(P.row[TREC * step + 1u]);
+        if (ram > 0.0) {
+            M.st(at + 3u, d2u(u2d(M.ld(at + 3u)) - ram));
+            M.st(at + 2u, d2u(u2d(M.ld(at + 2u)) + ram));  // ContainerPut succeeds at once
+            mq_push(MK_RAM_PUT, a, st_pack(RK_WAIT, sv, hops, 0u, step));
+            return;
+        }
+        m_urgent(UK_EDGE_INIT, a, (uint32_t)(P.srv[SREC * sv + 1u] >> 16) & 0xFFFFu, hops);
+    }
+    // the for-loop of _handle_request from step row `step` up to its next yield (server.py:197-259)
+    AF_CORE void m_srv_continue(uint64_t a, uint32_t sv, uint32_t step, uint32_t hops, bool core_locked, bool in_io) {
+        const uint32_t at = L.srv + LSRV * sv;
+        const uint32_t kind = (uint32_t)P.row[TREC * step + 2u];
+        if (kind == STEP_CPU) {
+            if (in_io) M.st(at + 1u, M.ld(at + 1u) - 1ull);
+            if (!core_locked) {  // cpu_req = CPU.get(1): append, trigger, `if not cpu_req.triggered`
+                const uint64_t q = M.ld(at + 4u);
+                const uint32_t cqn = (uint32_t)(q >> 16) & 0xFFFFu;
+                if (!q_push(L.cq, sv, (uint32_t)q & 0xFFFFu, cqn, a, st_pack(RK_WAIT, sv, hops, 0u, step))) return;
+                M.st(at + 4u, q + (1ull << 16));
+                if (m_cpu_trigger(sv, cqn) <= cqn) M.st(at, M.ld(at) + (1ull << 32));  // still queued: ready += 1
+                return;
+            }
+            m_emit(now + row_time(step), a, st_pack(RK_CPU, sv, hops, 0u, step), MK_STEP_TIMEOUT);
+            return;
+        }
+        if (kind == STEP_IO) {
+            if (core_locked) {  // yield CPU.put(1)
+                M.st(at, M.ld(at) + 1ull);
+                mq_push(MK_CPU_PUT_IO, a, st_pack(RK_WAIT, sv, hops, in_io ? 1u : 0u, step));
+                return;
+            }
+            if (!in_io) M.st(at + 1u, M.ld(at + 1u) + 1ull);
+            m_emit(now + row_time(step), a, st_pack(RK_IO, sv, hops, 1u, step), MK_STEP_TIMEOUT);
+            return;
+        }
+        if (core_locked) {  // endpoint finished holding the core: yield CPU.put(1)
+            M.st(at, M.ld(at) + 1ull);
+            mq_push(MK_CPU_PUT_END, a, st_pack(RK_WAIT, sv, hops, in_io ? 1u : 0u, step));
+            return;
+        }
+        m_srv_finish(a, sv, step, hops, in_io);
+    }
+    // head of _handle_request, run by its Initialize event (server.py:79-149)
+    AF_CORE void m_srv_init(uint64_t a, uint32_t sv, uint32_t hops) {
+        hops += 1u;
+        const uint32_t at = L.srv + LSRV * sv;
+        const uint64_t meta = P.srv[SREC * sv + 1u];
+        const uint32_t epb = (uint32_t)(meta >> 32) & 0xFFFFu;
+        const uint32_t n_ep = (uint32_t)(meta >> 48);
+        const uint64_t w1 = M.ld(at + 1u);
+        M.st(at + 1u, w1 + (1ull << 32));
+        const uint32_t pick = n_ep > 1u ? cold_endpoint_pick(seed, sv, (uint32_t)(w1 >> 32), n_ep) : 0u;
+        const uint32_t ep = epb + pick;
+        const double ram = u2d(P.ep[PREC * ep]);
+        const uint32_t step0 = (uint32_t)P.ep[PREC * ep + 1u];
+        if (ram > 0.0) {
+            const uint64_t q = M.ld(at + 4u);
+            if (ram > u2d(P.srv[SREC * sv]) || (q >> 63)) {  // same treatment as server_arrival
+                flags |= FLAG_RAM_STARVED;
+                M.st(at + 4u, q | (1ull << 63));
+                live -= 1u;
+                return;
+            }
+            if (q_push(L.rq, sv, (uint32_t)(q >> 32) & 0xFFFFu, (uint32_t)(q >> 48) & 0x7FFFu, a,
+                       st_pack(RK_WAIT, sv, hops, 0u, step0))) {
+                M.st(at + 4u, q + (1ull << 48));
+                m_ram_trigger(sv);
+            }
+            return;  // yield RAM.get(total_ram)
+        }
+        m_srv_continue(a, sv, step0, hops, false, false);
+    }
+
+    AF_CORE void micro_mode() {
+        mq_head = mq_n = bx_n = 0u;
+        uk = UK_NONE;
+        for (;;) {
+            // next event of this instant: timed ones by creation order, then the FIFO
+            uint32_t cls = 5u, best = 0xFFFFFFFFu;
+            if (heap_n > 0u && u2d(M.ld(L.hk)) == now) {
+                best = (uint32_t)(M.ld(L.hb) >> 32);
+                cls = 4u;
+            }
+            if (t_gen == now && q_gen < best) { best = q_gen; cls = 3u; }
+            if (t_tick == now && q_tick < best) { best = q_tick; cls = 2u; }
+            if (t_smark == now && q_smark < best) { best = q_smark; cls = 1u; }
+            if (t_emark == now && q_emark < best) { best = q_emark; cls = 0u; }
+            uint64_t ra = 0ull;
+            uint32_t rst = 0u, mk = MK_NONE, node = 0u, waiting = 0u;
+            if (cls == 4u) {
+                ra = M.ld(L.ha);
+                rst = (uint32_t)M.ld(L.hb);
+                m_heap_pop();
+                mk = st_kind(rst) == RK_TRANSIT ? MK_EDGE_TIMEOUT : MK_STEP_TIMEOUT;
+            } else if (cls == 3u) {  // rqs_generator.py:101-119
+                n_gen += 1u;
+                n_events += 1u;
+                live += 1u;
+                if (live > max_live) max_live = live;
+                m_urgent(UK_EDGE_INIT, d2u(now), P.gen_out_edge, 1u);
+                if (arr_ahead > 0u) {
+                    arr_ahead -= 1u;
+                    t_gen = u2d(M.ld(L.ring + (n_gen & (RING - 1u))));
+                } else {
+                    t_gen = draw_or(0u, n_gen, AF_INF);
+                }
+                q_gen = seq++;
+                fl |= F_DIRTY_ARR;
+            } else if (cls == 2u) {
+                sample_tick();
+                t_tick = now + P.sample_period;
+                q_tick = seq++;
+            } else if (cls == 1u) {
+                apply_smarks();
+            } else if (cls == 0u) {
+                apply_emarks();
+            } else {
+                if (mq_n == 0u) break;
+                const uint32_t at = 2u * mq_head;
+                ra = D.tie[at];
+                const uint64_t b = D.tie[at + 1u];
+                mq_head = (mq_head + 1u) & (L.tcap - 1u);
+                mq_n -= 1u;
+                rst = (uint32_t)b;
+                mk = (uint32_t)(b >> 32) & 0xFFu;
+                node = (uint32_t)(b >> 40) & 0xFFFFu;
+                waiting = (uint32_t)(b >> 56) & 1u;
+            }
+            const uint32_t sv = st_idx(rst);
+            const uint32_t hops = st_hops(rst);
+            const uint32_t step = st_step(rst);
+            switch (mk) {
+                case MK_EDGE_TIMEOUT: {  // edge.py:110-116, then StorePut on the target's inbox
+                    n_events += 1u;
+                    const uint32_t e = st_idx(rst);
+                    const uint32_t at = L.edge + LEDGE * e;
+                    M.st(at, M.ld(at) - 1ull);
+                    const uint32_t meta = (uint32_t)P.edge[EREC * e + 3u];
+                    const uint32_t tk = meta & 0xFFu;
+                    const uint32_t target = tk == NODE_CLIENT ? 0u : tk == NODE_LB ? 1u : 2u + ((meta >> 8) & 0xFFu);
+                    bx_push(target, ra, st_pack(RK_TRANSIT, e, hops + 1u, 0u, 0u));
+                    mq_push(MK_STORE_PUT, 0ull, 0u, target);
+                    break;
+                }
+                case MK_STORE_PUT: {  // the put is processed: Store._trigger_get is its first callback
+                    uint64_t a;
+                    uint32_t st;
+                    if (!busy(node) && bx_pop(node, a, st)) {
+                        set_busy(node, true);
+                        mq_push(MK_STORE_GET, a, st, node);
+                    }
+                    break;
+                }
+                case MK_STORE_GET: {  // a forwarder resumes with a message
+                    if (node == 0u) {  // client.py:46-71
+                        const uint32_t h = hops + 1u;
+                        if (h > 3u) {
+                            if (O.clock != nullptr) {
+                                if (n_comp < O.clock_cap) {
+                                    O.clock[2u * n_comp] = u2d(ra);
+                                    O.clock[2u * n_comp + 1u] = now;
+                                } else {
+                                    flags |= FLAG_CLOCK_OVERFLOW;
+                                }
+                            }
+                            n_comp += 1u;
+                            live -= 1u;
+                            mq_push(MK_CBOX_PUT, 0ull, 0u);  // yield completed_box.put(state)
+                        } else {
+                            m_urgent(UK_EDGE_INIT, ra, P.client_out_edge, h);
+                            m_forwarder_get(0u);
+                        }
+                    } else if (node == 1u) {  // load_balancer.py:60-72
+                        m_urgent(UK_EDGE_INIT, ra, lb_pick(), hops + 1u);
+                        m_forwarder_get(1u);
+                    } else {  // server.py:303-313
+                        m_urgent(UK_SRV_INIT, ra, node - 2u, hops);
+                        m_forwarder_get(node);
+                    }
+                    break;
+                }
+                case MK_CBOX_PUT: m_forwarder_get(0u); break;
+                case MK_RAM_GOT: {  // server.py:149-150
+                    const uint32_t at = L.srv + LSRV * sv;
+                    M.st(at + 3u, d2u(u2d(M.ld(at + 3u)) + u2d(P.row[TREC * step + 1u])));
+                    m_srv_continue(ra, sv, step, hops, false, false);
+                    break;
+                }
+                case MK_CPU_GOT: {  // server.py:220-231
+                    if (waiting) {
+                        const uint32_t at = L.srv + LSRV * sv;
+                        M.st(at, M.ld(at) - (1ull << 32));
+                    }
+                    m_emit(now + row_time(step), ra, st_pack(RK_CPU, sv, hops, 0u, step), MK_STEP_TIMEOUT);
+                    break;
+                }
+                case MK_STEP_TIMEOUT:  // the for-loop moves on to the next step row
+                    n_events += 1u;
+                    m_srv_continue(ra, sv, step + 1u, hops, st_kind(rst) == RK_CPU, st_io(rst) != 0u);
+                    break;
+                case MK_CPU_PUT_IO: {  // server.py:241-255: put processed -> grants, then the process resumes
+                    m_cpu_trigger(sv, 0xFFFFFFFFu);
+                    const uint32_t at = L.srv + LSRV * sv;
+                    if (!st_io(rst)) M.st(at + 1u, M.ld(at + 1u) + 1ull);
+                    m_emit(now + row_time(step), ra, st_pack(RK_IO, sv, hops, 1u, step), MK_STEP_TIMEOUT);
+                    break;
+                }
+                case MK_CPU_PUT_END:  // server.py:258-259
+                    m_cpu_trigger(sv, 0xFFFFFFFFu);
+                    m_srv_finish(ra, sv, step, hops, st_io(rst) != 0u);
+                    break;
+                case MK_RAM_PUT:  // server.py:273-276
+                    m_ram_trigger(sv);
+                    m_urgent(UK_EDGE_INIT, ra, (uint32_t)(P.srv[SREC * sv + 1u] >> 16) & 0xFFFFu, hops);
+                    break;
+                default: break;
+            }
+            while (uk != UK_NONE) {  // process Initialize events are URGENT
+                const uint32_t k = uk;
+                uk = UK_NONE;
+                if (k == UK_EDGE_INIT) edge_send<true>(ua, u_idx, u_hops);
+                else m_srv_init(ua, u_idx, u_hops);
+            }
+        }
+    }
+
     // ---- life cycle -----------------------------------------------------------------
     // `ovr` : per-lane reader of the override columns, ovr(k) -> double, k-th column;
     // ovr_index of a STEP_TIME column is a step ROW.
     template <class OvrFn>
     AF_CORE void init(const uint32_t* ovr_param, const uint32_t* ovr_index, uint32_t n_ovr, OvrFn ovr) {
         now = 0.0;
-        heap_n = seq = live = max_live = emark_i = smark_i = 0u;
-        n_gen = n_comp = n_drop = n_events = n_ticks = n_marks = rounds = 0u;
+        heap_n = live = max_live = emark_i = smark_i = 0u;
+        n_gen = n_comp = n_drop = n_events = n_ticks = n_marks = 0u;
+        // the Initialize events run in process start order (simulation_runner.py:364-366):
+        // edge timeline, server timeline, generator, ..., collector
+        q_emark = 0u;
+        q_smark = 1u;
+        q_gen = 2u;
+        q_tick = 3u;
+        seq = 4u;
+        for (uint32_t i = 0u; i < (2u + P.n_servers + 63u) / 64u; ++i) D.tie[4u * L.tcap + i] = 0ull;
         flags = D.flags_in;
         fl = 0u;
         pend_count = 0u;
@@ -833,6 +1260,10 @@ struct Lane {
         const double t_heap = heap_n > 0u ? u2d(M.ld(L.hk)) : AF_INF;
         const uint64_t root_a = M.ld(L.ha);
         const uint32_t root_st = (uint32_t)M.ld(L.hb);
+        // the root's children: an entry sharing the root's timestamp is always reachable through
+        // equal keys, so the two children tell whether the instant is shared inside the heap
+        const double t_c1 = u2d(M.ld(L.hk + 1u));
+        const double t_c2 = u2d(M.ld(L.hk + 2u));
         // next event among {heap, arrival, tick, server marks, edge marks}; on equal
         // times the LATER test wins: edge marks < server marks < tick < arrival < heap.
         uint32_t cls = 4u;
@@ -842,9 +1273,28 @@ struct Lane {
         if (t_smark <= t) { cls = 1u; t = t_smark; }
         if (t_emark <= t) { cls = 0u; t = t_emark; }
         if (!(t < P.total_time)) return false;  // the stop event is URGENT at T (pending top-ups are moot)
-        if (rounds > 0u && t == now) flags |= FLAG_TIME_TIE;
-        rounds += 1u;
         now = t;
+        // Two or more timed events at this instant: SimPy interleaves their zero-time steps.
+        const uint32_t same = (t_heap == t ? 1u : 0u) + (t_gen == t ? 1u : 0u) + (t_tick == t ? 1u : 0u) +
+                              (t_smark == t ? 1u : 0u) + (t_emark == t ? 1u : 0u) +
+                              ((heap_n > 1u && t_c1 == t) ? 1u : 0u) + ((heap_n > 2u && t_c2 == t) ? 1u : 0u);
+        // (sampler ticks and timeline marks commute with each other: an instant shared only by
+        // those needs no care, the fixed class order above is as good as any)
+        if (__builtin_expect(same > 1u && (t_heap == t || t_gen == t), 0)) {
+            if constexpr (kFaithful) {
+                micro_mode();
+                topup_end_arrivals(tu_arr);
+                topup_end_edge(tu_edge);
+                return true;
+            } else {
+                // Simulated again, from t = 0, by the variant that has the SimPy-order path.  (Handing
+                // the state over instead was measured: keeping it restorable costs the lean kernel
+                // 3.5 % on every sweep, and an engine that saw one such scenario starts its later
+                // sweeps with the other variant anyway.)
+                flags |= FLAG_SHARED_INSTANT;
+                return false;
+            }
+        }
 
         if (cls == 4u) {
             fl |= F_HOLE;
@@ -864,6 +1314,7 @@ struct Lane {
             n_events += 1u;
             live += 1u;
             if (live > max_live) max_live = live;
+            q_gen = seq++;  // next(time_gaps) + the new Timeout precede the edge process (rqs_generator.py:104-119)
             fl |= F_SEND;
             send_a = d2u(now);
             send_edge = P.gen_out_edge;
@@ -879,6 +1330,7 @@ struct Lane {
         } else if (cls == 2u) {
             sample_tick();
             t_tick = now + P.sample_period;
+            q_tick = seq++;
         } else if (cls == 1u) {
             apply_smarks();
         } else {
@@ -893,12 +1345,12 @@ struct Lane {
                 fl &= ~(F_ADV | F_ADV_CORE | F_ADV_IO);
                 advance(adv_a, adv_sv, adv_step, adv_hops, (f & F_ADV_CORE) != 0u, (f & F_ADV_IO) != 0u);
             }
-            if ((fl & F_GRANT) && pend_count < 2u) {
+            if ((fl & (F_GRANT | F_SEND_FIRST)) == F_GRANT && pend_count < 2u) {
                 fl &= ~F_GRANT;
                 cpu_granted();
             }
-            if ((fl & (F_SEND | F_GRANT)) == F_SEND && pend_count < 2u) {
-                fl &= ~F_SEND;
+            if ((fl & F_SEND) && (fl & (F_GRANT | F_SEND_FIRST)) != F_GRANT && pend_count < 2u) {
+                fl &= ~(F_SEND | F_SEND_FIRST);
                 edge_send(send_a, send_edge, send_hops);
             }
             if (fu_ram_sv >= 0 && !(fl & (F_GRANT | F_SEND))) ram_stage();

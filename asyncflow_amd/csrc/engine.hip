@@ -60,6 +60,9 @@ struct KArgs {
     uint32_t n_draw;
     uint32_t* pre_flags;    // [n_scen] AF_FLAG_DRAW_OVERFLOW from the arrival pre-generation
     uint32_t klog;          // log2(scenario lanes per wave)
+    uint64_t* tie;          // [n_scen][L.tie_words] scratch of the shared-timestamp path (HBM)
+    const uint32_t* scen_map;  // second pass: lane j simulates scenario scen_map[j] (null = identity)
+    uint32_t* n_shared;     // first pass: number of scenarios that met a shared instant
 };
 
 // Per-lane state memory, [index][lane] with 2^klog scenario lanes per wave.
@@ -83,8 +86,12 @@ __device__ __forceinline__ const LDS_AS uint64_t* lds_words(unsigned char* smem,
 
 // (Measured on MI355X, profiles/r01: forcing more than the natural 3 waves/SIMD with a
 // launch bound spills registers and is 1.5-3x slower; the kernel keeps its ~144 VGPRs.)
-template <bool kLdsState>
-__global__ void __launch_bounds__(64) af_des_kernel(const KArgs a) {
+//
+// kFaithful = false is the lean first pass: a scenario in which two timed events share an instant
+// stops there (af_core.hpp) and is simulated again by the kFaithful = true variant, whose extra
+// SimPy-order path costs ~20 % of kernel time through register pressure alone (measured).
+template <bool kLdsState, bool kFaithful>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) af_des_kernel(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lane = threadIdx.x;
 
@@ -125,7 +132,7 @@ __global__ void __launch_bounds__(64) af_des_kernel(const KArgs a) {
     const uint32_t kl = 1u << a.klog;
     const uint32_t scen = (blockIdx.x << a.klog) + lane;
     const bool active = lane < kl && scen < a.n_scen;
-    const uint32_t sc = active ? scen : 0u;
+    const uint32_t sc = active ? (a.scen_map ? a.scen_map[scen] : scen) : 0u;
 
     af::LaneOut O;
     O.clock = a.clock ? a.clock + (size_t)sc * a.clock_cap * 2u : nullptr;
@@ -141,30 +148,33 @@ __global__ void __launch_bounds__(64) af_des_kernel(const KArgs a) {
     D.base = a.draws + (size_t)sc * (1u + a.n_edges) * a.n_draw;
     D.n_per_stream = a.n_draw;
     D.flags_in = a.pre_flags[sc];
+    D.tie = a.tie + (size_t)sc * a.L.tie_words;
 
     if constexpr (kLdsState) {
         MemLds M;
         M.w = (LDS_AS uint64_t*)(smem + a.blob_bytes) + (lane & (kl - 1u));
         M.klog = a.klog;
-        af::Lane<MemLds> S(P, a.L, M, O, D, seed);
+        af::Lane<MemLds, kFaithful> S(P, a.L, M, O, D, seed);
         bool run = active;
         if (active) S.init(a.ovr_param, a.ovr_index, a.n_ovr, ovr);
         while (__any(run)) {
             if (run) run = S.round();
         }
         if (active) S.write_counts();
+        if (!kFaithful && active && (S.flags & af::FLAG_SHARED_INSTANT)) atomicAdd(a.n_shared, 1u);
     } else {
         unsigned char* base = a.state + (size_t)blockIdx.x * a.state_bytes_per_wave;
         MemGlobal M;
         M.w = reinterpret_cast<uint64_t*>(base) + (lane & (kl - 1u));
         M.klog = a.klog;
-        af::Lane<MemGlobal> S(P, a.L, M, O, D, seed);
+        af::Lane<MemGlobal, kFaithful> S(P, a.L, M, O, D, seed);
         bool run = active;
         if (active) S.init(a.ovr_param, a.ovr_index, a.n_ovr, ovr);
         while (__any(run)) {
             if (run) run = S.round();
         }
         if (active) S.write_counts();
+        if (!kFaithful && active && (S.flags & af::FLAG_SHARED_INSTANT)) atomicAdd(a.n_shared, 1u);
     }
 }
 
@@ -278,6 +288,12 @@ struct af_engine {
     size_t draws_cap = 0;
     uint32_t* d_pre_flags = nullptr;
     size_t pre_flags_cap = 0;
+    uint64_t* d_tie = nullptr;
+    size_t tie_cap = 0;
+    uint32_t* d_n_shared = nullptr;
+    uint32_t* d_map = nullptr;
+    size_t map_cap = 0;
+    bool shared_instants_likely = false;
     hipEvent_t ev3 = nullptr, ev4 = nullptr;
     size_t draw_memory_bytes = 0;
     uint32_t request_capacity = 0, fifo_capacity = 0, force_global = 0, lanes_per_wave = 0;
@@ -396,6 +412,7 @@ int af_engine_create(const af_plan_t* plan, int device, const af_engine_options_
     e->force_global = opts ? opts->force_global_state : 0u;
     e->lanes_per_wave = opts ? opts->lanes_per_wave : 0u;
     e->draw_memory_bytes = opts ? (size_t)opts->draw_memory_mb << 20 : 0;
+    e->shared_instants_likely = opts && opts->expect_shared_instants != 0u;
     if (e->lanes_per_wave & (e->lanes_per_wave - 1u)) {
         delete e;
         return fail(AF_ERR_INVALID, "lanes_per_wave must be 0 (auto) or a power of two <= 64");
@@ -416,6 +433,7 @@ int af_engine_create(const af_plan_t* plan, int device, const af_engine_options_
     if (err == hipSuccess) err = hipEventCreate(&e->ev2);
     if (err == hipSuccess) err = hipEventCreate(&e->ev3);
     if (err == hipSuccess) err = hipEventCreate(&e->ev4);
+    if (err == hipSuccess) err = hipMalloc((void**)&e->d_n_shared, 4);
     if (err == hipSuccess) err = hipMalloc((void**)&e->d_blob, blob.size() * 8u);
     if (err == hipSuccess) err = hipMemcpy(e->d_blob, blob.data(), blob.size() * 8u, hipMemcpyHostToDevice);
     if (err != hipSuccess) {
@@ -515,9 +533,20 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     a.draws = e->d_draws;
     a.n_draw = n_draw;
     a.pre_flags = e->d_pre_flags;
+    const size_t tie_bytes = (size_t)chunk * a.L.tie_words * 8u;
+    if (tie_bytes > e->tie_cap) {
+        if (e->d_tie) HIP_TRY(hipFree(e->d_tie));
+        e->d_tie = nullptr;
+        e->tie_cap = 0;
+        HIP_TRY(hipMalloc((void**)&e->d_tie, tie_bytes));
+        e->tie_cap = tie_bytes;
+    }
+    a.tie = e->d_tie;
+    a.n_shared = e->d_n_shared;
+    a.scen_map = nullptr;
 
     double ms_pregen = 0.0, ms_kernel = 0.0;
-    uint32_t kl = 0, waves = 0, lds_bytes = 0, n_chunks = 0;
+    uint32_t kl = 0, waves = 0, lds_bytes = 0, n_chunks = 0, n_rerun = 0;
     bool lds_state = false;
     for (uint32_t lo = 0; lo < n; lo += chunk) {
         const uint32_t nc = n - lo < chunk ? n - lo : chunk;
@@ -529,76 +558,118 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
         a.samples = out->samples ? out->samples + (size_t)lo * a.series_pitch * out->tick_capacity : nullptr;
         a.counts = out->counts + (size_t)lo * AF_CNT_SLOTS;
 
-        // Scenario lanes per wave and state placement.  The kernel is latency bound, so few
-        // scenarios are best spread over MANY narrow waves: fewer event kinds per round in a
-        // wave, every SIMD busy, several waves per SIMD hiding LDS latency.  Limits: ~144 VGPRs
-        // -> 3 waves/SIMD = 12 per CU; LDS-resident state -> 160 KiB per CU.  Cost model fitted
-        // to MI355X measurements (profiles/r01/lanes_sweep.md): relative time of one wave-round
-        // f(lanes), x 2.3 when the state lives in HBM, x the number of residency batches.
-        kl = e->lanes_per_wave;
-        {
-            static const double f_lanes[7] = {1.0, 1.4, 1.65, 2.2, 2.5, 2.4, 2.25};  // 1,2,4,...,64 lanes
-            const double n_cu = 256.0, vgpr_waves_per_cu = 12.0;
-            double best = 1e300;
-            uint32_t best_kl = 4;
-            bool best_lds = false;
-            for (uint32_t k = 0; k < 7; ++k) {
-                const uint32_t cand = 1u << k;
-                if (kl != 0u && cand != kl) continue;
-                const double waves_needed = (double)((nc + cand - 1u) / cand);
-                for (int lds = 1; lds >= 0; --lds) {
-                    if (lds && e->force_global) continue;
-                    double per_cu = vgpr_waves_per_cu;
-                    if (lds) {
-                        const uint64_t wg_bytes = (uint64_t)a.blob_bytes + bytes_per_lane * cand;
-                        if (wg_bytes > kLdsLimit) continue;
-                        const double fit = (double)(kLdsLimit / wg_bytes);
-                        per_cu = fit < per_cu ? fit : per_cu;
-                    }
-                    const double batches = waves_needed / (n_cu * per_cu);
-                    const double cost = (batches < 1.0 ? 1.0 : batches) * f_lanes[k] * (lds ? 1.0 : 2.3);
-                    if (cost < best) {
-                        best = cost;
-                        best_kl = cand;
-                        best_lds = lds != 0;
-                    }
-                }
-            }
-            kl = best_kl;
-            lds_state = best_lds;
-        }
-        uint32_t klog = 0;
-        while ((1u << klog) < kl) ++klog;
-        a.klog = klog;
-        const uint64_t state_per_wave = bytes_per_lane * kl;
-        waves = (nc + kl - 1) / kl;
-        lds_bytes = lds_state ? (uint32_t)(a.blob_bytes + state_per_wave) : a.blob_bytes;
-        a.state = nullptr;
-        a.state_bytes_per_wave = state_per_wave;
-        if (!lds_state) {
-            const size_t need = (size_t)state_per_wave * waves;
-            if (need > e->state_cap) {
-                if (e->d_state) HIP_TRY(hipFree(e->d_state));
-                e->d_state = nullptr;
-                e->state_cap = 0;
-                HIP_TRY(hipMalloc((void**)&e->d_state, need));
-                e->state_cap = need;
-            }
-            a.state = e->d_state;
-        }
-
-        // pre-generate every random draw of the chunk (HBM), then simulate
+        // pre-generate every random draw of the chunk (HBM)
         HIP_TRY(hipEventRecord(e->ev2, e->stream));
         hipLaunchKernelGGL(af_pregen_arrivals, dim3((nc + 63u) / 64u), dim3(64), 0, e->stream, a);
         hipLaunchKernelGGL(af_pregen_edges, dim3((n_draw + 255u) / 256u, nc, a.n_edges), dim3(256), 0, e->stream, a);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(e->ev3, e->stream));
-        if (lds_state) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(af_des_kernel<true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            hipLaunchKernelGGL(af_des_kernel<true>, dim3(waves), dim3(kWave), lds_bytes, e->stream, a);
-        } else {
-            hipLaunchKernelGGL(af_des_kernel<false>, dim3(waves), dim3(kWave), lds_bytes, e->stream, a);
+
+        // One launch of the next-event kernel over `count` scenarios (all of the chunk, or the
+        // ones listed in `map`).
+        auto launch_des = [&](uint32_t count, bool faithful, const uint32_t* map) -> int {
+            // Scenario lanes per wave and state placement.  The kernel is latency bound, so few
+            // scenarios are best spread over MANY narrow waves: fewer event kinds per round in a
+            // wave, every SIMD busy, several waves per SIMD hiding LDS latency.  Limits: <= 168
+            // VGPRs -> 3 waves/SIMD = 12 per CU; LDS-resident state -> 160 KiB per CU.  Cost model
+            // fitted to MI355X measurements (profiles/r01/lanes_sweep.md): relative time of one
+            // wave-round f(lanes), x 2.3 when the state lives in HBM, x the number of residency batches.
+            kl = e->lanes_per_wave;
+            {
+                static const double f_lanes[7] = {1.0, 1.4, 1.65, 2.2, 2.5, 2.4, 2.25};  // 1,2,4,...,64 lanes
+                const double n_cu = 256.0, vgpr_waves_per_cu = 12.0;
+                double best = 1e300;
+                uint32_t best_kl = 4;
+                bool best_lds = false;
+                for (uint32_t k = 0; k < 7; ++k) {
+                    const uint32_t cand = 1u << k;
+                    if (kl != 0u && cand != kl) continue;
+                    const double waves_needed = (double)((count + cand - 1u) / cand);
+                    for (int lds = 1; lds >= 0; --lds) {
+                        if (lds && e->force_global) continue;
+                        double per_cu = vgpr_waves_per_cu;
+                        if (lds) {
+                            const uint64_t wg_bytes = (uint64_t)a.blob_bytes + bytes_per_lane * cand;
+                            if (wg_bytes > kLdsLimit) continue;
+                            const double fit = (double)(kLdsLimit / wg_bytes);
+                            per_cu = fit < per_cu ? fit : per_cu;
+                        }
+                        const double batches = waves_needed / (n_cu * per_cu);
+                        const double cost = (batches < 1.0 ? 1.0 : batches) * f_lanes[k] * (lds ? 1.0 : 2.3);
+                        if (cost < best) {
+                            best = cost;
+                            best_kl = cand;
+                            best_lds = lds != 0;
+                        }
+                    }
+                }
+                kl = best_kl;
+                lds_state = best_lds;
+            }
+            uint32_t klog = 0;
+            while ((1u << klog) < kl) ++klog;
+            a.klog = klog;
+            a.n_scen = count;
+            a.scen_map = map;
+            const uint64_t state_per_wave = bytes_per_lane * kl;
+            waves = (count + kl - 1) / kl;
+            lds_bytes = lds_state ? (uint32_t)(a.blob_bytes + state_per_wave) : a.blob_bytes;
+            a.state = nullptr;
+            a.state_bytes_per_wave = state_per_wave;
+            if (!lds_state) {
+                const size_t need = (size_t)state_per_wave * waves;
+                if (need > e->state_cap) {
+                    if (e->d_state) HIP_TRY(hipFree(e->d_state));
+                    e->d_state = nullptr;
+                    e->state_cap = 0;
+                    HIP_TRY(hipMalloc((void**)&e->d_state, need));
+                    e->state_cap = need;
+                }
+                a.state = e->d_state;
+            }
+            const void* fn = lds_state ? (faithful ? reinterpret_cast<const void*>(af_des_kernel<true, true>)
+                                                   : reinterpret_cast<const void*>(af_des_kernel<true, false>))
+                                       : (faithful ? reinterpret_cast<const void*>(af_des_kernel<false, true>)
+                                                   : reinterpret_cast<const void*>(af_des_kernel<false, false>));
+            if (lds_state) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            void* kargs[] = {&a};
+            HIP_TRY(hipLaunchKernel(fn, dim3(waves), dim3(kWave), kargs, lds_bytes, e->stream));
+            return AF_OK;
+        };
+
+        // First pass: the lean kernel.  A scenario in which two timed events share an instant stops
+        // there and is simulated again, from its start, by the kernel that has SimPy's event-by-event
+        // path; engines whose plan keeps producing such scenarios go straight to that kernel.
+        const bool faithful_first = e->shared_instants_likely;
+        HIP_TRY(hipMemsetAsync(e->d_n_shared, 0, 4, e->stream));
+        if (int rc = launch_des(nc, faithful_first, nullptr)) return rc;
+        uint32_t n_shared = 0;
+        if (!faithful_first) {
+            HIP_TRY(hipMemcpyAsync(&n_shared, e->d_n_shared, 4, hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            if (n_shared > 0u) {
+                std::vector<uint32_t> cnt((size_t)nc * AF_CNT_SLOTS);
+                HIP_TRY(hipMemcpy(cnt.data(), a.counts, cnt.size() * 4u, hipMemcpyDeviceToHost));
+                std::vector<uint32_t> map;
+                map.reserve(n_shared);
+                for (uint32_t i = 0; i < nc; ++i)
+                    if (cnt[(size_t)i * AF_CNT_SLOTS + AF_CNT_FLAGS] & af::FLAG_SHARED_INSTANT) map.push_back(i);
+                if (map.size() * 4u > e->map_cap) {
+                    if (e->d_map) HIP_TRY(hipFree(e->d_map));
+                    e->d_map = nullptr;
+                    e->map_cap = 0;
+                    HIP_TRY(hipMalloc((void**)&e->d_map, (size_t)nc * 4u));
+                    e->map_cap = (size_t)nc * 4u;
+                }
+                HIP_TRY(hipMemcpy(e->d_map, map.data(), map.size() * 4u, hipMemcpyHostToDevice));
+                if (int rc = launch_des((uint32_t)map.size(), true, e->d_map)) return rc;
+                a.scen_map = nullptr;
+                a.n_scen = nc;
+                n_rerun += (uint32_t)map.size();
+                // such plans keep producing them: later runs start with the SimPy-order kernel, which
+                // is cheaper than a second pass over a few long scenarios in narrow, latency-bound waves
+                e->shared_instants_likely = true;
+            }
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(e->ev4, e->stream));
@@ -622,6 +693,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     e->stats.waves = waves;
     e->stats.lanes_per_wave = kl;
     e->stats.chunks = n_chunks;
+    e->stats.shared_instant_scenarios = n_rerun;
     e->stats.request_capacity = e->request_capacity;
     e->stats.fifo_capacity = e->fifo_capacity;
     return AF_OK;
@@ -702,6 +774,9 @@ void af_engine_destroy(af_engine_t* e) {
     if (e->ev4) (void)hipEventDestroy(e->ev4);
     if (e->d_draws) (void)hipFree(e->d_draws);
     if (e->d_pre_flags) (void)hipFree(e->d_pre_flags);
+    if (e->d_tie) (void)hipFree(e->d_tie);
+    if (e->d_n_shared) (void)hipFree(e->d_n_shared);
+    if (e->d_map) (void)hipFree(e->d_map);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }

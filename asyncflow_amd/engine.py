@@ -7,6 +7,7 @@ visible, :class:`EngineUnavailableError` is raised.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 from typing import Sequence
 
@@ -61,7 +62,7 @@ def _load_hip_runtime() -> None:
 def load_library(path: str | Path | None = None) -> C.CDLL:
     global _lib  # noqa: PLW0603
     if _lib is None:
-        p = Path(path) if path else LIB_PATH
+        p = Path(path or os.environ.get("ASYNCFLOW_HIP_LIB") or LIB_PATH)  # env override: A/B builds in experiments
         if not p.exists():
             msg = (
                 f"{p} not found: build it with `python -m asyncflow_amd.build` "
@@ -95,13 +96,13 @@ class Engine:
 
     def __init__(self, plan: DevicePlan, device: int = 0, *, request_capacity: int = 0,
                  fifo_capacity: int = 0, force_global_state: bool = False, lanes_per_wave: int = 0,
-                 draw_memory_mb: int = 0) -> None:
+                 draw_memory_mb: int = 0, expect_shared_instants: bool = False) -> None:
         self._lib = load_library()
         self.plan = plan
         self.device = device
         self._cplan = plan.as_ctypes()
         opts = _abi.AfEngineOptions(request_capacity, fifo_capacity, int(force_global_state), int(lanes_per_wave),
-                                    int(draw_memory_mb))
+                                    int(draw_memory_mb), int(expect_shared_instants))
         handle = C.c_void_p()
         _check(self._lib, self._lib.af_engine_create(C.byref(self._cplan), device, C.byref(opts), C.byref(handle)),
                "af_engine_create")

@@ -38,6 +38,10 @@ _STEP_RE = re.compile(
 )
 
 
+#: payloads (by content hash) whose sweeps met instants shared by several timed events
+_SHARED_INSTANTS_SEEN: dict[str, bool] = {}
+
+
 def resolve_sweep(plan: DevicePlan, sweep: Mapping[str, Any] | None, n: int) -> list[tuple[int, int, np.ndarray, str]]:
     """Map YAML-style paths to ``af_override_t`` columns.
 
@@ -103,6 +107,7 @@ class SimulationRunner:
         auto_grow: bool = True,
         lanes_per_wave: int = 0,
         draw_memory_mb: int = 0,
+        expect_shared_instants: bool | None = None,
     ) -> None:
         self.env = env  # accepted for signature compatibility; unused
         self.simulation_input = simulation_input
@@ -126,6 +131,10 @@ class SimulationRunner:
         self.auto_grow = auto_grow
         self.lanes_per_wave = lanes_per_wave
         self.draw_memory_mb = draw_memory_mb
+        #: True: start with the kernel variant that replays SimPy's event order at instants shared by
+        #: several timed events; None: start lean, hand such scenarios over, and remember (per
+        #: payload, in this process) that this topology produces them
+        self.expect_shared_instants = expect_shared_instants
         self._single = seeds is None and int(replicas) == 1 and not self.sweep
         self._engine: Engine | None = None
 
@@ -146,6 +155,12 @@ class SimulationRunner:
         clock_cap = int(self.clock_capacity or self.plan.clock_capacity(users_max, rpm_max))
         return cap, fifo, clock_cap
 
+    def _plan_key(self) -> str:
+        import hashlib
+        import json
+
+        return hashlib.sha1(json.dumps(self.plan.payload, sort_keys=True, default=str).encode()).hexdigest()
+
     def run(self) -> BatchedResults | ScenarioResults:
         """Lower once, launch the HIP kernel over every scenario, return results."""
         import torch
@@ -165,7 +180,10 @@ class SimulationRunner:
         for attempt in range(4):
             eng = Engine(self.plan, device, request_capacity=cap, fifo_capacity=fifo,
                          force_global_state=self.force_global_state, lanes_per_wave=self.lanes_per_wave,
-                         draw_memory_mb=self.draw_memory_mb)
+                         draw_memory_mb=self.draw_memory_mb,
+                         expect_shared_instants=(_SHARED_INSTANTS_SEEN.get(self._plan_key(), False)
+                                                 if self.expect_shared_instants is None
+                                                 else bool(self.expect_shared_instants)))
             self._engine = eng
             counts = torch.zeros((n, _abi.CNT_SLOTS), dtype=torch.int32, device=dev)
             clock = torch.empty((n, clock_cap, 2), dtype=torch.float64, device=dev) if self.collect_clock else None
@@ -185,6 +203,8 @@ class SimulationRunner:
                 draw_capacity=clock_cap,
             )
             eng.close()
+            if int(stats.shared_instant_scenarios) > 0:
+                _SHARED_INSTANTS_SEEN[self._plan_key()] = True
             res = BatchedResults(self.plan, self.seeds, counts, clock, samples, stats,
                                  time.perf_counter() - t0, {k: v for _, _, v, k in overrides})
             over = int(np.bitwise_or.reduce(res.flags)) & _abi.FATAL_FLAGS

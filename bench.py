@@ -296,6 +296,7 @@ def main() -> int:
                 "lds_bytes_per_wave": int(st.lds_bytes_per_wave),
                 "lanes_per_wave": int(st.lanes_per_wave),
                 "waves": int(st.waves),
+                "shared_instant_scenarios": int(st.shared_instant_scenarios),
             },
             "events_per_step": events_total,
             "per_gpu_value": total_events / elapsed / world,

@@ -182,9 +182,13 @@ enum af_flag {
     AF_FLAG_RAM_STARVED = 1u << 4,     /* a request needs more RAM than ram_mb: that
                                           server's RAM queue is blocked for good
                                           (same as the reference; informational) */
-    AF_FLAG_TIME_TIE = 1u << 5,        /* two timed events shared a timestamp: SimPy may
-                                          interleave their zero-time steps differently
-                                          (DESIGN.md "Ties"; informational) */
+    AF_FLAG_TIME_TIE = 1u << 5,        /* a zero-delay Timeout (step time or edge latency that
+                                          does not advance the f64 clock) was created while
+                                          other zero-time steps were pending and it is not a
+                                          delivery to the client: SimPy may order those steps
+                                          differently.  Instants shared by several timed events
+                                          are NOT flagged: they follow SimPy's event order
+                                          exactly (DESIGN.md "Ties"; informational) */
     AF_FLAG_DRAW_OVERFLOW = 1u << 6    /* more arrivals than draw_capacity            */
 };
 
@@ -216,6 +220,11 @@ typedef struct af_engine_options {
     uint32_t draw_memory_mb;    /* HBM budget for the pre-generated draws of one chunk of the
                                    sweep, MiB (0 = min(64 GiB, half of the free memory));
                                    larger sweeps run as several chunks                   */
+    uint32_t expect_shared_instants; /* 1 = start with the kernel variant that replays SimPy's
+                                   event order at instants shared by several timed events
+                                   (~20 % slower).  0 = lean variant first; scenarios that
+                                   meet such an instant are handed over to the other variant
+                                   and the engine remembers it for its later runs          */
 } af_engine_options_t;
 
 typedef struct af_stats {
@@ -230,6 +239,10 @@ typedef struct af_stats {
     uint32_t waves;             /* workgroups launched (one wavefront each)        */
     uint32_t lanes_per_wave;    /* scenarios carried by each wavefront             */
     uint32_t chunks;            /* sub-launches the sweep was split into           */
+    uint32_t shared_instant_scenarios; /* scenarios in which two timed events shared an instant:
+                                   simulated a second time by the kernel variant that replays
+                                   SimPy's event-by-event order (0 when the engine started
+                                   with that variant)                              */
     uint32_t request_capacity;
     uint32_t fifo_capacity;
 } af_stats_t;

@@ -29,8 +29,9 @@
  *
  * counts[AF_CNT_MARKS+...]: see orc_simulate; `ties` (returned through
  * orc_last_ties) counts timed events popped at the timestamp of the previous
- * one, i.e. the situations in which an engine that runs zero-time cascades
- * atomically may legally differ from SimPy's interleaving (DESIGN.md "Ties").
+ * one, i.e. the instants at which SimPy interleaves the zero-time steps of
+ * several cascades (DESIGN.md "Ties"); the tests use it to prove that a case
+ * exercises that regime.
  */
 #include <math.h>
 #include <stdint.h>

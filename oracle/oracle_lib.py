@@ -23,7 +23,7 @@ _lib: C.CDLL | None = None
 
 def build(force: bool = False) -> Path:
     """Compile the C restatement (gcc, seconds)."""
-    src_m = max((_HERE / n).stat().st_mtime for n in ("des_oracle.c", "des_oracle_atomic.c", "oracle_rng.h"))
+    src_m = max((_HERE / n).stat().st_mtime for n in ("des_oracle.c", "oracle_rng.h"))
     if force or not _LIB_PATH.exists() or _LIB_PATH.stat().st_mtime < src_m:
         subprocess.run(["make", "-C", str(_HERE), "-B", "libaf_oracle.so"], check=True, capture_output=True)
     return _LIB_PATH
@@ -39,10 +39,6 @@ def lib() -> C.CDLL:
             C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
         ]
         L.orc_simulate.restype = C.c_int
-        L.orc_simulate_atomic.argtypes = L.orc_simulate.argtypes
-        L.orc_simulate_atomic.restype = C.c_int
-        L.orc_atomic_last_ties.argtypes = []
-        L.orc_atomic_last_ties.restype = C.c_uint64
         L.orc_x_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
         L.orc_x_uniform.restype = C.c_double
         L.orc_x_word0.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
@@ -137,14 +133,10 @@ def simulate(
     clock_capacity: int | None = None,
     want_samples: bool = True,
     want_clock: bool = True,
-    atomic: bool = False,
 ) -> OracleResult:
-    """Run ONE scenario of ``plan`` with Philox key ``seed`` on the CPU.
-
-    ``atomic=False``: SimPy-faithful restatement (des_oracle.c) == the reference.
-    ``atomic=True``: the HIP engine's semantics (des_oracle_atomic.c): identical
-    unless two timed events share a timestamp (``ties > 0``).
-    """
+    """Run ONE scenario of ``plan`` with Philox key ``seed`` on the CPU: the SimPy-faithful
+    restatement (des_oracle.c) == the reference, exact timestamp ties included (``ties`` counts
+    the timed events that shared their timestamp with the previous one)."""
     L = lib()
     cplan = plan.as_ctypes()
     cap = int(clock_capacity if clock_capacity is not None else plan.clock_capacity())
@@ -152,8 +144,7 @@ def simulate(
     ticks = plan.tick_count
     samples = np.zeros((plan.n_series, max(ticks, 1)), dtype=np.uint32) if want_samples else None
     counts = np.zeros(_abi.CNT_SLOTS, dtype=np.uint64)
-    fn = L.orc_simulate_atomic if atomic else L.orc_simulate
-    rc = fn(
+    rc = L.orc_simulate(
         C.byref(cplan),
         C.c_uint64(seed),
         C.c_uint64(cap),
@@ -170,6 +161,6 @@ def simulate(
         counts=counts,
         clock=clock[: min(n, cap)].copy() if clock is not None else np.zeros((0, 2)),
         samples=samples[:, : int(counts[_abi.CNT_TICKS])].copy() if samples is not None else np.zeros((0, 0), np.uint32),
-        ties=int(L.orc_atomic_last_ties() if atomic else L.orc_last_ties()),
-        heap_events=0 if atomic else int(L.orc_last_heap_events()),
+        ties=int(L.orc_last_ties()),
+        heap_events=int(L.orc_last_heap_events()),
     )

@@ -303,6 +303,69 @@ def random_payload(rng: random.Random, horizon: int = 12) -> dict:
     return copy.deepcopy(p)
 
 
+def tie_storm(rng: random.Random, horizon: int = 12) -> dict:
+    """Payloads built to make timed events COLLIDE: dyadic step times on multi-core servers with a
+    tight RAM budget, Poisson (integer, often zero) edge latencies, sampler period and event marks on
+    the same dyadic grid.  Every grant burst then schedules several Timeouts for the same instant,
+    zero-delay deliveries are common, and ticks coincide with timeline marks -- the regime in which
+    SimPy's breadth-first interleaving of zero-time steps is observable."""
+    n_srv = rng.randint(1, 3)
+    use_lb = n_srv > 1 or rng.random() < 0.5
+    cpu = ["initial_parsing", "cpu_bound_operation"]
+    io = ["io_wait", "io_db", "io_cache"]
+    grid = [0.125, 0.25, 0.5, 1.0]
+    servers = []
+    for i in range(n_srv):
+        eps = []
+        for j in range(rng.randint(1, 2)):
+            steps: list[tuple[str, float]] = []
+            if rng.random() < 0.7:
+                steps.append(("ram", rng.choice([64, 100, 128, 200])))
+            for _ in range(rng.randint(1, 4)):
+                steps.append((rng.choice(cpu), rng.choice(grid)) if rng.random() < 0.55 else (rng.choice(io), rng.choice(grid)))
+            if rng.random() < 0.3:
+                steps.append(("ram", rng.choice([32, 64])))
+            eps.append(_endpoint(f"/t{j}", steps))
+        servers.append(_server(f"s{i}", rng.randint(1, 3), rng.choice([256, 300, 400]), eps))
+
+    def lat() -> tuple[float, str]:
+        return (rng.choice([0.3, 0.7, 1.2]), "poisson") if rng.random() < 0.75 else (rng.uniform(0.05, 0.3), "exponential")
+
+    edges = [_edge("g-c", "gen", "cli", *lat(), None, rng.choice([None, 0.0, 0.05]))]
+    if use_lb:
+        edges.append(_edge("c-lb", "cli", "lb", *lat(), None, rng.choice([None, 0.0])))
+        edges += [_edge(f"lb-s{i}", "lb", f"s{i}", *lat(), None, rng.choice([None, 0.0, 0.05])) for i in range(n_srv)]
+    else:
+        edges.append(_edge("c-s0", "cli", "s0", *lat(), None, None))
+    edges += [_edge(f"s{i}-c", f"s{i}", "cli", *lat(), None, rng.choice([None, 0.0])) for i in range(n_srv)]
+    nodes: dict[str, Any] = {"client": {"id": "cli"}, "servers": servers}
+    if use_lb:
+        nodes["load_balancer"] = {"id": "lb", "algorithms": rng.choice(["round_robin", "least_connection"]),
+                                  "server_covered": [f"s{i}" for i in range(n_srv)]}
+    p: dict[str, Any] = {
+        "rqs_input": {"id": "gen", "avg_active_users": {"mean": rng.choice([4, 10, 25])},
+                      "avg_request_per_minute_per_user": {"mean": rng.choice([30, 60, 120])},
+                      "user_sampling_window": rng.choice([1, 2, 60])},
+        "topology_graph": {"nodes": nodes, "edges": edges},
+        "sim_settings": {"total_simulation_time": horizon, "sample_period_s": rng.choice([0.0625, 0.03125, 0.015625])},
+    }
+    events = []
+    T = float(horizon)
+    for k in range(rng.randint(0, 2)):
+        a = rng.randrange(1, int(T * 2) - 4) / 2.0
+        b = min(T, a + rng.choice([0.5, 1.0, 2.5]))
+        events.append({"event_id": f"sp{k}", "target_id": rng.choice(edges)["id"],
+                       "start": {"kind": "network_spike_start", "t_start": a, "spike_s": rng.choice([0.25, 0.5, 1.0])},
+                       "end": {"kind": "network_spike_end", "t_end": b}})
+    if use_lb and n_srv > 1 and rng.random() < 0.6:
+        a = rng.randrange(2, int(T) - 3) * 1.0
+        events.append({"event_id": "out0", "target_id": f"s{rng.randrange(n_srv)}",
+                       "start": {"kind": "server_down", "t_start": a}, "end": {"kind": "server_up", "t_end": a + rng.choice([1.0, 2.5])}})
+    if events:
+        p["events"] = events
+    return copy.deepcopy(p)
+
+
 #: name -> (payload builder, seed) for the committed golden fixtures
 GOLDEN = {
     "single_server_t30": (lambda: single_server(horizon=30), 0),

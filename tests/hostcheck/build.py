@@ -41,6 +41,10 @@ def lib() -> C.CDLL:
             C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32,
         ]
         L.hc_simulate.restype = C.c_int
+        L.hc_set_two_pass.argtypes = [C.c_int]
+        L.hc_set_two_pass.restype = None
+        L.hc_reruns.argtypes = []
+        L.hc_reruns.restype = C.c_int
         L.hc_bytes_per_lane.argtypes = [C.c_uint32] * 7
         L.hc_bytes_per_lane.restype = C.c_uint64
         _lib = L

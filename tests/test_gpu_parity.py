@@ -11,7 +11,7 @@ import pytest
 from asyncflow_amd import _abi
 from asyncflow_amd.plan import lower
 from oracle import oracle_lib as ol
-from oracle.scenarios import fanout8, lb_two_servers, lb_with_events, overload, random_payload, single_server
+from oracle.scenarios import fanout8, lb_two_servers, lb_with_events, overload, random_payload, single_server, tie_storm
 from tests.conftest import GOLDEN_DIR, golden_names
 
 pytestmark = pytest.mark.gpu
@@ -65,19 +65,20 @@ def test_engine_reproduces_reference_fixtures(name):
     seed = int(fx["seed"])
     res = _runner(payload, seeds=[seed, seed + 1, seed]).run()
     plan = lower(payload)
-    want = ol.simulate(plan, seed, atomic=True)
+    want = ol.simulate(plan, seed)
     _assert_scenario(res[0], want)
     _assert_scenario(res[2], want)                      # same seed -> same result, any lane
-    _assert_scenario(res[1], ol.simulate(plan, seed + 1, atomic=True))
-    if ol.simulate(plan, seed).ties == 0:               # tie-free: identical to the reference itself
-        got = res[0]
-        assert np.array_equal(got.rqs_clock, fx["clock"]) and np.array_equal(got._samples, fx["samples"])  # noqa: SLF001
-        assert (got.total_generated, got.total_completed, got.total_dropped) == (
-            int(fx["generated"]), int(fx["completed"]), int(fx["dropped"]))
-        stats = got.get_latency_stats()
-        keys = ("total_requests", "mean", "median", "std_dev", "p95", "p99", "min", "max")
-        assert [stats[k] for k in keys] == list(fx["latency_stats"])   # same numpy calls as the analyzer
-        assert got.get_throughput_series()[1] == list(fx["rps"])
+    _assert_scenario(res[1], ol.simulate(plan, seed + 1))
+    # ... and identical to what the unmodified reference produced (exact timestamp ties included)
+    got = res[0]
+    assert not got.flags & _abi.FLAG_TIME_TIE
+    assert np.array_equal(got.rqs_clock, fx["clock"]) and np.array_equal(got._samples, fx["samples"])  # noqa: SLF001
+    assert (got.total_generated, got.total_completed, got.total_dropped) == (
+        int(fx["generated"]), int(fx["completed"]), int(fx["dropped"]))
+    stats = got.get_latency_stats()
+    keys = ("total_requests", "mean", "median", "std_dev", "p95", "p99", "min", "max")
+    assert [stats[k] for k in keys] == list(fx["latency_stats"])   # same numpy calls as the analyzer
+    assert got.get_throughput_series()[1] == list(fx["rps"])
 
 
 # --------------------------------------------------------------------- batches
@@ -88,8 +89,8 @@ def test_lb2_batch_matches_oracle_everywhere_sampled():
     assert res.engine_stats.state_in_lds == 1 and res.engine_stats.waves == 4
     plan = lower(payload)
     for i in (0, 1, 63, 64, 127, 199):
-        _assert_scenario(res[i], ol.simulate(plan, int(seeds[i]), atomic=True))
-    want_counts = np.array([ol.simulate(plan, int(s), atomic=True, want_clock=False, want_samples=False).counts[:5] for s in seeds])
+        _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])))
+    want_counts = np.array([ol.simulate(plan, int(s), want_clock=False, want_samples=False).counts[:5] for s in seeds])
     assert np.array_equal(res.counts[:, :5].astype(np.uint64), want_counts)
 
 
@@ -111,7 +112,7 @@ def test_large_state_falls_back_to_hbm_and_still_matches():
     assert res.engine_stats.state_in_lds == 0
     plan = lower(payload)
     for i in (0, 33):
-        _assert_scenario(res[i], ol.simulate(plan, int(seeds[i]), atomic=True))
+        _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])))
     narrow = _runner(payload, seeds=seeds).run()            # few scenarios -> narrow waves -> fits LDS
     assert narrow.engine_stats.state_in_lds == 1 and narrow.engine_stats.lanes_per_wave < 64
     assert np.array_equal(narrow.counts, res.counts)
@@ -141,7 +142,7 @@ def test_parameter_sweep_columns():
     for i in (0, 17, 50, 95):
         plan = lower(payload)
         ol.apply_overrides(plan, {("gen_users_mean", 0): users[i], **{("edge_mean", e): lat[i] for e in range(6)}})
-        _assert_scenario(res[i], ol.simulate(plan, int(seeds[i]), atomic=True))
+        _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])))
     gen = res.counts[:, _abi.CNT_GENERATED].astype(np.float64)
     assert gen[users == 480.0].mean() > 30 * gen[users == 10.0].mean()
 
@@ -171,16 +172,52 @@ def test_fuzzed_payloads(case):
     res = _runner(payload, seeds=seeds).run()
     plan = lower(payload)
     for i in range(3):
-        _assert_scenario(res[i], ol.simulate(plan, int(seeds[i]), atomic=True))
+        _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])))
 
 
-def test_exact_tie_scenarios_match_engine_semantics_and_are_flagged():
+def test_shared_timestamps_follow_simpy_order():
+    """Instants shared by several timed events run through the kernel's SimPy-order path."""
     payload = overload(horizon=12)
     res = _runner(payload, seeds=[5]).run()
     plan = lower(payload)
-    _assert_scenario(res[0], ol.simulate(plan, 5, atomic=True))
-    assert res[0].flags & 32          # AF_FLAG_TIME_TIE: SimPy may interleave differently here
-    assert ol.simulate(plan, 5).ties > 0
+    want = ol.simulate(plan, 5)
+    assert want.ties > 0
+    _assert_scenario(res[0], want)
+    assert not res[0].flags & _abi.FLAG_TIME_TIE
+    ties = 0
+    for case in range(24):                               # one launch per topology, 8 seeds each
+        payload = tie_storm(random.Random(777000 + case), horizon=12)
+        seeds = np.arange(8, dtype=np.uint64) + 5 + case
+        res = _runner(payload, seeds=seeds, lanes_per_wave=[1, 4, 64][case % 3]).run()
+        plan = lower(payload)
+        for i in (0, 3, 7):
+            want = ol.simulate(plan, int(seeds[i]))
+            ties += want.ties
+            _assert_scenario(res[i], want)
+        assert not int(np.bitwise_or.reduce(res.flags)) & _abi.FLAG_TIME_TIE
+    assert ties > 3000
+
+
+def test_handover_between_kernel_variants_is_invisible():
+    """Lean kernel first + hand-over of the scenarios that meet a shared instant == SimPy-order
+    kernel from the start; the runner remembers that a payload produces such instants."""
+    payload = tie_storm(random.Random(777003), horizon=12)
+    seeds = np.arange(40, dtype=np.uint64) + 900
+    two_pass = _runner(payload, seeds=seeds, expect_shared_instants=False).run()
+    direct = _runner(payload, seeds=seeds, expect_shared_instants=True).run()
+    assert two_pass.engine_stats.shared_instant_scenarios > 0 and direct.engine_stats.shared_instant_scenarios == 0
+    assert np.array_equal(two_pass.counts, direct.counts)
+    for i in range(40):
+        assert np.array_equal(two_pass[i].rqs_clock, direct[i].rqs_clock)
+        assert np.array_equal(two_pass[i]._samples, direct[i]._samples)  # noqa: SLF001
+    plan = lower(payload)
+    for i in (0, 17, 39):
+        _assert_scenario(direct[i], ol.simulate(plan, int(seeds[i])))
+    auto1 = _runner(payload, seeds=seeds).run()           # None: lean first, remembered per payload
+    auto2 = _runner(payload, seeds=seeds).run()
+    assert auto2.engine_stats.shared_instant_scenarios == 0 and np.array_equal(auto1.counts, auto2.counts)
+    calm = _runner(lb_two_servers(horizon=20), seeds=seeds).run()
+    assert calm.engine_stats.shared_instant_scenarios == 0
 
 
 # ------------------------------------------------------------------ edge cases
@@ -190,7 +227,7 @@ def test_overflow_is_reported_and_auto_grow_recovers():
         _runner(payload, seeds=[1, 2], request_capacity=16, fifo_capacity=8, auto_grow=False).run()
     with pytest.warns(RuntimeWarning):
         res = _runner(payload, seeds=[1, 2], request_capacity=64, fifo_capacity=16).run()
-    _assert_scenario(res[1], ol.simulate(lower(payload), 2, atomic=True))
+    _assert_scenario(res[1], ol.simulate(lower(payload), 2))
 
 
 def test_single_run_is_a_drop_in_for_the_reference_call(tmp_path):
@@ -252,4 +289,4 @@ def test_full_horizon_properties_and_statistical_parity_with_simpy():
                            stats[i, 1:], rtol=1e-9, atol=0)
         sm = s.get_sampled_metrics()
         assert max(sm["ram_in_use"]["srv-1"]) <= 2048 and min(sm["edge_concurrent_connection"]["lb-srv1"]) >= 0
-        assert np.array_equal(clock, ol.simulate(lower(payload), int(res.seeds[i]), atomic=True).clock)
+        assert np.array_equal(clock, ol.simulate(lower(payload), int(res.seeds[i])).clock)

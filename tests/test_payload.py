@@ -167,7 +167,7 @@ def test_capacity_estimates_cover_observed_live_requests():
     for payload, seed in ((lb_two_servers(horizon=60), 1), (stress_mixed(30), 3)):
         plan = lower(payload)
         cap, fifo = estimate_capacities(plan)
-        live = int(ol.simulate(plan, seed, atomic=True).counts[_abi.CNT_MAX_LIVE])
+        live = int(ol.simulate(plan, seed).counts[_abi.CNT_MAX_LIVE])
         assert cap >= live and fifo >= 8 and (fifo & (fifo - 1)) == 0
     plan = lower(lb_two_servers(horizon=600))
     mean, std = plan.expected_arrivals()

@@ -14,7 +14,7 @@ import pytest
 from asyncflow_amd.plan import lower
 from oracle import oracle_lib as ol
 from oracle import ref_env
-from oracle.scenarios import overload, random_payload
+from oracle.scenarios import overload, random_payload, tie_storm
 
 pytestmark = [
     pytest.mark.reference,
@@ -46,6 +46,13 @@ def test_exact_timestamp_ties_follow_simpy_interleaving():
     res = ol.simulate(lower(payload), 5)
     assert res.ties > 0
     _same(payload, 5)
+
+
+@pytest.mark.parametrize("case", range(30))
+def test_tie_storms_match_reference(case):
+    """Payloads built so that thousands of timed events share an instant (grant bursts, integer
+    edge latencies incl. zero, ticks on timeline marks)."""
+    _same(tie_storm(random.Random(777000 + case), horizon=12), 5 + case)
 
 
 def test_reference_suite_passes_on_the_simpy_standin():
