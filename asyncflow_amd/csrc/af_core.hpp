@@ -1262,6 +1262,8 @@ struct Lane : LaneRegs {
         const uint32_t root_st = (uint32_t)M.ld(L.hb);
         // the root's children: an entry sharing the root's timestamp is always reachable through
         // equal keys, so the two children tell whether the instant is shared inside the heap
+        // (prefetching them in full for the sift-down that follows was measured: no gain, the
+        // kernel is issue bound at 2-3 waves per SIMD)
         const double t_c1 = u2d(M.ld(L.hk + 1u));
         const double t_c2 = u2d(M.ld(L.hk + 2u));
         // next event among {heap, arrival, tick, server marks, edge marks}; on equal
@@ -1274,13 +1276,14 @@ struct Lane : LaneRegs {
         if (t_emark <= t) { cls = 0u; t = t_emark; }
         if (!(t < P.total_time)) return false;  // the stop event is URGENT at T (pending top-ups are moot)
         now = t;
-        // Two or more timed events at this instant: SimPy interleaves their zero-time steps.
-        const uint32_t same = (t_heap == t ? 1u : 0u) + (t_gen == t ? 1u : 0u) + (t_tick == t ? 1u : 0u) +
-                              (t_smark == t ? 1u : 0u) + (t_emark == t ? 1u : 0u) +
-                              ((heap_n > 1u && t_c1 == t) ? 1u : 0u) + ((heap_n > 2u && t_c2 == t) ? 1u : 0u);
-        // (sampler ticks and timeline marks commute with each other: an instant shared only by
-        // those needs no care, the fixed class order above is as good as any)
-        if (__builtin_expect(same > 1u && (t_heap == t || t_gen == t), 0)) {
+        // Two or more timed events at this instant: SimPy interleaves their zero-time steps.  On equal
+        // times the selection above prefers the timers, so: a request event (cls 4) shares its instant
+        // iff a child of the root has the same key; an arrival (cls 3) iff the heap root has; a tick or
+        // timeline mark needs care iff a request event or an arrival shares its instant (ticks and
+        // marks commute with each other, the fixed class order above is as good as any).
+        const bool shared = cls == 4u ? ((heap_n > 1u && t_c1 == t) || (heap_n > 2u && t_c2 == t))
+                                      : (t_heap == t || (cls < 3u && t_gen == t));
+        if (__builtin_expect(shared, 0)) {
             if constexpr (kFaithful) {
                 micro_mode();
                 topup_end_arrivals(tu_arr);
