@@ -10,12 +10,15 @@ from .payload import load_yaml, normalize_payload
 from .plan import DevicePlan, lower
 from .results import BatchedResults, ScenarioResults
 from .runner import SimulationRunner
+from .sweep import Sweep, expand_grid
 
 __all__ = [
     "BatchedResults",
     "DevicePlan",
     "ScenarioResults",
     "SimulationRunner",
+    "Sweep",
+    "expand_grid",
     "load_yaml",
     "lower",
     "normalize_payload",

@@ -303,6 +303,61 @@ class BatchedResults:
             out["series_mean"], out["series_max"] = smean, smax
         return out
 
+    def save_summary(self, path: str, *, hist_bins: int = 256, hist_max: float | None = None,
+                     series: bool = True) -> dict[str, np.ndarray]:
+        """Columnar dump of the sweep: one row per scenario with its seed, parameter
+        columns, counts, flags, the 8 latency statistics, the 1-s RPS series, a latency histogram
+        and the mean / maximum of every sampled series.  ``.npz`` (numpy) or ``.parquet`` (pyarrow;
+        array-valued columns become list columns).  Returns the columns."""
+        summ_kwargs: dict[str, Any] = {"rps": True, "series": series and self._samples_t is not None}
+        stats0 = None
+        if hist_bins:
+            if hist_max is None:      # 1.25 x the largest latency of the sweep
+                stats0 = self.summary(rps=False)["stats"].cpu().numpy()
+                mx = np.nanmax(stats0[:, 7]) if np.isfinite(stats0[:, 7]).any() else 1.0
+                hist_max = float(mx) * 1.25 or 1.0
+            summ_kwargs.update(hist_bins=hist_bins, hist_max=hist_max)
+        summ = self.summary(**summ_kwargs)
+        cols: dict[str, np.ndarray] = {"seed": np.asarray(self.seeds, dtype=np.uint64)}
+        for k, v in self.overrides.items():
+            cols[f"param:{k}"] = np.asarray(v, dtype=np.float64)
+        for name, slot in (("generated", _abi.CNT_GENERATED), ("completed", _abi.CNT_COMPLETED),
+                           ("dropped", _abi.CNT_DROPPED), ("request_events", _abi.CNT_EVENTS),
+                           ("ticks", _abi.CNT_TICKS), ("flags", _abi.CNT_FLAGS), ("max_live", _abi.CNT_MAX_LIVE)):
+            cols[name] = self.counts[:, slot].copy()
+        stats = summ["stats"].cpu().numpy()
+        for j, k in enumerate(LATENCY_KEYS):
+            cols[f"latency:{k}"] = stats[:, j].copy()
+        if "rps" in summ:
+            cols["rps"] = summ["rps"].cpu().numpy()
+        if "hist" in summ:
+            cols["latency_hist"] = summ["hist"].cpu().numpy().view(np.uint32)
+            cols["latency_hist_edges"] = np.linspace(0.0, float(hist_max), hist_bins + 1)
+        if "series_mean" in summ:
+            cols["series_mean"] = summ["series_mean"].cpu().numpy()
+            cols["series_max"] = summ["series_max"].cpu().numpy().view(np.uint32)
+            cols["series_names"] = np.asarray(self.series_names())
+        path = str(path)
+        if path.endswith(".parquet"):
+            import pyarrow as pa
+            import pyarrow.parquet as pq
+
+            n = len(self)
+            table = {k: (pa.array(list(v)) if v.ndim == 2 and v.shape[0] == n else pa.array(v))
+                     for k, v in cols.items() if v.shape[:1] == (n,)}
+            meta = {k: ",".join(map(str, v.tolist())) for k, v in cols.items() if v.shape[:1] != (n,)}
+            pq.write_table(pa.table(table).replace_schema_metadata(meta), path)
+        else:
+            np.savez_compressed(path, **cols)
+        return cols
+
+    def series_names(self) -> list[str]:
+        """Names of the sampled series in device order: edges, then ready/io/ram per server."""
+        names = [f"{e}:edge_concurrent_connection" for e in self.plan.edge_ids]
+        for sid in self.plan.server_ids:
+            names += [f"{sid}:ready_queue_len", f"{sid}:event_loop_io_sleep", f"{sid}:ram_in_use"]
+        return names
+
     def aggregate(self, level: float = 0.95) -> dict[str, Any]:
         """Monte-Carlo aggregation over the scenarios of the sweep (the reference's roadmap
         item, ROADMAP.md:23-29): mean, standard deviation and normal-approximation confidence

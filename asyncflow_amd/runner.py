@@ -79,6 +79,9 @@ def resolve_sweep(plan: DevicePlan, sweep: Mapping[str, Any] | None, n: int) -> 
             if idx < 0:
                 msg = f"sweep key {key!r}: not a CPU or I/O step"
                 raise ValueError(msg)
+            if np.any(col <= 0):
+                msg = f"sweep key {key!r}: step times must be positive"   # PositiveFloat in the reference schema
+                raise ValueError(msg)
             out.append((_abi.PARAM_CODES["step_time"], idx, col, key))
         else:
             msg = f"unsupported sweep key {key!r}"

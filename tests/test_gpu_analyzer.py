@@ -143,3 +143,29 @@ def test_summary_of_a_simulated_batch_matches_the_oracle(payload_fn):
     assert agg["n"] == 40 and agg["ci_halfwidth"]["p95"] > 0.0
     assert abs(agg["mean"]["p95"] - stats[:, 4].mean()) < 1e-15
     assert agg["rps_mean"].shape == (T,)
+
+
+def test_grid_sweep_and_on_disk_summary(tmp_path):
+    from asyncflow_amd import SimulationRunner, expand_grid
+
+    users = "rqs_input.avg_active_users.mean"
+    rtt = "topology_graph.edges[*].latency.mean"
+    sw = expand_grid({users: [20, 200, 60], rtt: [0.001, 0.01]}, replicas=3, seed_base=7000, order_by_load=users)
+    payload = lb_two_servers(horizon=20)
+    res = SimulationRunner(simulation_input=payload, **sw.runner_kwargs()).run()
+    cols = res.save_summary(str(tmp_path / "sweep.npz"))
+    z = np.load(tmp_path / "sweep.npz")
+    assert z["seed"].tolist() == sw.seeds.tolist() and np.array_equal(z[f"param:{users}"], sw.columns[users])
+    assert z["rps"].shape == (18, 20) and z["latency_hist"].shape == (18, 256)
+    assert np.array_equal(z["latency_hist"].sum(axis=1), z["completed"])
+    assert list(z["series_names"])[:1] == [f"{res.plan.edge_ids[0]}:edge_concurrent_connection"]
+    p95 = sw.by_point(cols["latency:p95"])                     # [users, rtt, replica]
+    assert p95.shape == (3, 2, 3) and (p95[:, 1].mean() > p95[:, 0].mean())     # 10x the per-hop latency
+    for i in (0, 9, 17):
+        _check_stats(np.array([cols[f"latency:{k}"][i] for k in ao.LATENCY_KEYS]), ao.latency_stats(res[i].rqs_clock))
+    res.save_summary(str(tmp_path / "sweep.parquet"))
+    import pyarrow.parquet as pq
+
+    t = pq.read_table(tmp_path / "sweep.parquet")
+    assert t.num_rows == 18 and t.column("latency:p95").to_pylist() == cols["latency:p95"].tolist()
+    assert len(t.column("rps")[0].as_py()) == 20
