@@ -152,7 +152,7 @@ AF_HD Layout make_layout(uint32_t cap, uint32_t fcap, uint32_t n_edges, uint32_t
     uint32_t tc = 16u;
     while (tc < 2u * cap + 8u) tc <<= 1;
     L.tcap = tc;
-    L.tie_words = 4u * tc + (2u + n_servers + 63u) / 64u;
+    L.tie_words = 4u * tc + (2u + n_servers + 63u) / 64u + 17u;  // + Lane::PARK_WORDS at the end
     return L;
 }
 AF_HD uint64_t layout_bytes_per_lane(const Layout& L) { return 8ull * L.n_words; }
@@ -267,6 +267,9 @@ struct LaneRegs {
     uint32_t heap_n, seq, live, max_live, lb_n, emark_i, smark_i;
     uint32_t n_gen, n_comp, n_drop, n_events, n_ticks, n_marks, flags;
 };
+
+template <bool kFaithful> struct RoundType { using type = uint32_t; };
+template <> struct RoundType<false> { using type = bool; };
 
 // kFaithful = false builds the lean variant used for the first pass of a sweep: it has no
 // SimPy-order path; a scenario that meets a shared instant stops with FLAG_SHARED_INSTANT and
@@ -1245,7 +1248,13 @@ struct Lane : LaneRegs {
     // The stage order is the order SimPy creates the corresponding Timeouts in
     // (server.py:235-276): own I/O timer before the CPU waiter's; on endpoint end
     // the CPU waiter's timer, then transport(), then the RAM waiters.
-    AF_CORE bool round() {
+    // Returns ROUND_STOP once the scenario reached the horizon, ROUND_SHARED when the next instant is
+    // shared by several timed events (nothing has been processed; the caller runs shared_instant()
+    // OUTSIDE its hot loop, so that the cold path's registers do not weigh on the loop).
+    // (the lean variant keeps a plain bool: a lane mask in scalar registers instead of a vector value)
+    using RoundT = typename RoundType<kFaithful>::type;
+    static constexpr RoundT ROUND_STOP = RoundT(0), ROUND_MORE = RoundT(1), ROUND_SHARED = RoundT(kFaithful ? 2 : 1);
+    AF_CORE RoundT round() {
         // top up the rings consumed from in the previous round: loads are issued now and
         // stored at the end of this round, so their HBM latency hides behind the round
         const bool want_arr = (fl & F_DIRTY_ARR) != 0u;
@@ -1274,7 +1283,7 @@ struct Lane : LaneRegs {
         if (t_tick <= t) { cls = 2u; t = t_tick; }
         if (t_smark <= t) { cls = 1u; t = t_smark; }
         if (t_emark <= t) { cls = 0u; t = t_emark; }
-        if (!(t < P.total_time)) return false;  // the stop event is URGENT at T (pending top-ups are moot)
+        if (!(t < P.total_time)) return ROUND_STOP;  // the stop event is URGENT at T (pending top-ups are moot)
         now = t;
         // Two or more timed events at this instant: SimPy interleaves their zero-time steps.  On equal
         // times the selection above prefers the timers, so: a request event (cls 4) shares its instant
@@ -1285,17 +1294,17 @@ struct Lane : LaneRegs {
                                       : (t_heap == t || (cls < 3u && t_gen == t));
         if (__builtin_expect(shared, 0)) {
             if constexpr (kFaithful) {
-                micro_mode();
-                topup_end_arrivals(tu_arr);
-                topup_end_edge(tu_edge);
-                return true;
+                // the top-ups this round had started are simply asked for again in the next one
+                if (want_arr) fl |= F_DIRTY_ARR;
+                if (want_edge) dirty_edge = (int32_t)tu_e;
+                return ROUND_SHARED;
             } else {
                 // Simulated again, from t = 0, by the variant that has the SimPy-order path.  (Handing
                 // the state over instead was measured: keeping it restorable costs the lean kernel
                 // 3.5 % on every sweep, and an engine that saw one such scenario starts its later
                 // sweeps with the other variant anyway.)
                 flags |= FLAG_SHARED_INSTANT;
-                return false;
+                return ROUND_STOP;
             }
         }
 
@@ -1363,7 +1372,49 @@ struct Lane : LaneRegs {
         }
         topup_end_arrivals(tu_arr);
         topup_end_edge(tu_edge);
-        return true;
+        return ROUND_MORE;
+    }
+    // the instant `now` that round() reported as shared, in SimPy's event order
+    AF_CORE void shared_instant() { micro_mode(); }
+
+    // All scalars of the lane through memory (volatile: the compiler must not forward the stored
+    // values to the loads).  The kernel does this around shared_instant() for every lane of the
+    // wave, so that NO value is live across the cold path and the hot loop keeps its own register
+    // allocation (engine.hip: run_lanes).
+    enum : uint32_t { PARK_WORDS = 17 };
+    AF_CORE void park_regs(volatile uint64_t* dst) const {
+        dst[0] = d2u(now); dst[1] = d2u(t_gen); dst[2] = d2u(t_tick); dst[3] = d2u(t_emark); dst[4] = d2u(t_smark);
+        dst[5] = lb_list;
+        dst[6] = q_gen | ((uint64_t)q_tick << 32);
+        dst[7] = q_emark | ((uint64_t)q_smark << 32);
+        dst[8] = arr_ahead | ((uint64_t)(uint32_t)dirty_edge << 32);
+        dst[9] = fl | ((uint64_t)heap_n << 32);
+        dst[10] = seq | ((uint64_t)live << 32);
+        dst[11] = max_live | ((uint64_t)lb_n << 32);
+        dst[12] = emark_i | ((uint64_t)smark_i << 32);
+        dst[13] = n_gen | ((uint64_t)n_comp << 32);
+        dst[14] = n_drop | ((uint64_t)n_events << 32);
+        dst[15] = n_ticks | ((uint64_t)n_marks << 32);
+        dst[16] = flags;
+    }
+    AF_CORE void unpark_regs(const volatile uint64_t* src) {
+        now = u2d(src[0]); t_gen = u2d(src[1]); t_tick = u2d(src[2]); t_emark = u2d(src[3]); t_smark = u2d(src[4]);
+        lb_list = src[5];
+        const uint64_t w6 = src[6], w7 = src[7], w8 = src[8], w9 = src[9], w10 = src[10], w11 = src[11], w12 = src[12],
+                       w13 = src[13], w14 = src[14], w15 = src[15];
+        q_gen = (uint32_t)w6; q_tick = (uint32_t)(w6 >> 32);
+        q_emark = (uint32_t)w7; q_smark = (uint32_t)(w7 >> 32);
+        arr_ahead = (uint32_t)w8; dirty_edge = (int32_t)(uint32_t)(w8 >> 32);
+        fl = (uint32_t)w9; heap_n = (uint32_t)(w9 >> 32);
+        seq = (uint32_t)w10; live = (uint32_t)(w10 >> 32);
+        max_live = (uint32_t)w11; lb_n = (uint32_t)(w11 >> 32);
+        emark_i = (uint32_t)w12; smark_i = (uint32_t)(w12 >> 32);
+        n_gen = (uint32_t)w13; n_comp = (uint32_t)(w13 >> 32);
+        n_drop = (uint32_t)w14; n_events = (uint32_t)(w14 >> 32);
+        n_ticks = (uint32_t)w15; n_marks = (uint32_t)(w15 >> 32);
+        flags = (uint32_t)src[16];
+        pend_count = 0u;
+        fu_ram_sv = -1;
     }
 
     AF_CORE void write_counts() const {

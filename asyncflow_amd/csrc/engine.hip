@@ -86,12 +86,47 @@ __device__ __forceinline__ const LDS_AS uint64_t* lds_words(unsigned char* smem,
     return (const LDS_AS uint64_t*)smem + word_off;
 }
 
+// The wave's main loop.  Lanes free-run round().  In the variant that has the SimPy-order path, a
+// lane that reports an instant shared by several timed events makes the wave leave the inner loop;
+// that lane replays the instant in SimPy's event order and the wave re-enters.  The cold path sits
+// OUTSIDE the inner loop and every lane's scalars go through memory around it, so that as little as
+// possible stays live across it (measured on the 10k LB-2 sweep with the path never taken: 3 472 ms
+// with the path inside the loop, 2 755 ms outside, 2 690 ms with the scalars parked; the lean
+// variant, which has no such path at all, takes 2 085 ms -- the rest is register pressure the
+// compiler still lets leak into the loop).
+template <class LaneT, bool kFaithful>
+__device__ __forceinline__ void run_lanes(LaneT& S, bool active) {
+    if constexpr (!kFaithful) {  // lean variant: round() never reports ROUND_SHARED
+        bool run = active;
+        while (__any(run)) {
+            if (run) run = S.round();
+        }
+    } else {
+        uint32_t st = active ? LaneT::ROUND_MORE : LaneT::ROUND_STOP;
+        for (;;) {
+            do {
+                if (st == LaneT::ROUND_MORE) st = S.round();
+            } while (!__any(st == LaneT::ROUND_SHARED) && __any(st == LaneT::ROUND_MORE));
+            if (!__any(st == LaneT::ROUND_SHARED)) break;
+            volatile uint64_t* slot = S.D.tie + (S.L.tie_words - LaneT::PARK_WORDS);
+            if (active) S.park_regs(slot);
+            if (st == LaneT::ROUND_SHARED) {
+                S.unpark_regs(slot);
+                S.shared_instant();
+                S.park_regs(slot);
+                st = LaneT::ROUND_MORE;
+            }
+            if (active) S.unpark_regs(slot);
+        }
+    }
+}
+
 // (Measured on MI355X, profiles/r01: forcing more than the natural 3 waves/SIMD with a
 // launch bound spills registers and is 1.5-3x slower; the kernel keeps its ~144 VGPRs.)
 //
 // kFaithful = false is the lean first pass: a scenario in which two timed events share an instant
 // stops there (af_core.hpp) and is simulated again by the kFaithful = true variant, whose extra
-// SimPy-order path costs ~20 % of kernel time through register pressure alone (measured).
+// SimPy-order path costs ~30 % of kernel time through register pressure alone (measured).
 template <bool kLdsState, bool kFaithful, int KLOG>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) af_des_kernel(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -156,11 +191,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) af
         MemLds<KLOG> M;
         M.w = (LDS_AS uint64_t*)(smem + a.blob_bytes) + (lane & (kl - 1u));
         af::Lane<MemLds<KLOG>, kFaithful> S(P, a.L, M, O, D, seed);
-        bool run = active;
         if (active) S.init(a.ovr_param, a.ovr_index, a.n_ovr, ovr);
-        while (__any(run)) {
-            if (run) run = S.round();
-        }
+        run_lanes<decltype(S), kFaithful>(S, active);
         if (active) S.write_counts();
         if (!kFaithful && active && (S.flags & af::FLAG_SHARED_INSTANT)) atomicAdd(a.n_shared, 1u);
     } else {
@@ -168,11 +200,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) af
         MemGlobal<KLOG> M;
         M.w = reinterpret_cast<uint64_t*>(base) + (lane & (kl - 1u));
         af::Lane<MemGlobal<KLOG>, kFaithful> S(P, a.L, M, O, D, seed);
-        bool run = active;
         if (active) S.init(a.ovr_param, a.ovr_index, a.n_ovr, ovr);
-        while (__any(run)) {
-            if (run) run = S.round();
-        }
+        run_lanes<decltype(S), kFaithful>(S, active);
         if (active) S.write_counts();
         if (!kFaithful && active && (S.flags & af::FLAG_SHARED_INSTANT)) atomicAdd(a.n_shared, 1u);
     }

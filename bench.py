@@ -121,6 +121,8 @@ def main() -> int:
     ap.add_argument("--no-series", action="store_true", help="do not store the sampled series")
     ap.add_argument("--lanes", type=int, default=0, help="scenario lanes per wave (0 = engine default)")
     ap.add_argument("--global-state", action="store_true", help="keep per-scenario state in HBM")
+    ap.add_argument("--expect-shared-instants", action="store_true",
+                    help="start with the kernel variant that has the SimPy-order path for shared instants")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
                     help="BASELINE.json config: 2 = 10k LB-2 seed replicas (the metric's config, default); "
                          "3 = users x RTT 100x100 grid; 4 = grid + injected spikes/outages; 5 = 8-server fan-out")
@@ -192,7 +194,7 @@ def main() -> int:
     clock_cap = plan.clock_capacity(users_max)
     ticks = max(plan.tick_count, 1)
     eng = Engine(plan, local_rank, request_capacity=cap, fifo_capacity=fifo, lanes_per_wave=args.lanes,
-                 force_global_state=args.global_state)
+                 force_global_state=args.global_state, expect_shared_instants=args.expect_shared_instants)
     counts = torch.zeros((n, _abi.CNT_SLOTS), dtype=torch.int32, device=dev)
     clock = torch.empty((n, clock_cap, 2), dtype=torch.float64, device=dev)
     samples = None if args.no_series else torch.zeros((n, ticks, plan.series_pitch), dtype=torch.int32, device=dev)

@@ -95,7 +95,7 @@ extern "C" int hc_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ovr, co
     if (g_two_pass) {  // what af_engine_run does: lean variant first, SimPy-order variant on demand
         af::Lane<MemHost, false> lean(V, L, MemHost{w.data()}, O, D, seed);
         lean.init(ovr_param, idx.data(), n_ovr, [&](uint32_t k) { return ovr_value[k]; });
-        while (lean.round()) {
+        while (lean.round() != lean.ROUND_STOP) {
         }
         lean.write_counts();
         g_reruns += (lean.flags & af::FLAG_SHARED_INSTANT) ? 1 : 0;
@@ -104,7 +104,10 @@ extern "C" int hc_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ovr, co
     }
     af::Lane<MemHost, true> lane(V, L, MemHost{w.data()}, O, D, seed);
     lane.init(ovr_param, idx.data(), n_ovr, [&](uint32_t k) { return ovr_value[k]; });
-    while (lane.round()) {
+    for (;;) {
+        const auto st = lane.round();
+        if (st == lane.ROUND_STOP) break;
+        if (st == lane.ROUND_SHARED) lane.shared_instant();
     }
     lane.write_counts();
     return 0;
