@@ -127,8 +127,11 @@ __device__ __forceinline__ void run_lanes(LaneT& S, bool active) {
 // kFaithful = false is the lean first pass: a scenario in which two timed events share an instant
 // stops there (af_core.hpp) and is simulated again by the kFaithful = true variant, whose extra
 // SimPy-order path costs ~30 % of kernel time through register pressure alone (measured).
-template <bool kLdsState, bool kFaithful, int KLOG>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) af_des_kernel(const KArgs a) {
+//
+// WPE = register budget as waves per SIMD: 3 (<= 168 VGPRs; the lean variant needs 134) or, for the
+// SimPy-order variant only, 2 (it wants ~210 VGPRs: no spills, but a third fewer resident waves).
+template <bool kLdsState, bool kFaithful, int KLOG, int WPE>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) af_des_kernel(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lane = threadIdx.x;
 
@@ -303,22 +306,23 @@ uint32_t pow2_at_least(uint32_t v) {
 
 }  // namespace
 
-// kernel variant table: [LDS state][SimPy-order path][log2 lanes per wave]
-template <bool kLds, bool kFaithful>
+// kernel variant table: [LDS state][SimPy-order path][log2 lanes per wave][waves per SIMD]
+template <bool kLds, bool kFaithful, int WPE>
 const void* des_kernel_klog(uint32_t klog) {
     switch (klog) {
-        case 0: return reinterpret_cast<const void*>(af_des_kernel<kLds, kFaithful, 0>);
-        case 1: return reinterpret_cast<const void*>(af_des_kernel<kLds, kFaithful, 1>);
-        case 2: return reinterpret_cast<const void*>(af_des_kernel<kLds, kFaithful, 2>);
-        case 3: return reinterpret_cast<const void*>(af_des_kernel<kLds, kFaithful, 3>);
-        case 4: return reinterpret_cast<const void*>(af_des_kernel<kLds, kFaithful, 4>);
-        case 5: return reinterpret_cast<const void*>(af_des_kernel<kLds, kFaithful, 5>);
-        default: return reinterpret_cast<const void*>(af_des_kernel<kLds, kFaithful, 6>);
+        case 0: return reinterpret_cast<const void*>(af_des_kernel<kLds, kFaithful, 0, WPE>);
+        case 1: return reinterpret_cast<const void*>(af_des_kernel<kLds, kFaithful, 1, WPE>);
+        case 2: return reinterpret_cast<const void*>(af_des_kernel<kLds, kFaithful, 2, WPE>);
+        case 3: return reinterpret_cast<const void*>(af_des_kernel<kLds, kFaithful, 3, WPE>);
+        case 4: return reinterpret_cast<const void*>(af_des_kernel<kLds, kFaithful, 4, WPE>);
+        case 5: return reinterpret_cast<const void*>(af_des_kernel<kLds, kFaithful, 5, WPE>);
+        default: return reinterpret_cast<const void*>(af_des_kernel<kLds, kFaithful, 6, WPE>);
     }
 }
-const void* des_kernel_for(bool lds, bool faithful, uint32_t klog) {
-    return lds ? (faithful ? des_kernel_klog<true, true>(klog) : des_kernel_klog<true, false>(klog))
-               : (faithful ? des_kernel_klog<false, true>(klog) : des_kernel_klog<false, false>(klog));
+const void* des_kernel_for(bool lds, bool faithful, uint32_t klog, bool roomy) {
+    if (!faithful) return lds ? des_kernel_klog<true, false, 3>(klog) : des_kernel_klog<false, false, 3>(klog);
+    if (roomy) return lds ? des_kernel_klog<true, true, 2>(klog) : des_kernel_klog<false, true, 2>(klog);
+    return lds ? des_kernel_klog<true, true, 3>(klog) : des_kernel_klog<false, true, 3>(klog);
 }
 
 struct af_engine {
@@ -557,11 +561,14 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     const size_t draw_bytes_per_scen = (size_t)(1u + a.n_edges) * n_draw * sizeof(double);
     size_t mem_free = 0, mem_total = 0;
     HIP_TRY(hipMemGetInfo(&mem_free, &mem_total));
-    size_t budget = e->draw_memory_bytes ? e->draw_memory_bytes : (size_t)64 << 30;
-    if (budget > mem_free / 2 + e->draws_cap) budget = mem_free / 2 + e->draws_cap;
+    // (one launch per chunk, and every launch ends with a latency-bound tail: chunks are a last resort)
+    size_t budget = e->draw_memory_bytes ? e->draw_memory_bytes : (size_t)160 << 30;
+    const size_t avail = mem_free + e->draws_cap;
+    if (budget > avail / 10u * 6u) budget = avail / 10u * 6u;
     uint32_t chunk = (uint32_t)(budget / draw_bytes_per_scen < 65535u ? budget / draw_bytes_per_scen : 65535u);
     if (chunk == 0) return fail(AF_ERR_CAPACITY, "draw_capacity too large for the device memory budget");
     if (chunk > n) chunk = n;
+    chunk = (n + (n + chunk - 1u) / chunk - 1u) / ((n + chunk - 1u) / chunk);  // equal chunks: no short, latency-bound tail launch
     const size_t draw_bytes = draw_bytes_per_scen * chunk;
     if (draw_bytes > e->draws_cap) {
         if (e->d_draws) HIP_TRY(hipFree(e->d_draws));
@@ -673,7 +680,17 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
                 }
                 a.state = e->d_state;
             }
-            const void* fn = des_kernel_for(lds_state, faithful, klog);
+            // SimPy-order variant: when the waves do not all fit at 3 per SIMD anyway, the build with
+            // the larger register budget (2 per SIMD, no spills) is the faster one (measured: 6 400
+            // grid points 6.2 s -> 5.5 s; 2 500 waves that do fit: 2.7 s vs 4.3 s).  Sweeps over the load
+            // (scenario lengths differ by orders of magnitude) do not run as lock-step batches: there the
+            // per-wave speed decides and the roomy build wins even when everything would fit.
+            const bool hetero = (mask & ((1u << AF_PARAM_GEN_USERS_MEAN) | (1u << AF_PARAM_GEN_RPM_MEAN))) != 0u;
+            const bool roomy = faithful && (waves > 3072u || hetero);
+            const void* fn = des_kernel_for(lds_state, faithful, klog, roomy);
+            if (std::getenv("AF_DEBUG"))
+                std::fprintf(stderr, "[af] launch: %u scenarios, %u waves x %u lanes, %s state, %s%s\n", count, waves, kl,
+                             lds_state ? "LDS" : "HBM", faithful ? "SimPy-order" : "lean", roomy ? " (2 waves/SIMD build)" : "");
             if (lds_state) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
             void* kargs[] = {&a};
             HIP_TRY(hipLaunchKernel(fn, dim3(waves), dim3(kWave), kargs, lds_bytes, e->stream));

@@ -218,7 +218,7 @@ typedef struct af_engine_options {
     uint32_t lanes_per_wave;    /* scenarios per wavefront: power of two <= 64, 0 = auto
                                    (few scenarios are spread over many narrow waves)    */
     uint32_t draw_memory_mb;    /* HBM budget for the pre-generated draws of one chunk of the
-                                   sweep, MiB (0 = min(64 GiB, half of the free memory));
+                                   sweep, MiB (0 = min(160 GiB, 60 % of the free memory));
                                    larger sweeps run as several chunks                   */
     uint32_t expect_shared_instants; /* 1 = start with the kernel variant that replays SimPy's
                                    event order at instants shared by several timed events
