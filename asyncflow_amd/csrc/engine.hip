@@ -217,32 +217,84 @@ __device__ __forceinline__ double ovr_or(const KArgs& a, uint32_t param, uint32_
     return dflt;
 }
 
-// Stream 0: one thread per scenario walks the (sequential) windowed arrival sampler and
-// stores the absolute arrival times: t_k = t_{k-1} + gap_k (env.now + gap, rqs_generator.py:104).
+// Stream 0: the windowed arrival sampler (af::gen_next_gap is its sequential statement: samplers/
+// poisson_poisson.py:51-82, gaussian_poisson.py:63-94) and the absolute arrival times
+// t_k = t_{k-1} + gap_k (env.now + gap, rqs_generator.py:104).  One WAVE per scenario: the expensive
+// part of a gap (Philox block, log, division) is evaluated for 64 consecutive draw indices at once
+// -- a draw is a pure function of its index -- and the cheap, order-dependent part (the running
+// sums, the window / horizon tests) is scanned in draw order, with the same f64 additions in the
+// same order as the sequential sampler.  A gap that crosses the window end discards the rest of the
+// batch (the next index is the new window's user draw).
 __global__ void __launch_bounds__(64) af_pregen_arrivals(const KArgs a) {
-    const uint32_t scen = blockIdx.x * blockDim.x + threadIdx.x;
-    if (scen >= a.n_scen) return;
+    const uint32_t scen = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
     const uint64_t seed = a.seeds[scen];
     const double users_mean = ovr_or(a, af::PARAM_GEN_USERS_MEAN, 0u, scen, a.gen_users_mean);
     const double users_sigma = ovr_or(a, af::PARAM_GEN_USERS_SIGMA, 0u, scen, a.gen_users_sigma);
     const double rpm = ovr_or(a, af::PARAM_GEN_RPM_MEAN, 0u, scen, a.gen_rpm_mean);
-    af::GenState g;
+    const double rps_per_user = rpm / 60.0;
+    const double T = a.total_time;
     double* out = a.draws + (size_t)scen * (1u + a.n_edges) * a.n_draw;  // stream 0 of this scenario
-    double t = 0.0;
-    uint32_t k = 0;
-    uint32_t flags = 0;
-    for (; k < a.n_draw; ++k) {
-        const double gap = af::gen_next_gap(g, seed, a.gen_users_dist, users_mean, users_sigma, rpm, a.gen_window_s,
-                                            a.total_time);
-        if (gap < 0.0) break;
-        t = t + gap;
-        out[k] = t;
+    double g_now = 0.0, g_wend = 0.0, lam = 0.0, t = 0.0;  // identical in every lane
+    uint32_t draws = 0u, k = 0u, flags = 0u;
+    bool done = false;
+    while (!done && g_now < T) {
+        if (g_now >= g_wend) {  // new window: the number of active users
+            g_wend = g_now + a.gen_window_s;
+            const uint32_t idx = draws++;
+            double users;
+            if (a.gen_users_dist == af::DIST_NORMAL) {
+                const double v = users_mean + users_sigma * af::af_norminv(af::uniform_j(seed, af::STREAM_GENERATOR, idx, 0u));
+                users = v > 0.0 ? v : 0.0;
+            } else {
+                users = (double)af::af_poisson(users_mean, seed, af::STREAM_GENERATOR, idx, 0u);
+            }
+            lam = users * rps_per_user;
+        }
+        if (lam <= 0.0) {
+            g_now = g_wend;
+            continue;
+        }
+        const af::U4 r = af::draw_block(seed, af::STREAM_GENERATOR, draws + lane, 0u);
+        double u = af::u53(r.x, r.y);
+        if (u < 1e-15) u = 1e-15;
+        const double dt = -af::af_log(1.0 - u) / lam;
+        double my_t = 0.0;
+        uint32_t my_k = 0xFFFFFFFFu, used = 0u;
+        const uint64_t dt_bits = af::d2u(dt);
+#pragma unroll 8
+        for (uint32_t j = 0u; j < 64u; ++j) {
+            // lane j's gap, broadcast through scalar registers (no LDS round trip in the dependent chain)
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)dt_bits, (int)j);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(dt_bits >> 32), (int)j);
+            const double dj = af::u2d(((uint64_t)hi << 32) | lo);
+            used = j + 1u;
+            if (g_now + dj > T) {  // the sampler is exhausted
+                done = true;
+                break;
+            }
+            if (g_now + dj >= g_wend) {  // crosses the window end: discarded, on to the next window
+                g_now = g_wend;
+                break;
+            }
+            g_now += dj;
+            if (k == a.n_draw) {  // one more arrival than the array holds
+                flags = AF_FLAG_DRAW_OVERFLOW;
+                done = true;
+                break;
+            }
+            t = t + dj;
+            if (lane == j) {
+                my_t = t;
+                my_k = k;
+            }
+            k += 1u;
+        }
+        if (my_k != 0xFFFFFFFFu) out[my_k] = my_t;  // one coalesced store of the batch's arrivals
+        draws += used;
     }
-    if (k == a.n_draw &&
-        af::gen_next_gap(g, seed, a.gen_users_dist, users_mean, users_sigma, rpm, a.gen_window_s, a.total_time) >= 0.0)
-        flags = AF_FLAG_DRAW_OVERFLOW;
-    for (; k < a.n_draw; ++k) out[k] = af::AF_INF;
-    a.pre_flags[scen] = flags;
+    for (uint32_t i = k + lane; i < a.n_draw; i += 64u) out[i] = af::AF_INF;
+    if (lane == 0u) a.pre_flags[scen] = flags;
 }
 
 // Streams 1 + e: block (x, scenario, edge) draws 256 consecutive messages (coalesced stores).
@@ -614,7 +666,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
 
         // pre-generate every random draw of the chunk (HBM)
         HIP_TRY(hipEventRecord(e->ev2, e->stream));
-        hipLaunchKernelGGL(af_pregen_arrivals, dim3((nc + 63u) / 64u), dim3(64), 0, e->stream, a);
+        hipLaunchKernelGGL(af_pregen_arrivals, dim3(nc), dim3(64), 0, e->stream, a);
         hipLaunchKernelGGL(af_pregen_edges, dim3((n_draw + 255u) / 256u, nc, a.n_edges), dim3(256), 0, e->stream, a);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(e->ev3, e->stream));

@@ -175,6 +175,23 @@ def test_fuzzed_payloads(case):
         _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])))
 
 
+def test_fuzz_sweep_of_topologies_all_scenarios_checked():
+    """60 random topologies x 5 seeds, every scenario compared with the oracle (all distributions,
+    multi-core servers, RAM queues, LB algorithms, spikes and outages)."""
+    checked = shared = 0
+    for case in range(60):
+        payload = random_payload(random.Random(31000 + case), horizon=6)
+        seeds = np.arange(5, dtype=np.uint64) + 17 * case
+        res = _runner(payload, seeds=seeds, lanes_per_wave=[0, 1, 2, 8][case % 4]).run()
+        plan = lower(payload)
+        shared += int(res.engine_stats.shared_instant_scenarios)
+        for i in range(5):
+            _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])))
+            checked += 1
+        assert not int(np.bitwise_or.reduce(res.flags)) & _abi.FLAG_TIME_TIE
+    assert checked == 300 and shared > 0
+
+
 def test_shared_timestamps_follow_simpy_order():
     """Instants shared by several timed events run through the kernel's SimPy-order path."""
     payload = overload(horizon=12)
