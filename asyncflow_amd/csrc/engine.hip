@@ -1,18 +1,24 @@
-// engine.hip -- MI355X (gfx950) batched discrete-event engine: kernel + C ABI.
+// engine.hip -- MI355X (gfx950) batched discrete-event engine: kernels + C ABI.
 //
-// One scenario per lane, one wavefront (64 scenarios) per workgroup, one
-// workgroup per CU-resident LDS allocation.  Each wave free-runs its 64
-// scenarios through af::Lane<Mem>::round() (af_core.hpp) until every lane has
-// reached the horizon (`__any` wave vote); there is no inter-wave communication.
+// Kernels of one af_engine_run:
+//   af_pregen_arrivals / af_pregen_edges   every random draw of every scenario, up front, at full
+//                                          occupancy, into HBM: draws[scenario][stream][index]
+//   af_des_kernel<LDS?, SimPy-order path?, log2 lanes, waves/SIMD>
+//                                          the sequential next-event loop: one scenario per lane,
+//                                          one wave per workgroup, only the first 2^KLOG lanes of a
+//                                          wave carry scenarios (few scenarios -> many narrow waves);
+//                                          each wave free-runs af::Lane::round() (af_core.hpp) until
+//                                          every lane reached the horizon; waves share nothing
+//   af_summary_kernel / af_series_kernel   af_engine_summarize: the analyzer (af_summary.hpp)
 //
 // Memory plan
-//   LDS  : [plan blob (read-only, shared by the 64 lanes)]
+//   LDS  : [plan blob (read-only, shared by the lanes of the wave)]
 //          [per-lane state: 64-bit words, SoA [index][lane]]
 //          -> any per-lane index pattern is bank-conflict free
 //             (ds_read_b64: bank pair = 2*lane mod 64 within each 32-lane group).
-//   HBM  : outputs only (rqs_clock, sampled series, counts); per-lane state too
-//          when 64 * bytes_per_lane exceeds the 160 KiB LDS of a CU ("global
-//          state" mode, same [index][lane] layout => coalesced for equal indices).
+//   HBM  : pre-generated draws (read once), outputs (rqs_clock, sampled series, counts), the scratch
+//          of the shared-instant path; the per-lane state too when it does not fit the 160 KiB LDS
+//          of a CU ("global state" mode, same [index][lane] layout => coalesced for equal indices).
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see build.py).
 #include <hip/hip_runtime.h>
@@ -122,7 +128,7 @@ __device__ __forceinline__ void run_lanes(LaneT& S, bool active) {
 }
 
 // (Measured on MI355X, profiles/r01: forcing more than the natural 3 waves/SIMD with a
-// launch bound spills registers and is 1.5-3x slower; the kernel keeps its ~144 VGPRs.)
+// launch bound spills registers and is 1.5-3x slower; the lean variant keeps its natural 134 VGPRs.)
 //
 // kFaithful = false is the lean first pass: a scenario in which two timed events share an instant
 // stops there (af_core.hpp) and is simulated again by the kFaithful = true variant, whose extra
