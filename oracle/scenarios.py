@@ -303,6 +303,36 @@ def random_payload(rng: random.Random, horizon: int = 12) -> dict:
     return copy.deepcopy(p)
 
 
+def wide_fanout(n_srv: int = 20, algo: str = "least_connection", horizon: int = 12, users: float = 150) -> dict:
+    """More than 8 servers behind the LB (the engine keeps the rotation list in state memory instead of
+    one register), multi-core, two outages and a spike: the wide-topology corner of the schema."""
+    servers = [
+        _server(f"s{i}", cores=1 + i % 3, ram=512,
+                endpoints=[_endpoint("/a", [("initial_parsing", 0.002 + 0.0005 * (i % 4)), ("ram", 96), ("io_wait", 0.02)]),
+                           _endpoint("/b", [("io_db", 0.004), ("cpu_bound_operation", 0.003)])])
+        for i in range(n_srv)
+    ]
+    edges = [_edge("g-c", "gen", "cli", 0.003), _edge("c-lb", "cli", "lb", 0.002, "normal", 0.001)]
+    for i in range(n_srv):
+        edges.append(_edge(f"lb-s{i}", "lb", f"s{i}", 0.002 + 0.001 * (i % 5), dropout=0.01))
+        edges.append(_edge(f"s{i}-c", f"s{i}", "cli", 0.004, "log_normal" if i % 2 else "exponential", 0.3 if i % 2 else None))
+    return {
+        "rqs_input": {"id": "gen", "avg_active_users": {"mean": users}, "avg_request_per_minute_per_user": {"mean": 120},
+                      "user_sampling_window": 5},
+        "topology_graph": {"nodes": {"client": {"id": "cli"}, "servers": servers,
+                                     "load_balancer": {"id": "lb", "algorithms": algo,
+                                                       "server_covered": [f"s{i}" for i in range(n_srv)]}},
+                           "edges": edges},
+        "sim_settings": {"total_simulation_time": horizon, "sample_period_s": 0.05},
+        "events": [
+            {"event_id": "o1", "target_id": "s3", "start": {"kind": "server_down", "t_start": 2.0}, "end": {"kind": "server_up", "t_end": 5.0}},
+            {"event_id": "o2", "target_id": f"s{n_srv - 1}", "start": {"kind": "server_down", "t_start": 6.0}, "end": {"kind": "server_up", "t_end": 9.5}},
+            {"event_id": "sp", "target_id": "c-lb", "start": {"kind": "network_spike_start", "t_start": 3.0, "spike_s": 0.02},
+             "end": {"kind": "network_spike_end", "t_end": 7.0}},
+        ],
+    }
+
+
 def tie_storm(rng: random.Random, horizon: int = 12) -> dict:
     """Payloads built to make timed events COLLIDE: dyadic step times on multi-core servers with a
     tight RAM budget, Poisson (integer, often zero) edge latencies, sampler period and event marks on

@@ -11,7 +11,8 @@ import pytest
 from asyncflow_amd import _abi
 from asyncflow_amd.plan import lower
 from oracle import oracle_lib as ol
-from oracle.scenarios import fanout8, lb_two_servers, lb_with_events, overload, random_payload, single_server, tie_storm
+from oracle.scenarios import (fanout8, lb_two_servers, lb_with_events, overload, random_payload, single_server,
+                              tie_storm, wide_fanout)
 from tests.conftest import GOLDEN_DIR, golden_names
 
 pytestmark = pytest.mark.gpu
@@ -172,6 +173,16 @@ def test_fuzzed_payloads(case):
     res = _runner(payload, seeds=seeds).run()
     plan = lower(payload)
     for i in range(3):
+        _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])))
+
+
+@pytest.mark.parametrize(("n_srv", "algo"), [(9, "round_robin"), (24, "least_connection")])
+def test_more_than_eight_servers_behind_the_load_balancer(n_srv, algo):
+    payload = wide_fanout(n_srv, algo)
+    seeds = np.arange(6, dtype=np.uint64) + 1
+    res = _runner(payload, seeds=seeds).run()
+    plan = lower(payload)
+    for i in range(6):
         _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])))
 
 

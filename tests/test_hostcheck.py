@@ -20,7 +20,7 @@ import pytest
 from asyncflow_amd import _abi
 from asyncflow_amd.plan import lower
 from oracle import oracle_lib as ol
-from oracle.scenarios import lb_two_servers, overload, random_payload, stress_mixed, tie_storm
+from oracle.scenarios import lb_two_servers, overload, random_payload, stress_mixed, tie_storm, wide_fanout
 from tests.conftest import GOLDEN_DIR, golden_names
 from tests.hostcheck import build as hc
 
@@ -85,6 +85,12 @@ def test_lean_first_pass_then_simpy_order_rerun_gives_the_same_results():
         assert L.hc_reruns() == before               # ... the BASELINE topology does not
     finally:
         L.hc_set_two_pass(0)
+
+
+@pytest.mark.parametrize(("n_srv", "algo"), [(9, "round_robin"), (20, "least_connection"), (40, "round_robin")])
+def test_more_than_eight_servers_behind_the_load_balancer(n_srv, algo):
+    """The rotation list no longer fits one register: it lives in state memory (outages edit it)."""
+    _assert_same(lower(wide_fanout(n_srv, algo)), 1)
 
 
 def test_overrides_are_applied_per_scenario():

@@ -14,7 +14,7 @@ import pytest
 from asyncflow_amd.plan import lower
 from oracle import oracle_lib as ol
 from oracle import ref_env
-from oracle.scenarios import overload, random_payload, tie_storm
+from oracle.scenarios import overload, random_payload, tie_storm, wide_fanout
 
 pytestmark = [
     pytest.mark.reference,
@@ -53,6 +53,11 @@ def test_tie_storms_match_reference(case):
     """Payloads built so that thousands of timed events share an instant (grant bursts, integer
     edge latencies incl. zero, ticks on timeline marks)."""
     _same(tie_storm(random.Random(777000 + case), horizon=12), 5 + case)
+
+
+@pytest.mark.parametrize(("n_srv", "algo"), [(9, "round_robin"), (20, "least_connection")])
+def test_wide_fanout_matches_reference(n_srv, algo):
+    _same(wide_fanout(n_srv, algo), 1)
 
 
 def test_reference_suite_passes_on_the_simpy_standin():
