@@ -101,6 +101,7 @@ struct PlanView {
     uint32_t metrics_mask, gen_users_dist;
     uint32_t gen_out_edge, client_out_edge;
     uint32_t n_edges, n_servers, lb_algo, n_lb_edges, n_rows, n_edge_marks, n_srv_marks;
+    uint32_t every_event_in_order;  // 1: every request event goes through the SimPy-order path (af_plan_pack.hpp)
     const AF_PLAN_AS uint64_t* edge;
     const AF_PLAN_AS uint64_t* srv;
     const AF_PLAN_AS uint64_t* ep;
@@ -1290,7 +1291,9 @@ struct Lane : LaneRegs {
         // iff a child of the root has the same key; an arrival (cls 3) iff the heap root has; a tick or
         // timeline mark needs care iff a request event or an arrival shares its instant (ticks and
         // marks commute with each other, the fixed class order above is as good as any).
-        const bool shared = cls == 4u ? ((heap_n > 1u && t_c1 == t) || (heap_n > 2u && t_c2 == t))
+        // (plans with P.every_event_in_order are never given to the lean variant: engine.hip)
+        const bool shared = cls == 4u ? ((heap_n > 1u && t_c1 == t) || (heap_n > 2u && t_c2 == t) ||
+                                         (kFaithful && P.every_event_in_order != 0u))
                                       : (t_heap == t || (cls < 3u && t_gen == t));
         if (__builtin_expect(shared, 0)) {
             if constexpr (kFaithful) {

@@ -87,6 +87,21 @@ inline std::string pack_plan(const af_plan_t& p, PackedPlan& out) {
 }
 
 // Fill the scalar part of a PlanView from the plan (pointers are set by the caller).
+// A server whose out-edge leads to another server or to the load balancer AND can deliver with zero
+// latency (an atom at 0: poisson, or normal truncated at 0): the zero-delay Timeout of such a
+// delivery is queued between the zero-time steps of the sending server's cascade, which the inline
+// cascades cannot express.  Such plans (none of the reference's own examples) run every request event
+// through the SimPy-order path.
+inline bool every_event_in_order(const af_plan_t& p) {
+    for (uint32_t s = 0; s < p.n_servers; ++s) {
+        const int32_t e = p.srv_out_edge[s];
+        if (e < 0) continue;
+        const bool atom_at_zero = p.edge_dist[e] == AF_DIST_POISSON || p.edge_dist[e] == AF_DIST_NORMAL;
+        if (p.edge_target_kind[e] != AF_NODE_CLIENT && atom_at_zero) return true;
+    }
+    return false;
+}
+
 inline void fill_view_scalars(const af_plan_t& p, const PackedPlan& pk, PlanView& V) {
     V.total_time = p.total_time;
     V.sample_period = p.sample_period;
@@ -105,6 +120,7 @@ inline void fill_view_scalars(const af_plan_t& p, const PackedPlan& pk, PlanView
     V.n_rows = pk.n_rows;
     V.n_edge_marks = p.n_edge_marks;
     V.n_srv_marks = p.n_srv_marks;
+    V.every_event_in_order = every_event_in_order(p) ? 1u : 0u;
 }
 
 }  // namespace af

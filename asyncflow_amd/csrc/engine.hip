@@ -43,7 +43,7 @@ constexpr uint32_t kWave = 64u;
 struct KArgs {
     double total_time, sample_period, gen_users_mean, gen_users_sigma, gen_rpm_mean, gen_window_s;
     uint32_t metrics_mask, gen_users_dist, gen_out_edge, client_out_edge;
-    uint32_t n_edges, n_servers, lb_algo, n_lb_edges, n_rows, n_edge_marks, n_srv_marks;
+    uint32_t n_edges, n_servers, lb_algo, n_lb_edges, n_rows, n_edge_marks, n_srv_marks, every_event_in_order;
     uint32_t off_edge, off_srv, off_ep, off_row, off_emark, off_smark, off_lb;  // word offsets in the blob
     uint32_t blob_bytes;  // multiple of 16
     const unsigned char* blob;
@@ -164,6 +164,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) 
     P.n_rows = a.n_rows;
     P.n_edge_marks = a.n_edge_marks;
     P.n_srv_marks = a.n_srv_marks;
+    P.every_event_in_order = a.every_event_in_order;
     P.edge = lds_words(smem, a.off_edge);
     P.srv = lds_words(smem, a.off_srv);
     P.ep = lds_words(smem, a.off_ep);
@@ -495,6 +496,7 @@ int af_engine_create(const af_plan_t* plan, int device, const af_engine_options_
     a.n_lb_edges = plan->n_lb_edges;
     a.n_edge_marks = plan->n_edge_marks;
     a.n_srv_marks = plan->n_srv_marks;
+    a.every_event_in_order = af::every_event_in_order(*plan) ? 1u : 0u;
     a.n_series = plan->n_edges + 3u * plan->n_servers;
     a.series_pitch = (a.n_series + 3u) & ~3u;
 
@@ -521,7 +523,7 @@ int af_engine_create(const af_plan_t* plan, int device, const af_engine_options_
     e->force_global = opts ? opts->force_global_state : 0u;
     e->lanes_per_wave = opts ? opts->lanes_per_wave : 0u;
     e->draw_memory_bytes = opts ? (size_t)opts->draw_memory_mb << 20 : 0;
-    e->shared_instants_likely = opts && opts->expect_shared_instants != 0u;
+    e->shared_instants_likely = (opts && opts->expect_shared_instants != 0u) || a.every_event_in_order != 0u;
     if (e->lanes_per_wave & (e->lanes_per_wave - 1u)) {
         delete e;
         return fail(AF_ERR_INVALID, "lanes_per_wave must be 0 (auto) or a power of two <= 64");

@@ -182,13 +182,16 @@ enum af_flag {
     AF_FLAG_RAM_STARVED = 1u << 4,     /* a request needs more RAM than ram_mb: that
                                           server's RAM queue is blocked for good
                                           (same as the reference; informational) */
-    AF_FLAG_TIME_TIE = 1u << 5,        /* a zero-delay Timeout (step time or edge latency that
-                                          does not advance the f64 clock) was created while
-                                          other zero-time steps were pending and it is not a
-                                          delivery to the client: SimPy may order those steps
-                                          differently.  Instants shared by several timed events
-                                          are NOT flagged: they follow SimPy's event order
-                                          exactly (DESIGN.md "Ties"; informational) */
+    AF_FLAG_TIME_TIE = 1u << 5,        /* a zero-delay Timeout that is not a delivery to the
+                                          client was created while other zero-time steps were
+                                          pending: SimPy may order those steps differently.
+                                          Needs a step time or an exponential / log-normal /
+                                          uniform latency that does not advance the f64 clock
+                                          (probability ~2^-53 per draw): instants shared by
+                                          several timed events and zero-latency hops between
+                                          servers (poisson / truncated normal) are NOT flagged,
+                                          they follow SimPy's event order exactly
+                                          (DESIGN.md "Ties"; informational) */
     AF_FLAG_DRAW_OVERFLOW = 1u << 6    /* more arrivals than draw_capacity            */
 };
 

@@ -333,6 +333,24 @@ def wide_fanout(n_srv: int = 20, algo: str = "least_connection", horizon: int = 
     }
 
 
+def server_chain(dist: str = "poisson", mean: float = 0.7, cores: int = 2, horizon: int = 40) -> dict:
+    """client -> s0 -> s1 -> client with dyadic step times on multi-core servers.  With `poisson` (or a
+    `normal` truncated at 0) the server-to-server hop is often a ZERO-delay delivery created in the
+    middle of the sending server's zero-time cascade: the engine then runs every request event through
+    its SimPy-order path (af_plan_pack.hpp::every_event_in_order)."""
+    s0 = _server("s0", cores, 512, [_endpoint("/a", [("initial_parsing", 0.5), ("ram", 100), ("io_wait", 1.0)])])
+    s1 = _server("s1", cores, 512, [_endpoint("/b", [("cpu_bound_operation", 0.5), ("io_db", 0.5)])])
+    var = 0.002 if dist == "normal" else None
+    edges = [_edge("g-c", "gen", "cli", 0.003), _edge("c-s0", "cli", "s0", mean, dist, var),
+             _edge("s0-s1", "s0", "s1", mean, dist, var), _edge("s1-c", "s1", "cli", mean, dist, var)]
+    return {
+        "rqs_input": {"id": "gen", "avg_active_users": {"mean": 8}, "avg_request_per_minute_per_user": {"mean": 60},
+                      "user_sampling_window": 5},
+        "topology_graph": {"nodes": {"client": {"id": "cli"}, "servers": [s0, s1]}, "edges": edges},
+        "sim_settings": {"total_simulation_time": horizon, "sample_period_s": 0.0625},
+    }
+
+
 def tie_storm(rng: random.Random, horizon: int = 12) -> dict:
     """Payloads built to make timed events COLLIDE: dyadic step times on multi-core servers with a
     tight RAM budget, Poisson (integer, often zero) edge latencies, sampler period and event marks on

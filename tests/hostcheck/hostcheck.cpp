@@ -92,7 +92,7 @@ extern "C" int hc_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ovr, co
     af::LaneOut O{clock, samples, counts, clock_cap, tick_cap, pitch};
     std::vector<uint64_t> tie(L.tie_words, 0ull);
     af::PreDraws D{draws.data(), n_draw, flags_in, tie.data()};
-    if (g_two_pass) {  // what af_engine_run does: lean variant first, SimPy-order variant on demand
+    if (g_two_pass && !V.every_event_in_order) {  // what af_engine_run does: lean variant first, SimPy-order variant on demand
         af::Lane<MemHost, false> lean(V, L, MemHost{w.data()}, O, D, seed);
         lean.init(ovr_param, idx.data(), n_ovr, [&](uint32_t k) { return ovr_value[k]; });
         while (lean.round() != lean.ROUND_STOP) {

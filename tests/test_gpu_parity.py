@@ -11,8 +11,8 @@ import pytest
 from asyncflow_amd import _abi
 from asyncflow_amd.plan import lower
 from oracle import oracle_lib as ol
-from oracle.scenarios import (fanout8, lb_two_servers, lb_with_events, overload, random_payload, single_server,
-                              tie_storm, wide_fanout)
+from oracle.scenarios import (fanout8, lb_two_servers, lb_with_events, overload, random_payload, server_chain,
+                              single_server, tie_storm, wide_fanout)
 from tests.conftest import GOLDEN_DIR, golden_names
 
 pytestmark = pytest.mark.gpu
@@ -184,6 +184,17 @@ def test_more_than_eight_servers_behind_the_load_balancer(n_srv, algo):
     plan = lower(payload)
     for i in range(6):
         _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])))
+
+
+@pytest.mark.parametrize(("dist", "mean"), [("exponential", 0.003), ("poisson", 0.7), ("normal", 0.001)])
+def test_server_to_server_chain_with_zero_delay_hops(dist, mean):
+    payload = server_chain(dist, mean)
+    seeds = np.arange(6, dtype=np.uint64) + 1
+    res = _runner(payload, seeds=seeds).run()
+    plan = lower(payload)
+    for i in range(6):
+        _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])))
+    assert not int(np.bitwise_or.reduce(res.flags)) & _abi.FLAG_TIME_TIE
 
 
 def test_fuzz_sweep_of_topologies_all_scenarios_checked():

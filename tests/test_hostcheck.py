@@ -20,7 +20,8 @@ import pytest
 from asyncflow_amd import _abi
 from asyncflow_amd.plan import lower
 from oracle import oracle_lib as ol
-from oracle.scenarios import lb_two_servers, overload, random_payload, stress_mixed, tie_storm, wide_fanout
+from oracle.scenarios import (lb_two_servers, overload, random_payload, server_chain, stress_mixed, tie_storm,
+                              wide_fanout)
 from tests.conftest import GOLDEN_DIR, golden_names
 from tests.hostcheck import build as hc
 
@@ -91,6 +92,13 @@ def test_lean_first_pass_then_simpy_order_rerun_gives_the_same_results():
 def test_more_than_eight_servers_behind_the_load_balancer(n_srv, algo):
     """The rotation list no longer fits one register: it lives in state memory (outages edit it)."""
     _assert_same(lower(wide_fanout(n_srv, algo)), 1)
+
+
+@pytest.mark.parametrize(("dist", "mean"), [("exponential", 0.003), ("poisson", 0.7), ("poisson", 0.2), ("normal", 0.001)])
+def test_server_to_server_chain_with_zero_delay_hops(dist, mean):
+    for seed in (1, 2, 3):
+        a, _ = _assert_same(lower(server_chain(dist, mean)), seed)
+        assert a.ties > 100
 
 
 def test_overrides_are_applied_per_scenario():

@@ -14,7 +14,7 @@ import pytest
 from asyncflow_amd.plan import lower
 from oracle import oracle_lib as ol
 from oracle import ref_env
-from oracle.scenarios import overload, random_payload, tie_storm, wide_fanout
+from oracle.scenarios import overload, random_payload, server_chain, tie_storm, wide_fanout
 
 pytestmark = [
     pytest.mark.reference,
@@ -58,6 +58,11 @@ def test_tie_storms_match_reference(case):
 @pytest.mark.parametrize(("n_srv", "algo"), [(9, "round_robin"), (20, "least_connection")])
 def test_wide_fanout_matches_reference(n_srv, algo):
     _same(wide_fanout(n_srv, algo), 1)
+
+
+@pytest.mark.parametrize(("dist", "mean"), [("exponential", 0.003), ("poisson", 0.7), ("normal", 0.001)])
+def test_server_chain_matches_reference(dist, mean):
+    _same(server_chain(dist, mean), 2)
 
 
 def test_reference_suite_passes_on_the_simpy_standin():
