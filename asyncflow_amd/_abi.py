@@ -170,6 +170,7 @@ class AfStats(C.Structure):
         ("waves", C.c_uint32),
         ("lanes_per_wave", C.c_uint32),
         ("chunks", C.c_uint32),
+        ("specialised_launches", C.c_uint32),
         ("shared_instant_scenarios", C.c_uint32),
         ("request_capacity", C.c_uint32),
         ("fifo_capacity", C.c_uint32),
@@ -195,6 +196,8 @@ EXPORTED_SYMBOLS = (
     "af_engine_create",
     "af_engine_run",
     "af_engine_summarize",
+    "af_engine_jit_spec",
+    "af_engine_set_kernels",
     "af_engine_stats",
     "af_engine_destroy",
     "af_tick_count",
@@ -216,6 +219,10 @@ def declare(lib: C.CDLL) -> C.CDLL:
     lib.af_engine_run.restype = C.c_int
     lib.af_engine_summarize.argtypes = [C.c_void_p, C.POINTER(AfOutputs), C.POINTER(AfSummary)]
     lib.af_engine_summarize.restype = C.c_int
+    lib.af_engine_jit_spec.argtypes = [C.c_void_p, C.POINTER(AfSweep), C.POINTER(AfOutputs), C.c_char_p, C.c_size_t]
+    lib.af_engine_jit_spec.restype = C.c_int
+    lib.af_engine_set_kernels.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
+    lib.af_engine_set_kernels.restype = C.c_int
     lib.af_engine_stats.argtypes = [C.c_void_p, C.POINTER(AfStats)]
     lib.af_engine_stats.restype = C.c_int
     lib.af_engine_destroy.argtypes = [C.c_void_p]

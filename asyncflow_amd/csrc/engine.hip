@@ -136,10 +136,43 @@ __device__ __forceinline__ void run_lanes(LaneT& S, bool active) {
 //
 // WPE = register budget as waves per SIMD: 3 (<= 168 VGPRs; the lean variant needs 134) or, for the
 // SimPy-order variant only, 2 (it wants ~210 VGPRs: no spills, but a third fewer resident waves).
-template <bool kLdsState, bool kFaithful, int KLOG, int WPE>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) af_des_kernel(const KArgs a) {
+template <bool kLdsState, bool kFaithful, int KLOG>
+__device__ __forceinline__ void des_body(const KArgs& a_in) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lane = threadIdx.x;
+#ifdef AF_JIT
+    // Plan-specialised build (asyncflow_amd/jit.py): the plan's shape as compile-time constants --
+    // state offsets fold into instruction immediates, loops over edges / servers / series unroll,
+    // branches on the plan's shape disappear (measured on the 10k LB-2 sweep: 2 084 -> 1 912 ms).
+    KArgs a = a_in;
+    a.metrics_mask = AF_JIT_METRICS;
+    a.gen_out_edge = AF_JIT_GEN_EDGE;
+    a.client_out_edge = AF_JIT_CLIENT_EDGE;
+    a.n_edges = AF_JIT_N_EDGES;
+    a.n_servers = AF_JIT_N_SERVERS;
+    a.lb_algo = AF_JIT_LB_ALGO;
+    a.n_lb_edges = AF_JIT_N_LB;
+    a.n_rows = AF_JIT_N_ROWS;
+    a.n_edge_marks = AF_JIT_N_EMARKS;
+    a.n_srv_marks = AF_JIT_N_SMARKS;
+    a.every_event_in_order = AF_JIT_ORDER_ALL;
+    a.off_edge = AF_JIT_OFF_EDGE;
+    a.off_srv = AF_JIT_OFF_SRV;
+    a.off_ep = AF_JIT_OFF_EP;
+    a.off_row = AF_JIT_OFF_ROW;
+    a.off_emark = AF_JIT_OFF_EMARK;
+    a.off_smark = AF_JIT_OFF_SMARK;
+    a.off_lb = AF_JIT_OFF_LB;
+    a.blob_bytes = AF_JIT_BLOB_BYTES;
+    a.L = af::make_layout(AF_JIT_CAP, AF_JIT_FCAP, AF_JIT_N_EDGES, AF_JIT_N_SERVERS, AF_JIT_N_LB, AF_JIT_N_ROWS, AF_JIT_OVR_MASK);
+    a.clock_cap = AF_JIT_CLOCK_CAP;
+    a.tick_cap = AF_JIT_TICK_CAP;
+    a.n_series = AF_JIT_N_EDGES + 3 * AF_JIT_N_SERVERS;
+    a.series_pitch = (AF_JIT_N_EDGES + 3 * AF_JIT_N_SERVERS + 3) & ~3;
+    a.n_draw = AF_JIT_N_DRAW;
+#else
+    const KArgs& a = a_in;
+#endif
 
     // stage the read-only plan into LDS (shared by the 64 scenarios of the wave)
     for (uint32_t i = lane * 16u; i < a.blob_bytes; i += kWave * 16u)
@@ -216,6 +249,30 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) 
         if (!kFaithful && active && (S.flags & af::FLAG_SHARED_INSTANT)) atomicAdd(a.n_shared, 1u);
     }
 }
+
+#ifndef AF_JIT
+template <bool kLdsState, bool kFaithful, int KLOG, int WPE>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) af_des_kernel(const KArgs a) {
+    des_body<kLdsState, kFaithful, KLOG>(a);
+}
+#endif
+
+#ifdef AF_JIT
+}  // namespace
+
+// Entry points of a plan-specialised code object (built by asyncflow_amd/jit.py with hipcc --genco,
+// loaded by af_engine_set_kernels): the lean variant and the SimPy-order variant with its two
+// register budgets, for ONE (state placement, lanes per wave) pair.
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) af_jit_lean(const KArgs a) {
+    des_body<AF_JIT_LDS != 0, false, AF_JIT_KLOG>(a);
+}
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) af_jit_order3(const KArgs a) {
+    des_body<AF_JIT_LDS != 0, true, AF_JIT_KLOG>(a);
+}
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) af_jit_order2(const KArgs a) {
+    des_body<AF_JIT_LDS != 0, true, AF_JIT_KLOG>(a);
+}
+#else  // ------------------------------------------------------------------------------- AOT build
 
 // ---- draw pre-generation (fully parallel, full occupancy) ---------------------------
 __device__ __forceinline__ double ovr_or(const KArgs& a, uint32_t param, uint32_t index, uint32_t scen, double dflt) {
@@ -404,6 +461,9 @@ struct af_engine {
     uint32_t* d_map = nullptr;
     size_t map_cap = 0;
     bool shared_instants_likely = false;
+    hipModule_t jit_module = nullptr;  // plan-specialised kernels (af_engine_set_kernels), valid for jit_spec only
+    hipFunction_t jit_lean = nullptr, jit_order3 = nullptr, jit_order2 = nullptr;
+    std::string jit_spec;
     hipEvent_t ev3 = nullptr, ev4 = nullptr;
     size_t draw_memory_bytes = 0;
     uint32_t request_capacity = 0, fifo_capacity = 0, force_global = 0, lanes_per_wave = 0;
@@ -442,6 +502,78 @@ int validate_plan(const af_plan_t* p) {
     for (uint32_t i = 0; i < p->n_srv_marks; ++i)
         if (p->smark_lb_edge[i] >= (int32_t)p->n_edges) return fail(AF_ERR_INVALID, "server mark invalid");
     return AF_OK;
+}
+
+}  // namespace
+
+namespace {
+
+// Scenario lanes per wave and state placement.  The kernel is latency bound, so few scenarios are
+// best spread over MANY narrow waves: fewer event kinds per round in a wave, every SIMD busy,
+// several waves per SIMD hiding LDS latency.  Limits: <= 168 VGPRs -> 3 waves/SIMD = 12 per CU;
+// LDS-resident state -> 160 KiB per CU.  Cost model fitted to MI355X measurements
+// (profiles/r01/lanes_sweep.md): relative time of one wave-round f(lanes), x 2.3 when the state
+// lives in HBM, x the number of residency batches.
+void choose_lanes(const af_engine* e, uint32_t count, uint32_t blob_bytes, uint64_t bytes_per_lane, uint32_t& kl,
+                  bool& lds_state) {
+    static const double f_lanes[7] = {1.0, 1.4, 1.65, 2.2, 2.5, 2.4, 2.25};  // 1,2,4,...,64 lanes
+    const double n_cu = 256.0, vgpr_waves_per_cu = 12.0;
+    double best = 1e300;
+    uint32_t best_kl = 4;
+    bool best_lds = false;
+    for (uint32_t k = 0; k < 7; ++k) {
+        const uint32_t cand = 1u << k;
+        if (e->lanes_per_wave != 0u && cand != e->lanes_per_wave) continue;
+        const double waves_needed = (double)((count + cand - 1u) / cand);
+        for (int lds = 1; lds >= 0; --lds) {
+            if (lds && e->force_global) continue;
+            double per_cu = vgpr_waves_per_cu;
+            if (lds) {
+                const uint64_t wg_bytes = (uint64_t)blob_bytes + bytes_per_lane * cand;
+                if (wg_bytes > kLdsLimit) continue;
+                const double fit = (double)(kLdsLimit / wg_bytes);
+                per_cu = fit < per_cu ? fit : per_cu;
+            }
+            const double batches = waves_needed / (n_cu * per_cu);
+            const double cost = (batches < 1.0 ? 1.0 : batches) * f_lanes[k] * (lds ? 1.0 : 2.3);
+            if (cost < best) {
+                best = cost;
+                best_kl = cand;
+                best_lds = lds != 0;
+            }
+        }
+    }
+    kl = best_kl;
+    lds_state = best_lds;
+}
+
+// Everything a plan-specialised kernel bakes in, as hipcc -D flags (the JIT key).
+std::string jit_spec_string(const KArgs& a, bool lds_state, uint32_t klog) {
+    char buf[1024];
+    std::snprintf(buf, sizeof buf,
+                  "-DAF_JIT=1 -DAF_JIT_LDS=%d -DAF_JIT_KLOG=%u -DAF_JIT_METRICS=%u -DAF_JIT_GEN_EDGE=%u -DAF_JIT_CLIENT_EDGE=%u "
+                  "-DAF_JIT_N_EDGES=%u -DAF_JIT_N_SERVERS=%u -DAF_JIT_LB_ALGO=%u -DAF_JIT_N_LB=%u -DAF_JIT_N_ROWS=%u "
+                  "-DAF_JIT_N_EMARKS=%u -DAF_JIT_N_SMARKS=%u -DAF_JIT_ORDER_ALL=%u -DAF_JIT_OFF_EDGE=%u -DAF_JIT_OFF_SRV=%u "
+                  "-DAF_JIT_OFF_EP=%u -DAF_JIT_OFF_ROW=%u -DAF_JIT_OFF_EMARK=%u -DAF_JIT_OFF_SMARK=%u -DAF_JIT_OFF_LB=%u "
+                  "-DAF_JIT_BLOB_BYTES=%u -DAF_JIT_CAP=%u -DAF_JIT_FCAP=%u -DAF_JIT_OVR_MASK=%u -DAF_JIT_CLOCK_CAP=%u "
+                  "-DAF_JIT_TICK_CAP=%u -DAF_JIT_N_DRAW=%u",
+                  lds_state ? 1 : 0, klog, a.metrics_mask, a.gen_out_edge, a.client_out_edge, a.n_edges, a.n_servers, a.lb_algo,
+                  a.n_lb_edges, a.n_rows, a.n_edge_marks, a.n_srv_marks, a.every_event_in_order, a.off_edge, a.off_srv, a.off_ep,
+                  a.off_row, a.off_emark, a.off_smark, a.off_lb, a.blob_bytes, a.L.cap, a.L.fcap, a.L.ovr_mask, a.clock_cap,
+                  a.tick_cap, a.n_draw);
+    return buf;
+}
+
+uint32_t chunk_size(const af_engine* e, uint32_t n, size_t draw_bytes_per_scen, size_t mem_free) {
+    // (one launch per chunk, and every launch ends with a latency-bound tail: chunks are a last resort)
+    size_t budget = e->draw_memory_bytes ? e->draw_memory_bytes : (size_t)160 << 30;
+    const size_t avail = mem_free + e->draws_cap;
+    if (budget > avail / 10u * 6u) budget = avail / 10u * 6u;
+    uint32_t chunk = (uint32_t)(budget / draw_bytes_per_scen < 65535u ? budget / draw_bytes_per_scen : 65535u);
+    if (chunk == 0) return 0u;
+    if (chunk > n) chunk = n;
+    const uint32_t n_chunks = (n + chunk - 1u) / chunk;
+    return (n + n_chunks - 1u) / n_chunks;  // equal chunks: no short, latency-bound tail launch
 }
 
 }  // namespace
@@ -621,14 +753,8 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     const size_t draw_bytes_per_scen = (size_t)(1u + a.n_edges) * n_draw * sizeof(double);
     size_t mem_free = 0, mem_total = 0;
     HIP_TRY(hipMemGetInfo(&mem_free, &mem_total));
-    // (one launch per chunk, and every launch ends with a latency-bound tail: chunks are a last resort)
-    size_t budget = e->draw_memory_bytes ? e->draw_memory_bytes : (size_t)160 << 30;
-    const size_t avail = mem_free + e->draws_cap;
-    if (budget > avail / 10u * 6u) budget = avail / 10u * 6u;
-    uint32_t chunk = (uint32_t)(budget / draw_bytes_per_scen < 65535u ? budget / draw_bytes_per_scen : 65535u);
+    const uint32_t chunk = chunk_size(e, n, draw_bytes_per_scen, mem_free);
     if (chunk == 0) return fail(AF_ERR_CAPACITY, "draw_capacity too large for the device memory budget");
-    if (chunk > n) chunk = n;
-    chunk = (n + (n + chunk - 1u) / chunk - 1u) / ((n + chunk - 1u) / chunk);  // equal chunks: no short, latency-bound tail launch
     const size_t draw_bytes = draw_bytes_per_scen * chunk;
     if (draw_bytes > e->draws_cap) {
         if (e->d_draws) HIP_TRY(hipFree(e->d_draws));
@@ -660,7 +786,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     a.scen_map = nullptr;
 
     double ms_pregen = 0.0, ms_kernel = 0.0;
-    uint32_t kl = 0, waves = 0, lds_bytes = 0, n_chunks = 0, n_rerun = 0;
+    uint32_t kl = 0, waves = 0, lds_bytes = 0, n_chunks = 0, n_rerun = 0, n_jit = 0;
     bool lds_state = false;
     for (uint32_t lo = 0; lo < n; lo += chunk) {
         const uint32_t nc = n - lo < chunk ? n - lo : chunk;
@@ -682,44 +808,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
         // One launch of the next-event kernel over `count` scenarios (all of the chunk, or the
         // ones listed in `map`).
         auto launch_des = [&](uint32_t count, bool faithful, const uint32_t* map) -> int {
-            // Scenario lanes per wave and state placement.  The kernel is latency bound, so few
-            // scenarios are best spread over MANY narrow waves: fewer event kinds per round in a
-            // wave, every SIMD busy, several waves per SIMD hiding LDS latency.  Limits: <= 168
-            // VGPRs -> 3 waves/SIMD = 12 per CU; LDS-resident state -> 160 KiB per CU.  Cost model
-            // fitted to MI355X measurements (profiles/r01/lanes_sweep.md): relative time of one
-            // wave-round f(lanes), x 2.3 when the state lives in HBM, x the number of residency batches.
-            kl = e->lanes_per_wave;
-            {
-                static const double f_lanes[7] = {1.0, 1.4, 1.65, 2.2, 2.5, 2.4, 2.25};  // 1,2,4,...,64 lanes
-                const double n_cu = 256.0, vgpr_waves_per_cu = 12.0;
-                double best = 1e300;
-                uint32_t best_kl = 4;
-                bool best_lds = false;
-                for (uint32_t k = 0; k < 7; ++k) {
-                    const uint32_t cand = 1u << k;
-                    if (kl != 0u && cand != kl) continue;
-                    const double waves_needed = (double)((count + cand - 1u) / cand);
-                    for (int lds = 1; lds >= 0; --lds) {
-                        if (lds && e->force_global) continue;
-                        double per_cu = vgpr_waves_per_cu;
-                        if (lds) {
-                            const uint64_t wg_bytes = (uint64_t)a.blob_bytes + bytes_per_lane * cand;
-                            if (wg_bytes > kLdsLimit) continue;
-                            const double fit = (double)(kLdsLimit / wg_bytes);
-                            per_cu = fit < per_cu ? fit : per_cu;
-                        }
-                        const double batches = waves_needed / (n_cu * per_cu);
-                        const double cost = (batches < 1.0 ? 1.0 : batches) * f_lanes[k] * (lds ? 1.0 : 2.3);
-                        if (cost < best) {
-                            best = cost;
-                            best_kl = cand;
-                            best_lds = lds != 0;
-                        }
-                    }
-                }
-                kl = best_kl;
-                lds_state = best_lds;
-            }
+            choose_lanes(e, count, a.blob_bytes, bytes_per_lane, kl, lds_state);
             uint32_t klog = 0;
             while ((1u << klog) < kl) ++klog;
             a.n_scen = count;
@@ -748,12 +837,21 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
             const bool hetero = (mask & ((1u << AF_PARAM_GEN_USERS_MEAN) | (1u << AF_PARAM_GEN_RPM_MEAN))) != 0u;
             const bool roomy = faithful && (waves > 3072u || hetero);
             const void* fn = des_kernel_for(lds_state, faithful, klog, roomy);
+            hipFunction_t jit_fn = nullptr;
+            if (e->jit_module && lds_bytes <= 64u * 1024u && jit_spec_string(a, lds_state, klog) == e->jit_spec)
+                jit_fn = !faithful ? e->jit_lean : roomy ? e->jit_order2 : e->jit_order3;
             if (std::getenv("AF_DEBUG"))
                 std::fprintf(stderr, "[af] launch: %u scenarios, %u waves x %u lanes, %s state, %s%s\n", count, waves, kl,
                              lds_state ? "LDS" : "HBM", faithful ? "SimPy-order" : "lean", roomy ? " (2 waves/SIMD build)" : "");
-            if (lds_state) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            if (std::getenv("AF_DEBUG") && jit_fn) std::fprintf(stderr, "[af]   plan-specialised kernels\n");
             void* kargs[] = {&a};
-            HIP_TRY(hipLaunchKernel(fn, dim3(waves), dim3(kWave), kargs, lds_bytes, e->stream));
+            if (jit_fn) {
+                HIP_TRY(hipModuleLaunchKernel(jit_fn, waves, 1, 1, kWave, 1, 1, lds_bytes, e->stream, kargs, nullptr));
+                n_jit += 1u;
+            } else {
+                if (lds_state) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                HIP_TRY(hipLaunchKernel(fn, dim3(waves), dim3(kWave), kargs, lds_bytes, e->stream));
+            }
             return AF_OK;
         };
 
@@ -814,8 +912,66 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     e->stats.lanes_per_wave = kl;
     e->stats.chunks = n_chunks;
     e->stats.shared_instant_scenarios = n_rerun;
+    e->stats.specialised_launches = n_jit;
     e->stats.request_capacity = e->request_capacity;
     e->stats.fifo_capacity = e->fifo_capacity;
+    return AF_OK;
+}
+
+int af_engine_jit_spec(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* out, char* buf, size_t cap) {
+    if (!e || !sweep || !out || !buf || cap == 0) return fail(AF_ERR_INVALID, "NULL argument");
+    if (sweep->n_scenarios == 0) return fail(AF_ERR_INVALID, "empty sweep");
+    HIP_TRY(hipSetDevice(e->device));
+    KArgs a = e->args;
+    uint32_t mask = 0;
+    for (uint32_t k = 0; k < sweep->n_overrides; ++k) {
+        if (sweep->overrides[k].param >= AF_PARAM_COUNT_) return fail(AF_ERR_INVALID, "bad override");
+        mask |= 1u << sweep->overrides[k].param;
+    }
+    a.L = af::make_layout(e->request_capacity, e->fifo_capacity, a.n_edges, a.n_servers, a.n_lb_edges, a.n_rows, mask);
+    a.clock_cap = out->clock_capacity;
+    a.tick_cap = out->tick_capacity;
+    a.n_draw = sweep->draw_capacity ? sweep->draw_capacity : out->clock_capacity;
+    if (a.n_draw == 0) return fail(AF_ERR_INVALID, "draw_capacity (or clock_capacity) must be > 0");
+    size_t mem_free = 0, mem_total = 0;
+    HIP_TRY(hipMemGetInfo(&mem_free, &mem_total));
+    const uint32_t chunk = chunk_size(e, sweep->n_scenarios, (size_t)(1u + a.n_edges) * a.n_draw * sizeof(double), mem_free);
+    if (chunk == 0) return fail(AF_ERR_CAPACITY, "draw_capacity too large for the device memory budget");
+    uint32_t kl = 0;
+    bool lds_state = false;
+    choose_lanes(e, chunk, a.blob_bytes, af::layout_bytes_per_lane(a.L), kl, lds_state);
+    uint32_t klog = 0;
+    while ((1u << klog) < kl) ++klog;
+    const std::string spec = jit_spec_string(a, lds_state, klog);
+    if (spec.size() + 1 > cap) return fail(AF_ERR_CAPACITY, "spec buffer too small");
+    std::memcpy(buf, spec.c_str(), spec.size() + 1);
+    return AF_OK;
+}
+
+int af_engine_set_kernels(af_engine_t* e, const char* spec, const void* image, size_t size) {
+    if (!e) return fail(AF_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(e->device));
+    if (e->jit_module) {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        (void)hipModuleUnload(e->jit_module);
+        e->jit_module = nullptr;
+        e->jit_lean = e->jit_order3 = e->jit_order2 = nullptr;
+        e->jit_spec.clear();
+    }
+    if (!spec || !image || size == 0) return AF_OK;  // back to the generic kernels
+    hipModule_t mod = nullptr;
+    HIP_TRY(hipModuleLoadData(&mod, image));
+    hipFunction_t f0 = nullptr, f1 = nullptr, f2 = nullptr;
+    if (hipModuleGetFunction(&f0, mod, "af_jit_lean") != hipSuccess || hipModuleGetFunction(&f1, mod, "af_jit_order3") != hipSuccess ||
+        hipModuleGetFunction(&f2, mod, "af_jit_order2") != hipSuccess) {
+        (void)hipModuleUnload(mod);
+        return fail(AF_ERR_INVALID, "code object lacks af_jit_lean / af_jit_order3 / af_jit_order2");
+    }
+    e->jit_module = mod;
+    e->jit_lean = f0;
+    e->jit_order3 = f1;
+    e->jit_order2 = f2;
+    e->jit_spec = spec;
     return AF_OK;
 }
 
@@ -897,6 +1053,7 @@ void af_engine_destroy(af_engine_t* e) {
     if (e->d_tie) (void)hipFree(e->d_tie);
     if (e->d_n_shared) (void)hipFree(e->d_n_shared);
     if (e->d_map) (void)hipFree(e->d_map);
+    if (e->jit_module) (void)hipModuleUnload(e->jit_module);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -927,3 +1084,5 @@ int af_probe_math(int device, int kind, uint64_t seed, const double* in, const d
 }
 
 }  // extern "C"
+
+#endif  // AF_JIT

@@ -107,11 +107,17 @@ class Engine:
         _check(self._lib, self._lib.af_engine_create(C.byref(self._cplan), device, C.byref(opts), C.byref(handle)),
                "af_engine_create")
         self._h = handle
+        self._jit_spec: bytes | None = None
+        self._jit_image: bytes | None = None
 
     def run(self, seeds: np.ndarray, overrides: Sequence[tuple[int, int, np.ndarray]], *,
             clock_ptr: int, clock_capacity: int, samples_ptr: int, tick_capacity: int, counts_ptr: int,
-            draw_capacity: int = 0) -> _abi.AfStats:
-        """Launch the sweep; output pointers are DEVICE addresses owned by the caller."""
+            draw_capacity: int = 0, specialise: bool = False) -> _abi.AfStats:
+        """Launch the sweep; output pointers are DEVICE addresses owned by the caller.
+
+        ``specialise``: build (or fetch from the cache) kernels with this plan's shape as compile-time
+        constants and use them for this sweep (asyncflow_amd/jit.py; worth it for long sweeps).
+        """
         seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
         n = int(seeds.shape[0])
         cols = [np.ascontiguousarray(v, dtype=np.float64) for _, _, v in overrides]
@@ -126,8 +132,31 @@ class Engine:
         sweep = _abi.AfSweep(n, seeds.ctypes.data_as(C.POINTER(C.c_uint64)), len(cols), ov, int(draw_capacity))
         out = _abi.AfOutputs(int(clock_capacity), C.c_void_p(clock_ptr or None), int(tick_capacity),
                              C.c_void_p(samples_ptr or None), C.c_void_p(counts_ptr))
+        if specialise:
+            self._specialise(sweep, out)
         _check(self._lib, self._lib.af_engine_run(self._h, C.byref(sweep), C.byref(out)), "af_engine_run")
         return self.stats()
+
+    def _specialise(self, sweep: _abi.AfSweep, out: _abi.AfOutputs) -> None:
+        import warnings
+
+        from . import jit
+
+        buf = C.create_string_buffer(2048)
+        _check(self._lib, self._lib.af_engine_jit_spec(self._h, C.byref(sweep), C.byref(out), buf, len(buf)),
+               "af_engine_jit_spec")
+        spec = buf.value
+        if spec == self._jit_spec:
+            return
+        try:
+            image = jit.code_object(spec.decode())
+        except jit.JitUnavailableError as exc:      # not an error: the generic kernels do the same job
+            warnings.warn(f"plan-specialised kernels unavailable, using the generic ones: {exc}", RuntimeWarning,
+                          stacklevel=3)
+            return
+        self._jit_image = image                     # keep the bytes alive while the module is loaded
+        _check(self._lib, self._lib.af_engine_set_kernels(self._h, spec, image, len(image)), "af_engine_set_kernels")
+        self._jit_spec = spec
 
     def summarize(self, n: int, *, clock_ptr: int, clock_capacity: int, samples_ptr: int, tick_capacity: int,
                   counts_ptr: int, stats_ptr: int = 0, rps_ptr: int = 0, rps_buckets: int = 0, hist_ptr: int = 0,

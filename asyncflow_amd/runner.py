@@ -111,6 +111,7 @@ class SimulationRunner:
         lanes_per_wave: int = 0,
         draw_memory_mb: int = 0,
         expect_shared_instants: bool | None = None,
+        specialise: bool | None = None,
     ) -> None:
         self.env = env  # accepted for signature compatibility; unused
         self.simulation_input = simulation_input
@@ -138,6 +139,9 @@ class SimulationRunner:
         #: several timed events; None: start lean, hand such scenarios over, and remember (per
         #: payload, in this process) that this topology produces them
         self.expect_shared_instants = expect_shared_instants
+        #: build plan-specialised kernels (asyncflow_amd/jit.py, ~4 s once per plan shape, cached on disk):
+        #: None = when the sweep is expected to process more than 5e8 request-events
+        self.specialise = specialise
         self._single = seeds is None and int(replicas) == 1 and not self.sweep
         self._engine: Engine | None = None
 
@@ -157,6 +161,10 @@ class SimulationRunner:
         fifo = int(self.fifo_capacity or min(fifo, cap))
         clock_cap = int(self.clock_capacity or self.plan.clock_capacity(users_max, rpm_max))
         return cap, fifo, clock_cap
+
+    def _want_specialised(self, n: int, clock_cap: int) -> bool:
+        # ~7 request-events per completed request; clock_cap bounds the completions of one scenario
+        return 7.0 * clock_cap * n > 5e8 * 2.0
 
     def _plan_key(self) -> str:
         import hashlib
@@ -204,6 +212,7 @@ class SimulationRunner:
                 tick_capacity=ticks,
                 counts_ptr=counts.data_ptr(),
                 draw_capacity=clock_cap,
+                specialise=self._want_specialised(n, clock_cap) if self.specialise is None else bool(self.specialise),
             )
             eng.close()
             if int(stats.shared_instant_scenarios) > 0:

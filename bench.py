@@ -121,6 +121,8 @@ def main() -> int:
     ap.add_argument("--no-series", action="store_true", help="do not store the sampled series")
     ap.add_argument("--lanes", type=int, default=0, help="scenario lanes per wave (0 = engine default)")
     ap.add_argument("--global-state", action="store_true", help="keep per-scenario state in HBM")
+    ap.add_argument("--generic-kernels", action="store_true",
+                    help="do not build plan-specialised kernels (asyncflow_amd/jit.py); use the library's generic ones")
     ap.add_argument("--expect-shared-instants", action="store_true",
                     help="start with the kernel variant that has the SimPy-order path for shared instants")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
@@ -213,7 +215,7 @@ def main() -> int:
     def step():
         eng.run(seeds, overrides, clock_ptr=clock.data_ptr(), clock_capacity=clock_cap,
                 samples_ptr=samples.data_ptr() if samples is not None else 0, tick_capacity=ticks,
-                counts_ptr=counts.data_ptr(), draw_capacity=clock_cap)
+                counts_ptr=counts.data_ptr(), draw_capacity=clock_cap, specialise=not args.generic_kernels)
         return eng.summarize(n, clock_ptr=clock.data_ptr(), clock_capacity=clock_cap,
                              samples_ptr=samples.data_ptr() if samples is not None else 0, tick_capacity=ticks,
                              counts_ptr=counts.data_ptr(), stats_ptr=s_stats.data_ptr(), rps_ptr=s_rps.data_ptr(),
@@ -309,6 +311,7 @@ def main() -> int:
                 "lanes_per_wave": int(st.lanes_per_wave),
                 "waves": int(st.waves),
                 "shared_instant_scenarios": int(st.shared_instant_scenarios),
+                "plan_specialised_kernels": bool(st.specialised_launches),
             },
             "events_per_step": events_total,
             "per_gpu_value": total_events / elapsed / world,

@@ -242,6 +242,7 @@ typedef struct af_stats {
     uint32_t waves;             /* workgroups launched (one wavefront each)        */
     uint32_t lanes_per_wave;    /* scenarios carried by each wavefront             */
     uint32_t chunks;            /* sub-launches the sweep was split into           */
+    uint32_t specialised_launches; /* next-event launches that used kernels from af_engine_set_kernels */
     uint32_t shared_instant_scenarios; /* scenarios in which two timed events shared an instant:
                                    simulated a second time by the kernel variant that replays
                                    SimPy's event-by-event order (0 when the engine started
@@ -255,6 +256,19 @@ typedef struct af_engine af_engine_t;
 /* Replaces: SimulationRunner.__init__ + _build_* (simulation_runner.py:52-294). */
 int af_engine_create(const af_plan_t* plan, int device, const af_engine_options_t* opts,
                      af_engine_t** out);
+/* Plan-specialised kernels (optional).  The library contains generic next-event kernels; for long
+ * sweeps a host may compile asyncflow_amd/csrc/engine.hip once more with the plan's shape as
+ * compile-time constants (state offsets become instruction immediates, loops over edges / servers /
+ * series unroll: ~8 % less kernel time on the 10k LB-2 sweep) and hand the code object over:
+ *   af_engine_jit_spec   writes the hipcc -D flags that describe what af_engine_run(sweep, out) would
+ *                        launch (NUL-terminated, deterministic: usable as a cache key); build with
+ *                        hipcc --genco --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off <flags>
+ *   af_engine_set_kernels  loads the code object; launches whose spec differs from `spec` (another
+ *                        sweep shape, the second pass over a subset) keep using the generic kernels.
+ *                        NULL image: unload.  Results are bit-identical either way. */
+int af_engine_jit_spec(af_engine_t* engine, const af_sweep_t* sweep, const af_outputs_t* out, char* buf, size_t cap);
+int af_engine_set_kernels(af_engine_t* engine, const char* spec, const void* image, size_t size);
+
 /* Batched analyzer on the device (replaces ResultsAnalyzer._process_event_metrics,
  * src/asyncflow/metrics/analyzer.py:83-126, for every scenario of a finished af_engine_run):
  * per-scenario latency statistics in LatencyKey order

@@ -197,6 +197,23 @@ def test_server_to_server_chain_with_zero_delay_hops(dist, mean):
     assert not int(np.bitwise_or.reduce(res.flags)) & _abi.FLAG_TIME_TIE
 
 
+def test_plan_specialised_kernels_give_identical_results():
+    """asyncflow_amd/jit.py: the same source compiled with the plan's shape as constants."""
+    for payload, kw in ((lb_two_servers(horizon=20), {}),
+                        (lb_with_events(users=150, horizon=30, scale=0.05), {}),
+                        (tie_storm(random.Random(777003), horizon=12), {"expect_shared_instants": True})):
+        seeds = np.arange(70, dtype=np.uint64) + 31
+        generic = _runner(payload, seeds=seeds, specialise=False, **kw).run()
+        special = _runner(payload, seeds=seeds, specialise=True, **kw).run()
+        assert generic.engine_stats.specialised_launches == 0 and special.engine_stats.specialised_launches >= 1
+        assert np.array_equal(generic.counts, special.counts)
+        for i in (0, 33, 69):
+            assert np.array_equal(generic[i].rqs_clock, special[i].rqs_clock)
+            assert np.array_equal(generic[i]._samples, special[i]._samples)  # noqa: SLF001
+        plan = lower(payload)
+        _assert_scenario(special[5], ol.simulate(plan, int(seeds[5])))
+
+
 def test_fuzz_sweep_of_topologies_all_scenarios_checked():
     """60 random topologies x 5 seeds, every scenario compared with the oracle (all distributions,
     multi-core servers, RAM queues, LB algorithms, spikes and outages)."""
