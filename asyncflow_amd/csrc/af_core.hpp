@@ -490,7 +490,7 @@ struct Lane : LaneRegs {
     AF_CORE void edge_send(uint64_t a, uint32_t e, uint32_t hops) {
         const uint32_t at = L.edge + LEDGE * e;
         const uint64_t cs = M.ld(at);  // conn[0:15] | ring_ahead[16:23] | sends<<32
-        const double spike = u2d(M.ld(at + 1u));
+        const double spike = P.n_edge_marks != 0u ? u2d(M.ld(at + 1u)) : 0.0;  // no timeline: never anything but +0.0
         const uint32_t idx = (uint32_t)(cs >> 32);
         const uint32_t ahead = (uint32_t)(cs >> 16) & 0xFFu;
         // transit time of this edge's idx-th message (pre-drawn; -1 = dropped, edge.py:78-86)
@@ -675,6 +675,7 @@ struct Lane : LaneRegs {
         }
     }
     AF_CORE uint32_t lb_pick() {
+        const uint32_t lb_n = P.n_srv_marks != 0u ? LaneRegs::lb_n : P.n_lb_edges;  // only outages change the membership
         uint32_t out = lb_get(0u);
         if (P.lb_algo == LB_LEAST_CONNECTIONS) {  // lb_algorithms.py:10-20: first minimum in current order
             uint32_t best = (uint32_t)M.ld(L.edge + LEDGE * out) & 0xFFFFu;
@@ -1282,8 +1283,9 @@ struct Lane : LaneRegs {
         double t = t_heap;
         if (t_gen <= t) { cls = 3u; t = t_gen; }
         if (t_tick <= t) { cls = 2u; t = t_tick; }
-        if (t_smark <= t) { cls = 1u; t = t_smark; }
-        if (t_emark <= t) { cls = 0u; t = t_emark; }
+        // (plans without timelines -- a compile-time fact in plan-specialised builds -- skip all of it)
+        if (P.n_srv_marks != 0u && t_smark <= t) { cls = 1u; t = t_smark; }
+        if (P.n_edge_marks != 0u && t_emark <= t) { cls = 0u; t = t_emark; }
         if (!(t < P.total_time)) return ROUND_STOP;  // the stop event is URGENT at T (pending top-ups are moot)
         now = t;
         // Two or more timed events at this instant: SimPy interleaves their zero-time steps.  On equal
@@ -1346,9 +1348,9 @@ struct Lane : LaneRegs {
             sample_tick();
             t_tick = now + P.sample_period;
             q_tick = seq++;
-        } else if (cls == 1u) {
+        } else if (P.n_srv_marks != 0u && cls == 1u) {
             apply_smarks();
-        } else {
+        } else if (P.n_edge_marks != 0u) {
             apply_emarks();
         }
 

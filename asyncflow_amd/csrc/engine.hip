@@ -170,6 +170,8 @@ __device__ __forceinline__ void des_body(const KArgs& a_in) {
     a.n_series = AF_JIT_N_EDGES + 3 * AF_JIT_N_SERVERS;
     a.series_pitch = (AF_JIT_N_EDGES + 3 * AF_JIT_N_SERVERS + 3) & ~3;
     a.n_draw = AF_JIT_N_DRAW;
+    if (AF_JIT_HAS_CLOCK) __builtin_assume(a.clock != nullptr); else a.clock = nullptr;
+    if (AF_JIT_HAS_SAMPLES) __builtin_assume(a.samples != nullptr); else a.samples = nullptr;
 #else
     const KArgs& a = a_in;
 #endif
@@ -556,11 +558,11 @@ std::string jit_spec_string(const KArgs& a, bool lds_state, uint32_t klog) {
                   "-DAF_JIT_N_EMARKS=%u -DAF_JIT_N_SMARKS=%u -DAF_JIT_ORDER_ALL=%u -DAF_JIT_OFF_EDGE=%u -DAF_JIT_OFF_SRV=%u "
                   "-DAF_JIT_OFF_EP=%u -DAF_JIT_OFF_ROW=%u -DAF_JIT_OFF_EMARK=%u -DAF_JIT_OFF_SMARK=%u -DAF_JIT_OFF_LB=%u "
                   "-DAF_JIT_BLOB_BYTES=%u -DAF_JIT_CAP=%u -DAF_JIT_FCAP=%u -DAF_JIT_OVR_MASK=%u -DAF_JIT_CLOCK_CAP=%u "
-                  "-DAF_JIT_TICK_CAP=%u -DAF_JIT_N_DRAW=%u",
+                  "-DAF_JIT_TICK_CAP=%u -DAF_JIT_N_DRAW=%u -DAF_JIT_HAS_CLOCK=%d -DAF_JIT_HAS_SAMPLES=%d",
                   lds_state ? 1 : 0, klog, a.metrics_mask, a.gen_out_edge, a.client_out_edge, a.n_edges, a.n_servers, a.lb_algo,
                   a.n_lb_edges, a.n_rows, a.n_edge_marks, a.n_srv_marks, a.every_event_in_order, a.off_edge, a.off_srv, a.off_ep,
                   a.off_row, a.off_emark, a.off_smark, a.off_lb, a.blob_bytes, a.L.cap, a.L.fcap, a.L.ovr_mask, a.clock_cap,
-                  a.tick_cap, a.n_draw);
+                  a.tick_cap, a.n_draw, a.clock ? 1 : 0, a.samples ? 1 : 0);
     return buf;
 }
 
@@ -931,6 +933,8 @@ int af_engine_jit_spec(af_engine_t* e, const af_sweep_t* sweep, const af_outputs
     a.L = af::make_layout(e->request_capacity, e->fifo_capacity, a.n_edges, a.n_servers, a.n_lb_edges, a.n_rows, mask);
     a.clock_cap = out->clock_capacity;
     a.tick_cap = out->tick_capacity;
+    a.clock = out->clock;      // only their presence enters the spec
+    a.samples = out->samples;
     a.n_draw = sweep->draw_capacity ? sweep->draw_capacity : out->clock_capacity;
     if (a.n_draw == 0) return fail(AF_ERR_INVALID, "draw_capacity (or clock_capacity) must be > 0");
     size_t mem_free = 0, mem_total = 0;
