@@ -342,7 +342,7 @@ def main() -> int:
                 "traffic": None,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "bytes_per_event": alg_bytes / max(events_rank, 1.0),
-                "kernel": "af_des_kernel",
+                "kernel": "af_jit_lean (plan-specialised build of af_des_kernel)" if st.specialised_launches else "af_des_kernel",
             },
         }
         if base is not None:
