@@ -321,7 +321,8 @@ def test_full_horizon_properties_and_statistical_parity_with_simpy():
     SimPy reference (mean 24.04 ms, p50 23.18, p95 33.65, p99 39.68)."""
     payload = lb_two_servers()
     n = 256
-    res = _runner(payload, replicas=n).run()
+    res = _runner(payload, replicas=n, specialise=True).run()      # the kernels bench.py measures
+    assert res.engine_stats.specialised_launches >= 1
     c = res.counts.astype(np.int64)
     gen, comp, drop, ev, ticks = (c[:, k] for k in range(5))
     assert np.all(ticks == 11999)
