@@ -130,7 +130,7 @@ struct Layout {
     //   zero-time event FIFO [tcap][2] | node inbox items [tcap][2] | forwarder-busy bits
     uint32_t tcap, tie_words;
 };
-enum : uint32_t { LEDGE = 2, LSRV = 5, RING = 4 };
+enum : uint32_t { LEDGE = 2, LSRV = 5, RING = 4, RING_LOW = 1 };
 
 AF_HD Layout make_layout(uint32_t cap, uint32_t fcap, uint32_t n_edges, uint32_t n_servers, uint32_t n_lb,
                          uint32_t n_rows, uint32_t ovr_mask) {
@@ -503,7 +503,8 @@ struct Lane : LaneRegs {
             transit = draw_or(1u + e, idx, -1.0);  // ring empty: straight from HBM (rare)
             if (idx >= D.n_per_stream) flags |= FLAG_DRAW_OVERFLOW;
         }
-        dirty_edge = (int32_t)e;
+        // ask for a top-up only at the low-water mark: one top-up then serves three sends instead of one
+        if (ahead <= RING_LOW + 1u) dirty_edge = (int32_t)e;
         if (transit < 0.0) {
             M.st(at, ncs);
             n_drop += 1u;
@@ -1069,7 +1070,7 @@ struct Lane : LaneRegs {
                     t_gen = draw_or(0u, n_gen, AF_INF);
                 }
                 q_gen = seq++;
-                fl |= F_DIRTY_ARR;
+                if (arr_ahead <= RING_LOW) fl |= F_DIRTY_ARR;
             } else if (cls == 2u) {
                 sample_tick();
                 t_tick = now + P.sample_period;
@@ -1343,7 +1344,7 @@ struct Lane : LaneRegs {
             } else {
                 t_gen = draw_or(0u, n_gen, AF_INF);  // ring empty: straight from HBM (rare)
             }
-            fl |= F_DIRTY_ARR;
+            if (arr_ahead <= RING_LOW) fl |= F_DIRTY_ARR;
         } else if (cls == 2u) {
             sample_tick();
             t_tick = now + P.sample_period;
