@@ -130,7 +130,10 @@ struct Layout {
     //   zero-time event FIFO [tcap][2] | node inbox items [tcap][2] | forwarder-busy bits
     uint32_t tcap, tie_words;
 };
-enum : uint32_t { LEDGE = 2, LSRV = 5, RING = 4, RING_LOW = 1 };
+#ifndef AF_RING_LOW
+#define AF_RING_LOW 1
+#endif
+enum : uint32_t { LEDGE = 2, LSRV = 5, RING = 4, RING_LOW = AF_RING_LOW };
 
 AF_HD Layout make_layout(uint32_t cap, uint32_t fcap, uint32_t n_edges, uint32_t n_servers, uint32_t n_lb,
                          uint32_t n_rows, uint32_t ovr_mask) {
