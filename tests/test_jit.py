@@ -1,0 +1,38 @@
+"""Host side of the plan-specialised kernels (asyncflow_amd/jit.py): hipcc cross-compiles gfx950
+code objects without a GPU; loading and running them is covered by tests/test_gpu_parity.py."""
+
+from __future__ import annotations
+
+import pytest
+
+from asyncflow_amd import jit
+
+LB2_SPEC = (
+    "-DAF_JIT=1 -DAF_JIT_LDS=1 -DAF_JIT_KLOG=2 -DAF_JIT_METRICS=15 -DAF_JIT_GEN_EDGE=0 -DAF_JIT_CLIENT_EDGE=1 "
+    "-DAF_JIT_N_EDGES=6 -DAF_JIT_N_SERVERS=2 -DAF_JIT_LB_ALGO=0 -DAF_JIT_N_LB=2 -DAF_JIT_N_ROWS=6 -DAF_JIT_N_EMARKS=0 "
+    "-DAF_JIT_N_SMARKS=0 -DAF_JIT_ORDER_ALL=0 -DAF_JIT_OFF_EDGE=0 -DAF_JIT_OFF_SRV=24 -DAF_JIT_OFF_EP=28 -DAF_JIT_OFF_ROW=32 "
+    "-DAF_JIT_OFF_EMARK=50 -DAF_JIT_OFF_SMARK=50 -DAF_JIT_OFF_LB=50 -DAF_JIT_BLOB_BYTES=416 -DAF_JIT_CAP=32 -DAF_JIT_FCAP=16 "
+    "-DAF_JIT_OVR_MASK=0 -DAF_JIT_CLOCK_CAP=1000 -DAF_JIT_TICK_CAP=399 -DAF_JIT_N_DRAW=1000 -DAF_JIT_HAS_CLOCK=1 "
+    "-DAF_JIT_HAS_SAMPLES=1"
+)
+
+
+def test_specialised_code_object_builds_caches_and_exports_the_three_entry_points(tmp_path, monkeypatch):
+    monkeypatch.setattr(jit, "CACHE_DIR", tmp_path)
+    image = jit.code_object(LB2_SPEC)
+    assert image.startswith(b"__CLANG_OFFLOAD_BUNDLE__") and b"gfx950" in image[:4096]
+    for name in (b"af_jit_lean", b"af_jit_order3", b"af_jit_order2"):
+        assert name in image
+    cached = list(tmp_path.glob("*.hsaco"))
+    assert len(cached) == 1 and not list(tmp_path.glob("*.tmp"))
+    assert jit.code_object(LB2_SPEC) == image                    # second call: from the cache
+    assert len(list(tmp_path.glob("*.hsaco"))) == 1
+    other = jit.code_object(LB2_SPEC.replace("-DAF_JIT_KLOG=2", "-DAF_JIT_KLOG=0"))
+    assert other != image and len(list(tmp_path.glob("*.hsaco"))) == 2
+
+
+def test_a_failing_build_is_reported_as_unavailable_not_as_a_crash(tmp_path, monkeypatch):
+    monkeypatch.setattr(jit, "CACHE_DIR", tmp_path)
+    with pytest.raises(jit.JitUnavailableError, match="hipcc --genco failed"):
+        jit.code_object("-DAF_JIT=1 -DAF_JIT_LDS=1")            # constants missing: does not compile
+    assert not list(tmp_path.iterdir())
