@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-AF_ABI_VERSION = 1
+AF_ABI_VERSION = 2
 
 # af_status
 AF_OK = 0
@@ -143,6 +143,11 @@ class AfOutputs(C.Structure):
         ("tick_capacity", C.c_uint32),
         ("samples", C.c_void_p),
         ("counts", C.c_void_p),
+        ("online_hist_bins", C.c_uint32),
+        ("online_hist_max", C.c_double),
+        ("online_hist", C.c_void_p),
+        ("online_rps_buckets", C.c_uint32),
+        ("online_rps", C.c_void_p),
     ]
 
 

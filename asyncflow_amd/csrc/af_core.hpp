@@ -167,7 +167,19 @@ struct LaneOut {
     uint32_t* samples;  // [tick_cap][series_pitch] or nullptr (16-byte aligned rows)
     uint32_t* counts;   // [CNT_SLOTS]
     uint32_t clock_cap, tick_cap, series_pitch;
+    // optional summary accumulated by the kernel itself (af_outputs_t.online_*): integer counters
+    // bumped with fire-and-forget atomics, for sweeps whose per-request clock would not fit
+    uint32_t* hist;     // [hist_bins] latency histogram or nullptr
+    uint32_t* rps;      // [rps_buckets] completions per 1-s window (k-1, k] or nullptr
+    uint32_t hist_bins, rps_buckets;
+    double hist_scale;  // hist_bins / hist_max
 };
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AF_BUMP(p) ((void)atomicAdd((p), 1u))  // result unused: the no-return form, never waited for
+#else
+#define AF_BUMP(p) ((void)(*(p) += 1u))
+#endif
 
 // one 16-byte store (rows of the sample array are 16-byte aligned)
 AF_HD void store4(uint32_t* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
@@ -701,6 +713,29 @@ struct Lane : LaneRegs {
         return out;
     }
 
+    // the client's second visit (client.py:62-69): the request is complete
+    AF_CORE void complete(uint64_t a) {
+        if (O.clock != nullptr) {
+            if (n_comp < O.clock_cap) {
+                O.clock[2u * n_comp] = u2d(a);
+                O.clock[2u * n_comp + 1u] = now;
+            } else {
+                flags |= FLAG_CLOCK_OVERFLOW;
+            }
+        }
+        if (O.hist != nullptr) {  // same binning as af_summary_t.hist
+            const double bf = (now - u2d(a)) * O.hist_scale;
+            AF_BUMP(O.hist + (bf >= (double)(O.hist_bins - 1u) ? O.hist_bins - 1u : (uint32_t)bf));
+        }
+        if (O.rps != nullptr) {  // window (k-1, k], analyzer.py:112-121
+            const double kf = __builtin_ceil(now);
+            const uint32_t k = kf < 1.0 ? 1u : (uint32_t)kf;
+            if (k <= O.rps_buckets) AF_BUMP(O.rps + (k - 1u));
+        }
+        n_comp += 1u;
+        live -= 1u;
+    }
+
     // EdgeRuntime._deliver after the timeout (edge.py:110-116) + the target node
     AF_CORE void deliver(uint64_t a, uint32_t e, uint32_t hops) {
         hops += 1u;  // record_hop(NETWORK_CONNECTION)
@@ -711,16 +746,7 @@ struct Lane : LaneRegs {
         if (tk == NODE_CLIENT) {  // ClientRuntime._forwarder, client.py:46-71
             hops += 1u;
             if (hops > 3u) {
-                if (O.clock != nullptr) {
-                    if (n_comp < O.clock_cap) {
-                        O.clock[2u * n_comp] = u2d(a);
-                        O.clock[2u * n_comp + 1u] = now;
-                    } else {
-                        flags |= FLAG_CLOCK_OVERFLOW;
-                    }
-                }
-                n_comp += 1u;
-                live -= 1u;
+                complete(a);
             } else {
                 fl |= F_SEND;
                 send_a = a;
@@ -1123,16 +1149,7 @@ struct Lane : LaneRegs {
                     if (node == 0u) {  // client.py:46-71
                         const uint32_t h = hops + 1u;
                         if (h > 3u) {
-                            if (O.clock != nullptr) {
-                                if (n_comp < O.clock_cap) {
-                                    O.clock[2u * n_comp] = u2d(ra);
-                                    O.clock[2u * n_comp + 1u] = now;
-                                } else {
-                                    flags |= FLAG_CLOCK_OVERFLOW;
-                                }
-                            }
-                            n_comp += 1u;
-                            live -= 1u;
+                            complete(ra);
                             mq_push(MK_CBOX_PUT, 0ull, 0u);  // yield completed_box.put(state)
                         } else {
                             m_urgent(UK_EDGE_INIT, ra, P.client_out_edge, h);

@@ -60,6 +60,10 @@ struct KArgs {
     uint32_t* samples;
     uint32_t tick_cap, n_series, series_pitch;
     uint32_t* counts;
+    uint32_t* online_hist;  // [n_scen][online_hist_bins] or null
+    uint32_t* online_rps;   // [n_scen][online_rps_buckets] or null
+    uint32_t online_hist_bins, online_rps_buckets;
+    double online_hist_scale;
     unsigned char* state;  // HBM-resident lane state (global-state mode only)
     uint64_t state_bytes_per_wave;
     double* draws;          // pre-generated draws [n_scen][1 + n_edges][n_draw]
@@ -172,6 +176,7 @@ __device__ __forceinline__ void des_body(const KArgs& a_in) {
     a.n_draw = AF_JIT_N_DRAW;
     if (AF_JIT_HAS_CLOCK) __builtin_assume(a.clock != nullptr); else a.clock = nullptr;
     if (AF_JIT_HAS_SAMPLES) __builtin_assume(a.samples != nullptr); else a.samples = nullptr;
+    if (!AF_JIT_HAS_ONLINE) a.online_hist = a.online_rps = nullptr;
 #else
     const KArgs& a = a_in;
 #endif
@@ -223,6 +228,11 @@ __device__ __forceinline__ void des_body(const KArgs& a_in) {
     O.clock_cap = a.clock_cap;
     O.tick_cap = a.tick_cap;
     O.series_pitch = a.series_pitch;
+    O.hist = a.online_hist ? a.online_hist + (size_t)sc * a.online_hist_bins : nullptr;
+    O.rps = a.online_rps ? a.online_rps + (size_t)sc * a.online_rps_buckets : nullptr;
+    O.hist_bins = a.online_hist_bins;
+    O.rps_buckets = a.online_rps_buckets;
+    O.hist_scale = a.online_hist_scale;
 
     const uint64_t seed = a.seeds[sc];
     auto ovr = [&](uint32_t k) { return a.ovr_values[(size_t)k * a.ovr_stride + sc]; };
@@ -361,6 +371,17 @@ __global__ void __launch_bounds__(64) af_pregen_arrivals(const KArgs a) {
     }
     for (uint32_t i = k + lane; i < a.n_draw; i += 64u) out[i] = af::AF_INF;
     if (lane == 0u) a.pre_flags[scen] = flags;
+}
+
+// second pass: the online counters of the scenarios that start over are cleared first
+__global__ void af_zero_online(const KArgs a, uint32_t count) {
+    const uint32_t j = blockIdx.x;
+    if (j >= count) return;
+    const uint32_t sc = a.scen_map[j];
+    if (a.online_hist)
+        for (uint32_t i = threadIdx.x; i < a.online_hist_bins; i += blockDim.x) a.online_hist[(size_t)sc * a.online_hist_bins + i] = 0u;
+    if (a.online_rps)
+        for (uint32_t i = threadIdx.x; i < a.online_rps_buckets; i += blockDim.x) a.online_rps[(size_t)sc * a.online_rps_buckets + i] = 0u;
 }
 
 // Streams 1 + e: block (x, scenario, edge) draws 256 consecutive messages (coalesced stores).
@@ -558,11 +579,11 @@ std::string jit_spec_string(const KArgs& a, bool lds_state, uint32_t klog) {
                   "-DAF_JIT_N_EMARKS=%u -DAF_JIT_N_SMARKS=%u -DAF_JIT_ORDER_ALL=%u -DAF_JIT_OFF_EDGE=%u -DAF_JIT_OFF_SRV=%u "
                   "-DAF_JIT_OFF_EP=%u -DAF_JIT_OFF_ROW=%u -DAF_JIT_OFF_EMARK=%u -DAF_JIT_OFF_SMARK=%u -DAF_JIT_OFF_LB=%u "
                   "-DAF_JIT_BLOB_BYTES=%u -DAF_JIT_CAP=%u -DAF_JIT_FCAP=%u -DAF_JIT_OVR_MASK=%u -DAF_JIT_CLOCK_CAP=%u "
-                  "-DAF_JIT_TICK_CAP=%u -DAF_JIT_N_DRAW=%u -DAF_JIT_HAS_CLOCK=%d -DAF_JIT_HAS_SAMPLES=%d",
+                  "-DAF_JIT_TICK_CAP=%u -DAF_JIT_N_DRAW=%u -DAF_JIT_HAS_CLOCK=%d -DAF_JIT_HAS_SAMPLES=%d -DAF_JIT_HAS_ONLINE=%d",
                   lds_state ? 1 : 0, klog, a.metrics_mask, a.gen_out_edge, a.client_out_edge, a.n_edges, a.n_servers, a.lb_algo,
                   a.n_lb_edges, a.n_rows, a.n_edge_marks, a.n_srv_marks, a.every_event_in_order, a.off_edge, a.off_srv, a.off_ep,
                   a.off_row, a.off_emark, a.off_smark, a.off_lb, a.blob_bytes, a.L.cap, a.L.fcap, a.L.ovr_mask, a.clock_cap,
-                  a.tick_cap, a.n_draw, a.clock ? 1 : 0, a.samples ? 1 : 0);
+                  a.tick_cap, a.n_draw, a.clock ? 1 : 0, a.samples ? 1 : 0, (a.online_hist || a.online_rps) ? 1 : 0);
     return buf;
 }
 
@@ -696,6 +717,9 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     if (!out->counts) return fail(AF_ERR_INVALID, "outputs.counts is required");
     if (out->clock && out->clock_capacity == 0) return fail(AF_ERR_INVALID, "clock buffer with zero capacity");
     if (out->samples && out->tick_capacity == 0) return fail(AF_ERR_INVALID, "samples buffer with zero capacity");
+    if (out->online_hist && (out->online_hist_bins == 0 || !(out->online_hist_max > 0.0)))
+        return fail(AF_ERR_INVALID, "online_hist needs online_hist_bins > 0 and online_hist_max > 0");
+    if (out->online_rps && out->online_rps_buckets == 0) return fail(AF_ERR_INVALID, "online_rps with zero buckets");
     HIP_TRY(hipSetDevice(e->device));
     KArgs a = e->args;
     const uint32_t n = sweep->n_scenarios;
@@ -799,6 +823,11 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
         a.clock = out->clock ? out->clock + (size_t)lo * out->clock_capacity * 2u : nullptr;
         a.samples = out->samples ? out->samples + (size_t)lo * a.series_pitch * out->tick_capacity : nullptr;
         a.counts = out->counts + (size_t)lo * AF_CNT_SLOTS;
+        a.online_hist = out->online_hist ? out->online_hist + (size_t)lo * out->online_hist_bins : nullptr;
+        a.online_rps = out->online_rps ? out->online_rps + (size_t)lo * out->online_rps_buckets : nullptr;
+        a.online_hist_bins = out->online_hist_bins;
+        a.online_rps_buckets = out->online_rps_buckets;
+        a.online_hist_scale = out->online_hist ? (double)out->online_hist_bins / out->online_hist_max : 0.0;
 
         // pre-generate every random draw of the chunk (HBM)
         HIP_TRY(hipEventRecord(e->ev2, e->stream));
@@ -882,6 +911,11 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
                     e->map_cap = (size_t)nc * 4u;
                 }
                 HIP_TRY(hipMemcpy(e->d_map, map.data(), map.size() * 4u, hipMemcpyHostToDevice));
+                if (a.online_hist || a.online_rps) {
+                    a.scen_map = e->d_map;
+                    hipLaunchKernelGGL(af_zero_online, dim3((uint32_t)map.size()), dim3(256), 0, e->stream, a, (uint32_t)map.size());
+                    HIP_TRY(hipGetLastError());
+                }
                 if (int rc = launch_des((uint32_t)map.size(), true, e->d_map)) return rc;
                 a.scen_map = nullptr;
                 a.n_scen = nc;
@@ -935,6 +969,8 @@ int af_engine_jit_spec(af_engine_t* e, const af_sweep_t* sweep, const af_outputs
     a.tick_cap = out->tick_capacity;
     a.clock = out->clock;      // only their presence enters the spec
     a.samples = out->samples;
+    a.online_hist = out->online_hist;
+    a.online_rps = out->online_rps;
     a.n_draw = sweep->draw_capacity ? sweep->draw_capacity : out->clock_capacity;
     if (a.n_draw == 0) return fail(AF_ERR_INVALID, "draw_capacity (or clock_capacity) must be > 0");
     size_t mem_free = 0, mem_total = 0;

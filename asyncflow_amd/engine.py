@@ -112,7 +112,8 @@ class Engine:
 
     def run(self, seeds: np.ndarray, overrides: Sequence[tuple[int, int, np.ndarray]], *,
             clock_ptr: int, clock_capacity: int, samples_ptr: int, tick_capacity: int, counts_ptr: int,
-            draw_capacity: int = 0, specialise: bool = False) -> _abi.AfStats:
+            draw_capacity: int = 0, specialise: bool = False, online_hist_ptr: int = 0, online_hist_bins: int = 0,
+            online_hist_max: float = 0.0, online_rps_ptr: int = 0, online_rps_buckets: int = 0) -> _abi.AfStats:
         """Launch the sweep; output pointers are DEVICE addresses owned by the caller.
 
         ``specialise``: build (or fetch from the cache) kernels with this plan's shape as compile-time
@@ -131,7 +132,9 @@ class Engine:
             ov[k].values = cols[k].ctypes.data_as(C.POINTER(C.c_double))
         sweep = _abi.AfSweep(n, seeds.ctypes.data_as(C.POINTER(C.c_uint64)), len(cols), ov, int(draw_capacity))
         out = _abi.AfOutputs(int(clock_capacity), C.c_void_p(clock_ptr or None), int(tick_capacity),
-                             C.c_void_p(samples_ptr or None), C.c_void_p(counts_ptr))
+                             C.c_void_p(samples_ptr or None), C.c_void_p(counts_ptr),
+                             int(online_hist_bins), float(online_hist_max), C.c_void_p(online_hist_ptr or None),
+                             int(online_rps_buckets), C.c_void_p(online_rps_ptr or None))
         if specialise:
             self._specialise(sweep, out)
         _check(self._lib, self._lib.af_engine_run(self._h, C.byref(sweep), C.byref(out)), "af_engine_run")

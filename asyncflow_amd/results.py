@@ -199,7 +199,8 @@ class BatchedResults:
     """All scenarios of a sweep; device-resident until a scenario is read."""
 
     def __init__(self, plan: DevicePlan, seeds: np.ndarray, counts: Any, clock: Any, samples: Any,
-                 stats: _abi.AfStats, wall_s: float, overrides: dict[str, np.ndarray] | None = None) -> None:
+                 stats: _abi.AfStats, wall_s: float, overrides: dict[str, np.ndarray] | None = None, *,
+                 online_hist: Any = None, online_rps: Any = None, online_hist_max: float = 0.0) -> None:
         self.plan = plan
         self.seeds = seeds
         self._counts_t, self._clock_t, self._samples_t = counts, clock, samples
@@ -208,6 +209,8 @@ class BatchedResults:
         self.engine_stats = stats
         self.wall_s = wall_s
         self.overrides = overrides or {}
+        #: kernel-side summary (SimulationRunner(online_summary=...)): int32 [n, bins] / [n, floor(T)] on the device
+        self.online_hist, self.online_rps, self.online_hist_max = online_hist, online_rps, float(online_hist_max)
 
     def __len__(self) -> int:
         return int(self.counts.shape[0])
@@ -263,7 +266,9 @@ class BatchedResults:
         from .engine import Engine
 
         if self._clock_t is None:
-            msg = "run(collect_clock=False) kept no rqs_clock"
+            if self.online_hist is not None:
+                return self._summary_from_online()
+            msg = "run(collect_clock=False) kept no rqs_clock (pass online_summary=... to keep a kernel-side summary)"
             raise RuntimeError(msg)
         if series and self._samples_t is None:
             msg = "run(collect_samples=False) kept no sampled series"
@@ -301,6 +306,42 @@ class BatchedResults:
             out["hist"] = hist_t
         if series:
             out["series_mean"], out["series_max"] = smean, smax
+        return out
+
+    def _summary_from_online(self) -> dict[str, Any]:
+        """Latency statistics read from the kernel-side histogram: total exact, everything else accurate
+        to one bin (mean / std from bin centres, percentiles by linear interpolation inside the bin,
+        min / max = edges of the extreme occupied bins)."""
+        import torch
+
+        h = self.online_hist.to(torch.float64)
+        n, bins = h.shape
+        width = self.online_hist_max / bins
+        centres = (torch.arange(bins, device=h.device, dtype=torch.float64) + 0.5) * width
+        total = h.sum(dim=1)
+        safe = total.clamp(min=1.0)
+        mean = (h * centres).sum(dim=1) / safe
+        var = (h * (centres.unsqueeze(0) - mean.unsqueeze(1)) ** 2).sum(dim=1) / safe
+        cdf = h.cumsum(dim=1)
+
+        def pct(q: float) -> Any:
+            target = (q / 100.0) * total
+            idx = torch.searchsorted(cdf, target.unsqueeze(1).contiguous(), right=False).squeeze(1).clamp(max=bins - 1)
+            below = torch.where(idx > 0, cdf.gather(1, (idx - 1).clamp(min=0).unsqueeze(1)).squeeze(1), torch.zeros_like(total))
+            inside = h.gather(1, idx.unsqueeze(1)).squeeze(1).clamp(min=1.0)
+            return (idx.to(torch.float64) + ((target - below) / inside).clamp(0.0, 1.0)) * width
+
+        occupied = h > 0
+        first = torch.where(occupied.any(dim=1), occupied.to(torch.int64).argmax(dim=1), torch.zeros(n, dtype=torch.int64, device=h.device))
+        last = bins - 1 - occupied.flip(dims=[1]).to(torch.int64).argmax(dim=1)
+        stats = torch.stack([total, mean, pct(50.0), var.sqrt(), pct(95.0), pct(99.0), first.to(torch.float64) * width,
+                             (last.to(torch.float64) + 1.0) * width], dim=1)
+        stats = torch.where((total > 0).unsqueeze(1), stats, torch.full_like(stats, float("nan")))
+        stats[:, 0] = total
+        out: dict[str, Any] = {"stats": stats, "keys": LATENCY_KEYS, "hist": self.online_hist, "approximate": True,
+                               "bin_width": width}
+        if self.online_rps is not None:
+            out["rps"] = self.online_rps.to(torch.float32)
         return out
 
     def save_summary(self, path: str, *, hist_bins: int = 256, hist_max: float | None = None,

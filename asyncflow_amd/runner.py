@@ -112,6 +112,7 @@ class SimulationRunner:
         draw_memory_mb: int = 0,
         expect_shared_instants: bool | None = None,
         specialise: bool | None = None,
+        online_summary: Mapping[str, Any] | None = None,
     ) -> None:
         self.env = env  # accepted for signature compatibility; unused
         self.simulation_input = simulation_input
@@ -131,6 +132,12 @@ class SimulationRunner:
         self.clock_capacity = clock_capacity
         self.collect_clock = collect_clock
         self.collect_samples = collect_samples
+        #: {"hist_max": seconds, "hist_bins": 4096}: let the kernel itself accumulate a latency histogram
+        #: and the 1-s completion counts per scenario (for sweeps run with collect_clock=False)
+        self.online_summary = dict(online_summary) if online_summary else None
+        if self.online_summary is not None and not float(self.online_summary.get("hist_max", 0.0)) > 0.0:
+            msg = "online_summary needs a positive 'hist_max' (seconds covered by the latency histogram)"
+            raise ValueError(msg)
         self.force_global_state = force_global_state
         self.auto_grow = auto_grow
         self.lanes_per_wave = lanes_per_wave
@@ -202,6 +209,15 @@ class SimulationRunner:
                 torch.zeros((n, ticks, self.plan.series_pitch), dtype=torch.int32, device=dev)
                 if self.collect_samples else None
             )
+            online_hist = online_rps = None
+            o_bins = o_buckets = 0
+            o_max = 0.0
+            if self.online_summary is not None:
+                o_bins = int(self.online_summary.get("hist_bins", 4096))
+                o_max = float(self.online_summary["hist_max"])
+                o_buckets = int(self.plan.total_time)
+                online_hist = torch.zeros((n, o_bins), dtype=torch.int32, device=dev)
+                online_rps = torch.zeros((n, max(o_buckets, 1)), dtype=torch.int32, device=dev)
             torch.cuda.synchronize(dev)
             stats = eng.run(
                 self.seeds,
@@ -213,12 +229,17 @@ class SimulationRunner:
                 counts_ptr=counts.data_ptr(),
                 draw_capacity=clock_cap,
                 specialise=self._want_specialised(n, clock_cap) if self.specialise is None else bool(self.specialise),
+                online_hist_ptr=online_hist.data_ptr() if online_hist is not None else 0, online_hist_bins=o_bins,
+                online_hist_max=o_max,
+                online_rps_ptr=online_rps.data_ptr() if online_rps is not None and o_buckets else 0,
+                online_rps_buckets=o_buckets,
             )
             eng.close()
             if int(stats.shared_instant_scenarios) > 0:
                 _SHARED_INSTANTS_SEEN[self._plan_key()] = True
             res = BatchedResults(self.plan, self.seeds, counts, clock, samples, stats,
-                                 time.perf_counter() - t0, {k: v for _, _, v, k in overrides})
+                                 time.perf_counter() - t0, {k: v for _, _, v, k in overrides},
+                                 online_hist=online_hist, online_rps=online_rps, online_hist_max=o_max)
             over = int(np.bitwise_or.reduce(res.flags)) & _abi.FATAL_FLAGS
             if not over or attempt == 3 or not self.auto_grow:
                 break
@@ -233,7 +254,7 @@ class SimulationRunner:
             warnings.warn(
                 f"engine capacity overflow (flags={over:#x}); retrying with request_capacity={cap}, "
                 f"fifo_capacity={fifo}, clock_capacity={clock_cap}", RuntimeWarning, stacklevel=2)
-            del counts, clock, samples, res
+            del counts, clock, samples, res, online_hist, online_rps
         res.raise_on_overflow()
         return res[0] if self._single else res
 

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define AF_ABI_VERSION 1
+#define AF_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------ */
 enum af_status {
@@ -212,6 +212,17 @@ typedef struct af_outputs {
     uint32_t* samples;
     /* DEVICE [n_scenarios][AF_CNT_SLOTS] u32 */
     uint32_t* counts;
+    /* Optional summary accumulated by the next-event kernel itself, for sweeps whose rqs_clock
+     * (16 B per completion) is not wanted: per scenario a linear latency histogram over
+     * [0, online_hist_max) whose last bin also takes the overflow (same binning as
+     * af_summary_t.hist) and the completions per 1-s window (k-1, k] (analyzer.py:112-121).
+     * DEVICE u32 arrays ZEROED BY THE CALLER; NULL = off.  Exact integer counts; percentiles read
+     * from the histogram are accurate to one bin. */
+    uint32_t online_hist_bins;
+    double online_hist_max;
+    uint32_t* online_hist;      /* [n_scenarios][online_hist_bins] */
+    uint32_t online_rps_buckets;
+    uint32_t* online_rps;       /* [n_scenarios][online_rps_buckets] */
 } af_outputs_t;
 
 typedef struct af_engine_options {

@@ -23,7 +23,8 @@ _lib: C.CDLL | None = None
 
 def build(force: bool = False) -> Path:
     """Compile the C restatement (gcc, seconds)."""
-    src_m = max((_HERE / n).stat().st_mtime for n in ("des_oracle.c", "oracle_rng.h"))
+    src_m = max([(_HERE / n).stat().st_mtime for n in ("des_oracle.c", "oracle_rng.h")]
+                + [(_HERE.parent / "include" / "asyncflow_hip.h").stat().st_mtime])
     if force or not _LIB_PATH.exists() or _LIB_PATH.stat().st_mtime < src_m:
         subprocess.run(["make", "-C", str(_HERE), "-B", "libaf_oracle.so"], check=True, capture_output=True)
     return _LIB_PATH

@@ -41,6 +41,8 @@ def lib() -> C.CDLL:
             C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32,
         ]
         L.hc_simulate.restype = C.c_int
+        L.hc_set_online.argtypes = [C.POINTER(C.c_uint32), C.c_uint32, C.c_double, C.POINTER(C.c_uint32), C.c_uint32]
+        L.hc_set_online.restype = None
         L.hc_set_two_pass.argtypes = [C.c_int]
         L.hc_set_two_pass.restype = None
         L.hc_reruns.argtypes = []

@@ -21,6 +21,9 @@ struct MemHost {
 };
 
 int g_two_pass = 0, g_reruns = 0;
+uint32_t *g_online_hist = nullptr, *g_online_rps = nullptr;
+uint32_t g_online_bins = 0, g_online_buckets = 0;
+double g_online_scale = 0.0;
 
 }  // namespace
 
@@ -89,7 +92,10 @@ extern "C" int hc_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ovr, co
     const af::Layout L = af::make_layout(cap, fcap, p->n_edges, p->n_servers, p->n_lb_edges, pk.n_rows, mask);
     std::vector<uint64_t> w(L.n_words ? L.n_words : 1, 0ull);
     const uint32_t pitch = (p->n_edges + 3u * p->n_servers + 3u) & ~3u;
-    af::LaneOut O{clock, samples, counts, clock_cap, tick_cap, pitch};
+    af::LaneOut O{clock, samples, counts, clock_cap, tick_cap, pitch, g_online_hist, g_online_rps, g_online_bins, g_online_buckets,
+                  g_online_scale};
+    if (g_online_hist) std::memset(g_online_hist, 0, 4u * g_online_bins);
+    if (g_online_rps) std::memset(g_online_rps, 0, 4u * g_online_buckets);
     std::vector<uint64_t> tie(L.tie_words, 0ull);
     af::PreDraws D{draws.data(), n_draw, flags_in, tie.data()};
     if (g_two_pass && !V.every_event_in_order) {  // what af_engine_run does: lean variant first, SimPy-order variant on demand
@@ -101,6 +107,8 @@ extern "C" int hc_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ovr, co
         g_reruns += (lean.flags & af::FLAG_SHARED_INSTANT) ? 1 : 0;
         if (!(lean.flags & af::FLAG_SHARED_INSTANT)) return 0;
         std::fill(w.begin(), w.end(), 0xDEADBEEFDEADBEEFull);  // the second pass starts over
+        if (g_online_hist) std::memset(g_online_hist, 0, 4u * g_online_bins);
+        if (g_online_rps) std::memset(g_online_rps, 0, 4u * g_online_buckets);
     }
     af::Lane<MemHost, true> lane(V, L, MemHost{w.data()}, O, D, seed);
     lane.init(ovr_param, idx.data(), n_ovr, [&](uint32_t k) { return ovr_value[k]; });
@@ -114,6 +122,13 @@ extern "C" int hc_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ovr, co
 }
 
 extern "C" void hc_set_two_pass(int on) { g_two_pass = on; }
+extern "C" void hc_set_online(uint32_t* hist, uint32_t bins, double hist_max, uint32_t* rps, uint32_t buckets) {
+    g_online_hist = hist;
+    g_online_bins = bins;
+    g_online_scale = hist ? (double)bins / hist_max : 0.0;
+    g_online_rps = rps;
+    g_online_buckets = buckets;
+}
 extern "C" int hc_reruns(void) { return g_reruns; }
 
 extern "C" uint64_t hc_bytes_per_lane(uint32_t cap, uint32_t fcap, uint32_t n_edges, uint32_t n_servers,

@@ -169,3 +169,36 @@ def test_grid_sweep_and_on_disk_summary(tmp_path):
     t = pq.read_table(tmp_path / "sweep.parquet")
     assert t.num_rows == 18 and t.column("latency:p95").to_pylist() == cols["latency:p95"].tolist()
     assert len(t.column("rps")[0].as_py()) == 20
+
+
+def test_kernel_side_summary_without_the_per_request_clock():
+    """SimulationRunner(online_summary=...): histogram + 1-s windows accumulated by the next-event kernel
+    (exact counts), usable with collect_clock=False; statistics read from it are accurate to one bin."""
+    from asyncflow_amd import SimulationRunner
+
+    payload = lb_with_events(users=150, horizon=40, scale=0.05)
+    seeds = np.arange(48, dtype=np.uint64) + 9
+    bins, hist_max = 2048, 0.256
+    both = SimulationRunner(simulation_input=payload, seeds=seeds, online_summary={"hist_bins": bins, "hist_max": hist_max}).run()
+    hist = both.online_hist.cpu().numpy().view(np.uint32)
+    rps = both.online_rps.cpu().numpy()
+    T = int(both.plan.total_time)
+    for i in range(len(both)):
+        ck = both[i].rqs_clock
+        assert np.array_equal(hist[i], ao.latency_histogram(ck, bins, hist_max))
+        assert np.array_equal(rps[i].astype(np.float64), ao.throughput_series(ck, T)[1])
+    exact = both.summary()["stats"].cpu().numpy()
+    lean = SimulationRunner(simulation_input=payload, seeds=seeds, collect_clock=False, collect_samples=False,
+                            online_summary={"hist_bins": bins, "hist_max": hist_max}).run()
+    assert np.array_equal(lean.counts[:, :5], both.counts[:, :5])
+    summ = lean.summary()
+    approx = summ["stats"].cpu().numpy()
+    assert summ["approximate"] and np.array_equal(approx[:, 0], exact[:, 0])
+    width = hist_max / bins
+    # numpy interpolates between two order statistics, which in a thin tail lie several bins apart
+    assert np.abs(approx[:, 2] - exact[:, 2]).max() <= width                          # median
+    assert np.abs(approx[:, [4, 5]] - exact[:, [4, 5]]).max() <= 4 * width            # p95, p99
+    assert np.abs(approx[:, 1] - exact[:, 1]).max() <= width / 2 + 1e-12             # mean
+    assert np.all(approx[:, 6] <= exact[:, 6]) and np.all(exact[:, 6] - approx[:, 6] <= width)
+    assert np.all(approx[:, 7] >= exact[:, 7]) and np.all(approx[:, 7] - exact[:, 7] <= width)
+    assert np.array_equal(summ["rps"].cpu().numpy(), rps.astype(np.float32))

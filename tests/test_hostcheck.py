@@ -101,6 +101,33 @@ def test_server_to_server_chain_with_zero_delay_hops(dist, mean):
         assert a.ties > 100
 
 
+def test_kernel_side_summary_counts_exactly():
+    """af_outputs_t.online_hist / online_rps: the histogram and the 1-s windows the kernel keeps itself
+    equal the analyzer oracle's on the scenario's own rqs_clock (also through the two-pass flow)."""
+    import ctypes as C
+
+    from oracle import analyzer_oracle as ao
+
+    L = hc.lib()
+    u32p = C.POINTER(C.c_uint32)
+    for two_pass, payload, seed in ((0, lb_two_servers(horizon=20), 3), (1, tie_storm(random.Random(777002), horizon=12), 7),
+                                    (0, stress_mixed(30), 1)):
+        plan = lower(payload)
+        bins, hist_max, buckets = 128, 0.5 if not two_pass else 8.0, int(plan.total_time)
+        hist = np.full(bins, 7, dtype=np.uint32)
+        rps = np.full(buckets, 7, dtype=np.uint32)
+        L.hc_set_two_pass(two_pass)
+        L.hc_set_online(hist.ctypes.data_as(u32p), bins, hist_max, rps.ctypes.data_as(u32p), buckets)
+        try:
+            _, clock, _ = hc.simulate(plan, seed)
+        finally:
+            L.hc_set_online(None, 0, 1.0, None, 0)
+            L.hc_set_two_pass(0)
+        assert len(clock) >= 3
+        assert np.array_equal(hist, ao.latency_histogram(clock, bins, hist_max))
+        assert np.array_equal(rps.astype(np.float64), ao.throughput_series(clock, plan.total_time)[1])
+
+
 def test_overrides_are_applied_per_scenario():
     payload = lb_two_servers(horizon=8)
     plan = lower(payload)

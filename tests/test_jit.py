@@ -13,7 +13,7 @@ LB2_SPEC = (
     "-DAF_JIT_N_SMARKS=0 -DAF_JIT_ORDER_ALL=0 -DAF_JIT_OFF_EDGE=0 -DAF_JIT_OFF_SRV=24 -DAF_JIT_OFF_EP=28 -DAF_JIT_OFF_ROW=32 "
     "-DAF_JIT_OFF_EMARK=50 -DAF_JIT_OFF_SMARK=50 -DAF_JIT_OFF_LB=50 -DAF_JIT_BLOB_BYTES=416 -DAF_JIT_CAP=32 -DAF_JIT_FCAP=16 "
     "-DAF_JIT_OVR_MASK=0 -DAF_JIT_CLOCK_CAP=1000 -DAF_JIT_TICK_CAP=399 -DAF_JIT_N_DRAW=1000 -DAF_JIT_HAS_CLOCK=1 "
-    "-DAF_JIT_HAS_SAMPLES=1"
+    "-DAF_JIT_HAS_SAMPLES=1 -DAF_JIT_HAS_ONLINE=0"
 )
 
 
