@@ -87,7 +87,8 @@ def cpu_baseline(payload: dict, budget_s: float = 12.0) -> dict:
     ol.simulate(plan, SEED_BASE)
     one = max(time.perf_counter() - t0, 1e-3)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    per_core = max(2, min(64, int(budget_s / one)))
+    # (a run takes ~5x longer with every hardware thread busy than alone: 16 per core ~ 15-20 s of wall)
+    per_core = max(2, min(16, int(budget_s / one)))
     jobs = [(payload, [SEED_BASE + c * per_core + k for k in range(per_core)]) for c in range(cores)]
     t0 = time.perf_counter()
     with mp.get_context("fork").Pool(cores) as pool:
