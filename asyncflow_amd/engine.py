@@ -110,15 +110,9 @@ class Engine:
         self._jit_spec: bytes | None = None
         self._jit_image: bytes | None = None
 
-    def run(self, seeds: np.ndarray, overrides: Sequence[tuple[int, int, np.ndarray]], *,
-            clock_ptr: int, clock_capacity: int, samples_ptr: int, tick_capacity: int, counts_ptr: int,
-            draw_capacity: int = 0, specialise: bool = False, online_hist_ptr: int = 0, online_hist_bins: int = 0,
-            online_hist_max: float = 0.0, online_rps_ptr: int = 0, online_rps_buckets: int = 0) -> _abi.AfStats:
-        """Launch the sweep; output pointers are DEVICE addresses owned by the caller.
-
-        ``specialise``: build (or fetch from the cache) kernels with this plan's shape as compile-time
-        constants and use them for this sweep (asyncflow_amd/jit.py; worth it for long sweeps).
-        """
+    def _sweep_structs(self, seeds, overrides, clock_ptr, clock_capacity, samples_ptr, tick_capacity, counts_ptr,
+                       draw_capacity, online_hist_ptr, online_hist_bins, online_hist_max, online_rps_ptr,
+                       online_rps_buckets):
         seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
         n = int(seeds.shape[0])
         cols = [np.ascontiguousarray(v, dtype=np.float64) for _, _, v in overrides]
@@ -135,10 +129,38 @@ class Engine:
                              C.c_void_p(samples_ptr or None), C.c_void_p(counts_ptr),
                              int(online_hist_bins), float(online_hist_max), C.c_void_p(online_hist_ptr or None),
                              int(online_rps_buckets), C.c_void_p(online_rps_ptr or None))
+        return sweep, out, (seeds, cols, ov)     # the last item keeps the host arrays alive
+
+    def run(self, seeds: np.ndarray, overrides: Sequence[tuple[int, int, np.ndarray]], *,
+            clock_ptr: int, clock_capacity: int, samples_ptr: int, tick_capacity: int, counts_ptr: int,
+            draw_capacity: int = 0, specialise: bool = False, online_hist_ptr: int = 0, online_hist_bins: int = 0,
+            online_hist_max: float = 0.0, online_rps_ptr: int = 0, online_rps_buckets: int = 0) -> _abi.AfStats:
+        """Launch the sweep; output pointers are DEVICE addresses owned by the caller.
+
+        ``specialise``: build (or fetch from the cache) kernels with this plan's shape as compile-time
+        constants and use them for this sweep (asyncflow_amd/jit.py; worth it for long sweeps).
+        """
+        sweep, out, _keep = self._sweep_structs(seeds, overrides, clock_ptr, clock_capacity, samples_ptr, tick_capacity,
+                                                counts_ptr, draw_capacity, online_hist_ptr, online_hist_bins,
+                                                online_hist_max, online_rps_ptr, online_rps_buckets)
         if specialise:
             self._specialise(sweep, out)
         _check(self._lib, self._lib.af_engine_run(self._h, C.byref(sweep), C.byref(out)), "af_engine_run")
         return self.stats()
+
+    def prepare(self, seeds: np.ndarray, overrides: Sequence[tuple[int, int, np.ndarray]], **kw) -> None:
+        """Build / load the plan-specialised kernels for a sweep of this shape without running it
+        (same keyword arguments as :meth:`run`)."""
+        kw.pop("specialise", None)
+        defaults = {"draw_capacity": 0, "online_hist_ptr": 0, "online_hist_bins": 0, "online_hist_max": 0.0,
+                    "online_rps_ptr": 0, "online_rps_buckets": 0}
+        defaults.update(kw)
+        sweep, out, _keep = self._sweep_structs(seeds, overrides, defaults["clock_ptr"], defaults["clock_capacity"],
+                                                defaults["samples_ptr"], defaults["tick_capacity"], defaults["counts_ptr"],
+                                                defaults["draw_capacity"], defaults["online_hist_ptr"],
+                                                defaults["online_hist_bins"], defaults["online_hist_max"],
+                                                defaults["online_rps_ptr"], defaults["online_rps_buckets"])
+        self._specialise(sweep, out)
 
     def _specialise(self, sweep: _abi.AfSweep, out: _abi.AfOutputs) -> None:
         import warnings

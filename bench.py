@@ -213,10 +213,14 @@ def main() -> int:
     s_mean = None if samples is None else torch.empty((n, plan.n_series), dtype=torch.float64, device=dev)
     s_max = None if samples is None else torch.empty((n, plan.n_series), dtype=torch.int32, device=dev)
 
+    run_kw = dict(clock_ptr=clock.data_ptr(), clock_capacity=clock_cap,
+                  samples_ptr=samples.data_ptr() if samples is not None else 0, tick_capacity=ticks,
+                  counts_ptr=counts.data_ptr(), draw_capacity=clock_cap)
+    if not args.generic_kernels:
+        eng.prepare(seeds, overrides, **run_kw)     # hipcc run or cache hit: never inside the timed region
+
     def step():
-        eng.run(seeds, overrides, clock_ptr=clock.data_ptr(), clock_capacity=clock_cap,
-                samples_ptr=samples.data_ptr() if samples is not None else 0, tick_capacity=ticks,
-                counts_ptr=counts.data_ptr(), draw_capacity=clock_cap, specialise=not args.generic_kernels)
+        eng.run(seeds, overrides, specialise=not args.generic_kernels, **run_kw)
         return eng.summarize(n, clock_ptr=clock.data_ptr(), clock_capacity=clock_cap,
                              samples_ptr=samples.data_ptr() if samples is not None else 0, tick_capacity=ticks,
                              counts_ptr=counts.data_ptr(), stats_ptr=s_stats.data_ptr(), rps_ptr=s_rps.data_ptr(),
