@@ -70,13 +70,70 @@ def build_fixture(name: str) -> dict[str, np.ndarray]:
     }
 
 
+POOLED_PATH = GOLDEN_DIR / "pooled_lb2_numpy.npz"
+POOLED_BINS, POOLED_MAX = 25_600, 0.256      # 10-us latency bins, last bin takes the overflow
+
+
+def _pooled_worker(seed: int) -> dict[str, np.ndarray]:
+    """One replica of two_servers_lb.yml on the STOCK reference: numpy PCG64 seeded through the
+    `runner.rng` seam of /root/reference/tests/integration/single_server/test_int_single_server.py:36."""
+    from asyncflow_amd.workloads import lb_two_servers
+    from oracle.reference_runner import run_reference_numpy
+
+    an = run_reference_numpy(lb_two_servers(), seed)
+    st = {str(getattr(k, "value", k)): float(v) for k, v in an.get_latency_stats().items()}
+    lat = np.asarray(an.latencies, dtype=np.float64)
+    hist = np.bincount(np.minimum((lat * (POOLED_BINS / POOLED_MAX)).astype(np.int64), POOLED_BINS - 1), minlength=POOLED_BINS)
+    rps = np.asarray(an.get_throughput_series()[1], dtype=np.float64)
+    sm = an.get_sampled_metrics()
+    series = {f"{m}:{ent}": float(np.mean(v)) for m, d in sm.items() for ent, v in d.items()}
+    return {
+        "stats": np.asarray([st[k] for k in STAT_KEYS], dtype=np.float64),
+        "hist": hist.astype(np.int64),
+        "thin": lat[500::1000].copy(),     # every 1000th completion: ~7.5 s apart, practically independent
+        "rps_mean": np.float64(rps.mean()),
+        "series_keys": np.array(json.dumps(sorted(series))),
+        "series_mean": np.asarray([series[k] for k in sorted(series)], dtype=np.float64),
+    }
+
+
+def build_pooled(n_seeds: int, procs: int) -> None:
+    """SURVEY 8d criterion (2): pooled statistics of >= 256 numpy-seeded reference replicas of LB-2."""
+    import multiprocessing as mp
+
+    with mp.get_context("fork").Pool(procs) as pool:
+        parts = pool.map(_pooled_worker, range(n_seeds), chunksize=1)
+    np.savez_compressed(
+        POOLED_PATH,
+        n_seeds=np.int64(n_seeds),
+        seeds=np.arange(n_seeds, dtype=np.int64),
+        stats=np.stack([p["stats"] for p in parts]),
+        hist=np.sum([p["hist"] for p in parts], axis=0),
+        hist_bins=np.int64(POOLED_BINS), hist_max=np.float64(POOLED_MAX),
+        thin=np.concatenate([p["thin"] for p in parts]),
+        rps_mean=np.asarray([p["rps_mean"] for p in parts]),
+        series_keys=parts[0]["series_keys"],
+        series_mean=np.stack([p["series_mean"] for p in parts]),
+        simpy_flavour=np.array(ref_env.simpy_flavour()),
+        generator=np.array("numpy PCG64 via runner.rng = np.random.default_rng(seed); unmodified reference actors"),
+    )
+    print(f"pooled: {n_seeds} replicas -> {POOLED_PATH.name} ({POOLED_PATH.stat().st_size} B)")
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--pooled", type=int, default=0, metavar="N",
+                    help="write tests/golden/pooled_lb2_numpy.npz from N numpy-seeded reference replicas of LB-2 "
+                         "(T = 600 s; ~12 s of one core each)")
+    ap.add_argument("--procs", type=int, default=8)
     ap.add_argument("names", nargs="*")
     args = ap.parse_args()
     ref_env.install()
     GOLDEN_DIR.mkdir(parents=True, exist_ok=True)
+    if args.pooled:
+        build_pooled(args.pooled, args.procs)
+        return 0
     rc = 0
     for name in args.names or list(GOLDEN):
         fx = build_fixture(name)

@@ -1,8 +1,9 @@
-"""Scenario library shared by the golden generator, the tests and bench.py.
+"""Scenario library of the golden generator and the tests.
 
-ORACLE / TEST INFRASTRUCTURE (bench.py only uses the two builders that restate
-BASELINE.json's configs; they contain no reference code, only the YAML values of
-/root/reference/examples/yaml_input/data/*.yml re-typed as Python dicts).
+ORACLE / TEST INFRASTRUCTURE.  The BASELINE.json workloads themselves (the values of
+/root/reference/examples/yaml_input/data/*.yml as dicts) live in the product package,
+asyncflow_amd/workloads.py, and are only re-exported here; this module adds the
+generality / fuzz / tie-storm payloads the parity tests need.
 """
 
 from __future__ import annotations
@@ -11,132 +12,15 @@ import copy
 import random
 from typing import Any
 
-
-def _server(sid: str, cores: int = 1, ram: int = 2048, endpoints: list | None = None) -> dict:
-    if endpoints is None:
-        endpoints = [_endpoint("/api", [("initial_parsing", 0.002), ("ram", 128), ("io_wait", 0.012)])]
-    return {"id": sid, "server_resources": {"cpu_cores": cores, "ram_mb": ram}, "endpoints": endpoints}
-
-
-def _endpoint(name: str, steps: list[tuple[str, float]]) -> dict:
-    out = []
-    for kind, val in steps:
-        key = "necessary_ram" if kind == "ram" else ("cpu_time" if kind in ("initial_parsing", "cpu_bound_operation") else "io_waiting_time")
-        out.append({"kind": kind, "step_operation": {key: val}})
-    return {"endpoint_name": name, "steps": out}
-
-
-def _edge(eid: str, src: str, tgt: str, mean: float, dist: str = "exponential", variance: float | None = None, dropout: float | None = None) -> dict:
-    lat: dict[str, Any] = {"mean": mean, "distribution": dist}
-    if variance is not None:
-        lat["variance"] = variance
-    e: dict[str, Any] = {"id": eid, "source": src, "target": tgt, "latency": lat}
-    if dropout is not None:
-        e["dropout_rate"] = dropout
-    return e
-
-
-def single_server(users: float = 100, rpm: float = 20, horizon: int = 300, period: float = 0.05) -> dict:
-    """examples/yaml_input/data/single_server.yml (BASELINE config 1; the file says T=500)."""
-    return {
-        "rqs_input": {
-            "id": "rqs-1",
-            "avg_active_users": {"mean": users},
-            "avg_request_per_minute_per_user": {"mean": rpm},
-            "user_sampling_window": 60,
-        },
-        "topology_graph": {
-            "nodes": {
-                "client": {"id": "client-1"},
-                "servers": [_server("srv-1", 1, 2048, [_endpoint("ep-1", [("initial_parsing", 0.001), ("ram", 100), ("io_wait", 0.1)])])],
-            },
-            "edges": [
-                _edge("gen-to-client", "rqs-1", "client-1", 0.003),
-                _edge("client-to-server", "client-1", "srv-1", 0.003),
-                _edge("server-to-client", "srv-1", "client-1", 0.003),
-            ],
-        },
-        "sim_settings": {"total_simulation_time": horizon, "sample_period_s": period},
-    }
-
-
-def lb_two_servers(users: float = 400, rpm: float = 20, horizon: int = 600, period: float = 0.05, algo: str = "round_robin") -> dict:
-    """examples/yaml_input/data/two_servers_lb.yml:14-71 (BASELINE config 2, "LB-2")."""
-    return {
-        "rqs_input": {
-            "id": "rqs-1",
-            "avg_active_users": {"mean": users},
-            "avg_request_per_minute_per_user": {"mean": rpm},
-            "user_sampling_window": 60,
-        },
-        "topology_graph": {
-            "nodes": {
-                "client": {"id": "client-1"},
-                "load_balancer": {"id": "lb-1", "algorithms": algo, "server_covered": ["srv-1", "srv-2"]},
-                "servers": [_server("srv-1"), _server("srv-2")],
-            },
-            "edges": [
-                _edge("gen-client", "rqs-1", "client-1", 0.003),
-                _edge("client-lb", "client-1", "lb-1", 0.002),
-                _edge("lb-srv1", "lb-1", "srv-1", 0.002),
-                _edge("lb-srv2", "lb-1", "srv-2", 0.002),
-                _edge("srv1-client", "srv-1", "client-1", 0.003),
-                _edge("srv2-client", "srv-2", "client-1", 0.003),
-            ],
-        },
-        "sim_settings": {
-            "total_simulation_time": horizon,
-            "sample_period_s": period,
-            "enabled_sample_metrics": ["ready_queue_len", "event_loop_io_sleep", "ram_in_use", "edge_concurrent_connection"],
-            "enabled_event_metrics": ["rqs_clock"],
-        },
-    }
-
-
-def lb_with_events(users: float = 120, horizon: int = 600, scale: float = 1.0) -> dict:
-    """examples/yaml_input/data/event_inj_lb.yml:73-102 (BASELINE config 4's events).
-
-    ``scale`` compresses the event times so short-horizon fixtures still see them.
-    """
-    p = lb_two_servers(users=users, horizon=horizon)
-    s = scale
-    p["events"] = [
-        {"event_id": "ev-spike-1", "target_id": "client-lb",
-         "start": {"kind": "network_spike_start", "t_start": 100.0 * s, "spike_s": 0.015}, "end": {"kind": "network_spike_end", "t_end": 160.0 * s}},
-        {"event_id": "ev-srv1-down", "target_id": "srv-1",
-         "start": {"kind": "server_down", "t_start": 180.0 * s}, "end": {"kind": "server_up", "t_end": 240.0 * s}},
-        {"event_id": "ev-spike-2", "target_id": "lb-srv2",
-         "start": {"kind": "network_spike_start", "t_start": 300.0 * s, "spike_s": 0.020}, "end": {"kind": "network_spike_end", "t_end": 360.0 * s}},
-        {"event_id": "ev-srv2-down", "target_id": "srv-2",
-         "start": {"kind": "server_down", "t_start": 360.0 * s}, "end": {"kind": "server_up", "t_end": 420.0 * s}},
-        {"event_id": "ev-spike-3", "target_id": "gen-client",
-         "start": {"kind": "network_spike_start", "t_start": 480.0 * s, "spike_s": 0.010}, "end": {"kind": "network_spike_end", "t_end": 540.0 * s}},
-    ]
-    return p
-
-
-def fanout8(users: float = 120, horizon: int = 600, period: float = 0.05) -> dict:
-    """BASELINE config 5: LB -> 8 identical servers, log-normal edges."""
-    servers = [_server(f"srv-{i}") for i in range(1, 9)]
-    edges = [
-        _edge("gen-client", "rqs-1", "client-1", 0.001, "log_normal", 0.25),
-        _edge("client-lb", "client-1", "lb-1", 0.001, "log_normal", 0.25),
-    ]
-    for i in range(1, 9):
-        edges.append(_edge(f"lb-srv{i}", "lb-1", f"srv-{i}", 0.001, "log_normal", 0.25))
-        edges.append(_edge(f"srv{i}-client", f"srv-{i}", "client-1", 0.001, "log_normal", 0.25))
-    return {
-        "rqs_input": {"id": "rqs-1", "avg_active_users": {"mean": users}, "avg_request_per_minute_per_user": {"mean": 20}, "user_sampling_window": 60},
-        "topology_graph": {
-            "nodes": {
-                "client": {"id": "client-1"},
-                "load_balancer": {"id": "lb-1", "algorithms": "round_robin", "server_covered": [f"srv-{i}" for i in range(1, 9)]},
-                "servers": servers,
-            },
-            "edges": edges,
-        },
-        "sim_settings": {"total_simulation_time": horizon, "sample_period_s": period},
-    }
+from asyncflow_amd.workloads import (  # noqa: E402,F401  (BASELINE workloads live in the package)
+    _edge,
+    _endpoint,
+    _server,
+    fanout8,
+    lb_two_servers,
+    lb_with_events,
+    single_server,
+)
 
 
 def stress_mixed(horizon: int = 40) -> dict:
