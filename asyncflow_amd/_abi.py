@@ -12,6 +12,8 @@ import ctypes as C
 AF_ABI_VERSION = 2
 
 # af_status
+MAX_REQUEST_CAPACITY = 65535   # include/asyncflow_hip.h AF_MAX_REQUEST_CAPACITY
+MAX_FIFO_CAPACITY = 16384      # AF_MAX_FIFO_CAPACITY
 AF_OK = 0
 AF_ERR_INVALID = -1
 AF_ERR_NO_DEVICE = -2

@@ -123,7 +123,7 @@ AF_HD uint64_t d2u(double d) { return __builtin_bit_cast(uint64_t, d); }
 //   [S][fcap][2] = {start time, state}; LB order [n_lb] (only used when n_lb > 8).
 struct Layout {
     uint32_t cap;       // pending timed events (== requests in flight) per scenario
-    uint32_t fcap;      // per-server wait-queue capacity (power of two, <= 32768)
+    uint32_t fcap;      // per-server wait-queue capacity (power of two, <= 16384: rq_n is a 15-bit field)
     uint32_t ovr_mask;  // bit p set: af_param class p is overridden per scenario
     uint32_t hk, ha, hb, edge, ring, stime, srv, cq, rq, lb, n_words;
     // per-scenario HBM scratch of the shared-timestamp path (64-bit words, plain array):

@@ -338,53 +338,71 @@ __global__ __launch_bounds__(kThreads) void af_summary_kernel(SumArgs a) {
 }
 
 // Per-series mean and maximum of the sampled metrics of every scenario
-// (samples [n][tick_cap][pitch] u32; only the first counts[CNT_TICKS] rows are valid).
+// (samples [n][tick_cap][pitch] 4-byte words; only the first counts[CNT_TICKS] rows are valid).
+// Column j < n_edges and the ready / io columns of a server hold int32 counts; the ram_in_use
+// column (j = n_edges + 3 s + 2) holds float32 values (include/asyncflow_hip.h): its mean is the
+// f64 sum of the float values / ticks, its maximum the float maximum, returned as float32 bits
+// (for non-negative floats the bit patterns order like the values).
 struct SeriesArgs {
     const uint32_t* samples;
     const uint32_t* counts;
-    uint32_t tick_cap, pitch, n_series, cnt_ticks_slot;
+    uint32_t tick_cap, pitch, n_series, cnt_ticks_slot, n_edges;
     double* mean;    // [n][n_series]
     uint32_t* maxv;  // [n][n_series]
 };
 
 constexpr int kSeriesThreads = 256;
 
+__device__ __forceinline__ bool series_is_float(uint32_t j, uint32_t n_edges, uint32_t n_series) {
+    return j >= n_edges && j < n_series && (j - n_edges) % 3u == 2u;
+}
+
 __global__ __launch_bounds__(kSeriesThreads) void af_series_kernel(SeriesArgs a) {
-    extern __shared__ unsigned long long sdyn[];  // [pitch] sums, then [pitch] u32 maxima
-    unsigned long long* sum_l = sdyn;
-    uint32_t* max_l = reinterpret_cast<uint32_t*>(sdyn + a.pitch);
+    // per-thread partial sums [thread][4] (u64 integer sum or f64 bits) and maxima, reduced per column
+    // in thread order: the result does not depend on scheduling
+    __shared__ unsigned long long part_sum[kSeriesThreads][4];
+    __shared__ uint32_t part_max[kSeriesThreads][4];
     const int tid = threadIdx.x;
     const uint32_t sc = blockIdx.x;
     uint32_t ticks = a.counts[(size_t)sc * 8u + a.cnt_ticks_slot];
     if (ticks > a.tick_cap) ticks = a.tick_cap;
-    for (uint32_t i = tid; i < a.pitch; i += kSeriesThreads) {
-        sum_l[i] = 0ull;
-        max_l[i] = 0u;
-    }
-    __syncthreads();
     const uint32_t pq = a.pitch / 4u;                       // 16-byte groups per row
     const uint32_t stride = (kSeriesThreads / pq) * pq;     // keeps a thread on one column group
     const uint4* rows = reinterpret_cast<const uint4*>(a.samples + (size_t)sc * a.tick_cap * a.pitch);
     const uint32_t total = ticks * pq;
+    const uint32_t col = ((uint32_t)tid % pq) * 4u;
+    unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    double f0 = 0.0, f1 = 0.0, f2 = 0.0, f3 = 0.0;
+    uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
     if ((uint32_t)tid < stride) {
-        unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-        uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
         for (uint32_t i = tid; i < total; i += stride) {
             const uint4 v = rows[i];
             s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+            f0 += (double)__uint_as_float(v.x); f1 += (double)__uint_as_float(v.y);
+            f2 += (double)__uint_as_float(v.z); f3 += (double)__uint_as_float(v.w);
             m0 = v.x > m0 ? v.x : m0; m1 = v.y > m1 ? v.y : m1;
             m2 = v.z > m2 ? v.z : m2; m3 = v.w > m3 ? v.w : m3;
         }
-        const uint32_t col = ((uint32_t)tid % pq) * 4u;
-        atomicAdd(&sum_l[col + 0], s0); atomicAdd(&sum_l[col + 1], s1);
-        atomicAdd(&sum_l[col + 2], s2); atomicAdd(&sum_l[col + 3], s3);
-        atomicMax(&max_l[col + 0], m0); atomicMax(&max_l[col + 1], m1);
-        atomicMax(&max_l[col + 2], m2); atomicMax(&max_l[col + 3], m3);
     }
+    part_sum[tid][0] = series_is_float(col + 0u, a.n_edges, a.n_series) ? (unsigned long long)__double_as_longlong(f0) : s0;
+    part_sum[tid][1] = series_is_float(col + 1u, a.n_edges, a.n_series) ? (unsigned long long)__double_as_longlong(f1) : s1;
+    part_sum[tid][2] = series_is_float(col + 2u, a.n_edges, a.n_series) ? (unsigned long long)__double_as_longlong(f2) : s2;
+    part_sum[tid][3] = series_is_float(col + 3u, a.n_edges, a.n_series) ? (unsigned long long)__double_as_longlong(f3) : s3;
+    part_max[tid][0] = m0; part_max[tid][1] = m1; part_max[tid][2] = m2; part_max[tid][3] = m3;
     __syncthreads();
     for (uint32_t j = tid; j < a.n_series; j += kSeriesThreads) {
-        if (a.mean) a.mean[(size_t)sc * a.n_series + j] = ticks ? (double)sum_l[j] / (double)ticks : __builtin_nan("");
-        if (a.maxv) a.maxv[(size_t)sc * a.n_series + j] = max_l[j];
+        const uint32_t g = j / 4u, k = j % 4u;
+        const bool is_f = series_is_float(j, a.n_edges, a.n_series);
+        unsigned long long si = 0;
+        double sf = 0.0;
+        uint32_t mx = 0;
+        for (uint32_t t = g; t < stride; t += pq) {  // the threads of this column group, in order
+            if (is_f) sf += __longlong_as_double((long long)part_sum[t][k]);
+            else si += part_sum[t][k];
+            mx = part_max[t][k] > mx ? part_max[t][k] : mx;
+        }
+        if (a.mean) a.mean[(size_t)sc * a.n_series + j] = ticks ? (is_f ? sf : (double)si) / (double)ticks : __builtin_nan("");
+        if (a.maxv) a.maxv[(size_t)sc * a.n_series + j] = mx;
     }
 }
 

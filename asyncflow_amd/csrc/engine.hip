@@ -684,9 +684,10 @@ int af_engine_create(const af_plan_t* plan, int device, const af_engine_options_
         return fail(AF_ERR_INVALID, "lanes_per_wave must be 0 (auto) or a power of two <= 64");
     }
     if (e->lanes_per_wave > 64u) e->lanes_per_wave = 64u;
-    if (e->request_capacity > 65535u || e->fifo_capacity > 32768u) {
+    // (the RAM wait-queue count is a 15-bit field next to the 'starved' bit, af_core.hpp: 16384 keeps it clear)
+    if (e->request_capacity > 65535u || e->fifo_capacity > AF_MAX_FIFO_CAPACITY) {
         delete e;
-        return fail(AF_ERR_CAPACITY, "request_capacity must be <= 65535 and fifo_capacity <= 32768");
+        return fail(AF_ERR_CAPACITY, "request_capacity must be <= 65535 and fifo_capacity <= 16384");
     }
     if (a.blob_bytes > kLdsLimit / 2) {
         delete e;
@@ -1057,10 +1058,11 @@ int af_engine_summarize(af_engine_t* e, const af_outputs_t* out, const af_summar
         s.pitch = e->args.series_pitch;
         s.n_series = e->args.n_edges + 3u * e->args.n_servers;
         s.cnt_ticks_slot = AF_CNT_TICKS;
+        s.n_edges = e->args.n_edges;
         s.mean = sum->series_mean;
         s.maxv = sum->series_max;
-        const size_t lds = (size_t)s.pitch * 12u;
-        hipLaunchKernelGGL(afs::af_series_kernel, dim3(sum->n_scenarios), dim3(afs::kSeriesThreads), lds, e->stream, s);
+        if (s.pitch / 4u > (uint32_t)afs::kSeriesThreads) return fail(AF_ERR_CAPACITY, "too many sampled series for af_series_kernel");
+        hipLaunchKernelGGL(afs::af_series_kernel, dim3(sum->n_scenarios), dim3(afs::kSeriesThreads), 0, e->stream, s);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(e->ev1, e->stream));

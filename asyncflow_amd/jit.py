@@ -7,7 +7,10 @@ plan's shape disappear -- about 8 % less kernel time on the 10 000-replica LB-2 
 bit-identical (tests/test_gpu_parity.py).
 
 One ``hipcc --genco`` call (~4 s) per distinct spec; code objects are cached in
-``asyncflow_amd/csrc/_jit/`` keyed by the spec and the sources' contents.
+``$ASYNCFLOW_JIT_CACHE`` (default ``asyncflow_amd/csrc/_jit/``; ``~/.cache/asyncflow_amd/jit`` when the
+package directory is read-only) keyed by the spec and the sources' contents.  Every failure on the
+way -- no hipcc, an unwritable cache, a failed build -- is a :class:`JitUnavailableError`: the caller
+falls back to the generic kernels, it never crashes a run.
 """
 
 from __future__ import annotations
@@ -21,7 +24,8 @@ from pathlib import Path
 
 from .build import ARCH, CSRC, hipcc_path
 
-CACHE_DIR = CSRC / "_jit"
+CACHE_DIR = Path(os.environ["ASYNCFLOW_JIT_CACHE"]) if os.environ.get("ASYNCFLOW_JIT_CACHE") else CSRC / "_jit"
+_FALLBACK_CACHE_DIR = Path.home() / ".cache" / "asyncflow_amd" / "jit"
 _SOURCES = ("engine.hip", "af_core.hpp", "af_math.hpp", "af_plan_pack.hpp", "af_summary.hpp")
 _FLAGS = (f"--offload-arch={ARCH}", "--genco", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
           "-Wno-unused-function")
@@ -43,24 +47,43 @@ def _sources_digest() -> str:
     return _source_digest
 
 
+def _writable_cache_dir() -> Path:
+    for cand in (CACHE_DIR, _FALLBACK_CACHE_DIR):
+        try:
+            cand.mkdir(parents=True, exist_ok=True)
+            with tempfile.NamedTemporaryFile(dir=cand, suffix=".probe"):
+                pass
+        except OSError:
+            continue
+        return cand
+    msg = f"no writable cache directory for plan-specialised kernels ({CACHE_DIR}, {_FALLBACK_CACHE_DIR})"
+    raise JitUnavailableError(msg)
+
+
 def code_object(spec: str) -> bytes:
     """The code object for ``spec`` (the ``-D`` flags from ``af_engine_jit_spec``), built on demand."""
     key = hashlib.sha1((_sources_digest() + "\n" + spec + "\n" + " ".join(_FLAGS)).encode()).hexdigest()
-    path = CACHE_DIR / f"{key}.hsaco"
-    if path.exists():
-        return path.read_bytes()
+    for cand in (CACHE_DIR, _FALLBACK_CACHE_DIR):
+        try:
+            return (cand / f"{key}.hsaco").read_bytes()
+        except OSError:
+            continue
     try:
         hipcc = hipcc_path()
     except RuntimeError as exc:
         raise JitUnavailableError(str(exc)) from exc
-    CACHE_DIR.mkdir(parents=True, exist_ok=True)
-    with tempfile.NamedTemporaryFile(dir=CACHE_DIR, suffix=".tmp", delete=False) as tmp:
-        tmp_path = Path(tmp.name)
-    cmd = [hipcc, *_FLAGS, *shlex.split(spec), "-o", str(tmp_path), str(CSRC / "engine.hip")]
-    res = subprocess.run(cmd, capture_output=True, text=True, check=False)
-    if res.returncode != 0 or tmp_path.stat().st_size == 0:
-        tmp_path.unlink(missing_ok=True)
-        msg = f"hipcc --genco failed ({res.returncode}):\n{res.stderr[-2000:]}"
-        raise JitUnavailableError(msg)
-    os.replace(tmp_path, path)          # atomic: concurrent ranks may build the same object
-    return path.read_bytes()
+    try:
+        cache = _writable_cache_dir()
+        path = cache / f"{key}.hsaco"
+        with tempfile.NamedTemporaryFile(dir=cache, suffix=".tmp", delete=False) as tmp:
+            tmp_path = Path(tmp.name)
+        cmd = [hipcc, *_FLAGS, *shlex.split(spec), "-o", str(tmp_path), str(CSRC / "engine.hip")]
+        res = subprocess.run(cmd, capture_output=True, text=True, check=False)
+        if res.returncode != 0 or tmp_path.stat().st_size == 0:
+            tmp_path.unlink(missing_ok=True)
+            msg = f"hipcc --genco failed ({res.returncode}):\n{res.stderr[-2000:]}"
+            raise JitUnavailableError(msg)
+        os.replace(tmp_path, path)          # atomic: concurrent ranks may build the same object
+        return path.read_bytes()
+    except OSError as exc:                  # read-only install, full disk, hipcc not executable, ...
+        raise JitUnavailableError(f"{type(exc).__name__}: {exc}") from exc

@@ -302,6 +302,26 @@ def lower(payload: Any) -> DevicePlan:  # noqa: C901, PLR0912, PLR0915
     emark_time = _env_times([m[0] for m in emarks])
     smark_time = _env_times([m[0] for m in smarks])
 
+    # An outage timeline must never leave the load balancer without a live out-edge: the reference
+    # then fails inside the run as soon as a request reaches the LB (`next(iter(...))` on an empty
+    # OrderedDict -> StopIteration, lb_algorithms.py:33; `min()` of an empty sequence, :19), the
+    # payload validators only forbid ALL servers being down at once (schemas/payload.py).  Rejected
+    # here, before anything runs.
+    if lb is not None and smarks:
+        live = list(lb_edges)
+        for m in smarks:
+            ei = edge_by_server.get(m[3], -1)
+            if ei < 0:
+                continue
+            if ei in live:
+                live.remove(ei)
+            if m[1] == 0:      # SERVER_UP: re-appended at the tail (injection.py:218-226)
+                live.append(ei)
+            if not live:
+                msg = (f"event '{m[2]}' takes the last live server behind load balancer '{lb['id']}' down at "
+                       f"t={m[0]}: the load balancer would have no out-edge to route to")
+                raise ValueError(msg)
+
     mask = 0
     for m in st["enabled_sample_metrics"]:
         mask |= _abi.METRIC_BITS[m]

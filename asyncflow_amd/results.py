@@ -211,6 +211,19 @@ class BatchedResults:
         self.overrides = overrides or {}
         #: kernel-side summary (SimulationRunner(online_summary=...)): int32 [n, bins] / [n, floor(T)] on the device
         self.online_hist, self.online_rps, self.online_hist_max = online_hist, online_rps, float(online_hist_max)
+        self._summ_engine: Any = None      # one af_engine_t serves every summary() call of this object
+
+    def close(self) -> None:
+        """Release the analyzer engine kept by :meth:`summary` (also done on garbage collection)."""
+        if self._summ_engine is not None:
+            self._summ_engine.close()
+            self._summ_engine = None
+
+    def __del__(self) -> None:  # pragma: no cover - best effort
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
     def __len__(self) -> int:
         return int(self.counts.shape[0])
@@ -258,7 +271,8 @@ class BatchedResults:
         LATENCY_KEYS order (= ``ResultsAnalyzer.get_latency_stats`` per scenario,
         metrics/analyzer.py:83-104), ``rps`` float32 [n, floor(T)] (analyzer.py:108-126),
         ``hist`` int32 [n, hist_bins], ``series_mean`` float64 / ``series_max`` int32
-        [n, n_series].  Order statistics (median, p95, p99, min, max) are bit-equal to
+        [n, n_series] (the ram_in_use columns of ``series_max`` hold float32 BITS, like the sample
+        words they are the maximum of: decode with :meth:`decode_series_max`).  Order statistics (median, p95, p99, min, max) are bit-equal to
         numpy's; mean/std agree to ~1e-13 relative (different summation order).
         """
         import torch
@@ -283,22 +297,20 @@ class BatchedResults:
         smean = torch.empty((n, self.plan.n_series), dtype=torch.float64, device=dev) if series else None
         smax = torch.empty((n, self.plan.n_series), dtype=torch.int32, device=dev) if series else None
         torch.cuda.synchronize(dev)
-        eng = Engine(self.plan, dev.index if dev.index is not None else torch.cuda.current_device())
-        try:
-            st = eng.summarize(
-                n,
-                clock_ptr=clock.data_ptr(), clock_capacity=cap,
-                samples_ptr=self._samples_t.data_ptr() if self._samples_t is not None else 0,
-                tick_capacity=int(self._samples_t.shape[1]) if self._samples_t is not None else 0,
-                counts_ptr=self._counts_t.data_ptr(),
-                stats_ptr=stats.data_ptr(),
-                rps_ptr=rps_t.data_ptr() if rps_t is not None else 0, rps_buckets=T if rps_t is not None else 0,
-                hist_ptr=hist_t.data_ptr() if hist_t is not None else 0, hist_bins=hist_bins, hist_max=hist_max,
-                series_mean_ptr=smean.data_ptr() if smean is not None else 0,
-                series_max_ptr=smax.data_ptr() if smax is not None else 0,
-            )
-        finally:
-            eng.close()
+        if self._summ_engine is None:
+            self._summ_engine = Engine(self.plan, dev.index if dev.index is not None else torch.cuda.current_device())
+        st = self._summ_engine.summarize(
+            n,
+            clock_ptr=clock.data_ptr(), clock_capacity=cap,
+            samples_ptr=self._samples_t.data_ptr() if self._samples_t is not None else 0,
+            tick_capacity=int(self._samples_t.shape[1]) if self._samples_t is not None else 0,
+            counts_ptr=self._counts_t.data_ptr(),
+            stats_ptr=stats.data_ptr(),
+            rps_ptr=rps_t.data_ptr() if rps_t is not None else 0, rps_buckets=T if rps_t is not None else 0,
+            hist_ptr=hist_t.data_ptr() if hist_t is not None else 0, hist_bins=hist_bins, hist_max=hist_max,
+            series_mean_ptr=smean.data_ptr() if smean is not None else 0,
+            series_max_ptr=smax.data_ptr() if smax is not None else 0,
+        )
         out: dict[str, Any] = {"stats": stats, "keys": LATENCY_KEYS, "summary_ms": float(st.summary_ms)}
         if rps_t is not None:
             out["rps"] = rps_t
@@ -376,7 +388,7 @@ class BatchedResults:
             cols["latency_hist_edges"] = np.linspace(0.0, float(hist_max), hist_bins + 1)
         if "series_mean" in summ:
             cols["series_mean"] = summ["series_mean"].cpu().numpy()
-            cols["series_max"] = summ["series_max"].cpu().numpy().view(np.uint32)
+            cols["series_max"] = self.decode_series_max(summ["series_max"].cpu().numpy())
             cols["series_names"] = np.asarray(self.series_names())
         path = str(path)
         if path.endswith(".parquet"):
@@ -392,6 +404,16 @@ class BatchedResults:
             np.savez_compressed(path, **cols)
         return cols
 
+    def decode_series_max(self, words: np.ndarray) -> np.ndarray:
+        """``series_max`` words [n, n_series] -> float64 values (counts as they are, the ram_in_use
+        columns decoded from their float32 bits)."""
+        w = np.ascontiguousarray(words).view(np.uint32)
+        out = w.astype(np.float64)
+        j = np.arange(w.shape[1])
+        ram = (j >= self.plan.n_edges) & ((j - self.plan.n_edges) % 3 == 2)
+        out[:, ram] = w[:, ram].view(np.float32).astype(np.float64)
+        return out
+
     def series_names(self) -> list[str]:
         """Names of the sampled series in device order: edges, then ready/io/ram per server."""
         names = [f"{e}:edge_concurrent_connection" for e in self.plan.edge_ids]
@@ -406,14 +428,17 @@ class BatchedResults:
         across scenarios per 1-s window)."""
         from statistics import NormalDist
 
+        import torch
+
         summ = self.summary(rps=True)
-        stats = summ["stats"].cpu().numpy()
-        ok = stats[:, 0] > 0
+        st = summ["stats"]                                  # [n, 8] on the run's device: reduced there,
+        ok = st[:, 0] > 0                                   # only the 8-vectors and the [T] bands come back
         z = NormalDist().inv_cdf(0.5 + level / 2.0)
         k = int(ok.sum())
-        body = stats[ok]
-        mean = body.mean(axis=0) if k else np.full(8, np.nan)
-        sd = body.std(axis=0, ddof=1) if k > 1 else np.full(8, np.nan)
+        body = st[ok]
+        nan8 = np.full(8, np.nan)
+        mean = body.mean(dim=0).cpu().numpy() if k else nan8
+        sd = body.std(dim=0, unbiased=True).cpu().numpy() if k > 1 else nan8
         out: dict[str, Any] = {
             "n": k,
             "keys": LATENCY_KEYS,
@@ -423,7 +448,33 @@ class BatchedResults:
             "level": level,
         }
         if "rps" in summ:
-            r = summ["rps"].cpu().numpy().astype(np.float64)
-            out["rps_mean"] = r.mean(axis=0)
-            out["rps_p05"], out["rps_p95"] = np.percentile(r, [5.0, 95.0], axis=0)
+            r = summ["rps"].to(torch.float64)
+            out["rps_mean"] = r.mean(dim=0).cpu().numpy()
+            q = torch.quantile(r, torch.tensor([0.05, 0.95], dtype=torch.float64, device=r.device), dim=0)
+            out["rps_p05"], out["rps_p95"] = q[0].cpu().numpy(), q[1].cpu().numpy()
         return out
+
+
+def load_summary(path: str) -> dict[str, np.ndarray]:
+    """Read a sweep summary written by :meth:`BatchedResults.save_summary` (``.npz`` or ``.parquet``)
+    back into the same columns: one row per scenario (``seed``, ``param:*``, counts, ``latency:*``,
+    ``rps`` [n, floor(T)], ``latency_hist`` [n, bins], ``series_mean`` / ``series_max`` [n, n_series])
+    plus the per-sweep vectors (``latency_hist_edges``, ``series_names``)."""
+    path = str(path)
+    if path.endswith(".parquet"):
+        import pyarrow.parquet as pq
+
+        table = pq.read_table(path)
+        cols: dict[str, np.ndarray] = {}
+        for name in table.column_names:
+            col = table.column(name).to_pylist()
+            cols[name] = np.asarray(col, dtype=np.uint64 if name == "seed" else None)
+        for k, v in (table.schema.metadata or {}).items():
+            key, text = k.decode(), v.decode()
+            if key == "series_names":
+                cols[key] = np.asarray(text.split(","))
+            else:
+                cols[key] = np.asarray([float(x) for x in text.split(",")] if text else [], dtype=np.float64)
+        return cols
+    with np.load(path, allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}

@@ -89,6 +89,14 @@ def resolve_sweep(plan: DevicePlan, sweep: Mapping[str, Any] | None, n: int) -> 
     return out
 
 
+def _fifo_pow2(want: int) -> int:
+    """Smallest power of two >= ``want``, clamped to the engine's wait-queue limit."""
+    p = 8
+    while p < want and p < _abi.MAX_FIFO_CAPACITY:
+        p *= 2
+    return p
+
+
 class SimulationRunner:
     """Build -> lower -> run the batched HIP engine -> results."""
 
@@ -164,8 +172,9 @@ class SimulationRunner:
                 base = float(self.plan.edge_mean[_idx]) or 1.0
                 lat_scale = max(lat_scale, float(col.max()) / base)
         cap, fifo = estimate_capacities(self.plan, users_max, lat_scale, rpm_max)
-        cap = int(self.request_capacity or min(cap, 65535))
-        fifo = int(self.fifo_capacity or min(fifo, cap))
+        cap = int(self.request_capacity or min(cap, _abi.MAX_REQUEST_CAPACITY))
+        # (the engine rounds the FIFO capacity up to a power of two and refuses more than MAX_FIFO_CAPACITY)
+        fifo = int(self.fifo_capacity or _fifo_pow2(min(fifo, cap)))
         clock_cap = int(self.clock_capacity or self.plan.clock_capacity(users_max, rpm_max))
         return cap, fifo, clock_cap
 
@@ -246,9 +255,9 @@ class SimulationRunner:
             # capacities are estimates (Little's law); overflow is flagged by the
             # kernel, never silent -> grow the overflowing pool and run again.
             if over & (_abi.FLAG_POOL_OVERFLOW | _abi.FLAG_FIFO_OVERFLOW):
-                if cap >= 65535 and fifo >= 65536:
-                    break
-                cap, fifo = min(65535, cap * 4), min(65536, fifo * 4)
+                if cap >= _abi.MAX_REQUEST_CAPACITY and fifo >= _abi.MAX_FIFO_CAPACITY:
+                    break           # both pools at their real maxima: raise_on_overflow() below reports it
+                cap, fifo = min(_abi.MAX_REQUEST_CAPACITY, cap * 4), _fifo_pow2(fifo * 4)
             if over & (_abi.FLAG_CLOCK_OVERFLOW | _abi.FLAG_DRAW_OVERFLOW):
                 clock_cap *= 2
             warnings.warn(

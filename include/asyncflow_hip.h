@@ -225,9 +225,12 @@ typedef struct af_outputs {
     uint32_t* online_rps;       /* [n_scenarios][online_rps_buckets] */
 } af_outputs_t;
 
+#define AF_MAX_REQUEST_CAPACITY 65535u
+#define AF_MAX_FIFO_CAPACITY 16384u   /* rounded up to a power of two by the engine */
+
 typedef struct af_engine_options {
-    uint32_t request_capacity;  /* live requests per scenario (0 = engine default) */
-    uint32_t fifo_capacity;     /* waiters per server queue   (0 = engine default) */
+    uint32_t request_capacity;  /* live requests per scenario (0 = engine default, <= AF_MAX_REQUEST_CAPACITY) */
+    uint32_t fifo_capacity;     /* waiters per server queue   (0 = engine default, <= AF_MAX_FIFO_CAPACITY)   */
     uint32_t force_global_state;/* 1 = keep per-scenario state in HBM even if it fits LDS */
     uint32_t lanes_per_wave;    /* scenarios per wavefront: power of two <= 64, 0 = auto
                                    (few scenarios are spread over many narrow waves)    */

@@ -67,11 +67,26 @@ def latency_histogram(clock: np.ndarray, bins: int, hist_max: float) -> np.ndarr
     return np.bincount(b, minlength=bins).astype(np.uint32)
 
 
-def series_mean_max(samples: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
-    """samples [n_series][ticks] u32 -> exact integer sum / ticks (f64) and maximum per series."""
-    samples = np.asarray(samples)
-    ticks = samples.shape[1]
-    sums = samples.astype(np.uint64).sum(axis=1)
-    mean = sums.astype(np.float64) / np.float64(ticks) if ticks else np.full(samples.shape[0], np.nan)
-    mx = samples.max(axis=1) if ticks else np.zeros(samples.shape[0], dtype=np.uint32)
-    return mean, mx.astype(np.uint32)
+def series_mean_max(samples: np.ndarray, n_edges: int | None = None) -> tuple[np.ndarray, np.ndarray]:
+    """samples [n_series][ticks] 4-byte words -> mean (f64) and maximum per series.
+
+    Rows are int32 counts, except the ram_in_use row of every server (row n_edges + 3 s + 2,
+    include/asyncflow_hip.h), which holds float32 values: its mean is the f64 sum of the values /
+    ticks (np.mean of the list the reference keeps, analyzer.py:127-142), its maximum the float
+    maximum returned as float32 bits.  ``n_edges=None`` treats every row as integers.
+    """
+    samples = np.asarray(samples).view(np.uint32)
+    n_series, ticks = samples.shape
+    is_f = np.zeros(n_series, dtype=bool)
+    if n_edges is not None:
+        j = np.arange(n_series)
+        is_f = (j >= n_edges) & ((j - n_edges) % 3 == 2)
+    if not ticks:
+        return np.full(n_series, np.nan), np.zeros(n_series, dtype=np.uint32)
+    mean = samples.astype(np.uint64).sum(axis=1).astype(np.float64) / np.float64(ticks)
+    mx = samples.max(axis=1).astype(np.uint32)
+    for r in np.nonzero(is_f)[0]:
+        vals = samples[r].view(np.float32).astype(np.float64)
+        mean[r] = vals.sum() / np.float64(ticks)
+        mx[r] = np.float32(vals.max()).view(np.uint32)
+    return mean, mx

@@ -134,8 +134,16 @@ def test_summary_of_a_simulated_batch_matches_the_oracle(payload_fn):
         _check_stats(stats[i], ao.latency_stats(sc.rqs_clock), f"scenario {i}")
         assert np.array_equal(rps[i].astype(np.float64), ao.throughput_series(sc.rqs_clock, T)[1])
         assert np.array_equal(hist[i], ao.latency_histogram(sc.rqs_clock, 64, 0.128))
-        m, x = ao.series_mean_max(sc._samples)  # noqa: SLF001
+        m, x = ao.series_mean_max(sc._samples, res.plan.n_edges)  # noqa: SLF001
         assert np.array_equal(smean[i].view(np.uint64), m.view(np.uint64)) and np.array_equal(smax[i], x)
+        # ram_in_use columns hold float32 values: mean / max of the list the drop-in accessor returns
+        sm = sc.get_sampled_metrics()
+        for v, sid in enumerate(res.plan.server_ids):
+            col = res.plan.n_edges + 3 * v + 2
+            ram = np.asarray(sm["ram_in_use"][sid], dtype=np.float64)
+            assert ram.max() > 0.0 and smean[i][col] == ram.sum() / len(ram)
+            assert res.decode_series_max(smax[i:i + 1])[0, col] == ram.max()
+            assert smean[i][col - 1] == np.mean(sm["event_loop_io_sleep"][sid])
         # the drop-in accessor of one scenario agrees with the batched row
         one = sc.get_latency_stats()
         assert one["p95"] == stats[i][4] and one["total_requests"] == stats[i][0]
@@ -169,6 +177,19 @@ def test_grid_sweep_and_on_disk_summary(tmp_path):
     t = pq.read_table(tmp_path / "sweep.parquet")
     assert t.num_rows == 18 and t.column("latency:p95").to_pylist() == cols["latency:p95"].tolist()
     assert len(t.column("rps")[0].as_py()) == 20
+    # load side: both formats come back as the columns save_summary() wrote
+    from asyncflow_amd.results import load_summary
+
+    for name in ("sweep.npz", "sweep.parquet"):
+        back = load_summary(str(tmp_path / name))
+        assert set(back) == set(cols), name
+        for k, v in cols.items():
+            if v.dtype.kind in "US":
+                assert list(back[k]) == list(v), (name, k)
+            else:
+                assert np.array_equal(np.asarray(back[k], dtype=np.float64), v.astype(np.float64), equal_nan=True), (name, k)
+    ram_col = res.plan.n_edges + 2
+    assert cols["series_max"][:, ram_col].max() in (128.0 * np.arange(1, 17))      # decoded MB, not float bits
 
 
 def test_kernel_side_summary_without_the_per_request_clock():

@@ -36,3 +36,24 @@ def test_a_failing_build_is_reported_as_unavailable_not_as_a_crash(tmp_path, mon
     with pytest.raises(jit.JitUnavailableError, match="hipcc --genco failed"):
         jit.code_object("-DAF_JIT=1 -DAF_JIT_LDS=1")            # constants missing: does not compile
     assert not list(tmp_path.iterdir())
+
+
+def test_an_unwritable_cache_is_reported_as_unavailable(tmp_path, monkeypatch):
+    blocker = tmp_path / "file"
+    blocker.write_text("x")                                       # a FILE where the cache directories should be
+    monkeypatch.setattr(jit, "CACHE_DIR", blocker / "a")
+    monkeypatch.setattr(jit, "_FALLBACK_CACHE_DIR", blocker / "b")
+    with pytest.raises(jit.JitUnavailableError, match="no writable cache"):
+        jit.code_object(LB2_SPEC)
+
+
+def test_the_runner_never_asks_for_a_fifo_the_engine_refuses():
+    """saturated payloads used to estimate fifo = 65535 -> AF_ERR_CAPACITY at engine creation."""
+    from asyncflow_amd import _abi
+    from asyncflow_amd.runner import SimulationRunner, _fifo_pow2
+    from oracle.scenarios import overload
+
+    r = SimulationRunner(simulation_input=overload(horizon=600))
+    cap, fifo, _ = r._capacities([])  # noqa: SLF001
+    assert cap <= _abi.MAX_REQUEST_CAPACITY and fifo <= _abi.MAX_FIFO_CAPACITY and fifo & (fifo - 1) == 0
+    assert _fifo_pow2(10**9) == _abi.MAX_FIFO_CAPACITY and _fifo_pow2(9) == 16

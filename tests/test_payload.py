@@ -173,3 +173,24 @@ def test_capacity_estimates_cover_observed_live_requests():
     mean, std = plan.expected_arrivals()
     assert abs(mean - 80000) < 1 and 1000 < std < 2000
     assert plan.clock_capacity() > mean + 6 * std
+
+
+def test_an_outage_that_empties_the_load_balancer_is_rejected_at_lowering():
+    """The LB covers srv-1 only (srv-2 is wired to the client but receives nothing): taking srv-1 down
+    passes the reference's "not all servers down" validator but leaves the LB with nothing to route
+    to -- the reference fails inside the run (StopIteration, lb_algorithms.py:33); lowering refuses."""
+    import copy
+
+    import pytest
+
+    from asyncflow_amd.plan import lower
+    from asyncflow_amd.workloads import lb_two_servers
+
+    p = copy.deepcopy(lb_two_servers(horizon=30))
+    p["topology_graph"]["nodes"]["load_balancer"]["server_covered"] = ["srv-1"]
+    p["topology_graph"]["edges"] = [e for e in p["topology_graph"]["edges"] if e["id"] != "lb-srv2"]
+    lower(p)                                                       # fine without the outage
+    p["events"] = [{"event_id": "down", "target_id": "srv-1", "start": {"kind": "server_down", "t_start": 5.0},
+                    "end": {"kind": "server_up", "t_end": 9.0}}]
+    with pytest.raises(ValueError, match="no out-edge to route to"):
+        lower(p)

@@ -85,3 +85,65 @@ def test_reference_suite_passes_on_the_simpy_standin():
     tail = out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-300:]
     assert out.returncode == 0, tail
     assert "179 passed, 4 skipped" in tail
+
+
+def test_baseline_workloads_equal_the_reference_yaml():
+    """asyncflow_amd/workloads.py restates the reference's example YAMLs value for value: both sides
+    are validated by the reference's own Pydantic models and compared as dumped models."""
+    import yaml
+
+    ref_env.install()
+    from asyncflow.schemas.payload import SimulationPayload
+
+    from asyncflow_amd import workloads as w
+
+    data = ref_env.REFERENCE_ROOT / "examples" / "yaml_input" / "data"
+    cases = {
+        "single_server.yml": w.single_server(horizon=500),
+        "two_servers_lb.yml": w.lb_two_servers(),
+        "event_inj_lb.yml": w.lb_with_events(users=120, horizon=600),
+    }
+    for name, ours in cases.items():
+        theirs = SimulationPayload.model_validate(yaml.safe_load((data / name).read_text())).model_dump(mode="json")
+        mine = SimulationPayload.model_validate(ours).model_dump(mode="json")
+        assert mine == theirs, name
+
+
+def test_results_feed_the_reference_plot_helpers(tmp_path):
+    """ScenarioResults.to_reference_analyzer(): the reference's own ResultsAnalyzer + plot helpers
+    (/root/reference/src/asyncflow/metrics/analyzer.py:264-589) run on the engine's arrays and report
+    the same statistics as the drop-in accessors."""
+    import json
+
+    import matplotlib
+
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+
+    from asyncflow_amd import _abi
+    from asyncflow_amd.results import ScenarioResults
+    from tests.conftest import GOLDEN_DIR
+
+    ref_env.install()
+    fx = np.load(GOLDEN_DIR / "lb2_rr_t30.npz", allow_pickle=False)
+    plan = lower(json.loads(str(fx["payload_json"])))
+    counts = np.zeros(_abi.CNT_SLOTS, dtype=np.uint32)
+    counts[_abi.CNT_GENERATED], counts[_abi.CNT_COMPLETED] = int(fx["generated"]), int(fx["completed"])
+    counts[_abi.CNT_TICKS] = int(fx["ticks"])
+    sc = ScenarioResults(plan, counts, fx["clock"], fx["samples"])
+    an = sc.to_reference_analyzer()
+    theirs = {str(getattr(k, "value", k)): float(v) for k, v in an.get_latency_stats().items()}
+    assert theirs == sc.get_latency_stats()
+    assert an.get_throughput_series()[1] == sc.get_throughput_series()[1]
+    assert an.list_server_ids() == sc.list_server_ids()
+    fig, axes = plt.subplots(2, 2)
+    an.plot_base_dashboard(axes[0][0], axes[0][1])
+    sid = plan.server_ids[0]
+    an.plot_single_server_ready_queue(axes[1][0], sid)
+    an.plot_single_server_ram(axes[1][1], sid)
+    fig.savefig(tmp_path / "dash.png")
+    assert (tmp_path / "dash.png").stat().st_size > 10_000
+    lines = axes[1][1].get_lines()
+    assert lines and np.array_equal(np.asarray(lines[0].get_ydata(), dtype=np.float64),
+                                    np.asarray(sc.get_sampled_metrics()["ram_in_use"][sid], dtype=np.float64))
+    plt.close(fig)
