@@ -1,31 +1,42 @@
 """Benchmark of the hot path: batched `env.run(until=T)` on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--replicas R]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C] [--scenarios S]
 
-Workload (BASELINE.json configs[1], the one the metric is quoted on): the
-2-server + load-balancer topology of examples/yaml_input/data/two_servers_lb.yml
-(400 users x 20 rpm, T = 600 s, 0.05 s sampling), 10 000 seed replicas per GPU,
-scenario i uses Philox key 0x5EED0000 + i, full-fidelity outputs (every
-(start, finish) pair and all 12 sampled series written to HBM).
+Workload (BASELINE.json configs[1], the one the metric is quoted on, default): the 2-server +
+load-balancer topology of examples/yaml_input/data/two_servers_lb.yml (400 users x 20 rpm,
+T = 600 s, 0.05 s sampling), 10 000 seed replicas per GPU, scenario i uses Philox key
+0x5EED0000 + i, full-fidelity outputs (every (start, finish) pair and all 12 sampled series
+written to HBM).  The other BASELINE configs are available with --config:
+  1  single_server.yml, T = 300 s, ONE replica (the reference's own CPU-runnable case)
+  3  users x RTT 100 x 100 grid (10 000 scenarios per GPU)
+  4  the grid x 10 seeds = 100 000 scenarios with event_inj_lb.yml's spikes / outages, SHARDED over
+     the ranks by expected load (strong scaling: the stated total is split, not replicated)
+  5  8-server fan-out with log-normal edges, 50 000 replicas sharded over the ranks
 
-A "step" is ONE pass of the hot path over that batch: af_engine_run() = seed
-upload + the HIP next-event kernel + stream sync, inputs/outputs resident in HBM.
-K steps are timed between barrier + torch.cuda.synchronize() on both sides, MAX
-over ranks; rank 0 prints ONE JSON line.  value = request-events simulated by all
-ranks / that time (request-event = one timed state transition of a request:
-arrival, edge delivery, CPU-step end, I/O-step end).
+A "step" is ONE pass of the hot path over the rank's batch: af_engine_run() (seed upload, the HIP
+kernels, stream sync) + af_engine_summarize() (the batched analyzer), inputs/outputs resident in
+HBM; batches that do not fit the HBM budget run as slices that reuse the output buffers.  K steps
+are timed between barrier + torch.cuda.synchronize() on both sides, MAX over ranks; rank 0 prints
+ONE JSON line.  value = request-events simulated by all ranks / that time (request-event = one
+timed state transition of a request: arrival, edge delivery, CPU-step end, I/O-step end;
+SURVEY.md section 8d).
 
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), scenarios
-sharded by rank with NO data-path collective (weak scaling: R replicas per GPU);
-ONE all_gather of the per-scenario summaries over xGMI after the timed region
-(reported as gather_ms).
+N > 1: one process per GPU.  Under torchrun (RANK / WORLD_SIZE in the environment) this process IS
+a rank; called plainly with --gpus N it re-executes itself under `python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`.  Scenarios are sharded by rank with NO
+data-path collective; ONE all-gather of the per-scenario summaries over xGMI after the timed region
+(reported as gather_ms).  `--selftest-cpu` drives the same launcher / sharding / gather path on CPU
+(gloo) with synthetic per-scenario summaries and no engine (tests/test_distributed_cpu.py).
 """
 
 from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -38,13 +49,67 @@ if str(ROOT) not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured-achievable
 HBM_ACHIEVABLE_GBS = 6290.0
-SEED_BASE = 0x5EED0000
+CONFIG_TOTALS = {4: 100_000, 5: 50_000}     # BASELINE.json: totals stated for the 8-GPU configs
 
 
-def lb2_payload(horizon: int = 600) -> dict:
-    from oracle.scenarios import lb_two_servers  # pure dict builder (the YAML's values), no oracle code
+# --------------------------------------------------------------------------- #
+# workloads (asyncflow_amd/workloads.py holds the BASELINE payloads)            #
+# --------------------------------------------------------------------------- #
+def build_workload(cfg: int, rank: int, world: int, scenarios: int, horizon: int | None) -> dict:
+    """The rank's share of BASELINE config `cfg`: payload, seeds, per-scenario parameter columns."""
+    from asyncflow_amd import workloads as w
+    from asyncflow_amd.distributed import interleave_by_load, shard_bounds
 
-    return lb_two_servers(horizon=horizon)
+    base = w.BASELINE_SEED_BASE[cfg]
+    cols: dict[str, np.ndarray] = {}
+    scaling = "weak"
+    if cfg == 1:
+        T = horizon or 300
+        payload, n = w.single_server(horizon=T), scenarios or 1
+        label = f"single_server.yml (100 users x 20 rpm, T={T} s), {n} replica(s) per GPU"
+        seeds = base + rank * n + np.arange(n, dtype=np.uint64)
+    elif cfg == 2:
+        T = horizon or 600
+        payload, n = w.lb_two_servers(horizon=T), scenarios or 10_000
+        label = f"two_servers_lb.yml (2 servers + LB, 400 users x 20 rpm, T={T} s, dt=0.05 s), {n} seed replicas per GPU"
+        seeds = base + rank * n + np.arange(n, dtype=np.uint64)
+    elif cfg == 3:
+        T = horizon or 600
+        payload = w.lb_two_servers(horizon=T)
+        side = int(round(math.sqrt(scenarios or 10_000)))
+        n = side * side
+        a, b = w.grid_users_rtt(side)
+        order = np.argsort(-a, kind="stable")            # heaviest first: similar scenarios run together
+        cols = {"rqs_input.avg_active_users.mean": a[order], "topology_graph.edges[*].latency.mean": b[order]}
+        seeds = (base + rank * n + np.arange(n, dtype=np.uint64))[order]
+        label = f"LB-2 grid avg_active_users (10..1000) x per-hop latency (0.5..50 ms), {side}x{side} points per GPU, T={T} s"
+    elif cfg == 4:
+        T = horizon or 600
+        payload = w.lb_with_events(users=400, horizon=T, scale=T / 600.0)
+        total = scenarios or CONFIG_TOTALS[4]
+        reps = max(1, total // 10_000)
+        side = int(round(math.sqrt(total / reps)))
+        a, b = w.grid_users_rtt(side)
+        a, b = np.repeat(a, reps), np.repeat(b, reps)
+        total = a.size
+        all_seeds = base + np.arange(total, dtype=np.uint64)
+        mine = interleave_by_load(a, world)[rank]         # SURVEY 8e: deal by expected event count
+        mine = mine[np.argsort(-a[mine], kind="stable")]
+        cols = {"rqs_input.avg_active_users.mean": a[mine], "topology_graph.edges[*].latency.mean": b[mine]}
+        seeds, n, scaling = all_seeds[mine], int(mine.size), "strong"
+        label = (f"LB-2 grid {side}x{side} x {reps} seeds = {total} scenarios with event_inj_lb.yml spikes/outages, "
+                 f"T={T} s, sharded by expected load over {world} GPU(s)")
+    elif cfg == 5:
+        T = horizon or 600
+        payload = w.fanout8(horizon=T)
+        total = scenarios or CONFIG_TOTALS[5]
+        lo, hi = shard_bounds(total, rank, world)
+        seeds, n, scaling = base + np.arange(lo, hi, dtype=np.uint64), hi - lo, "strong"
+        label = f"8-server fan-out, log-normal edges (120 users x 20 rpm, T={T} s), {total} replicas sharded over {world} GPU(s)"
+    else:
+        raise ValueError(cfg)
+    return {"payload": payload, "seeds": np.ascontiguousarray(seeds, dtype=np.uint64), "columns": cols, "n": int(n),
+            "label": label, "scaling": scaling, "horizon": T}
 
 
 def algorithmic_bytes(counts: np.ndarray, n_series: int, plan_bytes: int) -> float:
@@ -56,8 +121,26 @@ def algorithmic_bytes(counts: np.ndarray, n_series: int, plan_bytes: int) -> flo
 
 
 # --------------------------------------------------------------------------- #
-# CPU baseline: the SimPy-faithful C restatement (oracle/des_oracle.c), "port"  #
+# CPU baseline legs (oracle / hostcheck / reference are CHECKERS, timed beside) #
 # --------------------------------------------------------------------------- #
+def cgroup_cpu_quota() -> float | None:
+    """CPUs the cgroup lets this process use (cpu.max / cfs quota), or None when unlimited."""
+    try:
+        text = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if text and text[0] != "max":
+            return float(text[0]) / float(text[1])
+    except (OSError, ValueError, IndexError):
+        pass
+    try:
+        q = float(Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())
+        p = float(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+        if q > 0 and p > 0:
+            return q / p
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def _cpu_worker(args: tuple[dict, list[int]]) -> tuple[int, int, float]:
     payload, seeds = args
     from asyncflow_amd.plan import lower
@@ -74,92 +157,298 @@ def _cpu_worker(args: tuple[dict, list[int]]) -> tuple[int, int, float]:
     return ev, heap, time.perf_counter() - t0
 
 
-def cpu_baseline(payload: dict, budget_s: float = 12.0) -> dict:
-    """Time the oracle on the host cores over a bounded sample of the same workload."""
+def _time_serial(fn, budget_s: float) -> tuple[float, int, float]:
+    """Call fn(i) -> events until budget_s of wall is used; (events, calls, seconds)."""
+    ev, k, t0 = 0, 0, time.perf_counter()
+    while True:
+        ev += fn(k)
+        k += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s:
+            return float(ev), k, dt
+
+
+def cpu_baseline(payload: dict, seed_base: int, label: str, budget_s: float = 8.0) -> dict:
+    """CPU legs timed in THIS run on the host cores of this box, on a bounded sample of the same workload:
+    (a) the SimPy-faithful C restatement (oracle/des_oracle.c) on ONE unloaded core,
+    (b) the same on every usable core (affinity capped by the cgroup quota) -- the reported `value`,
+    (c) `port_lean`: the engine's own next-event core compiled for the host (tests/hostcheck), one core,
+    (d) the unmodified Python reference (numpy-seeded, runner.rng seam) when /root/reference exists here.
+    """
     import multiprocessing as mp
 
+    from asyncflow_amd import _abi
     from asyncflow_amd.plan import lower
     from oracle import oracle_lib as ol
+    from oracle import ref_env
 
     ol.build()
     plan = lower(payload)
+    ol.simulate(plan, seed_base)                                    # warm (page in, caches)
+    heap_total = [0]
+
+    def one(i: int) -> int:
+        r = ol.simulate(plan, seed_base + i)
+        heap_total[0] += r.heap_events
+        return r.events
+
+    ev1, runs1, s1 = _time_serial(one, min(3.0, budget_s / 2))
+    single = ev1 / s1
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = cgroup_cpu_quota()
+    procs = max(1, min(affinity, int(math.ceil(quota)) if quota else affinity))
+    per_run = s1 / runs1
+    per_core = max(2, min(32, int(budget_s / (3.0 * per_run))))     # (a run is ~2-5x slower with every hardware thread busy)
+    jobs = [(payload, [seed_base + 1000 + c * per_core + k for k in range(per_core)]) for c in range(procs)]
     t0 = time.perf_counter()
-    ol.simulate(plan, SEED_BASE)
-    one = max(time.perf_counter() - t0, 1e-3)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    # (a run takes ~5x longer with every hardware thread busy than alone: 16 per core ~ 15-20 s of wall)
-    per_core = max(2, min(16, int(budget_s / one)))
-    jobs = [(payload, [SEED_BASE + c * per_core + k for k in range(per_core)]) for c in range(cores)]
-    t0 = time.perf_counter()
-    with mp.get_context("fork").Pool(cores) as pool:
-        parts = pool.map(_cpu_worker, jobs)
+    with mp.get_context("fork").Pool(procs) as pool:
+        parts = pool.map(_cpu_worker, jobs, chunksize=1)
     wall = time.perf_counter() - t0
-    ev = sum(p[0] for p in parts)
-    heap = sum(p[1] for p in parts)
+    ev = float(sum(p[0] for p in parts))
+    heap = float(sum(p[1] for p in parts))
     busy = max(p[2] for p in parts)
-    return {
+    out = {
         "value": ev / busy,
         "unit": "request-events/s",
-        "cores": cores,
+        "cores": procs,
         "kind": "port",
-        "sample": f"{cores * per_core} LB-2 replicas (T=600 s) of the same workload, {per_core} per core, "
+        "sample": f"{procs * per_core} scenarios of the same workload ({label}), {per_core} per process on {procs} processes, "
                   f"C restatement of the reference actors + SimPy heap (oracle/des_oracle.c), "
-                  f"{heap / max(ev, 1):.1f} SimPy heap events per request-event, wall {wall:.1f} s",
-        "replicas_per_s": cores * per_core / busy,
-        "python_reference_events_per_s_per_core": 4.5e4,  # measured in the build container (BASELINE.md section 2)
+                  f"{heap / max(ev, 1.0):.1f} SimPy heap events per request-event, pool wall {wall:.1f} s",
+        "scenarios_per_s": procs * per_core / busy,
+        "single_core_unloaded": single,
+        "per_core_loaded": ev / busy / procs,
+        "cores_affinity": affinity,
+        "cores_cgroup_quota": quota,
     }
+    ratio = out["per_core_loaded"] / single
+    if ratio < 0.5:
+        out["note"] = (f"per-core rate with {procs} busy processes is {ratio:.2f}x the unloaded single-core rate: the "
+                       f"'cores' of this box are SMT threads / oversubscribed vCPUs (sched_getaffinity={affinity}, "
+                       f"cgroup quota={quota}); single_core_unloaded is the number comparable across machines")
+    # (c) the engine's own lean core on the host
+    try:
+        from tests.hostcheck import build as hc
+
+        hc.build()
+        hc.simulate(plan, seed_base)
+
+        def lean(i: int) -> int:
+            counts, _, _ = hc.simulate(plan, seed_base + i)
+            return int(counts[_abi.CNT_EVENTS])
+
+        evl, _, sl = _time_serial(lean, min(2.5, budget_s / 3))
+        out["port_lean"] = {"value": evl / sl, "unit": "request-events/s", "cores": 1, "kind": "port-lean",
+                            "what": "asyncflow_amd/csrc/af_core.hpp (the sequential next-event core) compiled by g++ for one lane"}
+    except Exception as exc:  # noqa: BLE001 - a missing g++ must not take the bench down
+        out["port_lean"] = {"value": None, "why": f"{type(exc).__name__}: {exc}"}
+    # (d) the Python reference itself, only where it exists (never on the GPU box)
+    out["python_reference"] = None
+    if ref_env.reference_available():
+        try:
+            from oracle.reference_runner import run_reference_numpy
+
+            short = json.loads(json.dumps(payload))
+            T_full = float(short["sim_settings"]["total_simulation_time"])
+            T_short = max(5.0, min(T_full, 60.0))
+            short["sim_settings"]["total_simulation_time"] = int(T_short)
+            t0 = time.perf_counter()
+            an = run_reference_numpy(short, 0)
+            an.get_latency_stats()
+            dt = time.perf_counter() - t0
+            ev_short = ev1 / runs1 * (T_short / T_full)        # request-events of the same scenario length
+            out["python_reference"] = {"value": ev_short / dt, "unit": "request-events/s", "cores": 1, "kind": "reference",
+                                       "sample": f"1 replica, T={int(T_short)} s, unmodified reference actors on "
+                                                 f"{ref_env.simpy_flavour()} SimPy, numpy PCG64 via runner.rng, wall {dt:.2f} s"}
+        except Exception as exc:  # noqa: BLE001
+            out["python_reference"] = {"value": None, "why": f"{type(exc).__name__}: {exc}"}
+    return out
 
 
 # --------------------------------------------------------------------------- #
-def main() -> int:
+# the rank's sweep: engine + HBM-resident outputs, run as slices                 #
+# --------------------------------------------------------------------------- #
+class RankSweep:
+    """Engine, output buffers and per-scenario summaries of this rank's share of the workload."""
+
+    def __init__(self, wl: dict, dev, args) -> None:
+        import torch
+
+        from asyncflow_amd import _abi
+        from asyncflow_amd.engine import Engine
+        from asyncflow_amd.plan import estimate_capacities, lower
+        from asyncflow_amd.runner import _fifo_pow2, resolve_sweep
+
+        self.torch, self._abi, self.args, self.dev = torch, _abi, args, dev
+        self.plan = plan = lower(wl["payload"])
+        self.n = n = wl["n"]
+        self.seeds = wl["seeds"]
+        self.over = resolve_sweep(plan, wl["columns"], n)
+        users = wl["columns"].get("rqs_input.avg_active_users.mean")
+        lat = wl["columns"].get("topology_graph.edges[*].latency.mean")
+        users_max = float(users.max()) if users is not None else None
+        lat_scale = float(lat.max() / plan.edge_mean.min()) if lat is not None else 1.0
+        cap, fifo = estimate_capacities(plan, users_max, lat_scale)
+        self.clock_cap = plan.clock_capacity(users_max)
+        self.ticks = max(plan.tick_count, 1)
+        self.T = int(plan.total_time)
+        # slices: outputs of one slice must fit the HBM budget (clock + samples; the engine's own buffers on top)
+        per_scen = self.clock_cap * 16 + (0 if args.no_series else self.ticks * plan.series_pitch * 4)
+        budget = int(args.hbm_budget_gb * (1 << 30))
+        self.slice = max(1, min(n, budget // max(per_scen, 1), 65535 if n > 65535 else n))
+        self.n_slices = (n + self.slice - 1) // self.slice
+        self.slice = (n + self.n_slices - 1) // self.n_slices
+        self.eng = Engine(plan, dev.index, request_capacity=min(cap, _abi.MAX_REQUEST_CAPACITY),
+                          fifo_capacity=_fifo_pow2(min(fifo, cap)), lanes_per_wave=args.lanes,
+                          force_global_state=args.global_state, expect_shared_instants=args.expect_shared_instants)
+        m = self.slice
+        self.counts = torch.zeros((n, _abi.CNT_SLOTS), dtype=torch.int32, device=dev)
+        self.clock = torch.empty((m, self.clock_cap, 2), dtype=torch.float64, device=dev)
+        self.samples = None if args.no_series else torch.zeros((m, self.ticks, plan.series_pitch), dtype=torch.int32, device=dev)
+        # per-scenario summaries (the analyzer step of the path), kept for the whole rank
+        self.s_stats = torch.empty((n, 8), dtype=torch.float64, device=dev)
+        self.s_rps = torch.empty((n, self.T), dtype=torch.float32, device=dev)
+        self.hist_max = {1: 1.024, 2: 0.256, 3: 2.56, 4: 2.56, 5: 25.6}[args.config]
+        self.s_hist = torch.empty((n, 256), dtype=torch.int32, device=dev)
+        self.s_mean = None if self.samples is None else torch.empty((n, plan.n_series), dtype=torch.float64, device=dev)
+        self.s_max = None if self.samples is None else torch.empty((n, plan.n_series), dtype=torch.int32, device=dev)
+        self.specialise = not args.generic_kernels
+
+    def _slice_args(self, lo: int, hi: int) -> tuple[np.ndarray, list, dict]:
+        seeds = self.seeds[lo:hi]
+        over = [(c, i, np.ascontiguousarray(v[lo:hi])) for c, i, v, _ in self.over]
+        kw = dict(clock_ptr=self.clock.data_ptr(), clock_capacity=self.clock_cap,
+                  samples_ptr=self.samples.data_ptr() if self.samples is not None else 0, tick_capacity=self.ticks,
+                  counts_ptr=self.counts[lo:hi].data_ptr(), draw_capacity=self.clock_cap)
+        return seeds, over, kw
+
+    def prepare(self) -> None:
+        if self.specialise:
+            seeds, over, kw = self._slice_args(0, min(self.slice, self.n))
+            self.eng.prepare(seeds, over, **kw)     # hipcc run or cache hit: never inside the timed region
+
+    def step(self) -> dict:
+        """One pass over the rank's batch; returns the engine's own timings summed over the slices."""
+        acc = {"kernel_ms": 0.0, "pregen_ms": 0.0, "summary_ms": 0.0, "shared": 0, "jit": 0}
+        for lo in range(0, self.n, self.slice):
+            hi = min(self.n, lo + self.slice)
+            seeds, over, kw = self._slice_args(lo, hi)
+            st = self.eng.run(seeds, over, specialise=self.specialise, **kw)
+            acc["kernel_ms"] += float(st.kernel_ms)
+            acc["pregen_ms"] += float(st.pregen_ms)
+            acc["shared"] += int(st.shared_instant_scenarios)
+            acc["jit"] += int(st.specialised_launches)
+            st = self.eng.summarize(hi - lo, clock_ptr=self.clock.data_ptr(), clock_capacity=self.clock_cap,
+                                    samples_ptr=self.samples.data_ptr() if self.samples is not None else 0,
+                                    tick_capacity=self.ticks, counts_ptr=self.counts[lo:hi].data_ptr(),
+                                    stats_ptr=self.s_stats[lo:hi].data_ptr(), rps_ptr=self.s_rps[lo:hi].data_ptr(),
+                                    rps_buckets=self.T, hist_ptr=self.s_hist[lo:hi].data_ptr(), hist_bins=256,
+                                    hist_max=self.hist_max,
+                                    series_mean_ptr=self.s_mean[lo:hi].data_ptr() if self.s_mean is not None else 0,
+                                    series_max_ptr=self.s_max[lo:hi].data_ptr() if self.s_max is not None else 0)
+            acc["summary_ms"] += float(st.summary_ms)
+            self.last_stats = st
+        return acc
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return int(s.getsockname()[1])
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` outside torchrun: re-execute under torch.distributed.run, one rank per GPU."""
+    env = dict(os.environ, AF_BENCH_SPAWNED="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(Path(__file__).resolve()), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env, check=False).returncode
+
+
+# --------------------------------------------------------------------------- #
+def selftest_cpu(args, rank: int, world: int) -> int:
+    """Launcher / sharding / gather path on CPU (gloo), no engine: every rank fabricates the summary
+    rows of ITS scenarios (a pure function of the seed), the ranks all-gather them, rank 0 checks that
+    the stated total arrived exactly once and prints the one JSON line."""
+    import torch
+    import torch.distributed as dist
+
+    from asyncflow_amd.distributed import gather_summaries
+
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    wl = build_workload(args.config, rank, world, args.scenarios, args.horizon)
+    seeds = wl["seeds"].astype(np.float64)
+    users = wl["columns"].get("rqs_input.avg_active_users.mean", np.full(wl["n"], 400.0))
+    local = torch.tensor(np.stack([seeds, users, np.full(wl["n"], float(rank))], axis=1), dtype=torch.float64)
+    t0 = time.perf_counter()
+    sizes = None
+    if world > 1:
+        sz = torch.zeros(world, dtype=torch.int64)
+        sz[rank] = wl["n"]
+        dist.all_reduce(sz)
+        sizes = [int(x) for x in sz.tolist()]
+    full = gather_summaries(local, sizes)
+    gather_ms = (time.perf_counter() - t0) * 1e3
+    load = torch.tensor([float(users.sum())], dtype=torch.float64)
+    loads = [load.clone() for _ in range(world)]
+    if world > 1:
+        dist.all_gather(loads, load)
+    if rank == 0:
+        got = np.sort(full[:, 0].numpy().astype(np.uint64))
+        total = int(full.shape[0])
+        line = {"selftest": True, "metric": "launcher selftest (no engine)", "value": float(total), "unit": "scenarios",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": wl["scaling"],
+                "config": {"workload": wl["label"]}, "scenarios_total": total, "unique_seeds": int(np.unique(got).size),
+                "scenarios_per_rank": sizes or [wl["n"]], "gather_ms": gather_ms,
+                "load_per_rank": [float(x) for x in torch.cat(loads).tolist()]}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+def main() -> int:  # noqa: C901, PLR0912, PLR0915
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--replicas", type=int, default=10_000, help="scenarios per GPU")
-    ap.add_argument("--horizon", type=int, default=600)
+    ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3, 4, 5], help="BASELINE.json config (see module docstring)")
+    ap.add_argument("--scenarios", "--replicas", type=int, default=0, dest="scenarios",
+                    help="scenarios per GPU (configs 1-3) or in total (configs 4, 5); 0 = the BASELINE size")
+    ap.add_argument("--horizon", type=int, default=0, help="simulated seconds (0 = the BASELINE horizon)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-series", action="store_true", help="do not store the sampled series")
-    ap.add_argument("--lanes", type=int, default=0, help="scenario lanes per wave (0 = engine default)")
+    ap.add_argument("--lanes", type=int, default=0, help="scenario lanes per wave of the sequential kernel (0 = engine default)")
     ap.add_argument("--global-state", action="store_true", help="keep per-scenario state in HBM")
     ap.add_argument("--generic-kernels", action="store_true",
                     help="do not build plan-specialised kernels (asyncflow_amd/jit.py); use the library's generic ones")
     ap.add_argument("--expect-shared-instants", action="store_true",
                     help="start with the kernel variant that has the SimPy-order path for shared instants")
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
-                    help="BASELINE.json config: 2 = 10k LB-2 seed replicas (the metric's config, default); "
-                         "3 = users x RTT 100x100 grid; 4 = grid + injected spikes/outages; 5 = 8-server fan-out")
+    ap.add_argument("--hbm-budget-gb", type=float, default=96.0, help="HBM for the output buffers of one slice")
+    ap.add_argument("--selftest-cpu", action="store_true", help="launcher / sharding / gather path on CPU (gloo), no engine")
     args = ap.parse_args()
+    args.horizon = args.horizon or None
 
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not under_launcher:
+        return spawn_ranks(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
-    payload = lb2_payload(args.horizon)
-    sweep: dict = {}
-    label = "two_servers_lb.yml (2 servers + LB, 400 users x 20 rpm"
-    if args.config in (3, 4):
-        from oracle.scenarios import lb_with_events
+    if args.selftest_cpu:
+        return selftest_cpu(args, rank, world)
 
-        if args.config == 4:
-            payload = lb_with_events(users=400, horizon=args.horizon, scale=args.horizon / 600.0)
-        label = "LB-2 grid avg_active_users x RTT" + (" + event_inj_lb.yml spikes/outages" if args.config == 4 else "")
-    if args.config == 5:
-        from oracle.scenarios import fanout8
-
-        payload = fanout8(horizon=args.horizon)
-        label = "8-server fan-out, log-normal edges (120 users x 20 rpm"
-
+    wl = build_workload(args.config, rank, world, args.scenarios, args.horizon)
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        base = cpu_baseline(payload)  # before CUDA is initialised (fork-safe)
+        from asyncflow_amd.workloads import BASELINE_SEED_BASE
+
+        base = cpu_baseline(wl["payload"], BASELINE_SEED_BASE[args.config], wl["label"])  # before HIP is initialised (fork-safe)
 
     import torch
 
     from asyncflow_amd import _abi
-    from asyncflow_amd.engine import Engine
-    from asyncflow_amd.plan import estimate_capacities, lower
 
     if not torch.cuda.is_available():
         print("bench.py needs an MI355X: the engine has no CPU fallback", file=sys.stderr)
@@ -172,61 +461,8 @@ def main() -> int:
 
         dist.init_process_group(backend="nccl", device_id=dev)
 
-    plan = lower(payload)
-    n = args.replicas
-    seeds = (SEED_BASE + rank * n + np.arange(n, dtype=np.uint64)).astype(np.uint64)
-    overrides = []
-    users_max = None
-    lat_scale = 1.0
-    if args.config in (3, 4):
-        # users = 10 a (a = 1..100), per-hop latency mean = 0.5 ms b (b = 1..100);
-        # scenarios are dealt to lanes by expected load so that a wave holds similar scenarios
-        from asyncflow_amd.runner import resolve_sweep
-
-        side = int(round(n ** 0.5))
-        n = side * side
-        a = np.repeat(np.arange(1, side + 1), side) * (1000.0 / side)
-        b = np.tile(np.arange(1, side + 1), side) * (0.05 / side)
-        order = np.argsort(-a, kind="stable")
-        a, b = a[order], b[order]
-        seeds = (0xC0F30000 + rank * n + np.arange(n, dtype=np.uint64)).astype(np.uint64)
-        overrides = [(c, i, v) for c, i, v, _ in resolve_sweep(plan, {
-            "rqs_input.avg_active_users.mean": a, "topology_graph.edges[*].latency.mean": b}, n)]
-        users_max, lat_scale = float(a.max()), float(b.max() / plan.edge_mean.min())
-    cap, fifo = estimate_capacities(plan, users_max, lat_scale)
-    clock_cap = plan.clock_capacity(users_max)
-    ticks = max(plan.tick_count, 1)
-    eng = Engine(plan, local_rank, request_capacity=cap, fifo_capacity=fifo, lanes_per_wave=args.lanes,
-                 force_global_state=args.global_state, expect_shared_instants=args.expect_shared_instants)
-    counts = torch.zeros((n, _abi.CNT_SLOTS), dtype=torch.int32, device=dev)
-    clock = torch.empty((n, clock_cap, 2), dtype=torch.float64, device=dev)
-    samples = None if args.no_series else torch.zeros((n, ticks, plan.series_pitch), dtype=torch.int32, device=dev)
-
-    # per-scenario summaries (the analyzer step of the path): 8 latency stats, 1-s RPS windows,
-    # mean/max of every sampled series -- computed by the HIP analyzer inside the timed step
-    T = int(plan.total_time)
-    s_stats = torch.empty((n, 8), dtype=torch.float64, device=dev)
-    s_rps = torch.empty((n, T), dtype=torch.float32, device=dev)
-    # 256-bin latency histogram per scenario (pooled percentiles across replicas / ranks)
-    hist_max = {2: 0.256, 3: 2.56, 4: 2.56, 5: 25.6}[args.config]
-    s_hist = torch.empty((n, 256), dtype=torch.int32, device=dev)
-    s_mean = None if samples is None else torch.empty((n, plan.n_series), dtype=torch.float64, device=dev)
-    s_max = None if samples is None else torch.empty((n, plan.n_series), dtype=torch.int32, device=dev)
-
-    run_kw = dict(clock_ptr=clock.data_ptr(), clock_capacity=clock_cap,
-                  samples_ptr=samples.data_ptr() if samples is not None else 0, tick_capacity=ticks,
-                  counts_ptr=counts.data_ptr(), draw_capacity=clock_cap)
-    if not args.generic_kernels:
-        eng.prepare(seeds, overrides, **run_kw)     # hipcc run or cache hit: never inside the timed region
-
-    def step():
-        eng.run(seeds, overrides, specialise=not args.generic_kernels, **run_kw)
-        return eng.summarize(n, clock_ptr=clock.data_ptr(), clock_capacity=clock_cap,
-                             samples_ptr=samples.data_ptr() if samples is not None else 0, tick_capacity=ticks,
-                             counts_ptr=counts.data_ptr(), stats_ptr=s_stats.data_ptr(), rps_ptr=s_rps.data_ptr(),
-                             rps_buckets=T, hist_ptr=s_hist.data_ptr(), hist_bins=256, hist_max=hist_max,
-                             series_mean_ptr=s_mean.data_ptr() if s_mean is not None else 0,
-                             series_max_ptr=s_max.data_ptr() if s_max is not None else 0)
+    sw = RankSweep(wl, dev, args)
+    sw.prepare()
 
     def barrier() -> None:
         if dist is not None:
@@ -234,62 +470,69 @@ def main() -> int:
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
-        step()
+        sw.step()
     barrier()
     t0 = time.perf_counter()
-    kernel_ms = []
+    accs = []
     for _ in range(args.steps):
-        st = step()
-        kernel_ms.append(st.kernel_ms)
+        accs.append(sw.step())
     barrier()
     elapsed = time.perf_counter() - t0
+    n, plan, st = sw.n, sw.plan, sw.last_stats
 
-    c = counts.cpu().numpy().view(np.uint32)
+    c = sw.counts.cpu().numpy().view(np.uint32)
     flags = int(np.bitwise_or.reduce(c[:, _abi.CNT_FLAGS]))
     if flags & _abi.FATAL_FLAGS:
         print(f"capacity overflow flags={flags:#x}: result invalid", file=sys.stderr)
         return 3
     events_rank = float(c[:, _abi.CNT_EVENTS].astype(np.float64).sum())
-
-    # ---- the single collective: gather per-scenario summaries (after the timed region)
-    summ = {"stats": s_stats, "rps": s_rps}
-    summary_ms = float(st.summary_ms)
     completed_rank = float(c[:, _abi.CNT_COMPLETED].astype(np.float64).sum())
     ticks_rank = float(c[:, _abi.CNT_TICKS].astype(np.float64).sum())
+    k_ms = float(np.mean([a["kernel_ms"] for a in accs]))
+    summary_ms = float(np.mean([a["summary_ms"] for a in accs]))
+
+    # ---- the single collective: gather per-scenario summaries (after the timed region)
     gather_ms = 0.0
-    stats_all = summ["stats"]
+    stats_all, hist_all = sw.s_stats, sw.s_hist.to(torch.float32)
+    kernel_ms_ranks = [k_ms]
+    n_total = n
     if dist is not None:
-        t2 = time.perf_counter()
         from asyncflow_amd.distributed import gather_summaries
 
-        packed = torch.cat([summ["stats"].to(torch.float32), summ["rps"], s_hist.to(torch.float32)], dim=1).contiguous()
-        out = gather_summaries(packed, [n] * world)   # ONE all_gather over xGMI (RCCL)
+        sizes_t = torch.zeros(world, dtype=torch.int64, device=dev)
+        sizes_t[rank] = n
+        dist.all_reduce(sizes_t)
+        sizes = [int(x) for x in sizes_t.tolist()]
+        packed = torch.cat([sw.s_stats.to(torch.float32), sw.s_rps, sw.s_hist.to(torch.float32)], dim=1).contiguous()
+        torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        out = gather_summaries(packed, sizes)          # ONE all_gather over xGMI (RCCL)
         torch.cuda.synchronize(dev)
         gather_ms = (time.perf_counter() - t2) * 1e3
-        stats_all = out[:, :8]
-        tot = torch.tensor([elapsed, events_rank], dtype=torch.float64, device=dev)
-        mx = tot.clone()
+        stats_all, hist_all = out[:, :8], out[:, 8 + sw.T:]
+        n_total = int(out.shape[0])
+        tot = torch.tensor([elapsed, events_rank, k_ms], dtype=torch.float64, device=dev)
+        mx, mn, sm = tot.clone(), tot.clone(), tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        sm = tot.clone()
+        dist.all_reduce(mn, op=dist.ReduceOp.MIN)
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        elapsed = float(mx[0])
-        events_total = float(sm[1])
+        elapsed, events_total = float(mx[0]), float(sm[1])
+        kernel_ms_ranks = [float(mn[2]), float(mx[2])]
     else:
         events_total = events_rank
 
     # pooled p95 over every scenario of the job, from the gathered (or local) 256-bin histograms
-    hist_all = out[:, 8 + T:] if dist is not None else s_hist.to(torch.float32)
     pooled = hist_all.sum(dim=0).double().cpu().numpy()
     cdf = np.cumsum(pooled) / max(pooled.sum(), 1.0)
-    pooled_p95_ms = float((np.searchsorted(cdf, 0.95) + 1) * hist_max / 256 * 1e3)
+    pooled_p95_ms = float((np.searchsorted(cdf, 0.95) + 1) * sw.hist_max / 256 * 1e3)
 
     if rank == 0:
         total_events = events_total * args.steps
-        k_ms = float(np.mean(kernel_ms))
-        alg_bytes = algorithmic_bytes(c, plan.n_series, int(st.lds_bytes_per_wave - 64 * st.state_bytes_per_scenario)
+        alg_bytes = algorithmic_bytes(c, plan.n_series, int(st.lds_bytes_per_wave - st.lanes_per_wave * st.state_bytes_per_scenario)
                                       if st.state_in_lds else 0)
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         sa = stats_all.double().cpu().numpy()
+        out_bytes = 16.0 * completed_rank + (4.0 * plan.series_pitch * ticks_rank if sw.samples is not None else 0.0)
         line = {
             "metric": "simulated request-events/sec (2-server LB scenario, 10k replicas/GPU)" if args.config == 2
                       else f"simulated request-events/sec (BASELINE config {args.config})",
@@ -300,38 +543,39 @@ def main() -> int:
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": wl["scaling"],
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{label}, T={args.horizon} s, dt=0.05 s), "
-                            f"{n} scenarios per GPU, full outputs"
-                            + (" without sampled series" if args.no_series else ""),
-                "scenarios_per_gpu": n,
+                "workload": wl["label"] + ", full outputs" + (" without sampled series" if args.no_series else ""),
+                "baseline_config": args.config,
+                "scenarios_rank0": n,
+                "scenarios_total": n_total,
+                "slices_per_step": sw.n_slices,
                 "parallelism": f"scenario-sharded x{world}, no data-path collective",
                 "state": "LDS" if st.state_in_lds else "HBM",
                 "request_capacity": int(st.request_capacity),
                 "lds_bytes_per_wave": int(st.lds_bytes_per_wave),
                 "lanes_per_wave": int(st.lanes_per_wave),
                 "waves": int(st.waves),
-                "shared_instant_scenarios": int(st.shared_instant_scenarios),
-                "plan_specialised_kernels": bool(st.specialised_launches),
+                "shared_instant_scenarios": int(accs[-1]["shared"]),
+                "plan_specialised_kernels": bool(accs[-1]["jit"]),
             },
             "events_per_step": events_total,
             "per_gpu_value": total_events / elapsed / world,
-            "sweep_wall_s_per_10k": elapsed / args.steps * (10_000 / n),
+            "sweep_wall_s_per_10k": elapsed / args.steps * (10_000 / max(n, 1)),
             "kernel_ms": k_ms,
-            "pregen_ms": float(st.pregen_ms),
+            "kernel_ms_ranks_min_max": kernel_ms_ranks,
+            "pregen_ms": float(np.mean([a["pregen_ms"] for a in accs])),
             "draw_bytes": int(st.draw_bytes),
             "summary_ms": summary_ms,
             "summary": {
                 "kernels": "af_summary_kernel + af_series_kernel (inside the timed step)",
                 "ms": summary_ms,
                 # one read of every rqs_clock row and sample word is the algorithmic minimum
-                "algorithmic_bytes": 16.0 * completed_rank + (4.0 * plan.series_pitch * ticks_rank if samples is not None else 0.0),
-                "achieved_GBps": (16.0 * completed_rank + (4.0 * plan.series_pitch * ticks_rank if samples is not None else 0.0))
-                                 / max(summary_ms, 1e-9) / 1e6,
+                "algorithmic_bytes": out_bytes,
+                "achieved_GBps": out_bytes / max(summary_ms, 1e-9) / 1e6,
             },
             "gather_ms": gather_ms,
             "p95_ms_mean": float(np.nanmean(sa[:, 4]) * 1e3),
@@ -347,21 +591,25 @@ def main() -> int:
                 "traffic": None,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "bytes_per_event": alg_bytes / max(events_rank, 1.0),
-                "kernel": "af_jit_lean (plan-specialised build of af_des_kernel)" if st.specialised_launches else "af_des_kernel",
+                "kernel": "af_jit_lean (plan-specialised build of af_des_kernel)" if accs[-1]["jit"] else "af_des_kernel",
             },
         }
         if base is not None:
             line["cpu_baseline"] = base
-            line["gpu_over_cpu_port_all_cores"] = (total_events / elapsed) / base["value"]
-        # HBM bytes per launch of the dominant kernel, from the committed PMC passes of THIS
-        # command (rocprofv3 cannot run inside the timed bench): profiles/r01/final/traffic.json
-        tpath = ROOT / "profiles" / "r01" / "final" / "traffic.json"
-        if args.config == 2 and n == 10_000 and not args.no_series and args.horizon == 600 and tpath.exists():
-            tj = json.loads(tpath.read_text())
-            line["roofline"]["traffic"] = tj["bytes_per_launch"]
-            line["roofline"]["traffic_source"] = "profiles/r01/final/traffic.json (2 x FETCH_SIZE + WRITE_SIZE, KB=1024 B)"
-        print(json.dumps(line))
-    eng.close()
+        # HBM bytes per launch of the dominant kernel, from the committed PMC passes of THIS command
+        # (rocprofv3 cannot run inside the timed bench): newest profiles/rNN/**/traffic.json
+        if args.config == 2 and n == 10_000 and not args.no_series and wl["horizon"] == 600:
+            found = sorted((ROOT / "profiles").glob("r*/**/traffic.json"))
+            for tpath in reversed(found):
+                tj = json.loads(tpath.read_text())
+                if tj.get("kernel", "") and tj["kernel"] not in line["roofline"]["kernel"]:
+                    continue
+                line["roofline"]["traffic"] = tj["bytes_per_launch"]
+                line["roofline"]["traffic_source"] = f"{tpath.relative_to(ROOT)} (2 x FETCH_SIZE + WRITE_SIZE, KB=1024 B)"
+                line["roofline"]["frac_traffic"] = tj["bytes_per_launch"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                break
+        print(json.dumps(line), flush=True)
+    sw.eng.close()
     if dist is not None:
         dist.destroy_process_group()
     return 0

@@ -79,3 +79,32 @@ def test_two_rank_gloo_gather_matches_serial(n_total):
 
     hc.build()
     mp.spawn(_worker, args=(2, _free_port(), n_total), nprocs=2, join=True)
+
+
+@pytest.mark.parametrize("config, scenarios", [(4, 1800), (5, 1001)])
+def test_bench_launcher_shards_the_stated_total_over_two_ranks(config, scenarios):
+    """`python bench.py --gpus 2` spawns its own ranks (torch.distributed.run, 127.0.0.1), shards the
+    STATED total (not a per-rank copy), gathers once and prints ONE line with n_gpus = 2.  --selftest-cpu
+    swaps the engine for fabricated summary rows and RCCL for gloo; everything else is the bench's own path."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--selftest-cpu", "--config", str(config),
+                          "--scenarios", str(scenarios)], capture_output=True, text=True, timeout=300, env=env, check=False)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["selftest"] is True
+    assert line["scenarios_total"] == line["unique_seeds"] == sum(line["scenarios_per_rank"])
+    assert abs(line["scenarios_per_rank"][0] - line["scenarios_per_rank"][1]) <= 1
+    if config == 4:      # the grid is dealt by expected load: both ranks carry the same users x T mass
+        a, b = line["load_per_rank"]
+        assert abs(a - b) / (a + b) < 0.01
+        assert line["scenarios_total"] == 42 * 42          # side^2 grid points x 1 seed
+    else:
+        assert line["scenarios_total"] == scenarios
