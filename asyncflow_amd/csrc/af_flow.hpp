@@ -1,0 +1,845 @@
+// af_flow.hpp -- stage-parallel ("flow") kernel: ONE WAVE PER SCENARIO, 64 requests per step.
+//
+// Replaces, for plans whose request path is feed-forward, the same thing af_core.hpp replaces --
+// `SimulationRunner.run()` -> `env.run(until=T)` of the reference
+// (/root/reference/src/asyncflow/runtime/simulation_runner.py:349-376) -- but instead of popping one
+// event per lane per round it moves a whole batch of requests through the stations of the path:
+//
+//   generator -> edge -> client (1st visit) -> edge -> [load balancer -> edge] -> server -> edge -> client (2nd visit)
+//   rqs_generator.py:97-119  edge.py:73-116  client.py:43-71  load_balancer.py:60-72  server.py:79-276
+//
+// Why this is exact.  A station's state (edge send counter = index of the edge's next random draw, the
+// LB rotation, a server's core / RAM / queues, the client's completion list) is only touched by the
+// events AT that station, and every message carries its own times.  If no two events of one station
+// share a timestamp, each station sees a uniquely ordered event sequence and the run is a
+// deterministic dataflow: processing the stations one after the other over a time window gives the
+// same f64 values as popping events one by one -- the same additions in the same order
+// (deliver = send + (transit + spike), edge.py:94-107; core grant = max(ready time, previous release),
+// server.py:210-231).  Per station the events of a window are put in time order by a bucket rank
+// (exact comparisons on the f64 keys), which also finds equal keys.  Whatever the scheme cannot
+// express -- two events of one station at the same instant, a RAM queue that would block, a list or
+// tick-ring overflow -- sets FLAG_FLOW_FALLBACK and the scenario is simulated again, from t = 0, by the
+// sequential next-event kernels (af_core.hpp), which follow SimPy's event-by-event order.
+//
+// Windowing.  Station s owns a list of messages whose delivery time is known but not yet final in
+// rank; `H_s` is its horizon: every message the station will ever receive with time < H_s is already in
+// the list.  H_generator = time of the next arrival not yet generated; H_s <= H_{s-1} because a
+// message leaves a station no earlier than it arrived.  Each round every station ranks the messages
+// with time < min(H_{s-1}, T), handles at most 64 of them (one per lane) and hands the results to the
+// next list; what does not fit stays (back-pressure through the list capacities).
+//
+// Sampled series (collector.py:50-66): every counter the collector reads is a sum of intervals
+// [event that increments, event that decrements) -- a message in transit on an edge, a request in the
+// ready queue / in an I/O step / holding RAM.  Both ends are known when the interval starts, so it is
+// entered as +w / -w at the first tick after each end in a ring of per-tick differences (LDS); rows
+// older than the last station's horizon are final: prefix-summed and streamed out.
+//
+// Device code under hipcc (wave backend: af_wave_hip in engine.hip); plain C++ under g++ for the
+// TEST-ONLY 64-fibre wave emulator of tests/hostcheck/ (never shipped).
+#pragma once
+
+#include <stdint.h>
+
+#include "af_core.hpp"
+
+namespace aff {
+
+using af::AF_INF;
+using af::d2u;
+using af::u2d;
+
+enum : uint32_t {
+    FLAG_FLOW_FALLBACK = 1u << 8,   // internal: never visible in the outputs of af_engine_run
+    // reasons (af_stats_t.flow_fallback_*), bits 9..12 of the same word, cleared with the flag
+    FLOW_WHY_TIE = 1u << 9,         // two events of one station (or an event and a tick / timeline mark) share an instant
+    FLOW_WHY_LIST = 1u << 10,       // more messages pending at a station than the list holds
+    FLOW_WHY_RING = 1u << 11,       // an interval reaches further ahead than the tick ring
+    FLOW_WHY_RAM = 1u << 12,        // a request would have to wait for RAM
+    FLOW_WHY_MASK = FLOW_WHY_TIE | FLOW_WHY_LIST | FLOW_WHY_RING | FLOW_WHY_RAM,
+};
+constexpr uint32_t kMaxServers = 8;    // lane k < n_servers runs server k's core / RAM recurrence
+constexpr uint32_t kMaxSteps = 8;      // CPU + I/O steps of an endpoint
+constexpr uint32_t kWave = 64;
+
+// LDS layout behind the plan blob, in 8-byte words; computed on the host (make_flow_layout).
+struct FlowLayout {
+    uint32_t cap;        // capacity of every station list (multiple of 64)
+    uint32_t ring_rows;  // rows of the tick-difference ring (power of two)
+    uint32_t g_ring;     // per-server ring of departure times (power of two >= RAM slots looked back)
+    uint32_t c_ring;     // per-server ring of core-release times (>= max cpu_cores)
+    uint32_t pitch;      // 4-byte words per tick row (n_series rounded up to 4)
+    uint32_t off_spike, off_list, off_aux, off_out, off_sorted, off_hist, off_seg, off_fr, off_gr, off_cnt, off_ring;
+    uint32_t n_words;
+};
+
+inline FlowLayout make_flow_layout(uint32_t cap, uint32_t ring_rows, uint32_t g_ring, uint32_t c_ring, uint32_t n_edges,
+                                   uint32_t n_servers, uint32_t n_edge_marks) {
+    FlowLayout L{};
+    L.cap = cap;
+    L.ring_rows = ring_rows;
+    L.g_ring = g_ring;
+    L.c_ring = c_ring;
+    L.pitch = (n_edges + 3u * n_servers + 3u) & ~3u;
+    uint32_t w = 0;
+    L.off_spike = w; w += n_edge_marks;                 // cumulative spike after each edge mark
+    L.off_list = w; w += 4u * 2u * cap;                 // 4 lists x (key, t0)
+    L.off_aux = w; w += (cap + 1u) / 2u;                // u32 per entry of the server list
+    L.off_out = w; w += 64u * 2u + 32u;                 // selected (key, t0) + u32 aux
+    L.off_sorted = w; w += cap;
+    L.off_hist = w; w += 32u + 32u + 8u;                // 64 u32 counts, 64 u32 bases, scalars
+    L.off_seg = w; w += 6u * 64u;                       // per-server segments: arrival, start, B, S, F, G
+    L.off_fr = w; w += n_servers * c_ring;
+    L.off_gr = w; w += n_servers * g_ring;
+    L.off_cnt = w; w += (n_edges + 1u) / 2u + 16u;      // u32 sends per edge; lb order (16 u32), head, n_live, mark cursor
+    L.off_ring = w; w += (ring_rows * L.pitch + 1u) / 2u;
+    L.n_words = w;
+    return L;
+}
+
+struct FlowArgs {
+    // plan (shape + blob; the blob is af_plan_pack.hpp's, patched per scenario with the overrides)
+    double total_time, sample_period, inv_period, tick_eps;
+    uint32_t metrics_mask, gen_out_edge, client_out_edge;
+    uint32_t n_edges, n_servers, has_lb, n_lb_edges, n_edge_marks, n_srv_marks;
+    uint32_t off_edge, off_srv, off_ep, off_row, off_emark, off_smark, off_lb;  // word offsets in the blob
+    uint32_t blob_bytes;
+    const unsigned char* blob;
+    FlowLayout L;
+    // ticks: tick_t[k] = time of tick k+1 (repeated f64 addition of the period, collector.py:50-53)
+    const double* tick_t;
+    uint32_t n_ticks;
+    // sweep
+    uint32_t n_scen;
+    const uint64_t* seeds;
+    uint32_t n_ovr;
+    const uint32_t* ovr_param;
+    const uint32_t* ovr_index;
+    const double* ovr_values;
+    uint32_t ovr_stride;
+    // inputs: arrival times of every scenario (af_pregen_arrivals), [n_scen][n_draw], AF_INF behind the last
+    const double* arrivals;
+    uint32_t n_draw;
+    const uint32_t* pre_flags;
+    // outputs (same arrays as the sequential kernels)
+    double* clock;
+    uint32_t clock_cap;
+    uint32_t* samples;
+    uint32_t tick_cap;
+    uint32_t* counts;
+    uint32_t* online_hist;
+    uint32_t* online_rps;
+    uint32_t online_hist_bins, online_rps_buckets;
+    double online_hist_scale;
+    uint32_t* n_fallback;   // [5]: scenarios handed over, then by reason (tie, list, ring, ram)
+};
+
+// ---- the algorithm, written against a wave backend W ---------------------------------------------
+//   W::lane()                       0..63
+//   W::ballot(bool) -> u64, W::any(bool)
+//   W::shfl32(v, src) / W::shfl64(v, src)   value of lane `src` (per-lane src allowed)
+//   W::sync()                       wave barrier + LDS visibility
+//   W::lds_add(p, v) -> old         atomic add on an LDS word
+//   W::global_add(p, v) / W::global_load(p) / W::global_fence()   device-scope atomic add / load past the L1 / fence
+//                                   (tick differences kept in HBM when the LDS ring would be too small)
+//   W::mbcnt(mask)                  popcount(mask & lanes below me)
+// Every W:: call is made by all 64 lanes from wave-uniform control flow.
+// IPL = list entries per lane (list capacity = 64 * IPL).
+template <class W, uint32_t IPL = 1u>
+struct Flow {
+    const FlowArgs& A;
+    AF_PLAN_AS uint64_t* blob;   // plan blob (LDS copy, patched)
+    AF_PLAN_AS uint64_t* M;      // layout words behind it
+    uint32_t lane;
+    uint64_t seed;
+
+    // uniform state (identical in every lane)
+    uint32_t cursor;             // arrivals generated so far
+    uint32_t n_list[4];          // messages pending at client-1st / LB / server / client-2nd
+    double H[4];                 // their horizons
+    uint32_t n_comp, tick_base;
+    bool gen_done;
+    // per-lane accumulators (reduced at the end)
+    uint32_t ev, drops, why;
+    int32_t run_val;             // lane s < n_series: current value of sampled series s
+
+    const double* arr;
+    double* clock;
+    uint32_t* samples;
+    uint32_t* o_hist;
+    uint32_t* o_rps;
+
+    AF_CORE Flow(const FlowArgs& a) : A(a) {}
+
+    // ---- LDS views ----------------------------------------------------------------------------
+    AF_CORE AF_PLAN_AS double* list_key(uint32_t s) const { return (AF_PLAN_AS double*)(M + A.L.off_list + 2u * A.L.cap * s); }
+    AF_CORE AF_PLAN_AS double* list_t0(uint32_t s) const { return list_key(s) + A.L.cap; }
+    AF_CORE AF_PLAN_AS uint32_t* list_aux() const { return (AF_PLAN_AS uint32_t*)(M + A.L.off_aux); }
+    AF_CORE AF_PLAN_AS double* out_key() const { return (AF_PLAN_AS double*)(M + A.L.off_out); }
+    AF_CORE AF_PLAN_AS double* out_t0() const { return out_key() + 64; }
+    AF_CORE AF_PLAN_AS uint32_t* out_aux() const { return (AF_PLAN_AS uint32_t*)(M + A.L.off_out + 128u); }
+    AF_CORE AF_PLAN_AS double* sorted() const { return (AF_PLAN_AS double*)(M + A.L.off_sorted); }
+    AF_CORE AF_PLAN_AS uint32_t* hist() const { return (AF_PLAN_AS uint32_t*)(M + A.L.off_hist); }
+    AF_CORE AF_PLAN_AS uint32_t* bbase() const { return hist() + 64; }
+    AF_CORE AF_PLAN_AS double* scal() const { return (AF_PLAN_AS double*)(M + A.L.off_hist + 64u); }   // [8] scalars
+    AF_CORE AF_PLAN_AS double* seg(uint32_t which) const { return (AF_PLAN_AS double*)(M + A.L.off_seg) + 64u * which; }
+    AF_CORE AF_PLAN_AS double* fr(uint32_t sv) const { return (AF_PLAN_AS double*)(M + A.L.off_fr) + sv * A.L.c_ring; }
+    AF_CORE AF_PLAN_AS double* gr(uint32_t sv) const { return (AF_PLAN_AS double*)(M + A.L.off_gr) + sv * A.L.g_ring; }
+    AF_CORE AF_PLAN_AS uint32_t* sends() const { return (AF_PLAN_AS uint32_t*)(M + A.L.off_cnt); }
+    AF_CORE AF_PLAN_AS uint32_t* lbw() const { return sends() + ((A.n_edges + 1u) & ~1u); }  // [0..15] order, 16 head, 17 n_live, 18 mark cursor, [24..31] arrivals per server
+    AF_CORE AF_PLAN_AS int32_t* ring() const { return (AF_PLAN_AS int32_t*)(M + A.L.off_ring); }
+    AF_CORE AF_PLAN_AS double* spike_cum() const { return (AF_PLAN_AS double*)(M + A.L.off_spike); }
+
+    AF_CORE const AF_PLAN_AS uint64_t* erec(uint32_t e) const { return blob + A.off_edge + af::EREC * e; }
+    AF_CORE const AF_PLAN_AS uint64_t* emark(uint32_t i) const { return blob + A.off_emark + af::MREC * i; }
+    AF_CORE const AF_PLAN_AS uint64_t* smark(uint32_t i) const { return blob + A.off_smark + af::NREC * i; }
+
+    // ---- small wave helpers ---------------------------------------------------------------------
+    AF_CORE static uint32_t popc64(uint64_t m) { return (uint32_t)__builtin_popcountll(m); }
+    AF_CORE double bcast_f64(double v, uint32_t src) const { return u2d(W::shfl64(d2u(v), src)); }
+    AF_CORE uint32_t excl_scan(uint32_t v, uint32_t& total) const {
+        uint32_t inc = v;
+#pragma unroll
+        for (uint32_t d = 1u; d < 64u; d <<= 1) {
+            const uint32_t o = W::shfl32(inc, lane >= d ? lane - d : lane);
+            if (lane >= d) inc += o;
+        }
+        total = W::shfl32(inc, 63u);
+        return inc - v;
+    }
+    AF_CORE uint32_t wave_sum(uint32_t v) const {
+#pragma unroll
+        for (uint32_t d = 1u; d < 64u; d <<= 1) v += W::shfl32(v, lane ^ d);
+        return v;
+    }
+    AF_CORE uint32_t wave_or(uint32_t v) const {
+#pragma unroll
+        for (uint32_t d = 1u; d < 64u; d <<= 1) v |= W::shfl32(v, lane ^ d);
+        return v;
+    }
+
+    // ---- ticks ------------------------------------------------------------------------------------
+    // number of ticks strictly before x, clipped to n_ticks (tick k = 1.. at tick_t[k-1])
+    AF_CORE uint32_t tick_index(double x, bool flag_ties) {
+        const uint32_t N = A.n_ticks;
+        if (!(x > 0.0)) return 0u;
+        const double q = x * A.inv_period;
+        if (q >= (double)N + 1.0) return N;
+        uint32_t g = (uint32_t)q;
+        const double frac = q - (double)g;
+        if (frac > A.tick_eps && frac < 1.0 - A.tick_eps) return g < N ? g : N;   // safely between two ticks
+        if (g > N) g = N;                                                             // next to a tick: look it up
+        while (g < N && A.tick_t[g] < x) ++g;
+        while (g > 0u && A.tick_t[g - 1u] >= x) --g;
+        if (flag_ties && g < N && A.tick_t[g] == x) why |= FLOW_WHY_TIE;
+        return g;
+    }
+    // the counter of `series` is larger by w during [a, b).  Differences go to the LDS ring, or -- plans whose
+    // intervals reach further ahead than an LDS ring can hold (ring_rows == 0) -- straight into the scenario's
+    // (zeroed) rows of the sample array in HBM, which flush_ticks() then prefix-sums in place.
+    AF_CORE void add_interval(uint32_t series, double a, double b, int32_t w) {
+        if (samples == nullptr) return;   // series not stored: ticks observe nothing, no tie can matter
+        const uint32_t ia = tick_index(a, true), ib = tick_index(b, true);
+        if (ia == ib) return;
+        const uint32_t R = A.L.ring_rows, N = A.n_ticks < A.tick_cap ? A.n_ticks : A.tick_cap;
+        if (R == 0u) {
+            if (ia < N) W::global_add(samples + (size_t)ia * A.L.pitch + series, (uint32_t)w);
+            if (ib < N) W::global_add(samples + (size_t)ib * A.L.pitch + series, (uint32_t)(-w));
+            return;
+        }
+        if (ia < N) {
+            if (ia - tick_base >= R) why |= FLOW_WHY_RING;
+            else W::lds_add((AF_PLAN_AS uint32_t*)(ring() + (ia & (R - 1u)) * A.L.pitch + series), (uint32_t)w);
+        }
+        if (ib < N) {
+            if (ib - tick_base >= R) why |= FLOW_WHY_RING;
+            else W::lds_add((AF_PLAN_AS uint32_t*)(ring() + (ib & (R - 1u)) * A.L.pitch + series), (uint32_t)(-w));
+        }
+    }
+    // rows [tick_base, upto) are final: prefix-sum the differences and stream the rows out
+    AF_CORE void flush_ticks(uint32_t upto) {
+        if (samples != nullptr) {
+            const uint32_t R = A.L.ring_rows, pitch = A.L.pitch, n_series = A.n_edges + 3u * A.n_servers;
+            const bool edges_on = (A.metrics_mask & af::METRIC_EDGE) != 0u;
+            constexpr uint32_t all = af::METRIC_READY | af::METRIC_IO | af::METRIC_RAM;
+            const bool servers_on = (A.metrics_mask & all) == all;
+            const bool is_srv = lane >= A.n_edges && lane < n_series;
+            const bool is_ram = is_srv && (lane - A.n_edges) % 3u == 2u;
+            const bool on = lane < A.n_edges ? edges_on : (is_srv && servers_on);
+            const uint32_t stop = upto < A.tick_cap ? upto : A.tick_cap;
+            for (uint32_t r = tick_base; r < stop; ++r) {
+                if (lane < pitch) {
+                    if (R == 0u) {
+                        run_val += (int32_t)W::global_load(samples + (size_t)r * pitch + lane);
+                    } else {
+                        AF_PLAN_AS int32_t* cell = ring() + (r & (R - 1u)) * pitch + lane;
+                        run_val += *cell;
+                        *cell = 0;
+                    }
+                    uint32_t word = 0u;
+                    if (on) word = is_ram ? __builtin_bit_cast(uint32_t, (float)(double)run_val) : (uint32_t)run_val;
+                    samples[(size_t)r * pitch + lane] = word;
+                }
+            }
+        }
+        tick_base = upto;
+    }
+
+    // ---- edges --------------------------------------------------------------------------------------
+    // cumulative spike of edge e seen by a message sent at `now` (injection.py:191-198: marks applied
+    // strictly before `now`; a mark AT `now` is a tie)
+    AF_CORE double spike_at(uint32_t e, double now) {
+        double sp = 0.0;
+        for (uint32_t i = 0u; i < A.n_edge_marks; ++i) {
+            const double tm = u2d(emark(i)[0]);
+            if ((uint32_t)emark(i)[2] != e) continue;
+            if (tm < now) sp = spike_cum()[i];
+            else if (tm == now) why |= FLOW_WHY_TIE;
+        }
+        return sp;
+    }
+    // EdgeRuntime._deliver (edge.py:73-116) for the idx-th message of edge e, sent at `now`.
+    // Returns false if the message is dropped; else `key` = delivery time.
+    AF_CORE bool edge_send(uint32_t e, uint32_t idx, double now, double& key) {
+        const AF_PLAN_AS uint64_t* r = erec(e);
+        const double mean = u2d(r[0]), sigma = u2d(r[1]), dropout = u2d(r[2]);
+        const uint32_t dist = (uint32_t)(r[3] >> 16) & 0xFFu;
+        const double transit = af::pre_edge_draw(seed, e, idx, dist, mean, sigma, dropout);
+        if (transit < 0.0) {
+            drops += 1u;
+            return false;
+        }
+        const double spike = A.n_edge_marks != 0u ? spike_at(e, now) : 0.0;
+        key = now + (transit + spike);
+        if (!(key > now)) why |= FLOW_WHY_TIE;     // a zero (or negative) delay: SimPy orders it among the zero-time steps
+        add_interval(e, now, key, 1);
+        return true;
+    }
+
+    // ---- station lists -------------------------------------------------------------------------------
+    AF_CORE void append(uint32_t s, bool have, double key, double t0, uint32_t aux) {
+        const uint64_t m = W::ballot(have);
+        const uint32_t pos = n_list[s] + W::mbcnt(m);
+        if (have) {
+            list_key(s)[pos] = key;
+            list_t0(s)[pos] = t0;
+            if (s == 2u) list_aux()[pos] = aux;
+        }
+        n_list[s] += popc64(m);
+    }
+
+    // Rank the messages of list s with time < min(H_in, T); hand the `n_sel` earliest (<= room, <= 64) to
+    // lanes 0..n_sel-1 in time order; keep the rest.  Returns n_sel.
+    AF_CORE uint32_t select(uint32_t s, double H_in, uint32_t room, double& okey, double& ot0, uint32_t& oaux) {
+        W::sync();   // appends of the previous station are visible
+        const double lo = H[s];
+        const double hi = H_in < A.total_time ? H_in : A.total_time;
+        const uint32_t n = n_list[s];
+        okey = AF_INF;
+        ot0 = 0.0;
+        oaux = 0u;
+        if (!(hi > lo)) return 0u;
+        if (n == 0u) {
+            H[s] = hi;
+            return 0u;
+        }
+        AF_PLAN_AS double* K = list_key(s);
+        AF_PLAN_AS double* T0 = list_t0(s);
+        AF_PLAN_AS uint32_t* AX = list_aux();
+        double sc = 64.0 / (hi - lo);
+        if (!(sc < 1e300)) sc = 1e300;
+        hist()[lane] = 0u;
+        W::sync();
+        // my (up to 4) entries; bucket counts
+        double k[IPL], t[IPL];
+        uint32_t a[IPL], b[IPL], slot[IPL];
+        bool valid[IPL], elig[IPL];
+#pragma unroll
+        for (uint32_t q = 0u; q < IPL; ++q) {
+            valid[q] = elig[q] = false;
+            k[q] = t[q] = 0.0;
+            a[q] = b[q] = slot[q] = 0u;
+            {
+                const uint32_t i = q * 64u + lane;
+                valid[q] = i < n;
+                if (valid[q]) {
+                    k[q] = K[i];
+                    t[q] = T0[i];
+                    a[q] = s == 2u ? AX[i] : 0u;
+                    elig[q] = k[q] < hi;
+                    if (elig[q]) {
+                        double x = (k[q] - lo) * sc;
+                        x = x < 63.0 ? x : 63.0;
+                        b[q] = x > 0.0 ? (uint32_t)x : 0u;
+                        slot[q] = W::lds_add(hist() + b[q], 1u);
+                    }
+                }
+            }
+        }
+        W::sync();
+        uint32_t E;
+        const uint32_t cnt = hist()[lane];
+        const uint32_t base = excl_scan(cnt, E);
+        bbase()[lane] = base;
+        W::sync();
+#pragma unroll
+        for (uint32_t q = 0u; q < IPL; ++q)
+            if (elig[q]) sorted()[bbase()[b[q]] + slot[q]] = k[q];
+        W::sync();
+        uint32_t rank[IPL];
+#pragma unroll
+        for (uint32_t q = 0u; q < IPL; ++q) {
+            rank[q] = 0u;
+            if (elig[q]) {
+                const uint32_t p0 = bbase()[b[q]], p1 = p0 + hist()[b[q]], me = p0 + slot[q];
+                uint32_t r = p0;
+                for (uint32_t p = p0; p < p1; ++p) {
+                    const double kk = sorted()[p];
+                    r += kk < k[q] ? 1u : 0u;
+                    if (kk == k[q] && p != me) why |= FLOW_WHY_TIE;   // two events of this station at one instant
+                }
+                rank[q] = r;
+            }
+        }
+        uint32_t n_sel = E < room ? E : room;
+        n_sel = n_sel < 64u ? n_sel : 64u;
+        if (n_sel < E) {   // the first message left behind bounds the horizon
+#pragma unroll
+            for (uint32_t q = 0u; q < IPL; ++q)
+                if (elig[q] && rank[q] == n_sel) scal()[0] = k[q];
+        }
+        uint32_t kept = 0u;
+#pragma unroll
+        for (uint32_t q = 0u; q < IPL; ++q) {
+            {
+                const bool sel = elig[q] && rank[q] < n_sel;
+                if (sel) {
+                    out_key()[rank[q]] = k[q];
+                    out_t0()[rank[q]] = t[q];
+                    out_aux()[rank[q]] = a[q];
+                }
+                const bool keep = valid[q] && !sel;
+                const uint64_t m = W::ballot(keep);
+                const uint32_t pos = kept + W::mbcnt(m);
+                if (keep) {
+                    K[pos] = k[q];
+                    T0[pos] = t[q];
+                    if (s == 2u) AX[pos] = a[q];
+                }
+                kept += popc64(m);
+            }
+        }
+        n_list[s] = kept;
+        W::sync();
+        H[s] = n_sel < E ? scal()[0] : hi;
+        if (lane < n_sel) {
+            okey = out_key()[lane];
+            ot0 = out_t0()[lane];
+            oaux = out_aux()[lane];
+        }
+        return n_sel;
+    }
+
+    // index of each lane's message on its edge: sends[e] + (messages of lower lanes on the same edge).
+    // Candidate edges: the LB's out-edges (payload order) or the servers' out-edges; lane c advances
+    // candidate c's counter afterwards.
+    AF_CORE uint32_t claim_send_index(bool have, uint32_t e, bool server_edges) {
+        const uint32_t n_cand = server_edges ? A.n_servers : A.n_lb_edges;
+        uint32_t idx = 0u, add_for_lane = 0u, edge_for_lane = 0u;
+        for (uint32_t c = 0u; c < n_cand; ++c) {
+            const uint32_t ce = server_edges ? (uint32_t)(blob[A.off_srv + af::SREC * c + 1u] >> 16) & 0xFFFFu
+                                             : (uint32_t)blob[A.off_lb + c];
+            const uint64_t m = W::ballot(have && e == ce);
+            if (have && e == ce) idx = sends()[ce] + W::mbcnt(m);
+            if (lane == c) {
+                add_for_lane = popc64(m);
+                edge_for_lane = ce;
+            }
+        }
+        W::sync();
+        if (add_for_lane != 0u) sends()[edge_for_lane] += add_for_lane;
+        W::sync();
+        return idx;
+    }
+
+    // ---- load balancer (round robin, lb_algorithms.py:22-36; outages injection.py:201-226) -----------
+    // picks for the n_sel messages now in out_key() (time order); lane r gets the out-edge of message r
+    AF_CORE uint32_t lb_pick(uint32_t n_sel, double my_key) {
+        AF_PLAN_AS uint32_t* lw = lbw();
+        uint32_t pick = 0u;
+        const uint32_t mi = lw[18];
+        const double t_last = bcast_f64(my_key, n_sel - 1u);
+        const bool marks_inside = mi < A.n_srv_marks && u2d(smark(mi)[0]) <= t_last;
+        if (!marks_inside) {
+            const uint32_t head = lw[16], nl = lw[17];
+            if (lane < n_sel) pick = lw[(head + lane) % nl];
+            W::sync();
+            if (lane == 0u) lw[16] = (head + n_sel) % nl;
+        } else {
+            W::sync();
+            if (lane == 0u) {   // rare (one round per outage mark): one lane walks the messages in time order
+                uint32_t head = lw[16], nl = lw[17], cur = mi;
+                for (uint32_t r = 0u; r < n_sel; ++r) {
+                    const double tr = out_key()[r];
+                    while (cur < A.n_srv_marks && u2d(smark(cur)[0]) <= tr) {
+                        if (u2d(smark(cur)[0]) == tr) why |= FLOW_WHY_TIE;
+                        const uint64_t meta = smark(cur)[1];
+                        const uint32_t e1 = (uint32_t)meta;
+                        if (e1 != 0u) {
+                            uint32_t tmp[16];
+                            for (uint32_t i = 0u; i < nl; ++i) tmp[i] = lw[(head + i) % nl];   // materialise the rotation
+                            uint32_t m2 = 0u;
+                            for (uint32_t i = 0u; i < nl; ++i)
+                                if (tmp[i] != e1 - 1u) tmp[m2++] = tmp[i];
+                            if (!(meta >> 32)) tmp[m2++] = e1 - 1u;   // SERVER_UP: back in at the tail
+                            nl = m2;
+                            head = 0u;
+                            for (uint32_t i = 0u; i < nl; ++i) lw[i] = tmp[i];
+                        }
+                        cur += 1u;
+                    }
+                    out_aux()[r] = lw[head % (nl ? nl : 1u)];
+                    head = nl ? (head + 1u) % nl : 0u;
+                }
+                lw[16] = head;
+                lw[17] = nl;
+                lw[18] = cur;
+            }
+            W::sync();
+            if (lane < n_sel) pick = out_aux()[lane];
+        }
+        W::sync();
+        return pick;
+    }
+
+    // ---- servers (server.py:79-276 for endpoints of the form IO* CPU* IO*) ----------------------------
+    // Lane k < n_servers walks the arrivals of server k (time order, segment [off, off+cnt) of seg(0)):
+    //   B = arrival + leading I/O steps; S = max(B, release of the core freed c arrivals ago);
+    //   F = S + CPU steps; G = F + trailing I/O steps           (every + is one timed event)
+    AF_CORE void server_walk(uint32_t off, uint32_t cnt) {
+        const uint32_t sv = lane;
+        const uint64_t meta = blob[A.off_srv + af::SREC * sv + 1u];
+        const uint32_t cores = (uint32_t)meta & 0xFFFFu;
+        const uint32_t ep = (uint32_t)(meta >> 32) & 0xFFFFu;
+        const double ram = u2d(blob[A.off_ep + af::PREC * ep]);
+        const uint32_t row0 = (uint32_t)blob[A.off_ep + af::PREC * ep + 1u];
+        const double ram_mb = u2d(blob[A.off_srv + af::SREC * sv]);
+        uint32_t slots = 0xFFFFFFFFu;   // requests that fit the RAM at once
+        if (ram > 0.0) {
+            const double s = ram_mb / ram;
+            slots = s < 4.0e9 ? (uint32_t)s : 0xFFFFFFFFu;
+            while ((double)slots * ram > ram_mb && slots > 0u) --slots;
+        }
+        const double T = A.total_time;
+        AF_PLAN_AS uint32_t* arrivals = lbw() + 24u;   // [kMaxServers] requests admitted so far
+        uint32_t j = arrivals[sv];
+        for (uint32_t i = 0u; i < cnt; ++i, ++j) {
+            const double a = seg(0)[off + i];
+            // RAM admission (server.py:146-149): strict FIFO; every request of this server needs the same
+            // amount, so request j is admitted when request j - slots has given its RAM back
+            double adm = a;
+            if (ram > 0.0) {
+                if (slots == 0u) {
+                    why |= FLOW_WHY_RAM;                                     // never fits: the reference blocks the queue for good
+                } else if (slots <= A.L.g_ring) {
+                    if (j >= slots) {
+                        const double g = gr(sv)[(j - slots) & (A.L.g_ring - 1u)];
+                        if (g == a) why |= FLOW_WHY_TIE;                     // arrival and RAM release at one instant
+                        if (g > a) adm = g;
+                    }
+                } else if (j >= A.L.g_ring && !(gr(sv)[(j - A.L.g_ring) & (A.L.g_ring - 1u)] < a)) {
+                    why |= FLOW_WHY_RAM;                                     // more requests inside than the ring remembers
+                }
+            }
+            seg(0)[off + i] = adm;
+            uint32_t row = row0;
+            double t = adm;
+            uint32_t e_cnt = 0u;
+            uint32_t kind = (uint32_t)blob[A.off_row + af::TREC * row + 2u];
+            while (kind == af::STEP_IO) {   // leading I/O steps
+                t = t + u2d(blob[A.off_row + af::TREC * row]);
+                e_cnt += t < T ? 1u : 0u;
+                kind = (uint32_t)blob[A.off_row + af::TREC * (++row) + 2u];
+            }
+            const double b = t;
+            double s = b;
+            if (kind == af::STEP_CPU) {
+                if (j >= cores) {
+                    const double rel = fr(sv)[j % cores];   // release of the core freed `cores` arrivals ago
+                    if (rel == b) why |= FLOW_WHY_TIE;   // arrival and core release at one instant: SimPy decides who waits
+                    if (rel > b) s = rel;
+                }
+                t = s;
+                while (kind == af::STEP_CPU) {
+                    t = t + u2d(blob[A.off_row + af::TREC * row]);
+                    e_cnt += t < T ? 1u : 0u;
+                    kind = (uint32_t)blob[A.off_row + af::TREC * (++row) + 2u];
+                }
+                fr(sv)[j % cores] = t;
+            }
+            const double f = t;
+            while (kind == af::STEP_IO) {   // trailing I/O steps
+                t = t + u2d(blob[A.off_row + af::TREC * row]);
+                e_cnt += t < T ? 1u : 0u;
+                kind = (uint32_t)blob[A.off_row + af::TREC * (++row) + 2u];
+            }
+            gr(sv)[j & (A.L.g_ring - 1u)] = t;
+            seg(2)[off + i] = b;
+            seg(3)[off + i] = s;
+            seg(4)[off + i] = f;
+            seg(5)[off + i] = t;
+            ev += e_cnt;
+        }
+        arrivals[sv] = j;
+    }
+
+    // ---- completion (client.py:62-69) -------------------------------------------------------------------
+    AF_CORE void complete(bool have, uint32_t r, double t0, double now) {
+        if (!have) return;
+        const uint32_t at = n_comp + r;
+        if (clock != nullptr) {
+            if (at < A.clock_cap) {
+                clock[2u * (size_t)at] = t0;
+                clock[2u * (size_t)at + 1u] = now;
+            }
+        }
+        if (o_hist != nullptr) {
+            const double bf = (now - t0) * A.online_hist_scale;
+            AF_BUMP(o_hist + (bf >= (double)(A.online_hist_bins - 1u) ? A.online_hist_bins - 1u : (uint32_t)bf));
+        }
+        if (o_rps != nullptr) {
+            const double kf = __builtin_ceil(now);
+            const uint32_t k = kf < 1.0 ? 1u : (uint32_t)kf;
+            if (k <= A.online_rps_buckets) AF_BUMP(o_rps + (k - 1u));
+        }
+    }
+
+    // ---- one scenario ------------------------------------------------------------------------------------
+    // `smem` : LDS of this wave (plan blob + layout words); `sc` : scenario index in the launch
+    AF_CORE void run(AF_PLAN_AS uint64_t* smem, uint32_t sc) {
+        lane = W::lane();
+        blob = smem;
+        M = smem + A.blob_bytes / 8u;
+        seed = A.seeds[sc];
+        arr = A.arrivals + (size_t)sc * A.n_draw;
+        clock = A.clock ? A.clock + (size_t)sc * A.clock_cap * 2u : nullptr;
+        samples = A.samples ? A.samples + (size_t)sc * A.L.pitch * A.tick_cap : nullptr;
+        o_hist = A.online_hist ? A.online_hist + (size_t)sc * A.online_hist_bins : nullptr;
+        o_rps = A.online_rps ? A.online_rps + (size_t)sc * A.online_rps_buckets : nullptr;
+        const double T = A.total_time;
+
+        // plan blob -> LDS, layout words zeroed
+        {
+            const uint64_t* g = reinterpret_cast<const uint64_t*>(A.blob);
+            for (uint32_t i = lane; i < A.blob_bytes / 8u; i += 64u) blob[i] = g[i];
+            for (uint32_t i = lane; i < A.L.n_words; i += 64u) M[i] = 0ull;
+        }
+        if (samples != nullptr && A.L.ring_rows == 0u) {   // tick differences accumulate in the sample rows themselves
+            const uint32_t rows = A.n_ticks < A.tick_cap ? A.n_ticks : A.tick_cap;
+            const size_t words = (size_t)rows * A.L.pitch;
+            for (size_t i = (size_t)lane * 4u; i < words; i += 256u) af::store4(samples + i, 0u, 0u, 0u, 0u);
+            W::global_fence();
+        }
+        W::sync();
+        if (lane == 0u) {
+            // per-scenario parameters (af_override_t columns): edge law, step times
+            for (uint32_t k = 0u; k < A.n_ovr; ++k) {
+                const uint64_t v = d2u(A.ovr_values[(size_t)k * A.ovr_stride + sc]);
+                const uint32_t p = A.ovr_param[k], idx = A.ovr_index[k];
+                if (p == af::PARAM_EDGE_MEAN) blob[A.off_edge + af::EREC * idx] = v;
+                else if (p == af::PARAM_EDGE_SIGMA) blob[A.off_edge + af::EREC * idx + 1u] = v;
+                else if (p == af::PARAM_EDGE_DROPOUT) blob[A.off_edge + af::EREC * idx + 2u] = v;
+                else if (p == af::PARAM_STEP_TIME) blob[A.off_row + af::TREC * idx] = v;   // idx is a step ROW
+            }
+            // cumulative spike per edge after every mark, the reference's own += / -= in f64 (injection.py:191-198)
+            for (uint32_t i = 0u; i < A.n_edge_marks; ++i) {
+                double acc = 0.0;
+                const uint32_t e = (uint32_t)emark(i)[2];
+                for (uint32_t p = 0u; p < i; ++p)
+                    if ((uint32_t)emark(p)[2] == e) acc = spike_cum()[p];
+                spike_cum()[i] = acc + u2d(emark(i)[1]);
+            }
+            AF_PLAN_AS uint32_t* lw = lbw();
+            for (uint32_t i = 0u; i < A.n_lb_edges; ++i) lw[i] = (uint32_t)blob[A.off_lb + i];
+            lw[16] = 0u;
+            lw[17] = A.n_lb_edges;
+            lw[18] = 0u;
+        }
+        W::sync();
+
+        cursor = n_comp = tick_base = 0u;
+        ev = drops = 0u;
+        why = 0u;
+        run_val = 0;
+        gen_done = false;
+        for (uint32_t s = 0u; s < 4u; ++s) {
+            n_list[s] = 0u;
+            H[s] = 0.0;
+        }
+        const uint32_t cap = A.L.cap;
+        const uint32_t first_srv_stage = A.has_lb ? 1u : 2u;   // where the client's out-edge leads
+
+        for (;;) {
+            uint32_t work = 0u;
+            const double h_done_before = H[3];
+            // ---- generator (rqs_generator.py:97-119): up to 64 arrivals, each sent on the generator's edge
+            double H_in;
+            {
+                uint32_t room = cap - n_list[0];
+                room = room < 64u ? room : 64u;
+                const uint32_t i = cursor + lane;
+                const double t0 = (lane < room && i < A.n_draw) ? arr[i] : AF_INF;
+                // with an LDS tick ring a round must not run further ahead of the completed ticks than the ring holds
+                const double t_cap = (samples != nullptr && A.L.ring_rows != 0u)
+                                         ? (double)(tick_base + A.L.ring_rows / 2u) * A.sample_period : AF_INF;
+                const uint64_t vm = W::ballot(t0 < T && t0 < t_cap);   // arrival times increase: a prefix of the lanes
+                const uint32_t n_new = popc64(vm);
+                const uint32_t nxt = cursor + n_new;
+                H_in = nxt < A.n_draw ? arr[nxt] : AF_INF;
+                gen_done = !(H_in < T);
+                const bool have = lane < n_new;
+                double key = 0.0;
+                bool ok = false;
+                if (have) {
+                    ev += 1u;
+                    ok = edge_send(A.gen_out_edge, i, t0, key);
+                }
+                append(0u, ok, key, t0, 0u);
+                cursor = nxt;
+                work += n_new;
+            }
+            // ---- client, first visit (client.py:46-60): forward on the client's out-edge
+            {
+                double key, t0;
+                uint32_t aux;
+                const uint32_t nxt = first_srv_stage;
+                const uint32_t n_sel = select(0u, H_in, cap - n_list[nxt], key, t0, aux);
+                const bool have = lane < n_sel;
+                const uint32_t e = A.client_out_edge;
+                double k2 = 0.0;
+                bool ok = false;
+                if (have) {
+                    ev += 1u;
+                    ok = edge_send(e, sends()[e] + lane, key, k2);
+                }
+                W::sync();
+                if (lane == 0u) sends()[e] += n_sel;
+                const uint32_t tgt = (uint32_t)(erec(e)[3] >> 8) & 0xFFu;
+                append(nxt, ok, k2, t0, tgt);
+                work += n_sel;
+                H_in = H[0];
+            }
+            // ---- load balancer
+            if (A.has_lb) {
+                double key, t0;
+                uint32_t aux;
+                const uint32_t n_sel = select(1u, H_in, cap - n_list[2], key, t0, aux);
+                if (n_sel > 0u) {
+                    const bool have = lane < n_sel;
+                    const uint32_t e = lb_pick(n_sel, key);
+                    const uint32_t idx = claim_send_index(have, e, false);
+                    double k3 = 0.0;
+                    bool ok = false;
+                    if (have) {
+                        ev += 1u;
+                        ok = edge_send(e, idx, key, k3);
+                    }
+                    const uint32_t tgt = have ? (uint32_t)(erec(e)[3] >> 8) & 0xFFu : 0u;
+                    append(2u, ok, k3, t0, tgt);
+                }
+                work += n_sel;
+                H_in = H[1];
+            }
+            // ---- servers
+            {
+                double key, t0;
+                uint32_t sv;
+                const uint32_t n_sel = select(2u, H_in, cap - n_list[3], key, t0, sv);
+                if (n_sel > 0u) {
+                    const bool have = lane < n_sel;
+                    // per-server segments of the (time-ordered) arrivals
+                    uint32_t my_off = 0u, my_cnt = 0u, pos = 0u, off = 0u;
+                    for (uint32_t k = 0u; k < A.n_servers; ++k) {
+                        const uint64_t m = W::ballot(have && sv == k);
+                        if (have && sv == k) pos = off + W::mbcnt(m);
+                        if (lane == k) {
+                            my_off = off;
+                            my_cnt = popc64(m);
+                        }
+                        off += popc64(m);
+                    }
+                    if (have) {
+                        ev += 1u;
+                        seg(0)[pos] = key;
+                        seg(1)[pos] = t0;
+                    }
+                    W::sync();
+                    if (lane < A.n_servers) server_walk(my_off, my_cnt);
+                    W::sync();
+                    double k4 = 0.0;
+                    bool ok = false;
+                    uint32_t e = 0u;
+                    if (have) {
+                        const double adm = seg(0)[pos], b = seg(2)[pos], s = seg(3)[pos], f = seg(4)[pos], g = seg(5)[pos];
+                        const uint64_t meta = blob[A.off_srv + af::SREC * sv + 1u];
+                        e = (uint32_t)(meta >> 16) & 0xFFFFu;
+                        const uint32_t ep = (uint32_t)(meta >> 32) & 0xFFFFu;
+                        const double ram = u2d(blob[A.off_ep + af::PREC * ep]);
+                        const uint32_t s0 = A.n_edges + 3u * sv;
+                        if (s > b) add_interval(s0, b, s, 1);                 // ready queue: waited for a core (server.py:215-225)
+                        if (b > adm) add_interval(s0 + 1u, adm, b, 1);        // leading I/O steps
+                        if (g > f) add_interval(s0 + 1u, f, g, 1);            // trailing I/O steps
+                        if (ram > 0.0) add_interval(s0 + 2u, adm, g, (int32_t)ram);   // RAM held from admission to the end (server.py:146-149, 270-273)
+                    }
+                    // transport() on the server's out-edge at G (server.py:276), if the horizon allows
+                    const bool sending = have && seg(5)[pos] < T;
+                    const uint32_t idx = claim_send_index(sending, e, true);
+                    if (sending) ok = edge_send(e, idx, seg(5)[pos], k4);
+                    append(3u, ok, k4, t0, 0u);
+                }
+                work += n_sel;
+                H_in = H[2];
+            }
+            // ---- client, second visit (client.py:62-69): the request is complete
+            {
+                double key, t0;
+                uint32_t aux;
+                const uint32_t n_sel = select(3u, H_in, 64u, key, t0, aux);
+                if (lane < n_sel) ev += 1u;
+                complete(lane < n_sel, lane, t0, key);
+                n_comp += n_sel;
+                work += n_sel;
+            }
+            // ---- ticks that can no longer change
+            const bool finished = gen_done && work == 0u && !(H[3] < T);
+            W::sync();
+            flush_ticks(finished ? A.n_ticks : tick_index(H[3], false));
+            W::sync();
+            const bool stuck = work == 0u && !finished && !(H[3] > h_done_before);
+            if (stuck) why |= FLOW_WHY_LIST;   // nothing moved, no horizon advanced: a list is full of later messages
+            if (finished || W::any(why != 0u)) break;
+        }
+
+        // ---- counts
+        const uint32_t ev_all = wave_sum(ev), drop_all = wave_sum(drops), why_all = wave_or(why);
+        if (lane == 0u) {
+            uint32_t flags = A.pre_flags[sc];
+            if (n_comp > A.clock_cap && clock != nullptr) flags |= af::FLAG_CLOCK_OVERFLOW;
+            if (A.n_ticks > A.tick_cap && samples != nullptr) flags |= af::FLAG_TICK_OVERFLOW;
+            if (why_all != 0u) flags |= FLAG_FLOW_FALLBACK | why_all;
+            uint32_t marks = 0u;
+            for (uint32_t i = 0u; i < A.n_edge_marks; ++i) marks += u2d(emark(i)[0]) < T ? 1u : 0u;
+            for (uint32_t i = 0u; i < A.n_srv_marks; ++i) marks += u2d(smark(i)[0]) < T ? 1u : 0u;
+            uint32_t* c = A.counts + (size_t)sc * af::CNT_SLOTS;
+            c[af::CNT_GENERATED] = cursor;
+            c[af::CNT_COMPLETED] = n_comp;
+            c[af::CNT_DROPPED] = drop_all;
+            c[af::CNT_EVENTS] = ev_all;
+            c[af::CNT_TICKS] = A.n_ticks;
+            c[af::CNT_FLAGS] = flags;
+            c[af::CNT_MAX_LIVE] = 0u;   // a diagnostic of the sequential kernels (peak of live requests)
+            c[af::CNT_MARKS] = marks;
+        }
+    }
+};
+
+}  // namespace aff

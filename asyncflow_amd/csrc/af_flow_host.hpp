@@ -1,0 +1,100 @@
+// af_flow_host.hpp -- HOST-side helpers of the stage-parallel kernel (af_flow.hpp): which plans it can
+// run, the tick-time table, the LDS layout.  Plain C++, no HIP (also used by the test-only wave emulator).
+#pragma once
+
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "../../include/asyncflow_hip.h"
+#include "af_flow.hpp"
+
+namespace aff {
+
+// Empty string: the plan's request path is the feed-forward chain the flow kernel implements.
+// Otherwise the reason it is not (the sequential next-event kernels run such plans).
+inline std::string flow_ineligible_reason(const af_plan_t& p) {
+    if (p.n_servers == 0) return "no server";
+    if (p.n_servers > kMaxServers) return "more than 8 servers";
+    if (p.n_edges + 3u * p.n_servers > 64u) return "more than 64 sampled series";
+    if (p.edge_target_kind[p.gen_out_edge] != AF_NODE_CLIENT) return "generator does not feed the client";
+    const uint32_t ck = p.edge_target_kind[p.client_out_edge];
+    if (p.has_lb) {
+        if (ck != AF_NODE_LB) return "client does not feed the load balancer";
+        if (p.lb_algo != AF_LB_ROUND_ROBIN) return "least-connections routing depends on in-flight counts";
+        if (p.n_lb_edges == 0 || p.n_lb_edges > 16u) return "load balancer fan-out outside 1..16";
+        for (uint32_t i = 0; i < p.n_lb_edges; ++i)
+            if (p.edge_target_kind[p.lb_edges[i]] != AF_NODE_SERVER) return "load balancer edge does not lead to a server";
+    } else if (ck != AF_NODE_SERVER) {
+        return "client does not feed a server";
+    }
+    for (uint32_t e = 0; e < p.n_edges; ++e)
+        if (p.edge_dist[e] == AF_DIST_POISSON) return "integer (Poisson) edge latencies tie constantly";
+    for (uint32_t s = 0; s < p.n_servers; ++s) {
+        if (p.edge_target_kind[p.srv_out_edge[s]] != AF_NODE_CLIENT) return "server chain";
+        if (p.srv_ep_begin[s + 1] - p.srv_ep_begin[s] != 1u) return "several endpoints per server";
+        if (p.srv_cores[s] > 64u) return "more than 64 cores";
+        const uint32_t ep = p.srv_ep_begin[s];
+        const double ram = p.ep_ram[ep];
+        if (ram != std::floor(ram) || ram < 0.0 || ram > 16777216.0) return "RAM need is not a small integer";
+        // step program must be IO* CPU* IO*: one contiguous CPU segment (no re-entry into the core queue)
+        uint32_t phase = 0;  // 0 leading IO, 1 CPU, 2 trailing IO
+        for (uint32_t i = p.ep_step_begin[ep]; i < p.ep_step_begin[ep + 1]; ++i) {
+            const bool cpu = p.step_kind[i] == AF_STEP_CPU;
+            if (phase == 0 && cpu) phase = 1;
+            else if (phase == 1 && !cpu) phase = 2;
+            else if (phase == 2 && cpu) return "endpoint re-enters the core queue after an I/O step";
+        }
+    }
+    return std::string();
+}
+
+struct TickTable {
+    std::vector<double> t;   // t[k] = time of tick k+1
+    double inv_period = 0.0, eps = 0.0;
+};
+// tick times exactly as the collector produces them (0 + p + p + ..., collector.py:50-53) and the
+// band around k * period inside which a time has to be compared with the table itself
+inline TickTable make_tick_table(double period, double total_time) {
+    TickTable tt;
+    tt.inv_period = 1.0 / period;
+    double t = 0.0 + period, dev = 0.0;
+    while (t < total_time) {
+        tt.t.push_back(t);
+        const double q = t * tt.inv_period;
+        const double d = std::fabs(q - (double)tt.t.size());
+        if (d > dev) dev = d;
+        t = t + period;
+    }
+    {   // one more tick position (the first one NOT taken) also bounds the fast path
+        const double d = std::fabs(t * tt.inv_period - (double)(tt.t.size() + 1));
+        if (d > dev) dev = d;
+    }
+    tt.eps = 4.0 * dev + 1e-9;
+    if (tt.eps > 0.25) tt.eps = 0.5;   // hopeless drift: every lookup goes through the table
+    return tt;
+}
+
+inline uint32_t pow2_ge(uint32_t v) {
+    uint32_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// list capacity (64 * ipl), tick-ring rows: from the expected number of messages in flight per
+// station and the time a round spans (host estimates; overflow is detected by the kernel)
+inline FlowLayout choose_flow_layout(const af_plan_t& p, uint32_t ipl, uint32_t ring_rows) {
+    uint32_t cmax = 1, gmax = 1;
+    for (uint32_t s = 0; s < p.n_servers; ++s) {
+        if (p.srv_cores[s] > cmax) cmax = p.srv_cores[s];
+        const double ram = p.ep_ram[p.srv_ep_begin[s]];
+        if (ram > 0.0) {
+            const double slots = std::floor(p.srv_ram_mb[s] / ram);
+            const uint32_t want = slots > 64.0 ? 64u : (uint32_t)slots;
+            if (want > gmax) gmax = want;
+        }
+    }
+    return make_flow_layout(64u * ipl, ring_rows ? pow2_ge(ring_rows) : 0u, pow2_ge(gmax), cmax, p.n_edges, p.n_servers, p.n_edge_marks);
+}
+
+}  // namespace aff

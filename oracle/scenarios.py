@@ -187,6 +187,103 @@ def random_payload(rng: random.Random, horizon: int = 12) -> dict:
     return copy.deepcopy(p)
 
 
+def flow_payload(rng: random.Random, horizon: int = 8) -> dict:
+    """Random payload INSIDE the range of the stage-parallel kernel (asyncflow_amd/csrc/af_flow.hpp):
+    generator -> client -> [round-robin LB ->] 1..8 servers -> client, one endpoint per server of the
+    form IO* CPU* IO*, continuous edge latencies.  Loads from idle to saturated, multi-core servers,
+    dyadic step times (exact ties under queueing), tight RAM (admission would block), spikes, outages,
+    Gaussian users: the kernel must either reproduce the oracle bit for bit or hand the scenario back."""
+    use_lb = rng.random() < 0.75
+    n_srv = rng.randint(1, 8) if use_lb else 1
+    cpu_kinds = ["initial_parsing", "cpu_bound_operation"]
+    io_kinds = ["io_task_spawn", "io_llm", "io_wait", "io_db", "io_cache"]
+    dyadic = rng.random() < 0.3
+
+    def dur(lo: float, hi: float) -> float:
+        if dyadic:
+            return rng.choice([1, 2, 3, 4, 6, 8, 12, 16]) / 1024.0
+        return round(rng.uniform(lo, hi), 5)
+
+    def rnd_latency() -> tuple[float, str, float | None]:
+        d = rng.choice(["exponential", "exponential", "exponential", "exponential", "normal", "log_normal", "uniform"])
+        if d == "exponential":
+            return rng.choice([rng.uniform(0.0005, 0.02), rng.uniform(0.0005, 0.02), rng.uniform(0.05, 0.4)]), d, None
+        if d == "normal":
+            return rng.uniform(0.002, 0.02), d, rng.uniform(0.0, 0.004)
+        if d == "log_normal":
+            return rng.uniform(0.001, 0.2), d, rng.uniform(0.05, 0.6)
+        return rng.uniform(0.1, 1.0), d, None
+
+    same_servers = rng.random() < 0.5
+    proto = None
+    servers = []
+    for i in range(n_srv):
+        if proto is None or not same_servers:
+            steps = [(rng.choice(io_kinds), dur(0.001, 0.03)) for _ in range(rng.choice([0, 0, 0, 1, 2]))]
+            steps += [(rng.choice(cpu_kinds), dur(0.0005, 0.01)) for _ in range(rng.choice([0, 1, 1, 1, 2, 3]))]
+            steps += [(rng.choice(io_kinds), dur(0.001, 0.06)) for _ in range(rng.choice([0, 1, 1, 2]))]
+            if not steps:
+                steps = [(rng.choice(io_kinds), dur(0.001, 0.03))]
+            if rng.random() < 0.8:
+                steps.insert(rng.randint(0, len(steps)), ("ram", rng.choice([16, 64, 128, 200, 333])))
+            proto = (steps, rng.randint(1, 3), rng.choice([256, 512, 1024, 2048]))
+        servers.append(_server(f"s{i}", proto[1], proto[2], [_endpoint("/e", list(proto[0]))]))
+    edges = []
+    m, d, v = rnd_latency()
+    edges.append(_edge("g-c", "gen", "cli", m, d, v, rng.choice([None, 0.0, 0.05])))
+    if use_lb:
+        m, d, v = rnd_latency()
+        edges.append(_edge("c-lb", "cli", "lb", m, d, v, rng.choice([None, 0.0, 0.02])))
+        for i in range(n_srv):
+            m, d, v = rnd_latency()
+            edges.append(_edge(f"lb-s{i}", "lb", f"s{i}", m, d, v, rng.choice([None, 0.0, 0.1])))
+    else:
+        m, d, v = rnd_latency()
+        edges.append(_edge("c-s0", "cli", "s0", m, d, v, rng.choice([None, 0.0])))
+    for i in range(n_srv):
+        m, d, v = rnd_latency()
+        edges.append(_edge(f"s{i}-c", f"s{i}", "cli", m, d, v, rng.choice([None, 0.0, 0.03])))
+    users_dist = rng.choice(["poisson", "poisson", "normal"])
+    users: dict[str, Any] = {"mean": rng.choice([5, 20, 60, 60, 150, 150, 400, 1500])}
+    if users_dist == "normal":
+        users.update(distribution="normal", variance=rng.choice([1, 10, 40]))
+    nodes: dict[str, Any] = {"client": {"id": "cli"}, "servers": servers}
+    if use_lb:
+        nodes["load_balancer"] = {"id": "lb", "algorithms": "round_robin", "server_covered": [f"s{i}" for i in range(n_srv)]}
+    p: dict[str, Any] = {
+        "rqs_input": {
+            "id": "gen",
+            "avg_active_users": users,
+            "avg_request_per_minute_per_user": {"mean": rng.choice([20, 20, 60, 60, 240])},
+            "user_sampling_window": rng.choice([1, 3, 60]),
+        },
+        "topology_graph": {"nodes": nodes, "edges": edges},
+        "sim_settings": {"total_simulation_time": horizon, "sample_period_s": rng.choice([0.01, 0.05, 0.1, 0.003, 0.0625])},
+    }
+    events = []
+    T = float(horizon)
+    for k in range(rng.randint(0, 3)):
+        e = rng.choice(edges)
+        a = rng.uniform(0, T * 0.8)
+        b = rng.uniform(a + 0.1, T)
+        events.append({"event_id": f"sp{k}", "target_id": e["id"],
+                       "start": {"kind": "network_spike_start", "t_start": round(a, 3), "spike_s": round(rng.uniform(0.005, 0.3), 4)},
+                       "end": {"kind": "network_spike_end", "t_end": round(b, 3)}})
+    if use_lb and n_srv > 1 and rng.random() < 0.6:
+        t = rng.uniform(0.5, 3.0)
+        for k in range(rng.randint(1, 3)):
+            sid = f"s{rng.randrange(n_srv)}"
+            dur_s = rng.uniform(0.5, 3.0)
+            if t + dur_s >= T:
+                break
+            events.append({"event_id": f"out{k}", "target_id": sid,
+                           "start": {"kind": "server_down", "t_start": round(t, 3)}, "end": {"kind": "server_up", "t_end": round(t + dur_s, 3)}})
+            t += dur_s + rng.choice([0.0, 0.7])
+    if events:
+        p["events"] = events
+    return copy.deepcopy(p)
+
+
 def wide_fanout(n_srv: int = 20, algo: str = "least_connection", horizon: int = 12, users: float = 150) -> dict:
     """More than 8 servers behind the LB (the engine keeps the rotation list in state memory instead of
     one register), multi-core, two outages and a spike: the wide-topology corner of the schema."""

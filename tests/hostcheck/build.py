@@ -18,8 +18,9 @@ _lib = None
 
 
 def build(force: bool = False) -> Path:
-    srcs = [HERE / "hostcheck.cpp", ROOT / "asyncflow_amd/csrc/af_core.hpp", ROOT / "asyncflow_amd/csrc/af_math.hpp",
-            ROOT / "asyncflow_amd/csrc/af_plan_pack.hpp"]
+    srcs = [HERE / "hostcheck.cpp", HERE / "wave_emul.hpp", ROOT / "asyncflow_amd/csrc/af_core.hpp",
+            ROOT / "asyncflow_amd/csrc/af_math.hpp", ROOT / "asyncflow_amd/csrc/af_plan_pack.hpp",
+            ROOT / "asyncflow_amd/csrc/af_flow.hpp", ROOT / "asyncflow_amd/csrc/af_flow_host.hpp"]
     newest = max(p.stat().st_mtime for p in srcs)
     if force or not LIB.exists() or LIB.stat().st_mtime < newest:
         subprocess.run(
@@ -49,6 +50,16 @@ def lib() -> C.CDLL:
         L.hc_reruns.restype = C.c_int
         L.hc_bytes_per_lane.argtypes = [C.c_uint32] * 7
         L.hc_bytes_per_lane.restype = C.c_uint64
+        L.hc_flow_simulate.argtypes = [
+            C.POINTER(_abi.AfPlan), C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+            C.POINTER(C.c_double), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double), C.c_uint32,
+            C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32,
+        ]
+        L.hc_flow_simulate.restype = C.c_int
+        L.hc_flow_reason.argtypes = []
+        L.hc_flow_reason.restype = C.c_char_p
+        L.hc_flow_lds_bytes.argtypes = [C.POINTER(_abi.AfPlan), C.c_uint32, C.c_uint32]
+        L.hc_flow_lds_bytes.restype = C.c_uint64
         _lib = L
     return _lib
 
@@ -81,3 +92,47 @@ def simulate(plan: DevicePlan, seed: int, *, cap: int = 4096, fcap: int = 4096,
     n = int(counts[_abi.CNT_COMPLETED])
     k = int(counts[_abi.CNT_TICKS])
     return counts, clock[: min(n, ccap)].copy(), np.ascontiguousarray(samples[:k, : plan.n_series].T)
+
+
+FLOW_FALLBACK = 1 << 8
+FLOW_WHY = {1 << 9: "tie", 1 << 10: "list", 1 << 11: "ring", 1 << 12: "ram"}
+
+
+def flow_simulate(plan: DevicePlan, seed: int, *, ipl: int = 1, ring_rows: int = 64,
+                  overrides: list[tuple[str, int, float]] | None = None, clock_capacity: int | None = None,
+                  draw_capacity: int | None = None):
+    """Run one scenario through the stage-parallel kernel (af_flow.hpp) on the 64-fibre wave emulator.
+
+    Returns (counts, clock, samples) like :func:`simulate`, or ``None`` when the plan is not eligible
+    (``flow_reason()`` says why).  ``counts[CNT_FLAGS] & FLOW_FALLBACK``: the kernel handed the scenario
+    back to the sequential kernels (outputs are then incomplete)."""
+    L = lib()
+    cplan = plan.as_ctypes()
+    ov = overrides or []
+    params = np.asarray([_abi.PARAM_CODES[o[0]] for o in ov], dtype=np.uint32)
+    idxs = np.asarray([o[1] for o in ov], dtype=np.uint32)
+    vals = np.asarray([o[2] for o in ov], dtype=np.float64)
+    ccap = int(clock_capacity if clock_capacity is not None else plan.clock_capacity())
+    clock = np.zeros((ccap, 2), dtype=np.float64)
+    ticks = max(plan.tick_count, 1)
+    samples = np.zeros((ticks, plan.series_pitch), dtype=np.uint32)
+    counts = np.zeros(_abi.CNT_SLOTS, dtype=np.uint32)
+    u32p, f64p = C.POINTER(C.c_uint32), C.POINTER(C.c_double)
+    rc = L.hc_flow_simulate(
+        C.byref(cplan), C.c_uint64(seed), len(ov), params.ctypes.data_as(u32p), idxs.ctypes.data_as(u32p),
+        vals.ctypes.data_as(f64p), ipl, ring_rows, ccap, clock.ctypes.data_as(f64p), ticks,
+        samples.ctypes.data_as(u32p), counts.ctypes.data_as(u32p),
+        int(draw_capacity if draw_capacity is not None else plan.clock_capacity()),
+    )
+    if rc == 1:
+        return None
+    if rc != 0:
+        msg = f"hc_flow_simulate failed: {rc}"
+        raise RuntimeError(msg)
+    n = int(counts[_abi.CNT_COMPLETED])
+    k = int(counts[_abi.CNT_TICKS])
+    return counts, clock[: min(n, ccap)].copy(), np.ascontiguousarray(samples[:k, : plan.n_series].T)
+
+
+def flow_reason() -> str:
+    return (lib().hc_flow_reason() or b"").decode()

@@ -11,6 +11,8 @@
 #include <vector>
 
 #include "../../asyncflow_amd/csrc/af_plan_pack.hpp"
+#include "../../asyncflow_amd/csrc/af_flow_host.hpp"
+#include "wave_emul.hpp"
 
 namespace {
 
@@ -134,4 +136,113 @@ extern "C" int hc_reruns(void) { return g_reruns; }
 extern "C" uint64_t hc_bytes_per_lane(uint32_t cap, uint32_t fcap, uint32_t n_edges, uint32_t n_servers,
                                       uint32_t n_lb, uint32_t n_rows, uint32_t mask) {
     return af::layout_bytes_per_lane(af::make_layout(cap, fcap, n_edges, n_servers, n_lb, n_rows, mask));
+}
+
+// ---- the stage-parallel kernel (af_flow.hpp) on the 64-fibre wave emulator ---------------------------
+namespace {
+std::string g_flow_reason;
+}
+
+extern "C" const char* hc_flow_reason(void) { return g_flow_reason.c_str(); }
+
+// Returns 0 when the scenario ran (counts[AF_CNT_FLAGS] may carry FLAG_FLOW_FALLBACK = 1 << 8 and the reason
+// bits 9..12: the product then re-runs the scenario on the sequential kernels), 1 when the plan is not
+// eligible for the flow kernel (hc_flow_reason() says why), < 0 on invalid arguments.
+extern "C" int hc_flow_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ovr, const uint32_t* ovr_param,
+                                const uint32_t* ovr_index, const double* ovr_value, uint32_t ipl, uint32_t ring_rows,
+                                uint32_t clock_cap, double* clock, uint32_t tick_cap, uint32_t* samples, uint32_t* counts,
+                                uint32_t draw_cap) {
+    if (!p || p->abi_version != AF_ABI_VERSION || p->struct_size != sizeof(af_plan_t)) return AF_ERR_ABI;
+    if (ipl != 1 && ipl != 2 && ipl != 4) return AF_ERR_INVALID;
+    g_flow_reason = aff::flow_ineligible_reason(*p);
+    if (!g_flow_reason.empty()) return 1;
+    af::PackedPlan pk;
+    if (!af::pack_plan(*p, pk).empty()) return AF_ERR_INVALID;
+
+    double users_mean = p->gen_users_mean, users_sigma = p->gen_users_sigma, rpm = p->gen_rpm_mean;
+    std::vector<uint32_t> idx(n_ovr ? n_ovr : 1, 0u);
+    for (uint32_t k = 0; k < n_ovr; ++k) {
+        idx[k] = ovr_param[k] == AF_PARAM_STEP_TIME ? pk.row_of_step[ovr_index[k]] : ovr_index[k];
+        if (ovr_param[k] == AF_PARAM_GEN_USERS_MEAN) users_mean = ovr_value[k];
+        if (ovr_param[k] == AF_PARAM_GEN_USERS_SIGMA) users_sigma = ovr_value[k];
+        if (ovr_param[k] == AF_PARAM_GEN_RPM_MEAN) rpm = ovr_value[k];
+    }
+    // arrivals, exactly what af_pregen_arrivals does on the GPU
+    const uint32_t n_draw = draw_cap ? draw_cap : 1u;
+    std::vector<double> arrivals(n_draw, af::AF_INF);
+    uint32_t flags_in = 0;
+    {
+        af::GenState g;
+        double t = 0.0;
+        uint32_t k = 0;
+        for (; k < n_draw; ++k) {
+            const double gap = af::gen_next_gap(g, seed, p->gen_users_dist, users_mean, users_sigma, rpm, p->gen_window_s, p->total_time);
+            if (gap < 0.0) break;
+            t = t + gap;
+            arrivals[k] = t;
+        }
+        if (k == n_draw && af::gen_next_gap(g, seed, p->gen_users_dist, users_mean, users_sigma, rpm, p->gen_window_s, p->total_time) >= 0.0)
+            flags_in |= AF_FLAG_DRAW_OVERFLOW;
+    }
+    const aff::TickTable tt = aff::make_tick_table(p->sample_period, p->total_time);
+
+    aff::FlowArgs a{};
+    a.total_time = p->total_time;
+    a.sample_period = p->sample_period;
+    a.inv_period = tt.inv_period;
+    a.tick_eps = tt.eps;
+    a.metrics_mask = p->metrics_mask;
+    a.gen_out_edge = (uint32_t)p->gen_out_edge;
+    a.client_out_edge = (uint32_t)p->client_out_edge;
+    a.n_edges = p->n_edges;
+    a.n_servers = p->n_servers;
+    a.has_lb = p->has_lb;
+    a.n_lb_edges = p->n_lb_edges;
+    a.n_edge_marks = p->n_edge_marks;
+    a.n_srv_marks = p->n_srv_marks;
+    a.off_edge = pk.off_edge; a.off_srv = pk.off_srv; a.off_ep = pk.off_ep; a.off_row = pk.off_row;
+    a.off_emark = pk.off_emark; a.off_smark = pk.off_smark; a.off_lb = pk.off_lb;
+    a.blob_bytes = (uint32_t)(pk.words.size() * 8u);
+    a.blob = reinterpret_cast<const unsigned char*>(pk.words.data());
+    a.L = aff::choose_flow_layout(*p, ipl, ring_rows);
+    a.tick_t = tt.t.data();
+    a.n_ticks = (uint32_t)tt.t.size();
+    a.n_scen = 1;
+    a.seeds = &seed;
+    a.n_ovr = n_ovr;
+    a.ovr_param = ovr_param;
+    a.ovr_index = idx.data();
+    a.ovr_values = ovr_value;
+    a.ovr_stride = 1;
+    a.arrivals = arrivals.data();
+    a.n_draw = n_draw;
+    a.pre_flags = &flags_in;
+    a.clock = clock;
+    a.clock_cap = clock_cap;
+    a.samples = samples;
+    a.tick_cap = tick_cap;
+    a.counts = counts;
+    a.online_hist = g_online_hist;
+    a.online_rps = g_online_rps;
+    a.online_hist_bins = g_online_bins;
+    a.online_rps_buckets = g_online_buckets;
+    a.online_hist_scale = g_online_scale;
+    if (g_online_hist) std::memset(g_online_hist, 0, 4u * g_online_bins);
+    if (g_online_rps) std::memset(g_online_rps, 0, 4u * g_online_buckets);
+    a.n_fallback = nullptr;
+
+    std::vector<uint64_t> lds(pk.words.size() + a.L.n_words + 2u, 0xDEADBEEFDEADBEEFull);
+    auto body = [&]() {
+        if (ipl == 1) { aff::Flow<emu::WaveEmu, 1> f(a); f.run(lds.data(), 0u); }
+        else if (ipl == 2) { aff::Flow<emu::WaveEmu, 2> f(a); f.run(lds.data(), 0u); }
+        else { aff::Flow<emu::WaveEmu, 4> f(a); f.run(lds.data(), 0u); }
+    };
+    emu::run_wave(body);
+    return 0;
+}
+
+extern "C" uint64_t hc_flow_lds_bytes(const af_plan_t* p, uint32_t ipl, uint32_t ring_rows) {
+    af::PackedPlan pk;
+    if (!p || !af::pack_plan(*p, pk).empty()) return 0;
+    return 8ull * (pk.words.size() + aff::choose_flow_layout(*p, ipl, ring_rows).n_words);
 }

@@ -1,0 +1,121 @@
+"""CPU differential tests of the STAGE-PARALLEL kernel (asyncflow_amd/csrc/af_flow.hpp).
+
+The kernel moves 64 requests per step through the stations of the request path (one wave per
+scenario).  tests/hostcheck/ runs the very same source on a 64-fibre wave emulator
+(tests/hostcheck/wave_emul.hpp, test-only) so that its logic is checked here, without a GPU, against
+the SimPy-faithful oracle (oracle/des_oracle.c, itself pinned on the reference's fixtures):
+
+* whenever the kernel does NOT hand a scenario back (FLAG_FLOW_FALLBACK clear) its outputs are the
+  oracle's bit for bit -- counts, every (start, finish) pair in completion order, every sample;
+* what it cannot express (two events of one station at one instant, RAM admission that would block,
+  list / tick-ring overflow) is handed back, never silently wrong.
+"""
+
+from __future__ import annotations
+
+import copy
+import json
+import random
+
+import numpy as np
+import pytest
+
+from asyncflow_amd import _abi
+from asyncflow_amd.plan import lower
+from asyncflow_amd.workloads import fanout8, lb_two_servers, lb_with_events, single_server
+from oracle import oracle_lib as ol
+from oracle.scenarios import flow_payload, stress_mixed, wide_fanout
+from tests.conftest import GOLDEN_DIR
+from tests.hostcheck import build as hc
+
+
+def _run(payload, seed, **kw):
+    plan = lower(payload)
+    got = hc.flow_simulate(plan, seed, **kw)
+    assert got is not None, hc.flow_reason()
+    counts, clock, samples = got
+    flags = int(counts[_abi.CNT_FLAGS])
+    if flags & hc.FLOW_FALLBACK:
+        return "fallback", {v for k, v in hc.FLOW_WHY.items() if flags & k}
+    want = ol.simulate(plan, seed)
+    assert np.array_equal(want.counts[:5].astype(np.uint32), counts[:5]), (want.counts[:8], counts[:8])
+    assert int(counts[_abi.CNT_MARKS]) == int(want.counts[_abi.CNT_MARKS])
+    assert np.array_equal(want.clock.view(np.uint64), clock.view(np.uint64))
+    assert np.array_equal(want.samples, samples)
+    assert (flags & _abi.FATAL_FLAGS) == 0
+    return "exact", want
+
+
+@pytest.mark.parametrize("name", ["single_server_t30", "lb2_rr_t30", "lb2_events_t60", "fanout8_t20"])
+def test_flow_kernel_reproduces_the_reference_fixtures(name):
+    fx = np.load(GOLDEN_DIR / f"{name}.npz", allow_pickle=False)
+    payload = json.loads(str(fx["payload_json"]))
+    plan = lower(payload)
+    counts, clock, samples = hc.flow_simulate(plan, int(fx["seed"]), ipl=2, ring_rows=256)
+    assert not int(counts[_abi.CNT_FLAGS]) & hc.FLOW_FALLBACK
+    assert (int(counts[0]), int(counts[1]), int(counts[2]), int(counts[4])) == \
+        (int(fx["generated"]), int(fx["completed"]), int(fx["dropped"]), int(fx["ticks"]))
+    assert np.array_equal(clock, fx["clock"]) and np.array_equal(samples, fx["samples"])   # the reference's own output
+
+
+@pytest.mark.parametrize("ring_rows", [64, 0])      # tick differences in the LDS ring / in the sample rows (HBM)
+def test_baseline_workloads_bit_exact(ring_rows):
+    assert _run(lb_two_servers(horizon=60), 0x5EED0000, ring_rows=ring_rows)[0] == "exact"
+    assert _run(single_server(horizon=60), 0, ring_rows=ring_rows)[0] == "exact"
+    assert _run(lb_with_events(users=300, horizon=60, scale=0.1), 42, ring_rows=ring_rows)[0] == "exact"
+    assert _run(fanout8(horizon=40), 11, ipl=2, ring_rows=256 if ring_rows else 0)[0] == "exact"
+
+
+def test_grid_corners_of_configs_3_and_4():
+    """users 10 / 1000 x per-hop latency 0.5 / 50 ms, with and without the injected events."""
+    for users, hop in ((10, 0.0005), (1000, 0.0005), (10, 0.05), (1000, 0.05)):
+        for base in (lb_two_servers(horizon=20), lb_with_events(users=400, horizon=20, scale=20 / 600)):
+            p = copy.deepcopy(base)
+            p["rqs_input"]["avg_active_users"]["mean"] = users
+            for e in p["topology_graph"]["edges"]:
+                e["latency"]["mean"] = hop
+            status, _ = _run(p, 0xC0F30000 + users, ipl=2, ring_rows=128)
+            assert status == "exact", (users, hop)
+
+
+def test_per_scenario_overrides_reach_the_kernel():
+    """af_override_t columns (users, an edge's mean and dropout, a step time) against the oracle run on
+    the payload that has those values written into it."""
+    base = lb_two_servers(horizon=20)
+    plan = lower(base)
+    ov = [("gen_users_mean", 0, 150.0), ("edge_mean", 1, 0.01), ("edge_dropout", 2, 0.2), ("step_time", 0, 0.004)]
+    counts, clock, samples = hc.flow_simulate(plan, 9, overrides=ov)
+    edited = copy.deepcopy(base)
+    edited["rqs_input"]["avg_active_users"]["mean"] = 150.0
+    edited["topology_graph"]["edges"][1]["latency"]["mean"] = 0.01
+    edited["topology_graph"]["edges"][2]["dropout_rate"] = 0.2
+    edited["topology_graph"]["nodes"]["servers"][0]["endpoints"][0]["steps"][0]["step_operation"] = {"cpu_time": 0.004}
+    want = ol.simulate(lower(edited), 9)
+    assert not int(counts[_abi.CNT_FLAGS]) & hc.FLOW_FALLBACK
+    assert np.array_equal(want.counts[:5].astype(np.uint32), counts[:5])
+    assert np.array_equal(want.clock, clock) and np.array_equal(want.samples, samples)
+
+
+def test_small_lists_hand_the_scenario_back_instead_of_dropping_messages():
+    status, why = _run(fanout8(horizon=30), 11, ipl=1, ring_rows=256)      # ~40 messages in flight per edge
+    assert status == "fallback" and "list" in why
+    status, why = _run(fanout8(horizon=30), 11, ipl=2, ring_rows=8)        # 1-s latencies, 0.4 s of ring
+    assert status == "fallback" and "ring" in why
+
+
+def test_plans_outside_the_feed_forward_range_are_refused():
+    for payload, word in ((stress_mixed(40), "least-connections"), (wide_fanout(horizon=12), "8 servers"),
+                          (lb_two_servers(horizon=10, algo="least_connection"), "least-connections")):
+        assert hc.flow_simulate(lower(payload), 1) is None
+        assert word in hc.flow_reason()
+
+
+@pytest.mark.parametrize("block", range(6))
+def test_fuzzed_feed_forward_payloads_are_exact_or_handed_back(block):
+    """Idle to saturated, multi-core, leading / trailing I/O, dyadic step times, tight RAM, spikes, outages."""
+    exact = 0
+    for case in range(block * 25, block * 25 + 25):
+        rng = random.Random(31000 + case)
+        status, _ = _run(flow_payload(rng, horizon=6), 900 + case, ipl=4, ring_rows=1024)
+        exact += status == "exact"
+    assert exact >= 4, f"only {exact} of 25 fuzzed payloads ran on the flow kernel"
