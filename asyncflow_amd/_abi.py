@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-AF_ABI_VERSION = 2
+AF_ABI_VERSION = 3
 
 # af_status
 MAX_REQUEST_CAPACITY = 65535   # include/asyncflow_hip.h AF_MAX_REQUEST_CAPACITY
@@ -161,6 +161,9 @@ class AfEngineOptions(C.Structure):
         ("lanes_per_wave", C.c_uint32),
         ("draw_memory_mb", C.c_uint32),
         ("expect_shared_instants", C.c_uint32),
+        ("flow_mode", C.c_uint32),
+        ("flow_list_entries", C.c_uint32),
+        ("flow_ring_rows", C.c_uint32),
     ]
 
 
@@ -181,7 +184,21 @@ class AfStats(C.Structure):
         ("shared_instant_scenarios", C.c_uint32),
         ("request_capacity", C.c_uint32),
         ("fifo_capacity", C.c_uint32),
+        ("flow_kernel_ms", C.c_double),
+        ("flow_scenarios", C.c_uint32),
+        ("flow_fallback", C.c_uint32),
+        ("flow_fallback_tie", C.c_uint32),
+        ("flow_fallback_list", C.c_uint32),
+        ("flow_fallback_ring", C.c_uint32),
+        ("flow_fallback_ram", C.c_uint32),
+        ("flow_list_entries", C.c_uint32),
+        ("flow_ring_rows", C.c_uint32),
+        ("flow_lds_bytes", C.c_uint32),
+        ("jit_fallbacks", C.c_uint32),
     ]
+
+
+FLOW_RING_IN_HBM = 0xFFFFFFFF   # AF_FLOW_RING_IN_HBM
 
 
 class AfSummary(C.Structure):
@@ -206,6 +223,7 @@ EXPORTED_SYMBOLS = (
     "af_engine_jit_spec",
     "af_engine_set_kernels",
     "af_engine_stats",
+    "af_engine_flow_reason",
     "af_engine_destroy",
     "af_tick_count",
     "af_series_count",
@@ -232,6 +250,8 @@ def declare(lib: C.CDLL) -> C.CDLL:
     lib.af_engine_set_kernels.restype = C.c_int
     lib.af_engine_stats.argtypes = [C.c_void_p, C.POINTER(AfStats)]
     lib.af_engine_stats.restype = C.c_int
+    lib.af_engine_flow_reason.argtypes = [C.c_void_p]
+    lib.af_engine_flow_reason.restype = C.c_char_p
     lib.af_engine_destroy.argtypes = [C.c_void_p]
     lib.af_engine_destroy.restype = None
     lib.af_tick_count.argtypes = [C.c_double, C.c_double]

@@ -30,6 +30,7 @@
 
 #include "../../include/asyncflow_hip.h"
 #include "af_core.hpp"
+#include "af_flow_host.hpp"
 #include "af_plan_pack.hpp"
 #include "af_summary.hpp"
 
@@ -70,7 +71,9 @@ struct KArgs {
     uint32_t n_draw;
     uint32_t* pre_flags;    // [n_scen] AF_FLAG_DRAW_OVERFLOW from the arrival pre-generation
     uint64_t* tie;          // [n_scen][L.tie_words] scratch of the shared-timestamp path (HBM)
-    const uint32_t* scen_map;  // second pass: lane j simulates scenario scen_map[j] (null = identity)
+    const uint32_t* scen_map;  // subset launches: lane j simulates scenario scen_map[j] (null = identity)
+    const uint32_t* draw_slot; // where lane j's pre-generated draws / pre_flags / scratch live (null = draws_by_lane ? j : scenario)
+    uint32_t draws_by_lane;
     uint32_t* n_shared;     // first pass: number of scenarios that met a shared instant
 };
 
@@ -236,11 +239,12 @@ __device__ __forceinline__ void des_body(const KArgs& a_in) {
 
     const uint64_t seed = a.seeds[sc];
     auto ovr = [&](uint32_t k) { return a.ovr_values[(size_t)k * a.ovr_stride + sc]; };
+    const uint32_t slot = !active ? 0u : a.draw_slot ? a.draw_slot[scen] : a.draws_by_lane ? scen : sc;
     af::PreDraws D;
-    D.base = a.draws + (size_t)sc * (1u + a.n_edges) * a.n_draw;
+    D.base = a.draws + (size_t)slot * (1u + a.n_edges) * a.n_draw;
     D.n_per_stream = a.n_draw;
-    D.flags_in = a.pre_flags[sc];
-    D.tie = a.tie + (size_t)sc * a.L.tie_words;
+    D.flags_in = a.pre_flags[slot];
+    D.tie = a.tie + (size_t)slot * a.L.tie_words;
 
     if constexpr (kLdsState) {
         MemLds<KLOG> M;
@@ -263,6 +267,59 @@ __device__ __forceinline__ void des_body(const KArgs& a_in) {
 }
 
 #ifndef AF_JIT
+// ---- stage-parallel kernel (af_flow.hpp): one wave per scenario -------------------------------------
+struct WaveHip {
+    static __device__ __forceinline__ uint32_t lane() { return threadIdx.x; }
+    static __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
+    static __device__ __forceinline__ bool any(bool p) { return __any(p) != 0; }
+    static __device__ __forceinline__ uint32_t shfl32(uint32_t v, uint32_t src) {
+        return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)v);
+    }
+    static __device__ __forceinline__ uint64_t shfl64(uint64_t v, uint32_t src) {
+        const uint32_t lo = shfl32((uint32_t)v, src), hi = shfl32((uint32_t)(v >> 32), src);
+        return ((uint64_t)hi << 32) | lo;
+    }
+    // one wave per workgroup: LDS traffic of a wave is processed in order, the fences keep the
+    // compiler from moving LDS accesses of other lanes' data across this point
+    static __device__ __forceinline__ void sync() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    static __device__ __forceinline__ uint32_t lds_add(LDS_AS uint32_t* p, uint32_t v) {
+        return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    static __device__ __forceinline__ void global_add(uint32_t* p, uint32_t v) {
+        (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    static __device__ __forceinline__ uint32_t global_load(const uint32_t* p) {
+        return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    static __device__ __forceinline__ void global_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); }
+    static __device__ __forceinline__ uint32_t mbcnt(uint64_t m) {
+        return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    }
+};
+
+template <uint32_t IPL>
+__global__ void __launch_bounds__(64) af_flow_kernel(const aff::FlowArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t sc = blockIdx.x;
+    if (sc >= a.n_scen) return;
+    aff::Flow<WaveHip, IPL> f(a);
+    f.run((LDS_AS uint64_t*)smem, sc);
+    if (threadIdx.x == 0u && a.n_fallback) {
+        const uint32_t flags = a.counts[(size_t)sc * af::CNT_SLOTS + af::CNT_FLAGS];
+        if (flags & aff::FLAG_FLOW_FALLBACK) {
+            atomicAdd(a.n_fallback, 1u);
+            if (flags & aff::FLOW_WHY_TIE) atomicAdd(a.n_fallback + 1, 1u);
+            if (flags & aff::FLOW_WHY_LIST) atomicAdd(a.n_fallback + 2, 1u);
+            if (flags & aff::FLOW_WHY_RING) atomicAdd(a.n_fallback + 3, 1u);
+            if (flags & aff::FLOW_WHY_RAM) atomicAdd(a.n_fallback + 4, 1u);
+        }
+    }
+}
+
 template <bool kLdsState, bool kFaithful, int KLOG, int WPE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) af_des_kernel(const KArgs a) {
     des_body<kLdsState, kFaithful, KLOG>(a);
@@ -301,8 +358,11 @@ __device__ __forceinline__ double ovr_or(const KArgs& a, uint32_t param, uint32_
 // sums, the window / horizon tests) is scanned in draw order, with the same f64 additions in the
 // same order as the sequential sampler.  A gap that crosses the window end discards the rest of the
 // batch (the next index is the new window's user draw).
-__global__ void __launch_bounds__(64) af_pregen_arrivals(const KArgs a) {
-    const uint32_t scen = blockIdx.x;
+// Block j pre-generates for scenario scen_map[j] (null = j) into slot j.  `stride` = doubles per slot
+// (n_draw when only the arrivals are wanted: the flow kernel; (1 + n_edges) * n_draw otherwise).
+__global__ void __launch_bounds__(64) af_pregen_arrivals(const KArgs a, uint32_t stride) {
+    const uint32_t slot = blockIdx.x;
+    const uint32_t scen = a.scen_map ? a.scen_map[slot] : slot;
     const uint32_t lane = threadIdx.x;
     const uint64_t seed = a.seeds[scen];
     const double users_mean = ovr_or(a, af::PARAM_GEN_USERS_MEAN, 0u, scen, a.gen_users_mean);
@@ -310,7 +370,7 @@ __global__ void __launch_bounds__(64) af_pregen_arrivals(const KArgs a) {
     const double rpm = ovr_or(a, af::PARAM_GEN_RPM_MEAN, 0u, scen, a.gen_rpm_mean);
     const double rps_per_user = rpm / 60.0;
     const double T = a.total_time;
-    double* out = a.draws + (size_t)scen * (1u + a.n_edges) * a.n_draw;  // stream 0 of this scenario
+    double* out = a.draws + (size_t)slot * stride;  // stream 0 of this slot
     double g_now = 0.0, g_wend = 0.0, lam = 0.0, t = 0.0;  // identical in every lane
     uint32_t draws = 0u, k = 0u, flags = 0u;
     bool done = false;
@@ -370,7 +430,7 @@ __global__ void __launch_bounds__(64) af_pregen_arrivals(const KArgs a) {
         draws += used;
     }
     for (uint32_t i = k + lane; i < a.n_draw; i += 64u) out[i] = af::AF_INF;
-    if (lane == 0u) a.pre_flags[scen] = flags;
+    if (lane == 0u) a.pre_flags[slot] = flags;
 }
 
 // second pass: the online counters of the scenarios that start over are cleared first
@@ -388,14 +448,15 @@ __global__ void af_zero_online(const KArgs a, uint32_t count) {
 __global__ void __launch_bounds__(256) af_pregen_edges(const KArgs a) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n_draw) return;
-    const uint32_t scen = blockIdx.y;
+    const uint32_t slot = blockIdx.y;
+    const uint32_t scen = a.scen_map ? a.scen_map[slot] : slot;
     const uint32_t e = blockIdx.z;
     const uint64_t* rec = reinterpret_cast<const uint64_t*>(a.blob) + a.off_edge + af::EREC * e;
     const double mean = ovr_or(a, af::PARAM_EDGE_MEAN, e, scen, af::u2d(rec[0]));
     const double sigma = ovr_or(a, af::PARAM_EDGE_SIGMA, e, scen, af::u2d(rec[1]));
     const double dropout = ovr_or(a, af::PARAM_EDGE_DROPOUT, e, scen, af::u2d(rec[2]));
     const uint32_t dist = (uint32_t)(rec[3] >> 16) & 0xFFu;
-    a.draws[((size_t)scen * (1u + a.n_edges) + 1u + e) * a.n_draw + i] =
+    a.draws[((size_t)slot * (1u + a.n_edges) + 1u + e) * a.n_draw + i] =
         af::pre_edge_draw(a.seeds[scen], e, i, dist, mean, sigma, dropout);
 }
 
@@ -493,6 +554,29 @@ struct af_engine {
     uint32_t n_lb_edges = 0;
     std::vector<uint32_t> row_of_step;
     af_stats_t stats{};
+    // stage-parallel kernel (af_flow.hpp)
+    bool flow_ok = false;
+    std::string flow_reason;
+    uint32_t flow_mode = 0, flow_list_entries = 0, flow_ring_rows = 0;
+    aff::FlowArgs fargs{};
+    aff::TickTable tick;
+    double* d_tick = nullptr;
+    double* d_arr = nullptr;       // arrival times of the chunk [n][n_draw]
+    size_t arr_cap = 0;
+    uint32_t* d_arr_flags = nullptr;
+    size_t arr_flags_cap = 0;
+    uint32_t* d_fb = nullptr;      // [5] hand-over counters
+    uint32_t* d_slot = nullptr;    // draw slots of a second pass over a subset
+    size_t slot_cap = 0;
+    // host copy of what the layout heuristics need
+    uint32_t has_lb = 0, cores_max = 1, ram_slots_max = 1;
+    std::vector<double> edge_mean, edge_sigma, edge_spike;   // per edge: latency law, largest cumulative spike
+    std::vector<uint8_t> edge_dist;
+    std::vector<int32_t> lb_edges, srv_out_edge;
+    double service_max = 0.0, cpu_max = 0.0;
+    int32_t gen_edge = 0, client_edge = 0;
+    double rpm_mean = 0.0, users_mean = 0.0, users_sigma = 0.0;
+    uint32_t users_dist = 0;
 };
 
 namespace {
@@ -694,7 +778,77 @@ int af_engine_create(const af_plan_t* plan, int device, const af_engine_options_
         return fail(AF_ERR_CAPACITY, "plan too large for the LDS-resident plan blob");
     }
 
+    // ---- stage-parallel kernel: is the plan in its range?  tick table, plan facts for the layout heuristics
+    e->flow_mode = opts ? opts->flow_mode : 0u;
+    e->flow_list_entries = opts ? opts->flow_list_entries : 0u;
+    e->flow_ring_rows = opts ? opts->flow_ring_rows : 0u;
+    if (e->flow_list_entries != 0u && e->flow_list_entries != 64u && e->flow_list_entries != 128u && e->flow_list_entries != 256u) {
+        delete e;
+        return fail(AF_ERR_INVALID, "flow_list_entries must be 0 (auto), 64, 128 or 256");
+    }
+    e->flow_reason = aff::flow_ineligible_reason(*plan);
+    e->flow_ok = e->flow_reason.empty();
+    e->has_lb = plan->has_lb;
+    e->gen_edge = plan->gen_out_edge;
+    e->client_edge = plan->client_out_edge;
+    e->rpm_mean = plan->gen_rpm_mean;
+    e->users_mean = plan->gen_users_mean;
+    e->users_sigma = plan->gen_users_sigma;
+    e->users_dist = plan->gen_users_dist;
+    e->edge_mean.assign(plan->edge_mean, plan->edge_mean + plan->n_edges);
+    e->edge_sigma.assign(plan->edge_sigma, plan->edge_sigma + plan->n_edges);
+    e->edge_dist.assign(plan->edge_dist, plan->edge_dist + plan->n_edges);
+    e->lb_edges.assign(plan->lb_edges, plan->lb_edges + plan->n_lb_edges);
+    e->srv_out_edge.assign(plan->srv_out_edge, plan->srv_out_edge + plan->n_servers);
+    e->edge_spike.assign(plan->n_edges, 0.0);
+    {
+        std::vector<double> acc(plan->n_edges, 0.0);
+        for (uint32_t i = 0; i < plan->n_edge_marks; ++i) {
+            const int32_t ed = plan->emark_edge[i];
+            acc[ed] += plan->emark_delta[i];
+            if (acc[ed] > e->edge_spike[ed]) e->edge_spike[ed] = acc[ed];
+        }
+    }
+    for (uint32_t sv = 0; sv < plan->n_servers; ++sv) {
+        if (plan->srv_cores[sv] > e->cores_max) e->cores_max = plan->srv_cores[sv];
+        for (uint32_t ep = plan->srv_ep_begin[sv]; ep < plan->srv_ep_begin[sv + 1]; ++ep) {
+            double svc = 0.0, cpu = 0.0;
+            for (uint32_t i = plan->ep_step_begin[ep]; i < plan->ep_step_begin[ep + 1]; ++i) {
+                svc += plan->step_time[i];
+                if (plan->step_kind[i] == AF_STEP_CPU) cpu += plan->step_time[i];
+            }
+            if (svc > e->service_max) e->service_max = svc;
+            if (cpu > e->cpu_max) e->cpu_max = cpu;
+        }
+    }
+    if (e->flow_ok) {
+        e->tick = aff::make_tick_table(plan->sample_period, plan->total_time);
+        aff::FlowArgs& f = e->fargs;
+        f.total_time = plan->total_time;
+        f.sample_period = plan->sample_period;
+        f.inv_period = e->tick.inv_period;
+        f.tick_eps = e->tick.eps;
+        f.metrics_mask = plan->metrics_mask;
+        f.gen_out_edge = (uint32_t)plan->gen_out_edge;
+        f.client_out_edge = (uint32_t)plan->client_out_edge;
+        f.n_edges = plan->n_edges;
+        f.n_servers = plan->n_servers;
+        f.has_lb = plan->has_lb;
+        f.n_lb_edges = plan->n_lb_edges;
+        f.n_edge_marks = plan->n_edge_marks;
+        f.n_srv_marks = plan->n_srv_marks;
+        f.off_edge = pk.off_edge; f.off_srv = pk.off_srv; f.off_ep = pk.off_ep; f.off_row = pk.off_row;
+        f.off_emark = pk.off_emark; f.off_smark = pk.off_smark; f.off_lb = pk.off_lb;
+        f.blob_bytes = a.blob_bytes;
+        f.n_ticks = (uint32_t)e->tick.t.size();
+        f.L = aff::choose_flow_layout(*plan, 1u, 64u);   // g_ring / c_ring; entries and rows are chosen per run
+    }
+
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (err == hipSuccess && e->flow_ok) err = hipMalloc((void**)&e->d_tick, (e->tick.t.size() + 1u) * 8u);
+    if (err == hipSuccess && e->flow_ok && !e->tick.t.empty())
+        err = hipMemcpy(e->d_tick, e->tick.t.data(), e->tick.t.size() * 8u, hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMalloc((void**)&e->d_fb, 5u * 4u);
     if (err == hipSuccess) err = hipEventCreate(&e->ev0);
     if (err == hipSuccess) err = hipEventCreate(&e->ev1);
     if (err == hipSuccess) err = hipEventCreate(&e->ev2);
@@ -708,6 +862,8 @@ int af_engine_create(const af_plan_t* plan, int device, const af_engine_options_
         return fail(AF_ERR_HIP, std::string("engine setup: ") + hipGetErrorString(err));
     }
     a.blob = e->d_blob;
+    e->fargs.blob = e->d_blob;
+    e->fargs.tick_t = e->d_tick;
     *out = e;
     return AF_OK;
 }
@@ -774,51 +930,254 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     a.clock_cap = out->clock_capacity;
     a.tick_cap = out->tick_capacity;
 
-    // ---- chunking: the pre-generated draws of a chunk must fit the draw budget --------
+    // ---- buffers ------------------------------------------------------------------------------------
     const uint32_t n_draw = sweep->draw_capacity ? sweep->draw_capacity : out->clock_capacity;
     if (n_draw == 0) return fail(AF_ERR_INVALID, "draw_capacity (or clock_capacity) must be > 0");
     const size_t draw_bytes_per_scen = (size_t)(1u + a.n_edges) * n_draw * sizeof(double);
+    const bool use_flow = e->flow_ok && e->flow_mode == 0u;
     size_t mem_free = 0, mem_total = 0;
     HIP_TRY(hipMemGetInfo(&mem_free, &mem_total));
-    const uint32_t chunk = chunk_size(e, n, draw_bytes_per_scen, mem_free);
+    // the stage-parallel kernel only needs the arrival times of a chunk; the next-event kernels every draw
+    const uint32_t chunk = chunk_size(e, n, use_flow ? (size_t)n_draw * sizeof(double) : draw_bytes_per_scen,
+                                      mem_free + (use_flow ? e->arr_cap : 0));
     if (chunk == 0) return fail(AF_ERR_CAPACITY, "draw_capacity too large for the device memory budget");
-    const size_t draw_bytes = draw_bytes_per_scen * chunk;
-    if (draw_bytes > e->draws_cap) {
-        if (e->d_draws) HIP_TRY(hipFree(e->d_draws));
-        e->d_draws = nullptr;
-        e->draws_cap = 0;
-        HIP_TRY(hipMalloc((void**)&e->d_draws, draw_bytes));
-        e->draws_cap = draw_bytes;
-    }
-    if ((size_t)chunk * 4 > e->pre_flags_cap) {
-        if (e->d_pre_flags) HIP_TRY(hipFree(e->d_pre_flags));
-        e->d_pre_flags = nullptr;
-        e->pre_flags_cap = 0;
-        HIP_TRY(hipMalloc((void**)&e->d_pre_flags, (size_t)chunk * 4));
-        e->pre_flags_cap = (size_t)chunk * 4;
-    }
-    a.draws = e->d_draws;
+    auto grow = [&](void** ptr, size_t& cap, size_t need) -> int {
+        if (need <= cap) return AF_OK;
+        if (*ptr) HIP_TRY(hipFree(*ptr));
+        *ptr = nullptr;
+        cap = 0;
+        HIP_TRY(hipMalloc(ptr, need));
+        cap = need;
+        return AF_OK;
+    };
     a.n_draw = n_draw;
-    a.pre_flags = e->d_pre_flags;
-    const size_t tie_bytes = (size_t)chunk * a.L.tie_words * 8u;
-    if (tie_bytes > e->tie_cap) {
-        if (e->d_tie) HIP_TRY(hipFree(e->d_tie));
-        e->d_tie = nullptr;
-        e->tie_cap = 0;
-        HIP_TRY(hipMalloc((void**)&e->d_tie, tie_bytes));
-        e->tie_cap = tie_bytes;
-    }
-    a.tie = e->d_tie;
     a.n_shared = e->d_n_shared;
     a.scen_map = nullptr;
+    a.draw_slot = nullptr;
+    a.draws_by_lane = 0u;
 
-    double ms_pregen = 0.0, ms_kernel = 0.0;
-    uint32_t kl = 0, waves = 0, lds_bytes = 0, n_chunks = 0, n_rerun = 0, n_jit = 0;
+    double ms_pregen = 0.0, ms_kernel = 0.0, ms_flow = 0.0;
+    uint32_t kl = 0, waves = 0, lds_bytes = 0, n_chunks = 0, n_rerun = 0, n_jit = 0, n_jit_miss = 0;
+    uint32_t fb_total[5] = {0, 0, 0, 0, 0}, flow_scen = 0, flow_lds = 0;
+    size_t draw_bytes = 0;
     bool lds_state = false;
+    aff::FlowLayout FL{};
+
+    // ---- stage-parallel kernel: list capacity and tick ring from what will be in flight ----------------
+    if (use_flow) {
+        double users = e->users_mean, rpm = e->rpm_mean;
+        std::vector<double> emean = e->edge_mean;
+        for (uint32_t k = 0; k < sweep->n_overrides; ++k) {
+            const af_override_t& o = sweep->overrides[k];
+            double mx = o.values[0];
+            for (uint32_t i = 1; i < n; ++i) mx = o.values[i] > mx ? o.values[i] : mx;
+            if (o.param == AF_PARAM_GEN_USERS_MEAN) users = mx;
+            else if (o.param == AF_PARAM_GEN_RPM_MEAN) rpm = mx;
+            else if (o.param == AF_PARAM_EDGE_MEAN) emean[o.index] = mx;
+        }
+        const double sd = e->users_dist == AF_DIST_POISSON ? std::sqrt(users > 0.0 ? users : 0.0) : e->users_sigma;
+        const double rate = (users + 4.0 * sd) * rpm / 60.0 + 1e-9;
+        auto lat_mean = [&](int32_t ed) {
+            const double m = emean[ed], sg = e->edge_sigma[ed];
+            switch (e->edge_dist[ed]) {
+                case AF_DIST_LOG_NORMAL: return std::exp(m + 0.5 * sg * sg < 50.0 ? m + 0.5 * sg * sg : 50.0);
+                case AF_DIST_NORMAL: return (m > 0.0 ? m : 0.0) + 0.4 * sg;
+                case AF_DIST_UNIFORM: return 0.5;
+                default: return m;
+            }
+        };
+        auto lat_hi = [&](int32_t ed) {   // a transit time one message in ~1e7 exceeds
+            const double m = emean[ed], sg = e->edge_sigma[ed];
+            switch (e->edge_dist[ed]) {
+                case AF_DIST_LOG_NORMAL: return std::exp(m + 5.2 * sg < 50.0 ? m + 5.2 * sg : 50.0);
+                case AF_DIST_NORMAL: return (m > 0.0 ? m : 0.0) + 5.2 * sg;
+                case AF_DIST_UNIFORM: return 1.0;
+                default: return 16.0 * m;
+            }
+        };
+        double lb_mean = 0.0, lb_hi = 0.0, so_mean = 0.0, so_hi = 0.0;
+        for (int32_t ed : e->lb_edges) {
+            lb_mean = std::fmax(lb_mean, lat_mean(ed) + e->edge_spike[ed]);
+            lb_hi = std::fmax(lb_hi, lat_hi(ed) + e->edge_spike[ed]);
+        }
+        for (int32_t ed : e->srv_out_edge) {
+            so_mean = std::fmax(so_mean, lat_mean(ed) + e->edge_spike[ed]);
+            so_hi = std::fmax(so_hi, lat_hi(ed) + e->edge_spike[ed]);
+        }
+        const double g_mean = lat_mean(e->gen_edge) + e->edge_spike[e->gen_edge], g_hi = lat_hi(e->gen_edge) + e->edge_spike[e->gen_edge];
+        const double c_mean = lat_mean(e->client_edge) + e->edge_spike[e->client_edge],
+                     c_hi = lat_hi(e->client_edge) + e->edge_spike[e->client_edge];
+        const double in_server = e->service_max + 20.0 * e->cpu_max;   // service + a generous queueing allowance
+        double pend = rate * std::fmax(std::fmax(g_mean, c_mean), std::fmax(lb_mean, so_mean + in_server));
+        pend += 5.0 * std::sqrt(pend + 1.0);
+        uint32_t entries = e->flow_list_entries;
+        if (entries == 0u) entries = pend <= 16.0 ? 64u : pend <= 80.0 ? 128u : 256u;
+        const double path_hi = g_hi + c_hi + lb_hi + so_hi + in_server;
+        uint32_t rows = e->flow_ring_rows;
+        const uint32_t pitch = a.series_pitch;
+        if (out->samples == nullptr) {
+            rows = 64u;   // unused
+        } else if (rows == AF_FLOW_RING_IN_HBM) {
+            rows = 0u;
+        } else if (rows == 0u) {
+            const double want = 2.0 * std::fmax(path_hi, 96.0 / rate) / a.sample_period + 4.0;
+            rows = want < 16384.0 ? aff::pow2_ge((uint32_t)want < 32u ? 32u : (uint32_t)want) : 0u;
+            if ((size_t)rows * pitch * 4u > 24u * 1024u) {   // does not fit next to the lists: keep the differences in HBM
+                const uint32_t fit = 24u * 1024u / (pitch * 4u);
+                uint32_t p2 = 32u;
+                while (p2 * 2u <= fit) p2 *= 2u;
+                // a ring that covers the slowest message still beats HBM atomics; otherwise HBM
+                rows = (2.0 * path_hi / a.sample_period + 4.0 <= (double)p2) ? p2 : 0u;
+            }
+        } else {
+            rows = aff::pow2_ge(rows);
+        }
+        FL = aff::make_flow_layout(entries, rows, e->fargs.L.g_ring, e->fargs.L.c_ring, a.n_edges, a.n_servers, a.n_edge_marks);
+        flow_lds = a.blob_bytes + FL.n_words * 8u;
+        if (flow_lds > kLdsLimit) return fail(AF_ERR_CAPACITY, "flow kernel layout exceeds the LDS of a compute unit");
+    }
+
+    const size_t tie_words = a.L.tie_words;
+    // One launch of the next-event kernel over `count` scenarios (all of the chunk, or the ones listed in `map`).
+    auto launch_des = [&](uint32_t count, bool faithful) -> int {
+        choose_lanes(e, count, a.blob_bytes, bytes_per_lane, kl, lds_state);
+        uint32_t klog = 0;
+        while ((1u << klog) < kl) ++klog;
+        a.n_scen = count;
+        const uint64_t state_per_wave = bytes_per_lane * kl;
+        waves = (count + kl - 1) / kl;
+        lds_bytes = lds_state ? (uint32_t)(a.blob_bytes + state_per_wave) : a.blob_bytes;
+        a.state = nullptr;
+        a.state_bytes_per_wave = state_per_wave;
+        if (!lds_state) {
+            if (int rc = grow((void**)&e->d_state, e->state_cap, (size_t)state_per_wave * waves)) return rc;
+            a.state = e->d_state;
+        }
+        // SimPy-order variant: when the waves do not all fit at 3 per SIMD anyway, the build with
+        // the larger register budget (2 per SIMD, no spills) is the faster one (measured: 6 400
+        // grid points 6.2 s -> 5.5 s; 2 500 waves that do fit: 2.7 s vs 4.3 s).  Sweeps over the load
+        // (scenario lengths differ by orders of magnitude) do not run as lock-step batches: there the
+        // per-wave speed decides and the roomy build wins even when everything would fit.
+        const bool hetero = (mask & ((1u << AF_PARAM_GEN_USERS_MEAN) | (1u << AF_PARAM_GEN_RPM_MEAN))) != 0u;
+        const bool roomy = faithful && (waves > 3072u || hetero);
+        const void* fn = des_kernel_for(lds_state, faithful, klog, roomy);
+        hipFunction_t jit_fn = nullptr;
+        if (e->jit_module && lds_bytes <= 64u * 1024u) {
+            if (jit_spec_string(a, lds_state, klog) == e->jit_spec) jit_fn = !faithful ? e->jit_lean : roomy ? e->jit_order2 : e->jit_order3;
+            else n_jit_miss += 1u;
+        }
+        if (std::getenv("AF_DEBUG"))
+            std::fprintf(stderr, "[af] launch: %u scenarios, %u waves x %u lanes, %s state, %s%s%s\n", count, waves, kl,
+                         lds_state ? "LDS" : "HBM", faithful ? "SimPy-order" : "lean", roomy ? " (2 waves/SIMD build)" : "",
+                         jit_fn ? ", plan-specialised" : "");
+        void* kargs[] = {&a};
+        if (jit_fn) {
+            HIP_TRY(hipModuleLaunchKernel(jit_fn, waves, 1, 1, kWave, 1, 1, lds_bytes, e->stream, kargs, nullptr));
+            n_jit += 1u;
+        } else {
+            if (lds_state) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            HIP_TRY(hipLaunchKernel(fn, dim3(waves), dim3(kWave), kargs, lds_bytes, e->stream));
+        }
+        return AF_OK;
+    };
+
+    // The next-event kernels over `count` scenarios of the current chunk: all of them (h_map == nullptr) or the
+    // listed ones.  Draws are pre-generated per slot j = position in the list; pieces that fit the draw budget.
+    auto run_sequential = [&](uint32_t count, const uint32_t* h_map, const KArgs& chunk_args) -> int {
+        size_t mf = 0, mt = 0;
+        HIP_TRY(hipMemGetInfo(&mf, &mt));
+        const uint32_t piece = chunk_size(e, count, draw_bytes_per_scen, mf);
+        if (piece == 0) return fail(AF_ERR_CAPACITY, "draw_capacity too large for the device memory budget");
+        for (uint32_t p0 = 0; p0 < count; p0 += piece) {
+            const uint32_t cnt = count - p0 < piece ? count - p0 : piece;
+            a = chunk_args;
+            if (int rc = grow((void**)&e->d_draws, e->draws_cap, draw_bytes_per_scen * cnt)) return rc;
+            if (int rc = grow((void**)&e->d_pre_flags, e->pre_flags_cap, (size_t)cnt * 4u)) return rc;
+            if (int rc = grow((void**)&e->d_tie, e->tie_cap, (size_t)cnt * tie_words * 8u)) return rc;
+            if (draw_bytes_per_scen * cnt > draw_bytes) draw_bytes = draw_bytes_per_scen * cnt;
+            a.draws = e->d_draws;
+            a.pre_flags = e->d_pre_flags;
+            a.tie = e->d_tie;
+            a.draw_slot = nullptr;
+            if (h_map) {
+                if (int rc = grow((void**)&e->d_map, e->map_cap, (size_t)cnt * 4u)) return rc;
+                HIP_TRY(hipMemcpyAsync(e->d_map, h_map + p0, (size_t)cnt * 4u, hipMemcpyHostToDevice, e->stream));
+                a.scen_map = e->d_map;
+                a.draws_by_lane = 1u;
+            } else {
+                a.scen_map = nullptr;
+                a.draws_by_lane = 0u;
+            }
+            a.n_scen = cnt;
+            HIP_TRY(hipEventRecord(e->ev2, e->stream));
+            hipLaunchKernelGGL(af_pregen_arrivals, dim3(cnt), dim3(64), 0, e->stream, a, (uint32_t)((1u + a.n_edges) * n_draw));
+            hipLaunchKernelGGL(af_pregen_edges, dim3((n_draw + 255u) / 256u, cnt, a.n_edges), dim3(256), 0, e->stream, a);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(e->ev3, e->stream));
+            if (h_map && (a.online_hist || a.online_rps)) {   // scenarios that start over: their online counters are cleared
+                hipLaunchKernelGGL(af_zero_online, dim3(cnt), dim3(256), 0, e->stream, a, cnt);
+                HIP_TRY(hipGetLastError());
+            }
+            // First pass: the lean kernel.  A scenario in which two timed events share an instant stops
+            // there and is simulated again, from its start, by the kernel that has SimPy's event-by-event
+            // path; engines whose plan keeps producing such scenarios go straight to that kernel.
+            const bool faithful_first = e->shared_instants_likely;
+            HIP_TRY(hipMemsetAsync(e->d_n_shared, 0, 4, e->stream));
+            if (int rc = launch_des(cnt, faithful_first)) return rc;
+            if (!faithful_first) {
+                uint32_t n_shared = 0;
+                HIP_TRY(hipMemcpyAsync(&n_shared, e->d_n_shared, 4, hipMemcpyDeviceToHost, e->stream));
+                HIP_TRY(hipStreamSynchronize(e->stream));
+                if (n_shared > 0u) {
+                    const uint32_t nc_all = chunk_args.n_scen;
+                    std::vector<uint32_t> cnt_host((size_t)nc_all * AF_CNT_SLOTS);
+                    HIP_TRY(hipMemcpy(cnt_host.data(), a.counts, cnt_host.size() * 4u, hipMemcpyDeviceToHost));
+                    std::vector<uint32_t> map2, slot2;
+                    for (uint32_t j = 0; j < cnt; ++j) {
+                        const uint32_t scn = h_map ? h_map[p0 + j] : j;
+                        if (cnt_host[(size_t)scn * AF_CNT_SLOTS + AF_CNT_FLAGS] & af::FLAG_SHARED_INSTANT) {
+                            map2.push_back(scn);
+                            slot2.push_back(j);
+                        }
+                    }
+                    if (!map2.empty()) {
+                        if (int rc = grow((void**)&e->d_map, e->map_cap, (size_t)nc_all * 4u)) return rc;
+                        if (int rc = grow((void**)&e->d_slot, e->slot_cap, map2.size() * 4u)) return rc;
+                        HIP_TRY(hipMemcpy(e->d_map, map2.data(), map2.size() * 4u, hipMemcpyHostToDevice));
+                        HIP_TRY(hipMemcpy(e->d_slot, slot2.data(), slot2.size() * 4u, hipMemcpyHostToDevice));
+                        a.scen_map = e->d_map;
+                        a.draw_slot = e->d_slot;
+                        if (a.online_hist || a.online_rps) {
+                            hipLaunchKernelGGL(af_zero_online, dim3((uint32_t)map2.size()), dim3(256), 0, e->stream, a, (uint32_t)map2.size());
+                            HIP_TRY(hipGetLastError());
+                        }
+                        if (int rc = launch_des((uint32_t)map2.size(), true)) return rc;
+                        n_rerun += (uint32_t)map2.size();
+                        // such plans keep producing them: later runs start with the SimPy-order kernel, which
+                        // is cheaper than a second pass over a few long scenarios in narrow, latency-bound waves
+                        e->shared_instants_likely = true;
+                    }
+                }
+            }
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(e->ev4, e->stream));
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            float ms_p = 0.f, ms_k = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms_p, e->ev2, e->ev3));
+            HIP_TRY(hipEventElapsedTime(&ms_k, e->ev3, e->ev4));
+            ms_pregen += ms_p;
+            ms_kernel += ms_k;
+        }
+        return AF_OK;
+    };
+
     for (uint32_t lo = 0; lo < n; lo += chunk) {
         const uint32_t nc = n - lo < chunk ? n - lo : chunk;
         n_chunks += 1u;
         a.n_scen = nc;
+        a.scen_map = nullptr;
+        a.draw_slot = nullptr;
+        a.draws_by_lane = 0u;
         a.seeds = reinterpret_cast<const uint64_t*>(ds) + lo;
         a.ovr_values = reinterpret_cast<const double*>(ds + seeds_b) + lo;
         a.clock = out->clock ? out->clock + (size_t)lo * out->clock_capacity * 2u : nullptr;
@@ -829,116 +1188,93 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
         a.online_hist_bins = out->online_hist_bins;
         a.online_rps_buckets = out->online_rps_buckets;
         a.online_hist_scale = out->online_hist ? (double)out->online_hist_bins / out->online_hist_max : 0.0;
+        const KArgs chunk_args = a;
 
-        // pre-generate every random draw of the chunk (HBM)
+        if (!use_flow) {
+            if (int rc = run_sequential(nc, nullptr, chunk_args)) return rc;
+            continue;
+        }
+        // ---- stage-parallel kernel over the whole chunk; what it hands back goes to the next-event kernels
+        if (int rc = grow((void**)&e->d_arr, e->arr_cap, (size_t)nc * n_draw * sizeof(double))) return rc;
+        if (int rc = grow((void**)&e->d_arr_flags, e->arr_flags_cap, (size_t)nc * 4u)) return rc;
+        if ((size_t)nc * n_draw * sizeof(double) > draw_bytes) draw_bytes = (size_t)nc * n_draw * sizeof(double);
+        a.draws = e->d_arr;
+        a.pre_flags = e->d_arr_flags;
         HIP_TRY(hipEventRecord(e->ev2, e->stream));
-        hipLaunchKernelGGL(af_pregen_arrivals, dim3(nc), dim3(64), 0, e->stream, a);
-        hipLaunchKernelGGL(af_pregen_edges, dim3((n_draw + 255u) / 256u, nc, a.n_edges), dim3(256), 0, e->stream, a);
+        hipLaunchKernelGGL(af_pregen_arrivals, dim3(nc), dim3(64), 0, e->stream, a, n_draw);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(e->ev3, e->stream));
-
-        // One launch of the next-event kernel over `count` scenarios (all of the chunk, or the
-        // ones listed in `map`).
-        auto launch_des = [&](uint32_t count, bool faithful, const uint32_t* map) -> int {
-            choose_lanes(e, count, a.blob_bytes, bytes_per_lane, kl, lds_state);
-            uint32_t klog = 0;
-            while ((1u << klog) < kl) ++klog;
-            a.n_scen = count;
-            a.scen_map = map;
-            const uint64_t state_per_wave = bytes_per_lane * kl;
-            waves = (count + kl - 1) / kl;
-            lds_bytes = lds_state ? (uint32_t)(a.blob_bytes + state_per_wave) : a.blob_bytes;
-            a.state = nullptr;
-            a.state_bytes_per_wave = state_per_wave;
-            if (!lds_state) {
-                const size_t need = (size_t)state_per_wave * waves;
-                if (need > e->state_cap) {
-                    if (e->d_state) HIP_TRY(hipFree(e->d_state));
-                    e->d_state = nullptr;
-                    e->state_cap = 0;
-                    HIP_TRY(hipMalloc((void**)&e->d_state, need));
-                    e->state_cap = need;
-                }
-                a.state = e->d_state;
-            }
-            // SimPy-order variant: when the waves do not all fit at 3 per SIMD anyway, the build with
-            // the larger register budget (2 per SIMD, no spills) is the faster one (measured: 6 400
-            // grid points 6.2 s -> 5.5 s; 2 500 waves that do fit: 2.7 s vs 4.3 s).  Sweeps over the load
-            // (scenario lengths differ by orders of magnitude) do not run as lock-step batches: there the
-            // per-wave speed decides and the roomy build wins even when everything would fit.
-            const bool hetero = (mask & ((1u << AF_PARAM_GEN_USERS_MEAN) | (1u << AF_PARAM_GEN_RPM_MEAN))) != 0u;
-            const bool roomy = faithful && (waves > 3072u || hetero);
-            const void* fn = des_kernel_for(lds_state, faithful, klog, roomy);
-            hipFunction_t jit_fn = nullptr;
-            if (e->jit_module && lds_bytes <= 64u * 1024u && jit_spec_string(a, lds_state, klog) == e->jit_spec)
-                jit_fn = !faithful ? e->jit_lean : roomy ? e->jit_order2 : e->jit_order3;
+        aff::FlowArgs f = e->fargs;
+        f.L = FL;
+        f.n_scen = nc;
+        f.seeds = a.seeds;
+        f.n_ovr = a.n_ovr;
+        f.ovr_param = a.ovr_param;
+        f.ovr_index = a.ovr_index;
+        f.ovr_values = a.ovr_values;
+        f.ovr_stride = a.ovr_stride;
+        f.arrivals = e->d_arr;
+        f.n_draw = n_draw;
+        f.pre_flags = e->d_arr_flags;
+        f.clock = a.clock;
+        f.clock_cap = a.clock_cap;
+        f.samples = a.samples;
+        f.tick_cap = a.tick_cap;
+        f.counts = a.counts;
+        f.online_hist = a.online_hist;
+        f.online_rps = a.online_rps;
+        f.online_hist_bins = a.online_hist_bins;
+        f.online_rps_buckets = a.online_rps_buckets;
+        f.online_hist_scale = a.online_hist_scale;
+        f.n_fallback = e->d_fb;
+        HIP_TRY(hipMemsetAsync(e->d_fb, 0, 5u * 4u, e->stream));
+        {
+            const void* fn = FL.cap == 64u    ? reinterpret_cast<const void*>(af_flow_kernel<1>)
+                             : FL.cap == 128u ? reinterpret_cast<const void*>(af_flow_kernel<2>)
+                                              : reinterpret_cast<const void*>(af_flow_kernel<4>);
+            if (flow_lds > 48u * 1024u) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flow_lds));
+            void* kargs[] = {&f};
             if (std::getenv("AF_DEBUG"))
-                std::fprintf(stderr, "[af] launch: %u scenarios, %u waves x %u lanes, %s state, %s%s\n", count, waves, kl,
-                             lds_state ? "LDS" : "HBM", faithful ? "SimPy-order" : "lean", roomy ? " (2 waves/SIMD build)" : "");
-            if (std::getenv("AF_DEBUG") && jit_fn) std::fprintf(stderr, "[af]   plan-specialised kernels\n");
-            void* kargs[] = {&a};
-            if (jit_fn) {
-                HIP_TRY(hipModuleLaunchKernel(jit_fn, waves, 1, 1, kWave, 1, 1, lds_bytes, e->stream, kargs, nullptr));
-                n_jit += 1u;
-            } else {
-                if (lds_state) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-                HIP_TRY(hipLaunchKernel(fn, dim3(waves), dim3(kWave), kargs, lds_bytes, e->stream));
-            }
-            return AF_OK;
-        };
-
-        // First pass: the lean kernel.  A scenario in which two timed events share an instant stops
-        // there and is simulated again, from its start, by the kernel that has SimPy's event-by-event
-        // path; engines whose plan keeps producing such scenarios go straight to that kernel.
-        const bool faithful_first = e->shared_instants_likely;
-        HIP_TRY(hipMemsetAsync(e->d_n_shared, 0, 4, e->stream));
-        if (int rc = launch_des(nc, faithful_first, nullptr)) return rc;
-        uint32_t n_shared = 0;
-        if (!faithful_first) {
-            HIP_TRY(hipMemcpyAsync(&n_shared, e->d_n_shared, 4, hipMemcpyDeviceToHost, e->stream));
-            HIP_TRY(hipStreamSynchronize(e->stream));
-            if (n_shared > 0u) {
-                std::vector<uint32_t> cnt((size_t)nc * AF_CNT_SLOTS);
-                HIP_TRY(hipMemcpy(cnt.data(), a.counts, cnt.size() * 4u, hipMemcpyDeviceToHost));
-                std::vector<uint32_t> map;
-                map.reserve(n_shared);
-                for (uint32_t i = 0; i < nc; ++i)
-                    if (cnt[(size_t)i * AF_CNT_SLOTS + AF_CNT_FLAGS] & af::FLAG_SHARED_INSTANT) map.push_back(i);
-                if (map.size() * 4u > e->map_cap) {
-                    if (e->d_map) HIP_TRY(hipFree(e->d_map));
-                    e->d_map = nullptr;
-                    e->map_cap = 0;
-                    HIP_TRY(hipMalloc((void**)&e->d_map, (size_t)nc * 4u));
-                    e->map_cap = (size_t)nc * 4u;
-                }
-                HIP_TRY(hipMemcpy(e->d_map, map.data(), map.size() * 4u, hipMemcpyHostToDevice));
-                if (a.online_hist || a.online_rps) {
-                    a.scen_map = e->d_map;
-                    hipLaunchKernelGGL(af_zero_online, dim3((uint32_t)map.size()), dim3(256), 0, e->stream, a, (uint32_t)map.size());
-                    HIP_TRY(hipGetLastError());
-                }
-                if (int rc = launch_des((uint32_t)map.size(), true, e->d_map)) return rc;
-                a.scen_map = nullptr;
-                a.n_scen = nc;
-                n_rerun += (uint32_t)map.size();
-                // such plans keep producing them: later runs start with the SimPy-order kernel, which
-                // is cheaper than a second pass over a few long scenarios in narrow, latency-bound waves
-                e->shared_instants_likely = true;
-            }
+                std::fprintf(stderr, "[af] flow launch: %u scenarios, %u list entries, %u ring rows, %u B LDS per wave\n", nc, FL.cap,
+                             FL.ring_rows, flow_lds);
+            HIP_TRY(hipLaunchKernel(fn, dim3(nc), dim3(kWave), kargs, flow_lds, e->stream));
         }
-        HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(e->ev4, e->stream));
+        uint32_t fb[5] = {0, 0, 0, 0, 0};
+        HIP_TRY(hipMemcpyAsync(fb, e->d_fb, sizeof fb, hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
-        float ms_p = 0.f, ms_k = 0.f;
+        float ms_p = 0.f, ms_f = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms_p, e->ev2, e->ev3));
-        HIP_TRY(hipEventElapsedTime(&ms_k, e->ev3, e->ev4));
+        HIP_TRY(hipEventElapsedTime(&ms_f, e->ev3, e->ev4));
         ms_pregen += ms_p;
-        ms_kernel += ms_k;
+        ms_flow += ms_f;
+        flow_scen += nc;
+        for (int k = 0; k < 5; ++k) fb_total[k] += fb[k];
+        if (fb[0] > 0u) {
+            std::vector<uint32_t> cnt_host((size_t)nc * AF_CNT_SLOTS);
+            HIP_TRY(hipMemcpy(cnt_host.data(), a.counts, cnt_host.size() * 4u, hipMemcpyDeviceToHost));
+            std::vector<uint32_t> map;
+            map.reserve(fb[0]);
+            for (uint32_t i = 0; i < nc; ++i)
+                if (cnt_host[(size_t)i * AF_CNT_SLOTS + AF_CNT_FLAGS] & aff::FLAG_FLOW_FALLBACK) map.push_back(i);
+            if (int rc = run_sequential((uint32_t)map.size(), map.data(), chunk_args)) return rc;
+        }
     }
 
     float ms_h2d = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms_h2d, e->ev0, e->ev1));
-    e->stats.kernel_ms = ms_kernel;
+    e->stats.kernel_ms = ms_kernel + ms_flow;
+    e->stats.flow_kernel_ms = ms_flow;
+    e->stats.flow_scenarios = flow_scen;
+    e->stats.flow_fallback = fb_total[0];
+    e->stats.flow_fallback_tie = fb_total[1];
+    e->stats.flow_fallback_list = fb_total[2];
+    e->stats.flow_fallback_ring = fb_total[3];
+    e->stats.flow_fallback_ram = fb_total[4];
+    e->stats.flow_list_entries = use_flow ? FL.cap : 0u;
+    e->stats.flow_ring_rows = use_flow ? FL.ring_rows : 0u;
+    e->stats.flow_lds_bytes = flow_lds;
+    e->stats.jit_fallbacks = n_jit_miss;
     e->stats.pregen_ms = ms_pregen;
     e->stats.h2d_ms = ms_h2d;
     e->stats.draw_bytes = draw_bytes;
@@ -1073,6 +1409,8 @@ int af_engine_summarize(af_engine_t* e, const af_outputs_t* out, const af_summar
     return AF_OK;
 }
 
+const char* af_engine_flow_reason(const af_engine_t* e) { return e ? e->flow_reason.c_str() : ""; }
+
 int af_engine_stats(const af_engine_t* e, af_stats_t* stats) {
     if (!e || !stats) return fail(AF_ERR_INVALID, "NULL argument");
     *stats = e->stats;
@@ -1095,6 +1433,11 @@ void af_engine_destroy(af_engine_t* e) {
     if (e->d_tie) (void)hipFree(e->d_tie);
     if (e->d_n_shared) (void)hipFree(e->d_n_shared);
     if (e->d_map) (void)hipFree(e->d_map);
+    if (e->d_tick) (void)hipFree(e->d_tick);
+    if (e->d_arr) (void)hipFree(e->d_arr);
+    if (e->d_arr_flags) (void)hipFree(e->d_arr_flags);
+    if (e->d_fb) (void)hipFree(e->d_fb);
+    if (e->d_slot) (void)hipFree(e->d_slot);
     if (e->jit_module) (void)hipModuleUnload(e->jit_module);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;

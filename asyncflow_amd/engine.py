@@ -96,13 +96,15 @@ class Engine:
 
     def __init__(self, plan: DevicePlan, device: int = 0, *, request_capacity: int = 0,
                  fifo_capacity: int = 0, force_global_state: bool = False, lanes_per_wave: int = 0,
-                 draw_memory_mb: int = 0, expect_shared_instants: bool = False) -> None:
+                 draw_memory_mb: int = 0, expect_shared_instants: bool = False, flow: bool = True,
+                 flow_list_entries: int = 0, flow_ring_rows: int = 0) -> None:
         self._lib = load_library()
         self.plan = plan
         self.device = device
         self._cplan = plan.as_ctypes()
         opts = _abi.AfEngineOptions(request_capacity, fifo_capacity, int(force_global_state), int(lanes_per_wave),
-                                    int(draw_memory_mb), int(expect_shared_instants))
+                                    int(draw_memory_mb), int(expect_shared_instants), 0 if flow else 1,
+                                    int(flow_list_entries), int(flow_ring_rows))
         handle = C.c_void_p()
         _check(self._lib, self._lib.af_engine_create(C.byref(self._cplan), device, C.byref(opts), C.byref(handle)),
                "af_engine_create")
@@ -195,6 +197,10 @@ class Engine:
                               C.c_void_p(series_mean_ptr or None), C.c_void_p(series_max_ptr or None))
         _check(self._lib, self._lib.af_engine_summarize(self._h, C.byref(out), C.byref(summ)), "af_engine_summarize")
         return self.stats()
+
+    def flow_reason(self) -> str:
+        """'' when the stage-parallel kernel can run this plan, else why it always runs on the next-event kernels."""
+        return (self._lib.af_engine_flow_reason(self._h) or b"").decode()
 
     def stats(self) -> _abi.AfStats:
         st = _abi.AfStats()

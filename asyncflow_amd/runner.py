@@ -121,6 +121,9 @@ class SimulationRunner:
         expect_shared_instants: bool | None = None,
         specialise: bool | None = None,
         online_summary: Mapping[str, Any] | None = None,
+        flow: bool = True,
+        flow_list_entries: int = 0,
+        flow_ring_rows: int = 0,
     ) -> None:
         self.env = env  # accepted for signature compatibility; unused
         self.simulation_input = simulation_input
@@ -157,6 +160,11 @@ class SimulationRunner:
         #: build plan-specialised kernels (asyncflow_amd/jit.py, ~4 s once per plan shape, cached on disk):
         #: None = when the sweep is expected to process more than 5e8 request-events
         self.specialise = specialise
+        #: stage-parallel kernel (one wave per scenario, 64 requests per step) for plans in its range
+        #: (Engine.flow_reason()); False = always the next-event kernels.  Results are bit-identical.
+        self.flow = flow
+        self.flow_list_entries = flow_list_entries
+        self.flow_ring_rows = flow_ring_rows
         self._single = seeds is None and int(replicas) == 1 and not self.sweep
         self._engine: Engine | None = None
 
@@ -207,7 +215,8 @@ class SimulationRunner:
         for attempt in range(4):
             eng = Engine(self.plan, device, request_capacity=cap, fifo_capacity=fifo,
                          force_global_state=self.force_global_state, lanes_per_wave=self.lanes_per_wave,
-                         draw_memory_mb=self.draw_memory_mb,
+                         draw_memory_mb=self.draw_memory_mb, flow=self.flow,
+                         flow_list_entries=self.flow_list_entries, flow_ring_rows=self.flow_ring_rows,
                          expect_shared_instants=(_SHARED_INSTANTS_SEEN.get(self._plan_key(), False)
                                                  if self.expect_shared_instants is None
                                                  else bool(self.expect_shared_instants)))

@@ -300,7 +300,10 @@ class RankSweep:
         self.slice = (n + self.n_slices - 1) // self.n_slices
         self.eng = Engine(plan, dev.index, request_capacity=min(cap, _abi.MAX_REQUEST_CAPACITY),
                           fifo_capacity=_fifo_pow2(min(fifo, cap)), lanes_per_wave=args.lanes,
-                          force_global_state=args.global_state, expect_shared_instants=args.expect_shared_instants)
+                          force_global_state=args.global_state, expect_shared_instants=args.expect_shared_instants,
+                          flow=not args.no_flow, flow_list_entries=args.flow_list_entries,
+                          flow_ring_rows=_abi.FLOW_RING_IN_HBM if args.flow_ring_rows < 0 else args.flow_ring_rows)
+        self.flow_reason = self.eng.flow_reason()
         m = self.slice
         self.counts = torch.zeros((n, _abi.CNT_SLOTS), dtype=torch.int32, device=dev)
         self.clock = torch.empty((m, self.clock_cap, 2), dtype=torch.float64, device=dev)
@@ -329,7 +332,8 @@ class RankSweep:
 
     def step(self) -> dict:
         """One pass over the rank's batch; returns the engine's own timings summed over the slices."""
-        acc = {"kernel_ms": 0.0, "pregen_ms": 0.0, "summary_ms": 0.0, "shared": 0, "jit": 0}
+        acc = {"kernel_ms": 0.0, "pregen_ms": 0.0, "summary_ms": 0.0, "shared": 0, "jit": 0, "flow_ms": 0.0, "flow_scen": 0,
+               "flow_fallback": [0, 0, 0, 0, 0], "jit_fallbacks": 0}
         for lo in range(0, self.n, self.slice):
             hi = min(self.n, lo + self.slice)
             seeds, over, kw = self._slice_args(lo, hi)
@@ -338,6 +342,16 @@ class RankSweep:
             acc["pregen_ms"] += float(st.pregen_ms)
             acc["shared"] += int(st.shared_instant_scenarios)
             acc["jit"] += int(st.specialised_launches)
+            acc["jit_fallbacks"] += int(st.jit_fallbacks)
+            acc["flow_ms"] += float(st.flow_kernel_ms)
+            acc["flow_scen"] += int(st.flow_scenarios)
+            for k, name in enumerate(("flow_fallback", "flow_fallback_tie", "flow_fallback_list", "flow_fallback_ring", "flow_fallback_ram")):
+                acc["flow_fallback"][k] += int(getattr(st, name))
+            self.run_stats = {"flow_list_entries": int(st.flow_list_entries), "flow_ring_rows": int(st.flow_ring_rows),
+                              "flow_lds_bytes": int(st.flow_lds_bytes), "state_in_lds": int(st.state_in_lds),
+                              "lds_bytes_per_wave": int(st.lds_bytes_per_wave), "lanes_per_wave": int(st.lanes_per_wave),
+                              "waves": int(st.waves), "request_capacity": int(st.request_capacity),
+                              "state_bytes_per_scenario": int(st.state_bytes_per_scenario), "draw_bytes": int(st.draw_bytes)}
             st = self.eng.summarize(hi - lo, clock_ptr=self.clock.data_ptr(), clock_capacity=self.clock_cap,
                                     samples_ptr=self.samples.data_ptr() if self.samples is not None else 0,
                                     tick_capacity=self.ticks, counts_ptr=self.counts[lo:hi].data_ptr(),
@@ -425,6 +439,9 @@ def main() -> int:  # noqa: C901, PLR0912, PLR0915
                     help="do not build plan-specialised kernels (asyncflow_amd/jit.py); use the library's generic ones")
     ap.add_argument("--expect-shared-instants", action="store_true",
                     help="start with the kernel variant that has the SimPy-order path for shared instants")
+    ap.add_argument("--no-flow", action="store_true", help="next-event kernels only (no stage-parallel kernel)")
+    ap.add_argument("--flow-list-entries", type=int, default=0, choices=[0, 64, 128, 256])
+    ap.add_argument("--flow-ring-rows", type=int, default=0, help="rows of the LDS tick ring (0 = auto, -1 = keep the differences in HBM)")
     ap.add_argument("--hbm-budget-gb", type=float, default=96.0, help="HBM for the output buffers of one slice")
     ap.add_argument("--selftest-cpu", action="store_true", help="launcher / sharding / gather path on CPU (gloo), no engine")
     args = ap.parse_args()
@@ -478,7 +495,8 @@ def main() -> int:  # noqa: C901, PLR0912, PLR0915
         accs.append(sw.step())
     barrier()
     elapsed = time.perf_counter() - t0
-    n, plan, st = sw.n, sw.plan, sw.last_stats
+    n, plan, rs = sw.n, sw.plan, sw.run_stats
+    flow_on = accs[-1]["flow_scen"] > 0
 
     c = sw.counts.cpu().numpy().view(np.uint32)
     flags = int(np.bitwise_or.reduce(c[:, _abi.CNT_FLAGS]))
@@ -528,9 +546,10 @@ def main() -> int:  # noqa: C901, PLR0912, PLR0915
 
     if rank == 0:
         total_events = events_total * args.steps
-        alg_bytes = algorithmic_bytes(c, plan.n_series, int(st.lds_bytes_per_wave - st.lanes_per_wave * st.state_bytes_per_scenario)
-                                      if st.state_in_lds else 0)
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        alg_bytes = algorithmic_bytes(c, plan.n_series, int(rs["lds_bytes_per_wave"] - rs["lanes_per_wave"] * rs["state_bytes_per_scenario"])
+                                      if rs["state_in_lds"] and not flow_on else 0)
+        dom_ms = float(np.mean([a["flow_ms"] for a in accs])) if flow_on else k_ms      # the dominant kernel's own duration
+        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         sa = stats_all.double().cpu().numpy()
         out_bytes = 16.0 * completed_rank + (4.0 * plan.series_pitch * ticks_rank if sw.samples is not None else 0.0)
         line = {
@@ -554,13 +573,15 @@ def main() -> int:  # noqa: C901, PLR0912, PLR0915
                 "scenarios_total": n_total,
                 "slices_per_step": sw.n_slices,
                 "parallelism": f"scenario-sharded x{world}, no data-path collective",
-                "state": "LDS" if st.state_in_lds else "HBM",
-                "request_capacity": int(st.request_capacity),
-                "lds_bytes_per_wave": int(st.lds_bytes_per_wave),
-                "lanes_per_wave": int(st.lanes_per_wave),
-                "waves": int(st.waves),
-                "shared_instant_scenarios": int(accs[-1]["shared"]),
-                "plan_specialised_kernels": bool(accs[-1]["jit"]),
+                "kernel": "af_flow_kernel (stage-parallel, one wave per scenario)" if flow_on else "af_des_kernel (next-event, one scenario per lane)",
+                "flow": {"scenarios": accs[-1]["flow_scen"], "list_entries": rs["flow_list_entries"], "ring_rows": rs["flow_ring_rows"],
+                         "lds_bytes_per_wave": rs["flow_lds_bytes"],
+                         "handed_back": dict(zip(("total", "tie", "list", "ring", "ram"), accs[-1]["flow_fallback"])),
+                         "not_used_because": sw.flow_reason or None},
+                "next_event": {"state": "LDS" if rs["state_in_lds"] else "HBM", "request_capacity": rs["request_capacity"],
+                               "lds_bytes_per_wave": rs["lds_bytes_per_wave"], "lanes_per_wave": rs["lanes_per_wave"],
+                               "waves": rs["waves"], "shared_instant_scenarios": int(accs[-1]["shared"]),
+                               "plan_specialised_kernels": bool(accs[-1]["jit"]), "jit_fallbacks": int(accs[-1]["jit_fallbacks"])},
             },
             "events_per_step": events_total,
             "per_gpu_value": total_events / elapsed / world,
@@ -568,7 +589,8 @@ def main() -> int:  # noqa: C901, PLR0912, PLR0915
             "kernel_ms": k_ms,
             "kernel_ms_ranks_min_max": kernel_ms_ranks,
             "pregen_ms": float(np.mean([a["pregen_ms"] for a in accs])),
-            "draw_bytes": int(st.draw_bytes),
+            "flow_kernel_ms": float(np.mean([a["flow_ms"] for a in accs])),
+            "draw_bytes": rs["draw_bytes"],
             "summary_ms": summary_ms,
             "summary": {
                 "kernels": "af_summary_kernel + af_series_kernel (inside the timed step)",
@@ -591,7 +613,9 @@ def main() -> int:  # noqa: C901, PLR0912, PLR0915
                 "traffic": None,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "bytes_per_event": alg_bytes / max(events_rank, 1.0),
-                "kernel": "af_jit_lean (plan-specialised build of af_des_kernel)" if accs[-1]["jit"] else "af_des_kernel",
+                "kernel": "af_flow_kernel" if flow_on else
+                          "af_jit_lean (plan-specialised build of af_des_kernel)" if accs[-1]["jit"] else "af_des_kernel",
+                "kernel_ms": float(np.mean([a["flow_ms"] for a in accs])) if flow_on else k_ms,
             },
         }
         if base is not None:
@@ -606,7 +630,7 @@ def main() -> int:  # noqa: C901, PLR0912, PLR0915
                     continue
                 line["roofline"]["traffic"] = tj["bytes_per_launch"]
                 line["roofline"]["traffic_source"] = f"{tpath.relative_to(ROOT)} (2 x FETCH_SIZE + WRITE_SIZE, KB=1024 B)"
-                line["roofline"]["frac_traffic"] = tj["bytes_per_launch"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                line["roofline"]["frac_traffic"] = tj["bytes_per_launch"] / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
                 break
         print(json.dumps(line), flush=True)
     sw.eng.close()

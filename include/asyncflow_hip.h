@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define AF_ABI_VERSION 2
+#define AF_ABI_VERSION 3
 
 /* ---- status codes ------------------------------------------------------ */
 enum af_status {
@@ -242,7 +242,19 @@ typedef struct af_engine_options {
                                    (~20 % slower).  0 = lean variant first; scenarios that
                                    meet such an instant are handed over to the other variant
                                    and the engine remembers it for its later runs          */
+    /* Stage-parallel ("flow") kernel: one wavefront per scenario moves 64 requests per step through
+     * the stations of a feed-forward request path (generator -> client -> [round-robin LB ->] servers
+     * with IO* CPU* IO* endpoints -> client).  Bit-identical to the next-event kernels; a scenario
+     * it cannot express (two events of one station at one instant, a list / tick-ring overflow) is
+     * simulated again by them.  af_engine_flow_reason() tells why a plan is outside its range. */
+    uint32_t flow_mode;         /* 0 = use it whenever the plan is in range, 1 = never          */
+    uint32_t flow_list_entries; /* capacity of each station's message list: 64, 128 or 256
+                                   (0 = from the expected number of messages in flight)         */
+    uint32_t flow_ring_rows;    /* rows of the LDS ring of per-tick differences (power of two);
+                                   0 = auto; AF_FLOW_RING_IN_HBM = keep the differences in the
+                                   sample rows in HBM (no limit on how far an interval reaches) */
 } af_engine_options_t;
+#define AF_FLOW_RING_IN_HBM 0xFFFFFFFFu
 
 typedef struct af_stats {
     double kernel_ms;           /* HIP-event time of the next-event kernel (af_des_kernel) */
@@ -263,6 +275,18 @@ typedef struct af_stats {
                                    with that variant)                              */
     uint32_t request_capacity;
     uint32_t fifo_capacity;
+    /* stage-parallel kernel (last af_engine_run) */
+    double flow_kernel_ms;         /* HIP-event time of the stage-parallel kernel, 0 = not used      */
+    uint32_t flow_scenarios;       /* scenarios it was launched on                                  */
+    uint32_t flow_fallback;        /* ... of which handed back to the next-event kernels, by reason: */
+    uint32_t flow_fallback_tie;    /*   two events of one station (or an event and a tick / mark) at one instant */
+    uint32_t flow_fallback_list;   /*   more messages pending at a station than flow_list_entries   */
+    uint32_t flow_fallback_ring;   /*   an interval reached beyond the tick ring                    */
+    uint32_t flow_fallback_ram;    /*   RAM admission the recurrence cannot express                 */
+    uint32_t flow_list_entries;    /* layout used                                                   */
+    uint32_t flow_ring_rows;       /* (0 = differences kept in HBM)                                 */
+    uint32_t flow_lds_bytes;       /* LDS per wavefront                                             */
+    uint32_t jit_fallbacks;        /* launches that wanted plan-specialised kernels but ran the generic ones */
 } af_stats_t;
 
 typedef struct af_engine af_engine_t;
@@ -311,6 +335,9 @@ int af_engine_summarize(af_engine_t* engine, const af_outputs_t* out, const af_s
  * sweep->n_scenarios independent scenarios. */
 int af_engine_run(af_engine_t* eng, const af_sweep_t* sweep, const af_outputs_t* out);
 int af_engine_stats(const af_engine_t* eng, af_stats_t* stats);
+/* Empty string: the stage-parallel kernel can run this engine's plan; otherwise why not (the plan then
+ * always runs on the next-event kernels).  The pointer stays valid until the engine is destroyed. */
+const char* af_engine_flow_reason(const af_engine_t* eng);
 void af_engine_destroy(af_engine_t* eng);
 
 /* Number of sampler ticks env.run(until=T) takes for (period, T): repeated f64

@@ -20,4 +20,4 @@ def pytest_configure(config: pytest.Config) -> None:
 
 
 def golden_names() -> list[str]:
-    return sorted(p.stem for p in GOLDEN_DIR.glob("*.npz"))
+    return sorted(p.stem for p in GOLDEN_DIR.glob("*.npz") if not p.stem.startswith("pooled_"))   # pooled_*: statistical fixture

@@ -20,7 +20,8 @@ _lib = None
 def build(force: bool = False) -> Path:
     srcs = [HERE / "hostcheck.cpp", HERE / "wave_emul.hpp", ROOT / "asyncflow_amd/csrc/af_core.hpp",
             ROOT / "asyncflow_amd/csrc/af_math.hpp", ROOT / "asyncflow_amd/csrc/af_plan_pack.hpp",
-            ROOT / "asyncflow_amd/csrc/af_flow.hpp", ROOT / "asyncflow_amd/csrc/af_flow_host.hpp"]
+            ROOT / "asyncflow_amd/csrc/af_flow.hpp", ROOT / "asyncflow_amd/csrc/af_flow_host.hpp",
+            ROOT / "include/asyncflow_hip.h"]
     newest = max(p.stat().st_mtime for p in srcs)
     if force or not LIB.exists() or LIB.stat().st_mtime < newest:
         subprocess.run(

@@ -1,0 +1,253 @@
+"""The stage-parallel kernel (af_flow_kernel) on a real MI355X, through the C ABI.
+
+* bit-identical to the oracle on the BASELINE workloads at their FULL sizes (T = 600 s; grid corners of
+  configs 3 / 4, config 4 = sweep columns AND injected events, config 5 through both kernels and both
+  state placements of the next-event kernel);
+* bit-identical to the next-event kernels (`flow=False`) on whole batches, including scenarios it hands
+  back (ties, RAM pressure, overflowing lists / rings): the hand-over is invisible in the results;
+* statistical parity with the STOCK numpy-seeded reference from a committed fixture
+  (tests/golden/pooled_lb2_numpy.npz, oracle/make_golden.py --pooled 256): SURVEY 8d criterion (2).
+"""
+
+from __future__ import annotations
+
+import copy
+import random
+
+import numpy as np
+import pytest
+
+from asyncflow_amd import _abi
+from asyncflow_amd.plan import lower
+from asyncflow_amd.workloads import BASELINE_SEED_BASE, fanout8, grid_users_rtt, lb_two_servers, lb_with_events, single_server
+from oracle import oracle_lib as ol
+from oracle.scenarios import flow_payload
+from tests.conftest import GOLDEN_DIR
+
+pytestmark = pytest.mark.gpu
+
+
+def _runner(payload, **kw):
+    from asyncflow_amd.runner import SimulationRunner
+
+    return SimulationRunner(simulation_input=payload, **kw)
+
+
+def _assert_scenario(got, want, what=""):
+    assert np.array_equal(got.counts[:5].astype(np.uint64), want.counts[:5]), (what, got.counts, want.counts)
+    assert int(got.counts[_abi.CNT_MARKS]) == int(want.counts[_abi.CNT_MARKS]), what
+    assert np.array_equal(got.rqs_clock.view(np.uint64), want.clock.view(np.uint64)), f"{what}: rqs_clock differs"
+    assert np.array_equal(got._samples, want.samples), f"{what}: sampled series differ"  # noqa: SLF001
+
+
+def _same_batches(a, b):
+    assert np.array_equal(a.counts[:, :6], b.counts[:, :6])          # generated .. ticks, flags
+    assert np.array_equal(a.counts[:, _abi.CNT_MARKS], b.counts[:, _abi.CNT_MARKS])
+    for i in range(len(a)):
+        assert np.array_equal(a[i].rqs_clock.view(np.uint64), b[i].rqs_clock.view(np.uint64)), f"scenario {i}: rqs_clock"
+        assert np.array_equal(a[i]._samples, b[i]._samples), f"scenario {i}: samples"  # noqa: SLF001
+
+
+# ------------------------------------------------------------------------------------------------ batches
+def test_lb2_batch_runs_on_the_flow_kernel_and_matches_the_oracle():
+    payload = lb_two_servers(horizon=30)
+    seeds = 0x5EED0000 + np.arange(200, dtype=np.uint64)
+    res = _runner(payload, seeds=seeds).run()
+    st = res.engine_stats
+    assert st.flow_scenarios == 200 and st.flow_fallback == 0 and st.flow_list_entries == 64 and st.flow_ring_rows >= 32
+    plan = lower(payload)
+    for i in (0, 1, 63, 64, 127, 199):
+        _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])), f"scenario {i}")
+    want_counts = np.array([ol.simulate(plan, int(s), want_clock=False, want_samples=False).counts[:5] for s in seeds])
+    assert np.array_equal(res.counts[:, :5].astype(np.uint64), want_counts)
+    _same_batches(res, _runner(payload, seeds=seeds, flow=False).run())
+
+
+@pytest.mark.parametrize("ring_rows", [0, 16, _abi.FLOW_RING_IN_HBM])
+def test_tick_ring_placement_does_not_change_results(ring_rows):
+    """auto / a ring far too small for some intervals (those scenarios are handed back) / differences in HBM."""
+    payload = lb_with_events(users=200, horizon=40, scale=0.05)
+    seeds = np.arange(96, dtype=np.uint64) + 31
+    res = _runner(payload, seeds=seeds, flow_ring_rows=ring_rows).run()
+    st = res.engine_stats
+    assert st.flow_scenarios == 96
+    if ring_rows == _abi.FLOW_RING_IN_HBM:
+        assert st.flow_ring_rows == 0 and st.flow_fallback == 0
+    _same_batches(res, _runner(payload, seeds=seeds, flow=False).run())
+
+
+def test_fanout_uses_larger_lists_and_hbm_differences():
+    payload = fanout8(horizon=60)
+    seeds = BASELINE_SEED_BASE[5] + np.arange(40, dtype=np.uint64)
+    res = _runner(payload, seeds=seeds).run()
+    st = res.engine_stats
+    assert st.flow_scenarios == 40 and st.flow_list_entries >= 128 and st.flow_ring_rows == 0   # ~1-s hops: differences in HBM
+    plan = lower(payload)
+    for i in (0, 17, 39):
+        _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])), f"scenario {i}")
+    small = _runner(payload, seeds=seeds, flow_list_entries=64).run()     # ~40 messages in flight per edge: lists overflow
+    assert small.engine_stats.flow_fallback_list > 0
+    _same_batches(res, small)
+
+
+def test_handed_back_scenarios_are_invisible_in_the_results():
+    """Fuzzed feed-forward payloads (idle to saturated, dyadic step times, tight RAM, spikes, outages): most
+    batches contain scenarios the flow kernel hands back; results equal the next-event kernels' everywhere."""
+    handed_back = ran = 0
+    for case in range(24):
+        rng = random.Random(31000 + case)
+        payload = flow_payload(rng, horizon=6)
+        seeds = np.arange(5, dtype=np.uint64) + 900 + case
+        res = _runner(payload, seeds=seeds).run()
+        st = res.engine_stats
+        assert st.flow_scenarios == 5
+        handed_back += st.flow_fallback
+        ran += 5 - st.flow_fallback
+        _same_batches(res, _runner(payload, seeds=seeds, flow=False).run())
+        _assert_scenario(res[0], ol.simulate(lower(payload), int(seeds[0])), f"case {case}")
+    assert handed_back > 10 and ran > 20
+
+
+def test_single_server_and_sweep_columns():
+    res = _runner(single_server(horizon=120), seeds=[0, 1, 2]).run()
+    assert res.engine_stats.flow_scenarios == 3 and res.engine_stats.flow_fallback == 0
+    plan = lower(single_server(horizon=120))
+    _assert_scenario(res[1], ol.simulate(plan, 1))
+    base = lb_two_servers(horizon=30)
+    users = np.array([20.0, 400.0, 900.0, 60.0])
+    hop = np.array([0.001, 0.004, 0.0005, 0.03])
+    cpu = np.array([0.002, 0.001, 0.0015, 0.004])
+    sweep = {"rqs_input.avg_active_users.mean": users, "topology_graph.edges[*].latency.mean": hop,
+             "topology_graph.nodes.servers[srv-1].endpoints[0].steps[0].cpu_time": cpu}
+    seeds = np.arange(4, dtype=np.uint64) + 70
+    res = _runner(base, seeds=seeds, sweep=sweep).run()
+    assert res.engine_stats.flow_scenarios == 4
+    for i in range(4):
+        p = copy.deepcopy(base)
+        p["rqs_input"]["avg_active_users"]["mean"] = float(users[i])
+        for e in p["topology_graph"]["edges"]:
+            e["latency"]["mean"] = float(hop[i])
+        p["topology_graph"]["nodes"]["servers"][0]["endpoints"][0]["steps"][0]["step_operation"] = {"cpu_time": float(cpu[i])}
+        _assert_scenario(res[i], ol.simulate(lower(p), int(seeds[i])), f"sweep point {i}")
+
+
+def test_kernel_side_summary_and_no_outputs_modes():
+    from oracle import analyzer_oracle as ao
+
+    payload = lb_two_servers(horizon=30)
+    seeds = np.arange(48, dtype=np.uint64) + 9
+    bins, hist_max = 1024, 0.256
+    both = _runner(payload, seeds=seeds, online_summary={"hist_bins": bins, "hist_max": hist_max}).run()
+    assert both.engine_stats.flow_scenarios == 48 and both.engine_stats.flow_fallback == 0
+    hist = both.online_hist.cpu().numpy().view(np.uint32)
+    rps = both.online_rps.cpu().numpy()
+    for i in (0, 47):
+        ck = both[i].rqs_clock
+        assert np.array_equal(hist[i], ao.latency_histogram(ck, bins, hist_max))
+        assert np.array_equal(rps[i].astype(np.float64), ao.throughput_series(ck, 30)[1])
+    lean = _runner(payload, seeds=seeds, collect_clock=False, collect_samples=False,
+                   online_summary={"hist_bins": bins, "hist_max": hist_max}).run()
+    assert np.array_equal(lean.counts[:, :5], both.counts[:, :5])
+    assert np.array_equal(lean.online_hist.cpu().numpy(), both.online_hist.cpu().numpy())
+
+
+# ------------------------------------------------------------------------- BASELINE configs at full size
+def _grid_payload(base: dict, users: float, hop: float) -> dict:
+    p = copy.deepcopy(base)
+    p["rqs_input"]["avg_active_users"]["mean"] = users
+    for e in p["topology_graph"]["edges"]:
+        e["latency"]["mean"] = hop
+    return p
+
+
+@pytest.mark.parametrize("config", [3, 4])
+def test_grid_corners_at_full_horizon(config):
+    """users 10 / 1000 x per-hop latency 0.5 / 50 ms, T = 600 s, 2 seeds each (8 scenarios), as ONE sweep with
+    per-scenario parameter columns; config 4 adds event_inj_lb.yml's spikes and outages.  Every scenario is
+    compared with the oracle run on the payload that has the column values written into it."""
+    base = lb_two_servers(horizon=600) if config == 3 else lb_with_events(users=400, horizon=600)
+    users = np.array([10.0, 10.0, 1000.0, 1000.0] * 2)
+    hop = np.array([0.0005, 0.05, 0.0005, 0.05] * 2)
+    seeds = BASELINE_SEED_BASE[config] + np.arange(8, dtype=np.uint64)
+    sweep = {"rqs_input.avg_active_users.mean": users, "topology_graph.edges[*].latency.mean": hop}
+    res = _runner(base, seeds=seeds, sweep=sweep).run()
+    st = res.engine_stats
+    assert st.flow_scenarios == 8
+    for i in range(8):
+        want = ol.simulate(lower(_grid_payload(base, float(users[i]), float(hop[i]))), int(seeds[i]))
+        _assert_scenario(res[i], want, f"config {config} users={users[i]} hop={hop[i]}")
+    assert int(res.counts[:, _abi.CNT_TICKS].min()) == 11999
+    seq = _runner(base, seeds=seeds, sweep=sweep, flow=False).run()           # the next-event kernels, same sweep
+    _same_batches(res, seq)
+
+
+def test_fanout_at_full_horizon_on_both_kernels_and_both_state_placements():
+    payload = fanout8(horizon=600)
+    seeds = BASELINE_SEED_BASE[5] + np.arange(8, dtype=np.uint64)
+    plan = lower(payload)
+    want = [ol.simulate(plan, int(s)) for s in seeds]
+    flow = _runner(payload, seeds=seeds).run()
+    assert flow.engine_stats.flow_scenarios == 8 and flow.engine_stats.flow_fallback == 0
+    lds = _runner(payload, seeds=seeds, flow=False).run()                      # few scenarios -> narrow waves -> LDS state
+    hbm = _runner(payload, seeds=seeds, flow=False, force_global_state=True).run()
+    assert lds.engine_stats.state_in_lds == 1 and hbm.engine_stats.state_in_lds == 0
+    for i in range(8):
+        for name, res in (("flow", flow), ("lds", lds), ("hbm", hbm)):
+            _assert_scenario(res[i], want[i], f"{name} scenario {i}")
+
+
+# -------------------------------------------------------------------- statistical parity (criterion 2)
+def test_statistical_parity_with_the_numpy_seeded_reference():
+    """256 replicas of two_servers_lb.yml here vs 256 replicas of the STOCK reference (numpy PCG64 through the
+    runner.rng seam; fixture written by `oracle/make_golden.py --pooled 256` in the build container):
+    pooled p50 / p95 within 1 % and 3 standard errors, mean RPS within 1 %, means of the sampled ram_in_use and
+    edge_concurrent_connection series within 2 %, two-sample KS at alpha = 0.01 on latencies thinned to one
+    per ~7.5 simulated seconds (practically independent draws)."""
+    fx = np.load(GOLDEN_DIR / "pooled_lb2_numpy.npz", allow_pickle=False)
+    n = int(fx["n_seeds"])
+    assert n >= 256
+    seeds = 0x5EED0000 + np.arange(n, dtype=np.uint64)
+    res = _runner(lb_two_servers(), seeds=seeds).run()
+    assert res.engine_stats.flow_scenarios == n
+    summ = res.summary(rps=True, series=True)
+    stats = summ["stats"].cpu().numpy()
+    ref = fx["stats"]
+    for col, name, tol in ((2, "p50", 0.01), (4, "p95", 0.01), (1, "mean", 0.01), (5, "p99", 0.02)):
+        a, b = stats[:, col], ref[:, col]
+        se = np.sqrt(a.var(ddof=1) / len(a) + b.var(ddof=1) / len(b))
+        assert abs(a.mean() - b.mean()) <= tol * b.mean(), (name, a.mean(), b.mean())
+        assert abs(a.mean() - b.mean()) <= 3.0 * se + 1e-5 * b.mean(), (name, a.mean(), b.mean(), se)
+    rps = summ["rps"].cpu().numpy().astype(np.float64).mean(axis=1)
+    assert abs(rps.mean() - fx["rps_mean"].mean()) <= 0.01 * fx["rps_mean"].mean()
+    # sampled series: means over ticks, averaged over replicas
+    import json
+
+    keys = json.loads(str(fx["series_keys"]))
+    names = res.series_names()
+    smean = summ["series_mean"].cpu().numpy()
+    for j, key in enumerate(keys):
+        metric, ent = key.split(":")
+        if metric not in ("ram_in_use", "edge_concurrent_connection"):
+            continue
+        col = names.index(f"{ent}:{metric}")
+        got, want = smean[:, col].mean(), fx["series_mean"][:, j].mean()
+        assert abs(got - want) <= 0.02 * want, (key, got, want)
+    # KS on thinned latencies: every 1000th completion of every replica, like the fixture
+    thin = np.concatenate([(res[i].rqs_clock[500::1000, 1] - res[i].rqs_clock[500::1000, 0]) for i in range(n)])
+    from scipy.stats import ks_2samp
+
+    ks = ks_2samp(thin, fx["thin"])
+    assert ks.pvalue > 0.01, (ks.statistic, ks.pvalue, len(thin), len(fx["thin"]))
+    # pooled percentiles from the fixture's 10-us histogram vs ours
+    lat = np.concatenate([res[i].rqs_clock[:, 1] - res[i].rqs_clock[:, 0] for i in range(0, n, 8)])
+    h = fx["hist"].astype(np.float64)
+    cdf = np.cumsum(h) / h.sum()
+    width = float(fx["hist_max"]) / int(fx["hist_bins"])
+    for q in (0.5, 0.95):
+        ref_q = (np.searchsorted(cdf, q) + 0.5) * width
+        assert abs(np.quantile(lat, q) - ref_q) <= 0.01 * ref_q, (q, np.quantile(lat, q), ref_q)
+
+
+def test_grid_columns_helper_matches_survey_definition():
+    a, b = grid_users_rtt(100)
+    assert a.size == 10_000 and a.min() == 10.0 and a.max() == 1000.0 and b.min() == 0.0005 and abs(b.max() - 0.05) < 1e-15

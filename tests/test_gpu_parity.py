@@ -1,4 +1,8 @@
-"""Parity tests proper: the HIP engine (through the C ABI) vs the oracle, on a real MI355X."""
+"""Parity tests proper: the HIP engine (through the C ABI) vs the oracle, on a real MI355X.
+
+This file pins the sequential next-event kernels (af_core.hpp; `flow=False`): they run every plan and
+take over whatever the stage-parallel kernel hands back.  tests/test_gpu_flow.py pins the
+stage-parallel kernel and the hand-over between the two."""
 
 from __future__ import annotations
 
@@ -21,6 +25,7 @@ pytestmark = pytest.mark.gpu
 def _runner(payload, **kw):
     from asyncflow_amd.runner import SimulationRunner
 
+    kw.setdefault("flow", False)
     return SimulationRunner(simulation_input=payload, **kw)
 
 
