@@ -54,7 +54,7 @@ def test_lb2_batch_runs_on_the_flow_kernel_and_matches_the_oracle():
     seeds = 0x5EED0000 + np.arange(200, dtype=np.uint64)
     res = _runner(payload, seeds=seeds).run()
     st = res.engine_stats
-    assert st.flow_scenarios == 200 and st.flow_fallback == 0 and st.flow_list_entries == 64 and st.flow_ring_rows >= 32
+    assert st.flow_scenarios == 200 and st.flow_fallback == 0 and st.flow_list_entries in (64, 128) and st.flow_ring_rows >= 32
     plan = lower(payload)
     for i in (0, 1, 63, 64, 127, 199):
         _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])), f"scenario {i}")
