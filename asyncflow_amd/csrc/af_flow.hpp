@@ -84,13 +84,17 @@ inline FlowLayout make_flow_layout(uint32_t cap, uint32_t ring_rows, uint32_t g_
     L.off_spike = w; w += n_edge_marks;                 // cumulative spike after each edge mark
     L.off_list = w; w += 4u * 2u * cap;                 // 4 lists x (key, t0)
     L.off_aux = w; w += (cap + 1u) / 2u;                // u32 per entry of the server list
-    L.off_out = w; w += 64u * 2u + 32u;                 // selected (key, t0) + u32 aux
+    // scratch of select() (selected (key, t0) + u32 aux; bucket-sorted keys; 64 u32 counts, 64 u32 bases, scalars)
+    // and the per-server segments of the server station (admission, B, S, F, G) are never live together
+    const uint32_t scratch0 = w;
+    L.off_out = w; w += 64u * 2u + 32u;
     L.off_sorted = w; w += cap;
-    L.off_hist = w; w += 32u + 32u + 8u;                // 64 u32 counts, 64 u32 bases, scalars
-    L.off_seg = w; w += 6u * 64u;                       // per-server segments: arrival, start, B, S, F, G
+    L.off_hist = w; w += 32u + 32u + 8u;
+    L.off_seg = scratch0;
+    if (w < scratch0 + 5u * 64u) w = scratch0 + 5u * 64u;
     L.off_fr = w; w += n_servers * c_ring;
     L.off_gr = w; w += n_servers * g_ring;
-    L.off_cnt = w; w += (n_edges + 1u) / 2u + 16u;      // u32 sends per edge; lb order (16 u32), head, n_live, mark cursor
+    L.off_cnt = w; w += (n_edges + 1u) / 2u + 24u;      // u32 sends per edge; 48 u32: lb order, head, n_live, mark cursor, per-server counters
     L.off_ring = w; w += (ring_rows * L.pitch + 1u) / 2u;
     L.n_words = w;
     return L;
@@ -154,8 +158,18 @@ struct Flow {
 
     // uniform state (identical in every lane)
     uint32_t cursor;             // arrivals generated so far
-    uint32_t n_list[4];          // messages pending at client-1st / LB / server / client-2nd
-    double H[4];                 // their horizons
+    // messages pending at client-1st / LB / server / client-2nd and their horizons: named scalars behind
+    // accessors (an array indexed by the station would live in scratch memory)
+    uint32_t nl0, nl1, nl2, nl3;
+    double h0, h1, h2, h3;
+    AF_CORE uint32_t n_list_get(uint32_t s) const { return s == 0u ? nl0 : s == 1u ? nl1 : s == 2u ? nl2 : nl3; }
+    AF_CORE void n_list_set(uint32_t s, uint32_t v) {
+        if (s == 0u) nl0 = v; else if (s == 1u) nl1 = v; else if (s == 2u) nl2 = v; else nl3 = v;
+    }
+    AF_CORE double H_get(uint32_t s) const { return s == 0u ? h0 : s == 1u ? h1 : s == 2u ? h2 : h3; }
+    AF_CORE void H_set(uint32_t s, double v) {
+        if (s == 0u) h0 = v; else if (s == 1u) h1 = v; else if (s == 2u) h2 = v; else h3 = v;
+    }
     uint32_t n_comp, tick_base;
     bool gen_done;
     // per-lane accumulators (reduced at the end)
@@ -185,7 +199,7 @@ struct Flow {
     AF_CORE AF_PLAN_AS double* fr(uint32_t sv) const { return (AF_PLAN_AS double*)(M + A.L.off_fr) + sv * A.L.c_ring; }
     AF_CORE AF_PLAN_AS double* gr(uint32_t sv) const { return (AF_PLAN_AS double*)(M + A.L.off_gr) + sv * A.L.g_ring; }
     AF_CORE AF_PLAN_AS uint32_t* sends() const { return (AF_PLAN_AS uint32_t*)(M + A.L.off_cnt); }
-    AF_CORE AF_PLAN_AS uint32_t* lbw() const { return sends() + ((A.n_edges + 1u) & ~1u); }  // [0..15] order, 16 head, 17 n_live, 18 mark cursor, [24..31] arrivals per server
+    AF_CORE AF_PLAN_AS uint32_t* lbw() const { return sends() + ((A.n_edges + 1u) & ~1u); }  // [0..15] order, 16 head, 17 n_live, 18 mark cursor, [24..31] arrivals per server, [32..39] / [40..47] segment start / length
     AF_CORE AF_PLAN_AS int32_t* ring() const { return (AF_PLAN_AS int32_t*)(M + A.L.off_ring); }
     AF_CORE AF_PLAN_AS double* spike_cum() const { return (AF_PLAN_AS double*)(M + A.L.off_spike); }
 
@@ -297,17 +311,26 @@ struct Flow {
         }
         return sp;
     }
+    AF_CORE_NOINLINE static double cold_variate(uint32_t dist, double mean, double sigma, double u1, uint64_t seed, uint32_t stream,
+                                                uint32_t idx) {
+        return af::variate_from_u1(dist, mean, sigma, u1, seed, stream, idx);
+    }
     // EdgeRuntime._deliver (edge.py:73-116) for the idx-th message of edge e, sent at `now`.
     // Returns false if the message is dropped; else `key` = delivery time.
     AF_CORE bool edge_send(uint32_t e, uint32_t idx, double now, double& key) {
         const AF_PLAN_AS uint64_t* r = erec(e);
         const double mean = u2d(r[0]), sigma = u2d(r[1]), dropout = u2d(r[2]);
         const uint32_t dist = (uint32_t)(r[3] >> 16) & 0xFFu;
-        const double transit = af::pre_edge_draw(seed, e, idx, dist, mean, sigma, dropout);
-        if (transit < 0.0) {
+        // af::pre_edge_draw (edge.py:78-90) with the exponential law -- the reference's default -- inline and the
+        // other laws behind one call
+        const uint32_t stream = af::stream_edge(e);
+        const af::U4 rr = af::draw_block(seed, stream, idx, 0u);
+        if (af::u53(rr.x, rr.y) < dropout) {   // dropped: no latency draw
             drops += 1u;
             return false;
         }
+        const double u1 = af::u53(rr.z, rr.w);
+        const double transit = dist == af::DIST_EXPONENTIAL ? -(mean * af::af_log(1.0 - u1)) : cold_variate(dist, mean, sigma, u1, seed, stream, idx);
         const double spike = A.n_edge_marks != 0u ? spike_at(e, now) : 0.0;
         key = now + (transit + spike);
         if (!(key > now)) why |= FLOW_WHY_TIE;     // a zero (or negative) delay: SimPy orders it among the zero-time steps
@@ -318,28 +341,29 @@ struct Flow {
     // ---- station lists -------------------------------------------------------------------------------
     AF_CORE void append(uint32_t s, bool have, double key, double t0, uint32_t aux) {
         const uint64_t m = W::ballot(have);
-        const uint32_t pos = n_list[s] + W::mbcnt(m);
+        const uint32_t n = n_list_get(s);
+        const uint32_t pos = n + W::mbcnt(m);
         if (have) {
             list_key(s)[pos] = key;
             list_t0(s)[pos] = t0;
             if (s == 2u) list_aux()[pos] = aux;
         }
-        n_list[s] += popc64(m);
+        n_list_set(s, n + popc64(m));
     }
 
     // Rank the messages of list s with time < min(H_in, T); hand the `n_sel` earliest (<= room, <= 64) to
     // lanes 0..n_sel-1 in time order; keep the rest.  Returns n_sel.
     AF_CORE uint32_t select(uint32_t s, double H_in, uint32_t room, double& okey, double& ot0, uint32_t& oaux) {
         W::sync();   // appends of the previous station are visible
-        const double lo = H[s];
+        const double lo = H_get(s);
         const double hi = H_in < A.total_time ? H_in : A.total_time;
-        const uint32_t n = n_list[s];
+        const uint32_t n = n_list_get(s);
         okey = AF_INF;
         ot0 = 0.0;
         oaux = 0u;
         if (!(hi > lo)) return 0u;
         if (n == 0u) {
-            H[s] = hi;
+            H_set(s, hi);
             return 0u;
         }
         AF_PLAN_AS double* K = list_key(s);
@@ -428,9 +452,9 @@ struct Flow {
                 kept += popc64(m);
             }
         }
-        n_list[s] = kept;
+        n_list_set(s, kept);
         W::sync();
-        H[s] = n_sel < E ? scal()[0] : hi;
+        H_set(s, n_sel < E ? scal()[0] : hi);
         if (lane < n_sel) {
             okey = out_key()[lane];
             ot0 = out_t0()[lane];
@@ -512,84 +536,120 @@ struct Flow {
     }
 
     // ---- servers (server.py:79-276 for endpoints of the form IO* CPU* IO*) ----------------------------
-    // Lane k < n_servers walks the arrivals of server k (time order, segment [off, off+cnt) of seg(0)):
-    //   B = arrival + leading I/O steps; S = max(B, release of the core freed c arrivals ago);
-    //   F = S + CPU steps; G = F + trailing I/O steps           (every + is one timed event)
-    AF_CORE void server_walk(uint32_t off, uint32_t cnt) {
-        const uint32_t sv = lane;
+    // Every request of a server runs the same step program, so the server is a tandem of FIFO stations and
+    //   adm_j = max(arrival_j, G_{j-slots})      RAM admission: strict FIFO, `slots` requests fit at once (server.py:146-149)
+    //   B_j   = adm_j + leading I/O steps
+    //   S_j   = max(B_j, F_{j-cores})            the core released `cores` requests earlier (server.py:210-231)
+    //   F_j   = S_j + CPU steps,  G_j = F_j + trailing I/O steps         (every + is one timed event)
+    // The lanes hold the window's arrivals (one each, time order, grouped per server in `seg`).  The recurrence
+    // is solved by relaxation: every lane recomputes its own times from its predecessors' until nothing changes.
+    // Values only grow and each is the same max / + the sequential walk does, so the fixed point IS the
+    // sequential result; the number of passes is the longest chain of requests that wait on each other.
+    struct SrvTimes {
+        double adm, b, s, f, g;
+        uint32_t events;   // step ends before the horizon
+    };
+    AF_CORE SrvTimes srv_program(uint32_t row0, double arrival, double g_prev, double f_prev) const {
+        SrvTimes r;
+        const double T = A.total_time;
+        r.adm = g_prev > arrival ? g_prev : arrival;
+        uint32_t row = row0;
+        double t = r.adm;
+        uint32_t e_cnt = 0u;
+        uint32_t kind = (uint32_t)blob[A.off_row + af::TREC * row + 2u];
+        while (kind == af::STEP_IO) {   // leading I/O steps
+            t = t + u2d(blob[A.off_row + af::TREC * row]);
+            e_cnt += t < T ? 1u : 0u;
+            kind = (uint32_t)blob[A.off_row + af::TREC * (++row) + 2u];
+        }
+        r.b = t;
+        r.s = t;
+        if (kind == af::STEP_CPU) {
+            r.s = f_prev > t ? f_prev : t;
+            t = r.s;
+            while (kind == af::STEP_CPU) {
+                t = t + u2d(blob[A.off_row + af::TREC * row]);
+                e_cnt += t < T ? 1u : 0u;
+                kind = (uint32_t)blob[A.off_row + af::TREC * (++row) + 2u];
+            }
+        }
+        r.f = t;
+        while (kind == af::STEP_IO) {   // trailing I/O steps
+            t = t + u2d(blob[A.off_row + af::TREC * row]);
+            e_cnt += t < T ? 1u : 0u;
+            kind = (uint32_t)blob[A.off_row + af::TREC * (++row) + 2u];
+        }
+        r.g = t;
+        r.events = e_cnt;
+        return r;
+    }
+    // `have` lanes: arrival `a` at server `sv`, position `pos` in seg (its server's segment starts at lbw()[32+sv] and
+    // holds lbw()[40+sv] arrivals).  Returns the lane's times; advances the server's counters and rings.
+    AF_CORE SrvTimes servers_solve(bool have, uint32_t sv, uint32_t pos, double a) {
+        AF_PLAN_AS uint32_t* lw = lbw();
+        const uint32_t off = have ? lw[32u + sv] : 0u, n_k = have ? lw[40u + sv] : 0u;
+        const uint32_t li = pos - off;                         // my index among this window's arrivals of my server
+        const uint32_t j = have ? lw[24u + sv] + li : 0u;      // ... and among all of them
         const uint64_t meta = blob[A.off_srv + af::SREC * sv + 1u];
         const uint32_t cores = (uint32_t)meta & 0xFFFFu;
         const uint32_t ep = (uint32_t)(meta >> 32) & 0xFFFFu;
         const double ram = u2d(blob[A.off_ep + af::PREC * ep]);
         const uint32_t row0 = (uint32_t)blob[A.off_ep + af::PREC * ep + 1u];
         const double ram_mb = u2d(blob[A.off_srv + af::SREC * sv]);
+        const uint32_t G = A.L.g_ring;
         uint32_t slots = 0xFFFFFFFFu;   // requests that fit the RAM at once
         if (ram > 0.0) {
-            const double s = ram_mb / ram;
-            slots = s < 4.0e9 ? (uint32_t)s : 0xFFFFFFFFu;
+            const double q = ram_mb / ram;
+            slots = q < 4.0e9 ? (uint32_t)q : 0xFFFFFFFFu;
             while ((double)slots * ram > ram_mb && slots > 0u) --slots;
         }
-        const double T = A.total_time;
-        AF_PLAN_AS uint32_t* arrivals = lbw() + 24u;   // [kMaxServers] requests admitted so far
-        uint32_t j = arrivals[sv];
-        for (uint32_t i = 0u; i < cnt; ++i, ++j) {
-            const double a = seg(0)[off + i];
-            // RAM admission (server.py:146-149): strict FIFO; every request of this server needs the same
-            // amount, so request j is admitted when request j - slots has given its RAM back
-            double adm = a;
-            if (ram > 0.0) {
-                if (slots == 0u) {
-                    why |= FLOW_WHY_RAM;                                     // never fits: the reference blocks the queue for good
-                } else if (slots <= A.L.g_ring) {
-                    if (j >= slots) {
-                        const double g = gr(sv)[(j - slots) & (A.L.g_ring - 1u)];
-                        if (g == a) why |= FLOW_WHY_TIE;                     // arrival and RAM release at one instant
-                        if (g > a) adm = g;
-                    }
-                } else if (j >= A.L.g_ring && !(gr(sv)[(j - A.L.g_ring) & (A.L.g_ring - 1u)] < a)) {
-                    why |= FLOW_WHY_RAM;                                     // more requests inside than the ring remembers
-                }
+        // where my predecessors' times come from: this window's segment, or the rings of earlier windows
+        const bool ram_gate = have && ram > 0.0 && slots != 0u && slots <= G && j >= slots;
+        const bool core_gate = have && j >= cores;
+        const bool g_in_seg = ram_gate && li >= slots, f_in_seg = core_gate && li >= cores;
+        double g_prev = -AF_INF, f_prev = -AF_INF;
+        if (ram_gate && !g_in_seg) g_prev = gr(sv)[(j - slots) & (G - 1u)];
+        if (core_gate && !f_in_seg) f_prev = fr(sv)[(j - cores) % cores];
+        if (have && ram > 0.0) {
+            if (slots == 0u) why |= FLOW_WHY_RAM;   // never fits: the reference blocks the queue for good
+            else if (slots > G && j >= G) {         // more slots than the ring remembers: fine while fewer than G requests are inside
+                const double gq = li >= G ? AF_INF : gr(sv)[(j - G) & (G - 1u)];   // (li >= G: G arrivals of one server in one window)
+                if (!(gq < a)) why |= FLOW_WHY_RAM;
             }
-            seg(0)[off + i] = adm;
-            uint32_t row = row0;
-            double t = adm;
-            uint32_t e_cnt = 0u;
-            uint32_t kind = (uint32_t)blob[A.off_row + af::TREC * row + 2u];
-            while (kind == af::STEP_IO) {   // leading I/O steps
-                t = t + u2d(blob[A.off_row + af::TREC * row]);
-                e_cnt += t < T ? 1u : 0u;
-                kind = (uint32_t)blob[A.off_row + af::TREC * (++row) + 2u];
-            }
-            const double b = t;
-            double s = b;
-            if (kind == af::STEP_CPU) {
-                if (j >= cores) {
-                    const double rel = fr(sv)[j % cores];   // release of the core freed `cores` arrivals ago
-                    if (rel == b) why |= FLOW_WHY_TIE;   // arrival and core release at one instant: SimPy decides who waits
-                    if (rel > b) s = rel;
-                }
-                t = s;
-                while (kind == af::STEP_CPU) {
-                    t = t + u2d(blob[A.off_row + af::TREC * row]);
-                    e_cnt += t < T ? 1u : 0u;
-                    kind = (uint32_t)blob[A.off_row + af::TREC * (++row) + 2u];
-                }
-                fr(sv)[j % cores] = t;
-            }
-            const double f = t;
-            while (kind == af::STEP_IO) {   // trailing I/O steps
-                t = t + u2d(blob[A.off_row + af::TREC * row]);
-                e_cnt += t < T ? 1u : 0u;
-                kind = (uint32_t)blob[A.off_row + af::TREC * (++row) + 2u];
-            }
-            gr(sv)[j & (A.L.g_ring - 1u)] = t;
-            seg(2)[off + i] = b;
-            seg(3)[off + i] = s;
-            seg(4)[off + i] = f;
-            seg(5)[off + i] = t;
-            ev += e_cnt;
         }
-        arrivals[sv] = j;
+        SrvTimes r = srv_program(row0, a, g_prev, f_prev);
+        for (;;) {
+            if (have) {
+                seg(3)[pos] = r.f;
+                seg(4)[pos] = r.g;
+            }
+            W::sync();
+            bool changed = false;
+            if (g_in_seg || f_in_seg) {
+                const double gp = g_in_seg ? seg(4)[pos - slots] : g_prev;
+                const double fp = f_in_seg ? seg(3)[pos - cores] : f_prev;
+                if (gp != g_prev || fp != f_prev) {
+                    g_prev = gp;
+                    f_prev = fp;
+                    const SrvTimes n = srv_program(row0, a, g_prev, f_prev);
+                    changed = n.f != r.f || n.g != r.g;
+                    r = n;
+                }
+            }
+            const bool again = W::any(changed);
+            W::sync();
+            if (!again) break;
+        }
+        if (have) {
+            if (ram_gate && g_prev == a) why |= FLOW_WHY_TIE;    // arrival and RAM release at one instant
+            if (core_gate && f_prev == r.b) why |= FLOW_WHY_TIE; // request for a core and core release at one instant: SimPy decides who waits
+            if (li + cores >= n_k) fr(sv)[j % cores] = r.f;      // the last `cores` releases / G departures feed later windows
+            if (li + G >= n_k) gr(sv)[j & (G - 1u)] = r.g;
+            ev += r.events;
+        }
+        W::sync();
+        if (lane < A.n_servers) lw[24u + lane] += lw[40u + lane];
+        return r;
     }
 
     // ---- completion (client.py:62-69) -------------------------------------------------------------------
@@ -671,150 +731,111 @@ struct Flow {
         why = 0u;
         run_val = 0;
         gen_done = false;
-        for (uint32_t s = 0u; s < 4u; ++s) {
-            n_list[s] = 0u;
-            H[s] = 0.0;
-        }
+        nl0 = nl1 = nl2 = nl3 = 0u;
+        h0 = h1 = h2 = h3 = 0.0;
         const uint32_t cap = A.L.cap;
         const uint32_t first_srv_stage = A.has_lb ? 1u : 2u;   // where the client's out-edge leads
 
+        // Every round walks the five stations in order.  The code of select() and of edge_send() exists ONCE
+        // (the loop is not unrolled): the kernel stays small enough for the instruction cache.
         for (;;) {
             uint32_t work = 0u;
-            const double h_done_before = H[3];
-            // ---- generator (rqs_generator.py:97-119): up to 64 arrivals, each sent on the generator's edge
-            double H_in;
-            {
-                uint32_t room = cap - n_list[0];
-                room = room < 64u ? room : 64u;
-                const uint32_t i = cursor + lane;
-                const double t0 = (lane < room && i < A.n_draw) ? arr[i] : AF_INF;
-                // with an LDS tick ring a round must not run further ahead of the completed ticks than the ring holds
-                const double t_cap = (samples != nullptr && A.L.ring_rows != 0u)
-                                         ? (double)(tick_base + A.L.ring_rows / 2u) * A.sample_period : AF_INF;
-                const uint64_t vm = W::ballot(t0 < T && t0 < t_cap);   // arrival times increase: a prefix of the lanes
-                const uint32_t n_new = popc64(vm);
-                const uint32_t nxt = cursor + n_new;
-                H_in = nxt < A.n_draw ? arr[nxt] : AF_INF;
-                gen_done = !(H_in < T);
-                const bool have = lane < n_new;
-                double key = 0.0;
-                bool ok = false;
-                if (have) {
-                    ev += 1u;
-                    ok = edge_send(A.gen_out_edge, i, t0, key);
+            const double h_done_before = h3;
+            double H_in = AF_INF;
+#pragma nounroll
+            for (uint32_t st = 0u; st < 5u; ++st) {
+                if (st == 2u && !A.has_lb) continue;
+                // ---- the station's batch: lane r < n_sel holds (key = event time, t0 = start time, aux)
+                double key = 0.0, t0 = 0.0;
+                uint32_t aux = 0u, n_sel;
+                const uint32_t nxt = st == 0u ? 0u : st == 1u ? first_srv_stage : st;   // list the results go to (st < 4)
+                if (st == 0u) {   // generator (rqs_generator.py:97-119): up to 64 arrivals
+                    uint32_t room = cap - nl0;
+                    room = room < 64u ? room : 64u;
+                    const uint32_t i = cursor + lane;
+                    t0 = (lane < room && i < A.n_draw) ? arr[i] : AF_INF;
+                    // with an LDS tick ring a round must not run further ahead of the completed ticks than the ring holds
+                    const double t_cap = (samples != nullptr && A.L.ring_rows != 0u)
+                                             ? (double)(tick_base + A.L.ring_rows / 2u) * A.sample_period : AF_INF;
+                    const uint64_t vm = W::ballot(t0 < T && t0 < t_cap);   // arrival times increase: a prefix of the lanes
+                    n_sel = popc64(vm);
+                    key = t0;
+                } else {
+                    n_sel = select(st - 1u, H_in, st == 4u ? 64u : cap - n_list_get(nxt), key, t0, aux);
                 }
-                append(0u, ok, key, t0, 0u);
-                cursor = nxt;
-                work += n_new;
-            }
-            // ---- client, first visit (client.py:46-60): forward on the client's out-edge
-            {
-                double key, t0;
-                uint32_t aux;
-                const uint32_t nxt = first_srv_stage;
-                const uint32_t n_sel = select(0u, H_in, cap - n_list[nxt], key, t0, aux);
                 const bool have = lane < n_sel;
-                const uint32_t e = A.client_out_edge;
-                double k2 = 0.0;
-                bool ok = false;
-                if (have) {
-                    ev += 1u;
-                    ok = edge_send(e, sends()[e] + lane, key, k2);
-                }
-                W::sync();
-                if (lane == 0u) sends()[e] += n_sel;
-                const uint32_t tgt = (uint32_t)(erec(e)[3] >> 8) & 0xFFu;
-                append(nxt, ok, k2, t0, tgt);
+                if (have) ev += 1u;                       // one timed event per message: arrival / delivery
                 work += n_sel;
-                H_in = H[0];
-            }
-            // ---- load balancer
-            if (A.has_lb) {
-                double key, t0;
-                uint32_t aux;
-                const uint32_t n_sel = select(1u, H_in, cap - n_list[2], key, t0, aux);
-                if (n_sel > 0u) {
-                    const bool have = lane < n_sel;
-                    const uint32_t e = lb_pick(n_sel, key);
-                    const uint32_t idx = claim_send_index(have, e, false);
-                    double k3 = 0.0;
-                    bool ok = false;
-                    if (have) {
-                        ev += 1u;
-                        ok = edge_send(e, idx, key, k3);
+                // ---- what the station does with it: the out-edge, the message's index on it, the send time
+                bool sending = have;
+                uint32_t e = 0u, idx = 0u, tgt = 0u;
+                double ts = key;
+                if (st == 0u) {
+                    e = A.gen_out_edge;
+                    idx = cursor + lane;
+                    cursor += n_sel;
+                    H_in = cursor < A.n_draw ? arr[cursor] : AF_INF;   // next arrival not yet generated
+                    gen_done = !(H_in < T);
+                } else if (st == 1u) {   // client, first visit (client.py:46-60): forward on the client's out-edge
+                    e = A.client_out_edge;
+                    idx = sends()[e] + lane;
+                    W::sync();
+                    if (lane == 0u) sends()[e] += n_sel;
+                    tgt = (uint32_t)(erec(e)[3] >> 8) & 0xFFu;
+                } else if (st == 2u) {   // load balancer
+                    if (n_sel > 0u) {
+                        e = lb_pick(n_sel, key);
+                        idx = claim_send_index(have, e, false);
+                        tgt = (uint32_t)(erec(e)[3] >> 8) & 0xFFu;
                     }
-                    const uint32_t tgt = have ? (uint32_t)(erec(e)[3] >> 8) & 0xFFu : 0u;
-                    append(2u, ok, k3, t0, tgt);
-                }
-                work += n_sel;
-                H_in = H[1];
-            }
-            // ---- servers
-            {
-                double key, t0;
-                uint32_t sv;
-                const uint32_t n_sel = select(2u, H_in, cap - n_list[3], key, t0, sv);
-                if (n_sel > 0u) {
-                    const bool have = lane < n_sel;
-                    // per-server segments of the (time-ordered) arrivals
-                    uint32_t my_off = 0u, my_cnt = 0u, pos = 0u, off = 0u;
-                    for (uint32_t k = 0u; k < A.n_servers; ++k) {
-                        const uint64_t m = W::ballot(have && sv == k);
-                        if (have && sv == k) pos = off + W::mbcnt(m);
-                        if (lane == k) {
-                            my_off = off;
-                            my_cnt = popc64(m);
+                } else if (st == 3u) {   // servers
+                    if (n_sel > 0u) {
+                        const uint32_t sv = aux;
+                        uint32_t pos = 0u, off = 0u;   // per-server segments of the time-ordered arrivals
+                        for (uint32_t k = 0u; k < A.n_servers; ++k) {
+                            const uint64_t m = W::ballot(have && sv == k);
+                            if (have && sv == k) pos = off + W::mbcnt(m);
+                            if (lane == k) {
+                                lbw()[32u + k] = off;
+                                lbw()[40u + k] = popc64(m);
+                            }
+                            off += popc64(m);
                         }
-                        off += popc64(m);
+                        W::sync();   // select()'s scratch is dead from here on: the segments reuse it
+                        const SrvTimes r = servers_solve(have, sv, pos, key);
+                        if (have) {
+                            const uint64_t meta = blob[A.off_srv + af::SREC * sv + 1u];
+                            e = (uint32_t)(meta >> 16) & 0xFFFFu;
+                            const uint32_t ep = (uint32_t)(meta >> 32) & 0xFFFFu;
+                            const double ram = u2d(blob[A.off_ep + af::PREC * ep]);
+                            const uint32_t s0 = A.n_edges + 3u * sv;
+                            if (r.s > r.b) add_interval(s0, r.b, r.s, 1);               // ready queue: waited for a core (server.py:215-225)
+                            if (r.b > r.adm) add_interval(s0 + 1u, r.adm, r.b, 1);      // leading I/O steps
+                            if (r.g > r.f) add_interval(s0 + 1u, r.f, r.g, 1);          // trailing I/O steps
+                            if (ram > 0.0) add_interval(s0 + 2u, r.adm, r.g, (int32_t)ram);   // RAM held from admission to the end (server.py:146-149, 270-273)
+                            ts = r.g;
+                        }
+                        sending = have && ts < T;      // transport() on the server's out-edge at G (server.py:276), if the horizon allows
+                        idx = claim_send_index(sending, e, true);
                     }
-                    if (have) {
-                        ev += 1u;
-                        seg(0)[pos] = key;
-                        seg(1)[pos] = t0;
-                    }
-                    W::sync();
-                    if (lane < A.n_servers) server_walk(my_off, my_cnt);
-                    W::sync();
-                    double k4 = 0.0;
-                    bool ok = false;
-                    uint32_t e = 0u;
-                    if (have) {
-                        const double adm = seg(0)[pos], b = seg(2)[pos], s = seg(3)[pos], f = seg(4)[pos], g = seg(5)[pos];
-                        const uint64_t meta = blob[A.off_srv + af::SREC * sv + 1u];
-                        e = (uint32_t)(meta >> 16) & 0xFFFFu;
-                        const uint32_t ep = (uint32_t)(meta >> 32) & 0xFFFFu;
-                        const double ram = u2d(blob[A.off_ep + af::PREC * ep]);
-                        const uint32_t s0 = A.n_edges + 3u * sv;
-                        if (s > b) add_interval(s0, b, s, 1);                 // ready queue: waited for a core (server.py:215-225)
-                        if (b > adm) add_interval(s0 + 1u, adm, b, 1);        // leading I/O steps
-                        if (g > f) add_interval(s0 + 1u, f, g, 1);            // trailing I/O steps
-                        if (ram > 0.0) add_interval(s0 + 2u, adm, g, (int32_t)ram);   // RAM held from admission to the end (server.py:146-149, 270-273)
-                    }
-                    // transport() on the server's out-edge at G (server.py:276), if the horizon allows
-                    const bool sending = have && seg(5)[pos] < T;
-                    const uint32_t idx = claim_send_index(sending, e, true);
-                    if (sending) ok = edge_send(e, idx, seg(5)[pos], k4);
-                    append(3u, ok, k4, t0, 0u);
+                } else {   // client, second visit (client.py:62-69): the request is complete
+                    complete(have, lane, t0, key);
+                    n_comp += n_sel;
+                    sending = false;
                 }
-                work += n_sel;
-                H_in = H[2];
-            }
-            // ---- client, second visit (client.py:62-69): the request is complete
-            {
-                double key, t0;
-                uint32_t aux;
-                const uint32_t n_sel = select(3u, H_in, 64u, key, t0, aux);
-                if (lane < n_sel) ev += 1u;
-                complete(lane < n_sel, lane, t0, key);
-                n_comp += n_sel;
-                work += n_sel;
+                if (st < 4u) {
+                    double k2 = 0.0;
+                    const bool ok = sending && edge_send(e, idx, ts, k2);
+                    append(nxt, ok, k2, t0, tgt);
+                    if (st > 0u) H_in = H_get(st - 1u);
+                }
             }
             // ---- ticks that can no longer change
-            const bool finished = gen_done && work == 0u && !(H[3] < T);
+            const bool finished = gen_done && work == 0u && !(h3 < T);
             W::sync();
-            flush_ticks(finished ? A.n_ticks : tick_index(H[3], false));
+            flush_ticks(finished ? A.n_ticks : tick_index(h3, false));
             W::sync();
-            const bool stuck = work == 0u && !finished && !(H[3] > h_done_before);
+            const bool stuck = work == 0u && !finished && !(h3 > h_done_before);
             if (stuck) why |= FLOW_WHY_LIST;   // nothing moved, no horizon advanced: a list is full of later messages
             if (finished || W::any(why != 0u)) break;
         }

@@ -301,8 +301,12 @@ struct WaveHip {
     }
 };
 
+// Register budget as waves per SIMD (measured on MI355X, profiles/r02: see DESIGN.md section 4e).
+#ifndef AF_FLOW_WPE
+#define AF_FLOW_WPE 4
+#endif
 template <uint32_t IPL>
-__global__ void __launch_bounds__(64) af_flow_kernel(const aff::FlowArgs a) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AF_FLOW_WPE))) af_flow_kernel(const aff::FlowArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t sc = blockIdx.x;
     if (sc >= a.n_scen) return;
@@ -1007,7 +1011,11 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
         const double g_mean = lat_mean(e->gen_edge) + e->edge_spike[e->gen_edge], g_hi = lat_hi(e->gen_edge) + e->edge_spike[e->gen_edge];
         const double c_mean = lat_mean(e->client_edge) + e->edge_spike[e->client_edge],
                      c_hi = lat_hi(e->client_edge) + e->edge_spike[e->client_edge];
-        const double in_server = e->service_max + 20.0 * e->cpu_max;   // service + a generous queueing allowance
+        // time in a server: service + the M/D/1 wait for a core at the heaviest load of the sweep
+        const double n_active = e->has_lb ? (double)(e->lb_edges.size() > 1 && a.n_srv_marks ? e->lb_edges.size() - 1 : e->lb_edges.size()) : 1.0;
+        const double rho = rate / n_active * e->cpu_max / (double)e->cores_max;
+        const double wait = rho < 0.9 ? rho * e->cpu_max / (2.0 * (1.0 - rho)) : 20.0 * e->cpu_max + 1.0;
+        const double in_server = e->service_max + 4.0 * wait;
         double pend = rate * std::fmax(std::fmax(g_mean, c_mean), std::fmax(lb_mean, so_mean + in_server));
         pend += 5.0 * std::sqrt(pend + 1.0);
         uint32_t entries = e->flow_list_entries;

@@ -1,0 +1,33 @@
+#!/bin/bash
+# Round-2 rocprofv3 evidence (run on the GPU box from the repo root): bash scripts/profile_round2.sh [tag] [bench flags...]
+#   -> gpurun_out/prof_<tag>/*   (kernel trace + stats; PMC passes on their own, never with trace domains)
+cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
+TAG=${1:-r02}; shift
+OUT=gpurun_out/prof_$TAG; mkdir -p $OUT
+KERN="af_flow|af_des|af_jit|af_pregen|af_summary|af_series"
+python bench.py --steps 3 --warmup 1 --no-cpu-baseline --generic-kernels "$@" > $OUT/bench_unprofiled.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt -o t -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --generic-kernels "$@" > $OUT/bench_under_trace.log 2>&1
+cp $(find /tmp/pt -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_trace.csv
+f=$(find /tmp/pt -name "*kernel_trace.csv" | head -1); head -1 $f > $OUT/kernel_trace_af.csv; grep -E "$KERN" $f >> $OUT/kernel_trace_af.csv
+pass() { i=$1; shift; timeout 300 rocprofv3 --pmc "$@" --output-format csv -d /tmp/pp$i -o p -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --generic-kernels $EXTRA > $OUT/bench_under_pmc$i.log 2>&1; f=$(find /tmp/pp$i -name "*counter_collection.csv" | head -1); head -1 $f > $OUT/pmc$i.csv; grep -E "$KERN" $f >> $OUT/pmc$i.csv; }
+EXTRA="$@"
+pass 1 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVES SQ_WAVE_CYCLES
+pass 2 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_THREAD_CYCLES_VALU
+pass 3 FETCH_SIZE
+pass 4 WRITE_SIZE
+pass 5 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_WAIT_INST_LDS
+ls -la $OUT
+python - <<PY
+import csv,collections
+for i in (1,2,3,4,5):
+    try:
+        rows=list(csv.DictReader(open("$OUT/pmc%d.csv"%i)))
+    except Exception as e:
+        print("pmc",i,e); continue
+    acc=collections.defaultdict(float)
+    for r in rows:
+        if "af_flow" in r.get("Kernel_Name",""):
+            acc[r["Counter_Name"]]+=float(r["Counter_Value"])
+    print(i, dict(acc))
+PY
+head -12 $OUT/kernel_stats_trace.csv
