@@ -14,6 +14,7 @@ AF_ABI_VERSION = 3
 # af_status
 MAX_REQUEST_CAPACITY = 65535   # include/asyncflow_hip.h AF_MAX_REQUEST_CAPACITY
 MAX_FIFO_CAPACITY = 16384      # AF_MAX_FIFO_CAPACITY
+COMM_ID_BYTES = 128            # AF_COMM_ID_BYTES
 AF_OK = 0
 AF_ERR_INVALID = -1
 AF_ERR_NO_DEVICE = -2
@@ -195,6 +196,7 @@ class AfStats(C.Structure):
         ("flow_ring_rows", C.c_uint32),
         ("flow_lds_bytes", C.c_uint32),
         ("jit_fallbacks", C.c_uint32),
+        ("gather_ms", C.c_double),
     ]
 
 
@@ -224,6 +226,11 @@ EXPORTED_SYMBOLS = (
     "af_engine_set_kernels",
     "af_engine_stats",
     "af_engine_flow_reason",
+    "af_engine_gather",
+    "af_comm_load",
+    "af_comm_unique_id",
+    "af_comm_init_rank",
+    "af_comm_destroy",
     "af_engine_destroy",
     "af_tick_count",
     "af_series_count",
@@ -252,6 +259,16 @@ def declare(lib: C.CDLL) -> C.CDLL:
     lib.af_engine_stats.restype = C.c_int
     lib.af_engine_flow_reason.argtypes = [C.c_void_p]
     lib.af_engine_flow_reason.restype = C.c_char_p
+    lib.af_engine_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(AfSummary), C.POINTER(AfSummary)]
+    lib.af_engine_gather.restype = C.c_int
+    lib.af_comm_load.argtypes = [C.c_char_p]
+    lib.af_comm_load.restype = C.c_int
+    lib.af_comm_unique_id.argtypes = [C.c_void_p]
+    lib.af_comm_unique_id.restype = C.c_int
+    lib.af_comm_init_rank.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    lib.af_comm_init_rank.restype = C.c_int
+    lib.af_comm_destroy.argtypes = [C.c_void_p]
+    lib.af_comm_destroy.restype = None
     lib.af_engine_destroy.argtypes = [C.c_void_p]
     lib.af_engine_destroy.restype = None
     lib.af_tick_count.argtypes = [C.c_double, C.c_double]

@@ -22,6 +22,7 @@
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see build.py).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <cstdio>
 #include <cstring>
@@ -1449,6 +1450,127 @@ void af_engine_destroy(af_engine_t* e) {
     if (e->jit_module) (void)hipModuleUnload(e->jit_module);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
+}
+
+// ---- RCCL, resolved at run time (include/asyncflow_hip.h: "the one collective") ------------------------
+namespace {
+struct nccl_id_t { char internal[AF_COMM_ID_BYTES]; };
+struct RcclApi {
+    void* handle = nullptr;
+    int (*GetUniqueId)(nccl_id_t*) = nullptr;
+    int (*CommInitRank)(void**, int, nccl_id_t, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string origin;
+    bool ok() const { return AllGather != nullptr; }
+};
+RcclApi g_rccl;
+
+bool rccl_bind(void* h, const std::string& origin) {
+    RcclApi r;
+    r.handle = h;
+    r.origin = origin;
+    void* scope = h ? h : RTLD_DEFAULT;
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(scope, "ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(scope, "ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(scope, "ncclCommDestroy"));
+    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(scope, "ncclAllGather"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(scope, "ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(scope, "ncclGroupEnd"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(scope, "ncclGetErrorString"));
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GroupStart || !r.GroupEnd) return false;
+    g_rccl = r;
+    return true;
+}
+int rccl_need() {
+    if (g_rccl.ok()) return AF_OK;
+    if (rccl_bind(nullptr, "already in the process")) return AF_OK;
+    std::vector<std::string> cands;
+    if (const char* env = std::getenv("ASYNCFLOW_RCCL_LIB")) cands.push_back(env);
+    cands.push_back("librccl.so.1");
+    cands.push_back("librccl.so");
+    for (const std::string& c : cands)
+        if (void* h = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL))
+            if (rccl_bind(h, c)) return AF_OK;
+    return fail(AF_ERR_INVALID, "RCCL not found: call af_comm_load(path) or set ASYNCFLOW_RCCL_LIB");
+}
+#define RCCL_TRY(expr)                                                                                   \
+    do {                                                                                                 \
+        const int r_ = (expr);                                                                           \
+        if (r_ != 0)                                                                                     \
+            return fail(AF_ERR_HIP, std::string(#expr) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "rccl error")); \
+    } while (0)
+}  // namespace
+
+int af_comm_load(const char* path) {
+    if (!path) return rccl_need();
+    void* h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!h) return fail(AF_ERR_INVALID, std::string("dlopen(") + path + "): " + dlerror());
+    if (!rccl_bind(h, path)) return fail(AF_ERR_INVALID, std::string(path) + " does not export the RCCL entry points");
+    return AF_OK;
+}
+
+int af_comm_unique_id(void* id_out) {
+    if (!id_out) return fail(AF_ERR_INVALID, "NULL argument");
+    if (int rc = rccl_need()) return rc;
+    nccl_id_t id;
+    RCCL_TRY(g_rccl.GetUniqueId(&id));
+    std::memcpy(id_out, &id, sizeof id);
+    return AF_OK;
+}
+
+int af_comm_init_rank(const void* id, int world_size, int rank, int device, void** comm_out) {
+    if (!id || !comm_out || world_size <= 0 || rank < 0 || rank >= world_size) return fail(AF_ERR_INVALID, "bad communicator arguments");
+    if (int rc = rccl_need()) return rc;
+    HIP_TRY(hipSetDevice(device));
+    nccl_id_t nid;
+    std::memcpy(&nid, id, sizeof nid);
+    void* comm = nullptr;
+    RCCL_TRY(g_rccl.CommInitRank(&comm, world_size, nid, rank));
+    *comm_out = comm;
+    return AF_OK;
+}
+
+void af_comm_destroy(void* comm) {
+    if (comm && g_rccl.ok()) (void)g_rccl.CommDestroy(comm);
+}
+
+int af_engine_gather(af_engine_t* e, void* comm, int world_size, const af_summary_t* local, const af_summary_t* out) {
+    if (!e || !comm || !local || !out || world_size <= 0) return fail(AF_ERR_INVALID, "NULL argument");
+    if (local->n_scenarios == 0) return fail(AF_ERR_INVALID, "empty shard");
+    if (out->n_scenarios != local->n_scenarios * (uint32_t)world_size)
+        return fail(AF_ERR_INVALID, "gathered.n_scenarios must be world_size * local.n_scenarios");
+    if (int rc = rccl_need()) return rc;
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t n = local->n_scenarios;
+    const uint32_t n_series = e->args.n_series;
+    struct Part { const void* src; void* dst; size_t row_bytes; const char* what; };
+    const Part parts[] = {
+        {local->stats, out->stats, 8u * sizeof(double), "stats"},
+        {local->rps, out->rps, (size_t)local->rps_buckets * sizeof(float), "rps"},
+        {local->hist, out->hist, (size_t)local->hist_bins * sizeof(uint32_t), "hist"},
+        {local->series_mean, out->series_mean, (size_t)n_series * sizeof(double), "series_mean"},
+        {local->series_max, out->series_max, (size_t)n_series * sizeof(uint32_t), "series_max"},
+    };
+    for (const Part& p : parts)
+        if ((p.src == nullptr) != (p.dst == nullptr)) return fail(AF_ERR_INVALID, std::string("local / gathered disagree on ") + p.what);
+    if (out->rps_buckets != local->rps_buckets || out->hist_bins != local->hist_bins)
+        return fail(AF_ERR_INVALID, "local / gathered row lengths differ");
+    HIP_TRY(hipEventRecord(e->ev0, e->stream));
+    RCCL_TRY(g_rccl.GroupStart());
+    for (const Part& p : parts)
+        if (p.src && p.row_bytes)
+            RCCL_TRY(g_rccl.AllGather(p.src, p.dst, n * p.row_bytes, /* ncclInt8 */ 0, comm, e->stream));
+    RCCL_TRY(g_rccl.GroupEnd());
+    HIP_TRY(hipEventRecord(e->ev1, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    e->stats.gather_ms = ms;
+    return AF_OK;
 }
 
 int af_probe_math(int device, int kind, uint64_t seed, const double* in, const double* in2, double* out, size_t n) {

@@ -198,6 +198,22 @@ class Engine:
         _check(self._lib, self._lib.af_engine_summarize(self._h, C.byref(out), C.byref(summ)), "af_engine_summarize")
         return self.stats()
 
+    def gather(self, comm: "C.c_void_p | int", world_size: int, n_local: int, local: dict, gathered: dict, *,
+               rps_buckets: int = 0, hist_bins: int = 0) -> _abi.AfStats:
+        """``af_engine_gather``: ONE grouped RCCL all-gather of the per-scenario summaries.
+
+        ``local`` / ``gathered`` map ``stats | rps | hist | series_mean | series_max`` to DEVICE pointers
+        (0 / missing = not gathered); every rank passes the same ``n_local`` (pad the last shard)."""
+        def summ(n: int, ptrs: dict) -> _abi.AfSummary:
+            return _abi.AfSummary(int(n), int(rps_buckets), int(hist_bins), 0.0,
+                                  C.c_void_p(ptrs.get("stats") or None), C.c_void_p(ptrs.get("rps") or None),
+                                  C.c_void_p(ptrs.get("hist") or None), C.c_void_p(ptrs.get("series_mean") or None),
+                                  C.c_void_p(ptrs.get("series_max") or None))
+
+        a, b = summ(n_local, local), summ(n_local * world_size, gathered)
+        _check(self._lib, self._lib.af_engine_gather(self._h, comm, int(world_size), C.byref(a), C.byref(b)), "af_engine_gather")
+        return self.stats()
+
     def flow_reason(self) -> str:
         """'' when the stage-parallel kernel can run this plan, else why it always runs on the next-event kernels."""
         return (self._lib.af_engine_flow_reason(self._h) or b"").decode()

@@ -426,33 +426,96 @@ class BatchedResults:
         item, ROADMAP.md:23-29): mean, standard deviation and normal-approximation confidence
         half-width of every latency statistic, plus the mean RPS band (5th/95th percentile
         across scenarios per 1-s window)."""
-        from statistics import NormalDist
+        return aggregate_summary(self.summary(rps=True), level)
 
+
+def aggregate_summary(summ: dict[str, Any], level: float = 0.95) -> dict[str, Any]:
+    """Monte-Carlo aggregation of a ``summary()`` dict (see :meth:`BatchedResults.aggregate`)."""
+    from statistics import NormalDist
+
+    import torch
+
+    st = summ["stats"]                                  # [n, 8] on the run's device: reduced there,
+    ok = st[:, 0] > 0                                   # only the 8-vectors and the [T] bands come back
+    z = NormalDist().inv_cdf(0.5 + level / 2.0)
+    k = int(ok.sum())
+    body = st[ok]
+    nan8 = np.full(8, np.nan)
+    mean = body.mean(dim=0).cpu().numpy() if k else nan8
+    sd = body.std(dim=0, unbiased=True).cpu().numpy() if k > 1 else nan8
+    out: dict[str, Any] = {
+        "n": k,
+        "keys": LATENCY_KEYS,
+        "mean": dict(zip(LATENCY_KEYS, mean.tolist())),
+        "std": dict(zip(LATENCY_KEYS, sd.tolist())),
+        "ci_halfwidth": dict(zip(LATENCY_KEYS, (z * sd / np.sqrt(max(k, 1))).tolist())),
+        "level": level,
+    }
+    if "rps" in summ:
+        r = summ["rps"].to(torch.float64)
+        out["rps_mean"] = r.mean(dim=0).cpu().numpy()
+        q = torch.quantile(r, torch.tensor([0.05, 0.95], dtype=torch.float64, device=r.device), dim=0)
+        out["rps_p05"], out["rps_p95"] = q[0].cpu().numpy(), q[1].cpu().numpy()
+    return out
+
+
+class ShardedResults:
+    """A sweep run on several devices by ONE process (``SimulationRunner(devices=[...])``): the shards'
+    :class:`BatchedResults` behind the indices of the original sweep."""
+
+    def __init__(self, shards: list[BatchedResults], index: list[np.ndarray], wall_s: float) -> None:
+        self.shards, self.index, self.wall_s = shards, index, wall_s
+        n = sum(len(ix) for ix in index)
+        self._where = np.zeros((n, 2), dtype=np.int64)
+        for k, ix in enumerate(index):
+            self._where[ix, 0] = k
+            self._where[ix, 1] = np.arange(len(ix))
+        self.plan = shards[0].plan
+        self.counts = np.zeros((n, _abi.CNT_SLOTS), dtype=np.uint32)
+        self.seeds = np.zeros(n, dtype=np.uint64)
+        for k, ix in enumerate(index):
+            self.counts[ix] = shards[k].counts
+            self.seeds[ix] = shards[k].seeds
+        self.kernel_ms = max(s.kernel_ms for s in shards)
+
+    def __len__(self) -> int:
+        return int(self.counts.shape[0])
+
+    def __getitem__(self, i: int) -> ScenarioResults:
+        k, j = self._where[int(i)]
+        return self.shards[int(k)][int(j)]
+
+    def __iter__(self) -> Iterator[ScenarioResults]:
+        return (self[i] for i in range(len(self)))
+
+    @property
+    def flags(self) -> np.ndarray:
+        return self.counts[:, _abi.CNT_FLAGS]
+
+    @property
+    def request_events(self) -> np.ndarray:
+        return self.counts[:, _abi.CNT_EVENTS].astype(np.int64)
+
+    def raise_on_overflow(self) -> None:
+        for s in self.shards:
+            s.raise_on_overflow()
+
+    def summary(self, **kw: Any) -> dict[str, Any]:
+        """Per-scenario summaries of every shard (each computed on its own device), concatenated on the
+        first shard's device in the order of the original sweep."""
         import torch
 
-        summ = self.summary(rps=True)
-        st = summ["stats"]                                  # [n, 8] on the run's device: reduced there,
-        ok = st[:, 0] > 0                                   # only the 8-vectors and the [T] bands come back
-        z = NormalDist().inv_cdf(0.5 + level / 2.0)
-        k = int(ok.sum())
-        body = st[ok]
-        nan8 = np.full(8, np.nan)
-        mean = body.mean(dim=0).cpu().numpy() if k else nan8
-        sd = body.std(dim=0, unbiased=True).cpu().numpy() if k > 1 else nan8
-        out: dict[str, Any] = {
-            "n": k,
-            "keys": LATENCY_KEYS,
-            "mean": dict(zip(LATENCY_KEYS, mean.tolist())),
-            "std": dict(zip(LATENCY_KEYS, sd.tolist())),
-            "ci_halfwidth": dict(zip(LATENCY_KEYS, (z * sd / np.sqrt(max(k, 1))).tolist())),
-            "level": level,
-        }
-        if "rps" in summ:
-            r = summ["rps"].to(torch.float64)
-            out["rps_mean"] = r.mean(dim=0).cpu().numpy()
-            q = torch.quantile(r, torch.tensor([0.05, 0.95], dtype=torch.float64, device=r.device), dim=0)
-            out["rps_p05"], out["rps_p95"] = q[0].cpu().numpy(), q[1].cpu().numpy()
+        parts = [s.summary(**kw) for s in self.shards]
+        dev = parts[0]["stats"].device
+        order = torch.as_tensor(np.argsort(np.concatenate(self.index), kind="stable"), device=dev)
+        out: dict[str, Any] = {"keys": LATENCY_KEYS}
+        for key in ("stats", "rps", "hist", "series_mean", "series_max"):
+            if key in parts[0]:
+                out[key] = torch.cat([p[key].to(dev) for p in parts], dim=0).index_select(0, order)
         return out
+
+    def aggregate(self, level: float = 0.95) -> dict[str, Any]:
+        return aggregate_summary(self.summary(rps=True), level)
 
 
 def load_summary(path: str) -> dict[str, np.ndarray]:

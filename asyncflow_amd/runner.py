@@ -124,6 +124,7 @@ class SimulationRunner:
         flow: bool = True,
         flow_list_entries: int = 0,
         flow_ring_rows: int = 0,
+        devices: Sequence[int] | None = None,
     ) -> None:
         self.env = env  # accepted for signature compatibility; unused
         self.simulation_input = simulation_input
@@ -165,6 +166,17 @@ class SimulationRunner:
         self.flow = flow
         self.flow_list_entries = flow_list_entries
         self.flow_ring_rows = flow_ring_rows
+        #: several GPUs from ONE process: scenarios are dealt to the devices (by expected load when the sweep
+        #: has a users column; contiguous otherwise), one engine per device runs in its own host
+        #: thread, no exchange during simulation.  (One process per GPU + the RCCL gather: bench.py --gpus N.)
+        self.devices = [int(d) for d in devices] if devices else None
+        self._init_kwargs = dict(replicas=replicas, device=device, request_capacity=request_capacity,
+                                 fifo_capacity=fifo_capacity, clock_capacity=clock_capacity, collect_clock=collect_clock,
+                                 collect_samples=collect_samples, force_global_state=force_global_state, auto_grow=auto_grow,
+                                 lanes_per_wave=lanes_per_wave, draw_memory_mb=draw_memory_mb,
+                                 expect_shared_instants=expect_shared_instants, specialise=specialise,
+                                 online_summary=online_summary, flow=flow, flow_list_entries=flow_list_entries,
+                                 flow_ring_rows=flow_ring_rows)
         self._single = seeds is None and int(replicas) == 1 and not self.sweep
         self._engine: Engine | None = None
 
@@ -196,9 +208,51 @@ class SimulationRunner:
 
         return hashlib.sha1(json.dumps(self.plan.payload, sort_keys=True, default=str).encode()).hexdigest()
 
+    def _run_sharded(self) -> Any:
+        import threading
+
+        from .distributed import interleave_by_load, shard_bounds
+        from .results import ShardedResults
+
+        n, k = int(self.seeds.size), len(self.devices)
+        users = self.sweep.get("rqs_input.avg_active_users.mean")
+        if users is not None:
+            index = interleave_by_load(np.broadcast_to(np.asarray(users, dtype=np.float64), (n,)), k)
+        else:
+            index = [np.arange(*shard_bounds(n, r, k)) for r in range(k)]
+        shards: list[Any] = [None] * k
+        errors: list[BaseException] = []
+
+        def work(r: int) -> None:
+            try:
+                cols = {key: np.ascontiguousarray(np.broadcast_to(np.asarray(v, dtype=np.float64), (n,))[index[r]])
+                        for key, v in self.sweep.items()}
+                kw = dict(self._init_kwargs, device=self.devices[r])
+                kw.pop("replicas")
+                child = SimulationRunner(simulation_input=self.simulation_input, seeds=self.seeds[index[r]], sweep=cols, **kw)
+                shards[r] = child.run()
+            except BaseException as exc:  # noqa: BLE001 - re-raised in the caller's thread
+                errors.append(exc)
+
+        t0 = time.perf_counter()
+        threads = [threading.Thread(target=work, args=(r,)) for r in range(k) if len(index[r])]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        keep = [r for r in range(k) if shards[r] is not None]
+        return ShardedResults([shards[r] for r in keep], [index[r] for r in keep], time.perf_counter() - t0)
+
     def run(self) -> BatchedResults | ScenarioResults:
         """Lower once, launch the HIP kernel over every scenario, return results."""
         import torch
+
+        if self.devices is not None and (len(self.devices) > 1 or self.device is None):
+            if len(self.devices) > 1:
+                return self._run_sharded()
+            self.device = self.devices[0]
 
         if not torch.cuda.is_available():
             from .engine import EngineUnavailableError

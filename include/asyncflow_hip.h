@@ -287,6 +287,7 @@ typedef struct af_stats {
     uint32_t flow_ring_rows;       /* (0 = differences kept in HBM)                                 */
     uint32_t flow_lds_bytes;       /* LDS per wavefront                                             */
     uint32_t jit_fallbacks;        /* launches that wanted plan-specialised kernels but ran the generic ones */
+    double gather_ms;              /* last af_engine_gather (HIP events around the grouped all-gather)        */
 } af_stats_t;
 
 typedef struct af_engine af_engine_t;
@@ -330,6 +331,30 @@ typedef struct af_summary_t {
 /* `out` is the af_outputs_t the run filled (clock + counts are required, samples only for the
  * series outputs).  Synchronous like af_engine_run. */
 int af_engine_summarize(af_engine_t* engine, const af_outputs_t* out, const af_summary_t* summary);
+
+/* ---- the one collective of a multi-GPU sweep ---------------------------------------------
+ * Scenarios shard over the GPUs of a node with no exchange during simulation; at the end every rank
+ * contributes the summaries of ITS scenarios and receives everybody's: one grouped RCCL all-gather
+ * over xGMI on the engine's stream.  The reference has nothing to replace here (single process, one
+ * env per run: docs/api/high-level/runner.md:203-207); this is the Monte-Carlo roadmap item
+ * (ROADMAP.md:23-29) across devices.
+ *
+ * RCCL is resolved at run time, NOT linked: af_comm_load(path) opens a specific librccl (a host that
+ * already uses RCCL -- e.g. PyTorch, whose copy is torch/lib/librccl.so -- must name that one so that a
+ * single RCCL lives in the process); with NULL the engine takes the RCCL already visible in the process,
+ * then $ASYNCFLOW_RCCL_LIB, then librccl.so.1.  `comm` is a ncclComm_t: the host's own, or one made by
+ * af_comm_init_rank from the 128-byte id rank 0 obtained with af_comm_unique_id and shared out of band. */
+#define AF_COMM_ID_BYTES 128
+int af_comm_load(const char* librccl_path);
+int af_comm_unique_id(void* id_out /* AF_COMM_ID_BYTES */);
+int af_comm_init_rank(const void* id, int world_size, int rank, int device, void** comm_out);
+void af_comm_destroy(void* comm);
+/* All-gather of per-scenario summaries: every non-NULL array of `local` (n_scenarios rows: the rank's
+ * shard, padded by the caller to the same n on every rank) into the array of the same name in `gathered`
+ * (world_size * n_scenarios rows, rank order).  rps_buckets / hist_bins give the row lengths; series
+ * arrays have af_series_count(plan) columns.  DEVICE memory owned by the caller; synchronous. */
+int af_engine_gather(af_engine_t* engine, void* rccl_comm, int world_size, const af_summary_t* local,
+                     const af_summary_t* gathered);
 
 /* Replaces: _start_* + env.run(until=T) (simulation_runner.py:301-369) for
  * sweep->n_scenarios independent scenarios. */
