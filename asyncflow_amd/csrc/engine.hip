@@ -357,18 +357,23 @@ __device__ __forceinline__ double ovr_or(const KArgs& a, uint32_t param, uint32_
 
 // Stream 0: the windowed arrival sampler (af::gen_next_gap is its sequential statement: samplers/
 // poisson_poisson.py:51-82, gaussian_poisson.py:63-94) and the absolute arrival times
-// t_k = t_{k-1} + gap_k (env.now + gap, rqs_generator.py:104).  One WAVE per scenario: the expensive
-// part of a gap (Philox block, log, division) is evaluated for 64 consecutive draw indices at once
-// -- a draw is a pure function of its index -- and the cheap, order-dependent part (the running
-// sums, the window / horizon tests) is scanned in draw order, with the same f64 additions in the
-// same order as the sequential sampler.  A gap that crosses the window end discards the rest of the
-// batch (the next index is the new window's user draw).
-// Block j pre-generates for scenario scen_map[j] (null = j) into slot j.  `stride` = doubles per slot
-// (n_draw when only the arrivals are wanted: the flow kernel; (1 + n_edges) * n_draw otherwise).
+// t_k = t_{k-1} + gap_k (env.now + gap, rqs_generator.py:104).
+//
+// FOUR scenarios per wave, 16 lanes each.  The expensive part of a gap (Philox block, log, division) is
+// evaluated for 16 consecutive draw indices of each scenario at once -- a draw is a pure function of its
+// index.  The order-dependent part is two running f64 sums (the sampler's virtual clock and the
+// simulation clock): lane l of a group adds the gaps 0..l of the batch to the group's sums ONE BY ONE, in
+// draw order -- the sequential sampler's own additions, so every prefix is bit-identical to it -- while the
+// 16 steps serve the four scenarios of the wave together.  The window / horizon tests are then evaluated
+// on all prefixes at once; the first draw that crosses the window end (discarded, on to the next window:
+// the next index is the new window's user draw) or the horizon ends the batch.
+// Block b pre-generates for scenarios scen_map[4 b + g] (null = 4 b + g) into slots 4 b + g.  `stride` =
+// doubles per slot (n_draw when only the arrivals are wanted: the flow kernel; (1 + n_edges) * n_draw otherwise).
 __global__ void __launch_bounds__(64) af_pregen_arrivals(const KArgs a, uint32_t stride) {
-    const uint32_t slot = blockIdx.x;
-    const uint32_t scen = a.scen_map ? a.scen_map[slot] : slot;
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x, l = lane & 15u, gbase = lane & ~15u;
+    const uint32_t slot = blockIdx.x * 4u + (lane >> 4);
+    const bool valid = slot < a.n_scen;
+    const uint32_t scen = valid ? (a.scen_map ? a.scen_map[slot] : slot) : 0u;
     const uint64_t seed = a.seeds[scen];
     const double users_mean = ovr_or(a, af::PARAM_GEN_USERS_MEAN, 0u, scen, a.gen_users_mean);
     const double users_sigma = ovr_or(a, af::PARAM_GEN_USERS_SIGMA, 0u, scen, a.gen_users_sigma);
@@ -376,11 +381,12 @@ __global__ void __launch_bounds__(64) af_pregen_arrivals(const KArgs a, uint32_t
     const double rps_per_user = rpm / 60.0;
     const double T = a.total_time;
     double* out = a.draws + (size_t)slot * stride;  // stream 0 of this slot
-    double g_now = 0.0, g_wend = 0.0, lam = 0.0, t = 0.0;  // identical in every lane
+    double g_now = 0.0, g_wend = 0.0, lam = 0.0, t = 0.0;  // identical in the 16 lanes of a group
     uint32_t draws = 0u, k = 0u, flags = 0u;
-    bool done = false;
-    while (!done && g_now < T) {
-        if (g_now >= g_wend) {  // new window: the number of active users
+    bool run = valid;
+    while (__any(run)) {
+        run = run && g_now < T;
+        if (run && g_now >= g_wend) {  // new window: the number of active users
             g_wend = g_now + a.gen_window_s;
             const uint32_t idx = draws++;
             double users;
@@ -392,50 +398,61 @@ __global__ void __launch_bounds__(64) af_pregen_arrivals(const KArgs a, uint32_t
             }
             lam = users * rps_per_user;
         }
-        if (lam <= 0.0) {
-            g_now = g_wend;
-            continue;
-        }
-        const af::U4 r = af::draw_block(seed, af::STREAM_GENERATOR, draws + lane, 0u);
+        const bool idle = run && lam <= 0.0;   // nobody active in this window
+        if (idle) g_now = g_wend;
+        const bool draw = run && !idle;
+        // 16 gaps of this scenario (lanes of scenarios that do not draw compute a harmless dummy)
+        const af::U4 r = af::draw_block(seed, af::STREAM_GENERATOR, draws + l, 0u);
         double u = af::u53(r.x, r.y);
         if (u < 1e-15) u = 1e-15;
-        const double dt = -af::af_log(1.0 - u) / lam;
-        double my_t = 0.0;
-        uint32_t my_k = 0xFFFFFFFFu, used = 0u;
-        const uint64_t dt_bits = af::d2u(dt);
-#pragma unroll 8
-        for (uint32_t j = 0u; j < 64u; ++j) {
-            // lane j's gap, broadcast through scalar registers (no LDS round trip in the dependent chain)
-            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)dt_bits, (int)j);
-            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(dt_bits >> 32), (int)j);
-            const double dj = af::u2d(((uint64_t)hi << 32) | lo);
-            used = j + 1u;
-            if (g_now + dj > T) {  // the sampler is exhausted
-                done = true;
-                break;
+        const double dt = -af::af_log(1.0 - u) / (draw ? lam : 1.0);
+        // prefixes in draw order: G = sampler clock after gap l, S = simulation clock after gap l
+        double G = g_now, S = t;
+#pragma unroll
+        for (uint32_t j = 0u; j < 16u; ++j) {
+            const double dj = __shfl(dt, (int)(gbase + j), 64);
+            if (l >= j) {
+                G += dj;
+                S = S + dj;
             }
-            if (g_now + dj >= g_wend) {  // crosses the window end: discarded, on to the next window
-                g_now = g_wend;
-                break;
-            }
-            g_now += dj;
-            if (k == a.n_draw) {  // one more arrival than the array holds
-                flags = AF_FLAG_DRAW_OVERFLOW;
-                done = true;
-                break;
-            }
-            t = t + dj;
-            if (lane == j) {
-                my_t = t;
-                my_k = k;
-            }
-            k += 1u;
         }
-        if (my_k != 0xFFFFFFFFu) out[my_k] = my_t;  // one coalesced store of the batch's arrivals
-        draws += used;
+        const bool over = G > T;                 // the sampler is exhausted at this draw
+        const bool cross = !over && G >= g_wend; // this draw crosses the window end: discarded
+        const uint64_t stops = __ballot(draw && (over || cross));
+        const uint32_t mine = (uint32_t)(stops >> gbase) & 0xFFFFu;
+        const uint32_t first = mine ? (uint32_t)__builtin_ctz(mine) : 16u;   // draws before it are arrivals
+        uint32_t n_acc = first;
+        bool full = false;
+        if (draw && k + n_acc > a.n_draw) {  // more arrivals than the array holds
+            n_acc = a.n_draw - k;
+            full = true;
+        }
+        if (draw && l < n_acc) out[k + l] = S;
+        // the group's state after the batch
+        const double G15 = __shfl(G, (int)(gbase + 15u), 64), S15 = __shfl(S, (int)(gbase + 15u), 64);
+        const double Sprev = __shfl(S, (int)(gbase + (first > 0u ? first - 1u : 0u)), 64);
+        const bool over_first = ((__ballot(over) >> gbase) >> (first & 15u)) & 1ull;
+        if (draw) {
+            k += n_acc;
+            if (full) {
+                flags = AF_FLAG_DRAW_OVERFLOW;
+                run = false;
+            } else if (first == 16u) {
+                g_now = G15;
+                t = S15;
+                draws += 16u;
+            } else {
+                if (first > 0u) t = Sprev;
+                draws += first + 1u;
+                if (over_first) run = false;
+                else g_now = g_wend;
+            }
+        }
     }
-    for (uint32_t i = k + lane; i < a.n_draw; i += 64u) out[i] = af::AF_INF;
-    if (lane == 0u) a.pre_flags[slot] = flags;
+    if (valid) {
+        for (uint32_t i = k + l; i < a.n_draw; i += 16u) out[i] = af::AF_INF;
+        if (l == 0u) a.pre_flags[slot] = flags;
+    }
 }
 
 // second pass: the online counters of the scenarios that start over are cleared first
@@ -1025,7 +1042,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
         uint32_t rows = e->flow_ring_rows;
         const uint32_t pitch = a.series_pitch;
         if (out->samples == nullptr) {
-            rows = 64u;   // unused
+            rows = 0u;    // no series: neither ring nor rows are touched
         } else if (rows == AF_FLOW_RING_IN_HBM) {
             rows = 0u;
         } else if (rows == 0u) {
@@ -1119,7 +1136,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
             }
             a.n_scen = cnt;
             HIP_TRY(hipEventRecord(e->ev2, e->stream));
-            hipLaunchKernelGGL(af_pregen_arrivals, dim3(cnt), dim3(64), 0, e->stream, a, (uint32_t)((1u + a.n_edges) * n_draw));
+            hipLaunchKernelGGL(af_pregen_arrivals, dim3((cnt + 3u) / 4u), dim3(64), 0, e->stream, a, (uint32_t)((1u + a.n_edges) * n_draw));
             hipLaunchKernelGGL(af_pregen_edges, dim3((n_draw + 255u) / 256u, cnt, a.n_edges), dim3(256), 0, e->stream, a);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(e->ev3, e->stream));
@@ -1130,7 +1147,9 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
             // First pass: the lean kernel.  A scenario in which two timed events share an instant stops
             // there and is simulated again, from its start, by the kernel that has SimPy's event-by-event
             // path; engines whose plan keeps producing such scenarios go straight to that kernel.
-            const bool faithful_first = e->shared_instants_likely;
+            // (a handful of scenarios handed back by the stage-parallel kernel -- usually for a tie -- go straight to the
+            // SimPy-order kernel: a second pass over them would cost a whole latency-bound launch more)
+            const bool faithful_first = e->shared_instants_likely || (h_map != nullptr && (uint64_t)count * 50u < chunk_args.n_scen);
             HIP_TRY(hipMemsetAsync(e->d_n_shared, 0, 4, e->stream));
             if (int rc = launch_des(cnt, faithful_first)) return rc;
             if (!faithful_first) {
@@ -1210,7 +1229,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
         a.draws = e->d_arr;
         a.pre_flags = e->d_arr_flags;
         HIP_TRY(hipEventRecord(e->ev2, e->stream));
-        hipLaunchKernelGGL(af_pregen_arrivals, dim3(nc), dim3(64), 0, e->stream, a, n_draw);
+        hipLaunchKernelGGL(af_pregen_arrivals, dim3((nc + 3u) / 4u), dim3(64), 0, e->stream, a, n_draw);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(e->ev3, e->stream));
         aff::FlowArgs f = e->fargs;

@@ -293,7 +293,10 @@ class RankSweep:
         self.ticks = max(plan.tick_count, 1)
         self.T = int(plan.total_time)
         # slices: outputs of one slice must fit the HBM budget (clock + samples; the engine's own buffers on top)
-        per_scen = self.clock_cap * 16 + (0 if args.no_series else self.ticks * plan.series_pitch * 4)
+        self.online = bool(args.online_summary)
+        if self.online:
+            args.no_series = True
+        per_scen = (0 if self.online else self.clock_cap * 16) + (0 if args.no_series else self.ticks * plan.series_pitch * 4) + 8192
         budget = int(args.hbm_budget_gb * (1 << 30))
         self.slice = max(1, min(n, budget // max(per_scen, 1), 65535 if n > 65535 else n))
         self.n_slices = (n + self.slice - 1) // self.slice
@@ -306,13 +309,15 @@ class RankSweep:
         self.flow_reason = self.eng.flow_reason()
         m = self.slice
         self.counts = torch.zeros((n, _abi.CNT_SLOTS), dtype=torch.int32, device=dev)
-        self.clock = torch.empty((m, self.clock_cap, 2), dtype=torch.float64, device=dev)
+        self.clock = None if self.online else torch.empty((m, self.clock_cap, 2), dtype=torch.float64, device=dev)
+        self.o_hist = torch.zeros((m, 1024), dtype=torch.int32, device=dev) if self.online else None
+        self.o_rps = torch.zeros((m, max(self.T, 1)), dtype=torch.int32, device=dev) if self.online else None
         self.samples = None if args.no_series else torch.zeros((m, self.ticks, plan.series_pitch), dtype=torch.int32, device=dev)
         # per-scenario summaries (the analyzer step of the path), kept for the whole rank
-        self.s_stats = torch.empty((n, 8), dtype=torch.float64, device=dev)
-        self.s_rps = torch.empty((n, self.T), dtype=torch.float32, device=dev)
+        self.s_stats = torch.full((n, 8), float("nan"), dtype=torch.float64, device=dev)
+        self.s_rps = torch.zeros((n, self.T), dtype=torch.float32, device=dev)
         self.hist_max = {1: 1.024, 2: 0.256, 3: 2.56, 4: 2.56, 5: 25.6}[args.config]
-        self.s_hist = torch.empty((n, 256), dtype=torch.int32, device=dev)
+        self.s_hist = torch.zeros((n, 256), dtype=torch.int32, device=dev)
         self.s_mean = None if self.samples is None else torch.empty((n, plan.n_series), dtype=torch.float64, device=dev)
         self.s_max = None if self.samples is None else torch.empty((n, plan.n_series), dtype=torch.int32, device=dev)
         self.specialise = not args.generic_kernels
@@ -320,9 +325,12 @@ class RankSweep:
     def _slice_args(self, lo: int, hi: int) -> tuple[np.ndarray, list, dict]:
         seeds = self.seeds[lo:hi]
         over = [(c, i, np.ascontiguousarray(v[lo:hi])) for c, i, v, _ in self.over]
-        kw = dict(clock_ptr=self.clock.data_ptr(), clock_capacity=self.clock_cap,
+        kw = dict(clock_ptr=self.clock.data_ptr() if self.clock is not None else 0, clock_capacity=self.clock_cap,
                   samples_ptr=self.samples.data_ptr() if self.samples is not None else 0, tick_capacity=self.ticks,
                   counts_ptr=self.counts[lo:hi].data_ptr(), draw_capacity=self.clock_cap)
+        if self.online:
+            kw.update(online_hist_ptr=self.o_hist.data_ptr(), online_hist_bins=1024, online_hist_max=self.hist_max,
+                      online_rps_ptr=self.o_rps.data_ptr(), online_rps_buckets=self.T)
         return seeds, over, kw
 
     def prepare(self) -> None:
@@ -337,6 +345,9 @@ class RankSweep:
         for lo in range(0, self.n, self.slice):
             hi = min(self.n, lo + self.slice)
             seeds, over, kw = self._slice_args(lo, hi)
+            if self.online:
+                self.o_hist.zero_()
+                self.o_rps.zero_()
             st = self.eng.run(seeds, over, specialise=self.specialise, **kw)
             acc["kernel_ms"] += float(st.kernel_ms)
             acc["pregen_ms"] += float(st.pregen_ms)
@@ -352,6 +363,9 @@ class RankSweep:
                               "lds_bytes_per_wave": int(st.lds_bytes_per_wave), "lanes_per_wave": int(st.lanes_per_wave),
                               "waves": int(st.waves), "request_capacity": int(st.request_capacity),
                               "state_bytes_per_scenario": int(st.state_bytes_per_scenario), "draw_bytes": int(st.draw_bytes)}
+            if self.online:      # the kernel-side summary IS the analyzer step of this mode
+                self.last_stats = st
+                continue
             st = self.eng.summarize(hi - lo, clock_ptr=self.clock.data_ptr(), clock_capacity=self.clock_cap,
                                     samples_ptr=self.samples.data_ptr() if self.samples is not None else 0,
                                     tick_capacity=self.ticks, counts_ptr=self.counts[lo:hi].data_ptr(),
@@ -439,6 +453,10 @@ def main() -> int:  # noqa: C901, PLR0912, PLR0915
                     help="do not build plan-specialised kernels (asyncflow_amd/jit.py); use the library's generic ones")
     ap.add_argument("--expect-shared-instants", action="store_true",
                     help="start with the kernel variant that has the SimPy-order path for shared instants")
+    ap.add_argument("--online-summary", action="store_true",
+                    help="DIAGNOSTIC mode: no per-request clock and no sampled series; the kernel keeps a 1024-bin latency "
+                         "histogram and the 1-s completion counts per scenario (19 KB instead of 1.9 MB per LB-2 scenario), "
+                         "so that sweeps far beyond the BASELINE sizes fit (e.g. --scenarios 131072)")
     ap.add_argument("--no-flow", action="store_true", help="next-event kernels only (no stage-parallel kernel)")
     ap.add_argument("--flow-list-entries", type=int, default=0, choices=[0, 64, 128, 256])
     ap.add_argument("--flow-ring-rows", type=int, default=0, help="rows of the LDS tick ring (0 = auto, -1 = keep the differences in HBM)")
@@ -586,7 +604,9 @@ def main() -> int:  # noqa: C901, PLR0912, PLR0915
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": wl["label"] + ", full outputs" + (" without sampled series" if args.no_series else ""),
+                "workload": wl["label"] + (", DIAGNOSTIC: kernel-side summary only (no rqs_clock, no sampled series)" if sw.online
+                                           else ", full outputs" + (" without sampled series" if args.no_series else "")),
+                "diagnostic": bool(sw.online),
                 "baseline_config": args.config,
                 "scenarios_rank0": n,
                 "scenarios_total": n_total,
@@ -620,9 +640,9 @@ def main() -> int:  # noqa: C901, PLR0912, PLR0915
             },
             "gather_ms": gather_ms,
             "gather_path": gather_path,
-            "p95_ms_mean": float(np.nanmean(sa[:, 4]) * 1e3),
-            "p95_ms_pooled_hist": pooled_p95_ms,
-            "p50_ms_mean": float(np.nanmean(sa[:, 2]) * 1e3),
+            "p95_ms_mean": None if sw.online else float(np.nanmean(sa[:, 4]) * 1e3),
+            "p95_ms_pooled_hist": None if sw.online else pooled_p95_ms,
+            "p50_ms_mean": None if sw.online else float(np.nanmean(sa[:, 2]) * 1e3),
             "roofline": {
                 "bound": "hbm",
                 "achieved": achieved,

@@ -7,7 +7,7 @@ tag,path=sys.argv[1],sys.argv[2]
 l=[x for x in open(path) if x.startswith("{")]
 if l:
     d=json.loads(l[-1]); f=d["config"]["flow"]
-    print("%-40s value %.3e ms/step %.1f flow_ms %.1f pregen %.1f summary %.1f list %d ring %d lds %d fb %s frac %.3f" % (tag, d["value"], d["ms_per_step"], d["flow_kernel_ms"], d["pregen_ms"], d["summary_ms"], f["list_entries"], f["ring_rows"], f["lds_bytes_per_wave"], f["handed_back"]["total"], d["roofline"]["frac"]))
+    print("%-40s value %.3e ms/step %.1f flow_ms %.1f pregen %.1f summary %.1f list %d ring %d lds %d fb %s frac %.3f" % (tag, d["value"], d["ms_per_step"], d["flow_kernel_ms"], d["pregen_ms"], d["summary_ms"], f["list_entries"], f["ring_rows"], f["lds_bytes_per_wave"], str(f["handed_back"]), d["roofline"]["frac"]))
 else: print(tag, "FAILED"); print(open(path).read()[-1500:])
 PY
 }
