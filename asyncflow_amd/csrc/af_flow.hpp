@@ -148,8 +148,16 @@ struct FlowArgs {
 //   W::mbcnt(mask)                  popcount(mask & lanes below me)
 // Every W:: call is made by all 64 lanes from wave-uniform control flow.
 // IPL = list entries per lane (list capacity = 64 * IPL).
-template <class W, uint32_t IPL = 1u>
+// FEAT = features compiled in (the host picks the leanest instantiation that covers the launch: every
+// feature costs wave-uniform registers, and the kernel is short of them -- DESIGN.md section 4e):
+//   FEAT_MARKS     injected spikes / outages (the plan has timeline marks)
+//   FEAT_ONLINE    kernel-side latency histogram / completion counts (af_outputs_t.online_*)
+//   FEAT_HBM_RING  tick differences kept in the sample rows in HBM (layout.ring_rows == 0 with series stored)
+enum : uint32_t { FEAT_MARKS = 1u, FEAT_ONLINE = 2u, FEAT_HBM_RING = 4u, FEAT_ALL = 7u };
+template <class W, uint32_t IPL = 1u, uint32_t FEAT = FEAT_ALL>
 struct Flow {
+    static constexpr bool kMarks = (FEAT & FEAT_MARKS) != 0u, kOnline = (FEAT & FEAT_ONLINE) != 0u,
+                          kHbmRing = (FEAT & FEAT_HBM_RING) != 0u;
     const FlowArgs& A;
     AF_PLAN_AS uint64_t* blob;   // plan blob (LDS copy, patched)
     AF_PLAN_AS uint64_t* M;      // layout words behind it
@@ -255,7 +263,7 @@ struct Flow {
         const uint32_t ia = tick_index(a, true), ib = tick_index(b, true);
         if (ia == ib) return;
         const uint32_t R = A.L.ring_rows, N = A.n_ticks < A.tick_cap ? A.n_ticks : A.tick_cap;
-        if (R == 0u) {
+        if (kHbmRing && R == 0u) {
             if (ia < N) W::global_add(samples + (size_t)ia * A.L.pitch + series, (uint32_t)w);
             if (ib < N) W::global_add(samples + (size_t)ib * A.L.pitch + series, (uint32_t)(-w));
             return;
@@ -282,7 +290,7 @@ struct Flow {
             const uint32_t stop = upto < A.tick_cap ? upto : A.tick_cap;
             for (uint32_t r = tick_base; r < stop; ++r) {
                 if (lane < pitch) {
-                    if (R == 0u) {
+                    if (kHbmRing && R == 0u) {
                         run_val += (int32_t)W::global_load(samples + (size_t)r * pitch + lane);
                     } else {
                         AF_PLAN_AS int32_t* cell = ring() + (r & (R - 1u)) * pitch + lane;
@@ -331,7 +339,7 @@ struct Flow {
         }
         const double u1 = af::u53(rr.z, rr.w);
         const double transit = dist == af::DIST_EXPONENTIAL ? -(mean * af::af_log(1.0 - u1)) : cold_variate(dist, mean, sigma, u1, seed, stream, idx);
-        const double spike = A.n_edge_marks != 0u ? spike_at(e, now) : 0.0;
+        const double spike = (kMarks && A.n_edge_marks != 0u) ? spike_at(e, now) : 0.0;
         key = now + (transit + spike);
         if (!(key > now)) why |= FLOW_WHY_TIE;     // a zero (or negative) delay: SimPy orders it among the zero-time steps
         add_interval(e, now, key, 1);
@@ -492,7 +500,7 @@ struct Flow {
         uint32_t pick = 0u;
         const uint32_t mi = lw[18];
         const double t_last = bcast_f64(my_key, n_sel - 1u);
-        const bool marks_inside = mi < A.n_srv_marks && u2d(smark(mi)[0]) <= t_last;
+        const bool marks_inside = kMarks && mi < A.n_srv_marks && u2d(smark(mi)[0]) <= t_last;
         if (!marks_inside) {
             const uint32_t head = lw[16], nl = lw[17];
             if (lane < n_sel) pick = lw[(head + lane) % nl];
@@ -662,11 +670,11 @@ struct Flow {
                 clock[2u * (size_t)at + 1u] = now;
             }
         }
-        if (o_hist != nullptr) {
+        if (kOnline && o_hist != nullptr) {
             const double bf = (now - t0) * A.online_hist_scale;
             AF_BUMP(o_hist + (bf >= (double)(A.online_hist_bins - 1u) ? A.online_hist_bins - 1u : (uint32_t)bf));
         }
-        if (o_rps != nullptr) {
+        if (kOnline && o_rps != nullptr) {
             const double kf = __builtin_ceil(now);
             const uint32_t k = kf < 1.0 ? 1u : (uint32_t)kf;
             if (k <= A.online_rps_buckets) AF_BUMP(o_rps + (k - 1u));
@@ -683,8 +691,8 @@ struct Flow {
         arr = A.arrivals + (size_t)sc * A.n_draw;
         clock = A.clock ? A.clock + (size_t)sc * A.clock_cap * 2u : nullptr;
         samples = A.samples ? A.samples + (size_t)sc * A.L.pitch * A.tick_cap : nullptr;
-        o_hist = A.online_hist ? A.online_hist + (size_t)sc * A.online_hist_bins : nullptr;
-        o_rps = A.online_rps ? A.online_rps + (size_t)sc * A.online_rps_buckets : nullptr;
+        o_hist = (kOnline && A.online_hist) ? A.online_hist + (size_t)sc * A.online_hist_bins : nullptr;
+        o_rps = (kOnline && A.online_rps) ? A.online_rps + (size_t)sc * A.online_rps_buckets : nullptr;
         const double T = A.total_time;
 
         // plan blob -> LDS, layout words zeroed
@@ -693,7 +701,7 @@ struct Flow {
             for (uint32_t i = lane; i < A.blob_bytes / 8u; i += 64u) blob[i] = g[i];
             for (uint32_t i = lane; i < A.L.n_words; i += 64u) M[i] = 0ull;
         }
-        if (samples != nullptr && A.L.ring_rows == 0u) {   // tick differences accumulate in the sample rows themselves
+        if (kHbmRing && samples != nullptr && A.L.ring_rows == 0u) {   // tick differences accumulate in the sample rows themselves
             const uint32_t rows = A.n_ticks < A.tick_cap ? A.n_ticks : A.tick_cap;
             const size_t words = (size_t)rows * A.L.pitch;
             for (size_t i = (size_t)lane * 4u; i < words; i += 256u) af::store4(samples + i, 0u, 0u, 0u, 0u);
@@ -755,7 +763,7 @@ struct Flow {
                     const uint32_t i = cursor + lane;
                     t0 = (lane < room && i < A.n_draw) ? arr[i] : AF_INF;
                     // with an LDS tick ring a round must not run further ahead of the completed ticks than the ring holds
-                    const double t_cap = (samples != nullptr && A.L.ring_rows != 0u)
+                    const double t_cap = (samples != nullptr && (!kHbmRing || A.L.ring_rows != 0u))
                                              ? (double)(tick_base + A.L.ring_rows / 2u) * A.sample_period : AF_INF;
                     const uint64_t vm = W::ballot(t0 < T && t0 < t_cap);   // arrival times increase: a prefix of the lanes
                     n_sel = popc64(vm);

@@ -306,12 +306,12 @@ struct WaveHip {
 #ifndef AF_FLOW_WPE
 #define AF_FLOW_WPE 4
 #endif
-template <uint32_t IPL>
+template <uint32_t IPL, uint32_t FEAT>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AF_FLOW_WPE))) af_flow_kernel(const aff::FlowArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t sc = blockIdx.x;
     if (sc >= a.n_scen) return;
-    aff::Flow<WaveHip, IPL> f(a);
+    aff::Flow<WaveHip, IPL, FEAT> f(a);
     f.run((LDS_AS uint64_t*)smem, sc);
     if (threadIdx.x == 0u && a.n_fallback) {
         const uint32_t flags = a.counts[(size_t)sc * af::CNT_SLOTS + af::CNT_FLAGS];
@@ -981,6 +981,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     double ms_pregen = 0.0, ms_kernel = 0.0, ms_flow = 0.0;
     uint32_t kl = 0, waves = 0, lds_bytes = 0, n_chunks = 0, n_rerun = 0, n_jit = 0, n_jit_miss = 0;
     uint32_t fb_total[5] = {0, 0, 0, 0, 0}, flow_scen = 0, flow_lds = 0;
+    bool flow_lean = false;
     size_t draw_bytes = 0;
     bool lds_state = false;
     aff::FlowLayout FL{};
@@ -1257,14 +1258,20 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
         f.n_fallback = e->d_fb;
         HIP_TRY(hipMemsetAsync(e->d_fb, 0, 5u * 4u, e->stream));
         {
-            const void* fn = FL.cap == 64u    ? reinterpret_cast<const void*>(af_flow_kernel<1>)
-                             : FL.cap == 128u ? reinterpret_cast<const void*>(af_flow_kernel<2>)
-                                              : reinterpret_cast<const void*>(af_flow_kernel<4>);
+            // the leanest instantiation that covers this launch (a compiled-in feature costs wave-uniform registers)
+            const bool lean = a.n_edge_marks == 0u && a.n_srv_marks == 0u && !f.online_hist && !f.online_rps &&
+                              (FL.ring_rows != 0u || f.samples == nullptr);
+            flow_lean = lean;
+            const void* fn = FL.cap == 64u    ? (lean ? reinterpret_cast<const void*>(af_flow_kernel<1, 0u>)
+                                                      : reinterpret_cast<const void*>(af_flow_kernel<1, aff::FEAT_ALL>))
+                             : FL.cap == 128u ? (lean ? reinterpret_cast<const void*>(af_flow_kernel<2, 0u>)
+                                                      : reinterpret_cast<const void*>(af_flow_kernel<2, aff::FEAT_ALL>))
+                                              : reinterpret_cast<const void*>(af_flow_kernel<4, aff::FEAT_ALL>);
             if (flow_lds > 48u * 1024u) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flow_lds));
             void* kargs[] = {&f};
             if (std::getenv("AF_DEBUG"))
-                std::fprintf(stderr, "[af] flow launch: %u scenarios, %u list entries, %u ring rows, %u B LDS per wave\n", nc, FL.cap,
-                             FL.ring_rows, flow_lds);
+                std::fprintf(stderr, "[af] flow launch: %u scenarios, %u list entries, %u ring rows, %u B LDS per wave%s\n", nc, FL.cap,
+                             FL.ring_rows, flow_lds, flow_lean ? ", lean instantiation" : "");
             HIP_TRY(hipLaunchKernel(fn, dim3(nc), dim3(kWave), kargs, flow_lds, e->stream));
         }
         HIP_TRY(hipEventRecord(e->ev4, e->stream));
@@ -1302,6 +1309,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     e->stats.flow_list_entries = use_flow ? FL.cap : 0u;
     e->stats.flow_ring_rows = use_flow ? FL.ring_rows : 0u;
     e->stats.flow_lds_bytes = flow_lds;
+    (void)flow_lean;
     e->stats.jit_fallbacks = n_jit_miss;
     e->stats.pregen_ms = ms_pregen;
     e->stats.h2d_ms = ms_h2d;

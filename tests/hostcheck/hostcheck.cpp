@@ -232,8 +232,12 @@ extern "C" int hc_flow_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ov
     a.n_fallback = nullptr;
 
     std::vector<uint64_t> lds(pk.words.size() + a.L.n_words + 2u, 0xDEADBEEFDEADBEEFull);
+    // the instantiation the engine would launch: the lean one when the launch needs none of the optional features
+    const bool lean = p->n_edge_marks == 0 && p->n_srv_marks == 0 && !g_online_hist && !g_online_rps && (a.L.ring_rows != 0 || !samples);
     auto body = [&]() {
-        if (ipl == 1) { aff::Flow<emu::WaveEmu, 1> f(a); f.run(lds.data(), 0u); }
+        if (ipl == 1 && lean) { aff::Flow<emu::WaveEmu, 1, 0u> f(a); f.run(lds.data(), 0u); }
+        else if (ipl == 1) { aff::Flow<emu::WaveEmu, 1> f(a); f.run(lds.data(), 0u); }
+        else if (ipl == 2 && lean) { aff::Flow<emu::WaveEmu, 2, 0u> f(a); f.run(lds.data(), 0u); }
         else if (ipl == 2) { aff::Flow<emu::WaveEmu, 2> f(a); f.run(lds.data(), 0u); }
         else { aff::Flow<emu::WaveEmu, 4> f(a); f.run(lds.data(), 0u); }
     };
