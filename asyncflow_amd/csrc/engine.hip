@@ -173,11 +173,10 @@ __device__ __forceinline__ void des_body(const KArgs& a_in) {
     a.off_lb = AF_JIT_OFF_LB;
     a.blob_bytes = AF_JIT_BLOB_BYTES;
     a.L = af::make_layout(AF_JIT_CAP, AF_JIT_FCAP, AF_JIT_N_EDGES, AF_JIT_N_SERVERS, AF_JIT_N_LB, AF_JIT_N_ROWS, AF_JIT_OVR_MASK);
-    a.clock_cap = AF_JIT_CLOCK_CAP;
-    a.tick_cap = AF_JIT_TICK_CAP;
+    // (clock / tick / draw capacities stay run-time values: they change with replicas, horizon and the runner's
+    // auto-grow, and a key that contains them recompiles -- or silently misses -- for every such change)
     a.n_series = AF_JIT_N_EDGES + 3 * AF_JIT_N_SERVERS;
     a.series_pitch = (AF_JIT_N_EDGES + 3 * AF_JIT_N_SERVERS + 3) & ~3;
-    a.n_draw = AF_JIT_N_DRAW;
     if (AF_JIT_HAS_CLOCK) __builtin_assume(a.clock != nullptr); else a.clock = nullptr;
     if (AF_JIT_HAS_SAMPLES) __builtin_assume(a.samples != nullptr); else a.samples = nullptr;
     if (!AF_JIT_HAS_ONLINE) a.online_hist = a.online_rps = nullptr;
@@ -684,12 +683,12 @@ std::string jit_spec_string(const KArgs& a, bool lds_state, uint32_t klog) {
                   "-DAF_JIT_N_EDGES=%u -DAF_JIT_N_SERVERS=%u -DAF_JIT_LB_ALGO=%u -DAF_JIT_N_LB=%u -DAF_JIT_N_ROWS=%u "
                   "-DAF_JIT_N_EMARKS=%u -DAF_JIT_N_SMARKS=%u -DAF_JIT_ORDER_ALL=%u -DAF_JIT_OFF_EDGE=%u -DAF_JIT_OFF_SRV=%u "
                   "-DAF_JIT_OFF_EP=%u -DAF_JIT_OFF_ROW=%u -DAF_JIT_OFF_EMARK=%u -DAF_JIT_OFF_SMARK=%u -DAF_JIT_OFF_LB=%u "
-                  "-DAF_JIT_BLOB_BYTES=%u -DAF_JIT_CAP=%u -DAF_JIT_FCAP=%u -DAF_JIT_OVR_MASK=%u -DAF_JIT_CLOCK_CAP=%u "
-                  "-DAF_JIT_TICK_CAP=%u -DAF_JIT_N_DRAW=%u -DAF_JIT_HAS_CLOCK=%d -DAF_JIT_HAS_SAMPLES=%d -DAF_JIT_HAS_ONLINE=%d",
+                  "-DAF_JIT_BLOB_BYTES=%u -DAF_JIT_CAP=%u -DAF_JIT_FCAP=%u -DAF_JIT_OVR_MASK=%u "
+                  "-DAF_JIT_HAS_CLOCK=%d -DAF_JIT_HAS_SAMPLES=%d -DAF_JIT_HAS_ONLINE=%d",
                   lds_state ? 1 : 0, klog, a.metrics_mask, a.gen_out_edge, a.client_out_edge, a.n_edges, a.n_servers, a.lb_algo,
                   a.n_lb_edges, a.n_rows, a.n_edge_marks, a.n_srv_marks, a.every_event_in_order, a.off_edge, a.off_srv, a.off_ep,
-                  a.off_row, a.off_emark, a.off_smark, a.off_lb, a.blob_bytes, a.L.cap, a.L.fcap, a.L.ovr_mask, a.clock_cap,
-                  a.tick_cap, a.n_draw, a.clock ? 1 : 0, a.samples ? 1 : 0, (a.online_hist || a.online_rps) ? 1 : 0);
+                  a.off_row, a.off_emark, a.off_smark, a.off_lb, a.blob_bytes, a.L.cap, a.L.fcap, a.L.ovr_mask,
+                  a.clock ? 1 : 0, a.samples ? 1 : 0, (a.online_hist || a.online_rps) ? 1 : 0);
     return buf;
 }
 

@@ -334,7 +334,9 @@ class RankSweep:
         return seeds, over, kw
 
     def prepare(self) -> None:
-        if self.specialise:
+        # plan-specialised builds exist for the next-event kernels only; when the stage-parallel kernel runs the plan
+        # (AOT instantiations in the library) nothing is compiled at run time -- hand-backs use the generic kernels
+        if self.specialise and (self.args.no_flow or self.flow_reason):
             seeds, over, kw = self._slice_args(0, min(self.slice, self.n))
             self.eng.prepare(seeds, over, **kw)     # hipcc run or cache hit: never inside the timed region
 
@@ -348,7 +350,7 @@ class RankSweep:
             if self.online:
                 self.o_hist.zero_()
                 self.o_rps.zero_()
-            st = self.eng.run(seeds, over, specialise=self.specialise, **kw)
+            st = self.eng.run(seeds, over, specialise=self.specialise and bool(self.args.no_flow or self.flow_reason), **kw)
             acc["kernel_ms"] += float(st.kernel_ms)
             acc["pregen_ms"] += float(st.pregen_ms)
             acc["shared"] += int(st.shared_instant_scenarios)

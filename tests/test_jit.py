@@ -12,8 +12,7 @@ LB2_SPEC = (
     "-DAF_JIT_N_EDGES=6 -DAF_JIT_N_SERVERS=2 -DAF_JIT_LB_ALGO=0 -DAF_JIT_N_LB=2 -DAF_JIT_N_ROWS=6 -DAF_JIT_N_EMARKS=0 "
     "-DAF_JIT_N_SMARKS=0 -DAF_JIT_ORDER_ALL=0 -DAF_JIT_OFF_EDGE=0 -DAF_JIT_OFF_SRV=24 -DAF_JIT_OFF_EP=28 -DAF_JIT_OFF_ROW=32 "
     "-DAF_JIT_OFF_EMARK=50 -DAF_JIT_OFF_SMARK=50 -DAF_JIT_OFF_LB=50 -DAF_JIT_BLOB_BYTES=416 -DAF_JIT_CAP=32 -DAF_JIT_FCAP=16 "
-    "-DAF_JIT_OVR_MASK=0 -DAF_JIT_CLOCK_CAP=1000 -DAF_JIT_TICK_CAP=399 -DAF_JIT_N_DRAW=1000 -DAF_JIT_HAS_CLOCK=1 "
-    "-DAF_JIT_HAS_SAMPLES=1 -DAF_JIT_HAS_ONLINE=0"
+    "-DAF_JIT_OVR_MASK=0 -DAF_JIT_HAS_CLOCK=1 -DAF_JIT_HAS_SAMPLES=1 -DAF_JIT_HAS_ONLINE=0"
 )
 
 
