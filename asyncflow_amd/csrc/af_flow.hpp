@@ -65,6 +65,8 @@ constexpr uint32_t kWave = 64;
 struct FlowLayout {
     uint32_t cap;        // capacity of every station list (multiple of 64)
     uint32_t ring_rows;  // rows of the tick-difference ring (power of two)
+    uint32_t win_rows;   // how many ticks past the completed ones the generator may run (the rest of the ring is for
+                         // intervals that end later: the in-flight time of the slowest message)
     uint32_t g_ring;     // per-server ring of departure times (power of two >= RAM slots looked back)
     uint32_t c_ring;     // per-server ring of core-release times (>= max cpu_cores)
     uint32_t pitch;      // 4-byte words per tick row (n_series rounded up to 4)
@@ -77,6 +79,7 @@ inline FlowLayout make_flow_layout(uint32_t cap, uint32_t ring_rows, uint32_t g_
     FlowLayout L{};
     L.cap = cap;
     L.ring_rows = ring_rows;
+    L.win_rows = ring_rows / 2u;
     L.g_ring = g_ring;
     L.c_ring = c_ring;
     L.pitch = (n_edges + 3u * n_servers + 3u) & ~3u;
@@ -764,7 +767,7 @@ struct Flow {
                     t0 = (lane < room && i < A.n_draw) ? arr[i] : AF_INF;
                     // with an LDS tick ring a round must not run further ahead of the completed ticks than the ring holds
                     const double t_cap = (samples != nullptr && (!kHbmRing || A.L.ring_rows != 0u))
-                                             ? (double)(tick_base + A.L.ring_rows / 2u) * A.sample_period : AF_INF;
+                                             ? (double)(tick_base + A.L.win_rows) * A.sample_period : AF_INF;
                     const uint64_t vm = W::ballot(t0 < T && t0 < t_cap);   // arrival times increase: a prefix of the lanes
                     n_sel = popc64(vm);
                     key = t0;

@@ -1008,57 +1008,92 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
                 default: return m;
             }
         };
-        auto lat_hi = [&](int32_t ed) {   // a transit time one message in ~1e7 exceeds
+        auto lat_sd = [&](int32_t ed) {
             const double m = emean[ed], sg = e->edge_sigma[ed];
             switch (e->edge_dist[ed]) {
-                case AF_DIST_LOG_NORMAL: return std::exp(m + 5.2 * sg < 50.0 ? m + 5.2 * sg : 50.0);
-                case AF_DIST_NORMAL: return (m > 0.0 ? m : 0.0) + 5.2 * sg;
-                case AF_DIST_UNIFORM: return 1.0;
-                default: return 16.0 * m;
+                case AF_DIST_LOG_NORMAL: {
+                    const double v = sg * sg < 50.0 ? sg * sg : 50.0;
+                    return lat_mean(ed) * std::sqrt(std::exp(v) - 1.0);
+                }
+                case AF_DIST_NORMAL: return sg;
+                case AF_DIST_UNIFORM: return 0.29;
+                default: return m;
             }
         };
-        double lb_mean = 0.0, lb_hi = 0.0, so_mean = 0.0, so_hi = 0.0;
-        for (int32_t ed : e->lb_edges) {
-            lb_mean = std::fmax(lb_mean, lat_mean(ed) + e->edge_spike[ed]);
-            lb_hi = std::fmax(lb_hi, lat_hi(ed) + e->edge_spike[ed]);
-        }
-        for (int32_t ed : e->srv_out_edge) {
-            so_mean = std::fmax(so_mean, lat_mean(ed) + e->edge_spike[ed]);
-            so_hi = std::fmax(so_hi, lat_hi(ed) + e->edge_spike[ed]);
-        }
-        const double g_mean = lat_mean(e->gen_edge) + e->edge_spike[e->gen_edge], g_hi = lat_hi(e->gen_edge) + e->edge_spike[e->gen_edge];
-        const double c_mean = lat_mean(e->client_edge) + e->edge_spike[e->client_edge],
-                     c_hi = lat_hi(e->client_edge) + e->edge_spike[e->client_edge];
+        auto lat_q = [&](int32_t ed) {   // a transit time one message in ~1e11 exceeds
+            const double m = emean[ed], sg = e->edge_sigma[ed];
+            switch (e->edge_dist[ed]) {
+                case AF_DIST_LOG_NORMAL: return std::exp(m + 6.7 * sg < 50.0 ? m + 6.7 * sg : 50.0);
+                case AF_DIST_NORMAL: return (m > 0.0 ? m : 0.0) + 6.7 * sg;
+                case AF_DIST_UNIFORM: return 1.0;
+                default: return 25.3 * m;
+            }
+        };
+        // the hops of the request path: generator edge, client edge, the slowest LB edge, the slowest server out-edge
+        std::vector<int32_t> hops = {e->gen_edge, e->client_edge};
+        auto slowest = [&](const std::vector<int32_t>& es) {
+            int32_t best = -1;
+            for (int32_t ed : es)
+                if (best < 0 || lat_mean(ed) + e->edge_spike[ed] > lat_mean(best) + e->edge_spike[best]) best = ed;
+            return best;
+        };
+        if (!e->lb_edges.empty()) hops.push_back(slowest(e->lb_edges));
+        hops.push_back(slowest(e->srv_out_edge));
         // time in a server: service + the M/D/1 wait for a core at the heaviest load of the sweep
         const double n_active = e->has_lb ? (double)(e->lb_edges.size() > 1 && a.n_srv_marks ? e->lb_edges.size() - 1 : e->lb_edges.size()) : 1.0;
         const double rho = rate / n_active * e->cpu_max / (double)e->cores_max;
         const double wait = rho < 0.9 ? rho * e->cpu_max / (2.0 * (1.0 - rho)) : 20.0 * e->cpu_max + 1.0;
         const double in_server = e->service_max + 4.0 * wait;
-        double pend = rate * std::fmax(std::fmax(g_mean, c_mean), std::fmax(lb_mean, so_mean + in_server));
-        pend += 5.0 * std::sqrt(pend + 1.0);
+        // messages pending at a station ~ rate x time in flight towards it (the completion list also holds the server time)
+        double pend = 0.0;
+        for (size_t h = 0; h < hops.size(); ++h) {
+            const double fly = lat_mean(hops[h]) + e->edge_spike[hops[h]] + (h + 1 == hops.size() ? in_server : 0.0);
+            pend = std::fmax(pend, rate * fly);
+        }
+        // A list only has to leave ROOM: 64 - pending new messages fit per round.  Larger lists cost LDS (occupancy) and
+        // ranking work on every round of every scenario (measured on the config-3 grid: 64 entries 122 ms, 128 entries
+        // 144 ms, no hand-backs either way); an overflow costs one scenario a second run.  `pend` is the MEAN at the
+        // heaviest point of the sweep: half a list of pending messages still leaves half a batch of room.
         uint32_t entries = e->flow_list_entries;
-        if (entries == 0u) entries = pend <= 16.0 ? 64u : pend <= 80.0 ? 128u : 256u;
-        const double path_hi = g_hi + c_hi + lb_hi + so_hi + in_server;
-        uint32_t rows = e->flow_ring_rows;
+        if (entries == 0u) entries = pend <= 32.0 ? 64u : pend <= 96.0 ? 128u : 256u;
+        // in-flight time of the slowest message of the sweep (~1e-11 per request): the largest single hop at that
+        // quantile, the other hops at mean + 3 sd, spikes, the server
+        double tail = in_server;
+        {
+            size_t worst = 0;
+            for (size_t h = 1; h < hops.size(); ++h)
+                if (lat_q(hops[h]) > lat_q(hops[worst])) worst = h;
+            for (size_t h = 0; h < hops.size(); ++h)
+                tail += e->edge_spike[hops[h]] + (h == worst ? lat_q(hops[h]) : lat_mean(hops[h]) + 3.0 * lat_sd(hops[h]));
+        }
+        uint32_t rows = e->flow_ring_rows, win_rows = 0u;
         const uint32_t pitch = a.series_pitch;
+        const double tail_rows = std::ceil(tail / a.sample_period) + 2.0;
         if (out->samples == nullptr) {
             rows = 0u;    // no series: neither ring nor rows are touched
         } else if (rows == AF_FLOW_RING_IN_HBM) {
             rows = 0u;
         } else if (rows == 0u) {
-            const double want = 2.0 * std::fmax(path_hi, 96.0 / rate) / a.sample_period + 4.0;
-            rows = want < 16384.0 ? aff::pow2_ge((uint32_t)want < 32u ? 32u : (uint32_t)want) : 0u;
-            if ((size_t)rows * pitch * 4u > 24u * 1024u) {   // does not fit next to the lists: keep the differences in HBM
-                const uint32_t fit = 24u * 1024u / (pitch * 4u);
-                uint32_t p2 = 32u;
-                while (p2 * 2u <= fit) p2 *= 2u;
-                // a ring that covers the slowest message still beats HBM atomics; otherwise HBM
-                rows = (2.0 * path_hi / a.sample_period + 4.0 <= (double)p2) ? p2 : 0u;
+            // the ring covers the generator's window (enough ticks for a full batch of arrivals at the heaviest load,
+            // at least 8) + the tail; 8 KB of LDS keep 16 waves per CU, 24 KB are the limit before HBM takes over
+            const double want_win = std::fmin(std::fmax(std::ceil(96.0 / rate / a.sample_period), 8.0), 4096.0);
+            const uint32_t cap_pref = aff::pow2_ge(8u * 1024u / (pitch * 4u) + 1u) / 2u, cap_max = aff::pow2_ge(24u * 1024u / (pitch * 4u) + 1u) / 2u;
+            if (tail_rows + 8.0 > (double)cap_max) {
+                rows = 0u;   // the slowest message outlives any ring that fits: differences in HBM
+            } else {
+                rows = aff::pow2_ge((uint32_t)(tail_rows + want_win));
+                if (rows > cap_pref) rows = cap_pref >= aff::pow2_ge((uint32_t)(tail_rows + 8.0)) ? cap_pref : aff::pow2_ge((uint32_t)(tail_rows + 8.0));
+                if (rows < 16u) rows = 16u;
             }
         } else {
             rows = aff::pow2_ge(rows);
         }
+        if (rows != 0u) {
+            const double w = (double)rows - tail_rows;
+            win_rows = w >= (double)(rows / 2u) ? (uint32_t)w : rows / 2u;   // an explicit small ring: half of it, overflow -> hand-back
+        }
         FL = aff::make_flow_layout(entries, rows, e->fargs.L.g_ring, e->fargs.L.c_ring, a.n_edges, a.n_servers, a.n_edge_marks);
+        FL.win_rows = win_rows;
         flow_lds = a.blob_bytes + FL.n_words * 8u;
         if (flow_lds > kLdsLimit) return fail(AF_ERR_CAPACITY, "flow kernel layout exceeds the LDS of a compute unit");
     }
