@@ -10,8 +10,11 @@
 // two agree to ~1e-13 relative, not bit for bit).
 //
 // HBM-bound: one workgroup per scenario streams that scenario's rqs_clock rows (16 B per
-// completed request) 3 times in the common case:
-//   pass 1  sum / min / max / RPS buckets / histogram of the f64 exponent field
+// completed request) TWICE in the common case (three times in round 1):
+//   pass 1  sum / min / max / RPS buckets / histogram of the f64 exponent field -- and, for the (<= 3)
+//           exponent bins in which the first 512 latencies put the wanted ranks, already the next 10 key
+//           bits: when the guess covers every wanted rank (latencies of one scenario span 2-3 binades)
+//           the first radix level costs no pass of its own
 //   pass 2+ (only while a wanted rank still has > kCand candidates) 10 more key bits per pass,
 //           MSB-first radix select, all wanted ranks at once
 //   last    gather the <= kCand candidates of every wanted rank into LDS, accumulate the squared
@@ -121,6 +124,8 @@ __global__ __launch_bounds__(kThreads) void af_summary_kernel(SumArgs a) {
     __shared__ uint32_t slot_of[kRanks];
     __shared__ uint32_t n_slots, more;
     __shared__ double val[kRanks];
+    __shared__ uint32_t g_pfx[3];   // exponent bins guessed from the first 512 latencies
+    __shared__ uint32_t g_n, g_hit;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t sc = blockIdx.x;
@@ -132,7 +137,38 @@ __global__ __launch_bounds__(kThreads) void af_summary_kernel(SumArgs a) {
 
     for (int i = tid; i < kExpBins; i += kThreads) exp_hist[i] = 0u;
     for (uint32_t i = tid; i < a.rps_buckets + (a.hist ? a.hist_bins : 0u); i += kThreads) dyn[i] = 0u;
+    for (uint32_t i = tid; i < 3u * (uint32_t)kDigBins; i += kThreads) (&dig_hist[0][0])[i] = 0u;
     __syncthreads();
+
+    // ---- guess: in which exponent bins do the first 512 latencies put the median / p95 / p99? ------------
+    {
+        const uint32_t m = n < (uint32_t)kThreads ? n : (uint32_t)kThreads;
+        if ((uint32_t)tid < m) {
+            const double2 c = ck[tid];
+            atomicAdd(&exp_hist[((unsigned long long)__double_as_longlong(c.y - c.x) >> 52) & (kExpBins - 1)], 1u);
+        }
+        __syncthreads();
+        if (wave < 3 && m > 0u) {
+            const uint32_t k = wave == 0 ? m / 2u : wave == 1 ? (uint32_t)((double)(m - 1u) * 0.95) : (uint32_t)((double)(m - 1u) * 0.99);
+            uint32_t bin, below, count;
+            wave_select(exp_hist, kExpBins, k, bin, below, count);
+            if (lane == 0) g_pfx[wave] = bin;
+        }
+        __syncthreads();
+        if (tid == 0) {   // distinct guesses first
+            uint32_t k = 0;
+            if (m > 0u)
+                for (uint32_t r = 0; r < 3u; ++r) {
+                    bool seen = false;
+                    for (uint32_t q = 0; q < k; ++q) seen = seen || g_pfx[q] == g_pfx[r];
+                    if (!seen) g_pfx[k++] = g_pfx[r];
+                }
+            g_n = k;
+        }
+        for (int i = tid; i < kExpBins; i += kThreads) exp_hist[i] = 0u;
+        __syncthreads();
+    }
+    const uint32_t gn = g_n, gp0 = g_pfx[0], gp1 = g_pfx[1], gp2 = g_pfx[2];
 
     // ---- pass 1 -----------------------------------------------------------------------------
     double s = 0.0, mn = __builtin_inf(), mx = -__builtin_inf();
@@ -153,7 +189,12 @@ __global__ __launch_bounds__(kThreads) void af_summary_kernel(SumArgs a) {
             mn = fmin(mn, lat);
             mx = fmax(mx, lat);
             const unsigned long long key = (unsigned long long)__double_as_longlong(lat);
-            atomicAdd(&exp_hist[(key >> 52) & (kExpBins - 1)], 1u);
+            const uint32_t ebin = (uint32_t)(key >> 52) & (kExpBins - 1);
+            atomicAdd(&exp_hist[ebin], 1u);
+            const uint32_t dig = (uint32_t)(key >> (52 - kDigBits)) & (kDigBins - 1);
+            if (gn > 0u && ebin == gp0) atomicAdd(&dig_hist[0][dig], 1u);
+            else if (gn > 1u && ebin == gp1) atomicAdd(&dig_hist[1][dig], 1u);
+            else if (gn > 2u && ebin == gp2) atomicAdd(&dig_hist[2][dig], 1u);
             if (a.rps) {
                 // window (k-1, k]; a finish at exactly 0 belongs to the first window (analyzer.py:112-121)
                 const double kf = ceil(c.y);
@@ -227,6 +268,38 @@ __global__ __launch_bounds__(kThreads) void af_summary_kernel(SumArgs a) {
         }
     }
     int shift = 52;
+    // ---- the guessed bins already carry their next 10 key bits: if they cover every wanted rank that still has
+    // too many candidates ... (a rank that is already narrow enough keeps its exponent bin: prefixes of different
+    // lengths cannot be mixed, so the shortcut is taken only when ALL ranks can take it)
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t hit = 1u;
+        for (int r = 0; r < kRanks; ++r) {
+            bool ok = false;
+            for (uint32_t q = 0; q < g_n; ++q) ok = ok || pfx[r] == (unsigned long long)g_pfx[q];
+            if (!ok) hit = 0u;
+        }
+        g_hit = hit;
+    }
+    __syncthreads();
+    if (g_hit) {
+        if (wave < kRanks) {
+            uint32_t q = 0;
+            for (uint32_t j = 0; j < g_n; ++j)
+                if (pfx[wave] == (unsigned long long)g_pfx[j]) q = j;
+            uint32_t bin, below, count;
+            wave_select(dig_hist[q], kDigBins, rank_in[wave], bin, below, count);
+            __syncthreads();
+            if (lane == 0) {
+                pfx[wave] = (pfx[wave] << kDigBits) | bin;
+                rank_in[wave] -= below;
+                cnt[wave] = count;
+            }
+        } else {
+            __syncthreads();
+        }
+        shift = 52 - kDigBits;
+    }
 
     // ---- deeper levels while some rank still has too many candidates ------------------------------
     for (;;) {
