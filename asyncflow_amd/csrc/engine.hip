@@ -692,6 +692,21 @@ std::string jit_spec_string(const KArgs& a, bool lds_state, uint32_t klog) {
     return buf;
 }
 
+// Experiment hook (AF_WAVES_PER_CU=k): ask for more LDS per workgroup than it needs so that at most k waves fit a
+// CU.  Measured on MI355X (10 000 LB-2 replicas): capping the stage-parallel kernel at 14 waves per CU -- three
+// equal residency rounds instead of 16 + 16 + a partial one -- is SLOWER (81.6 vs 73.7 ms): the partial round already
+// runs faster per wave (4 096 scenarios 30.1 ms, 8 192: 58.0 ms, 10 000: 73.7 ms), so the default pads nothing.
+uint32_t spread_lds_bytes(uint32_t need_bytes) {
+    if (const char* env = std::getenv("AF_WAVES_PER_CU")) {
+        const uint32_t k = (uint32_t)std::atoi(env);
+        if (k != 0u) {
+            const uint32_t b = (kLdsLimit / k) & ~511u;
+            return b > need_bytes ? b : need_bytes;
+        }
+    }
+    return need_bytes;
+}
+
 uint32_t chunk_size(const af_engine* e, uint32_t n, size_t draw_bytes_per_scen, size_t mem_free) {
     // (one launch per chunk, and every launch ends with a latency-bound tail: chunks are a last resort)
     size_t budget = e->draw_memory_bytes ? e->draw_memory_bytes : (size_t)160 << 30;
@@ -1171,7 +1186,8 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
             }
             a.n_scen = cnt;
             HIP_TRY(hipEventRecord(e->ev2, e->stream));
-            hipLaunchKernelGGL(af_pregen_arrivals, dim3((cnt + 3u) / 4u), dim3(64), 0, e->stream, a, (uint32_t)((1u + a.n_edges) * n_draw));
+            hipLaunchKernelGGL(af_pregen_arrivals, dim3((cnt + 3u) / 4u), dim3(64), 0, e->stream, a,
+                               (uint32_t)((1u + a.n_edges) * n_draw));
             hipLaunchKernelGGL(af_pregen_edges, dim3((n_draw + 255u) / 256u, cnt, a.n_edges), dim3(256), 0, e->stream, a);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(e->ev3, e->stream));
@@ -1301,12 +1317,13 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
                              : FL.cap == 128u ? (lean ? reinterpret_cast<const void*>(af_flow_kernel<2, 0u>)
                                                       : reinterpret_cast<const void*>(af_flow_kernel<2, aff::FEAT_ALL>))
                                               : reinterpret_cast<const void*>(af_flow_kernel<4, aff::FEAT_ALL>);
-            if (flow_lds > 48u * 1024u) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flow_lds));
+            const uint32_t flow_lds_launch = spread_lds_bytes(flow_lds);
+            if (flow_lds_launch > 48u * 1024u) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flow_lds_launch));
             void* kargs[] = {&f};
             if (std::getenv("AF_DEBUG"))
                 std::fprintf(stderr, "[af] flow launch: %u scenarios, %u list entries, %u ring rows, %u B LDS per wave%s\n", nc, FL.cap,
                              FL.ring_rows, flow_lds, flow_lean ? ", lean instantiation" : "");
-            HIP_TRY(hipLaunchKernel(fn, dim3(nc), dim3(kWave), kargs, flow_lds, e->stream));
+            HIP_TRY(hipLaunchKernel(fn, dim3(nc), dim3(kWave), kargs, flow_lds_launch, e->stream));
         }
         HIP_TRY(hipEventRecord(e->ev4, e->stream));
         uint32_t fb[5] = {0, 0, 0, 0, 0};
