@@ -149,6 +149,7 @@ struct FlowArgs {
 //   W::global_add(p, v) / W::global_load(p) / W::global_fence()   device-scope atomic add / load past the L1 / fence
 //                                   (tick differences kept in HBM when the LDS ring would be too small)
 //   W::mbcnt(mask)                  popcount(mask & lanes below me)
+//   W::rcp(x)                       ~1/x (only ever used where the exact value does not matter)
 // Every W:: call is made by all 64 lanes from wave-uniform control flow.
 // IPL = list entries per lane (list capacity = 64 * IPL).
 // FEAT = features compiled in (the host picks the leanest instantiation that covers the launch: every
@@ -380,7 +381,9 @@ struct Flow {
         AF_PLAN_AS double* K = list_key(s);
         AF_PLAN_AS double* T0 = list_t0(s);
         AF_PLAN_AS uint32_t* AX = list_aux();
-        double sc = 64.0 / (hi - lo);
+        // (any positive scale gives a monotone key -> bucket map; ranks come from exact comparisons, so the hardware's
+        // approximate reciprocal is as good as a division here)
+        double sc = 64.0 * W::rcp(hi - lo);
         if (!(sc < 1e300)) sc = 1e300;
         hist()[lane] = 0u;
         W::sync();

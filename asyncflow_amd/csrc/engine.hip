@@ -296,6 +296,7 @@ struct WaveHip {
         return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     static __device__ __forceinline__ void global_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); }
+    static __device__ __forceinline__ double rcp(double x) { return __builtin_amdgcn_rcp(x); }
     static __device__ __forceinline__ uint32_t mbcnt(uint64_t m) {
         return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     }

@@ -126,6 +126,7 @@ struct WaveEmu {
     static void global_add(uint32_t* p, uint32_t v) { *p += v; }
     static uint32_t global_load(const uint32_t* p) { return *p; }
     static void global_fence() {}
+    static double rcp(double x) { return 1.0 / x; }
     static uint32_t mbcnt(uint64_t m) { return (uint32_t)__builtin_popcountll(m & ((1ull << lane()) - 1ull)); }
 };
 
