@@ -192,6 +192,8 @@ class AfStats(C.Structure):
         ("flow_fallback_list", C.c_uint32),
         ("flow_fallback_ring", C.c_uint32),
         ("flow_fallback_ram", C.c_uint32),
+        ("flow_retried", C.c_uint32),
+        ("flow_to_next_event", C.c_uint32),
         ("flow_list_entries", C.c_uint32),
         ("flow_ring_rows", C.c_uint32),
         ("flow_lds_bytes", C.c_uint32),

@@ -221,7 +221,7 @@ AF_HD double pre_edge_draw(uint64_t seed, uint32_t e, uint32_t idx, uint32_t dis
     const uint32_t stream = stream_edge(e);
     const U4 r = draw_block(seed, stream, idx, 0u);
     if (u53(r.x, r.y) < dropout) return -1.0;  // dropped: no latency draw
-    return variate_from_u1(dist, mean, sigma, u53(r.z, r.w), seed, stream, idx);
+    return test_quant(variate_from_u1(dist, mean, sigma, u53(r.z, r.w), seed, stream, idx));
 }
 
 // The windowed arrival sampler: samplers/poisson_poisson.py:51-82, gaussian_poisson.py:63-94.
@@ -252,7 +252,7 @@ AF_HD double gen_next_gap(GenState& g, uint64_t seed, uint32_t users_dist, doubl
         const U4 r = draw_block(seed, STREAM_GENERATOR, g.draws++, 0u);
         double u = u53(r.x, r.y);
         if (u < 1e-15) u = 1e-15;
-        const double dt = -af_log(1.0 - u) / g.g_lam;
+        const double dt = test_quant(-af_log(1.0 - u) / g.g_lam);
         if (g.g_now + dt > T) break;
         if (g.g_now + dt >= g.g_wend) {
             g.g_now = g.g_wend;

@@ -70,12 +70,13 @@ struct FlowLayout {
     uint32_t g_ring;     // per-server ring of departure times (power of two >= RAM slots looked back)
     uint32_t c_ring;     // per-server ring of core-release times (>= max cpu_cores)
     uint32_t pitch;      // 4-byte words per tick row (n_series rounded up to 4)
+    uint32_t list_arrays;  // f64 arrays per station list: key, t0 [, send time (FEAT_TIEBREAK)]
     uint32_t off_spike, off_list, off_aux, off_out, off_sorted, off_hist, off_seg, off_fr, off_gr, off_cnt, off_ring;
     uint32_t n_words;
 };
 
 inline FlowLayout make_flow_layout(uint32_t cap, uint32_t ring_rows, uint32_t g_ring, uint32_t c_ring, uint32_t n_edges,
-                                   uint32_t n_servers, uint32_t n_edge_marks) {
+                                   uint32_t n_servers, uint32_t n_edge_marks, bool tiebreak = false) {
     FlowLayout L{};
     L.cap = cap;
     L.ring_rows = ring_rows;
@@ -85,13 +86,14 @@ inline FlowLayout make_flow_layout(uint32_t cap, uint32_t ring_rows, uint32_t g_
     L.pitch = (n_edges + 3u * n_servers + 3u) & ~3u;
     uint32_t w = 0;
     L.off_spike = w; w += n_edge_marks;                 // cumulative spike after each edge mark
-    L.off_list = w; w += 4u * 2u * cap;                 // 4 lists x (key, t0)
+    L.list_arrays = tiebreak ? 3u : 2u;
+    L.off_list = w; w += 4u * L.list_arrays * cap;      // 4 lists x (key, t0 [, send time])
     L.off_aux = w; w += (cap + 1u) / 2u;                // u32 per entry of the server list
     // scratch of select() (selected (key, t0) + u32 aux; bucket-sorted keys; 64 u32 counts, 64 u32 bases, scalars)
     // and the per-server segments of the server station (admission, B, S, F, G) are never live together
     const uint32_t scratch0 = w;
     L.off_out = w; w += 64u * 2u + 32u;
-    L.off_sorted = w; w += cap;
+    L.off_sorted = w; w += tiebreak ? 2u * cap : cap;   // bucket-sorted keys [, their send times]
     L.off_hist = w; w += 32u + 32u + 8u;
     L.off_seg = scratch0;
     if (w < scratch0 + 5u * 64u) w = scratch0 + 5u * 64u;
@@ -138,6 +140,7 @@ struct FlowArgs {
     uint32_t online_hist_bins, online_rps_buckets;
     double online_hist_scale;
     uint32_t* n_fallback;   // [5]: scenarios handed over, then by reason (tie, list, ring, ram)
+    const uint32_t* scen_map;  // second-chance launch: wave j simulates scenario scen_map[j] (null = j)
 };
 
 // ---- the algorithm, written against a wave backend W ---------------------------------------------
@@ -157,11 +160,15 @@ struct FlowArgs {
 //   FEAT_MARKS     injected spikes / outages (the plan has timeline marks)
 //   FEAT_ONLINE    kernel-side latency histogram / completion counts (af_outputs_t.online_*)
 //   FEAT_HBM_RING  tick differences kept in the sample rows in HBM (layout.ring_rows == 0 with series stored)
-enum : uint32_t { FEAT_MARKS = 1u, FEAT_ONLINE = 2u, FEAT_HBM_RING = 4u, FEAT_ALL = 7u };
+//   FEAT_TIEBREAK  every message also carries its SEND time; two deliveries of one station at the same instant are
+//                  then handled in the order SimPy pops them -- the order their Timeouts were created, i.e. by send
+//                  time (heap key (time, priority, event id)) -- instead of being handed back.  Used by
+//                  the second-chance launch over the scenarios the lean instantiation hands back (engine.hip).
+enum : uint32_t { FEAT_MARKS = 1u, FEAT_ONLINE = 2u, FEAT_HBM_RING = 4u, FEAT_ALL = 7u, FEAT_TIEBREAK = 8u };
 template <class W, uint32_t IPL = 1u, uint32_t FEAT = FEAT_ALL>
 struct Flow {
     static constexpr bool kMarks = (FEAT & FEAT_MARKS) != 0u, kOnline = (FEAT & FEAT_ONLINE) != 0u,
-                          kHbmRing = (FEAT & FEAT_HBM_RING) != 0u;
+                          kHbmRing = (FEAT & FEAT_HBM_RING) != 0u, kTieBreak = (FEAT & FEAT_TIEBREAK) != 0u;
     const FlowArgs& A;
     AF_PLAN_AS uint64_t* blob;   // plan blob (LDS copy, patched)
     AF_PLAN_AS uint64_t* M;      // layout words behind it
@@ -197,8 +204,12 @@ struct Flow {
     AF_CORE Flow(const FlowArgs& a) : A(a) {}
 
     // ---- LDS views ----------------------------------------------------------------------------
-    AF_CORE AF_PLAN_AS double* list_key(uint32_t s) const { return (AF_PLAN_AS double*)(M + A.L.off_list + 2u * A.L.cap * s); }
+    AF_CORE AF_PLAN_AS double* list_key(uint32_t s) const {
+        return (AF_PLAN_AS double*)(M + A.L.off_list + (kTieBreak ? 3u : 2u) * A.L.cap * s);
+    }
     AF_CORE AF_PLAN_AS double* list_t0(uint32_t s) const { return list_key(s) + A.L.cap; }
+    AF_CORE AF_PLAN_AS double* list_ts(uint32_t s) const { return list_key(s) + 2u * A.L.cap; }   // FEAT_TIEBREAK only
+    AF_CORE AF_PLAN_AS double* sorted_ts() const { return sorted() + A.L.cap; }
     AF_CORE AF_PLAN_AS uint32_t* list_aux() const { return (AF_PLAN_AS uint32_t*)(M + A.L.off_aux); }
     AF_CORE AF_PLAN_AS double* out_key() const { return (AF_PLAN_AS double*)(M + A.L.off_out); }
     AF_CORE AF_PLAN_AS double* out_t0() const { return out_key() + 64; }
@@ -342,22 +353,28 @@ struct Flow {
             return false;
         }
         const double u1 = af::u53(rr.z, rr.w);
-        const double transit = dist == af::DIST_EXPONENTIAL ? -(mean * af::af_log(1.0 - u1)) : cold_variate(dist, mean, sigma, u1, seed, stream, idx);
+        const double transit =
+            af::test_quant(dist == af::DIST_EXPONENTIAL ? -(mean * af::af_log(1.0 - u1)) : cold_variate(dist, mean, sigma, u1, seed, stream, idx));
         const double spike = (kMarks && A.n_edge_marks != 0u) ? spike_at(e, now) : 0.0;
         key = now + (transit + spike);
-        if (!(key > now)) why |= FLOW_WHY_TIE;     // a zero (or negative) delay: SimPy orders it among the zero-time steps
+        // A transit time that does not advance the f64 clock (an exponential draw below half an ulp of `now`, a normal
+        // truncated at 0) delivers at the send instant: an event of the NEXT station, which commutes with this one;
+        // if the next station has another event at that instant the equal keys are seen there.  A NEGATIVE delay
+        // (spike residue after += / -=) raises in the reference (simpy: "Negative delay"): handed back.
+        if (key < now) why |= FLOW_WHY_TIE;
         add_interval(e, now, key, 1);
         return true;
     }
 
     // ---- station lists -------------------------------------------------------------------------------
-    AF_CORE void append(uint32_t s, bool have, double key, double t0, uint32_t aux) {
+    AF_CORE void append(uint32_t s, bool have, double key, double t0, uint32_t aux, double sent) {
         const uint64_t m = W::ballot(have);
         const uint32_t n = n_list_get(s);
         const uint32_t pos = n + W::mbcnt(m);
         if (have) {
             list_key(s)[pos] = key;
             list_t0(s)[pos] = t0;
+            if (kTieBreak) list_ts(s)[pos] = sent;
             if (s == 2u) list_aux()[pos] = aux;
         }
         n_list_set(s, n + popc64(m));
@@ -380,6 +397,7 @@ struct Flow {
         }
         AF_PLAN_AS double* K = list_key(s);
         AF_PLAN_AS double* T0 = list_t0(s);
+        AF_PLAN_AS double* TS = list_ts(s);
         AF_PLAN_AS uint32_t* AX = list_aux();
         // (any positive scale gives a monotone key -> bucket map; ranks come from exact comparisons, so the hardware's
         // approximate reciprocal is as good as a division here)
@@ -388,13 +406,13 @@ struct Flow {
         hist()[lane] = 0u;
         W::sync();
         // my (up to 4) entries; bucket counts
-        double k[IPL], t[IPL];
+        double k[IPL], t[IPL], sent[IPL];
         uint32_t a[IPL], b[IPL], slot[IPL];
         bool valid[IPL], elig[IPL];
 #pragma unroll
         for (uint32_t q = 0u; q < IPL; ++q) {
             valid[q] = elig[q] = false;
-            k[q] = t[q] = 0.0;
+            k[q] = t[q] = sent[q] = 0.0;
             a[q] = b[q] = slot[q] = 0u;
             {
                 const uint32_t i = q * 64u + lane;
@@ -402,6 +420,7 @@ struct Flow {
                 if (valid[q]) {
                     k[q] = K[i];
                     t[q] = T0[i];
+                    if (kTieBreak) sent[q] = TS[i];
                     a[q] = s == 2u ? AX[i] : 0u;
                     elig[q] = k[q] < hi;
                     if (elig[q]) {
@@ -421,7 +440,10 @@ struct Flow {
         W::sync();
 #pragma unroll
         for (uint32_t q = 0u; q < IPL; ++q)
-            if (elig[q]) sorted()[bbase()[b[q]] + slot[q]] = k[q];
+            if (elig[q]) {
+                sorted()[bbase()[b[q]] + slot[q]] = k[q];
+                if (kTieBreak) sorted_ts()[bbase()[b[q]] + slot[q]] = sent[q];
+            }
         W::sync();
         uint32_t rank[IPL];
 #pragma unroll
@@ -433,7 +455,15 @@ struct Flow {
                 for (uint32_t p = p0; p < p1; ++p) {
                     const double kk = sorted()[p];
                     r += kk < k[q] ? 1u : 0u;
-                    if (kk == k[q] && p != me) why |= FLOW_WHY_TIE;   // two events of this station at one instant
+                    if (kk == k[q] && p != me) {   // two deliveries of this station at one instant
+                        if (kTieBreak) {           // SimPy pops the one whose Timeout was created -- that was sent -- first
+                            const double other = sorted_ts()[p];
+                            r += other < sent[q] ? 1u : 0u;
+                            if (other == sent[q]) why |= FLOW_WHY_TIE;
+                        } else {
+                            why |= FLOW_WHY_TIE;
+                        }
+                    }
                 }
                 rank[q] = r;
             }
@@ -461,6 +491,7 @@ struct Flow {
                 if (keep) {
                     K[pos] = k[q];
                     T0[pos] = t[q];
+                    if (kTieBreak) TS[pos] = sent[q];
                     if (s == 2u) AX[pos] = a[q];
                 }
                 kept += popc64(m);
@@ -840,7 +871,7 @@ struct Flow {
                 if (st < 4u) {
                     double k2 = 0.0;
                     const bool ok = sending && edge_send(e, idx, ts, k2);
-                    append(nxt, ok, k2, t0, tgt);
+                    append(nxt, ok, k2, t0, tgt, ts);
                     if (st > 0u) H_in = H_get(st - 1u);
                 }
             }

@@ -208,6 +208,22 @@ AF_HD int64_t af_poisson(double mean, uint64_t seed, uint32_t stream, uint32_t i
     return total;
 }
 
+// TEST-ONLY hook, host builds of this header only (g++: tests/hostcheck; never under hipcc, host or device pass):
+// latencies and arrival gaps rounded down to a multiple of 2^-bits seconds, so that exact timestamp ties --
+// probability ~1e-6 per scenario with continuous laws -- happen thousands of times per scenario.  The oracle has
+// the same hook (oracle/des_oracle.c: orc_set_test_quantum); tests/test_flow_hostcheck.py uses both to pin the
+// tie handling of the stage-parallel kernel on SimPy's event order.
+#if !defined(__HIPCC__)
+inline int g_test_quantum_bits = 0;
+inline double test_quant(double x) {
+    if (g_test_quantum_bits <= 0 || !(x > 0.0)) return x;
+    const double s = (double)(1ull << g_test_quantum_bits);
+    return __builtin_floor(x * s) / s;
+}
+#else
+AF_HD double test_quant(double x) { return x; }
+#endif
+
 enum Dist : uint32_t { DIST_POISSON = 0, DIST_NORMAL = 1, DIST_LOG_NORMAL = 2, DIST_EXPONENTIAL = 3, DIST_UNIFORM = 4 };
 
 // general_sampler (samplers/common_helpers.py:49-89) on the stream spec; `u1`

@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -309,8 +310,8 @@ struct WaveHip {
 template <uint32_t IPL, uint32_t FEAT>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AF_FLOW_WPE))) af_flow_kernel(const aff::FlowArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t sc = blockIdx.x;
-    if (sc >= a.n_scen) return;
+    if (blockIdx.x >= a.n_scen) return;
+    const uint32_t sc = a.scen_map ? a.scen_map[blockIdx.x] : blockIdx.x;
     aff::Flow<WaveHip, IPL, FEAT> f(a);
     f.run((LDS_AS uint64_t*)smem, sc);
     if (threadIdx.x == 0u && a.n_fallback) {
@@ -587,7 +588,7 @@ struct af_engine {
     size_t arr_cap = 0;
     uint32_t* d_arr_flags = nullptr;
     size_t arr_flags_cap = 0;
-    uint32_t* d_fb = nullptr;      // [5] hand-over counters
+    uint32_t* d_fb = nullptr;      // [10] hand-over counters of the first and of the second-chance launch
     uint32_t* d_slot = nullptr;    // draw slots of a second pass over a subset
     size_t slot_cap = 0;
     // host copy of what the layout heuristics need
@@ -885,7 +886,7 @@ int af_engine_create(const af_plan_t* plan, int device, const af_engine_options_
     if (err == hipSuccess && e->flow_ok) err = hipMalloc((void**)&e->d_tick, (e->tick.t.size() + 1u) * 8u);
     if (err == hipSuccess && e->flow_ok && !e->tick.t.empty())
         err = hipMemcpy(e->d_tick, e->tick.t.data(), e->tick.t.size() * 8u, hipMemcpyHostToDevice);
-    if (err == hipSuccess) err = hipMalloc((void**)&e->d_fb, 5u * 4u);
+    if (err == hipSuccess) err = hipMalloc((void**)&e->d_fb, 10u * 4u);
     if (err == hipSuccess) err = hipEventCreate(&e->ev0);
     if (err == hipSuccess) err = hipEventCreate(&e->ev1);
     if (err == hipSuccess) err = hipEventCreate(&e->ev2);
@@ -997,6 +998,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     uint32_t kl = 0, waves = 0, lds_bytes = 0, n_chunks = 0, n_rerun = 0, n_jit = 0, n_jit_miss = 0;
     uint32_t fb_total[5] = {0, 0, 0, 0, 0}, flow_scen = 0, flow_lds = 0;
     bool flow_lean = false;
+    uint32_t flow_retried = 0, flow_to_next = 0;
     size_t draw_bytes = 0;
     bool lds_state = false;
     aff::FlowLayout FL{};
@@ -1307,7 +1309,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
         f.online_rps_buckets = a.online_rps_buckets;
         f.online_hist_scale = a.online_hist_scale;
         f.n_fallback = e->d_fb;
-        HIP_TRY(hipMemsetAsync(e->d_fb, 0, 5u * 4u, e->stream));
+        HIP_TRY(hipMemsetAsync(e->d_fb, 0, 10u * 4u, e->stream));
         {
             // the leanest instantiation that covers this launch (a compiled-in feature costs wave-uniform registers)
             const bool lean = a.n_edge_marks == 0u && a.n_srv_marks == 0u && !f.online_hist && !f.online_rps &&
@@ -1340,11 +1342,65 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
         if (fb[0] > 0u) {
             std::vector<uint32_t> cnt_host((size_t)nc * AF_CNT_SLOTS);
             HIP_TRY(hipMemcpy(cnt_host.data(), a.counts, cnt_host.size() * 4u, hipMemcpyDeviceToHost));
-            std::vector<uint32_t> map;
-            map.reserve(fb[0]);
-            for (uint32_t i = 0; i < nc; ++i)
-                if (cnt_host[(size_t)i * AF_CNT_SLOTS + AF_CNT_FLAGS] & aff::FLAG_FLOW_FALLBACK) map.push_back(i);
-            if (int rc = run_sequential((uint32_t)map.size(), map.data(), chunk_args)) return rc;
+            // Second chance on the stage-parallel kernel itself, in its most tolerant form: 256-entry lists, tick
+            // differences in HBM (no reach limit), messages carry their send time so that two deliveries of one station
+            // at the same instant are ordered the way SimPy orders them.  A wave costs tens of milliseconds; the same
+            // scenario on a next-event kernel is a latency-bound chain of ~1 s (LB-2).  Only what this launch hands
+            // back again -- or what can never fit its RAM model -- goes to the next-event kernels.
+            std::vector<uint32_t> retry, rest;
+            for (uint32_t i = 0; i < nc; ++i) {
+                const uint32_t fl = cnt_host[(size_t)i * AF_CNT_SLOTS + AF_CNT_FLAGS];
+                if (!(fl & aff::FLAG_FLOW_FALLBACK)) continue;
+                if (fl & aff::FLOW_WHY_RAM) rest.push_back(i);
+                else retry.push_back(i);
+            }
+            if (!retry.empty()) {
+                if (int rc = grow((void**)&e->d_map, e->map_cap, retry.size() * 4u)) return rc;
+                HIP_TRY(hipMemcpyAsync(e->d_map, retry.data(), retry.size() * 4u, hipMemcpyHostToDevice, e->stream));
+                aff::FlowArgs f2 = f;
+                f2.L = aff::make_flow_layout(256u, 0u, e->fargs.L.g_ring, e->fargs.L.c_ring, a.n_edges, a.n_servers, a.n_edge_marks, true);
+                f2.L.win_rows = 0u;
+                f2.n_scen = (uint32_t)retry.size();
+                f2.scen_map = e->d_map;
+                f2.n_fallback = e->d_fb + 5;
+                const uint32_t lds2 = a.blob_bytes + f2.L.n_words * 8u;
+                if (lds2 > kLdsLimit) return fail(AF_ERR_CAPACITY, "flow kernel layout exceeds the LDS of a compute unit");
+                if (a.online_hist || a.online_rps) {
+                    a.scen_map = e->d_map;
+                    hipLaunchKernelGGL(af_zero_online, dim3((uint32_t)retry.size()), dim3(256), 0, e->stream, a, (uint32_t)retry.size());
+                    HIP_TRY(hipGetLastError());
+                    a.scen_map = nullptr;
+                }
+                const void* fn2 = reinterpret_cast<const void*>(af_flow_kernel<4, aff::FEAT_ALL | aff::FEAT_TIEBREAK>);
+                if (lds2 > 48u * 1024u) HIP_TRY(hipFuncSetAttribute(fn2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+                HIP_TRY(hipEventRecord(e->ev3, e->stream));
+                void* kargs2[] = {&f2};
+                if (std::getenv("AF_DEBUG")) {
+                    std::fprintf(stderr, "[af] flow second chance: %zu scenarios (256-entry lists with send times, differences in HBM), %u B LDS:",
+                                 retry.size(), lds2);
+                    for (size_t q = 0; q < retry.size() && q < 16; ++q)
+                        std::fprintf(stderr, " %u(flags %#x)", lo + retry[q], cnt_host[(size_t)retry[q] * AF_CNT_SLOTS + AF_CNT_FLAGS]);
+                    std::fprintf(stderr, "\n");
+                }
+                HIP_TRY(hipLaunchKernel(fn2, dim3((uint32_t)retry.size()), dim3(kWave), kargs2, lds2, e->stream));
+                HIP_TRY(hipEventRecord(e->ev4, e->stream));
+                uint32_t fb2[5] = {0, 0, 0, 0, 0};
+                HIP_TRY(hipMemcpyAsync(fb2, e->d_fb + 5, sizeof fb2, hipMemcpyDeviceToHost, e->stream));
+                HIP_TRY(hipStreamSynchronize(e->stream));
+                float ms2 = 0.f;
+                HIP_TRY(hipEventElapsedTime(&ms2, e->ev3, e->ev4));
+                ms_flow += ms2;
+                flow_retried += (uint32_t)retry.size();
+                if (fb2[0] > 0u) {
+                    HIP_TRY(hipMemcpy(cnt_host.data(), a.counts, cnt_host.size() * 4u, hipMemcpyDeviceToHost));
+                    for (uint32_t i : retry)
+                        if (cnt_host[(size_t)i * AF_CNT_SLOTS + AF_CNT_FLAGS] & aff::FLAG_FLOW_FALLBACK) rest.push_back(i);
+                    std::sort(rest.begin(), rest.end());
+                }
+            }
+            flow_to_next += (uint32_t)rest.size();
+            if (!rest.empty())
+                if (int rc = run_sequential((uint32_t)rest.size(), rest.data(), chunk_args)) return rc;
         }
     }
 
@@ -1358,6 +1414,8 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     e->stats.flow_fallback_list = fb_total[2];
     e->stats.flow_fallback_ring = fb_total[3];
     e->stats.flow_fallback_ram = fb_total[4];
+    e->stats.flow_retried = flow_retried;
+    e->stats.flow_to_next_event = flow_to_next;
     e->stats.flow_list_entries = use_flow ? FL.cap : 0u;
     e->stats.flow_ring_rows = use_flow ? FL.ring_rows : 0u;
     e->stats.flow_lds_bytes = flow_lds;

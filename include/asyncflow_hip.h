@@ -278,11 +278,14 @@ typedef struct af_stats {
     /* stage-parallel kernel (last af_engine_run) */
     double flow_kernel_ms;         /* HIP-event time of the stage-parallel kernel, 0 = not used      */
     uint32_t flow_scenarios;       /* scenarios it was launched on                                  */
-    uint32_t flow_fallback;        /* ... of which handed back to the next-event kernels, by reason: */
+    uint32_t flow_fallback;        /* ... of which handed back by the first launch, by reason:        */
     uint32_t flow_fallback_tie;    /*   two events of one station (or an event and a tick / mark) at one instant */
     uint32_t flow_fallback_list;   /*   more messages pending at a station than flow_list_entries   */
     uint32_t flow_fallback_ring;   /*   an interval reached beyond the tick ring                    */
     uint32_t flow_fallback_ram;    /*   RAM admission the recurrence cannot express                 */
+    uint32_t flow_retried;         /* handed-back scenarios run again by the kernel's most tolerant instantiation
+                                      (256-entry lists carrying send times, tick differences in HBM)             */
+    uint32_t flow_to_next_event;   /* scenarios finally simulated by the next-event kernels                       */
     uint32_t flow_list_entries;    /* layout used                                                   */
     uint32_t flow_ring_rows;       /* (0 = differences kept in HBM)                                 */
     uint32_t flow_lds_bytes;       /* LDS per wavefront                                             */

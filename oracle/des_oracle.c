@@ -232,6 +232,17 @@ static void sched_abs(sim_t* s, double t, int kind) {
 /* Returns the next inter-arrival gap or -1 when the sampler is exhausted.
  * Follows poisson_poisson.py:55-82 line by line (gaussian_poisson.py:67-94 is
  * identical except for the users draw). */
+/* TEST-ONLY: latencies and arrival gaps rounded down to a multiple of 2^-bits s (0 = off), the same hook as
+ * asyncflow_amd/csrc/af_math.hpp::test_quant in the host builds of the engine core: exact timestamp ties by the
+ * thousand, to pin tie handling on SimPy's event order (tests/test_flow_hostcheck.py). */
+static int g_test_quantum_bits = 0;
+void orc_set_test_quantum(int bits) { g_test_quantum_bits = bits; }
+static double test_quant(double x) {
+    if (g_test_quantum_bits <= 0 || !(x > 0.0)) return x;
+    const double sc = (double)(1ull << g_test_quantum_bits);
+    return floor(x * sc) / sc;
+}
+
 static double next_gap(sim_t* s) {
     const af_plan_t* p = s->p;
     const double T = p->total_time;
@@ -257,7 +268,7 @@ static double next_gap(sim_t* s) {
         }
         double u = orc_uniform(s->seed, ORC_STREAM_GENERATOR, s->g_draws++, 0);
         if (u < 1e-15) u = 1e-15; /* max(u, 1e-15) */
-        double dt = -orc_log(1.0 - u) / s->g_lam;
+        double dt = test_quant(-orc_log(1.0 - u) / s->g_lam);
         if (s->g_now + dt > T) break;
         if (s->g_now + dt >= s->g_window_end) {
             s->g_now = s->g_window_end;
@@ -303,8 +314,8 @@ static void edge_init(sim_t* s, int r) {
         return;
     }
     ed->conn += 1; /* edge.py:88 */
-    double transit = orc_variate(p->edge_dist[e], p->edge_mean[e], p->edge_sigma[e], s->seed,
-                                 ORC_STREAM_EDGE(e), idx, 1);
+    double transit = test_quant(orc_variate(p->edge_dist[e], p->edge_mean[e], p->edge_sigma[e], s->seed,
+                                            ORC_STREAM_EDGE(e), idx, 1));
     double effective = transit + ed->spike; /* edge.py:94-106, spike read at SEND time */
     sched(s, effective, PRIO_NORMAL, EV_EDGE_TIMEOUT, r, 0);
 }

@@ -53,6 +53,8 @@ def lib() -> C.CDLL:
         L.orc_x_poisson.restype = C.c_int64
         L.orc_x_variate.argtypes = [C.c_int, C.c_double, C.c_double, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
         L.orc_x_variate.restype = C.c_double
+        L.orc_set_test_quantum.argtypes = [C.c_int]
+        L.orc_set_test_quantum.restype = None
         L.orc_last_ties.argtypes = []
         L.orc_last_ties.restype = C.c_uint64
         L.orc_last_heap_events.argtypes = []
@@ -165,3 +167,9 @@ def simulate(
         ties=int(L.orc_last_ties()),
         heap_events=int(L.orc_last_heap_events()),
     )
+
+
+def set_test_quantum(bits: int) -> None:
+    """TEST-ONLY: round every latency / arrival gap down to a multiple of 2**-bits s (0 = off) -- exact
+    timestamp ties by the thousand; tests/hostcheck has the same switch (build.set_test_quantum)."""
+    lib().orc_set_test_quantum(int(bits))

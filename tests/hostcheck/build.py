@@ -57,6 +57,8 @@ def lib() -> C.CDLL:
             C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32,
         ]
         L.hc_flow_simulate.restype = C.c_int
+        L.hc_set_test_quantum.argtypes = [C.c_int]
+        L.hc_set_test_quantum.restype = None
         L.hc_flow_reason.argtypes = []
         L.hc_flow_reason.restype = C.c_char_p
         L.hc_flow_lds_bytes.argtypes = [C.POINTER(_abi.AfPlan), C.c_uint32, C.c_uint32]
@@ -99,13 +101,15 @@ FLOW_FALLBACK = 1 << 8
 FLOW_WHY = {1 << 9: "tie", 1 << 10: "list", 1 << 11: "ring", 1 << 12: "ram"}
 
 
-def flow_simulate(plan: DevicePlan, seed: int, *, ipl: int = 1, ring_rows: int = 64,
+def flow_simulate(plan: DevicePlan, seed: int, *, ipl: int = 1, ring_rows: int = 64, robust: bool = False,
                   overrides: list[tuple[str, int, float]] | None = None, clock_capacity: int | None = None,
                   draw_capacity: int | None = None):
     """Run one scenario through the stage-parallel kernel (af_flow.hpp) on the 64-fibre wave emulator.
 
     Returns (counts, clock, samples) like :func:`simulate`, or ``None`` when the plan is not eligible
-    (``flow_reason()`` says why).  ``counts[CNT_FLAGS] & FLOW_FALLBACK``: the kernel handed the scenario
+    (``flow_reason()`` says why).  ``robust``: the second-chance instantiation (256-entry lists that carry the
+    send times: equal delivery times at a station are ordered like SimPy orders them).
+    ``counts[CNT_FLAGS] & FLOW_FALLBACK``: the kernel handed the scenario
     back to the sequential kernels (outputs are then incomplete)."""
     L = lib()
     cplan = plan.as_ctypes()
@@ -121,7 +125,7 @@ def flow_simulate(plan: DevicePlan, seed: int, *, ipl: int = 1, ring_rows: int =
     u32p, f64p = C.POINTER(C.c_uint32), C.POINTER(C.c_double)
     rc = L.hc_flow_simulate(
         C.byref(cplan), C.c_uint64(seed), len(ov), params.ctypes.data_as(u32p), idxs.ctypes.data_as(u32p),
-        vals.ctypes.data_as(f64p), ipl, ring_rows, ccap, clock.ctypes.data_as(f64p), ticks,
+        vals.ctypes.data_as(f64p), ipl | (0x100 if robust else 0), ring_rows, ccap, clock.ctypes.data_as(f64p), ticks,
         samples.ctypes.data_as(u32p), counts.ctypes.data_as(u32p),
         int(draw_capacity if draw_capacity is not None else plan.clock_capacity()),
     )
@@ -137,3 +141,8 @@ def flow_simulate(plan: DevicePlan, seed: int, *, ipl: int = 1, ring_rows: int =
 
 def flow_reason() -> str:
     return (lib().hc_flow_reason() or b"").decode()
+
+
+def set_test_quantum(bits: int) -> None:
+    """TEST-ONLY tie generator of the host builds (asyncflow_amd/csrc/af_math.hpp::test_quant)."""
+    lib().hc_set_test_quantum(int(bits))

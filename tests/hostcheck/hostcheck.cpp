@@ -124,6 +124,7 @@ extern "C" int hc_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ovr, co
 }
 
 extern "C" void hc_set_two_pass(int on) { g_two_pass = on; }
+extern "C" void hc_set_test_quantum(int bits) { af::g_test_quantum_bits = bits; }   // af_math.hpp: test-only tie generator
 extern "C" void hc_set_online(uint32_t* hist, uint32_t bins, double hist_max, uint32_t* rps, uint32_t buckets) {
     g_online_hist = hist;
     g_online_bins = bins;
@@ -153,6 +154,9 @@ extern "C" int hc_flow_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ov
                                 uint32_t clock_cap, double* clock, uint32_t tick_cap, uint32_t* samples, uint32_t* counts,
                                 uint32_t draw_cap) {
     if (!p || p->abi_version != AF_ABI_VERSION || p->struct_size != sizeof(af_plan_t)) return AF_ERR_ABI;
+    const bool robust = (ipl & 0x100u) != 0u;   // the second-chance instantiation: 256 entries + send times
+    ipl &= 0xFFu;
+    if (robust) ipl = 4;
     if (ipl != 1 && ipl != 2 && ipl != 4) return AF_ERR_INVALID;
     g_flow_reason = aff::flow_ineligible_reason(*p);
     if (!g_flow_reason.empty()) return 1;
@@ -205,6 +209,10 @@ extern "C" int hc_flow_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ov
     a.blob_bytes = (uint32_t)(pk.words.size() * 8u);
     a.blob = reinterpret_cast<const unsigned char*>(pk.words.data());
     a.L = aff::choose_flow_layout(*p, ipl, ring_rows);
+    if (robust) {
+        a.L = aff::make_flow_layout(256u, a.L.ring_rows, a.L.g_ring, a.L.c_ring, p->n_edges, p->n_servers, p->n_edge_marks, true);
+        a.L.win_rows = a.L.ring_rows / 2u;
+    }
     a.tick_t = tt.t.data();
     a.n_ticks = (uint32_t)tt.t.size();
     a.n_scen = 1;
@@ -235,7 +243,8 @@ extern "C" int hc_flow_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ov
     // the instantiation the engine would launch: the lean one when the launch needs none of the optional features
     const bool lean = p->n_edge_marks == 0 && p->n_srv_marks == 0 && !g_online_hist && !g_online_rps && (a.L.ring_rows != 0 || !samples);
     auto body = [&]() {
-        if (ipl == 1 && lean) { aff::Flow<emu::WaveEmu, 1, 0u> f(a); f.run(lds.data(), 0u); }
+        if (robust) { aff::Flow<emu::WaveEmu, 4, aff::FEAT_ALL | aff::FEAT_TIEBREAK> f(a); f.run(lds.data(), 0u); }
+        else if (ipl == 1 && lean) { aff::Flow<emu::WaveEmu, 1, 0u> f(a); f.run(lds.data(), 0u); }
         else if (ipl == 1) { aff::Flow<emu::WaveEmu, 1> f(a); f.run(lds.data(), 0u); }
         else if (ipl == 2 && lean) { aff::Flow<emu::WaveEmu, 2, 0u> f(a); f.run(lds.data(), 0u); }
         else if (ipl == 2) { aff::Flow<emu::WaveEmu, 2> f(a); f.run(lds.data(), 0u); }

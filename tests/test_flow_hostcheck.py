@@ -119,3 +119,43 @@ def test_fuzzed_feed_forward_payloads_are_exact_or_handed_back(block):
         status, _ = _run(flow_payload(rng, horizon=6), 900 + case, ipl=4, ring_rows=1024)
         exact += status == "exact"
     assert exact >= 4, f"only {exact} of 25 fuzzed payloads ran on the flow kernel"
+
+
+@pytest.fixture
+def quantised_times():
+    """TEST-ONLY switch of the oracle and of the host builds: latencies and arrival gaps rounded down to a multiple
+    of 2**-bits s, so that exact timestamp ties happen by the thousand (with continuous laws: ~1e-6 per scenario)."""
+    def switch(bits: int) -> None:
+        hc.set_test_quantum(bits)
+        ol.set_test_quantum(bits)
+    yield switch
+    switch(0)
+
+
+@pytest.mark.parametrize("bits", [12, 16])
+def test_exact_ties_by_the_thousand_follow_simpy_order(quantised_times, bits):
+    """Equal delivery times at a station, deliveries at their own send instant, arrivals on core / RAM releases, events on
+    ticks: the lean instantiation hands such scenarios back; the second-chance instantiation (messages carry their send
+    time) orders two deliveries of one station the way SimPy pops them -- by creation of their Timeouts = by send time --
+    and must then equal the SimPy-faithful oracle bit for bit.  Never a silent difference in either."""
+    quantised_times(bits)
+    cases = [(lb_two_servers(horizon=15), s) for s in range(4)] + [(lb_with_events(users=300, horizon=30, scale=0.05), 7)]
+    cases += [(single_server(horizon=20), 3), (fanout8(horizon=15), 5)]
+    cases += [(flow_payload(random.Random(31000 + k), horizon=5), 900 + k) for k in range(24)]
+    ties = resolved = 0
+    for payload, seed in cases:
+        plan = lower(payload)
+        want = ol.simulate(plan, seed, clock_capacity=4 * plan.clock_capacity())
+        if int(want.counts[_abi.CNT_FLAGS]) & _abi.FATAL_FLAGS:
+            continue
+        ties += int(ol.lib().orc_last_ties())
+        for kw in (dict(ipl=2, ring_rows=256), dict(robust=True, ring_rows=0)):
+            counts, clock, samples = hc.flow_simulate(plan, seed, clock_capacity=4 * plan.clock_capacity(),
+                                                      draw_capacity=4 * plan.clock_capacity(), **kw)
+            if int(counts[_abi.CNT_FLAGS]) & (hc.FLOW_FALLBACK | _abi.FATAL_FLAGS):
+                continue
+            assert np.array_equal(want.counts[:5].astype(np.uint32), counts[:5]), (seed, kw)
+            assert np.array_equal(want.clock.view(np.uint64), clock.view(np.uint64)), (seed, kw)
+            assert np.array_equal(want.samples, samples), (seed, kw)
+            resolved += bool(kw.get("robust"))
+    assert ties > 2_000 and resolved >= 5, (ties, resolved)

@@ -73,6 +73,8 @@ def test_tick_ring_placement_does_not_change_results(ring_rows):
     assert st.flow_scenarios == 96
     if ring_rows == _abi.FLOW_RING_IN_HBM:
         assert st.flow_ring_rows == 0 and st.flow_fallback == 0
+    if ring_rows == 16:      # 0.8 s of ring against 0.75-s spikes: handed back, re-run with the differences in HBM
+        assert st.flow_fallback_ring > 0 and st.flow_retried == st.flow_fallback and st.flow_to_next_event == 0
     _same_batches(res, _runner(payload, seeds=seeds, flow=False).run())
 
 
@@ -86,7 +88,8 @@ def test_fanout_uses_larger_lists_and_hbm_differences():
     for i in (0, 17, 39):
         _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])), f"scenario {i}")
     small = _runner(payload, seeds=seeds, flow_list_entries=64).run()     # ~40 messages in flight per edge: lists overflow
-    assert small.engine_stats.flow_fallback_list > 0
+    st = small.engine_stats
+    assert st.flow_fallback_list > 0 and st.flow_retried == st.flow_fallback and st.flow_to_next_event == 0   # second chance: 256-entry lists
     _same_batches(res, small)
 
 
@@ -101,11 +104,12 @@ def test_handed_back_scenarios_are_invisible_in_the_results():
         res = _runner(payload, seeds=seeds).run()
         st = res.engine_stats
         assert st.flow_scenarios == 5
-        handed_back += st.flow_fallback
-        ran += 5 - st.flow_fallback
+        handed_back += st.flow_to_next_event
+        ran += 5 - st.flow_to_next_event
+        assert st.flow_retried <= st.flow_fallback and st.flow_to_next_event <= st.flow_fallback
         _same_batches(res, _runner(payload, seeds=seeds, flow=False).run())
         _assert_scenario(res[0], ol.simulate(lower(payload), int(seeds[0])), f"case {case}")
-    assert handed_back > 10 and ran > 20
+    assert handed_back > 5 and ran > 20
 
 
 def test_single_server_and_sweep_columns():
@@ -251,3 +255,13 @@ def test_statistical_parity_with_the_numpy_seeded_reference():
 def test_grid_columns_helper_matches_survey_definition():
     a, b = grid_users_rtt(100)
     assert a.size == 10_000 and a.min() == 10.0 and a.max() == 1000.0 and b.min() == 0.0005 and abs(b.max() - 0.05) < 1e-15
+
+
+def test_a_delivery_that_does_not_advance_the_clock_stays_on_the_flow_kernel():
+    """Replica 101 670 of the BASELINE seed range draws an exponential transit time below half an ulp of the clock: the
+    delivery happens at its own send instant.  That is an event of the NEXT station (it commutes with the sender's);
+    round 2's first version handed the scenario back for it (1.1 s on a next-event kernel)."""
+    seed = 0x5EED0000 + 101_670
+    res = _runner(lb_two_servers(), seeds=[seed, seed + 1]).run()
+    assert res.engine_stats.flow_scenarios == 2 and res.engine_stats.flow_fallback == 0
+    _assert_scenario(res[0], ol.simulate(lower(lb_two_servers()), seed))
