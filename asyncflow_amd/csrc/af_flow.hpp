@@ -99,7 +99,7 @@ inline FlowLayout make_flow_layout(uint32_t cap, uint32_t ring_rows, uint32_t g_
     if (w < scratch0 + 5u * 64u) w = scratch0 + 5u * 64u;
     L.off_fr = w; w += n_servers * c_ring;
     L.off_gr = w; w += n_servers * g_ring;
-    L.off_cnt = w; w += (n_edges + 1u) / 2u + 24u;      // u32 sends per edge; 48 u32: lb order, head, n_live, mark cursor, per-server counters
+    L.off_cnt = w; w += (n_edges + 1u) / 2u + 28u;      // u32 sends per edge; 56 u32: lb order, head, n_live, mark cursor, per-server counters
     L.off_ring = w; w += (ring_rows * L.pitch + 1u) / 2u;
     L.n_words = w;
     return L;
@@ -110,6 +110,7 @@ struct FlowArgs {
     double total_time, sample_period, inv_period, tick_eps;
     uint32_t metrics_mask, gen_out_edge, client_out_edge;
     uint32_t n_edges, n_servers, has_lb, n_lb_edges, n_edge_marks, n_srv_marks;
+    uint32_t max_pre, max_cpu, max_post;   // longest leading-I/O / CPU / trailing-I/O run over the servers' endpoints
     uint32_t off_edge, off_srv, off_ep, off_row, off_emark, off_smark, off_lb;  // word offsets in the blob
     uint32_t blob_bytes;
     const unsigned char* blob;
@@ -222,7 +223,7 @@ struct Flow {
     AF_CORE AF_PLAN_AS double* fr(uint32_t sv) const { return (AF_PLAN_AS double*)(M + A.L.off_fr) + sv * A.L.c_ring; }
     AF_CORE AF_PLAN_AS double* gr(uint32_t sv) const { return (AF_PLAN_AS double*)(M + A.L.off_gr) + sv * A.L.g_ring; }
     AF_CORE AF_PLAN_AS uint32_t* sends() const { return (AF_PLAN_AS uint32_t*)(M + A.L.off_cnt); }
-    AF_CORE AF_PLAN_AS uint32_t* lbw() const { return sends() + ((A.n_edges + 1u) & ~1u); }  // [0..15] order, 16 head, 17 n_live, 18 mark cursor, [24..31] arrivals per server, [32..39] / [40..47] segment start / length
+    AF_CORE AF_PLAN_AS uint32_t* lbw() const { return sends() + ((A.n_edges + 1u) & ~1u); }  // [0..15] order, 16 head, 17 n_live, 18 mark cursor, [24..31] arrivals per server, [32..39] / [40..47] segment start / length, [48..55] step counts (leading I/O | CPU << 8 | trailing I/O << 16)
     AF_CORE AF_PLAN_AS int32_t* ring() const { return (AF_PLAN_AS int32_t*)(M + A.L.off_ring); }
     AF_CORE AF_PLAN_AS double* spike_cum() const { return (AF_PLAN_AS double*)(M + A.L.off_spike); }
 
@@ -594,36 +595,34 @@ struct Flow {
         double adm, b, s, f, g;
         uint32_t events;   // step ends before the horizon
     };
-    AF_CORE SrvTimes srv_program(uint32_t row0, double arrival, double g_prev, double f_prev) const {
+    // (the loops run to the plan-wide maxima with the lane's own counts as predicates: wave-uniform loop control
+    // instead of three per-lane while loops)
+    AF_CORE SrvTimes srv_program(uint32_t row0, uint32_t counts, double arrival, double g_prev, double f_prev) const {
         SrvTimes r;
         const double T = A.total_time;
+        const uint32_t n_pre = counts & 0xFFu, n_cpu = (counts >> 8) & 0xFFu, n_post = (counts >> 16) & 0xFFu;
         r.adm = g_prev > arrival ? g_prev : arrival;
-        uint32_t row = row0;
         double t = r.adm;
         uint32_t e_cnt = 0u;
-        uint32_t kind = (uint32_t)blob[A.off_row + af::TREC * row + 2u];
-        while (kind == af::STEP_IO) {   // leading I/O steps
-            t = t + u2d(blob[A.off_row + af::TREC * row]);
-            e_cnt += t < T ? 1u : 0u;
-            kind = (uint32_t)blob[A.off_row + af::TREC * (++row) + 2u];
-        }
-        r.b = t;
-        r.s = t;
-        if (kind == af::STEP_CPU) {
-            r.s = f_prev > t ? f_prev : t;
-            t = r.s;
-            while (kind == af::STEP_CPU) {
-                t = t + u2d(blob[A.off_row + af::TREC * row]);
+        for (uint32_t i = 0u; i < A.max_pre; ++i)   // leading I/O steps
+            if (i < n_pre) {
+                t = t + u2d(blob[A.off_row + af::TREC * (row0 + i)]);
                 e_cnt += t < T ? 1u : 0u;
-                kind = (uint32_t)blob[A.off_row + af::TREC * (++row) + 2u];
             }
-        }
+        r.b = t;
+        if (n_cpu > 0u && f_prev > t) t = f_prev;
+        r.s = t;
+        for (uint32_t i = 0u; i < A.max_cpu; ++i)
+            if (i < n_cpu) {
+                t = t + u2d(blob[A.off_row + af::TREC * (row0 + n_pre + i)]);
+                e_cnt += t < T ? 1u : 0u;
+            }
         r.f = t;
-        while (kind == af::STEP_IO) {   // trailing I/O steps
-            t = t + u2d(blob[A.off_row + af::TREC * row]);
-            e_cnt += t < T ? 1u : 0u;
-            kind = (uint32_t)blob[A.off_row + af::TREC * (++row) + 2u];
-        }
+        for (uint32_t i = 0u; i < A.max_post; ++i)  // trailing I/O steps
+            if (i < n_post) {
+                t = t + u2d(blob[A.off_row + af::TREC * (row0 + n_pre + n_cpu + i)]);
+                e_cnt += t < T ? 1u : 0u;
+            }
         r.g = t;
         r.events = e_cnt;
         return r;
@@ -662,7 +661,8 @@ struct Flow {
                 if (!(gq < a)) why |= FLOW_WHY_RAM;
             }
         }
-        SrvTimes r = srv_program(row0, a, g_prev, f_prev);
+        const uint32_t prog = lw[48u + sv];
+        SrvTimes r = srv_program(row0, prog, a, g_prev, f_prev);
         for (;;) {
             if (have) {
                 seg(3)[pos] = r.f;
@@ -676,7 +676,7 @@ struct Flow {
                 if (gp != g_prev || fp != f_prev) {
                     g_prev = gp;
                     f_prev = fp;
-                    const SrvTimes n = srv_program(row0, a, g_prev, f_prev);
+                    const SrvTimes n = srv_program(row0, prog, a, g_prev, f_prev);
                     changed = n.f != r.f || n.g != r.g;
                     r = n;
                 }
@@ -764,6 +764,18 @@ struct Flow {
                 spike_cum()[i] = acc + u2d(emark(i)[1]);
             }
             AF_PLAN_AS uint32_t* lw = lbw();
+            for (uint32_t v = 0u; v < A.n_servers; ++v) {   // step counts of each server's (only) endpoint: IO* CPU* IO*
+                const uint32_t ep = (uint32_t)(blob[A.off_srv + af::SREC * v + 1u] >> 32) & 0xFFFFu;
+                uint32_t row = (uint32_t)blob[A.off_ep + af::PREC * ep + 1u], cnt[3] = {0u, 0u, 0u}, phase = 0u;
+                for (;; ++row) {
+                    const uint32_t kind = (uint32_t)blob[A.off_row + af::TREC * row + 2u];
+                    if (kind == af::STEP_END) break;
+                    if (phase == 0u && kind == af::STEP_CPU) phase = 1u;
+                    else if (phase == 1u && kind == af::STEP_IO) phase = 2u;
+                    cnt[phase] += 1u;
+                }
+                lw[48u + v] = cnt[0] | (cnt[1] << 8) | (cnt[2] << 16);
+            }
             for (uint32_t i = 0u; i < A.n_lb_edges; ++i) lw[i] = (uint32_t)blob[A.off_lb + i];
             lw[16] = 0u;
             lw[17] = A.n_lb_edges;

@@ -75,6 +75,24 @@ inline TickTable make_tick_table(double period, double total_time) {
     return tt;
 }
 
+// longest leading-I/O / CPU / trailing-I/O run over the servers' endpoints (eligible plans: IO* CPU* IO*)
+inline void flow_step_maxima(const af_plan_t& p, uint32_t& max_pre, uint32_t& max_cpu, uint32_t& max_post) {
+    max_pre = max_cpu = max_post = 0;
+    for (uint32_t s = 0; s < p.n_servers; ++s) {
+        const uint32_t ep = p.srv_ep_begin[s];
+        uint32_t cnt[3] = {0, 0, 0}, phase = 0;
+        for (uint32_t i = p.ep_step_begin[ep]; i < p.ep_step_begin[ep + 1]; ++i) {
+            const bool cpu = p.step_kind[i] == AF_STEP_CPU;
+            if (phase == 0 && cpu) phase = 1;
+            else if (phase == 1 && !cpu) phase = 2;
+            cnt[phase] += 1;
+        }
+        if (cnt[0] > max_pre) max_pre = cnt[0];
+        if (cnt[1] > max_cpu) max_cpu = cnt[1];
+        if (cnt[2] > max_post) max_post = cnt[2];
+    }
+}
+
 inline uint32_t pow2_ge(uint32_t v) {
     uint32_t p = 1;
     while (p < v) p <<= 1;

@@ -875,6 +875,7 @@ int af_engine_create(const af_plan_t* plan, int device, const af_engine_options_
         f.n_lb_edges = plan->n_lb_edges;
         f.n_edge_marks = plan->n_edge_marks;
         f.n_srv_marks = plan->n_srv_marks;
+        aff::flow_step_maxima(*plan, f.max_pre, f.max_cpu, f.max_post);
         f.off_edge = pk.off_edge; f.off_srv = pk.off_srv; f.off_ep = pk.off_ep; f.off_row = pk.off_row;
         f.off_emark = pk.off_emark; f.off_smark = pk.off_smark; f.off_lb = pk.off_lb;
         f.blob_bytes = a.blob_bytes;

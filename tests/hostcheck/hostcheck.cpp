@@ -204,6 +204,7 @@ extern "C" int hc_flow_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ov
     a.n_lb_edges = p->n_lb_edges;
     a.n_edge_marks = p->n_edge_marks;
     a.n_srv_marks = p->n_srv_marks;
+    aff::flow_step_maxima(*p, a.max_pre, a.max_cpu, a.max_post);
     a.off_edge = pk.off_edge; a.off_srv = pk.off_srv; a.off_ep = pk.off_ep; a.off_row = pk.off_row;
     a.off_emark = pk.off_emark; a.off_smark = pk.off_smark; a.off_lb = pk.off_lb;
     a.blob_bytes = (uint32_t)(pk.words.size() * 8u);
