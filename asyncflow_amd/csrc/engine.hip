@@ -25,6 +25,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -370,10 +371,15 @@ __device__ __forceinline__ double ovr_or(const KArgs& a, uint32_t param, uint32_
 // the next index is the new window's user draw) or the horizon ends the batch.
 // Block b pre-generates for scenarios scen_map[4 b + g] (null = 4 b + g) into slots 4 b + g.  `stride` =
 // doubles per slot (n_draw when only the arrivals are wanted: the flow kernel; (1 + n_edges) * n_draw otherwise).
+// G = lanes per scenario (16, 12 or 8: 4, 5 or 8 scenarios per wave).  The kernel is bound by instruction issue per
+// SIMD, so its time is (waves on the fullest SIMD) x (work of a wave): 2 500 waves of 4 scenarios on 1 024 SIMDs take
+// the time of 3 waves, 2 000 waves of 5 scenarios the time of 2 slightly longer ones (af_engine_run picks G).
+template <uint32_t G>
 __global__ void __launch_bounds__(64) af_pregen_arrivals(const KArgs a, uint32_t stride) {
-    const uint32_t lane = threadIdx.x, l = lane & 15u, gbase = lane & ~15u;
-    const uint32_t slot = blockIdx.x * 4u + (lane >> 4);
-    const bool valid = slot < a.n_scen;
+    constexpr uint32_t S = 64u / G;                     // scenarios per wave (lanes >= S * G idle)
+    const uint32_t lane = threadIdx.x, grp = lane / G, l = lane - grp * G, gbase = grp * G;
+    const uint32_t slot = blockIdx.x * S + grp;
+    const bool valid = grp < S && slot < a.n_scen;
     const uint32_t scen = valid ? (a.scen_map ? a.scen_map[slot] : slot) : 0u;
     const uint64_t seed = a.seeds[scen];
     const double users_mean = ovr_or(a, af::PARAM_GEN_USERS_MEAN, 0u, scen, a.gen_users_mean);
@@ -382,7 +388,7 @@ __global__ void __launch_bounds__(64) af_pregen_arrivals(const KArgs a, uint32_t
     const double rps_per_user = rpm / 60.0;
     const double T = a.total_time;
     double* out = a.draws + (size_t)slot * stride;  // stream 0 of this slot
-    double g_now = 0.0, g_wend = 0.0, lam = 0.0, t = 0.0;  // identical in the 16 lanes of a group
+    double g_now = 0.0, g_wend = 0.0, lam = 0.0, t = 0.0;  // identical in the G lanes of a group
     uint32_t draws = 0u, k = 0u, flags = 0u;
     bool run = valid;
     while (__any(run)) {
@@ -402,46 +408,46 @@ __global__ void __launch_bounds__(64) af_pregen_arrivals(const KArgs a, uint32_t
         const bool idle = run && lam <= 0.0;   // nobody active in this window
         if (idle) g_now = g_wend;
         const bool draw = run && !idle;
-        // 16 gaps of this scenario (lanes of scenarios that do not draw compute a harmless dummy)
+        // G gaps of this scenario (lanes of scenarios that do not draw compute a harmless dummy)
         const af::U4 r = af::draw_block(seed, af::STREAM_GENERATOR, draws + l, 0u);
         double u = af::u53(r.x, r.y);
         if (u < 1e-15) u = 1e-15;
         const double dt = -af::af_log(1.0 - u) / (draw ? lam : 1.0);
-        // prefixes in draw order: G = sampler clock after gap l, S = simulation clock after gap l
-        double G = g_now, S = t;
+        // prefixes in draw order: Gs = sampler clock after gap l, Ss = simulation clock after gap l
+        double Gs = g_now, Ss = t;
 #pragma unroll
-        for (uint32_t j = 0u; j < 16u; ++j) {
-            const double dj = __shfl(dt, (int)(gbase + j), 64);
+        for (uint32_t j = 0u; j < G; ++j) {
+            const double dj = __shfl(dt, (int)((gbase + j) & 63u), 64);
             if (l >= j) {
-                G += dj;
-                S = S + dj;
+                Gs += dj;
+                Ss = Ss + dj;
             }
         }
-        const bool over = G > T;                 // the sampler is exhausted at this draw
-        const bool cross = !over && G >= g_wend; // this draw crosses the window end: discarded
+        const bool over = Gs > T;                  // the sampler is exhausted at this draw
+        const bool cross = !over && Gs >= g_wend;  // this draw crosses the window end: discarded
         const uint64_t stops = __ballot(draw && (over || cross));
-        const uint32_t mine = (uint32_t)(stops >> gbase) & 0xFFFFu;
-        const uint32_t first = mine ? (uint32_t)__builtin_ctz(mine) : 16u;   // draws before it are arrivals
+        const uint32_t mine = (uint32_t)(stops >> (gbase & 63u)) & ((1u << G) - 1u);
+        const uint32_t first = mine ? (uint32_t)__builtin_ctz(mine) : G;   // draws before it are arrivals
         uint32_t n_acc = first;
         bool full = false;
         if (draw && k + n_acc > a.n_draw) {  // more arrivals than the array holds
             n_acc = a.n_draw - k;
             full = true;
         }
-        if (draw && l < n_acc) out[k + l] = S;
+        if (draw && l < n_acc) out[k + l] = Ss;
         // the group's state after the batch
-        const double G15 = __shfl(G, (int)(gbase + 15u), 64), S15 = __shfl(S, (int)(gbase + 15u), 64);
-        const double Sprev = __shfl(S, (int)(gbase + (first > 0u ? first - 1u : 0u)), 64);
-        const bool over_first = ((__ballot(over) >> gbase) >> (first & 15u)) & 1ull;
+        const double Glast = __shfl(Gs, (int)((gbase + G - 1u) & 63u), 64), Slast = __shfl(Ss, (int)((gbase + G - 1u) & 63u), 64);
+        const double Sprev = __shfl(Ss, (int)((gbase + (first > 0u ? first - 1u : 0u)) & 63u), 64);
+        const bool over_first = ((__ballot(over) >> (gbase & 63u)) >> (first % G)) & 1ull;
         if (draw) {
             k += n_acc;
             if (full) {
                 flags = AF_FLAG_DRAW_OVERFLOW;
                 run = false;
-            } else if (first == 16u) {
-                g_now = G15;
-                t = S15;
-                draws += 16u;
+            } else if (first == G) {
+                g_now = Glast;
+                t = Slast;
+                draws += G;
             } else {
                 if (first > 0u) t = Sprev;
                 draws += first + 1u;
@@ -451,9 +457,35 @@ __global__ void __launch_bounds__(64) af_pregen_arrivals(const KArgs a, uint32_t
         }
     }
     if (valid) {
-        for (uint32_t i = k + l; i < a.n_draw; i += 16u) out[i] = af::AF_INF;
+        for (uint32_t i = k + l; i < a.n_draw; i += G) out[i] = af::AF_INF;
         if (l == 0u) a.pre_flags[slot] = flags;
     }
+}
+
+// launch helper: the group width with the shortest issue-bound time for `n` scenarios (see the kernel's comment).
+// Measured (10 000 / 8 192 LB-2 replicas): 4 per wave 15.2 / 9.5 ms, 5 per wave 11.7 / -, 8 per wave - / 15.1 ms (one wave
+// per SIMD: nothing hides its latencies).  More than 4 per wave only when the SIMDs still get ~2 waves each and the
+// scenarios are alike (`uniform_load`: no per-scenario users / rpm column -- a wave is as slow as its heaviest scenario).
+static void launch_pregen_arrivals(const KArgs& a, uint32_t n, uint32_t stride, bool uniform_load, hipStream_t stream) {
+    double best = 1e300;
+    uint32_t best_s = 4u;
+    for (uint32_t s : {4u, 5u, 8u}) {
+        const double waves = std::ceil((double)n / (double)s);
+        if (s != 4u && (!uniform_load || waves / 1024.0 < 1.9)) continue;
+        const double cost = std::ceil(waves / 1024.0) * (4.06 * (double)s + 8.0);
+        if (cost < best - 1e-9) {
+            best = cost;
+            best_s = s;
+        }
+    }
+    if (const char* env = std::getenv("AF_PREGEN_SCEN_PER_WAVE")) {
+        const uint32_t v = (uint32_t)std::atoi(env);
+        if (v == 4u || v == 5u || v == 8u) best_s = v;
+    }
+    const dim3 grid((n + best_s - 1u) / best_s);
+    if (best_s == 4u) hipLaunchKernelGGL(af_pregen_arrivals<16>, grid, dim3(64), 0, stream, a, stride);
+    else if (best_s == 5u) hipLaunchKernelGGL(af_pregen_arrivals<12>, grid, dim3(64), 0, stream, a, stride);
+    else hipLaunchKernelGGL(af_pregen_arrivals<8>, grid, dim3(64), 0, stream, a, stride);
 }
 
 // second pass: the online counters of the scenarios that start over are cleared first
@@ -1118,6 +1150,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     }
 
     const size_t tie_words = a.L.tie_words;
+    const bool hetero_load = (mask & ((1u << AF_PARAM_GEN_USERS_MEAN) | (1u << AF_PARAM_GEN_RPM_MEAN))) != 0u;
     // One launch of the next-event kernel over `count` scenarios (all of the chunk, or the ones listed in `map`).
     auto launch_des = [&](uint32_t count, bool faithful) -> int {
         choose_lanes(e, count, a.blob_bytes, bytes_per_lane, kl, lds_state);
@@ -1190,8 +1223,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
             }
             a.n_scen = cnt;
             HIP_TRY(hipEventRecord(e->ev2, e->stream));
-            hipLaunchKernelGGL(af_pregen_arrivals, dim3((cnt + 3u) / 4u), dim3(64), 0, e->stream, a,
-                               (uint32_t)((1u + a.n_edges) * n_draw));
+            launch_pregen_arrivals(a, cnt, (uint32_t)((1u + a.n_edges) * n_draw), !hetero_load, e->stream);
             hipLaunchKernelGGL(af_pregen_edges, dim3((n_draw + 255u) / 256u, cnt, a.n_edges), dim3(256), 0, e->stream, a);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(e->ev3, e->stream));
@@ -1284,7 +1316,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
         a.draws = e->d_arr;
         a.pre_flags = e->d_arr_flags;
         HIP_TRY(hipEventRecord(e->ev2, e->stream));
-        hipLaunchKernelGGL(af_pregen_arrivals, dim3((nc + 3u) / 4u), dim3(64), 0, e->stream, a, n_draw);
+        launch_pregen_arrivals(a, nc, n_draw, !hetero_load, e->stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(e->ev3, e->stream));
         aff::FlowArgs f = e->fargs;

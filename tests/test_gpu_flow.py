@@ -268,3 +268,21 @@ def test_a_delivery_that_does_not_advance_the_clock_stays_on_the_flow_kernel():
     res = _runner(lb_two_servers(), seeds=[seed, seed + 1]).run()
     assert res.engine_stats.flow_scenarios == 2 and res.engine_stats.flow_fallback == 0
     _assert_scenario(res[0], ol.simulate(lower(lb_two_servers()), seed))
+
+
+@pytest.mark.parametrize("per_wave", [4, 5, 8])
+def test_arrival_pregeneration_group_widths_are_equivalent(monkeypatch, per_wave):
+    """af_pregen_arrivals packs 4, 5 or 8 scenarios into a wave (16 / 12 / 8 lanes each; the engine picks by sweep size):
+    same arrival times whichever it is -- tiny sampling windows (window ends inside most batches), Gaussian users, a
+    scenario count that leaves the last wave ragged."""
+    monkeypatch.setenv("AF_PREGEN_SCEN_PER_WAVE", str(per_wave))
+    payload = lb_two_servers(horizon=40)
+    payload["rqs_input"]["user_sampling_window"] = 1
+    payload["rqs_input"]["avg_active_users"] = {"mean": 150, "distribution": "normal", "variance": 60}
+    seeds = np.arange(37, dtype=np.uint64) + 5000
+    res = _runner(payload, seeds=seeds).run()
+    plan = lower(payload)
+    for i in (0, 4, 5, 17, 36):
+        _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])), f"{per_wave} per wave, scenario {i}")
+    want = np.array([ol.simulate(plan, int(s), want_clock=False, want_samples=False).counts[:5] for s in seeds])
+    assert np.array_equal(res.counts[:, :5].astype(np.uint64), want)
