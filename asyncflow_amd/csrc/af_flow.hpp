@@ -58,8 +58,6 @@ enum : uint32_t {
     FLOW_WHY_MASK = FLOW_WHY_TIE | FLOW_WHY_LIST | FLOW_WHY_RING | FLOW_WHY_RAM,
 };
 constexpr uint32_t kMaxServers = 8;    // lane k < n_servers runs server k's core / RAM recurrence
-constexpr uint32_t kMaxSteps = 8;      // CPU + I/O steps of an endpoint
-constexpr uint32_t kWave = 64;
 
 // LDS layout behind the plan blob, in 8-byte words; computed on the host (make_flow_layout).
 struct FlowLayout {

@@ -1,24 +1,25 @@
 // engine.hip -- MI355X (gfx950) batched discrete-event engine: kernels + C ABI.
 //
 // Kernels of one af_engine_run:
-//   af_pregen_arrivals / af_pregen_edges   every random draw of every scenario, up front, at full
-//                                          occupancy, into HBM: draws[scenario][stream][index]
-//   af_des_kernel<LDS?, SimPy-order path?, log2 lanes, waves/SIMD>
-//                                          the sequential next-event loop: one scenario per lane,
-//                                          one wave per workgroup, only the first 2^KLOG lanes of a
-//                                          wave carry scenarios (few scenarios -> many narrow waves);
-//                                          each wave free-runs af::Lane::round() (af_core.hpp) until
-//                                          every lane reached the horizon; waves share nothing
+//   af_pregen_arrivals<G>                  arrival times of every scenario (the windowed sampler), 64 / G scenarios per
+//                                          wave, into HBM: arrivals[scenario][index]
+//   af_flow_kernel<IPL, FEAT>              stage-parallel kernel (af_flow.hpp): ONE WAVE PER SCENARIO moves up to 64
+//                                          requests per step through the stations of a feed-forward request path;
+//                                          every other random draw is produced where it is consumed.  Runs every plan
+//                                          in its range (af_engine_flow_reason); scenarios it hands back get a second
+//                                          chance on its most tolerant instantiation, then go to:
+//   af_pregen_edges + af_des_kernel<LDS?, SimPy-order path?, log2 lanes, waves/SIMD>
+//                                          the sequential next-event loop (af_core.hpp): one scenario per lane, one
+//                                          wave per workgroup, only the first 2^KLOG lanes of a wave carry scenarios;
+//                                          every edge draw pre-generated into HBM: draws[slot][stream][index]
 //   af_summary_kernel / af_series_kernel   af_engine_summarize: the analyzer (af_summary.hpp)
 //
 // Memory plan
-//   LDS  : [plan blob (read-only, shared by the lanes of the wave)]
-//          [per-lane state: 64-bit words, SoA [index][lane]]
-//          -> any per-lane index pattern is bank-conflict free
-//             (ds_read_b64: bank pair = 2*lane mod 64 within each 32-lane group).
-//   HBM  : pre-generated draws (read once), outputs (rqs_clock, sampled series, counts), the scratch
-//          of the shared-instant path; the per-lane state too when it does not fit the 160 KiB LDS
-//          of a CU ("global state" mode, same [index][lane] layout => coalesced for equal indices).
+//   LDS  : flow kernel: [plan blob, patched per scenario][station lists, select scratch / server segments, rings,
+//          counters, tick-difference ring] (aff::make_flow_layout); next-event kernels: [plan blob][per-lane state:
+//          64-bit words, SoA [index][lane]] -> any per-lane index pattern is bank-conflict free
+//   HBM  : arrival times / pre-generated draws (read once), outputs (rqs_clock, sampled series, counts), the scratch
+//          of the shared-instant path; the next-event per-lane state too when it does not fit the 160 KiB LDS of a CU
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see build.py).
 #include <hip/hip_runtime.h>
