@@ -90,6 +90,9 @@ def test_fanout_uses_larger_lists_and_hbm_differences():
     st = small.engine_stats
     assert st.flow_fallback_list > 0 and st.flow_retried == st.flow_fallback and st.flow_to_next_event == 0   # second chance: 256-entry lists
     _same_batches(res, small)
+    big = _runner(payload, seeds=seeds, flow_list_entries=256).run()      # the 4-entries-per-lane instantiation
+    assert big.engine_stats.flow_list_entries == 256 and big.engine_stats.flow_fallback == 0
+    _same_batches(res, big)
     ring = _runner(payload, seeds=seeds, flow_ring_rows=16).run()         # 0.8 s of LDS ring against ~1-s hops
     st = ring.engine_stats
     assert st.flow_fallback_ring > 0 and st.flow_retried == st.flow_fallback and st.flow_to_next_event == 0   # second chance: differences in HBM
