@@ -655,6 +655,9 @@ def main() -> int:  # noqa: C901, PLR0912, PLR0915
                 "traffic": None,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "bytes_per_event": alg_bytes / max(events_rank, 1.0),
+                "note": "achieved = SURVEY 8d's algorithmic bytes (80 B of per-event state traffic + outputs, a state-in-HBM model) / "
+                        "the dominant kernel's time; the kernel keeps that state in LDS, so the bytes it really moves are "
+                        "`traffic` (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE) and `frac_traffic` is the fraction of the HBM peak it uses",
                 "kernel": "af_flow_kernel" if flow_on else
                           "af_jit_lean (plan-specialised build of af_des_kernel)" if accs[-1]["jit"] else "af_des_kernel",
                 "kernel_ms": float(np.mean([a["flow_ms"] for a in accs])) if flow_on else k_ms,
