@@ -152,6 +152,8 @@ struct FlowArgs {
 //                                   (tick differences kept in HBM when the LDS ring would be too small)
 //   W::mbcnt(mask)                  popcount(mask & lanes below me)
 //   W::rcp(x)                       ~1/x (only ever used where the exact value does not matter)
+//   W::scan_incl_u32(v)             inclusive prefix sum over the lanes (DPP row shifts / broadcasts on the device)
+//   W::bcast32 / bcast64(v, lane)   value of a WAVE-UNIFORM lane (v_readlane on the device)
 // Every W:: call is made by all 64 lanes from wave-uniform control flow.
 // IPL = list entries per lane (list capacity = 64 * IPL).
 // FEAT = features compiled in (the host picks the leanest instantiation that covers the launch: every
@@ -231,15 +233,10 @@ struct Flow {
 
     // ---- small wave helpers ---------------------------------------------------------------------
     AF_CORE static uint32_t popc64(uint64_t m) { return (uint32_t)__builtin_popcountll(m); }
-    AF_CORE double bcast_f64(double v, uint32_t src) const { return u2d(W::shfl64(d2u(v), src)); }
+    AF_CORE double bcast_f64(double v, uint32_t src) const { return u2d(W::bcast64(d2u(v), src)); }   // src wave-uniform
     AF_CORE uint32_t excl_scan(uint32_t v, uint32_t& total) const {
-        uint32_t inc = v;
-#pragma unroll
-        for (uint32_t d = 1u; d < 64u; d <<= 1) {
-            const uint32_t o = W::shfl32(inc, lane >= d ? lane - d : lane);
-            if (lane >= d) inc += o;
-        }
-        total = W::shfl32(inc, 63u);
+        const uint32_t inc = W::scan_incl_u32(v);
+        total = W::bcast32(inc, 63u);
         return inc - v;
     }
     AF_CORE uint32_t wave_sum(uint32_t v) const {

@@ -282,12 +282,15 @@ struct WaveHip {
         const uint32_t lo = shfl32((uint32_t)v, src), hi = shfl32((uint32_t)(v >> 32), src);
         return ((uint64_t)hi << 32) | lo;
     }
-    // one wave per workgroup: LDS traffic of a wave is processed in order, the fences keep the
-    // compiler from moving LDS accesses of other lanes' data across this point
+    // One wave per workgroup: its LDS instructions execute in order, so "every lane's LDS writes are visible to every
+    // lane" needs no hardware wait beyond the data dependences the compiler tracks (lgkmcnt) -- only the COMPILER must
+    // not move LDS accesses to other lanes' data across this point: wavefront-scope fences + a scheduling barrier.
+    // (Workgroup-scope fences here cost an s_waitcnt vmcnt(0) each: ~30 times per round the wave waited for its own
+    // rqs_clock / sample stores to reach memory.)
     static __device__ __forceinline__ void sync() {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     static __device__ __forceinline__ uint32_t lds_add(LDS_AS uint32_t* p, uint32_t v) {
         return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -300,6 +303,27 @@ struct WaveHip {
     }
     static __device__ __forceinline__ void global_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); }
     static __device__ __forceinline__ double rcp(double x) { return __builtin_amdgcn_rcp(x); }
+    static __device__ __forceinline__ uint32_t bcast32(uint32_t v, uint32_t src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src); }
+    static __device__ __forceinline__ uint64_t bcast64(uint64_t v, uint32_t src) {
+        const uint32_t lo = bcast32((uint32_t)v, src), hi = bcast32((uint32_t)(v >> 32), src);
+        return ((uint64_t)hi << 32) | lo;
+    }
+    // wave64 inclusive prefix sum without LDS: Kogge-Stone inside each row of 16 lanes with DPP row shifts (lanes
+    // shifted in from outside the row read 0), then the row totals with row_bcast:15 into rows 1, 3 and row_bcast:31
+    // into rows 2, 3 (a lane whose row is masked off keeps `old` = 0)
+    template <int CTRL, int ROW_MASK>
+    static __device__ __forceinline__ uint32_t dpp(uint32_t v) {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true);
+    }
+    static __device__ __forceinline__ uint32_t scan_incl_u32(uint32_t v) {
+        v += dpp<0x111, 0xF>(v);   // row_shr:1
+        v += dpp<0x112, 0xF>(v);   // row_shr:2
+        v += dpp<0x114, 0xF>(v);   // row_shr:4
+        v += dpp<0x118, 0xF>(v);   // row_shr:8
+        v += dpp<0x142, 0xA>(v);   // row_bcast:15 -> rows 1 and 3
+        v += dpp<0x143, 0xC>(v);   // row_bcast:31 -> rows 2 and 3
+        return v;
+    }
     static __device__ __forceinline__ uint32_t mbcnt(uint64_t m) {
         return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     }

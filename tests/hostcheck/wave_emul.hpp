@@ -127,6 +127,14 @@ struct WaveEmu {
     static uint32_t global_load(const uint32_t* p) { return *p; }
     static void global_fence() {}
     static double rcp(double x) { return 1.0 / x; }
+    static uint32_t bcast32(uint32_t v, uint32_t src) { return shfl32(v, src); }
+    static uint64_t bcast64(uint64_t v, uint32_t src) { return shfl64(v, src); }
+    static uint32_t scan_incl_u32(uint32_t v) {
+        Exchange x(v, 5u);
+        uint32_t s = 0;
+        for (uint32_t i = 0; i <= lane(); ++i) s += (uint32_t)x.of(i);
+        return s;
+    }
     static uint32_t mbcnt(uint64_t m) { return (uint32_t)__builtin_popcountll(m & ((1ull << lane()) - 1ull)); }
 };
 
