@@ -97,7 +97,7 @@ inline FlowLayout make_flow_layout(uint32_t cap, uint32_t ring_rows, uint32_t g_
     if (w < scratch0 + 5u * 64u) w = scratch0 + 5u * 64u;
     L.off_fr = w; w += n_servers * c_ring;
     L.off_gr = w; w += n_servers * g_ring;
-    L.off_cnt = w; w += (n_edges + 1u) / 2u + 28u;      // u32 sends per edge; 56 u32: lb order, head, n_live, mark cursor, per-server counters
+    L.off_cnt = w; w += (n_edges + 1u) / 2u + 32u;      // u32 sends per edge; 64 u32: lb order, head, n_live, mark cursor, per-server counters
     L.off_ring = w; w += (ring_rows * L.pitch + 1u) / 2u;
     L.n_words = w;
     return L;
@@ -223,7 +223,7 @@ struct Flow {
     AF_CORE AF_PLAN_AS double* fr(uint32_t sv) const { return (AF_PLAN_AS double*)(M + A.L.off_fr) + sv * A.L.c_ring; }
     AF_CORE AF_PLAN_AS double* gr(uint32_t sv) const { return (AF_PLAN_AS double*)(M + A.L.off_gr) + sv * A.L.g_ring; }
     AF_CORE AF_PLAN_AS uint32_t* sends() const { return (AF_PLAN_AS uint32_t*)(M + A.L.off_cnt); }
-    AF_CORE AF_PLAN_AS uint32_t* lbw() const { return sends() + ((A.n_edges + 1u) & ~1u); }  // [0..15] order, 16 head, 17 n_live, 18 mark cursor, [24..31] arrivals per server, [32..39] / [40..47] segment start / length, [48..55] step counts (leading I/O | CPU << 8 | trailing I/O << 16)
+    AF_CORE AF_PLAN_AS uint32_t* lbw() const { return sends() + ((A.n_edges + 1u) & ~1u); }  // [0..15] order, 16 head, 17 n_live, 18 mark cursor, 19 ceil(2^32 / n_live), [24..31] arrivals per server, [32..39] / [40..47] segment start / length, [48..55] step counts (leading I/O | CPU << 8 | trailing I/O << 16), [56..63] RAM slots (requests that fit at once)
     AF_CORE AF_PLAN_AS int32_t* ring() const { return (AF_PLAN_AS int32_t*)(M + A.L.off_ring); }
     AF_CORE AF_PLAN_AS double* spike_cum() const { return (AF_PLAN_AS double*)(M + A.L.off_spike); }
 
@@ -536,7 +536,10 @@ struct Flow {
         const bool marks_inside = kMarks && mi < A.n_srv_marks && u2d(smark(mi)[0]) <= t_last;
         if (!marks_inside) {
             const uint32_t head = lw[16], nl = lw[17];
-            if (lane < n_sel) pick = lw[(head + lane) % nl];
+            // (head + lane) mod nl by multiplication: head + lane < 2^16, magic = ceil(2^32 / nl)
+            const uint32_t x = head + lane;
+            const uint32_t q = nl > 1u ? (uint32_t)(((uint64_t)x * lw[19]) >> 32) : x;   // lw[19] = ceil(2^32 / nl), kept with nl
+            if (lane < n_sel) pick = lw[x - q * nl];
             W::sync();
             if (lane == 0u) lw[16] = (head + n_sel) % nl;
         } else {
@@ -568,6 +571,7 @@ struct Flow {
                 lw[16] = head;
                 lw[17] = nl;
                 lw[18] = cur;
+                lw[19] = nl ? 0xFFFFFFFFu / nl + 1u : 0u;
             }
             W::sync();
             if (lane < n_sel) pick = out_aux()[lane];
@@ -634,21 +638,15 @@ struct Flow {
         const uint32_t ep = (uint32_t)(meta >> 32) & 0xFFFFu;
         const double ram = u2d(blob[A.off_ep + af::PREC * ep]);
         const uint32_t row0 = (uint32_t)blob[A.off_ep + af::PREC * ep + 1u];
-        const double ram_mb = u2d(blob[A.off_srv + af::SREC * sv]);
         const uint32_t G = A.L.g_ring;
-        uint32_t slots = 0xFFFFFFFFu;   // requests that fit the RAM at once
-        if (ram > 0.0) {
-            const double q = ram_mb / ram;
-            slots = q < 4.0e9 ? (uint32_t)q : 0xFFFFFFFFu;
-            while ((double)slots * ram > ram_mb && slots > 0u) --slots;
-        }
+        const uint32_t slots = lw[56u + sv];   // requests that fit the RAM at once
         // where my predecessors' times come from: this window's segment, or the rings of earlier windows
         const bool ram_gate = have && ram > 0.0 && slots != 0u && slots <= G && j >= slots;
         const bool core_gate = have && j >= cores;
         const bool g_in_seg = ram_gate && li >= slots, f_in_seg = core_gate && li >= cores;
         double g_prev = -AF_INF, f_prev = -AF_INF;
         if (ram_gate && !g_in_seg) g_prev = gr(sv)[(j - slots) & (G - 1u)];
-        if (core_gate && !f_in_seg) f_prev = fr(sv)[(j - cores) % cores];
+        if (core_gate && !f_in_seg) f_prev = fr(sv)[cores == 1u ? 0u : (j - cores) % cores];
         if (have && ram > 0.0) {
             if (slots == 0u) why |= FLOW_WHY_RAM;   // never fits: the reference blocks the queue for good
             else if (slots > G && j >= G) {         // more slots than the ring remembers: fine while fewer than G requests are inside
@@ -683,7 +681,7 @@ struct Flow {
         if (have) {
             if (ram_gate && g_prev == a) why |= FLOW_WHY_TIE;    // arrival and RAM release at one instant
             if (core_gate && f_prev == r.b) why |= FLOW_WHY_TIE; // request for a core and core release at one instant: SimPy decides who waits
-            if (li + cores >= n_k) fr(sv)[j % cores] = r.f;      // the last `cores` releases / G departures feed later windows
+            if (li + cores >= n_k) fr(sv)[cores == 1u ? 0u : j % cores] = r.f;   // the last `cores` releases / G departures feed later windows
             if (li + G >= n_k) gr(sv)[j & (G - 1u)] = r.g;
             ev += r.events;
         }
@@ -770,11 +768,20 @@ struct Flow {
                     cnt[phase] += 1u;
                 }
                 lw[48u + v] = cnt[0] | (cnt[1] << 8) | (cnt[2] << 16);
+                const double ram = u2d(blob[A.off_ep + af::PREC * ep]), ram_mb = u2d(blob[A.off_srv + af::SREC * v]);
+                uint32_t slots = 0xFFFFFFFFu;   // requests that fit the RAM at once
+                if (ram > 0.0) {
+                    const double q = ram_mb / ram;
+                    slots = q < 4.0e9 ? (uint32_t)q : 0xFFFFFFFFu;
+                    while ((double)slots * ram > ram_mb && slots > 0u) --slots;
+                }
+                lw[56u + v] = slots;
             }
             for (uint32_t i = 0u; i < A.n_lb_edges; ++i) lw[i] = (uint32_t)blob[A.off_lb + i];
             lw[16] = 0u;
             lw[17] = A.n_lb_edges;
             lw[18] = 0u;
+            lw[19] = A.n_lb_edges ? 0xFFFFFFFFu / A.n_lb_edges + 1u : 0u;
         }
         W::sync();
 
