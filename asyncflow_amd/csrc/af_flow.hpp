@@ -71,11 +71,19 @@ struct FlowLayout {
     uint32_t list_arrays;  // f64 arrays per station list: key, t0 [, send time (FEAT_TIEBREAK)]
     uint32_t off_spike, off_list, off_aux, off_out, off_sorted, off_hist, off_seg, off_fr, off_gr, off_cnt, off_ring;
     uint32_t n_words;
+    // FEAT_BIGLIST: every list has its own capacity (a list behind a spiked edge holds rate x spike messages when the
+    // spike ends); cap is then the largest of them
+    uint32_t cap_of[4], off_list_of[4], off_eb;
 };
 
 inline FlowLayout make_flow_layout(uint32_t cap, uint32_t ring_rows, uint32_t g_ring, uint32_t c_ring, uint32_t n_edges,
-                                   uint32_t n_servers, uint32_t n_edge_marks, bool tiebreak = false) {
+                                   uint32_t n_servers, uint32_t n_edge_marks, bool tiebreak = false,
+                                   const uint32_t* caps4 = nullptr) {
     FlowLayout L{};
+    for (uint32_t s = 0; s < 4u; ++s) {
+        L.cap_of[s] = caps4 ? caps4[s] : cap;
+        if (caps4 && caps4[s] > cap) cap = caps4[s];
+    }
     L.cap = cap;
     L.ring_rows = ring_rows;
     L.win_rows = ring_rows / 2u;
@@ -85,14 +93,19 @@ inline FlowLayout make_flow_layout(uint32_t cap, uint32_t ring_rows, uint32_t g_
     uint32_t w = 0;
     L.off_spike = w; w += n_edge_marks;                 // cumulative spike after each edge mark
     L.list_arrays = tiebreak ? 3u : 2u;
-    L.off_list = w; w += 4u * L.list_arrays * cap;      // 4 lists x (key, t0 [, send time])
-    L.off_aux = w; w += (cap + 1u) / 2u;                // u32 per entry of the server list
+    L.off_list = w;                                     // 4 lists x (key, t0 [, send time])
+    for (uint32_t s = 0; s < 4u; ++s) {
+        L.off_list_of[s] = w;
+        w += L.list_arrays * L.cap_of[s];
+    }
+    L.off_aux = w; w += (L.cap_of[2] + 1u) / 2u;        // u32 per entry of the server list
     // scratch of select() (selected (key, t0) + u32 aux; bucket-sorted keys; 64 u32 counts, 64 u32 bases, scalars)
     // and the per-server segments of the server station (admission, B, S, F, G) are never live together
     const uint32_t scratch0 = w;
     L.off_out = w; w += 64u * 2u + 32u;
     L.off_sorted = w; w += tiebreak ? 2u * cap : cap;   // bucket-sorted keys [, their send times]
     L.off_hist = w; w += 32u + 32u + 8u;
+    L.off_eb = w; w += caps4 ? (cap + 1u) / 2u : 0u;    // FEAT_BIGLIST: u32 per entry (bucket | slot, then rank)
     L.off_seg = scratch0;
     if (w < scratch0 + 5u * 64u) w = scratch0 + 5u * 64u;
     L.off_fr = w; w += n_servers * c_ring;
@@ -165,11 +178,15 @@ struct FlowArgs {
 //                  then handled in the order SimPy pops them -- the order their Timeouts were created, i.e. by send
 //                  time (heap key (time, priority, event id)) -- instead of being handed back.  Used by
 //                  the second-chance launch over the scenarios the lean instantiation hands back (engine.hip).
-enum : uint32_t { FEAT_MARKS = 1u, FEAT_ONLINE = 2u, FEAT_HBM_RING = 4u, FEAT_ALL = 7u, FEAT_TIEBREAK = 8u };
+//   FEAT_BIGLIST   lists of any length with their own capacities (FlowLayout::cap_of): select() walks a list in
+//                  chunks of 64 at a cost proportional to what it holds, instead of keeping IPL entries per lane in
+//                  registers.  For plans whose spikes pile up rate x spike messages at one station when they end.
+enum : uint32_t { FEAT_MARKS = 1u, FEAT_ONLINE = 2u, FEAT_HBM_RING = 4u, FEAT_ALL = 7u, FEAT_TIEBREAK = 8u, FEAT_BIGLIST = 16u };
 template <class W, uint32_t IPL = 1u, uint32_t FEAT = FEAT_ALL>
 struct Flow {
     static constexpr bool kMarks = (FEAT & FEAT_MARKS) != 0u, kOnline = (FEAT & FEAT_ONLINE) != 0u,
-                          kHbmRing = (FEAT & FEAT_HBM_RING) != 0u, kTieBreak = (FEAT & FEAT_TIEBREAK) != 0u;
+                          kHbmRing = (FEAT & FEAT_HBM_RING) != 0u, kTieBreak = (FEAT & FEAT_TIEBREAK) != 0u,
+                          kBig = (FEAT & FEAT_BIGLIST) != 0u;
     const FlowArgs& A;
     AF_PLAN_AS uint64_t* blob;   // plan blob (LDS copy, patched)
     AF_PLAN_AS uint64_t* M;      // layout words behind it
@@ -188,10 +205,11 @@ struct Flow {
     }
     AF_CORE double H_get(uint32_t s) const { return s == 0u ? h0 : s == 1u ? h1 : s == 2u ? h2 : h3; }
     AF_CORE void H_set(uint32_t s, double v) {
+        moved = moved || v > H_get(s);
         if (s == 0u) h0 = v; else if (s == 1u) h1 = v; else if (s == 2u) h2 = v; else h3 = v;
     }
     uint32_t n_comp, tick_base;
-    bool gen_done;
+    bool gen_done, moved;        // moved: a horizon advanced in this round
     // per-lane accumulators (reduced at the end)
     uint32_t ev, drops, why;
     int32_t run_val;             // lane s < n_series: current value of sampled series s
@@ -205,12 +223,14 @@ struct Flow {
     AF_CORE Flow(const FlowArgs& a) : A(a) {}
 
     // ---- LDS views ----------------------------------------------------------------------------
+    AF_CORE uint32_t cap_of(uint32_t s) const { return kBig ? A.L.cap_of[s] : A.L.cap; }
     AF_CORE AF_PLAN_AS double* list_key(uint32_t s) const {
-        return (AF_PLAN_AS double*)(M + A.L.off_list + (kTieBreak ? 3u : 2u) * A.L.cap * s);
+        return (AF_PLAN_AS double*)(M + (kBig ? A.L.off_list_of[s] : A.L.off_list + (kTieBreak ? 3u : 2u) * A.L.cap * s));
     }
-    AF_CORE AF_PLAN_AS double* list_t0(uint32_t s) const { return list_key(s) + A.L.cap; }
-    AF_CORE AF_PLAN_AS double* list_ts(uint32_t s) const { return list_key(s) + 2u * A.L.cap; }   // FEAT_TIEBREAK only
-    AF_CORE AF_PLAN_AS double* sorted_ts() const { return sorted() + A.L.cap; }
+    AF_CORE AF_PLAN_AS double* list_t0(uint32_t s) const { return list_key(s) + cap_of(s); }
+    AF_CORE AF_PLAN_AS double* list_ts(uint32_t s) const { return list_key(s) + 2u * cap_of(s); }   // FEAT_TIEBREAK only
+    AF_CORE AF_PLAN_AS uint32_t* eb() const { return (AF_PLAN_AS uint32_t*)(M + A.L.off_eb); }       // FEAT_BIGLIST only
+    AF_CORE AF_PLAN_AS double* sorted_ts() const { return sorted() + A.L.cap; }   // (cap: the largest list)
     AF_CORE AF_PLAN_AS uint32_t* list_aux() const { return (AF_PLAN_AS uint32_t*)(M + A.L.off_aux); }
     AF_CORE AF_PLAN_AS double* out_key() const { return (AF_PLAN_AS double*)(M + A.L.off_out); }
     AF_CORE AF_PLAN_AS double* out_t0() const { return out_key() + 64; }
@@ -330,6 +350,31 @@ struct Flow {
         }
         return sp;
     }
+    // Earliest delivery time of anything station `st` sends from `h` on (it has sent everything before h): h plus
+    // the spike its out-edges carry then, or a later mark's time plus the spike left after it.  A spike of s seconds
+    // lets the next station run s seconds AHEAD of this one instead of piling up s seconds' worth of messages it may
+    // not touch yet (conservative lookahead; f64 addition is monotone, so now >= h gives key >= the floor bit for bit).
+    AF_CORE double send_floor(uint32_t st, double h) const {
+        if (!(kMarks && A.n_edge_marks != 0u) || !(h < AF_INF)) return h;
+        double best = AF_INF;
+        const uint32_t n_out = st == 2u ? A.n_lb_edges : st == 3u ? A.n_servers : 1u;
+        for (uint32_t c = 0u; c < n_out; ++c) {
+            const uint32_t e = st == 0u   ? A.gen_out_edge
+                               : st == 1u ? A.client_out_edge
+                               : st == 2u ? (uint32_t)blob[A.off_lb + c]
+                                          : (uint32_t)(blob[A.off_srv + af::SREC * c + 1u] >> 16) & 0xFFFFu;
+            double sp = 0.0, fl = AF_INF;
+            for (uint32_t i = 0u; i < A.n_edge_marks; ++i) {   // marks are in time order
+                if ((uint32_t)emark(i)[2] != e) continue;
+                const double tm = u2d(emark(i)[0]), after = spike_cum()[i];
+                if (tm < h) sp = after;
+                else if (tm + after < fl) fl = tm + after;
+            }
+            if (h + sp < fl) fl = h + sp;
+            if (fl < best) best = fl;
+        }
+        return best;
+    }
     AF_CORE_NOINLINE static double cold_variate(uint32_t dist, double mean, double sigma, double u1, uint64_t seed, uint32_t stream,
                                                 uint32_t idx) {
         return af::variate_from_u1(dist, mean, sigma, u1, seed, stream, idx);
@@ -379,6 +424,7 @@ struct Flow {
     // Rank the messages of list s with time < min(H_in, T); hand the `n_sel` earliest (<= room, <= 64) to
     // lanes 0..n_sel-1 in time order; keep the rest.  Returns n_sel.
     AF_CORE uint32_t select(uint32_t s, double H_in, uint32_t room, double& okey, double& ot0, uint32_t& oaux) {
+        if (kBig) return select_big(s, H_in, room, okey, ot0, oaux);
         W::sync();   // appends of the previous station are visible
         const double lo = H_get(s);
         const double hi = H_in < A.total_time ? H_in : A.total_time;
@@ -492,6 +538,133 @@ struct Flow {
                 }
                 kept += popc64(m);
             }
+        }
+        n_list_set(s, kept);
+        W::sync();
+        H_set(s, n_sel < E ? scal()[0] : hi);
+        if (lane < n_sel) {
+            okey = out_key()[lane];
+            ot0 = out_t0()[lane];
+            oaux = out_aux()[lane];
+        }
+        return n_sel;
+    }
+
+    // The same selection for lists of any length (FEAT_BIGLIST): the list is walked in chunks of 64, what select()
+    // keeps in registers lives in a u32 per entry (bucket | slot, then the rank), and exact ranks are only worked out
+    // for the buckets that can reach the first n_sel places (or hold the first message left behind).
+    AF_CORE uint32_t select_big(uint32_t s, double H_in, uint32_t room, double& okey, double& ot0, uint32_t& oaux) {
+        W::sync();
+        const double lo = H_get(s);
+        const double hi = H_in < A.total_time ? H_in : A.total_time;
+        const uint32_t n = n_list_get(s);
+        okey = AF_INF;
+        ot0 = 0.0;
+        oaux = 0u;
+        if (!(hi > lo)) return 0u;
+        if (n == 0u) {
+            H_set(s, hi);
+            return 0u;
+        }
+        AF_PLAN_AS double* K = list_key(s);
+        AF_PLAN_AS double* T0 = list_t0(s);
+        AF_PLAN_AS double* TS = list_ts(s);
+        AF_PLAN_AS uint32_t* AX = list_aux();
+        AF_PLAN_AS uint32_t* EB = eb();
+        constexpr uint32_t kNone = 0xFFFFFFFFu, kFar = 0xFFFFFFFEu;
+        double sc = 64.0 * W::rcp(hi - lo);
+        if (!(sc < 1e300)) sc = 1e300;
+        hist()[lane] = 0u;
+        W::sync();
+        const uint32_t nq = (n + 63u) / 64u;
+        for (uint32_t q = 0u; q < nq; ++q) {
+            const uint32_t i = q * 64u + lane;
+            if (i < n) {
+                const double k = K[i];
+                uint32_t w = kNone;
+                if (k < hi) {
+                    double x = (k - lo) * sc;
+                    x = x < 63.0 ? x : 63.0;
+                    const uint32_t b = x > 0.0 ? (uint32_t)x : 0u;
+                    w = (b << 16) | W::lds_add(hist() + b, 1u);
+                }
+                EB[i] = w;
+            }
+        }
+        W::sync();
+        uint32_t E;
+        const uint32_t cnt = hist()[lane];
+        const uint32_t base = excl_scan(cnt, E);
+        bbase()[lane] = base;
+        W::sync();
+        for (uint32_t q = 0u; q < nq; ++q) {
+            const uint32_t i = q * 64u + lane;
+            if (i < n && EB[i] != kNone) {
+                const uint32_t at = bbase()[EB[i] >> 16] + (EB[i] & 0xFFFFu);
+                sorted()[at] = K[i];
+                if (kTieBreak) sorted_ts()[at] = TS[i];
+            }
+        }
+        W::sync();
+        uint32_t n_sel = E < room ? E : room;
+        n_sel = n_sel < 64u ? n_sel : 64u;
+        for (uint32_t q = 0u; q < nq; ++q) {
+            const uint32_t i = q * 64u + lane;
+            if (i < n && EB[i] != kNone) {
+                const uint32_t b = EB[i] >> 16, p0 = bbase()[b];
+                uint32_t r = kFar;
+                if (p0 <= n_sel) {
+                    const uint32_t p1 = p0 + hist()[b], me = p0 + (EB[i] & 0xFFFFu);
+                    const double k = K[i];
+                    r = p0;
+                    for (uint32_t p = p0; p < p1; ++p) {
+                        const double kk = sorted()[p];
+                        r += kk < k ? 1u : 0u;
+                        if (kk == k && p != me) {   // two deliveries of this station at one instant (see select())
+                            if (kTieBreak) {
+                                const double other = sorted_ts()[p], mine = TS[i];
+                                r += other < mine ? 1u : 0u;
+                                if (other == mine) why |= FLOW_WHY_TIE;
+                            } else {
+                                why |= FLOW_WHY_TIE;
+                            }
+                        }
+                    }
+                    if (r == n_sel && n_sel < E) scal()[0] = k;   // the first message left behind bounds the horizon
+                }
+                EB[i] = r;
+            }
+        }
+        W::sync();
+        uint32_t kept = 0u;
+        for (uint32_t q = 0u; q < nq; ++q) {
+            const uint32_t i = q * 64u + lane;
+            const bool valid = i < n;
+            double k = 0.0, t = 0.0, ts = 0.0;
+            uint32_t a = 0u, r = kNone;
+            if (valid) {
+                k = K[i];
+                t = T0[i];
+                if (kTieBreak) ts = TS[i];
+                if (s == 2u) a = AX[i];
+                r = EB[i];
+            }
+            const bool sel = valid && r < n_sel;
+            if (sel) {
+                out_key()[r] = k;
+                out_t0()[r] = t;
+                out_aux()[r] = a;
+            }
+            const bool keep = valid && !sel;
+            const uint64_t m = W::ballot(keep);       // (every lane has read its entry of this chunk: writes below
+            const uint32_t pos = kept + W::mbcnt(m);  //  land at or before the writer's own index)
+            if (keep) {
+                K[pos] = k;
+                T0[pos] = t;
+                if (kTieBreak) TS[pos] = ts;
+                if (s == 2u) AX[pos] = a;
+            }
+            kept += popc64(m);
         }
         n_list_set(s, kept);
         W::sync();
@@ -679,8 +852,13 @@ struct Flow {
             if (!again) break;
         }
         if (have) {
-            if (ram_gate && g_prev == a) why |= FLOW_WHY_TIE;    // arrival and RAM release at one instant
-            if (core_gate && f_prev == r.b) why |= FLOW_WHY_TIE; // request for a core and core release at one instant: SimPy decides who waits
+            // g_prev == a (an arrival at the instant a predecessor frees its RAM) and f_prev == r.b (a request for a
+            // core at the instant one is released) need no hand-back: whichever of the two SimPy pops first, the
+            // request is admitted / granted AT that instant, behind the same earlier waiters (both queues are FIFO
+            // in arrival order), and the zero-length wait it may be counted for ends before any tick can see it
+            // (a tick at that very instant is flagged by tick_index).  A RAM-bound server with deterministic step
+            // times produces such instants all the time: F[j-1] = G[j-1-slots] + cpu and G[j-slots] = F[j-slots] + io
+            // are the same sum.
             if (li + cores >= n_k) fr(sv)[cores == 1u ? 0u : j % cores] = r.f;   // the last `cores` releases / G departures feed later windows
             if (li + G >= n_k) gr(sv)[j & (G - 1u)] = r.g;
             ev += r.events;
@@ -792,15 +970,14 @@ struct Flow {
         gen_done = false;
         nl0 = nl1 = nl2 = nl3 = 0u;
         h0 = h1 = h2 = h3 = 0.0;
-        const uint32_t cap = A.L.cap;
         const uint32_t first_srv_stage = A.has_lb ? 1u : 2u;   // where the client's out-edge leads
 
         // Every round walks the five stations in order.  The code of select() and of edge_send() exists ONCE
         // (the loop is not unrolled): the kernel stays small enough for the instruction cache.
         for (;;) {
             uint32_t work = 0u;
-            const double h_done_before = h3;
-            double H_in = AF_INF;
+            moved = false;
+            double H_in = AF_INF, h_gen = AF_INF;
 #pragma nounroll
             for (uint32_t st = 0u; st < 5u; ++st) {
                 if (st == 2u && !A.has_lb) continue;
@@ -809,7 +986,7 @@ struct Flow {
                 uint32_t aux = 0u, n_sel;
                 const uint32_t nxt = st == 0u ? 0u : st == 1u ? first_srv_stage : st;   // list the results go to (st < 4)
                 if (st == 0u) {   // generator (rqs_generator.py:97-119): up to 64 arrivals
-                    uint32_t room = cap - nl0;
+                    uint32_t room = cap_of(0u) - nl0;
                     room = room < 64u ? room : 64u;
                     const uint32_t i = cursor + lane;
                     t0 = (lane < room && i < A.n_draw) ? arr[i] : AF_INF;
@@ -820,7 +997,7 @@ struct Flow {
                     n_sel = popc64(vm);
                     key = t0;
                 } else {
-                    n_sel = select(st - 1u, H_in, st == 4u ? 64u : cap - n_list_get(nxt), key, t0, aux);
+                    n_sel = select(st - 1u, H_in, st == 4u ? 64u : cap_of(nxt) - n_list_get(nxt), key, t0, aux);
                 }
                 const bool have = lane < n_sel;
                 if (have) ev += 1u;                       // one timed event per message: arrival / delivery
@@ -835,6 +1012,7 @@ struct Flow {
                     cursor += n_sel;
                     H_in = cursor < A.n_draw ? arr[cursor] : AF_INF;   // next arrival not yet generated
                     gen_done = !(H_in < T);
+                    h_gen = H_in;
                 } else if (st == 1u) {   // client, first visit (client.py:46-60): forward on the client's out-edge
                     e = A.client_out_edge;
                     idx = sends()[e] + lane;
@@ -887,14 +1065,23 @@ struct Flow {
                     const bool ok = sending && edge_send(e, idx, ts, k2);
                     append(nxt, ok, k2, t0, tgt, ts);
                     if (st > 0u) H_in = H_get(st - 1u);
+                    H_in = send_floor(st, H_in);   // what the next station may touch: everything delivered before this
                 }
             }
             // ---- ticks that can no longer change
-            const bool finished = gen_done && work == 0u && !(h3 < T);
+            // (a station behind a spiked edge runs AHEAD of the one that feeds it: the slowest horizon bounds what is final)
+            double h_min = h3;
+            if (kMarks && A.n_edge_marks != 0u) {
+                h_min = h_min < h_gen ? h_min : h_gen;
+                h_min = h_min < h0 ? h_min : h0;
+                h_min = (A.has_lb && h1 < h_min) ? h1 : h_min;
+                h_min = h_min < h2 ? h_min : h2;
+            }
+            const bool finished = gen_done && work == 0u && !(h_min < T);
             W::sync();
-            flush_ticks(finished ? A.n_ticks : tick_index(h3, false));
+            flush_ticks(finished ? A.n_ticks : tick_index(h_min, false));
             W::sync();
-            const bool stuck = work == 0u && !finished && !(h3 > h_done_before);
+            const bool stuck = work == 0u && !finished && !moved;
             if (stuck) why |= FLOW_WHY_LIST;   // nothing moved, no horizon advanced: a list is full of later messages
             if (finished || W::any(why != 0u)) break;
         }

@@ -1059,7 +1059,9 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     uint32_t flow_retried = 0, flow_to_next = 0;
     size_t draw_bytes = 0;
     bool lds_state = false;
-    aff::FlowLayout FL{};
+    aff::FlowLayout FL{}, FL2{};     // first launch; second chance (long lists with send times)
+    bool flow_big = false;           // the first launch already runs the long-list instantiation
+    uint32_t big_caps[4] = {256u, 256u, 256u, 256u};
 
     // ---- stage-parallel kernel: list capacity and tick ring from what will be in flight ----------------
     if (use_flow) {
@@ -1121,17 +1123,39 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
         const double wait = rho < 0.9 ? rho * e->cpu_max / (2.0 * (1.0 - rho)) : 20.0 * e->cpu_max + 1.0;
         const double in_server = e->service_max + 4.0 * wait;
         // messages pending at a station ~ rate x time in flight towards it (the completion list also holds the server time)
-        double pend = 0.0;
+        // (a spiked edge: the station behind it runs ahead by the spike while it lasts -- Flow::send_floor -- but when it
+        // ends, the messages still in flight and the ones sent after it interleave: rate x spike of them wait there, and
+        // the servers then work off that burst, so as many wait for their departure in the completion list)
+        double pend = 0.0, burst = 0.0;
+        std::vector<double> pend_of(hops.size(), 0.0);
         for (size_t h = 0; h < hops.size(); ++h) {
             const double fly = lat_mean(hops[h]) + e->edge_spike[hops[h]] + (h + 1 == hops.size() ? in_server : 0.0);
+            burst = std::fmax(burst, rate * e->edge_spike[hops[h]]);
+            pend_of[h] = rate * fly;
             pend = std::fmax(pend, rate * fly);
+        }
+        pend_of.back() = std::fmax(pend_of.back(), burst + rate * (lat_mean(hops.back()) + in_server));
+        pend = std::fmax(pend, pend_of.back());
+        // capacities of the four station lists for the FEAT_BIGLIST instantiation (hops -> lists: generator edge -> 0,
+        // client edge -> 1 with a load balancer else 2, LB edges -> 2, server out-edges -> 3)
+        {
+            for (uint32_t s = 0; s < 4u; ++s) big_caps[s] = (s == 1u && !e->has_lb) ? 64u : 256u;   // (no LB: its list stays empty)
+            for (size_t h = 0; h < hops.size(); ++h) {
+                const uint32_t s = h == 0 ? 0u : h + 1 == hops.size() ? 3u : (h == 1 && e->has_lb) ? 1u : 2u;
+                const double want = 1.5 * pend_of[h] + 128.0;
+                const uint32_t c = want < 16384.0 ? ((uint32_t)want + 63u) & ~63u : 16384u;   // any multiple of 64
+                if (c > big_caps[s]) big_caps[s] = c;
+            }
         }
         // A list only has to leave ROOM: 64 - pending new messages fit per round.  Larger lists cost LDS (occupancy) and
         // ranking work on every round of every scenario (measured on the config-3 grid: 64 entries 122 ms, 128 entries
         // 144 ms, no hand-backs either way); an overflow costs one scenario a second run.  `pend` is the MEAN at the
         // heaviest point of the sweep: half a list of pending messages still leaves half a batch of room.
         uint32_t entries = e->flow_list_entries;
-        if (entries == 0u) entries = pend <= 32.0 ? 64u : pend <= 96.0 ? 128u : 256u;
+        if (entries == 0u) {
+            entries = pend <= 32.0 ? 64u : pend <= 96.0 ? 128u : 256u;
+            flow_big = pend > 200.0;   // more than register-resident lists hold: the whole launch on the long-list instantiation
+        }
         // in-flight time of the slowest message of the sweep (~1e-11 per request): the largest single hop at that
         // quantile, the other hops at mean + 3 sd, spikes, the server
         double tail = in_server;
@@ -1168,8 +1192,31 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
             const double w = (double)rows - tail_rows;
             win_rows = w >= (double)(rows / 2u) ? (uint32_t)w : rows / 2u;   // an explicit small ring: half of it, overflow -> hand-back
         }
-        FL = aff::make_flow_layout(entries, rows, e->fargs.L.g_ring, e->fargs.L.c_ring, a.n_edges, a.n_servers, a.n_edge_marks);
+        // long lists have to fit the LDS of a compute unit next to everything else: halve the longest until they do
+        auto big_layout = [&](uint32_t ring) {
+            aff::FlowLayout L = aff::make_flow_layout(0u, ring, e->fargs.L.g_ring, e->fargs.L.c_ring, a.n_edges, a.n_servers, a.n_edge_marks, true, big_caps);
+            while (a.blob_bytes + L.n_words * 8u > kLdsLimit) {
+                uint32_t m = 0;
+                for (uint32_t s = 1; s < 4u; ++s)
+                    if (big_caps[s] > big_caps[m]) m = s;
+                if (big_caps[m] <= 256u) break;
+                big_caps[m] = (big_caps[m] / 2u + 63u) & ~63u;
+                L = aff::make_flow_layout(0u, ring, e->fargs.L.g_ring, e->fargs.L.c_ring, a.n_edges, a.n_servers, a.n_edge_marks, true, big_caps);
+            }
+            return L;
+        };
+        if (flow_big) {
+            if (rows * pitch * 4u > 8u * 1024u) {   // the lists need the LDS more than the tick ring does
+                rows = 0u;
+                win_rows = 0u;
+            }
+            FL = big_layout(rows);
+        } else {
+            FL = aff::make_flow_layout(entries, rows, e->fargs.L.g_ring, e->fargs.L.c_ring, a.n_edges, a.n_servers, a.n_edge_marks);
+        }
         FL.win_rows = win_rows;
+        FL2 = big_layout(0u);   // second chance: tick differences in HBM (no reach limit)
+        FL2.win_rows = 0u;
         flow_lds = a.blob_bytes + FL.n_words * 8u;
         if (flow_lds > kLdsLimit) return fail(AF_ERR_CAPACITY, "flow kernel layout exceeds the LDS of a compute unit");
     }
@@ -1373,7 +1420,8 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
             const bool lean = a.n_edge_marks == 0u && a.n_srv_marks == 0u && !f.online_hist && !f.online_rps &&
                               (FL.ring_rows != 0u || f.samples == nullptr);
             flow_lean = lean;
-            const void* fn = FL.cap == 64u    ? (lean ? reinterpret_cast<const void*>(af_flow_kernel<1, 0u>)
+            const void* fn = flow_big         ? reinterpret_cast<const void*>(af_flow_kernel<1, aff::FEAT_ALL | aff::FEAT_TIEBREAK | aff::FEAT_BIGLIST>)
+                             : FL.cap == 64u  ? (lean ? reinterpret_cast<const void*>(af_flow_kernel<1, 0u>)
                                                       : reinterpret_cast<const void*>(af_flow_kernel<1, aff::FEAT_ALL>))
                              : FL.cap == 128u ? (lean ? reinterpret_cast<const void*>(af_flow_kernel<2, 0u>)
                                                       : reinterpret_cast<const void*>(af_flow_kernel<2, aff::FEAT_ALL>))
@@ -1382,8 +1430,8 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
             if (flow_lds_launch > 48u * 1024u) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flow_lds_launch));
             void* kargs[] = {&f};
             if (std::getenv("AF_DEBUG"))
-                std::fprintf(stderr, "[af] flow launch: %u scenarios, %u list entries, %u ring rows, %u B LDS per wave%s\n", nc, FL.cap,
-                             FL.ring_rows, flow_lds, flow_lean ? ", lean instantiation" : "");
+                std::fprintf(stderr, "[af] flow launch: %u scenarios, %u list entries%s, %u ring rows, %u B LDS per wave%s\n", nc, FL.cap,
+                             flow_big ? " (long-list instantiation)" : "", FL.ring_rows, flow_lds, flow_lean ? ", lean instantiation" : "");
             HIP_TRY(hipLaunchKernel(fn, dim3(nc), dim3(kWave), kargs, flow_lds_launch, e->stream));
         }
         HIP_TRY(hipEventRecord(e->ev4, e->stream));
@@ -1409,15 +1457,14 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
             for (uint32_t i = 0; i < nc; ++i) {
                 const uint32_t fl = cnt_host[(size_t)i * AF_CNT_SLOTS + AF_CNT_FLAGS];
                 if (!(fl & aff::FLAG_FLOW_FALLBACK)) continue;
-                if (fl & aff::FLOW_WHY_RAM) rest.push_back(i);
+                if ((fl & aff::FLOW_WHY_RAM) || flow_big) rest.push_back(i);   // (flow_big: that WAS the most tolerant form)
                 else retry.push_back(i);
             }
             if (!retry.empty()) {
                 if (int rc = grow((void**)&e->d_map, e->map_cap, retry.size() * 4u)) return rc;
                 HIP_TRY(hipMemcpyAsync(e->d_map, retry.data(), retry.size() * 4u, hipMemcpyHostToDevice, e->stream));
                 aff::FlowArgs f2 = f;
-                f2.L = aff::make_flow_layout(256u, 0u, e->fargs.L.g_ring, e->fargs.L.c_ring, a.n_edges, a.n_servers, a.n_edge_marks, true);
-                f2.L.win_rows = 0u;
+                f2.L = FL2;
                 f2.n_scen = (uint32_t)retry.size();
                 f2.scen_map = e->d_map;
                 f2.n_fallback = e->d_fb + 5;
@@ -1429,13 +1476,13 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
                     HIP_TRY(hipGetLastError());
                     a.scen_map = nullptr;
                 }
-                const void* fn2 = reinterpret_cast<const void*>(af_flow_kernel<4, aff::FEAT_ALL | aff::FEAT_TIEBREAK>);
+                const void* fn2 = reinterpret_cast<const void*>(af_flow_kernel<1, aff::FEAT_ALL | aff::FEAT_TIEBREAK | aff::FEAT_BIGLIST>);
                 if (lds2 > 48u * 1024u) HIP_TRY(hipFuncSetAttribute(fn2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
                 HIP_TRY(hipEventRecord(e->ev3, e->stream));
                 void* kargs2[] = {&f2};
                 if (std::getenv("AF_DEBUG")) {
-                    std::fprintf(stderr, "[af] flow second chance: %zu scenarios (256-entry lists with send times, differences in HBM), %u B LDS:",
-                                 retry.size(), lds2);
+                    std::fprintf(stderr, "[af] flow second chance: %zu scenarios (lists of %u/%u/%u/%u entries with send times, differences in HBM), %u B LDS:",
+                                 retry.size(), FL2.cap_of[0], FL2.cap_of[1], FL2.cap_of[2], FL2.cap_of[3], lds2);
                     for (size_t q = 0; q < retry.size() && q < 16; ++q)
                         std::fprintf(stderr, " %u(flags %#x)", lo + retry[q], cnt_host[(size_t)retry[q] * AF_CNT_SLOTS + AF_CNT_FLAGS]);
                     std::fprintf(stderr, "\n");

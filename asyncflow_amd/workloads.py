@@ -3,6 +3,8 @@
 ``single_server``  examples/yaml_input/data/single_server.yml            (config 1)
 ``lb_two_servers`` examples/yaml_input/data/two_servers_lb.yml:14-71      (config 2, "LB-2")
 ``lb_with_events`` LB-2 + the events of examples/yaml_input/data/event_inj_lb.yml:73-102 (config 4)
+``single_server_with_spike`` examples/yaml_input/data/event_inj_single_server.yml / heavy_inj_single_server.yml
+                   (a 2 s / 3 s network spike on the client -> server edge: rate x spike messages pile up when it ends)
 ``fanout8``        8-server fan-out with log-normal edges     (config 5)
 ``grid_users_rtt`` the users x RTT grid of configs 3 / 4 as sweep columns
 
@@ -119,6 +121,28 @@ def lb_with_events(users: float = 120, horizon: int = 600, scale: float = 1.0) -
         {"event_id": "ev-spike-3", "target_id": "gen-client",
          "start": {"kind": "network_spike_start", "t_start": 480.0 * s, "spike_s": 0.010}, "end": {"kind": "network_spike_end", "t_end": 540.0 * s}},
     ]
+    return p
+
+
+def single_server_with_spike(heavy: bool = False, horizon: int | None = None, scale: float = 1.0) -> dict:
+    """examples/yaml_input/data/event_inj_single_server.yml, or heavy_inj_single_server.yml with ``heavy``.
+
+    ``scale`` compresses the event times (and ``horizon`` the run) so short fixtures still see the spike end.
+    """
+    if heavy:
+        p = single_server(users=300, rpm=30, horizon=600 if horizon is None else horizon)
+        srv = p["topology_graph"]["nodes"]["servers"][0]
+        srv["server_resources"]["ram_mb"] = 8000
+        srv["endpoints"] = [_endpoint("ep-1", [("initial_parsing", 0.005), ("ram", 200), ("io_wait", 0.2)])]
+        ev = {"event_id": "ev-spike-heavy", "target_id": "client-to-server",
+              "start": {"kind": "network_spike_start", "t_start": 180.0 * scale, "spike_s": 3.0}, "end": {"kind": "network_spike_end", "t_end": 300.0 * scale}}
+    else:
+        p = single_server(users=100, rpm=20, horizon=500 if horizon is None else horizon)
+        ev = {"event_id": "ev-spike-1", "target_id": "client-to-server",
+              "start": {"kind": "network_spike_start", "t_start": 120.0 * scale, "spike_s": 2.0}, "end": {"kind": "network_spike_end", "t_end": 240.0 * scale}}
+    p["sim_settings"]["enabled_sample_metrics"] = ["ready_queue_len", "event_loop_io_sleep", "ram_in_use", "edge_concurrent_connection"]
+    p["sim_settings"]["enabled_event_metrics"] = ["rqs_clock"]
+    p["events"] = [ev]
     return p
 
 

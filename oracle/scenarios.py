@@ -20,6 +20,7 @@ from asyncflow_amd.workloads import (  # noqa: E402,F401  (BASELINE workloads li
     lb_two_servers,
     lb_with_events,
     single_server,
+    single_server_with_spike,
 )
 
 
@@ -168,8 +169,11 @@ def random_payload(rng: random.Random, horizon: int = 12) -> dict:
         e = rng.choice(edges)
         a = rng.uniform(0, T * 0.8)
         b = rng.uniform(a + 0.1, T)
+        amount = round(rng.uniform(0.005, 0.3), 4)
+        if int(a * 1000.0) % 4 == 0:
+            amount = round(amount * 10.0, 4)   # seconds-long spikes (the reference's *_inj_single_server examples): long lists, lookahead
         events.append({"event_id": f"sp{k}", "target_id": e["id"],
-                       "start": {"kind": "network_spike_start", "t_start": round(a, 3), "spike_s": round(rng.uniform(0.005, 0.3), 4)},
+                       "start": {"kind": "network_spike_start", "t_start": round(a, 3), "spike_s": amount},
                        "end": {"kind": "network_spike_end", "t_end": round(b, 3)}})
     if use_lb and n_srv > 1 and rng.random() < 0.7:
         # non-overlapping outages, one server at a time
@@ -266,8 +270,11 @@ def flow_payload(rng: random.Random, horizon: int = 8) -> dict:
         e = rng.choice(edges)
         a = rng.uniform(0, T * 0.8)
         b = rng.uniform(a + 0.1, T)
+        amount = round(rng.uniform(0.005, 0.3), 4)
+        if int(a * 1000.0) % 4 == 0:
+            amount = round(amount * 10.0, 4)   # seconds-long spikes (the reference's *_inj_single_server examples): long lists, lookahead
         events.append({"event_id": f"sp{k}", "target_id": e["id"],
-                       "start": {"kind": "network_spike_start", "t_start": round(a, 3), "spike_s": round(rng.uniform(0.005, 0.3), 4)},
+                       "start": {"kind": "network_spike_start", "t_start": round(a, 3), "spike_s": amount},
                        "end": {"kind": "network_spike_end", "t_end": round(b, 3)}})
     if use_lb and n_srv > 1 and rng.random() < 0.6:
         t = rng.uniform(0.5, 3.0)

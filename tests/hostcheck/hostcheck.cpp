@@ -154,7 +154,10 @@ extern "C" int hc_flow_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ov
                                 uint32_t clock_cap, double* clock, uint32_t tick_cap, uint32_t* samples, uint32_t* counts,
                                 uint32_t draw_cap) {
     if (!p || p->abi_version != AF_ABI_VERSION || p->struct_size != sizeof(af_plan_t)) return AF_ERR_ABI;
-    const bool robust = (ipl & 0x100u) != 0u;   // the second-chance instantiation: 256 entries + send times
+    // the second-chance instantiation (FEAT_TIEBREAK | FEAT_BIGLIST): send times + lists of their own lengths;
+    // bits 16..31 = entries of the long list(s) (0: 256), bits 12..14 = which list is long (0: all four; else index + 1, the others hold 256)
+    const bool robust = (ipl & 0x100u) != 0u;
+    const uint32_t big_cap = (ipl >> 16) ? (ipl >> 16) : 256u, big_which = (ipl >> 12) & 7u;
     ipl &= 0xFFu;
     if (robust) ipl = 4;
     if (ipl != 1 && ipl != 2 && ipl != 4) return AF_ERR_INVALID;
@@ -211,7 +214,9 @@ extern "C" int hc_flow_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ov
     a.blob = reinterpret_cast<const unsigned char*>(pk.words.data());
     a.L = aff::choose_flow_layout(*p, ipl, ring_rows);
     if (robust) {
-        a.L = aff::make_flow_layout(256u, a.L.ring_rows, a.L.g_ring, a.L.c_ring, p->n_edges, p->n_servers, p->n_edge_marks, true);
+        uint32_t caps4[4];
+        for (uint32_t s = 0; s < 4u; ++s) caps4[s] = (big_which == 0u || big_which == s + 1u) ? big_cap : 256u;
+        a.L = aff::make_flow_layout(0u, a.L.ring_rows, a.L.g_ring, a.L.c_ring, p->n_edges, p->n_servers, p->n_edge_marks, true, caps4);
         a.L.win_rows = a.L.ring_rows / 2u;
     }
     a.tick_t = tt.t.data();
@@ -244,7 +249,7 @@ extern "C" int hc_flow_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ov
     // the instantiation the engine would launch: the lean one when the launch needs none of the optional features
     const bool lean = p->n_edge_marks == 0 && p->n_srv_marks == 0 && !g_online_hist && !g_online_rps && (a.L.ring_rows != 0 || !samples);
     auto body = [&]() {
-        if (robust) { aff::Flow<emu::WaveEmu, 4, aff::FEAT_ALL | aff::FEAT_TIEBREAK> f(a); f.run(lds.data(), 0u); }
+        if (robust) { aff::Flow<emu::WaveEmu, 1, aff::FEAT_ALL | aff::FEAT_TIEBREAK | aff::FEAT_BIGLIST> f(a); f.run(lds.data(), 0u); }
         else if (ipl == 1 && lean) { aff::Flow<emu::WaveEmu, 1, 0u> f(a); f.run(lds.data(), 0u); }
         else if (ipl == 1) { aff::Flow<emu::WaveEmu, 1> f(a); f.run(lds.data(), 0u); }
         else if (ipl == 2 && lean) { aff::Flow<emu::WaveEmu, 2, 0u> f(a); f.run(lds.data(), 0u); }

@@ -22,7 +22,7 @@ import pytest
 
 from asyncflow_amd import _abi
 from asyncflow_amd.plan import lower
-from asyncflow_amd.workloads import fanout8, lb_two_servers, lb_with_events, single_server
+from asyncflow_amd.workloads import fanout8, lb_two_servers, lb_with_events, single_server, single_server_with_spike
 from oracle import oracle_lib as ol
 from oracle.scenarios import flow_payload, stress_mixed, wide_fanout
 from tests.conftest import GOLDEN_DIR
@@ -159,3 +159,33 @@ def test_exact_ties_by_the_thousand_follow_simpy_order(quantised_times, bits):
             assert np.array_equal(want.samples, samples), (seed, kw)
             resolved += bool(kw.get("robust"))
     assert ties > 2_000 and resolved >= 5, (ties, resolved)
+
+
+@pytest.mark.parametrize("heavy", [False, True])
+def test_second_long_spikes_of_the_reference_examples(heavy):
+    """event_inj_single_server.yml / heavy_inj_single_server.yml: a 2 s / 3 s spike on the client -> server edge.
+
+    While the spike lasts the server station runs AHEAD of the client by the spike (Flow::send_floor); when it ends,
+    rate x spike messages wait at the servers and then in the completion list: register-resident lists hand that
+    back, the long-list instantiation (FEAT_BIGLIST, per-list capacities) carries it, bit for bit.
+    The heavy file is RAM-bound with one core and fixed step times: a request is admitted at the very instant its
+    predecessor frees a core (G[j-slots] == F[j-1], the same f64 sum) all the time -- which must not hand back."""
+    p = single_server_with_spike(heavy=heavy, horizon=60, scale=0.1)     # spike from t = 12 / 18 s to 24 / 30 s
+    seed = 0x5EED0002
+    st, why = _run(p, seed, ring_rows=0)
+    if heavy:
+        assert (st, why) == ("fallback", {"list"})                          # 450 messages do not fit 64 entries
+    for kw in (dict(long_list_entries=1024), dict(long_list_entries=1024, long_list=2)):
+        st, got = _run(p, seed, ring_rows=0, robust=True, **kw)
+        if "long_list" in kw and heavy:
+            assert (st, got) == ("fallback", {"list"})                      # the completion list needs the room too
+        else:
+            assert st == "exact"
+            assert got.completed > (2500 if heavy else 500)
+
+
+def test_long_list_instantiation_matches_the_register_resident_one():
+    """FEAT_BIGLIST changes how a list is walked, not what is selected: same outputs on workloads both can run."""
+    for payload, seed in ((lb_two_servers(horizon=30), 7), (lb_with_events(users=300, horizon=60, scale=0.1), 42), (fanout8(horizon=20), 11)):
+        assert _run(payload, seed, ring_rows=0, robust=True, long_list_entries=64)[0] in ("exact", "fallback")
+        assert _run(payload, seed, ring_rows=0, robust=True, long_list_entries=512)[0] == "exact"

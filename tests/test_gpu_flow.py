@@ -19,7 +19,15 @@ import pytest
 
 from asyncflow_amd import _abi
 from asyncflow_amd.plan import lower
-from asyncflow_amd.workloads import BASELINE_SEED_BASE, fanout8, grid_users_rtt, lb_two_servers, lb_with_events, single_server
+from asyncflow_amd.workloads import (
+    BASELINE_SEED_BASE,
+    fanout8,
+    grid_users_rtt,
+    lb_two_servers,
+    lb_with_events,
+    single_server,
+    single_server_with_spike,
+)
 from oracle import oracle_lib as ol
 from oracle.scenarios import flow_payload
 from tests.conftest import GOLDEN_DIR
@@ -289,3 +297,23 @@ def test_arrival_pregeneration_group_widths_are_equivalent(monkeypatch, per_wave
         _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])), f"{per_wave} per wave, scenario {i}")
     want = np.array([ol.simulate(plan, int(s), want_clock=False, want_samples=False).counts[:5] for s in seeds])
     assert np.array_equal(res.counts[:, :5].astype(np.uint64), want)
+
+
+# ------------------------------------------------------------------- seconds-long spikes (reference examples)
+@pytest.mark.parametrize("heavy", [False, True])
+def test_reference_spike_examples_stay_on_the_flow_kernel(heavy):
+    """examples/yaml_input/data/event_inj_single_server.yml and heavy_inj_single_server.yml at their full length:
+    a 2 s / 3 s spike on the client -> server edge.  The station behind the spike runs ahead of the client while it
+    lasts; when it ends, rate x spike messages wait at the servers -- the long-list instantiation carries them
+    (heavy: the whole launch starts there; light: the few scenarios that outgrow 64 entries get it as second chance)."""
+    payload = single_server_with_spike(heavy=heavy)
+    seeds = 0x5EED0000 + np.arange(96, dtype=np.uint64)
+    res = _runner(payload, seeds=seeds).run()
+    st = res.engine_stats
+    assert st.flow_scenarios == 96 and st.flow_to_next_event == 0, (st.flow_fallback, st.flow_fallback_list, st.flow_fallback_tie, st.flow_fallback_ram)
+    if heavy:
+        assert st.flow_list_entries >= 512 and st.flow_fallback == 0
+    plan = lower(payload)
+    for i in (0, 2, 95):
+        _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])), f"scenario {i}")
+    _same_batches(res, _runner(payload, seeds=seeds, flow=False).run())

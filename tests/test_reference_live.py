@@ -102,6 +102,8 @@ def test_baseline_workloads_equal_the_reference_yaml():
         "single_server.yml": w.single_server(horizon=500),
         "two_servers_lb.yml": w.lb_two_servers(),
         "event_inj_lb.yml": w.lb_with_events(users=120, horizon=600),
+        "event_inj_single_server.yml": w.single_server_with_spike(),
+        "heavy_inj_single_server.yml": w.single_server_with_spike(heavy=True),
     }
     for name, ours in cases.items():
         theirs = SimulationPayload.model_validate(yaml.safe_load((data / name).read_text())).model_dump(mode="json")
