@@ -110,7 +110,7 @@ inline FlowLayout make_flow_layout(uint32_t cap, uint32_t ring_rows, uint32_t g_
     if (w < scratch0 + 5u * 64u) w = scratch0 + 5u * 64u;
     L.off_fr = w; w += n_servers * c_ring;
     L.off_gr = w; w += n_servers * g_ring;
-    L.off_cnt = w; w += (n_edges + 1u) / 2u + 32u;      // u32 sends per edge; 64 u32: lb order, head, n_live, mark cursor, per-server counters
+    L.off_cnt = w; w += (n_edges + 1u) / 2u + 32u + 12u;   // u32 sends per edge; 64 u32: lb order, head, n_live, mark cursor, per-server counters; send_floor's 4 x 3 f64
     L.off_ring = w; w += (ring_rows * L.pitch + 1u) / 2u;
     L.n_words = w;
     return L;
@@ -205,7 +205,7 @@ struct Flow {
     }
     AF_CORE double H_get(uint32_t s) const { return s == 0u ? h0 : s == 1u ? h1 : s == 2u ? h2 : h3; }
     AF_CORE void H_set(uint32_t s, double v) {
-        moved = moved || v > H_get(s);
+        if (kMarks) moved = moved || v > H_get(s);   // (without lookahead the last horizon is the slowest: run() watches h3)
         if (s == 0u) h0 = v; else if (s == 1u) h1 = v; else if (s == 2u) h2 = v; else h3 = v;
     }
     uint32_t n_comp, tick_base;
@@ -244,6 +244,7 @@ struct Flow {
     AF_CORE AF_PLAN_AS double* gr(uint32_t sv) const { return (AF_PLAN_AS double*)(M + A.L.off_gr) + sv * A.L.g_ring; }
     AF_CORE AF_PLAN_AS uint32_t* sends() const { return (AF_PLAN_AS uint32_t*)(M + A.L.off_cnt); }
     AF_CORE AF_PLAN_AS uint32_t* lbw() const { return sends() + ((A.n_edges + 1u) & ~1u); }  // [0..15] order, 16 head, 17 n_live, 18 mark cursor, 19 ceil(2^32 / n_live), [24..31] arrivals per server, [32..39] / [40..47] segment start / length, [48..55] step counts (leading I/O | CPU << 8 | trailing I/O << 16), [56..63] RAM slots (requests that fit at once)
+    AF_CORE AF_PLAN_AS double* fcache() const { return (AF_PLAN_AS double*)(M + A.L.off_cnt + (A.n_edges + 1u) / 2u + 32u); }   // [4][3], send_floor
     AF_CORE AF_PLAN_AS int32_t* ring() const { return (AF_PLAN_AS int32_t*)(M + A.L.off_ring); }
     AF_CORE AF_PLAN_AS double* spike_cum() const { return (AF_PLAN_AS double*)(M + A.L.off_spike); }
 
@@ -354,26 +355,41 @@ struct Flow {
     // the spike its out-edges carry then, or a later mark's time plus the spike left after it.  A spike of s seconds
     // lets the next station run s seconds AHEAD of this one instead of piling up s seconds' worth of messages it may
     // not touch yet (conservative lookahead; f64 addition is monotone, so now >= h gives key >= the floor bit for bit).
-    AF_CORE double send_floor(uint32_t st, double h) const {
+    AF_CORE double send_floor(uint32_t st, double h) {
         if (!(kMarks && A.n_edge_marks != 0u) || !(h < AF_INF)) return h;
-        double best = AF_INF;
-        const uint32_t n_out = st == 2u ? A.n_lb_edges : st == 3u ? A.n_servers : 1u;
-        for (uint32_t c = 0u; c < n_out; ++c) {
-            const uint32_t e = st == 0u   ? A.gen_out_edge
-                               : st == 1u ? A.client_out_edge
-                               : st == 2u ? (uint32_t)blob[A.off_lb + c]
-                                          : (uint32_t)(blob[A.off_srv + af::SREC * c + 1u] >> 16) & 0xFFFFu;
-            double sp = 0.0, fl = AF_INF;
-            for (uint32_t i = 0u; i < A.n_edge_marks; ++i) {   // marks are in time order
-                if ((uint32_t)emark(i)[2] != e) continue;
-                const double tm = u2d(emark(i)[0]), after = spike_cum()[i];
-                if (tm < h) sp = after;
-                else if (tm + after < fl) fl = tm + after;
+        // per station: [0] the next mark of its out-edges at or after the h this was worked out for, [1] the smallest
+        // spike its out-edges carry until then, [2] the smallest (mark time + spike left after it) over the later marks
+        AF_PLAN_AS double* c = fcache() + 3u * st;
+        double until = c[0], sp_min = c[1], cand = c[2];
+        if (!(h < until)) {   // h passed a mark (or first call: the words start at 0): walk the marks again
+            until = cand = sp_min = AF_INF;
+            const uint32_t n_out = st == 2u ? A.n_lb_edges : st == 3u ? A.n_servers : 1u;
+            for (uint32_t k = 0u; k < n_out; ++k) {
+                const uint32_t e = st == 0u   ? A.gen_out_edge
+                                   : st == 1u ? A.client_out_edge
+                                   : st == 2u ? (uint32_t)blob[A.off_lb + k]
+                                              : (uint32_t)(blob[A.off_srv + af::SREC * k + 1u] >> 16) & 0xFFFFu;
+                double sp = 0.0;
+                for (uint32_t i = 0u; i < A.n_edge_marks; ++i) {   // marks are in time order
+                    if ((uint32_t)emark(i)[2] != e) continue;
+                    const double tm = u2d(emark(i)[0]), after = spike_cum()[i];
+                    if (tm < h) {
+                        sp = after;
+                    } else {
+                        until = tm < until ? tm : until;
+                        cand = tm + after < cand ? tm + after : cand;
+                    }
+                }
+                sp_min = sp < sp_min ? sp : sp_min;
             }
-            if (h + sp < fl) fl = h + sp;
-            if (fl < best) best = fl;
+            if (lane == 0u) {   // (read again a round later at the earliest: many W::sync() in between)
+                c[0] = until;
+                c[1] = sp_min;
+                c[2] = cand;
+            }
         }
-        return best;
+        const double fl = h + sp_min;
+        return fl < cand ? fl : cand;
     }
     AF_CORE_NOINLINE static double cold_variate(uint32_t dist, double mean, double sigma, double u1, uint64_t seed, uint32_t stream,
                                                 uint32_t idx) {
@@ -970,6 +986,7 @@ struct Flow {
         gen_done = false;
         nl0 = nl1 = nl2 = nl3 = 0u;
         h0 = h1 = h2 = h3 = 0.0;
+        const uint32_t cap = A.L.cap;
         const uint32_t first_srv_stage = A.has_lb ? 1u : 2u;   // where the client's out-edge leads
 
         // Every round walks the five stations in order.  The code of select() and of edge_send() exists ONCE
@@ -977,6 +994,7 @@ struct Flow {
         for (;;) {
             uint32_t work = 0u;
             moved = false;
+            const double h_done_before = h3;
             double H_in = AF_INF, h_gen = AF_INF;
 #pragma nounroll
             for (uint32_t st = 0u; st < 5u; ++st) {
@@ -986,7 +1004,7 @@ struct Flow {
                 uint32_t aux = 0u, n_sel;
                 const uint32_t nxt = st == 0u ? 0u : st == 1u ? first_srv_stage : st;   // list the results go to (st < 4)
                 if (st == 0u) {   // generator (rqs_generator.py:97-119): up to 64 arrivals
-                    uint32_t room = cap_of(0u) - nl0;
+                    uint32_t room = (kBig ? cap_of(0u) : cap) - nl0;
                     room = room < 64u ? room : 64u;
                     const uint32_t i = cursor + lane;
                     t0 = (lane < room && i < A.n_draw) ? arr[i] : AF_INF;
@@ -997,7 +1015,7 @@ struct Flow {
                     n_sel = popc64(vm);
                     key = t0;
                 } else {
-                    n_sel = select(st - 1u, H_in, st == 4u ? 64u : cap_of(nxt) - n_list_get(nxt), key, t0, aux);
+                    n_sel = select(st - 1u, H_in, st == 4u ? 64u : (kBig ? cap_of(nxt) : cap) - n_list_get(nxt), key, t0, aux);
                 }
                 const bool have = lane < n_sel;
                 if (have) ev += 1u;                       // one timed event per message: arrival / delivery
@@ -1081,7 +1099,7 @@ struct Flow {
             W::sync();
             flush_ticks(finished ? A.n_ticks : tick_index(h_min, false));
             W::sync();
-            const bool stuck = work == 0u && !finished && !moved;
+            const bool stuck = work == 0u && !finished && !(kMarks ? moved : h3 > h_done_before);
             if (stuck) why |= FLOW_WHY_LIST;   // nothing moved, no horizon advanced: a list is full of later messages
             if (finished || W::any(why != 0u)) break;
         }

@@ -1134,7 +1134,8 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
             pend_of[h] = rate * fly;
             pend = std::fmax(pend, rate * fly);
         }
-        pend_of.back() = std::fmax(pend_of.back(), burst + rate * (lat_mean(hops.back()) + in_server));
+        if (burst > 16.0)   // (millisecond spikes -- BASELINE config 4 -- change nothing a 64-entry list would notice)
+            pend_of.back() = std::fmax(pend_of.back(), burst + rate * (lat_mean(hops.back()) + in_server));
         pend = std::fmax(pend, pend_of.back());
         // capacities of the four station lists for the FEAT_BIGLIST instantiation (hops -> lists: generator edge -> 0,
         // client edge -> 1 with a load balancer else 2, LB edges -> 2, server out-edges -> 3)
