@@ -817,8 +817,12 @@ struct Flow {
     }
     // `have` lanes: arrival `a` at server `sv`, position `pos` in seg (its server's segment starts at lbw()[32+sv] and
     // holds lbw()[40+sv] arrivals).  Returns the lane's times; advances the server's counters and rings.
-    AF_CORE SrvTimes servers_solve(bool have, uint32_t sv, uint32_t pos, double a) {
+    AF_CORE SrvTimes servers_solve(bool arrived, uint32_t sv, uint32_t pos, double a) {
         AF_PLAN_AS uint32_t* lw = lbw();
+        // A server whose endpoint needs more RAM than the server has never admits anybody: the first request blocks in
+        // RAM.get() for good and everything behind it queues up (server.py:146-149; Container gets are FIFO).  Such
+        // arrivals are timed events and nothing else.
+        const bool have = arrived && lw[56u + sv] != 0u;
         const uint32_t off = have ? lw[32u + sv] : 0u, n_k = have ? lw[40u + sv] : 0u;
         const uint32_t li = pos - off;                         // my index among this window's arrivals of my server
         const uint32_t j = have ? lw[24u + sv] + li : 0u;      // ... and among all of them
@@ -837,8 +841,7 @@ struct Flow {
         if (ram_gate && !g_in_seg) g_prev = gr(sv)[(j - slots) & (G - 1u)];
         if (core_gate && !f_in_seg) f_prev = fr(sv)[cores == 1u ? 0u : (j - cores) % cores];
         if (have && ram > 0.0) {
-            if (slots == 0u) why |= FLOW_WHY_RAM;   // never fits: the reference blocks the queue for good
-            else if (slots > G && j >= G) {         // more slots than the ring remembers: fine while fewer than G requests are inside
+            if (slots > G && j >= G) {         // more slots than the ring remembers: fine while fewer than G requests are inside
                 const double gq = li >= G ? AF_INF : gr(sv)[(j - G) & (G - 1u)];   // (li >= G: G arrivals of one server in one window)
                 if (!(gq < a)) why |= FLOW_WHY_RAM;
             }
@@ -881,6 +884,7 @@ struct Flow {
         }
         W::sync();
         if (lane < A.n_servers) lw[24u + lane] += lw[40u + lane];
+        if (arrived && !have) r.adm = r.b = r.s = r.f = r.g = AF_INF;   // never admitted
         return r;
     }
 

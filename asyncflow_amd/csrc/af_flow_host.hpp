@@ -108,7 +108,10 @@ inline FlowLayout choose_flow_layout(const af_plan_t& p, uint32_t ipl, uint32_t 
         const double ram = p.ep_ram[p.srv_ep_begin[s]];
         if (ram > 0.0) {
             const double slots = std::floor(p.srv_ram_mb[s] / ram);
-            const uint32_t want = slots > 64.0 ? 64u : (uint32_t)slots;
+            // (the ring remembers this many departures per server: 8 KB of LDS at most; servers with more slots than
+            // that run here as long as fewer requests than the ring holds are inside at once)
+            const double lim = p.n_servers <= 4u ? 256.0 : 128.0;
+            const uint32_t want = slots > lim ? (uint32_t)lim : (uint32_t)slots;
             if (want > gmax) gmax = want;
         }
     }
