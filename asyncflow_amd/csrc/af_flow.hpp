@@ -74,11 +74,13 @@ struct FlowLayout {
     // FEAT_BIGLIST: every list has its own capacity (a list behind a spiked edge holds rate x spike messages when the
     // spike ends); cap is then the largest of them
     uint32_t cap_of[4], off_list_of[4], off_eb;
+    // FEAT_LC: the next 64 (dropout, transit) draws of every LB out-edge, f64 [n_lb_edges][64]
+    uint32_t off_lc;
 };
 
 inline FlowLayout make_flow_layout(uint32_t cap, uint32_t ring_rows, uint32_t g_ring, uint32_t c_ring, uint32_t n_edges,
                                    uint32_t n_servers, uint32_t n_edge_marks, bool tiebreak = false,
-                                   const uint32_t* caps4 = nullptr) {
+                                   const uint32_t* caps4 = nullptr, uint32_t lc_edges = 0u) {
     FlowLayout L{};
     for (uint32_t s = 0; s < 4u; ++s) {
         L.cap_of[s] = caps4 ? caps4[s] : cap;
@@ -111,6 +113,7 @@ inline FlowLayout make_flow_layout(uint32_t cap, uint32_t ring_rows, uint32_t g_
     L.off_fr = w; w += n_servers * c_ring;
     L.off_gr = w; w += n_servers * g_ring;
     L.off_cnt = w; w += (n_edges + 1u) / 2u + 32u + 12u;   // u32 sends per edge; 64 u32: lb order, head, n_live, mark cursor, per-server counters; send_floor's 4 x 3 f64
+    L.off_lc = w; w += lc_edges * 64u;
     L.off_ring = w; w += (ring_rows * L.pitch + 1u) / 2u;
     L.n_words = w;
     return L;
@@ -121,6 +124,7 @@ struct FlowArgs {
     double total_time, sample_period, inv_period, tick_eps;
     uint32_t metrics_mask, gen_out_edge, client_out_edge;
     uint32_t n_edges, n_servers, has_lb, n_lb_edges, n_edge_marks, n_srv_marks;
+    uint32_t lb_least_connections;   // 0 round robin, 1 least connections (needs a FEAT_LC instantiation)
     uint32_t max_pre, max_cpu, max_post;   // longest leading-I/O / CPU / trailing-I/O run over the servers' endpoints
     uint32_t off_edge, off_srv, off_ep, off_row, off_emark, off_smark, off_lb;  // word offsets in the blob
     uint32_t blob_bytes;
@@ -181,12 +185,14 @@ struct FlowArgs {
 //   FEAT_BIGLIST   lists of any length with their own capacities (FlowLayout::cap_of): select() walks a list in
 //                  chunks of 64 at a cost proportional to what it holds, instead of keeping IPL entries per lane in
 //                  registers.  For plans whose spikes pile up rate x spike messages at one station when they end.
-enum : uint32_t { FEAT_MARKS = 1u, FEAT_ONLINE = 2u, FEAT_HBM_RING = 4u, FEAT_ALL = 7u, FEAT_TIEBREAK = 8u, FEAT_BIGLIST = 16u };
+//   FEAT_LC        least-connections load balancer (Flow::lb_pick_lc): the batch of the LB station is walked one
+//                  message at a time by the whole wave
+enum : uint32_t { FEAT_MARKS = 1u, FEAT_ONLINE = 2u, FEAT_HBM_RING = 4u, FEAT_ALL = 7u, FEAT_TIEBREAK = 8u, FEAT_BIGLIST = 16u, FEAT_LC = 32u };
 template <class W, uint32_t IPL = 1u, uint32_t FEAT = FEAT_ALL>
 struct Flow {
     static constexpr bool kMarks = (FEAT & FEAT_MARKS) != 0u, kOnline = (FEAT & FEAT_ONLINE) != 0u,
                           kHbmRing = (FEAT & FEAT_HBM_RING) != 0u, kTieBreak = (FEAT & FEAT_TIEBREAK) != 0u,
-                          kBig = (FEAT & FEAT_BIGLIST) != 0u;
+                          kBig = (FEAT & FEAT_BIGLIST) != 0u, kLC = (FEAT & FEAT_LC) != 0u;
     const FlowArgs& A;
     AF_PLAN_AS uint64_t* blob;   // plan blob (LDS copy, patched)
     AF_PLAN_AS uint64_t* M;      // layout words behind it
@@ -211,7 +217,7 @@ struct Flow {
     uint32_t n_comp, tick_base;
     bool gen_done, moved;        // moved: a horizon advanced in this round
     // per-lane accumulators (reduced at the end)
-    uint32_t ev, drops, why;
+    uint32_t ev, drops, why, info;   // info: informational result flags
     int32_t run_val;             // lane s < n_series: current value of sampled series s
 
     const double* arr;
@@ -245,6 +251,7 @@ struct Flow {
     AF_CORE AF_PLAN_AS uint32_t* sends() const { return (AF_PLAN_AS uint32_t*)(M + A.L.off_cnt); }
     AF_CORE AF_PLAN_AS uint32_t* lbw() const { return sends() + ((A.n_edges + 1u) & ~1u); }  // [0..15] order, 16 head, 17 n_live, 18 mark cursor, 19 ceil(2^32 / n_live), [24..31] arrivals per server, [32..39] / [40..47] segment start / length, [48..55] step counts (leading I/O | CPU << 8 | trailing I/O << 16), [56..63] RAM slots (requests that fit at once)
     AF_CORE AF_PLAN_AS double* fcache() const { return (AF_PLAN_AS double*)(M + A.L.off_cnt + (A.n_edges + 1u) / 2u + 32u); }   // [4][3], send_floor
+    AF_CORE AF_PLAN_AS double* lc_tab() const { return (AF_PLAN_AS double*)(M + A.L.off_lc); }   // FEAT_LC only
     AF_CORE AF_PLAN_AS int32_t* ring() const { return (AF_PLAN_AS int32_t*)(M + A.L.off_ring); }
     AF_CORE AF_PLAN_AS double* spike_cum() const { return (AF_PLAN_AS double*)(M + A.L.off_spike); }
 
@@ -357,6 +364,7 @@ struct Flow {
     // not touch yet (conservative lookahead; f64 addition is monotone, so now >= h gives key >= the floor bit for bit).
     AF_CORE double send_floor(uint32_t st, double h) {
         if (!(kMarks && A.n_edge_marks != 0u) || !(h < AF_INF)) return h;
+        if (kLC && st == 2u) return h;   // lb_pick_lc counts the server list as "everything not delivered before t"
         // per station: [0] the next mark of its out-edges at or after the h this was worked out for, [1] the smallest
         // spike its out-edges carry until then, [2] the smallest (mark time + spike left after it) over the later marks
         AF_PLAN_AS double* c = fcache() + 3u * st;
@@ -397,21 +405,27 @@ struct Flow {
     }
     // EdgeRuntime._deliver (edge.py:73-116) for the idx-th message of edge e, sent at `now`.
     // Returns false if the message is dropped; else `key` = delivery time.
-    AF_CORE bool edge_send(uint32_t e, uint32_t idx, double now, double& key) {
+    // the draws of the idx-th message of edge e (af::pre_edge_draw, edge.py:78-90): false = dropped, else its transit
+    // time; the exponential law -- the reference's default -- inline and the other laws behind one call
+    AF_CORE bool edge_draw(uint32_t e, uint32_t idx, double& transit) const {
         const AF_PLAN_AS uint64_t* r = erec(e);
         const double mean = u2d(r[0]), sigma = u2d(r[1]), dropout = u2d(r[2]);
         const uint32_t dist = (uint32_t)(r[3] >> 16) & 0xFFu;
-        // af::pre_edge_draw (edge.py:78-90) with the exponential law -- the reference's default -- inline and the
-        // other laws behind one call
         const uint32_t stream = af::stream_edge(e);
         const af::U4 rr = af::draw_block(seed, stream, idx, 0u);
-        if (af::u53(rr.x, rr.y) < dropout) {   // dropped: no latency draw
+        if (af::u53(rr.x, rr.y) < dropout) return false;   // dropped: no latency draw
+        const double u1 = af::u53(rr.z, rr.w);
+        transit = af::test_quant(dist == af::DIST_EXPONENTIAL ? -(mean * af::af_log(1.0 - u1)) : cold_variate(dist, mean, sigma, u1, seed, stream, idx));
+        return true;
+    }
+    // `pre`: the draws were made earlier (lb_pick_lc): `pre_transit` < 0 = dropped
+    AF_CORE bool edge_send(uint32_t e, uint32_t idx, double now, double& key, bool pre = false, double pre_transit = 0.0) {
+        double transit = pre_transit;
+        const bool sent = (kLC && pre) ? !(pre_transit < 0.0) : edge_draw(e, idx, transit);
+        if (!sent) {
             drops += 1u;
             return false;
         }
-        const double u1 = af::u53(rr.z, rr.w);
-        const double transit =
-            af::test_quant(dist == af::DIST_EXPONENTIAL ? -(mean * af::af_log(1.0 - u1)) : cold_variate(dist, mean, sigma, u1, seed, stream, idx));
         const double spike = (kMarks && A.n_edge_marks != 0u) ? spike_at(e, now) : 0.0;
         key = now + (transit + spike);
         // A transit time that does not advance the f64 clock (an exponential draw below half an ulp of `now`, a normal
@@ -769,6 +783,92 @@ struct Flow {
         return pick;
     }
 
+    // least_connections (lb_algorithms.py:10-20): the out-edge with the fewest messages in flight, the first such in
+    // the current order.  "In flight on an LB edge at time t" is knowledge of the LB station alone: sent before t (by
+    // this station, in time order) and delivered after t -- the entries of the server list with that target and a
+    // later delivery time (the server station only ever took deliveries before its horizon <= t: no lookahead
+    // behind a least-connections LB, send_floor) plus the earlier messages of this batch.  Dropped messages never
+    // count (edge.py:78-88).  The picks depend on each other, so the whole wave walks the batch one message at a
+    // time; what does not depend on them is done first and in parallel: the next 64 draws of every out-edge.
+    // Returns lane r's out-edge; `tr` = its transit time (< 0: dropped).
+    AF_CORE uint32_t lb_pick_lc(uint32_t n_sel, double my_key, double& tr) {
+        AF_PLAN_AS uint32_t* lw = lbw();
+        AF_PLAN_AS double* tab = lc_tab();
+        for (uint32_t c = 0u; c < A.n_lb_edges; ++c) {
+            const uint32_t e = (uint32_t)blob[A.off_lb + c];
+            double x = -1.0;
+            if (!edge_draw(e, sends()[e] + lane, x)) x = -1.0;
+            tab[c * 64u + lane] = x;
+        }
+        W::sync();
+        const AF_PLAN_AS double* K2 = list_key(2u);
+        const AF_PLAN_AS uint32_t* AX = list_aux();
+        const uint32_t n2 = n_list_get(2u), nq = (n2 + 63u) / 64u;
+        uint32_t my_e = 0u, cur = lw[18];
+        double my_k2 = -AF_INF;   // delivery time of my message once it is picked (-inf: not picked yet / dropped)
+        tr = -1.0;
+        for (uint32_t r = 0u; r < n_sel; ++r) {
+            const double t = bcast_f64(my_key, r);
+            if (kMarks && cur < A.n_srv_marks && u2d(smark(cur)[0]) <= t) {   // outages up to t (injection.py:201-226)
+                W::sync();
+                if (lane == 0u) {
+                    uint32_t nl = lw[17];
+                    while (cur < A.n_srv_marks && u2d(smark(cur)[0]) <= t) {
+                        if (u2d(smark(cur)[0]) == t) why |= FLOW_WHY_TIE;
+                        const uint64_t meta = smark(cur)[1];
+                        const uint32_t e1 = (uint32_t)meta;
+                        if (e1 != 0u) {
+                            uint32_t m2 = 0u;
+                            for (uint32_t i = 0u; i < nl; ++i)
+                                if (lw[i] != e1 - 1u) lw[m2++] = lw[i];
+                            if (!(meta >> 32)) lw[m2++] = e1 - 1u;   // SERVER_UP: back in at the tail
+                            nl = m2;
+                        }
+                        cur += 1u;
+                    }
+                    lw[17] = nl;
+                    lw[18] = cur;
+                }
+                W::sync();
+                cur = lw[18];
+            }
+            const uint32_t nl = lw[17];
+            uint32_t best = 0xFFFFFFFFu, best_e = 0u;
+            for (uint32_t i = 0u; i < nl; ++i) {
+                const uint32_t e = lw[i];
+                const uint32_t srv = (uint32_t)(erec(e)[3] >> 8) & 0xFFu;
+                uint32_t cnt = 0u;
+                for (uint32_t q = 0u; q < nq; ++q) {
+                    const uint32_t i2 = q * 64u + lane;
+                    const bool mine = i2 < n2 && AX[i2] == srv;
+                    const double k = mine ? K2[i2] : 0.0;
+                    cnt += popc64(W::ballot(mine && k > t));
+                    if (mine && k == t) why |= FLOW_WHY_TIE;   // a delivery on this edge at the very instant of the decision
+                }
+                const bool earlier = lane < r && my_e == e;
+                cnt += popc64(W::ballot(earlier && my_k2 > t));
+                if (earlier && my_k2 == t) why |= FLOW_WHY_TIE;
+                if (cnt < best) {
+                    best = cnt;
+                    best_e = e;
+                }
+            }
+            // the message's place among this batch's messages on that edge = which of the prepared draws is its own
+            const uint32_t k_on_edge = popc64(W::ballot(lane < r && my_e == best_e));
+            uint32_t c_of = 0u;
+            for (uint32_t c = 0u; c < A.n_lb_edges; ++c) c_of = (uint32_t)blob[A.off_lb + c] == best_e ? c : c_of;
+            const double x = tab[c_of * 64u + k_on_edge];
+            const double sp = (kMarks && A.n_edge_marks != 0u) ? spike_at(best_e, t) : 0.0;
+            if (lane == r) {
+                my_e = best_e;
+                tr = x;
+                my_k2 = x < 0.0 ? -AF_INF : t + (x + sp);
+            }
+        }
+        W::sync();
+        return my_e;
+    }
+
     // ---- servers (server.py:79-276 for endpoints of the form IO* CPU* IO*) ----------------------------
     // Every request of a server runs the same step program, so the server is a tandem of FIFO stations and
     //   adm_j = max(arrival_j, G_{j-slots})      RAM admission: strict FIFO, `slots` requests fit at once (server.py:146-149)
@@ -884,7 +984,10 @@ struct Flow {
         }
         W::sync();
         if (lane < A.n_servers) lw[24u + lane] += lw[40u + lane];
-        if (arrived && !have) r.adm = r.b = r.s = r.f = r.g = AF_INF;   // never admitted
+        if (arrived && !have) {   // never admitted (the sequential kernels and the oracle report the same, informational, flag)
+            r.adm = r.b = r.s = r.f = r.g = AF_INF;
+            info |= af::FLAG_RAM_STARVED;
+        }
         return r;
     }
 
@@ -985,7 +1088,7 @@ struct Flow {
 
         cursor = n_comp = tick_base = 0u;
         ev = drops = 0u;
-        why = 0u;
+        why = info = 0u;
         run_val = 0;
         gen_done = false;
         nl0 = nl1 = nl2 = nl3 = 0u;
@@ -1025,9 +1128,9 @@ struct Flow {
                 if (have) ev += 1u;                       // one timed event per message: arrival / delivery
                 work += n_sel;
                 // ---- what the station does with it: the out-edge, the message's index on it, the send time
-                bool sending = have;
+                bool sending = have, pre = false;
                 uint32_t e = 0u, idx = 0u, tgt = 0u;
-                double ts = key;
+                double ts = key, pre_tr = 0.0;
                 if (st == 0u) {
                     e = A.gen_out_edge;
                     idx = cursor + lane;
@@ -1043,7 +1146,12 @@ struct Flow {
                     tgt = (uint32_t)(erec(e)[3] >> 8) & 0xFFu;
                 } else if (st == 2u) {   // load balancer
                     if (n_sel > 0u) {
-                        e = lb_pick(n_sel, key);
+                        if (kLC && A.lb_least_connections) {
+                            e = lb_pick_lc(n_sel, key, pre_tr);
+                            pre = true;
+                        } else {
+                            e = lb_pick(n_sel, key);
+                        }
                         idx = claim_send_index(have, e, false);
                         tgt = (uint32_t)(erec(e)[3] >> 8) & 0xFFu;
                     }
@@ -1084,7 +1192,7 @@ struct Flow {
                 }
                 if (st < 4u) {
                     double k2 = 0.0;
-                    const bool ok = sending && edge_send(e, idx, ts, k2);
+                    const bool ok = sending && edge_send(e, idx, ts, k2, kLC && pre, pre_tr);
                     append(nxt, ok, k2, t0, tgt, ts);
                     if (st > 0u) H_in = H_get(st - 1u);
                     H_in = send_floor(st, H_in);   // what the next station may touch: everything delivered before this
@@ -1109,9 +1217,9 @@ struct Flow {
         }
 
         // ---- counts
-        const uint32_t ev_all = wave_sum(ev), drop_all = wave_sum(drops), why_all = wave_or(why);
+        const uint32_t ev_all = wave_sum(ev), drop_all = wave_sum(drops), why_all = wave_or(why), info_all = wave_or(info);
         if (lane == 0u) {
-            uint32_t flags = A.pre_flags[sc];
+            uint32_t flags = A.pre_flags[sc] | info_all;
             if (n_comp > A.clock_cap && clock != nullptr) flags |= af::FLAG_CLOCK_OVERFLOW;
             if (A.n_ticks > A.tick_cap && samples != nullptr) flags |= af::FLAG_TICK_OVERFLOW;
             if (why_all != 0u) flags |= FLAG_FLOW_FALLBACK | why_all;

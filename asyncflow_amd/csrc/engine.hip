@@ -930,6 +930,7 @@ int af_engine_create(const af_plan_t* plan, int device, const af_engine_options_
         f.n_servers = plan->n_servers;
         f.has_lb = plan->has_lb;
         f.n_lb_edges = plan->n_lb_edges;
+        f.lb_least_connections = aff::lc_edges(*plan) != 0u ? 1u : 0u;
         f.n_edge_marks = plan->n_edge_marks;
         f.n_srv_marks = plan->n_srv_marks;
         aff::flow_step_maxima(*plan, f.max_pre, f.max_cpu, f.max_post);
@@ -1194,15 +1195,16 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
             win_rows = w >= (double)(rows / 2u) ? (uint32_t)w : rows / 2u;   // an explicit small ring: half of it, overflow -> hand-back
         }
         // long lists have to fit the LDS of a compute unit next to everything else: halve the longest until they do
+        const uint32_t lc_n = e->fargs.lb_least_connections ? e->fargs.n_lb_edges : 0u;   // least connections: a table of prepared draws
         auto big_layout = [&](uint32_t ring) {
-            aff::FlowLayout L = aff::make_flow_layout(0u, ring, e->fargs.L.g_ring, e->fargs.L.c_ring, a.n_edges, a.n_servers, a.n_edge_marks, true, big_caps);
+            aff::FlowLayout L = aff::make_flow_layout(0u, ring, e->fargs.L.g_ring, e->fargs.L.c_ring, a.n_edges, a.n_servers, a.n_edge_marks, true, big_caps, lc_n);
             while (a.blob_bytes + L.n_words * 8u > kLdsLimit) {
                 uint32_t m = 0;
                 for (uint32_t s = 1; s < 4u; ++s)
                     if (big_caps[s] > big_caps[m]) m = s;
                 if (big_caps[m] <= 256u) break;
                 big_caps[m] = (big_caps[m] / 2u + 63u) & ~63u;
-                L = aff::make_flow_layout(0u, ring, e->fargs.L.g_ring, e->fargs.L.c_ring, a.n_edges, a.n_servers, a.n_edge_marks, true, big_caps);
+                L = aff::make_flow_layout(0u, ring, e->fargs.L.g_ring, e->fargs.L.c_ring, a.n_edges, a.n_servers, a.n_edge_marks, true, big_caps, lc_n);
             }
             return L;
         };
@@ -1213,7 +1215,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
             }
             FL = big_layout(rows);
         } else {
-            FL = aff::make_flow_layout(entries, rows, e->fargs.L.g_ring, e->fargs.L.c_ring, a.n_edges, a.n_servers, a.n_edge_marks);
+            FL = aff::make_flow_layout(entries, rows, e->fargs.L.g_ring, e->fargs.L.c_ring, a.n_edges, a.n_servers, a.n_edge_marks, false, nullptr, lc_n);
         }
         FL.win_rows = win_rows;
         FL2 = big_layout(0u);   // second chance: tick differences in HBM (no reach limit)
@@ -1420,8 +1422,14 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
             // the leanest instantiation that covers this launch (a compiled-in feature costs wave-uniform registers)
             const bool lean = a.n_edge_marks == 0u && a.n_srv_marks == 0u && !f.online_hist && !f.online_rps &&
                               (FL.ring_rows != 0u || f.samples == nullptr);
-            flow_lean = lean;
-            const void* fn = flow_big         ? reinterpret_cast<const void*>(af_flow_kernel<1, aff::FEAT_ALL | aff::FEAT_TIEBREAK | aff::FEAT_BIGLIST>)
+            flow_lean = lean && !flow_big && f.lb_least_connections == 0u;
+            constexpr uint32_t kRobust = aff::FEAT_ALL | aff::FEAT_TIEBREAK | aff::FEAT_BIGLIST, kLC = aff::FEAT_LC;
+            const bool lc = f.lb_least_connections != 0u;
+            const void* fn = flow_big         ? (lc ? reinterpret_cast<const void*>(af_flow_kernel<1, kRobust | kLC>)
+                                                    : reinterpret_cast<const void*>(af_flow_kernel<1, kRobust>))
+                             : lc             ? (FL.cap == 64u    ? reinterpret_cast<const void*>(af_flow_kernel<1, aff::FEAT_ALL | kLC>)
+                                                 : FL.cap == 128u ? reinterpret_cast<const void*>(af_flow_kernel<2, aff::FEAT_ALL | kLC>)
+                                                                  : reinterpret_cast<const void*>(af_flow_kernel<4, aff::FEAT_ALL | kLC>))
                              : FL.cap == 64u  ? (lean ? reinterpret_cast<const void*>(af_flow_kernel<1, 0u>)
                                                       : reinterpret_cast<const void*>(af_flow_kernel<1, aff::FEAT_ALL>))
                              : FL.cap == 128u ? (lean ? reinterpret_cast<const void*>(af_flow_kernel<2, 0u>)
@@ -1477,7 +1485,9 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
                     HIP_TRY(hipGetLastError());
                     a.scen_map = nullptr;
                 }
-                const void* fn2 = reinterpret_cast<const void*>(af_flow_kernel<1, aff::FEAT_ALL | aff::FEAT_TIEBREAK | aff::FEAT_BIGLIST>);
+                constexpr uint32_t kRobust = aff::FEAT_ALL | aff::FEAT_TIEBREAK | aff::FEAT_BIGLIST;
+                const void* fn2 = f2.lb_least_connections ? reinterpret_cast<const void*>(af_flow_kernel<1, kRobust | aff::FEAT_LC>)
+                                                          : reinterpret_cast<const void*>(af_flow_kernel<1, kRobust>);
                 if (lds2 > 48u * 1024u) HIP_TRY(hipFuncSetAttribute(fn2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
                 HIP_TRY(hipEventRecord(e->ev3, e->stream));
                 void* kargs2[] = {&f2};

@@ -193,7 +193,7 @@ def random_payload(rng: random.Random, horizon: int = 12) -> dict:
 
 def flow_payload(rng: random.Random, horizon: int = 8) -> dict:
     """Random payload INSIDE the range of the stage-parallel kernel (asyncflow_amd/csrc/af_flow.hpp):
-    generator -> client -> [round-robin LB ->] 1..8 servers -> client, one endpoint per server of the
+    generator -> client -> [LB (round robin / least connections) ->] 1..8 servers -> client, one endpoint per server of the
     form IO* CPU* IO*, continuous edge latencies.  Loads from idle to saturated, multi-core servers,
     dyadic step times (exact ties under queueing), tight RAM (admission would block), spikes, outages,
     Gaussian users: the kernel must either reproduce the oracle bit for bit or hand the scenario back."""
@@ -253,7 +253,8 @@ def flow_payload(rng: random.Random, horizon: int = 8) -> dict:
         users.update(distribution="normal", variance=rng.choice([1, 10, 40]))
     nodes: dict[str, Any] = {"client": {"id": "cli"}, "servers": servers}
     if use_lb:
-        nodes["load_balancer"] = {"id": "lb", "algorithms": "round_robin", "server_covered": [f"s{i}" for i in range(n_srv)]}
+        algo = "least_connection" if int(m * 1.0e6) % 3 == 0 else "round_robin"   # (a third of the LBs; no extra draw)
+        nodes["load_balancer"] = {"id": "lb", "algorithms": algo, "server_covered": [f"s{i}" for i in range(n_srv)]}
     p: dict[str, Any] = {
         "rqs_input": {
             "id": "gen",

@@ -205,6 +205,7 @@ extern "C" int hc_flow_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ov
     a.n_servers = p->n_servers;
     a.has_lb = p->has_lb;
     a.n_lb_edges = p->n_lb_edges;
+    a.lb_least_connections = aff::lc_edges(*p) != 0u ? 1u : 0u;
     a.n_edge_marks = p->n_edge_marks;
     a.n_srv_marks = p->n_srv_marks;
     aff::flow_step_maxima(*p, a.max_pre, a.max_cpu, a.max_post);
@@ -216,7 +217,7 @@ extern "C" int hc_flow_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ov
     if (robust) {
         uint32_t caps4[4];
         for (uint32_t s = 0; s < 4u; ++s) caps4[s] = (big_which == 0u || big_which == s + 1u) ? big_cap : 256u;
-        a.L = aff::make_flow_layout(0u, a.L.ring_rows, a.L.g_ring, a.L.c_ring, p->n_edges, p->n_servers, p->n_edge_marks, true, caps4);
+        a.L = aff::make_flow_layout(0u, a.L.ring_rows, a.L.g_ring, a.L.c_ring, p->n_edges, p->n_servers, p->n_edge_marks, true, caps4, aff::lc_edges(*p));
         a.L.win_rows = a.L.ring_rows / 2u;
     }
     a.tick_t = tt.t.data();
@@ -248,8 +249,14 @@ extern "C" int hc_flow_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ov
     std::vector<uint64_t> lds(pk.words.size() + a.L.n_words + 2u, 0xDEADBEEFDEADBEEFull);
     // the instantiation the engine would launch: the lean one when the launch needs none of the optional features
     const bool lean = p->n_edge_marks == 0 && p->n_srv_marks == 0 && !g_online_hist && !g_online_rps && (a.L.ring_rows != 0 || !samples);
+    const bool lc = a.lb_least_connections != 0u;
+    constexpr uint32_t kAll = aff::FEAT_ALL, kRobust = aff::FEAT_ALL | aff::FEAT_TIEBREAK | aff::FEAT_BIGLIST, kLC = aff::FEAT_LC;
     auto body = [&]() {
-        if (robust) { aff::Flow<emu::WaveEmu, 1, aff::FEAT_ALL | aff::FEAT_TIEBREAK | aff::FEAT_BIGLIST> f(a); f.run(lds.data(), 0u); }
+        if (robust && lc) { aff::Flow<emu::WaveEmu, 1, kRobust | kLC> f(a); f.run(lds.data(), 0u); }
+        else if (robust) { aff::Flow<emu::WaveEmu, 1, kRobust> f(a); f.run(lds.data(), 0u); }
+        else if (lc && ipl == 1) { aff::Flow<emu::WaveEmu, 1, kAll | kLC> f(a); f.run(lds.data(), 0u); }
+        else if (lc && ipl == 2) { aff::Flow<emu::WaveEmu, 2, kAll | kLC> f(a); f.run(lds.data(), 0u); }
+        else if (lc) { aff::Flow<emu::WaveEmu, 4, kAll | kLC> f(a); f.run(lds.data(), 0u); }
         else if (ipl == 1 && lean) { aff::Flow<emu::WaveEmu, 1, 0u> f(a); f.run(lds.data(), 0u); }
         else if (ipl == 1) { aff::Flow<emu::WaveEmu, 1> f(a); f.run(lds.data(), 0u); }
         else if (ipl == 2 && lean) { aff::Flow<emu::WaveEmu, 2, 0u> f(a); f.run(lds.data(), 0u); }

@@ -24,7 +24,7 @@ from asyncflow_amd import _abi
 from asyncflow_amd.plan import lower
 from asyncflow_amd.workloads import fanout8, lb_two_servers, lb_with_events, single_server, single_server_with_spike
 from oracle import oracle_lib as ol
-from oracle.scenarios import flow_payload, stress_mixed, wide_fanout
+from oracle.scenarios import flow_payload, server_chain, stress_mixed, wide_fanout
 from tests.conftest import GOLDEN_DIR
 from tests.hostcheck import build as hc
 
@@ -43,6 +43,7 @@ def _run(payload, seed, **kw):
     assert np.array_equal(want.clock.view(np.uint64), clock.view(np.uint64))
     assert np.array_equal(want.samples, samples)
     assert (flags & _abi.FATAL_FLAGS) == 0
+    assert (flags & 0xFF) == (int(want.counts[_abi.CNT_FLAGS]) & 0xFF)      # informational flags too (RAM_STARVED)
     return "exact", want
 
 
@@ -104,8 +105,8 @@ def test_small_lists_hand_the_scenario_back_instead_of_dropping_messages():
 
 
 def test_plans_outside_the_feed_forward_range_are_refused():
-    for payload, word in ((stress_mixed(40), "least-connections"), (wide_fanout(horizon=12), "8 servers"),
-                          (lb_two_servers(horizon=10, algo="least_connection"), "least-connections")):
+    for payload, word in ((stress_mixed(40), "Poisson"), (wide_fanout(horizon=12), "8 servers"),
+                          (server_chain("exponential", 0.003), "server chain")):
         assert hc.flow_simulate(lower(payload), 1) is None
         assert word in hc.flow_reason()
 
@@ -189,3 +190,17 @@ def test_long_list_instantiation_matches_the_register_resident_one():
     for payload, seed in ((lb_two_servers(horizon=30), 7), (lb_with_events(users=300, horizon=60, scale=0.1), 42), (fanout8(horizon=20), 11)):
         assert _run(payload, seed, ring_rows=0, robust=True, long_list_entries=64)[0] in ("exact", "fallback")
         assert _run(payload, seed, ring_rows=0, robust=True, long_list_entries=512)[0] == "exact"
+
+
+@pytest.mark.parametrize("kw", [dict(ipl=1, ring_rows=64), dict(ipl=2, ring_rows=0), dict(robust=True, ring_rows=0)])
+def test_least_connections_is_a_decision_of_the_lb_station_alone(kw):
+    """lb_algorithms.py:10-20 picks the out-edge with the fewest messages IN FLIGHT ON THE EDGE (edge.py:90,115):
+    sent by the LB before t, delivered after t -- no feedback from the servers, so the plan stays feed-forward.
+    Flow::lb_pick_lc walks the batch one message at a time against the server list; outages reorder the candidates."""
+    assert _run(lb_two_servers(horizon=30, algo="least_connection"), 5, **kw)[0] == "exact"
+    p = lb_with_events(users=300, horizon=60, scale=0.1)
+    p["topology_graph"]["nodes"]["load_balancer"]["algorithms"] = "least_connection"
+    assert _run(p, 42, **kw)[0] == "exact"
+    p = fanout8(horizon=20)
+    p["topology_graph"]["nodes"]["load_balancer"]["algorithms"] = "least_connection"
+    assert _run(p, 11, **dict(kw, ring_rows=0, ipl=2))[0] == "exact"      # (~1-s hops: 128-entry lists, differences in HBM)

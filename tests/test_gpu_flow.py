@@ -123,7 +123,7 @@ def test_handed_back_scenarios_are_invisible_in_the_results():
         assert st.flow_retried <= st.flow_fallback and st.flow_to_next_event <= st.flow_fallback
         _same_batches(res, _runner(payload, seeds=seeds, flow=False).run())
         _assert_scenario(res[0], ol.simulate(lower(payload), int(seeds[0])), f"case {case}")
-    assert handed_back > 5 and ran > 20
+    assert handed_back >= 3 and ran > 20     # (the kernel models more every round: 4 of 120 are left, all exact ties)
 
 
 def test_single_server_and_sweep_columns():
@@ -317,3 +317,24 @@ def test_reference_spike_examples_stay_on_the_flow_kernel(heavy):
     for i in (0, 2, 95):
         _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])), f"scenario {i}")
     _same_batches(res, _runner(payload, seeds=seeds, flow=False).run())
+
+
+# ------------------------------------------------------------------------------------ least connections
+def test_least_connections_runs_on_the_flow_kernel():
+    """lb_algorithms.py:10-20: fewest messages in flight on the LB's out-edges -- a decision of the LB station alone."""
+    payload = lb_two_servers(horizon=60, algo="least_connection")
+    seeds = 0x1EA50000 + np.arange(160, dtype=np.uint64)
+    res = _runner(payload, seeds=seeds).run()
+    st = res.engine_stats
+    assert st.flow_scenarios == 160 and st.flow_to_next_event == 0
+    plan = lower(payload)
+    for i in (0, 1, 159):
+        _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])), f"scenario {i}")
+    _same_batches(res, _runner(payload, seeds=seeds, flow=False).run())
+    # with injected outages (the candidate list changes) and spikes, on the 8-server fan-out too
+    for payload in (lb_with_events(users=300, horizon=60, scale=0.1), fanout8(horizon=40)):
+        payload["topology_graph"]["nodes"]["load_balancer"]["algorithms"] = "least_connection"
+        seeds = np.arange(64, dtype=np.uint64) + 77
+        res = _runner(payload, seeds=seeds).run()
+        assert res.engine_stats.flow_scenarios == 64 and res.engine_stats.flow_to_next_event == 0
+        _same_batches(res, _runner(payload, seeds=seeds, flow=False).run())
