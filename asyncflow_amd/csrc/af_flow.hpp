@@ -74,13 +74,11 @@ struct FlowLayout {
     // FEAT_BIGLIST: every list has its own capacity (a list behind a spiked edge holds rate x spike messages when the
     // spike ends); cap is then the largest of them
     uint32_t cap_of[4], off_list_of[4], off_eb;
-    // FEAT_LC: the next 64 (dropout, transit) draws of every LB out-edge, f64 [n_lb_edges][64]
-    uint32_t off_lc;
 };
 
 inline FlowLayout make_flow_layout(uint32_t cap, uint32_t ring_rows, uint32_t g_ring, uint32_t c_ring, uint32_t n_edges,
                                    uint32_t n_servers, uint32_t n_edge_marks, bool tiebreak = false,
-                                   const uint32_t* caps4 = nullptr, uint32_t lc_edges = 0u) {
+                                   const uint32_t* caps4 = nullptr) {
     FlowLayout L{};
     for (uint32_t s = 0; s < 4u; ++s) {
         L.cap_of[s] = caps4 ? caps4[s] : cap;
@@ -113,7 +111,6 @@ inline FlowLayout make_flow_layout(uint32_t cap, uint32_t ring_rows, uint32_t g_
     L.off_fr = w; w += n_servers * c_ring;
     L.off_gr = w; w += n_servers * g_ring;
     L.off_cnt = w; w += (n_edges + 1u) / 2u + 32u + 12u;   // u32 sends per edge; 64 u32: lb order, head, n_live, mark cursor, per-server counters; send_floor's 4 x 3 f64
-    L.off_lc = w; w += lc_edges * 64u;
     L.off_ring = w; w += (ring_rows * L.pitch + 1u) / 2u;
     L.n_words = w;
     return L;
@@ -251,7 +248,6 @@ struct Flow {
     AF_CORE AF_PLAN_AS uint32_t* sends() const { return (AF_PLAN_AS uint32_t*)(M + A.L.off_cnt); }
     AF_CORE AF_PLAN_AS uint32_t* lbw() const { return sends() + ((A.n_edges + 1u) & ~1u); }  // [0..15] order, 16 head, 17 n_live, 18 mark cursor, 19 ceil(2^32 / n_live), [24..31] arrivals per server, [32..39] / [40..47] segment start / length, [48..55] step counts (leading I/O | CPU << 8 | trailing I/O << 16), [56..63] RAM slots (requests that fit at once)
     AF_CORE AF_PLAN_AS double* fcache() const { return (AF_PLAN_AS double*)(M + A.L.off_cnt + (A.n_edges + 1u) / 2u + 32u); }   // [4][3], send_floor
-    AF_CORE AF_PLAN_AS double* lc_tab() const { return (AF_PLAN_AS double*)(M + A.L.off_lc); }   // FEAT_LC only
     AF_CORE AF_PLAN_AS int32_t* ring() const { return (AF_PLAN_AS int32_t*)(M + A.L.off_ring); }
     AF_CORE AF_PLAN_AS double* spike_cum() const { return (AF_PLAN_AS double*)(M + A.L.off_spike); }
 
@@ -327,18 +323,36 @@ struct Flow {
             const bool is_ram = is_srv && (lane - A.n_edges) % 3u == 2u;
             const bool on = lane < A.n_edges ? edges_on : (is_srv && servers_on);
             const uint32_t stop = upto < A.tick_cap ? upto : A.tick_cap;
-            for (uint32_t r = tick_base; r < stop; ++r) {
-                if (lane < pitch) {
-                    if (kHbmRing && R == 0u) {
-                        run_val += (int32_t)W::global_load(samples + (size_t)r * pitch + lane);
-                    } else {
+            if (kHbmRing && R == 0u) {
+                // the differences of kBatch rows are fetched before the first of them is summed: one HBM latency per batch
+                // instead of one per row (config 5: 32 rows per round; -2.5 % kernel time.  The LDS ring gains nothing.)
+                constexpr uint32_t kBatch = 8u;
+                for (uint32_t r0 = tick_base; r0 < stop; r0 += kBatch) {
+                    int32_t d[kBatch];
+#pragma unroll
+                    for (uint32_t u = 0u; u < kBatch; ++u)
+                        d[u] = (lane < pitch && r0 + u < stop) ? (int32_t)W::global_load(samples + (size_t)(r0 + u) * pitch + lane) : 0;
+#pragma unroll
+                    for (uint32_t u = 0u; u < kBatch; ++u) {
+                        const uint32_t r = r0 + u;
+                        if (lane < pitch && r < stop) {
+                            run_val += d[u];
+                            uint32_t word = 0u;
+                            if (on) word = is_ram ? __builtin_bit_cast(uint32_t, (float)(double)run_val) : (uint32_t)run_val;
+                            samples[(size_t)r * pitch + lane] = word;
+                        }
+                    }
+                }
+            } else {
+                for (uint32_t r = tick_base; r < stop; ++r) {
+                    if (lane < pitch) {
                         AF_PLAN_AS int32_t* cell = ring() + (r & (R - 1u)) * pitch + lane;
                         run_val += *cell;
                         *cell = 0;
+                        uint32_t word = 0u;
+                        if (on) word = is_ram ? __builtin_bit_cast(uint32_t, (float)(double)run_val) : (uint32_t)run_val;
+                        samples[(size_t)r * pitch + lane] = word;
                     }
-                    uint32_t word = 0u;
-                    if (on) word = is_ram ? __builtin_bit_cast(uint32_t, (float)(double)run_val) : (uint32_t)run_val;
-                    samples[(size_t)r * pitch + lane] = word;
                 }
             }
         }
@@ -793,71 +807,96 @@ struct Flow {
     // Returns lane r's out-edge; `tr` = its transit time (< 0: dropped).
     AF_CORE uint32_t lb_pick_lc(uint32_t n_sel, double my_key, double& tr) {
         AF_PLAN_AS uint32_t* lw = lbw();
-        AF_PLAN_AS double* tab = lc_tab();
-        for (uint32_t c = 0u; c < A.n_lb_edges; ++c) {
-            const uint32_t e = (uint32_t)blob[A.off_lb + c];
-            double x = -1.0;
-            if (!edge_draw(e, sends()[e] + lane, x)) x = -1.0;
-            tab[c * 64u + lane] = x;
+        // xs[c]: my lane's draw on the c-th out-edge (payload order) = the transit time of the (lane+1)-th message this
+        // batch sends there (< 0: dropped).  Registers, not LDS: the walk below reads one of them per message, and an
+        // LDS round trip per message would be most of its time.
+        double xs[kMaxServers];
+#pragma unroll
+        for (uint32_t c = 0u; c < kMaxServers; ++c) {
+            xs[c] = -1.0;
+            if (c < A.n_lb_edges) {
+                const uint32_t e = (uint32_t)blob[A.off_lb + c];
+                double x = -1.0;
+                if (edge_draw(e, sends()[e] + lane, x)) xs[c] = x;
+            }
         }
-        W::sync();
+        // What does not depend on the picks either: how many entries of the server list are still in flight towards
+        // each server at MY message's time -- every lane walks the list (the same entry in all lanes: LDS broadcasts)
+        // and keeps eight 16-bit counts in two words (<= kMaxServers servers, <= 16 384 entries).
         const AF_PLAN_AS double* K2 = list_key(2u);
         const AF_PLAN_AS uint32_t* AX = list_aux();
-        const uint32_t n2 = n_list_get(2u), nq = (n2 + 63u) / 64u;
-        uint32_t my_e = 0u, cur = lw[18];
+        const uint32_t n2 = n_list_get(2u);
+        uint64_t b_lo = 0ull, b_hi = 0ull;
+        for (uint32_t i2 = 0u; i2 < n2; ++i2) {
+            const double k = K2[i2];
+            const uint32_t ax = W::bcast32(AX[i2], 0u);
+            const uint64_t inc = k > my_key ? 1ull << (16u * (ax & 3u)) : 0ull;
+            if (ax < 4u) b_lo += inc;
+            else b_hi += inc;
+            if (k == my_key) why |= FLOW_WHY_TIE;   // a delivery by the LB's edges at the very instant of a decision
+        }
+        // the candidates in the LB's current order: lane i < n_live holds (out-edge, its server, its place in the payload order)
+        uint32_t live_e = 0u, live_srv = 0u, live_c = 0u, nl = 0u, cur = 0u;
+        double next_mark = AF_INF;   // time of the next outage mark
+        auto load_live = [&]() {
+            nl = lw[17];
+            cur = lw[18];
+            next_mark = (kMarks && cur < A.n_srv_marks) ? u2d(smark(cur)[0]) : AF_INF;
+            live_e = lane < nl ? lw[lane] : 0u;
+            live_srv = (uint32_t)(erec(live_e)[3] >> 8) & 0xFFu;
+            live_c = 0u;
+            for (uint32_t c = 0u; c < A.n_lb_edges; ++c) live_c = (uint32_t)blob[A.off_lb + c] == live_e ? c : live_c;
+        };
+        load_live();
+        uint32_t my_e = 0u;
         double my_k2 = -AF_INF;   // delivery time of my message once it is picked (-inf: not picked yet / dropped)
         tr = -1.0;
         for (uint32_t r = 0u; r < n_sel; ++r) {
             const double t = bcast_f64(my_key, r);
-            if (kMarks && cur < A.n_srv_marks && u2d(smark(cur)[0]) <= t) {   // outages up to t (injection.py:201-226)
+            if (kMarks && next_mark <= t) {   // outages up to t (injection.py:201-226)
                 W::sync();
                 if (lane == 0u) {
-                    uint32_t nl = lw[17];
+                    uint32_t m = lw[17];
                     while (cur < A.n_srv_marks && u2d(smark(cur)[0]) <= t) {
                         if (u2d(smark(cur)[0]) == t) why |= FLOW_WHY_TIE;
                         const uint64_t meta = smark(cur)[1];
                         const uint32_t e1 = (uint32_t)meta;
                         if (e1 != 0u) {
                             uint32_t m2 = 0u;
-                            for (uint32_t i = 0u; i < nl; ++i)
+                            for (uint32_t i = 0u; i < m; ++i)
                                 if (lw[i] != e1 - 1u) lw[m2++] = lw[i];
                             if (!(meta >> 32)) lw[m2++] = e1 - 1u;   // SERVER_UP: back in at the tail
-                            nl = m2;
+                            m = m2;
                         }
                         cur += 1u;
                     }
-                    lw[17] = nl;
+                    lw[17] = m;
                     lw[18] = cur;
                 }
                 W::sync();
-                cur = lw[18];
+                load_live();
             }
-            const uint32_t nl = lw[17];
-            uint32_t best = 0xFFFFFFFFu, best_e = 0u;
+            const uint64_t blo = W::bcast64(b_lo, r), bhi = W::bcast64(b_hi, r);
+            uint32_t best = 0xFFFFFFFFu, best_e = 0u, best_i = 0u;
             for (uint32_t i = 0u; i < nl; ++i) {
-                const uint32_t e = lw[i];
-                const uint32_t srv = (uint32_t)(erec(e)[3] >> 8) & 0xFFu;
-                uint32_t cnt = 0u;
-                for (uint32_t q = 0u; q < nq; ++q) {
-                    const uint32_t i2 = q * 64u + lane;
-                    const bool mine = i2 < n2 && AX[i2] == srv;
-                    const double k = mine ? K2[i2] : 0.0;
-                    cnt += popc64(W::ballot(mine && k > t));
-                    if (mine && k == t) why |= FLOW_WHY_TIE;   // a delivery on this edge at the very instant of the decision
-                }
+                const uint32_t e = W::bcast32(live_e, i), srv = W::bcast32(live_srv, i);
+                uint32_t cnt = (uint32_t)((srv < 4u ? blo : bhi) >> (16u * (srv & 3u))) & 0xFFFFu;
                 const bool earlier = lane < r && my_e == e;
                 cnt += popc64(W::ballot(earlier && my_k2 > t));
                 if (earlier && my_k2 == t) why |= FLOW_WHY_TIE;
                 if (cnt < best) {
                     best = cnt;
                     best_e = e;
+                    best_i = i;
                 }
             }
             // the message's place among this batch's messages on that edge = which of the prepared draws is its own
             const uint32_t k_on_edge = popc64(W::ballot(lane < r && my_e == best_e));
-            uint32_t c_of = 0u;
-            for (uint32_t c = 0u; c < A.n_lb_edges; ++c) c_of = (uint32_t)blob[A.off_lb + c] == best_e ? c : c_of;
-            const double x = tab[c_of * 64u + k_on_edge];
+            const uint32_t c_of = W::bcast32(live_c, best_i);
+            double x = -1.0;
+#pragma unroll
+            for (uint32_t c = 0u; c < kMaxServers; ++c)
+                if (c == c_of) x = bcast_f64(xs[c], k_on_edge);
             const double sp = (kMarks && A.n_edge_marks != 0u) ? spike_at(best_e, t) : 0.0;
             if (lane == r) {
                 my_e = best_e;

@@ -22,6 +22,7 @@ inline std::string flow_ineligible_reason(const af_plan_t& p) {
     if (p.has_lb) {
         if (ck != AF_NODE_LB) return "client does not feed the load balancer";
         if (p.n_lb_edges == 0 || p.n_lb_edges > 16u) return "load balancer fan-out outside 1..16";
+        if (p.lb_algo == AF_LB_LEAST_CONNECTIONS && p.n_lb_edges > kMaxServers) return "least-connections fan-out above 8";
         for (uint32_t i = 0; i < p.n_lb_edges; ++i)
             if (p.edge_target_kind[p.lb_edges[i]] != AF_NODE_SERVER) return "load balancer edge does not lead to a server";
     } else if (ck != AF_NODE_SERVER) {
@@ -98,7 +99,7 @@ inline uint32_t pow2_ge(uint32_t v) {
     return p;
 }
 
-// LB out-edges whose next draws the least-connections walk prepares (0: round robin / no LB)
+// LB out-edges of a least-connections load balancer (0: round robin / no LB)
 inline uint32_t lc_edges(const af_plan_t& p) { return (p.has_lb && p.lb_algo == AF_LB_LEAST_CONNECTIONS) ? p.n_lb_edges : 0u; }
 
 // list capacity (64 * ipl), tick-ring rows: from the expected number of messages in flight per
@@ -117,8 +118,7 @@ inline FlowLayout choose_flow_layout(const af_plan_t& p, uint32_t ipl, uint32_t 
             if (want > gmax) gmax = want;
         }
     }
-    return make_flow_layout(64u * ipl, ring_rows ? pow2_ge(ring_rows) : 0u, pow2_ge(gmax), cmax, p.n_edges, p.n_servers, p.n_edge_marks,
-                            false, nullptr, lc_edges(p));
+    return make_flow_layout(64u * ipl, ring_rows ? pow2_ge(ring_rows) : 0u, pow2_ge(gmax), cmax, p.n_edges, p.n_servers, p.n_edge_marks);
 }
 
 }  // namespace aff

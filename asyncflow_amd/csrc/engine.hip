@@ -1195,16 +1195,15 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
             win_rows = w >= (double)(rows / 2u) ? (uint32_t)w : rows / 2u;   // an explicit small ring: half of it, overflow -> hand-back
         }
         // long lists have to fit the LDS of a compute unit next to everything else: halve the longest until they do
-        const uint32_t lc_n = e->fargs.lb_least_connections ? e->fargs.n_lb_edges : 0u;   // least connections: a table of prepared draws
         auto big_layout = [&](uint32_t ring) {
-            aff::FlowLayout L = aff::make_flow_layout(0u, ring, e->fargs.L.g_ring, e->fargs.L.c_ring, a.n_edges, a.n_servers, a.n_edge_marks, true, big_caps, lc_n);
+            aff::FlowLayout L = aff::make_flow_layout(0u, ring, e->fargs.L.g_ring, e->fargs.L.c_ring, a.n_edges, a.n_servers, a.n_edge_marks, true, big_caps);
             while (a.blob_bytes + L.n_words * 8u > kLdsLimit) {
                 uint32_t m = 0;
                 for (uint32_t s = 1; s < 4u; ++s)
                     if (big_caps[s] > big_caps[m]) m = s;
                 if (big_caps[m] <= 256u) break;
                 big_caps[m] = (big_caps[m] / 2u + 63u) & ~63u;
-                L = aff::make_flow_layout(0u, ring, e->fargs.L.g_ring, e->fargs.L.c_ring, a.n_edges, a.n_servers, a.n_edge_marks, true, big_caps, lc_n);
+                L = aff::make_flow_layout(0u, ring, e->fargs.L.g_ring, e->fargs.L.c_ring, a.n_edges, a.n_servers, a.n_edge_marks, true, big_caps);
             }
             return L;
         };
@@ -1215,7 +1214,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
             }
             FL = big_layout(rows);
         } else {
-            FL = aff::make_flow_layout(entries, rows, e->fargs.L.g_ring, e->fargs.L.c_ring, a.n_edges, a.n_servers, a.n_edge_marks, false, nullptr, lc_n);
+            FL = aff::make_flow_layout(entries, rows, e->fargs.L.g_ring, e->fargs.L.c_ring, a.n_edges, a.n_servers, a.n_edge_marks);
         }
         FL.win_rows = win_rows;
         FL2 = big_layout(0u);   // second chance: tick differences in HBM (no reach limit)

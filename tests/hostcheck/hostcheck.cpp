@@ -217,7 +217,7 @@ extern "C" int hc_flow_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ov
     if (robust) {
         uint32_t caps4[4];
         for (uint32_t s = 0; s < 4u; ++s) caps4[s] = (big_which == 0u || big_which == s + 1u) ? big_cap : 256u;
-        a.L = aff::make_flow_layout(0u, a.L.ring_rows, a.L.g_ring, a.L.c_ring, p->n_edges, p->n_servers, p->n_edge_marks, true, caps4, aff::lc_edges(*p));
+        a.L = aff::make_flow_layout(0u, a.L.ring_rows, a.L.g_ring, a.L.c_ring, p->n_edges, p->n_servers, p->n_edge_marks, true, caps4);
         a.L.win_rows = a.L.ring_rows / 2u;
     }
     a.tick_t = tt.t.data();
