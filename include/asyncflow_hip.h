@@ -243,7 +243,7 @@ typedef struct af_engine_options {
                                    meet such an instant are handed over to the other variant
                                    and the engine remembers it for its later runs          */
     /* Stage-parallel ("flow") kernel: one wavefront per scenario moves 64 requests per step through
-     * the stations of a feed-forward request path (generator -> client -> [round-robin LB ->] servers
+     * the stations of a feed-forward request path (generator -> client -> [LB, round robin or least connections ->] servers
      * with IO* CPU* IO* endpoints -> client).  Bit-identical to the next-event kernels; a scenario
      * it cannot express (two events of one station at one instant, a list / tick-ring overflow) is
      * simulated again by them.  af_engine_flow_reason() tells why a plan is outside its range. */
