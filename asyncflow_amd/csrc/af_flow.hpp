@@ -30,9 +30,15 @@
 //
 // Sampled series (collector.py:50-66): every counter the collector reads is a sum of intervals
 // [event that increments, event that decrements) -- a message in transit on an edge, a request in the
-// ready queue / in an I/O step / holding RAM.  Both ends are known when the interval starts, so it is
-// entered as +w / -w at the first tick after each end in a ring of per-tick differences (LDS); rows
-// older than the last station's horizon are final: prefix-summed and streamed out.
+// ready queue / in an I/O step / holding RAM.  Each end is entered as +w / -w at the first tick after
+// it in a ring of per-tick differences (LDS).  The sending station knows both ends of a message's stay
+// on an edge: it enters nothing when no tick lies between them, both when the ring reaches the
+// delivery's row (fast hops: always), and otherwise only the send -- it marks the message (sign of
+// t0) and the RECEIVING station enters the delivery when it handles it, i.e. at a time no station is
+// allowed to pass in that round (t_lim).  The server's queue / step / RAM intervals are entered by the
+// server station.  An entry therefore never lies ahead of the ring's window by more than a server
+// sojourn, however slow the edges are.  Rows older than the slowest station's horizon are final:
+// prefix-summed and streamed out.
 //
 // Device code under hipcc (wave backend: af_wave_hip in engine.hip); plain C++ under g++ for the
 // TEST-ONLY 64-fibre wave emulator of tests/hostcheck/ (never shipped).
@@ -69,7 +75,7 @@ struct FlowLayout {
     uint32_t c_ring;     // per-server ring of core-release times (>= max cpu_cores)
     uint32_t pitch;      // 4-byte words per tick row (n_series rounded up to 4)
     uint32_t list_arrays;  // f64 arrays per station list: key, t0 [, send time (FEAT_TIEBREAK)]
-    uint32_t off_spike, off_list, off_aux, off_out, off_sorted, off_hist, off_seg, off_fr, off_gr, off_cnt, off_ring;
+    uint32_t off_spike, off_list, off_aux, off_aux3, off_out, off_sorted, off_hist, off_seg, off_fr, off_gr, off_cnt, off_ring;
     uint32_t n_words;
     // FEAT_BIGLIST: every list has its own capacity (a list behind a spiked edge holds rate x spike messages when the
     // spike ends); cap is then the largest of them
@@ -98,7 +104,8 @@ inline FlowLayout make_flow_layout(uint32_t cap, uint32_t ring_rows, uint32_t g_
         L.off_list_of[s] = w;
         w += L.list_arrays * L.cap_of[s];
     }
-    L.off_aux = w; w += (L.cap_of[2] + 1u) / 2u;        // u32 per entry of the server list
+    L.off_aux = w; w += (L.cap_of[2] + 3u) / 4u;        // u16 per entry of the server list: server | in-edge << 8
+    L.off_aux3 = w; w += (L.cap_of[3] + 3u) / 4u;       // ... and of the completion list: the server's out-edge
     // scratch of select() (selected (key, t0) + u32 aux; bucket-sorted keys; 64 u32 counts, 64 u32 bases, scalars)
     // and the per-server segments of the server station (admission, B, S, F, G) are never live together
     const uint32_t scratch0 = w;
@@ -184,12 +191,16 @@ struct FlowArgs {
 //                  registers.  For plans whose spikes pile up rate x spike messages at one station when they end.
 //   FEAT_LC        least-connections load balancer (Flow::lb_pick_lc): the batch of the LB station is walked one
 //                  message at a time by the whole wave
-enum : uint32_t { FEAT_MARKS = 1u, FEAT_ONLINE = 2u, FEAT_HBM_RING = 4u, FEAT_ALL = 7u, FEAT_TIEBREAK = 8u, FEAT_BIGLIST = 16u, FEAT_LC = 32u };
+//   FEAT_FAR       edges slower than the LDS tick ring reaches: the sender enters only the send of such a message and
+//                  marks it, the receiving station enters the delivery (file header, "Sampled series").  Without it the
+//                  sender enters both ends and a delivery beyond the ring hands the scenario back.
+enum : uint32_t { FEAT_MARKS = 1u, FEAT_ONLINE = 2u, FEAT_HBM_RING = 4u, FEAT_FAR = 64u, FEAT_ALL = 7u | FEAT_FAR, FEAT_TIEBREAK = 8u,
+                  FEAT_BIGLIST = 16u, FEAT_LC = 32u };
 template <class W, uint32_t IPL = 1u, uint32_t FEAT = FEAT_ALL>
 struct Flow {
     static constexpr bool kMarks = (FEAT & FEAT_MARKS) != 0u, kOnline = (FEAT & FEAT_ONLINE) != 0u,
                           kHbmRing = (FEAT & FEAT_HBM_RING) != 0u, kTieBreak = (FEAT & FEAT_TIEBREAK) != 0u,
-                          kBig = (FEAT & FEAT_BIGLIST) != 0u, kLC = (FEAT & FEAT_LC) != 0u;
+                          kBig = (FEAT & FEAT_BIGLIST) != 0u, kLC = (FEAT & FEAT_LC) != 0u, kFar = (FEAT & FEAT_FAR) != 0u;
     const FlowArgs& A;
     AF_PLAN_AS uint64_t* blob;   // plan blob (LDS copy, patched)
     AF_PLAN_AS uint64_t* M;      // layout words behind it
@@ -212,6 +223,7 @@ struct Flow {
         if (s == 0u) h0 = v; else if (s == 1u) h1 = v; else if (s == 2u) h2 = v; else h3 = v;
     }
     uint32_t n_comp, tick_base;
+    double t_lim;                // FEAT_FAR: no station handles an event at or after this time in the current round (the tick ring's window)
     bool gen_done, moved;        // moved: a horizon advanced in this round
     // per-lane accumulators (reduced at the end)
     uint32_t ev, drops, why, info;   // info: informational result flags
@@ -234,7 +246,7 @@ struct Flow {
     AF_CORE AF_PLAN_AS double* list_ts(uint32_t s) const { return list_key(s) + 2u * cap_of(s); }   // FEAT_TIEBREAK only
     AF_CORE AF_PLAN_AS uint32_t* eb() const { return (AF_PLAN_AS uint32_t*)(M + A.L.off_eb); }       // FEAT_BIGLIST only
     AF_CORE AF_PLAN_AS double* sorted_ts() const { return sorted() + A.L.cap; }   // (cap: the largest list)
-    AF_CORE AF_PLAN_AS uint32_t* list_aux() const { return (AF_PLAN_AS uint32_t*)(M + A.L.off_aux); }
+    AF_CORE AF_PLAN_AS uint16_t* list_aux(uint32_t s = 2u) const { return (AF_PLAN_AS uint16_t*)(M + ((kFar && s == 3u) ? A.L.off_aux3 : A.L.off_aux)); }   // lists 2 and (FEAT_FAR) 3
     AF_CORE AF_PLAN_AS double* out_key() const { return (AF_PLAN_AS double*)(M + A.L.off_out); }
     AF_CORE AF_PLAN_AS double* out_t0() const { return out_key() + 64; }
     AF_CORE AF_PLAN_AS uint32_t* out_aux() const { return (AF_PLAN_AS uint32_t*)(M + A.L.off_out + 128u); }
@@ -290,11 +302,21 @@ struct Flow {
         if (flag_ties && g < N && A.tick_t[g] == x) why |= FLOW_WHY_TIE;
         return g;
     }
-    // the counter of `series` is larger by w during [a, b).  Differences go to the LDS ring, or -- plans whose
-    // intervals reach further ahead than an LDS ring can hold (ring_rows == 0) -- straight into the scenario's
-    // (zeroed) rows of the sample array in HBM, which flush_ticks() then prefix-sums in place.
+    // the counter of `series` changes by w at the first tick after an event: tick row `row` (tick_index of the event's
+    // time).  Differences go to the LDS ring, or -- ring_rows == 0 -- straight into the scenario's (zeroed) rows of the
+    // sample array in HBM, which flush_ticks() then prefix-sums in place.
+    AF_CORE void add_point(uint32_t series, uint32_t row, int32_t w) {
+        const uint32_t R = A.L.ring_rows, N = A.n_ticks < A.tick_cap ? A.n_ticks : A.tick_cap;
+        if (row >= N) return;
+        if (kHbmRing && R == 0u) {
+            W::global_add(samples + (size_t)row * A.L.pitch + series, (uint32_t)w);
+            return;
+        }
+        if (row - tick_base >= R) why |= FLOW_WHY_RING;
+        else W::lds_add((AF_PLAN_AS uint32_t*)(ring() + (row & (R - 1u)) * A.L.pitch + series), (uint32_t)w);
+    }
+    // the counter of `series` is larger by w during [a, b)
     AF_CORE void add_interval(uint32_t series, double a, double b, int32_t w) {
-        if (samples == nullptr) return;   // series not stored: ticks observe nothing, no tie can matter
         const uint32_t ia = tick_index(a, true), ib = tick_index(b, true);
         if (ia == ib) return;
         const uint32_t R = A.L.ring_rows, N = A.n_ticks < A.tick_cap ? A.n_ticks : A.tick_cap;
@@ -311,6 +333,12 @@ struct Flow {
             if (ib - tick_base >= R) why |= FLOW_WHY_RING;
             else W::lds_add((AF_PLAN_AS uint32_t*)(ring() + (ib & (R - 1u)) * A.L.pitch + series), (uint32_t)(-w));
         }
+    }
+    // ... is larger by w between the events whose tick rows are ia and ib (nothing to enter when no tick lies between)
+    AF_CORE void add_span(uint32_t series, uint32_t ia, uint32_t ib, int32_t w) {
+        if (ia == ib) return;
+        add_point(series, ia, w);
+        add_point(series, ib, -w);
     }
     // rows [tick_base, upto) are final: prefix-sum the differences and stream the rows out
     AF_CORE void flush_ticks(uint32_t upto) {
@@ -432,8 +460,12 @@ struct Flow {
         transit = af::test_quant(dist == af::DIST_EXPONENTIAL ? -(mean * af::af_log(1.0 - u1)) : cold_variate(dist, mean, sigma, u1, seed, stream, idx));
         return true;
     }
-    // `pre`: the draws were made earlier (lb_pick_lc): `pre_transit` < 0 = dropped
-    AF_CORE bool edge_send(uint32_t e, uint32_t idx, double now, double& key, bool pre = false, double pre_transit = 0.0) {
+    // `pre`: the draws were made earlier (lb_pick_lc): `pre_transit` < 0 = dropped.
+    // Sampled series: `row_now` = tick row of `now`; `counted` = the message was entered in its edge's series (a tick
+    // lies between send and delivery): the receiving station then enters the other end.
+    AF_CORE bool edge_send(uint32_t e, uint32_t idx, double now, uint32_t row_now, double& key, bool& counted, bool pre = false,
+                           double pre_transit = 0.0) {
+        counted = false;
         double transit = pre_transit;
         const bool sent = (kLC && pre) ? !(pre_transit < 0.0) : edge_draw(e, idx, transit);
         if (!sent) {
@@ -447,7 +479,18 @@ struct Flow {
         // if the next station has another event at that instant the equal keys are seen there.  A NEGATIVE delay
         // (spike residue after += / -=) raises in the reference (simpy: "Negative delay"): handed back.
         if (key < now) why |= FLOW_WHY_TIE;
-        add_interval(e, now, key, 1);
+        if (!kFar) {
+            if (samples != nullptr) add_interval(e, now, key, 1);
+        } else if (samples != nullptr) {   // (row_now: the caller needed it for the delivery it handled)
+            const uint32_t ib = tick_index(key, true);
+            if (ib != row_now) {
+                add_point(e, row_now, 1);
+                // the other end: here and now if the ring reaches it (fast hops: always), else by the receiving station
+                const uint32_t R = A.L.ring_rows, N = A.n_ticks < A.tick_cap ? A.n_ticks : A.tick_cap;
+                if ((kHbmRing && R == 0u) || ib >= N || ib - tick_base < R) add_point(e, ib, -1);
+                else counted = true;
+            }
+        }
         return true;
     }
 
@@ -460,7 +503,7 @@ struct Flow {
             list_key(s)[pos] = key;
             list_t0(s)[pos] = t0;
             if (kTieBreak) list_ts(s)[pos] = sent;
-            if (s == 2u) list_aux()[pos] = aux;
+            if (s == 2u || (kFar && s == 3u)) list_aux(s)[pos] = (uint16_t)aux;
         }
         n_list_set(s, n + popc64(m));
     }
@@ -471,7 +514,7 @@ struct Flow {
         if (kBig) return select_big(s, H_in, room, okey, ot0, oaux);
         W::sync();   // appends of the previous station are visible
         const double lo = H_get(s);
-        const double hi = H_in < A.total_time ? H_in : A.total_time;
+        const double hi_t = H_in < A.total_time ? H_in : A.total_time, hi = (kFar && t_lim < hi_t) ? t_lim : hi_t;   // (t_lim: run())
         const uint32_t n = n_list_get(s);
         okey = AF_INF;
         ot0 = 0.0;
@@ -484,7 +527,7 @@ struct Flow {
         AF_PLAN_AS double* K = list_key(s);
         AF_PLAN_AS double* T0 = list_t0(s);
         AF_PLAN_AS double* TS = list_ts(s);
-        AF_PLAN_AS uint32_t* AX = list_aux();
+        AF_PLAN_AS uint16_t* AX = list_aux(s);
         // (any positive scale gives a monotone key -> bucket map; ranks come from exact comparisons, so the hardware's
         // approximate reciprocal is as good as a division here)
         double sc = 64.0 * W::rcp(hi - lo);
@@ -507,7 +550,7 @@ struct Flow {
                     k[q] = K[i];
                     t[q] = T0[i];
                     if (kTieBreak) sent[q] = TS[i];
-                    a[q] = s == 2u ? AX[i] : 0u;
+                    a[q] = (s == 2u || (kFar && s == 3u)) ? AX[i] : 0u;
                     elig[q] = k[q] < hi;
                     if (elig[q]) {
                         double x = (k[q] - lo) * sc;
@@ -578,7 +621,7 @@ struct Flow {
                     K[pos] = k[q];
                     T0[pos] = t[q];
                     if (kTieBreak) TS[pos] = sent[q];
-                    if (s == 2u) AX[pos] = a[q];
+                    if (s == 2u || (kFar && s == 3u)) AX[pos] = (uint16_t)a[q];
                 }
                 kept += popc64(m);
             }
@@ -600,7 +643,7 @@ struct Flow {
     AF_CORE uint32_t select_big(uint32_t s, double H_in, uint32_t room, double& okey, double& ot0, uint32_t& oaux) {
         W::sync();
         const double lo = H_get(s);
-        const double hi = H_in < A.total_time ? H_in : A.total_time;
+        const double hi_t = H_in < A.total_time ? H_in : A.total_time, hi = (kFar && t_lim < hi_t) ? t_lim : hi_t;   // (t_lim: run())
         const uint32_t n = n_list_get(s);
         okey = AF_INF;
         ot0 = 0.0;
@@ -613,7 +656,7 @@ struct Flow {
         AF_PLAN_AS double* K = list_key(s);
         AF_PLAN_AS double* T0 = list_t0(s);
         AF_PLAN_AS double* TS = list_ts(s);
-        AF_PLAN_AS uint32_t* AX = list_aux();
+        AF_PLAN_AS uint16_t* AX = list_aux(s);
         AF_PLAN_AS uint32_t* EB = eb();
         constexpr uint32_t kNone = 0xFFFFFFFFu, kFar = 0xFFFFFFFEu;
         double sc = 64.0 * W::rcp(hi - lo);
@@ -690,7 +733,7 @@ struct Flow {
                 k = K[i];
                 t = T0[i];
                 if (kTieBreak) ts = TS[i];
-                if (s == 2u) a = AX[i];
+                if (s == 2u || (kFar && s == 3u)) a = AX[i];
                 r = EB[i];
             }
             const bool sel = valid && r < n_sel;
@@ -706,7 +749,7 @@ struct Flow {
                 K[pos] = k;
                 T0[pos] = t;
                 if (kTieBreak) TS[pos] = ts;
-                if (s == 2u) AX[pos] = a;
+                if (s == 2u || (kFar && s == 3u)) AX[pos] = (uint16_t)a;
             }
             kept += popc64(m);
         }
@@ -824,12 +867,12 @@ struct Flow {
         // each server at MY message's time -- every lane walks the list (the same entry in all lanes: LDS broadcasts)
         // and keeps eight 16-bit counts in two words (<= kMaxServers servers, <= 16 384 entries).
         const AF_PLAN_AS double* K2 = list_key(2u);
-        const AF_PLAN_AS uint32_t* AX = list_aux();
+        const AF_PLAN_AS uint16_t* AX = list_aux();
         const uint32_t n2 = n_list_get(2u);
         uint64_t b_lo = 0ull, b_hi = 0ull;
         for (uint32_t i2 = 0u; i2 < n2; ++i2) {
             const double k = K2[i2];
-            const uint32_t ax = W::bcast32(AX[i2], 0u);
+            const uint32_t ax = W::bcast32(AX[i2], 0u) & 0xFFu;
             const uint64_t inc = k > my_key ? 1ull << (16u * (ax & 3u)) : 0ull;
             if (ax < 4u) b_lo += inc;
             else b_hi += inc;
@@ -1140,6 +1183,10 @@ struct Flow {
         for (;;) {
             uint32_t work = 0u;
             moved = false;
+            // With an LDS tick ring the generator does not run further ahead of the completed ticks than the ring's window;
+            // with FEAT_FAR no station handles an event beyond it (select()): the receiving station enters the delivery of
+            // a marked message at the time of that event.
+            if (kFar) t_lim = (samples != nullptr && (!kHbmRing || A.L.ring_rows != 0u)) ? (double)(tick_base + A.L.win_rows) * A.sample_period : AF_INF;
             const double h_done_before = h3;
             double H_in = AF_INF, h_gen = AF_INF;
 #pragma nounroll
@@ -1154,9 +1201,9 @@ struct Flow {
                     room = room < 64u ? room : 64u;
                     const uint32_t i = cursor + lane;
                     t0 = (lane < room && i < A.n_draw) ? arr[i] : AF_INF;
-                    // with an LDS tick ring a round must not run further ahead of the completed ticks than the ring holds
-                    const double t_cap = (samples != nullptr && (!kHbmRing || A.L.ring_rows != 0u))
-                                             ? (double)(tick_base + A.L.win_rows) * A.sample_period : AF_INF;
+                    const double t_cap = kFar ? t_lim
+                                         : (samples != nullptr && (!kHbmRing || A.L.ring_rows != 0u)) ? (double)(tick_base + A.L.win_rows) * A.sample_period
+                                                                                                       : AF_INF;
                     const uint64_t vm = W::ballot(t0 < T && t0 < t_cap);   // arrival times increase: a prefix of the lanes
                     n_sel = popc64(vm);
                     key = t0;
@@ -1166,6 +1213,14 @@ struct Flow {
                 const bool have = lane < n_sel;
                 if (have) ev += 1u;                       // one timed event per message: arrival / delivery
                 work += n_sel;
+                // ---- sampled series: the delivery ends the message's stay on the edge it came by (edge.py:115), if the
+                // sender entered it (sign of t0); `row` = tick row of the station's event, which the send below starts at
+                const bool series_on = samples != nullptr;
+                const bool cnt_in = kFar && series_on && have && st > 0u && __builtin_signbit(t0);
+                if (kFar && st > 0u) t0 = __builtin_fabs(t0);
+                uint32_t row = 0u;
+                if (kFar && series_on && have && (st <= 2u || cnt_in)) row = tick_index(key, true);
+                if (kFar && cnt_in) add_point(st == 1u ? A.gen_out_edge : st == 2u ? A.client_out_edge : st == 3u ? aux >> 8 : aux, row, -1);
                 // ---- what the station does with it: the out-edge, the message's index on it, the send time
                 bool sending = have, pre = false;
                 uint32_t e = 0u, idx = 0u, tgt = 0u;
@@ -1196,7 +1251,7 @@ struct Flow {
                     }
                 } else if (st == 3u) {   // servers
                     if (n_sel > 0u) {
-                        const uint32_t sv = aux;
+                        const uint32_t sv = aux & 0xFFu;
                         uint32_t pos = 0u, off = 0u;   // per-server segments of the time-ordered arrivals
                         for (uint32_t k = 0u; k < A.n_servers; ++k) {
                             const uint64_t m = W::ballot(have && sv == k);
@@ -1215,11 +1270,29 @@ struct Flow {
                             const uint32_t ep = (uint32_t)(meta >> 32) & 0xFFFFu;
                             const double ram = u2d(blob[A.off_ep + af::PREC * ep]);
                             const uint32_t s0 = A.n_edges + 3u * sv;
-                            if (r.s > r.b) add_interval(s0, r.b, r.s, 1);               // ready queue: waited for a core (server.py:215-225)
-                            if (r.b > r.adm) add_interval(s0 + 1u, r.adm, r.b, 1);      // leading I/O steps
-                            if (r.g > r.f) add_interval(s0 + 1u, r.f, r.g, 1);          // trailing I/O steps
-                            if (ram > 0.0) add_interval(s0 + 2u, r.adm, r.g, (int32_t)ram);   // RAM held from admission to the end (server.py:146-149, 270-273)
                             ts = r.g;
+                            // ready queue: waited for a core (server.py:215-225); leading / trailing I/O steps; RAM held from
+                            // admission to the end (server.py:146-149, 270-273)
+                            if (!kFar && series_on) {
+                                if (r.s > r.b) add_interval(s0, r.b, r.s, 1);
+                                if (r.b > r.adm) add_interval(s0 + 1u, r.adm, r.b, 1);
+                                if (r.g > r.f) add_interval(s0 + 1u, r.f, r.g, 1);
+                                if (ram > 0.0) add_interval(s0 + 2u, r.adm, r.g, (int32_t)ram);
+                            }
+                            if (kFar && series_on) {   // (one tick row per distinct time: the send below starts at G's)
+                                const bool q_ready = r.s > r.b, q_pre = r.b > r.adm, q_post = r.g > r.f, q_ram = ram > 0.0;
+                                uint32_t t_adm = 0u, t_b = 0u, t_s = 0u, t_f = 0u, t_g = 0u;
+                                if (q_pre || q_ram) t_adm = tick_index(r.adm, true);
+                                if (q_ready || q_pre) t_b = tick_index(r.b, true);
+                                if (q_ready) t_s = tick_index(r.s, true);
+                                if (q_post) t_f = tick_index(r.f, true);
+                                if (q_post || q_ram || ts < T) t_g = tick_index(r.g, true);
+                                if (q_ready) add_span(s0, t_b, t_s, 1);
+                                if (q_pre) add_span(s0 + 1u, t_adm, t_b, 1);
+                                if (q_post) add_span(s0 + 1u, t_f, t_g, 1);
+                                if (q_ram) add_span(s0 + 2u, t_adm, t_g, (int32_t)ram);
+                                row = t_g;
+                            }
                         }
                         sending = have && ts < T;      // transport() on the server's out-edge at G (server.py:276), if the horizon allows
                         idx = claim_send_index(sending, e, true);
@@ -1231,8 +1304,10 @@ struct Flow {
                 }
                 if (st < 4u) {
                     double k2 = 0.0;
-                    const bool ok = sending && edge_send(e, idx, ts, k2, kLC && pre, pre_tr);
-                    append(nxt, ok, k2, t0, tgt, ts);
+                    bool counted = false;
+                    const bool ok = sending && edge_send(e, idx, ts, row, k2, counted, kLC && pre, pre_tr);
+                    // (server list: the server and the edge the message comes by; completion list: the server's out-edge)
+                    append(nxt, ok, k2, (kFar && counted) ? -t0 : t0, !kFar ? tgt : st == 3u ? e : tgt | (e << 8), ts);
                     if (st > 0u) H_in = H_get(st - 1u);
                     H_in = send_floor(st, H_in);   // what the next station may touch: everything delivered before this
                 }

@@ -1062,6 +1062,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     bool lds_state = false;
     aff::FlowLayout FL{}, FL2{};     // first launch; second chance (long lists with send times)
     bool flow_big = false;           // the first launch already runs the long-list instantiation
+    bool flow_far = false;           // the tick ring does not reach the slowest message: a FEAT_FAR instantiation
     uint32_t big_caps[4] = {256u, 256u, 256u, 256u};
 
     // ---- stage-parallel kernel: list capacity and tick ring from what will be in flight ----------------
@@ -1085,27 +1086,6 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
                 case AF_DIST_NORMAL: return (m > 0.0 ? m : 0.0) + 0.4 * sg;
                 case AF_DIST_UNIFORM: return 0.5;
                 default: return m;
-            }
-        };
-        auto lat_sd = [&](int32_t ed) {
-            const double m = emean[ed], sg = e->edge_sigma[ed];
-            switch (e->edge_dist[ed]) {
-                case AF_DIST_LOG_NORMAL: {
-                    const double v = sg * sg < 50.0 ? sg * sg : 50.0;
-                    return lat_mean(ed) * std::sqrt(std::exp(v) - 1.0);
-                }
-                case AF_DIST_NORMAL: return sg;
-                case AF_DIST_UNIFORM: return 0.29;
-                default: return m;
-            }
-        };
-        auto lat_q = [&](int32_t ed) {   // a transit time one message in ~1e11 exceeds
-            const double m = emean[ed], sg = e->edge_sigma[ed];
-            switch (e->edge_dist[ed]) {
-                case AF_DIST_LOG_NORMAL: return std::exp(m + 6.7 * sg < 50.0 ? m + 6.7 * sg : 50.0);
-                case AF_DIST_NORMAL: return (m > 0.0 ? m : 0.0) + 6.7 * sg;
-                case AF_DIST_UNIFORM: return 1.0;
-                default: return 25.3 * m;
             }
         };
         // the hops of the request path: generator edge, client edge, the slowest LB edge, the slowest server out-edge
@@ -1158,16 +1138,40 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
             entries = pend <= 32.0 ? 64u : pend <= 96.0 ? 128u : 256u;
             flow_big = pend > 200.0;   // more than register-resident lists hold: the whole launch on the long-list instantiation
         }
-        // in-flight time of the slowest message of the sweep (~1e-11 per request): the largest single hop at that
-        // quantile, the other hops at mean + 3 sd, spikes, the server
-        double tail = in_server;
+        // What the tick ring has to reach past its window.  With FEAT_FAR: the time a request spends INSIDE a server (its
+        // queue / step / RAM intervals are entered when it arrives); a delivery the ring does not reach is entered by the
+        // receiving station (af_flow.hpp, "Sampled series").  Without: the in-flight time of the slowest message of the
+        // sweep (~1e-11 per request) -- the largest single hop at that quantile, the other hops at mean + 3 sd, spikes.
+        auto lat_sd = [&](int32_t ed) {
+            const double m = emean[ed], sg = e->edge_sigma[ed];
+            switch (e->edge_dist[ed]) {
+                case AF_DIST_LOG_NORMAL: {
+                    const double v = sg * sg < 50.0 ? sg * sg : 50.0;
+                    return lat_mean(ed) * std::sqrt(std::exp(v) - 1.0);
+                }
+                case AF_DIST_NORMAL: return sg;
+                case AF_DIST_UNIFORM: return 0.29;
+                default: return m;
+            }
+        };
+        auto lat_q = [&](int32_t ed) {   // a transit time one message in ~1e11 exceeds
+            const double m = emean[ed], sg = e->edge_sigma[ed];
+            switch (e->edge_dist[ed]) {
+                case AF_DIST_LOG_NORMAL: return std::exp(m + 6.7 * sg < 50.0 ? m + 6.7 * sg : 50.0);
+                case AF_DIST_NORMAL: return (m > 0.0 ? m : 0.0) + 6.7 * sg;
+                case AF_DIST_UNIFORM: return 1.0;
+                default: return 25.3 * m;
+            }
+        };
+        double tail_full = in_server;
         {
             size_t worst = 0;
             for (size_t h = 1; h < hops.size(); ++h)
                 if (lat_q(hops[h]) > lat_q(hops[worst])) worst = h;
             for (size_t h = 0; h < hops.size(); ++h)
-                tail += e->edge_spike[hops[h]] + (h == worst ? lat_q(hops[h]) : lat_mean(hops[h]) + 3.0 * lat_sd(hops[h]));
+                tail_full += e->edge_spike[hops[h]] + (h == worst ? lat_q(hops[h]) : lat_mean(hops[h]) + 3.0 * lat_sd(hops[h]));
         }
+        const double tail = in_server;
         uint32_t rows = e->flow_ring_rows, win_rows = 0u;
         const uint32_t pitch = a.series_pitch;
         const double tail_rows = std::ceil(tail / a.sample_period) + 2.0;
@@ -1177,21 +1181,30 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
             rows = 0u;
         } else if (rows == 0u) {
             // the ring covers the generator's window (enough ticks for a full batch of arrivals at the heaviest load,
-            // at least 8) + the tail; 8 KB of LDS keep 16 waves per CU, 24 KB are the limit before HBM takes over
+            // at least 8) + the server time; 8 KB of LDS keep 16 waves per CU, 24 KB are the limit before HBM takes over
             const double want_win = std::fmin(std::fmax(std::ceil(96.0 / rate / a.sample_period), 8.0), 4096.0);
             const uint32_t cap_pref = aff::pow2_ge(8u * 1024u / (pitch * 4u) + 1u) / 2u, cap_max = aff::pow2_ge(24u * 1024u / (pitch * 4u) + 1u) / 2u;
             if (tail_rows + 8.0 > (double)cap_max) {
-                rows = 0u;   // the slowest message outlives any ring that fits: differences in HBM
+                rows = 0u;   // a request stays in its server longer than any ring that fits reaches: differences in HBM
             } else {
                 rows = aff::pow2_ge((uint32_t)(tail_rows + want_win));
                 if (rows > cap_pref) rows = cap_pref >= aff::pow2_ge((uint32_t)(tail_rows + 8.0)) ? cap_pref : aff::pow2_ge((uint32_t)(tail_rows + 8.0));
                 if (rows < 16u) rows = 16u;
+                // a window of two or three batches binds less often: take it where it costs no occupancy (16 waves per CU
+                // leave 10 KB each)
+                if (!flow_big) {
+                    const uint32_t no_ring = a.blob_bytes + aff::make_flow_layout(entries, 0u, e->fargs.L.g_ring, e->fargs.L.c_ring, a.n_edges,
+                                                                                  a.n_servers, a.n_edge_marks).n_words * 8u;
+                    while (rows < aff::pow2_ge((uint32_t)(tail_rows + 2.0 * want_win)) && no_ring + 2u * rows * pitch * 4u <= 10u * 1024u) rows *= 2u;
+                }
             }
         } else {
             rows = aff::pow2_ge(rows);
         }
         if (rows != 0u) {
-            const double w = (double)rows - tail_rows;
+            const double full_rows = std::ceil(tail_full / a.sample_period) + 2.0;
+            flow_far = (double)rows - full_rows < std::fmin(8.0, (double)(rows / 2u));
+            const double w = (double)rows - (flow_far ? tail_rows : full_rows);
             win_rows = w >= (double)(rows / 2u) ? (uint32_t)w : rows / 2u;   // an explicit small ring: half of it, overflow -> hand-back
         }
         // long lists have to fit the LDS of a compute unit next to everything else: halve the longest until they do
@@ -1429,9 +1442,11 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
                              : lc             ? (FL.cap == 64u    ? reinterpret_cast<const void*>(af_flow_kernel<1, aff::FEAT_ALL | kLC>)
                                                  : FL.cap == 128u ? reinterpret_cast<const void*>(af_flow_kernel<2, aff::FEAT_ALL | kLC>)
                                                                   : reinterpret_cast<const void*>(af_flow_kernel<4, aff::FEAT_ALL | kLC>))
-                             : FL.cap == 64u  ? (lean ? reinterpret_cast<const void*>(af_flow_kernel<1, 0u>)
+                             : FL.cap == 64u  ? (lean ? (flow_far ? reinterpret_cast<const void*>(af_flow_kernel<1, aff::FEAT_FAR>)
+                                                                  : reinterpret_cast<const void*>(af_flow_kernel<1, 0u>))
                                                       : reinterpret_cast<const void*>(af_flow_kernel<1, aff::FEAT_ALL>))
-                             : FL.cap == 128u ? (lean ? reinterpret_cast<const void*>(af_flow_kernel<2, 0u>)
+                             : FL.cap == 128u ? (lean ? (flow_far ? reinterpret_cast<const void*>(af_flow_kernel<2, aff::FEAT_FAR>)
+                                                                  : reinterpret_cast<const void*>(af_flow_kernel<2, 0u>))
                                                       : reinterpret_cast<const void*>(af_flow_kernel<2, aff::FEAT_ALL>))
                                               : reinterpret_cast<const void*>(af_flow_kernel<4, aff::FEAT_ALL>);
             const uint32_t flow_lds_launch = spread_lds_bytes(flow_lds);
@@ -1439,7 +1454,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
             void* kargs[] = {&f};
             if (std::getenv("AF_DEBUG"))
                 std::fprintf(stderr, "[af] flow launch: %u scenarios, %u list entries%s, %u ring rows, %u B LDS per wave%s\n", nc, FL.cap,
-                             flow_big ? " (long-list instantiation)" : "", FL.ring_rows, flow_lds, flow_lean ? ", lean instantiation" : "");
+                             flow_big ? " (long-list instantiation)" : "", FL.ring_rows, flow_lds, flow_lean ? (flow_far ? ", lean instantiation with far edges" : ", lean instantiation") : "");
             HIP_TRY(hipLaunchKernel(fn, dim3(nc), dim3(kWave), kargs, flow_lds_launch, e->stream));
         }
         HIP_TRY(hipEventRecord(e->ev4, e->stream));

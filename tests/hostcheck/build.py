@@ -101,7 +101,7 @@ FLOW_FALLBACK = 1 << 8
 FLOW_WHY = {1 << 9: "tie", 1 << 10: "list", 1 << 11: "ring", 1 << 12: "ram"}
 
 
-def flow_simulate(plan: DevicePlan, seed: int, *, ipl: int = 1, ring_rows: int = 64, robust: bool = False,
+def flow_simulate(plan: DevicePlan, seed: int, *, ipl: int = 1, ring_rows: int = 64, robust: bool = False, far: bool = True,
                   long_list_entries: int = 256, long_list: int | None = None,
                   overrides: list[tuple[str, int, float]] | None = None, clock_capacity: int | None = None,
                   draw_capacity: int | None = None):
@@ -110,7 +110,8 @@ def flow_simulate(plan: DevicePlan, seed: int, *, ipl: int = 1, ring_rows: int =
     Returns (counts, clock, samples) like :func:`simulate`, or ``None`` when the plan is not eligible
     (``flow_reason()`` says why).  ``robust``: the second-chance instantiation (lists that carry the send times:
     equal delivery times at a station are ordered like SimPy orders them; ``long_list_entries`` for station list
-    ``long_list`` -- or all four --, 256 for the others).
+    ``long_list`` -- or all four --, 256 for the others).  ``far=False``: the lean instantiations without FEAT_FAR (the sender
+    enters both ends of every message; a delivery beyond the tick ring hands the scenario back).
     ``counts[CNT_FLAGS] & FLOW_FALLBACK``: the kernel handed the scenario
     back to the sequential kernels (outputs are then incomplete)."""
     L = lib()
@@ -128,7 +129,7 @@ def flow_simulate(plan: DevicePlan, seed: int, *, ipl: int = 1, ring_rows: int =
     rc = L.hc_flow_simulate(
         C.byref(cplan), C.c_uint64(seed), len(ov), params.ctypes.data_as(u32p), idxs.ctypes.data_as(u32p),
         vals.ctypes.data_as(f64p),
-        ipl | ((0x100 | (long_list_entries << 16) | ((0 if long_list is None else long_list + 1) << 12)) if robust else 0), ring_rows, ccap, clock.ctypes.data_as(f64p), ticks,
+        ipl | (0 if far else 0x200) | ((0x100 | (long_list_entries << 16) | ((0 if long_list is None else long_list + 1) << 12)) if robust else 0), ring_rows, ccap, clock.ctypes.data_as(f64p), ticks,
         samples.ctypes.data_as(u32p), counts.ctypes.data_as(u32p),
         int(draw_capacity if draw_capacity is not None else plan.clock_capacity()),
     )

@@ -157,6 +157,7 @@ extern "C" int hc_flow_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ov
     // the second-chance instantiation (FEAT_TIEBREAK | FEAT_BIGLIST): send times + lists of their own lengths;
     // bits 16..31 = entries of the long list(s) (0: 256), bits 12..14 = which list is long (0: all four; else index + 1, the others hold 256)
     const bool robust = (ipl & 0x100u) != 0u;
+    const bool near_only = (ipl & 0x200u) != 0u;   // the lean instantiations without FEAT_FAR (the sender enters both ends of every message)
     const uint32_t big_cap = (ipl >> 16) ? (ipl >> 16) : 256u, big_which = (ipl >> 12) & 7u;
     ipl &= 0xFFu;
     if (robust) ipl = 4;
@@ -257,9 +258,11 @@ extern "C" int hc_flow_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ov
         else if (lc && ipl == 1) { aff::Flow<emu::WaveEmu, 1, kAll | kLC> f(a); f.run(lds.data(), 0u); }
         else if (lc && ipl == 2) { aff::Flow<emu::WaveEmu, 2, kAll | kLC> f(a); f.run(lds.data(), 0u); }
         else if (lc) { aff::Flow<emu::WaveEmu, 4, kAll | kLC> f(a); f.run(lds.data(), 0u); }
-        else if (ipl == 1 && lean) { aff::Flow<emu::WaveEmu, 1, 0u> f(a); f.run(lds.data(), 0u); }
+        else if (ipl == 1 && lean && near_only) { aff::Flow<emu::WaveEmu, 1, 0u> f(a); f.run(lds.data(), 0u); }
+        else if (ipl == 1 && lean) { aff::Flow<emu::WaveEmu, 1, aff::FEAT_FAR> f(a); f.run(lds.data(), 0u); }
         else if (ipl == 1) { aff::Flow<emu::WaveEmu, 1> f(a); f.run(lds.data(), 0u); }
-        else if (ipl == 2 && lean) { aff::Flow<emu::WaveEmu, 2, 0u> f(a); f.run(lds.data(), 0u); }
+        else if (ipl == 2 && lean && near_only) { aff::Flow<emu::WaveEmu, 2, 0u> f(a); f.run(lds.data(), 0u); }
+        else if (ipl == 2 && lean) { aff::Flow<emu::WaveEmu, 2, aff::FEAT_FAR> f(a); f.run(lds.data(), 0u); }
         else if (ipl == 2) { aff::Flow<emu::WaveEmu, 2> f(a); f.run(lds.data(), 0u); }
         else { aff::Flow<emu::WaveEmu, 4> f(a); f.run(lds.data(), 0u); }
     };

@@ -59,12 +59,15 @@ def test_flow_kernel_reproduces_the_reference_fixtures(name):
     assert np.array_equal(clock, fx["clock"]) and np.array_equal(samples, fx["samples"])   # the reference's own output
 
 
-@pytest.mark.parametrize("ring_rows", [64, 0])      # tick differences in the LDS ring / in the sample rows (HBM)
-def test_baseline_workloads_bit_exact(ring_rows):
-    assert _run(lb_two_servers(horizon=60), 0x5EED0000, ring_rows=ring_rows)[0] == "exact"
-    assert _run(single_server(horizon=60), 0, ring_rows=ring_rows)[0] == "exact"
-    assert _run(lb_with_events(users=300, horizon=60, scale=0.1), 42, ring_rows=ring_rows)[0] == "exact"
-    assert _run(fanout8(horizon=40), 11, ipl=2, ring_rows=256 if ring_rows else 0)[0] == "exact"
+@pytest.mark.parametrize(("ring_rows", "far"), [(64, True), (64, False), (0, True)])
+def test_baseline_workloads_bit_exact(ring_rows, far):
+    """tick differences in the LDS ring (lean instantiations with / without FEAT_FAR) / in the sample rows (HBM)"""
+    assert _run(lb_two_servers(horizon=60), 0x5EED0000, ring_rows=ring_rows, far=far)[0] == "exact"
+    assert _run(single_server(horizon=60), 0, ring_rows=ring_rows, far=far)[0] == "exact"
+    assert _run(lb_with_events(users=300, horizon=60, scale=0.1), 42, ring_rows=ring_rows, far=far)[0] == "exact"
+    assert _run(fanout8(horizon=40), 11, ipl=2, ring_rows=256 if ring_rows else 0, far=far)[0] == "exact"
+    if ring_rows and far:      # (the ring a sweep of this plan gets on the device: 32 rows = 1.6 s for ~4-s requests)
+        assert _run(fanout8(horizon=40), 12, ipl=2, ring_rows=32)[0] == "exact"
 
 
 def test_grid_corners_of_configs_3_and_4():
@@ -100,7 +103,13 @@ def test_per_scenario_overrides_reach_the_kernel():
 def test_small_lists_hand_the_scenario_back_instead_of_dropping_messages():
     status, why = _run(fanout8(horizon=30), 11, ipl=1, ring_rows=256)      # ~40 messages in flight per edge
     assert status == "fallback" and "list" in why
-    status, why = _run(fanout8(horizon=30), 11, ipl=2, ring_rows=8)        # 1-s latencies, 0.4 s of ring
+    # FEAT_FAR: a delivery the ring does not reach is entered by the receiving station when it handles it, so 1-s hops
+    # do not need a ring that reaches 1 s ahead (0.4 s of ring here); without it the sender enters both ends: handed back
+    assert _run(fanout8(horizon=30), 11, ipl=2, ring_rows=8)[0] == "exact"
+    status, why = _run(fanout8(horizon=30), 11, ipl=2, ring_rows=8, far=False)
+    assert status == "fallback" and "ring" in why
+    # ... only the time a request spends INSIDE a server has to fit: a saturated server (1 400 rps on 1 000 rps of core)
+    status, why = _run(single_server(users=700, rpm=120, horizon=6), 3, ipl=4, ring_rows=8)
     assert status == "fallback" and "ring" in why
 
 

@@ -85,12 +85,13 @@ def test_tick_ring_placement_does_not_change_results(ring_rows):
     _same_batches(res, _runner(payload, seeds=seeds, flow=False).run())
 
 
-def test_fanout_uses_larger_lists_and_hbm_differences():
+def test_fanout_uses_larger_lists_and_far_edges():
     payload = fanout8(horizon=60)
     seeds = BASELINE_SEED_BASE[5] + np.arange(40, dtype=np.uint64)
     res = _runner(payload, seeds=seeds).run()
     st = res.engine_stats
-    assert st.flow_scenarios == 40 and st.flow_list_entries >= 128 and st.flow_ring_rows == 0   # ~1-s hops: differences in HBM
+    # ~1-s hops on an LDS ring of 1.6 s: the deliveries are entered by the receiving stations (FEAT_FAR), nothing is handed back
+    assert st.flow_scenarios == 40 and st.flow_list_entries >= 128 and 16 <= st.flow_ring_rows <= 64 and st.flow_fallback == 0
     plan = lower(payload)
     for i in (0, 17, 39):
         _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])), f"scenario {i}")
@@ -101,10 +102,23 @@ def test_fanout_uses_larger_lists_and_hbm_differences():
     big = _runner(payload, seeds=seeds, flow_list_entries=256).run()      # the 4-entries-per-lane instantiation
     assert big.engine_stats.flow_list_entries == 256 and big.engine_stats.flow_fallback == 0
     _same_batches(res, big)
-    ring = _runner(payload, seeds=seeds, flow_ring_rows=16).run()         # 0.8 s of LDS ring against ~1-s hops
-    st = ring.engine_stats
-    assert st.flow_fallback_ring > 0 and st.flow_retried == st.flow_fallback and st.flow_to_next_event == 0   # second chance: differences in HBM
+    ring = _runner(payload, seeds=seeds, flow_ring_rows=16).run()         # 0.8 s of LDS ring against ~1-s hops: still nothing handed back
+    assert ring.engine_stats.flow_ring_rows == 16 and ring.engine_stats.flow_fallback == 0
     _same_batches(res, ring)
+    hbm = _runner(payload, seeds=seeds, flow_ring_rows=_abi.FLOW_RING_IN_HBM).run()
+    assert hbm.engine_stats.flow_ring_rows == 0 and hbm.engine_stats.flow_fallback == 0
+    _same_batches(res, hbm)
+
+
+def test_a_ring_shorter_than_the_stay_in_a_server_hands_back():
+    """What a ring still has to reach: the time a request spends inside its server (100-ms I/O step, 4 rows of 50 ms)."""
+    payload = single_server(horizon=30)
+    seeds = np.arange(48, dtype=np.uint64) + 5
+    res = _runner(payload, seeds=seeds, flow_ring_rows=4).run()
+    st = res.engine_stats
+    assert st.flow_fallback_ring > 0 and st.flow_retried == st.flow_fallback and st.flow_to_next_event == 0   # second chance: differences in HBM
+    _same_batches(res, _runner(payload, seeds=seeds).run())
+    _assert_scenario(res[3], ol.simulate(lower(payload), int(seeds[3])), "scenario 3")
 
 
 def test_handed_back_scenarios_are_invisible_in_the_results():
