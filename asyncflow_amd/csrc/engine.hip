@@ -1435,6 +1435,8 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
             const bool lean = a.n_edge_marks == 0u && a.n_srv_marks == 0u && !f.online_hist && !f.online_rps &&
                               (FL.ring_rows != 0u || f.samples == nullptr);
             flow_lean = lean && !flow_big && f.lb_least_connections == 0u;
+            // injected spikes / outages, but neither the kernel-side summary nor tick differences in HBM (BASELINE config 4)
+            const bool marks_only = !lean && !f.online_hist && !f.online_rps && (FL.ring_rows != 0u || f.samples == nullptr);
             constexpr uint32_t kRobust = aff::FEAT_ALL | aff::FEAT_TIEBREAK | aff::FEAT_BIGLIST, kLC = aff::FEAT_LC;
             const bool lc = f.lb_least_connections != 0u;
             const void* fn = flow_big         ? (lc ? reinterpret_cast<const void*>(af_flow_kernel<1, kRobust | kLC>)
@@ -1444,9 +1446,11 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
                                                                   : reinterpret_cast<const void*>(af_flow_kernel<4, aff::FEAT_ALL | kLC>))
                              : FL.cap == 64u  ? (lean ? (flow_far ? reinterpret_cast<const void*>(af_flow_kernel<1, aff::FEAT_FAR>)
                                                                   : reinterpret_cast<const void*>(af_flow_kernel<1, 0u>))
+                                                 : marks_only ? reinterpret_cast<const void*>(af_flow_kernel<1, aff::FEAT_MARKS | aff::FEAT_FAR>)
                                                       : reinterpret_cast<const void*>(af_flow_kernel<1, aff::FEAT_ALL>))
                              : FL.cap == 128u ? (lean ? (flow_far ? reinterpret_cast<const void*>(af_flow_kernel<2, aff::FEAT_FAR>)
                                                                   : reinterpret_cast<const void*>(af_flow_kernel<2, 0u>))
+                                                 : marks_only ? reinterpret_cast<const void*>(af_flow_kernel<2, aff::FEAT_MARKS | aff::FEAT_FAR>)
                                                       : reinterpret_cast<const void*>(af_flow_kernel<2, aff::FEAT_ALL>))
                                               : reinterpret_cast<const void*>(af_flow_kernel<4, aff::FEAT_ALL>);
             const uint32_t flow_lds_launch = spread_lds_bytes(flow_lds);

@@ -251,6 +251,7 @@ extern "C" int hc_flow_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ov
     // the instantiation the engine would launch: the lean one when the launch needs none of the optional features
     const bool lean = p->n_edge_marks == 0 && p->n_srv_marks == 0 && !g_online_hist && !g_online_rps && (a.L.ring_rows != 0 || !samples);
     const bool lc = a.lb_least_connections != 0u;
+    const bool marks_only = !lean && !g_online_hist && !g_online_rps && (a.L.ring_rows != 0 || !samples);   // (engine.hip: config-4-like launches)
     constexpr uint32_t kAll = aff::FEAT_ALL, kRobust = aff::FEAT_ALL | aff::FEAT_TIEBREAK | aff::FEAT_BIGLIST, kLC = aff::FEAT_LC;
     auto body = [&]() {
         if (robust && lc) { aff::Flow<emu::WaveEmu, 1, kRobust | kLC> f(a); f.run(lds.data(), 0u); }
@@ -260,9 +261,11 @@ extern "C" int hc_flow_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ov
         else if (lc) { aff::Flow<emu::WaveEmu, 4, kAll | kLC> f(a); f.run(lds.data(), 0u); }
         else if (ipl == 1 && lean && near_only) { aff::Flow<emu::WaveEmu, 1, 0u> f(a); f.run(lds.data(), 0u); }
         else if (ipl == 1 && lean) { aff::Flow<emu::WaveEmu, 1, aff::FEAT_FAR> f(a); f.run(lds.data(), 0u); }
+        else if (ipl == 1 && marks_only) { aff::Flow<emu::WaveEmu, 1, aff::FEAT_MARKS | aff::FEAT_FAR> f(a); f.run(lds.data(), 0u); }
         else if (ipl == 1) { aff::Flow<emu::WaveEmu, 1> f(a); f.run(lds.data(), 0u); }
         else if (ipl == 2 && lean && near_only) { aff::Flow<emu::WaveEmu, 2, 0u> f(a); f.run(lds.data(), 0u); }
         else if (ipl == 2 && lean) { aff::Flow<emu::WaveEmu, 2, aff::FEAT_FAR> f(a); f.run(lds.data(), 0u); }
+        else if (ipl == 2 && marks_only) { aff::Flow<emu::WaveEmu, 2, aff::FEAT_MARKS | aff::FEAT_FAR> f(a); f.run(lds.data(), 0u); }
         else if (ipl == 2) { aff::Flow<emu::WaveEmu, 2> f(a); f.run(lds.data(), 0u); }
         else { aff::Flow<emu::WaveEmu, 4> f(a); f.run(lds.data(), 0u); }
     };
