@@ -238,24 +238,38 @@ struct Flow {
     AF_CORE Flow(const FlowArgs& a) : A(a) {}
 
     // ---- LDS views ----------------------------------------------------------------------------
-    AF_CORE uint32_t cap_of(uint32_t s) const { return kBig ? A.L.cap_of[s] : A.L.cap; }
+    // Register-resident lists have 64 * IPL entries: everything up to the per-server rings then sits at a compile-time
+    // distance from the lists (make_flow_layout's own arithmetic; run() checks it in the host builds), and every offset that
+    // is not loaded from the arguments is one wave-uniform register less in a kernel that spills them.
+    // (Measured, not reasoned: the register allocation of this kernel is chaotic.  FEAT_FAR / MARKS | FAR instantiations
+    // -2 % -- configs 3, 4, 5 --, the plain lean one +0.6 % with 224 instead of 153 static v_readlanes: it keeps loading.)
+    static constexpr bool kCt = !kBig && !kTieBreak && FEAT != 0u;
+    static constexpr uint32_t kCap = 64u * IPL, kAuxW = (kCap + 3u) / 4u;
+    AF_CORE uint32_t o_list() const { return (kCt && !kMarks) ? 0u : A.L.off_list; }   // (no marks: no spike table in front)
+    AF_CORE uint32_t o_aux() const { return kCt ? o_list() + 8u * kCap : A.L.off_aux; }
+    AF_CORE uint32_t o_aux3() const { return kCt ? o_aux() + kAuxW : A.L.off_aux3; }
+    AF_CORE uint32_t o_out() const { return kCt ? o_aux3() + kAuxW : A.L.off_out; }
+    AF_CORE uint32_t o_sorted() const { return kCt ? o_out() + 160u : A.L.off_sorted; }
+    AF_CORE uint32_t o_hst() const { return kCt ? o_sorted() + kCap : A.L.off_hist; }
+    AF_CORE uint32_t o_fr() const { return kCt ? o_out() + (kCap + 232u > 320u ? kCap + 232u : 320u) : A.L.off_fr; }
+    AF_CORE uint32_t cap_of(uint32_t s) const { return kBig ? A.L.cap_of[s] : kCt ? kCap : A.L.cap; }
     AF_CORE AF_PLAN_AS double* list_key(uint32_t s) const {
-        return (AF_PLAN_AS double*)(M + (kBig ? A.L.off_list_of[s] : A.L.off_list + (kTieBreak ? 3u : 2u) * A.L.cap * s));
+        return (AF_PLAN_AS double*)(M + (kBig ? A.L.off_list_of[s] : o_list() + (kTieBreak ? 3u : 2u) * cap_of(0u) * s));
     }
     AF_CORE AF_PLAN_AS double* list_t0(uint32_t s) const { return list_key(s) + cap_of(s); }
     AF_CORE AF_PLAN_AS double* list_ts(uint32_t s) const { return list_key(s) + 2u * cap_of(s); }   // FEAT_TIEBREAK only
     AF_CORE AF_PLAN_AS uint32_t* eb() const { return (AF_PLAN_AS uint32_t*)(M + A.L.off_eb); }       // FEAT_BIGLIST only
     AF_CORE AF_PLAN_AS double* sorted_ts() const { return sorted() + A.L.cap; }   // (cap: the largest list)
-    AF_CORE AF_PLAN_AS uint16_t* list_aux(uint32_t s = 2u) const { return (AF_PLAN_AS uint16_t*)(M + ((kFar && s == 3u) ? A.L.off_aux3 : A.L.off_aux)); }   // lists 2 and (FEAT_FAR) 3
-    AF_CORE AF_PLAN_AS double* out_key() const { return (AF_PLAN_AS double*)(M + A.L.off_out); }
+    AF_CORE AF_PLAN_AS uint16_t* list_aux(uint32_t s = 2u) const { return (AF_PLAN_AS uint16_t*)(M + ((kFar && s == 3u) ? o_aux3() : o_aux())); }   // lists 2 and (FEAT_FAR) 3
+    AF_CORE AF_PLAN_AS double* out_key() const { return (AF_PLAN_AS double*)(M + o_out()); }
     AF_CORE AF_PLAN_AS double* out_t0() const { return out_key() + 64; }
-    AF_CORE AF_PLAN_AS uint32_t* out_aux() const { return (AF_PLAN_AS uint32_t*)(M + A.L.off_out + 128u); }
-    AF_CORE AF_PLAN_AS double* sorted() const { return (AF_PLAN_AS double*)(M + A.L.off_sorted); }
-    AF_CORE AF_PLAN_AS uint32_t* hist() const { return (AF_PLAN_AS uint32_t*)(M + A.L.off_hist); }
+    AF_CORE AF_PLAN_AS uint32_t* out_aux() const { return (AF_PLAN_AS uint32_t*)(M + o_out() + 128u); }
+    AF_CORE AF_PLAN_AS double* sorted() const { return (AF_PLAN_AS double*)(M + o_sorted()); }
+    AF_CORE AF_PLAN_AS uint32_t* hist() const { return (AF_PLAN_AS uint32_t*)(M + o_hst()); }
     AF_CORE AF_PLAN_AS uint32_t* bbase() const { return hist() + 64; }
-    AF_CORE AF_PLAN_AS double* scal() const { return (AF_PLAN_AS double*)(M + A.L.off_hist + 64u); }   // [8] scalars
-    AF_CORE AF_PLAN_AS double* seg(uint32_t which) const { return (AF_PLAN_AS double*)(M + A.L.off_seg) + 64u * which; }
-    AF_CORE AF_PLAN_AS double* fr(uint32_t sv) const { return (AF_PLAN_AS double*)(M + A.L.off_fr) + sv * A.L.c_ring; }
+    AF_CORE AF_PLAN_AS double* scal() const { return (AF_PLAN_AS double*)(M + o_hst() + 64u); }   // [8] scalars
+    AF_CORE AF_PLAN_AS double* seg(uint32_t which) const { return (AF_PLAN_AS double*)(M + o_out()) + 64u * which; }   // (aliases select()'s scratch)
+    AF_CORE AF_PLAN_AS double* fr(uint32_t sv) const { return (AF_PLAN_AS double*)(M + o_fr()) + sv * A.L.c_ring; }
     AF_CORE AF_PLAN_AS double* gr(uint32_t sv) const { return (AF_PLAN_AS double*)(M + A.L.off_gr) + sv * A.L.g_ring; }
     AF_CORE AF_PLAN_AS uint32_t* sends() const { return (AF_PLAN_AS uint32_t*)(M + A.L.off_cnt); }
     AF_CORE AF_PLAN_AS uint32_t* lbw() const { return sends() + ((A.n_edges + 1u) & ~1u); }  // [0..15] order, 16 head, 17 n_live, 18 mark cursor, 19 ceil(2^32 / n_live), [24..31] arrivals per server, [32..39] / [40..47] segment start / length, [48..55] step counts (leading I/O | CPU << 8 | trailing I/O << 16), [56..63] RAM slots (requests that fit at once)
@@ -1099,6 +1113,11 @@ struct Flow {
     AF_CORE void run(AF_PLAN_AS uint64_t* smem, uint32_t sc) {
         lane = W::lane();
         blob = smem;
+#if !defined(__HIP_DEVICE_COMPILE__)
+        if (kCt && (A.L.cap != kCap || A.L.off_list != (kMarks ? A.L.off_list : 0u) || A.L.off_aux != o_aux() || A.L.off_aux3 != o_aux3() ||
+                    A.L.off_out != o_out() || A.L.off_seg != o_out() || A.L.off_sorted != o_sorted() || A.L.off_hist != o_hst() || A.L.off_fr != o_fr()))
+            __builtin_trap();   // make_flow_layout and the compile-time offsets above disagree
+#endif
         M = smem + A.blob_bytes / 8u;
         seed = A.seeds[sc];
         arr = A.arrivals + (size_t)sc * A.n_draw;
@@ -1175,7 +1194,7 @@ struct Flow {
         gen_done = false;
         nl0 = nl1 = nl2 = nl3 = 0u;
         h0 = h1 = h2 = h3 = 0.0;
-        const uint32_t cap = A.L.cap;
+        const uint32_t cap = kCt ? kCap : A.L.cap;
         const uint32_t first_srv_stage = A.has_lb ? 1u : 2u;   // where the client's out-edge leads
 
         // Every round walks the five stations in order.  The code of select() and of edge_send() exists ONCE

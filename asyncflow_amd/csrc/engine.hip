@@ -1203,7 +1203,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
         }
         if (rows != 0u) {
             const double full_rows = std::ceil(tail_full / a.sample_period) + 2.0;
-            flow_far = (double)rows - full_rows < std::fmin(8.0, (double)(rows / 2u));
+            flow_far = (double)rows - full_rows < std::fmin(8.0, (double)(rows / 2u)) || std::getenv("AF_FLOW_FORCE_FAR") != nullptr;   // (env: experiment hook)
             const double w = (double)rows - (flow_far ? tail_rows : full_rows);
             win_rows = w >= (double)(rows / 2u) ? (uint32_t)w : rows / 2u;   // an explicit small ring: half of it, overflow -> hand-back
         }
