@@ -63,6 +63,23 @@ __device__ inline double wave_max(double v) {
     return v;
 }
 
+// One LDS atomic per DISTINCT index of a wave instead of one per lane, for counters whose index is nearly the same in all
+// 64 lanes (the exponent bin of a latency: 2-3 bins per scenario; the 1-s window of a completion: consecutive completions):
+// 64 lanes on one LDS word serialise, and two such atomics per element made pass 1 LDS-bound rather than HBM-bound.
+// Called by all lanes of the wave from uniform control flow; after 4 distinct values the rest go one by one.
+__device__ inline void wave_agg_add(uint32_t* base, uint32_t idx, bool active) {
+    unsigned long long todo = __ballot(active);
+    const int lane = threadIdx.x & 63;
+    for (int it = 0; it < 4 && todo; ++it) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t v = __shfl(idx, leader, 64);
+        const unsigned long long same = __ballot(active && idx == v) & todo;
+        if (lane == leader) atomicAdd(&base[v], (uint32_t)__popcll(same));
+        todo &= ~same;
+    }
+    if ((todo >> lane) & 1ull) atomicAdd(&base[idx], 1u);
+}
+
 // Deterministic block sum: per-thread partials -> wave tree -> the 8 wave results in lane order.
 __device__ inline double block_sum(double v, double* scratch /* [kWaves] */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -182,26 +199,30 @@ __global__ __launch_bounds__(kThreads) void af_summary_kernel(SumArgs a) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint32_t i = base + (uint32_t)u * kThreads + tid;
-            if (i >= n) continue;
+            const bool act = i < n;
             const double2 c = c4[u];
             const double lat = c.y - c.x;
-            s += lat;
-            mn = fmin(mn, lat);
-            mx = fmax(mx, lat);
+            if (act) {
+                s += lat;
+                mn = fmin(mn, lat);
+                mx = fmax(mx, lat);
+            }
             const unsigned long long key = (unsigned long long)__double_as_longlong(lat);
             const uint32_t ebin = (uint32_t)(key >> 52) & (kExpBins - 1);
-            atomicAdd(&exp_hist[ebin], 1u);
-            const uint32_t dig = (uint32_t)(key >> (52 - kDigBits)) & (kDigBins - 1);
-            if (gn > 0u && ebin == gp0) atomicAdd(&dig_hist[0][dig], 1u);
-            else if (gn > 1u && ebin == gp1) atomicAdd(&dig_hist[1][dig], 1u);
-            else if (gn > 2u && ebin == gp2) atomicAdd(&dig_hist[2][dig], 1u);
+            wave_agg_add(exp_hist, ebin, act);
+            if (act) {
+                const uint32_t dig = (uint32_t)(key >> (52 - kDigBits)) & (kDigBins - 1);
+                if (gn > 0u && ebin == gp0) atomicAdd(&dig_hist[0][dig], 1u);
+                else if (gn > 1u && ebin == gp1) atomicAdd(&dig_hist[1][dig], 1u);
+                else if (gn > 2u && ebin == gp2) atomicAdd(&dig_hist[2][dig], 1u);
+            }
             if (a.rps) {
                 // window (k-1, k]; a finish at exactly 0 belongs to the first window (analyzer.py:112-121)
                 const double kf = ceil(c.y);
                 const uint32_t k = kf < 1.0 ? 1u : (kf > 4.0e9 ? 0xFFFFFFFFu : (uint32_t)kf);
-                if (k <= a.rps_buckets) atomicAdd(&rps_l[k - 1u], 1u);
+                wave_agg_add(rps_l, k - 1u, act && k <= a.rps_buckets);
             }
-            if (a.hist) {
+            if (a.hist && act) {
                 const double bf = lat * a.hist_scale;
                 const uint32_t b = bf >= (double)(a.hist_bins - 1u) ? a.hist_bins - 1u : (uint32_t)bf;
                 atomicAdd(&hist_l[b], 1u);
