@@ -385,6 +385,38 @@ struct Flow {
                         }
                     }
                 }
+            } else if (pitch <= 32u) {
+                // several rows per step: lane = (row q of the step, series): the rows of a step are one contiguous store
+                // (5 rows = 240 B for LB-2 instead of five 48-byte stores), the running values of the series come from the
+                // lanes of row 0 and go back there from the step's last row
+                const uint32_t rpi = 64u / pitch;                                             // rows per step (2 .. 16)
+                const uint32_t q = (lane * (65536u / pitch + 1u)) >> 16, ser = lane - q * pitch;   // lane / pitch, lane % pitch
+                const bool s_srv = ser >= A.n_edges && ser < n_series;
+                const bool s_ram = s_srv && (ser - A.n_edges) % 3u == 2u;
+                const bool s_on = ser < A.n_edges ? edges_on : (s_srv && servers_on);
+                for (uint32_t r0 = tick_base; r0 < stop; r0 += rpi) {
+                    const uint32_t rr = r0 + q, n_rows = stop - r0 < rpi ? stop - r0 : rpi;
+                    const bool valid = q < n_rows;
+                    int32_t acc = 0;
+                    if (valid) {
+                        AF_PLAN_AS int32_t* cell = ring() + (rr & (R - 1u)) * pitch + ser;
+                        acc = *cell;
+                        *cell = 0;
+                    }
+                    const int32_t d = acc;
+                    for (uint32_t k = 1u; k < rpi; ++k) {   // inclusive sum over the rows above, same series
+                        const int32_t up = (int32_t)W::shfl32((uint32_t)d, (lane - k * pitch) & 63u);
+                        if (q >= k) acc += up;
+                    }
+                    const int32_t value = (int32_t)W::shfl32((uint32_t)run_val, ser) + acc;
+                    if (valid) {
+                        uint32_t word = 0u;
+                        if (s_on) word = s_ram ? __builtin_bit_cast(uint32_t, (float)(double)value) : (uint32_t)value;
+                        samples[(size_t)rr * pitch + ser] = word;
+                    }
+                    const int32_t last = (int32_t)W::shfl32((uint32_t)value, ((n_rows - 1u) * pitch + lane) & 63u);
+                    if (lane < pitch) run_val = last;
+                }
             } else {
                 for (uint32_t r = tick_base; r < stop; ++r) {
                     if (lane < pitch) {
