@@ -251,8 +251,11 @@ typedef struct af_engine_options {
     uint32_t flow_list_entries; /* capacity of each station's message list: 64, 128 or 256
                                    (0 = from the expected number of messages in flight)         */
     uint32_t flow_ring_rows;    /* rows of the LDS ring of per-tick differences (power of two);
-                                   0 = auto; AF_FLOW_RING_IN_HBM = keep the differences in the
-                                   sample rows in HBM (no limit on how far an interval reaches) */
+                                   0 = auto (a window of a few batches of arrivals + the time a
+                                   request spends inside a server; edges slower than the ring
+                                   reaches are handled by the receiving station);
+                                   AF_FLOW_RING_IN_HBM = keep the differences in the sample rows
+                                   in HBM (no limit on how far an interval reaches)            */
 } af_engine_options_t;
 #define AF_FLOW_RING_IN_HBM 0xFFFFFFFFu
 
@@ -281,7 +284,8 @@ typedef struct af_stats {
     uint32_t flow_fallback;        /* ... of which handed back by the first launch, by reason:        */
     uint32_t flow_fallback_tie;    /*   two events of one station (or an event and a tick / mark) at one instant */
     uint32_t flow_fallback_list;   /*   more messages pending at a station than flow_list_entries   */
-    uint32_t flow_fallback_ring;   /*   an interval reached beyond the tick ring                    */
+    uint32_t flow_fallback_ring;   /*   a request stayed in its server (or, fast-hop launches, a message on its edge)
+                                        longer than the tick ring reaches                          */
     uint32_t flow_fallback_ram;    /*   RAM admission the recurrence cannot express                 */
     uint32_t flow_retried;         /* handed-back scenarios run again by the kernel's most tolerant instantiation
                                       (256-entry lists carrying send times, tick differences in HBM)             */

@@ -352,3 +352,16 @@ def test_least_connections_runs_on_the_flow_kernel():
         res = _runner(payload, seeds=seeds).run()
         assert res.engine_stats.flow_scenarios == 64 and res.engine_stats.flow_to_next_event == 0
         _same_batches(res, _runner(payload, seeds=seeds, flow=False).run())
+
+
+def test_far_and_near_lean_instantiations_agree(monkeypatch):
+    """LB-2's hops are fast: the engine launches the plain lean instantiation (the sender enters both ends of every
+    message); AF_FLOW_FORCE_FAR makes it launch the FEAT_FAR one with the window rule of slow-hop plans.  Same results."""
+    payload = lb_two_servers(horizon=40)
+    seeds = 0xFA50000 + np.arange(96, dtype=np.uint64)
+    near = _runner(payload, seeds=seeds).run()
+    monkeypatch.setenv("AF_FLOW_FORCE_FAR", "1")
+    far = _runner(payload, seeds=seeds).run()
+    assert near.engine_stats.flow_fallback == 0 and far.engine_stats.flow_fallback == 0
+    _same_batches(near, far)
+    _assert_scenario(far[5], ol.simulate(lower(payload), int(seeds[5])), "scenario 5")
