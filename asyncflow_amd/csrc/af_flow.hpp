@@ -491,8 +491,6 @@ struct Flow {
                                                 uint32_t idx) {
         return af::variate_from_u1(dist, mean, sigma, u1, seed, stream, idx);
     }
-    // EdgeRuntime._deliver (edge.py:73-116) for the idx-th message of edge e, sent at `now`.
-    // Returns false if the message is dropped; else `key` = delivery time.
     // the draws of the idx-th message of edge e (af::pre_edge_draw, edge.py:78-90): false = dropped, else its transit
     // time; the exponential law -- the reference's default -- inline and the other laws behind one call
     AF_CORE bool edge_draw(uint32_t e, uint32_t idx, double& transit) const {
@@ -506,9 +504,11 @@ struct Flow {
         transit = af::test_quant(dist == af::DIST_EXPONENTIAL ? -(mean * af::af_log(1.0 - u1)) : cold_variate(dist, mean, sigma, u1, seed, stream, idx));
         return true;
     }
+    // EdgeRuntime._deliver (edge.py:73-116) for the idx-th message of edge e, sent at `now`.
+    // Returns false if the message is dropped; else `key` = delivery time.
     // `pre`: the draws were made earlier (lb_pick_lc): `pre_transit` < 0 = dropped.
-    // Sampled series: `row_now` = tick row of `now`; `counted` = the message was entered in its edge's series (a tick
-    // lies between send and delivery): the receiving station then enters the other end.
+    // Sampled series, FEAT_FAR: `row_now` = tick row of `now` (worked out by the caller); `counted` = only the send was
+    // entered in the edge's series, the receiving station enters the delivery.  Otherwise both ends are entered here.
     AF_CORE bool edge_send(uint32_t e, uint32_t idx, double now, uint32_t row_now, double& key, bool& counted, bool pre = false,
                            double pre_transit = 0.0) {
         counted = false;
