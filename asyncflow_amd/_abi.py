@@ -240,6 +240,7 @@ EXPORTED_SYMBOLS = (
     "af_last_error",
     "af_abi_version",
     "af_probe_math",
+    "af_probe_store",
 )
 
 
@@ -285,4 +286,6 @@ def declare(lib: C.CDLL) -> C.CDLL:
     lib.af_abi_version.restype = C.c_int
     lib.af_probe_math.argtypes = [C.c_int, C.c_int, C.c_uint64, _pd, _pd, _pd, C.c_size_t]
     lib.af_probe_math.restype = C.c_int
+    lib.af_probe_store.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]
+    lib.af_probe_store.restype = C.c_int
     return lib

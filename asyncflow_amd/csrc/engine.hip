@@ -151,7 +151,7 @@ template <bool kLdsState, bool kFaithful, int KLOG>
 __device__ __forceinline__ void des_body(const KArgs& a_in) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lane = threadIdx.x;
-#ifdef AF_JIT
+#if defined(AF_JIT) && !defined(AF_FLOW_JIT)
     // Plan-specialised build (asyncflow_amd/jit.py): the plan's shape as compile-time constants --
     // state offsets fold into instruction immediates, loops over edges / servers / series unroll,
     // branches on the plan's shape disappear (measured on the 10k LB-2 sweep: 2 084 -> 1 912 ms).
@@ -269,7 +269,7 @@ __device__ __forceinline__ void des_body(const KArgs& a_in) {
     }
 }
 
-#ifndef AF_JIT
+#if !defined(AF_JIT) || defined(AF_FLOW_JIT)
 // ---- stage-parallel kernel (af_flow.hpp): one wave per scenario -------------------------------------
 struct WaveHip {
     static __device__ __forceinline__ uint32_t lane() { return threadIdx.x; }
@@ -333,6 +333,8 @@ struct WaveHip {
 #ifndef AF_FLOW_WPE
 #define AF_FLOW_WPE 4
 #endif
+#endif
+#ifndef AF_JIT
 template <uint32_t IPL, uint32_t FEAT>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AF_FLOW_WPE))) af_flow_kernel(const aff::FlowArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -358,7 +360,68 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) 
 }
 #endif
 
-#ifdef AF_JIT
+#ifdef AF_FLOW_JIT
+}  // namespace
+
+// Plan-specialised build of the stage-parallel kernel (asyncflow_amd/jit.py; the flags come from af_engine_jit_spec when
+// the sweep would run on af_flow_kernel): the instantiation (IPL, FEAT), the plan's shape, the horizon / tick constants
+// and the whole LDS layout are compile-time constants.  The generic kernel reads ~100 wave-uniform launch arguments
+// that do not fit the 102 SGPRs (a quarter of its static VALU instructions are v_mov, 12 % SGPR<->VGPR-lane spills:
+// DESIGN.md section 4e); here they are immediates, LDS offsets fold into the instructions, loops over servers / LB
+// edges / step programs have constant trip counts.  Same source, same arithmetic: results are bit-identical.
+// What stays a run-time argument: every pointer, the scenario count and the clock / tick / draw capacities (they
+// change with replicas and the runner's auto-grow; a key that contained them would recompile for every such change).
+#define AF_FJ_F64(bits) __builtin_bit_cast(double, (uint64_t)(bits))
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AF_FLOW_WPE))) af_flow_jit(const aff::FlowArgs a_in) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (blockIdx.x >= a_in.n_scen) return;
+    aff::FlowArgs a = a_in;
+    a.total_time = AF_FJ_F64(AF_FJ_TOTAL_TIME);
+    a.sample_period = AF_FJ_F64(AF_FJ_PERIOD);
+    a.inv_period = AF_FJ_F64(AF_FJ_INV_PERIOD);
+    a.tick_eps = AF_FJ_F64(AF_FJ_TICK_EPS);
+    a.metrics_mask = AF_FJ_METRICS;
+    a.gen_out_edge = AF_FJ_GEN_EDGE;
+    a.client_out_edge = AF_FJ_CLIENT_EDGE;
+    a.n_edges = AF_FJ_N_EDGES;
+    a.n_servers = AF_FJ_N_SERVERS;
+    a.has_lb = AF_FJ_HAS_LB;
+    a.n_lb_edges = AF_FJ_N_LB;
+    a.n_edge_marks = AF_FJ_N_EMARKS;
+    a.n_srv_marks = AF_FJ_N_SMARKS;
+    a.lb_least_connections = AF_FJ_LC;
+    a.max_pre = AF_FJ_MAX_PRE;
+    a.max_cpu = AF_FJ_MAX_CPU;
+    a.max_post = AF_FJ_MAX_POST;
+    a.off_edge = AF_FJ_OFF_EDGE;
+    a.off_srv = AF_FJ_OFF_SRV;
+    a.off_ep = AF_FJ_OFF_EP;
+    a.off_row = AF_FJ_OFF_ROW;
+    a.off_emark = AF_FJ_OFF_EMARK;
+    a.off_smark = AF_FJ_OFF_SMARK;
+    a.off_lb = AF_FJ_OFF_LB;
+    a.blob_bytes = AF_FJ_BLOB_BYTES;
+    a.n_ticks = AF_FJ_N_TICKS;
+    a.L = aff::FlowLayout{AF_FJ_LAYOUT};
+    if (AF_FJ_HAS_CLOCK) __builtin_assume(a.clock != nullptr); else a.clock = nullptr;
+    if (AF_FJ_HAS_SAMPLES) __builtin_assume(a.samples != nullptr); else a.samples = nullptr;
+    if (!AF_FJ_HAS_ONLINE) a.online_hist = a.online_rps = nullptr;
+    if (!AF_FJ_HAS_OVR) a.n_ovr = 0u;
+    const uint32_t sc = a.scen_map ? a.scen_map[blockIdx.x] : blockIdx.x;
+    aff::Flow<WaveHip, AF_FJ_IPL, AF_FJ_FEAT> f(a);
+    f.run((LDS_AS uint64_t*)smem, sc);
+    if (threadIdx.x == 0u && a.n_fallback) {
+        const uint32_t flags = a.counts[(size_t)sc * af::CNT_SLOTS + af::CNT_FLAGS];
+        if (flags & aff::FLAG_FLOW_FALLBACK) {
+            atomicAdd(a.n_fallback, 1u);
+            if (flags & aff::FLOW_WHY_TIE) atomicAdd(a.n_fallback + 1, 1u);
+            if (flags & aff::FLOW_WHY_LIST) atomicAdd(a.n_fallback + 2, 1u);
+            if (flags & aff::FLOW_WHY_RING) atomicAdd(a.n_fallback + 3, 1u);
+            if (flags & aff::FLOW_WHY_RAM) atomicAdd(a.n_fallback + 4, 1u);
+        }
+    }
+}
+#elif defined(AF_JIT)
 }  // namespace
 
 // Entry points of a plan-specialised code object (built by asyncflow_amd/jit.py with hipcc --genco,
@@ -563,6 +626,29 @@ __global__ void af_probe_kernel(int kind, uint64_t seed, const double* in, const
     out[i] = r;
 }
 
+// ---- store-pattern probes (af_probe_store): calibration of rocprofv3's WRITE_SIZE on the store shapes of the
+// stage-parallel kernel (MI355X_MICROARCH.md: the counter is calibrated for wide coalesced stores only).  Each wave owns
+// a contiguous region and fills it exactly once with
+//   wide     : 16 B per lane, 64 lanes = 1 KB per store instruction (the reference pattern);
+//   pairs16  : the rqs_clock store of Flow::complete -- 16 B per lane, `lanes` consecutive lanes (a batch of n_sel <= 64
+//              completions), the next batch right behind it: chunks of lanes x 16 B that are not 64-B aligned;
+//   rows48   : the sample store of Flow::flush_ticks for a 12-word pitch -- 4 B per lane, 60 lanes = five 48-byte rows
+//              = 240 B per store instruction, the next five rows right behind them.
+__global__ void __launch_bounds__(64) af_probe_store_wide(uint32_t* out, size_t words_per_wave) {
+    uint32_t* base = out + (size_t)blockIdx.x * words_per_wave;
+    for (size_t w = (size_t)threadIdx.x * 4u; w + 4u <= words_per_wave; w += 256u) af::store4(base + w, 1u, 2u, 3u, 4u);
+}
+__global__ void __launch_bounds__(64) af_probe_store_pairs16(uint32_t* out, size_t words_per_wave, uint32_t lanes) {
+    uint32_t* base = out + (size_t)blockIdx.x * words_per_wave;
+    for (size_t w0 = 0; w0 + 4u * lanes <= words_per_wave; w0 += 4u * lanes)
+        if (threadIdx.x < lanes) af::store4(base + w0 + 4u * threadIdx.x, 1u, 2u, 3u, 4u);
+}
+__global__ void __launch_bounds__(64) af_probe_store_rows48(uint32_t* out, size_t words_per_wave) {
+    uint32_t* base = out + (size_t)blockIdx.x * words_per_wave;
+    for (size_t w0 = 0; w0 + 60u <= words_per_wave; w0 += 60u)
+        if (threadIdx.x < 60u) base[w0 + threadIdx.x] = (uint32_t)w0;
+}
+
 // ---- host side ---------------------------------------------------------------
 thread_local std::string g_err;
 
@@ -628,6 +714,9 @@ struct af_engine {
     hipModule_t jit_module = nullptr;  // plan-specialised kernels (af_engine_set_kernels), valid for jit_spec only
     hipFunction_t jit_lean = nullptr, jit_order3 = nullptr, jit_order2 = nullptr;
     std::string jit_spec;
+    hipModule_t flow_jit_module = nullptr;   // plan-specialised stage-parallel kernel, valid for flow_jit_spec only
+    hipFunction_t flow_jit_fn = nullptr;
+    std::string flow_jit_spec;
     hipEvent_t ev3 = nullptr, ev4 = nullptr;
     size_t draw_memory_bytes = 0;
     uint32_t request_capacity = 0, fifo_capacity = 0, force_global = 0, lanes_per_wave = 0;
@@ -778,6 +867,273 @@ uint32_t chunk_size(const af_engine* e, uint32_t n, size_t draw_bytes_per_scen, 
     return (n + n_chunks - 1u) / n_chunks;  // equal chunks: no short, latency-bound tail launch
 }
 
+
+// ---- stage-parallel kernel: what one af_engine_run launches -------------------------------------------------
+// List capacity and tick ring from what will be in flight at the heaviest point of the sweep, the instantiation
+// (IPL, FEAT) that covers the launch.  Shared by af_engine_run and af_engine_jit_spec (the plan-specialised build
+// bakes exactly this in).
+struct FlowPlan {
+    aff::FlowLayout FL{}, FL2{};   // first launch; second chance (long lists with send times)
+    bool big = false;              // the first launch already runs the long-list instantiation
+    bool far = false;              // the tick ring does not reach the slowest message: a FEAT_FAR instantiation
+    uint32_t big_caps[4] = {256u, 256u, 256u, 256u};
+    uint32_t lds = 0;              // bytes of LDS per wave of the first launch
+    uint32_t ipl = 1u, feat = 0u;  // instantiation of the first launch
+    bool lean = false;
+};
+
+int plan_flow(const af_engine* e, const KArgs& a, const af_sweep_t* sweep, const af_outputs_t* out, FlowPlan& P) {
+    const uint32_t n = sweep->n_scenarios;
+    aff::FlowLayout& FL = P.FL;
+    aff::FlowLayout& FL2 = P.FL2;
+    bool& flow_big = P.big;
+    bool& flow_far = P.far;
+    uint32_t (&big_caps)[4] = P.big_caps;
+    uint32_t& flow_lds = P.lds;
+    double users = e->users_mean, rpm = e->rpm_mean;
+    std::vector<double> emean = e->edge_mean;
+    for (uint32_t k = 0; k < sweep->n_overrides; ++k) {
+        const af_override_t& o = sweep->overrides[k];
+        double mx = o.values[0];
+        for (uint32_t i = 1; i < n; ++i) mx = o.values[i] > mx ? o.values[i] : mx;
+        if (o.param == AF_PARAM_GEN_USERS_MEAN) users = mx;
+        else if (o.param == AF_PARAM_GEN_RPM_MEAN) rpm = mx;
+        else if (o.param == AF_PARAM_EDGE_MEAN) emean[o.index] = mx;
+    }
+    const double sd = e->users_dist == AF_DIST_POISSON ? std::sqrt(users > 0.0 ? users : 0.0) : e->users_sigma;
+    const double rate = (users + 4.0 * sd) * rpm / 60.0 + 1e-9;
+    auto lat_mean = [&](int32_t ed) {
+        const double m = emean[ed], sg = e->edge_sigma[ed];
+        switch (e->edge_dist[ed]) {
+            case AF_DIST_LOG_NORMAL: return std::exp(m + 0.5 * sg * sg < 50.0 ? m + 0.5 * sg * sg : 50.0);
+            case AF_DIST_NORMAL: return (m > 0.0 ? m : 0.0) + 0.4 * sg;
+            case AF_DIST_UNIFORM: return 0.5;
+            default: return m;
+        }
+    };
+    // the hops of the request path: generator edge, client edge, the slowest LB edge, the slowest server out-edge
+    std::vector<int32_t> hops = {e->gen_edge, e->client_edge};
+    auto slowest = [&](const std::vector<int32_t>& es) {
+        int32_t best = -1;
+        for (int32_t ed : es)
+            if (best < 0 || lat_mean(ed) + e->edge_spike[ed] > lat_mean(best) + e->edge_spike[best]) best = ed;
+        return best;
+    };
+    if (!e->lb_edges.empty()) hops.push_back(slowest(e->lb_edges));
+    hops.push_back(slowest(e->srv_out_edge));
+    // time in a server: service + the M/D/1 wait for a core at the heaviest load of the sweep
+    const double n_active = e->has_lb ? (double)(e->lb_edges.size() > 1 && a.n_srv_marks ? e->lb_edges.size() - 1 : e->lb_edges.size()) : 1.0;
+    const double rho = rate / n_active * e->cpu_max / (double)e->cores_max;
+    const double wait = rho < 0.9 ? rho * e->cpu_max / (2.0 * (1.0 - rho)) : 20.0 * e->cpu_max + 1.0;
+    const double in_server = e->service_max + 4.0 * wait;
+    // messages pending at a station ~ rate x time in flight towards it (the completion list also holds the server time)
+    // (a spiked edge: the station behind it runs ahead by the spike while it lasts -- Flow::send_floor -- but when it
+    // ends, the messages still in flight and the ones sent after it interleave: rate x spike of them wait there, and
+    // the servers then work off that burst, so as many wait for their departure in the completion list)
+    double pend = 0.0, burst = 0.0;
+    std::vector<double> pend_of(hops.size(), 0.0);
+    for (size_t h = 0; h < hops.size(); ++h) {
+        const double fly = lat_mean(hops[h]) + e->edge_spike[hops[h]] + (h + 1 == hops.size() ? in_server : 0.0);
+        burst = std::fmax(burst, rate * e->edge_spike[hops[h]]);
+        pend_of[h] = rate * fly;
+        pend = std::fmax(pend, rate * fly);
+    }
+    if (burst > 16.0)   // (millisecond spikes -- BASELINE config 4 -- change nothing a 64-entry list would notice)
+        pend_of.back() = std::fmax(pend_of.back(), burst + rate * (lat_mean(hops.back()) + in_server));
+    pend = std::fmax(pend, pend_of.back());
+    // capacities of the four station lists for the FEAT_BIGLIST instantiation (hops -> lists: generator edge -> 0,
+    // client edge -> 1 with a load balancer else 2, LB edges -> 2, server out-edges -> 3)
+    {
+        for (uint32_t s = 0; s < 4u; ++s) big_caps[s] = (s == 1u && !e->has_lb) ? 64u : 256u;   // (no LB: its list stays empty)
+        for (size_t h = 0; h < hops.size(); ++h) {
+            const uint32_t s = h == 0 ? 0u : h + 1 == hops.size() ? 3u : (h == 1 && e->has_lb) ? 1u : 2u;
+            const double want = 1.5 * pend_of[h] + 128.0;
+            const uint32_t c = want < 16384.0 ? ((uint32_t)want + 63u) & ~63u : 16384u;   // any multiple of 64
+            if (c > big_caps[s]) big_caps[s] = c;
+        }
+    }
+    // A list only has to leave ROOM: 64 - pending new messages fit per round.  Larger lists cost LDS (occupancy) and
+    // ranking work on every round of every scenario (measured on the config-3 grid: 64 entries 122 ms, 128 entries
+    // 144 ms, no hand-backs either way); an overflow costs one scenario a second run.  `pend` is the MEAN at the
+    // heaviest point of the sweep: half a list of pending messages still leaves half a batch of room.
+    uint32_t entries = e->flow_list_entries;
+    if (entries == 0u) {
+        entries = pend <= 32.0 ? 64u : pend <= 96.0 ? 128u : 256u;
+        flow_big = pend > 200.0;   // more than register-resident lists hold: the whole launch on the long-list instantiation
+    }
+    // What the tick ring has to reach past its window.  With FEAT_FAR: the time a request spends INSIDE a server (its
+    // queue / step / RAM intervals are entered when it arrives); a delivery the ring does not reach is entered by the
+    // receiving station (af_flow.hpp, "Sampled series").  Without: the in-flight time of the slowest message of the
+    // sweep (~1e-11 per request) -- the largest single hop at that quantile, the other hops at mean + 3 sd, spikes.
+    auto lat_sd = [&](int32_t ed) {
+        const double m = emean[ed], sg = e->edge_sigma[ed];
+        switch (e->edge_dist[ed]) {
+            case AF_DIST_LOG_NORMAL: {
+                const double v = sg * sg < 50.0 ? sg * sg : 50.0;
+                return lat_mean(ed) * std::sqrt(std::exp(v) - 1.0);
+            }
+            case AF_DIST_NORMAL: return sg;
+            case AF_DIST_UNIFORM: return 0.29;
+            default: return m;
+        }
+    };
+    auto lat_q = [&](int32_t ed) {   // a transit time one message in ~1e11 exceeds
+        const double m = emean[ed], sg = e->edge_sigma[ed];
+        switch (e->edge_dist[ed]) {
+            case AF_DIST_LOG_NORMAL: return std::exp(m + 6.7 * sg < 50.0 ? m + 6.7 * sg : 50.0);
+            case AF_DIST_NORMAL: return (m > 0.0 ? m : 0.0) + 6.7 * sg;
+            case AF_DIST_UNIFORM: return 1.0;
+            default: return 25.3 * m;
+        }
+    };
+    double tail_full = in_server;
+    {
+        size_t worst = 0;
+        for (size_t h = 1; h < hops.size(); ++h)
+            if (lat_q(hops[h]) > lat_q(hops[worst])) worst = h;
+        for (size_t h = 0; h < hops.size(); ++h)
+            tail_full += e->edge_spike[hops[h]] + (h == worst ? lat_q(hops[h]) : lat_mean(hops[h]) + 3.0 * lat_sd(hops[h]));
+    }
+    const double tail = in_server;
+    uint32_t rows = e->flow_ring_rows, win_rows = 0u;
+    const uint32_t pitch = a.series_pitch;
+    const double tail_rows = std::ceil(tail / a.sample_period) + 2.0;
+    if (out->samples == nullptr) {
+        rows = 0u;    // no series: neither ring nor rows are touched
+    } else if (rows == AF_FLOW_RING_IN_HBM) {
+        rows = 0u;
+    } else if (rows == 0u) {
+        // the ring covers the generator's window (enough ticks for a full batch of arrivals at the heaviest load,
+        // at least 8) + the server time; 8 KB of LDS keep 16 waves per CU, 24 KB are the limit before HBM takes over
+        const double want_win = std::fmin(std::fmax(std::ceil(96.0 / rate / a.sample_period), 8.0), 4096.0);
+        const uint32_t cap_pref = aff::pow2_ge(8u * 1024u / (pitch * 4u) + 1u) / 2u, cap_max = aff::pow2_ge(24u * 1024u / (pitch * 4u) + 1u) / 2u;
+        if (tail_rows + 8.0 > (double)cap_max) {
+            rows = 0u;   // a request stays in its server longer than any ring that fits reaches: differences in HBM
+        } else {
+            rows = aff::pow2_ge((uint32_t)(tail_rows + want_win));
+            if (rows > cap_pref) rows = cap_pref >= aff::pow2_ge((uint32_t)(tail_rows + 8.0)) ? cap_pref : aff::pow2_ge((uint32_t)(tail_rows + 8.0));
+            if (rows < 16u) rows = 16u;
+            // a window of two or three batches binds less often: take it where it costs no occupancy (16 waves per CU
+            // leave 10 KB each)
+            if (!flow_big) {
+                const uint32_t no_ring = a.blob_bytes + aff::make_flow_layout(entries, 0u, e->fargs.L.g_ring, e->fargs.L.c_ring, a.n_edges,
+                                                                              a.n_servers, a.n_edge_marks).n_words * 8u;
+                while (rows < aff::pow2_ge((uint32_t)(tail_rows + 2.0 * want_win)) && no_ring + 2u * rows * pitch * 4u <= 10u * 1024u) rows *= 2u;
+            }
+        }
+    } else {
+        rows = aff::pow2_ge(rows);
+    }
+    if (rows != 0u) {
+        const double full_rows = std::ceil(tail_full / a.sample_period) + 2.0;
+        flow_far = (double)rows - full_rows < std::fmin(8.0, (double)(rows / 2u)) || std::getenv("AF_FLOW_FORCE_FAR") != nullptr;   // (env: experiment hook)
+        const double w = (double)rows - (flow_far ? tail_rows : full_rows);
+        win_rows = w >= (double)(rows / 2u) ? (uint32_t)w : rows / 2u;   // an explicit small ring: half of it, overflow -> hand-back
+    }
+    // long lists have to fit the LDS of a compute unit next to everything else: halve the longest until they do
+    auto big_layout = [&](uint32_t ring) {
+        aff::FlowLayout L = aff::make_flow_layout(0u, ring, e->fargs.L.g_ring, e->fargs.L.c_ring, a.n_edges, a.n_servers, a.n_edge_marks, true, big_caps);
+        while (a.blob_bytes + L.n_words * 8u > kLdsLimit) {
+            uint32_t m = 0;
+            for (uint32_t s = 1; s < 4u; ++s)
+                if (big_caps[s] > big_caps[m]) m = s;
+            if (big_caps[m] <= 256u) break;
+            big_caps[m] = (big_caps[m] / 2u + 63u) & ~63u;
+            L = aff::make_flow_layout(0u, ring, e->fargs.L.g_ring, e->fargs.L.c_ring, a.n_edges, a.n_servers, a.n_edge_marks, true, big_caps);
+        }
+        return L;
+    };
+    if (flow_big) {
+        if (rows * pitch * 4u > 8u * 1024u) {   // the lists need the LDS more than the tick ring does
+            rows = 0u;
+            win_rows = 0u;
+        }
+        FL = big_layout(rows);
+    } else {
+        FL = aff::make_flow_layout(entries, rows, e->fargs.L.g_ring, e->fargs.L.c_ring, a.n_edges, a.n_servers, a.n_edge_marks);
+    }
+    FL.win_rows = win_rows;
+    FL2 = big_layout(0u);   // second chance: tick differences in HBM (no reach limit)
+    FL2.win_rows = 0u;
+    flow_lds = a.blob_bytes + FL.n_words * 8u;
+    if (flow_lds > kLdsLimit) return fail(AF_ERR_CAPACITY, "flow kernel layout exceeds the LDS of a compute unit");
+
+    // the leanest instantiation that covers this launch (a compiled-in feature costs wave-uniform registers)
+    const bool lc = e->fargs.lb_least_connections != 0u;
+    const bool has_online = out->online_hist != nullptr || out->online_rps != nullptr;
+    const bool ring_ok = FL.ring_rows != 0u || out->samples == nullptr;
+    const bool lean = a.n_edge_marks == 0u && a.n_srv_marks == 0u && !has_online && ring_ok;
+    // injected spikes / outages, but neither the kernel-side summary nor tick differences in HBM (BASELINE config 4)
+    const bool marks_only = !lean && !has_online && ring_ok;
+    constexpr uint32_t kRobust = aff::FEAT_ALL | aff::FEAT_TIEBREAK | aff::FEAT_BIGLIST;
+    P.lean = lean && !flow_big && !lc;
+    if (flow_big) {
+        P.ipl = 1u;
+        P.feat = kRobust | (lc ? (uint32_t)aff::FEAT_LC : 0u);
+    } else if (lc) {
+        P.ipl = FL.cap == 64u ? 1u : FL.cap == 128u ? 2u : 4u;
+        P.feat = aff::FEAT_ALL | aff::FEAT_LC;
+    } else if (FL.cap == 64u || FL.cap == 128u) {
+        P.ipl = FL.cap / 64u;
+        P.feat = lean ? (flow_far ? (uint32_t)aff::FEAT_FAR : 0u) : marks_only ? (uint32_t)(aff::FEAT_MARKS | aff::FEAT_FAR) : (uint32_t)aff::FEAT_ALL;
+    } else {
+        P.ipl = 4u;
+        P.feat = aff::FEAT_ALL;
+    }
+    return AF_OK;
+}
+
+// the library's own (generic) instantiation for (ipl, feat); nullptr = not built
+const void* flow_kernel_for(uint32_t ipl, uint32_t feat) {
+    constexpr uint32_t kRobust = aff::FEAT_ALL | aff::FEAT_TIEBREAK | aff::FEAT_BIGLIST, kLC = aff::FEAT_LC, kAll = aff::FEAT_ALL;
+    constexpr uint32_t kFar = aff::FEAT_FAR, kMarksFar = aff::FEAT_MARKS | aff::FEAT_FAR;
+#define AF_FLOW_CASE(I, F) if (ipl == (I) && feat == (F)) return reinterpret_cast<const void*>(af_flow_kernel<(I), (F)>)
+    AF_FLOW_CASE(1u, kRobust | kLC);
+    AF_FLOW_CASE(1u, kRobust);
+    AF_FLOW_CASE(1u, kAll | kLC);
+    AF_FLOW_CASE(2u, kAll | kLC);
+    AF_FLOW_CASE(4u, kAll | kLC);
+    AF_FLOW_CASE(1u, kFar);
+    AF_FLOW_CASE(1u, 0u);
+    AF_FLOW_CASE(1u, kMarksFar);
+    AF_FLOW_CASE(1u, kAll);
+    AF_FLOW_CASE(2u, kFar);
+    AF_FLOW_CASE(2u, 0u);
+    AF_FLOW_CASE(2u, kMarksFar);
+    AF_FLOW_CASE(2u, kAll);
+    AF_FLOW_CASE(4u, kAll);
+#undef AF_FLOW_CASE
+    return nullptr;
+}
+
+// Everything the plan-specialised stage-parallel kernel bakes in, as hipcc -D flags (the JIT key).
+std::string flow_jit_spec_string(const af_engine* e, const FlowPlan& P, const af_outputs_t* out, bool has_ovr) {
+    const aff::FlowArgs& f = e->fargs;
+    const aff::FlowLayout& L = P.FL;
+    auto bits = [](double v) {
+        uint64_t u;
+        std::memcpy(&u, &v, 8);
+        return (unsigned long long)u;
+    };
+    char buf[2048];
+    std::snprintf(buf, sizeof buf,
+                  "-DAF_JIT=1 -DAF_FLOW_JIT=1 -DAF_FJ_IPL=%u -DAF_FJ_FEAT=%u -DAF_FJ_TOTAL_TIME=0x%llxull -DAF_FJ_PERIOD=0x%llxull "
+                  "-DAF_FJ_INV_PERIOD=0x%llxull -DAF_FJ_TICK_EPS=0x%llxull -DAF_FJ_METRICS=%u -DAF_FJ_GEN_EDGE=%u -DAF_FJ_CLIENT_EDGE=%u "
+                  "-DAF_FJ_N_EDGES=%u -DAF_FJ_N_SERVERS=%u -DAF_FJ_HAS_LB=%u -DAF_FJ_N_LB=%u -DAF_FJ_N_EMARKS=%u -DAF_FJ_N_SMARKS=%u "
+                  "-DAF_FJ_LC=%u -DAF_FJ_MAX_PRE=%u -DAF_FJ_MAX_CPU=%u -DAF_FJ_MAX_POST=%u -DAF_FJ_OFF_EDGE=%u -DAF_FJ_OFF_SRV=%u "
+                  "-DAF_FJ_OFF_EP=%u -DAF_FJ_OFF_ROW=%u -DAF_FJ_OFF_EMARK=%u -DAF_FJ_OFF_SMARK=%u -DAF_FJ_OFF_LB=%u -DAF_FJ_BLOB_BYTES=%u "
+                  "-DAF_FJ_N_TICKS=%u -DAF_FJ_HAS_CLOCK=%d -DAF_FJ_HAS_SAMPLES=%d -DAF_FJ_HAS_ONLINE=%d -DAF_FJ_HAS_OVR=%d "
+                  "-DAF_FJ_LAYOUT=%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u",
+                  P.ipl, P.feat, bits(f.total_time), bits(f.sample_period), bits(f.inv_period), bits(f.tick_eps), f.metrics_mask,
+                  f.gen_out_edge, f.client_out_edge, f.n_edges, f.n_servers, f.has_lb, f.n_lb_edges, f.n_edge_marks, f.n_srv_marks,
+                  f.lb_least_connections, f.max_pre, f.max_cpu, f.max_post, f.off_edge, f.off_srv, f.off_ep, f.off_row, f.off_emark,
+                  f.off_smark, f.off_lb, f.blob_bytes, f.n_ticks, out->clock ? 1 : 0, out->samples ? 1 : 0,
+                  (out->online_hist || out->online_rps) ? 1 : 0, has_ovr ? 1 : 0,
+                  L.cap, L.ring_rows, L.win_rows, L.g_ring, L.c_ring, L.pitch, L.list_arrays, L.off_spike, L.off_list, L.off_aux, L.off_aux3,
+                  L.off_out, L.off_sorted, L.off_hist, L.off_seg, L.off_fr, L.off_gr, L.off_cnt, L.off_ring, L.n_words, L.cap_of[0],
+                  L.cap_of[1], L.cap_of[2], L.cap_of[3], L.off_list_of[0], L.off_list_of[1], L.off_list_of[2], L.off_list_of[3], L.off_eb);
+    return buf;
+}
 }  // namespace
 
 extern "C" {
@@ -1055,186 +1411,18 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
 
     double ms_pregen = 0.0, ms_kernel = 0.0, ms_flow = 0.0;
     uint32_t kl = 0, waves = 0, lds_bytes = 0, n_chunks = 0, n_rerun = 0, n_jit = 0, n_jit_miss = 0;
-    uint32_t fb_total[5] = {0, 0, 0, 0, 0}, flow_scen = 0, flow_lds = 0;
-    bool flow_lean = false;
+    uint32_t fb_total[5] = {0, 0, 0, 0, 0}, flow_scen = 0;
     uint32_t flow_retried = 0, flow_to_next = 0;
     size_t draw_bytes = 0;
     bool lds_state = false;
-    aff::FlowLayout FL{}, FL2{};     // first launch; second chance (long lists with send times)
-    bool flow_big = false;           // the first launch already runs the long-list instantiation
-    bool flow_far = false;           // the tick ring does not reach the slowest message: a FEAT_FAR instantiation
-    uint32_t big_caps[4] = {256u, 256u, 256u, 256u};
 
-    // ---- stage-parallel kernel: list capacity and tick ring from what will be in flight ----------------
-    if (use_flow) {
-        double users = e->users_mean, rpm = e->rpm_mean;
-        std::vector<double> emean = e->edge_mean;
-        for (uint32_t k = 0; k < sweep->n_overrides; ++k) {
-            const af_override_t& o = sweep->overrides[k];
-            double mx = o.values[0];
-            for (uint32_t i = 1; i < n; ++i) mx = o.values[i] > mx ? o.values[i] : mx;
-            if (o.param == AF_PARAM_GEN_USERS_MEAN) users = mx;
-            else if (o.param == AF_PARAM_GEN_RPM_MEAN) rpm = mx;
-            else if (o.param == AF_PARAM_EDGE_MEAN) emean[o.index] = mx;
-        }
-        const double sd = e->users_dist == AF_DIST_POISSON ? std::sqrt(users > 0.0 ? users : 0.0) : e->users_sigma;
-        const double rate = (users + 4.0 * sd) * rpm / 60.0 + 1e-9;
-        auto lat_mean = [&](int32_t ed) {
-            const double m = emean[ed], sg = e->edge_sigma[ed];
-            switch (e->edge_dist[ed]) {
-                case AF_DIST_LOG_NORMAL: return std::exp(m + 0.5 * sg * sg < 50.0 ? m + 0.5 * sg * sg : 50.0);
-                case AF_DIST_NORMAL: return (m > 0.0 ? m : 0.0) + 0.4 * sg;
-                case AF_DIST_UNIFORM: return 0.5;
-                default: return m;
-            }
-        };
-        // the hops of the request path: generator edge, client edge, the slowest LB edge, the slowest server out-edge
-        std::vector<int32_t> hops = {e->gen_edge, e->client_edge};
-        auto slowest = [&](const std::vector<int32_t>& es) {
-            int32_t best = -1;
-            for (int32_t ed : es)
-                if (best < 0 || lat_mean(ed) + e->edge_spike[ed] > lat_mean(best) + e->edge_spike[best]) best = ed;
-            return best;
-        };
-        if (!e->lb_edges.empty()) hops.push_back(slowest(e->lb_edges));
-        hops.push_back(slowest(e->srv_out_edge));
-        // time in a server: service + the M/D/1 wait for a core at the heaviest load of the sweep
-        const double n_active = e->has_lb ? (double)(e->lb_edges.size() > 1 && a.n_srv_marks ? e->lb_edges.size() - 1 : e->lb_edges.size()) : 1.0;
-        const double rho = rate / n_active * e->cpu_max / (double)e->cores_max;
-        const double wait = rho < 0.9 ? rho * e->cpu_max / (2.0 * (1.0 - rho)) : 20.0 * e->cpu_max + 1.0;
-        const double in_server = e->service_max + 4.0 * wait;
-        // messages pending at a station ~ rate x time in flight towards it (the completion list also holds the server time)
-        // (a spiked edge: the station behind it runs ahead by the spike while it lasts -- Flow::send_floor -- but when it
-        // ends, the messages still in flight and the ones sent after it interleave: rate x spike of them wait there, and
-        // the servers then work off that burst, so as many wait for their departure in the completion list)
-        double pend = 0.0, burst = 0.0;
-        std::vector<double> pend_of(hops.size(), 0.0);
-        for (size_t h = 0; h < hops.size(); ++h) {
-            const double fly = lat_mean(hops[h]) + e->edge_spike[hops[h]] + (h + 1 == hops.size() ? in_server : 0.0);
-            burst = std::fmax(burst, rate * e->edge_spike[hops[h]]);
-            pend_of[h] = rate * fly;
-            pend = std::fmax(pend, rate * fly);
-        }
-        if (burst > 16.0)   // (millisecond spikes -- BASELINE config 4 -- change nothing a 64-entry list would notice)
-            pend_of.back() = std::fmax(pend_of.back(), burst + rate * (lat_mean(hops.back()) + in_server));
-        pend = std::fmax(pend, pend_of.back());
-        // capacities of the four station lists for the FEAT_BIGLIST instantiation (hops -> lists: generator edge -> 0,
-        // client edge -> 1 with a load balancer else 2, LB edges -> 2, server out-edges -> 3)
-        {
-            for (uint32_t s = 0; s < 4u; ++s) big_caps[s] = (s == 1u && !e->has_lb) ? 64u : 256u;   // (no LB: its list stays empty)
-            for (size_t h = 0; h < hops.size(); ++h) {
-                const uint32_t s = h == 0 ? 0u : h + 1 == hops.size() ? 3u : (h == 1 && e->has_lb) ? 1u : 2u;
-                const double want = 1.5 * pend_of[h] + 128.0;
-                const uint32_t c = want < 16384.0 ? ((uint32_t)want + 63u) & ~63u : 16384u;   // any multiple of 64
-                if (c > big_caps[s]) big_caps[s] = c;
-            }
-        }
-        // A list only has to leave ROOM: 64 - pending new messages fit per round.  Larger lists cost LDS (occupancy) and
-        // ranking work on every round of every scenario (measured on the config-3 grid: 64 entries 122 ms, 128 entries
-        // 144 ms, no hand-backs either way); an overflow costs one scenario a second run.  `pend` is the MEAN at the
-        // heaviest point of the sweep: half a list of pending messages still leaves half a batch of room.
-        uint32_t entries = e->flow_list_entries;
-        if (entries == 0u) {
-            entries = pend <= 32.0 ? 64u : pend <= 96.0 ? 128u : 256u;
-            flow_big = pend > 200.0;   // more than register-resident lists hold: the whole launch on the long-list instantiation
-        }
-        // What the tick ring has to reach past its window.  With FEAT_FAR: the time a request spends INSIDE a server (its
-        // queue / step / RAM intervals are entered when it arrives); a delivery the ring does not reach is entered by the
-        // receiving station (af_flow.hpp, "Sampled series").  Without: the in-flight time of the slowest message of the
-        // sweep (~1e-11 per request) -- the largest single hop at that quantile, the other hops at mean + 3 sd, spikes.
-        auto lat_sd = [&](int32_t ed) {
-            const double m = emean[ed], sg = e->edge_sigma[ed];
-            switch (e->edge_dist[ed]) {
-                case AF_DIST_LOG_NORMAL: {
-                    const double v = sg * sg < 50.0 ? sg * sg : 50.0;
-                    return lat_mean(ed) * std::sqrt(std::exp(v) - 1.0);
-                }
-                case AF_DIST_NORMAL: return sg;
-                case AF_DIST_UNIFORM: return 0.29;
-                default: return m;
-            }
-        };
-        auto lat_q = [&](int32_t ed) {   // a transit time one message in ~1e11 exceeds
-            const double m = emean[ed], sg = e->edge_sigma[ed];
-            switch (e->edge_dist[ed]) {
-                case AF_DIST_LOG_NORMAL: return std::exp(m + 6.7 * sg < 50.0 ? m + 6.7 * sg : 50.0);
-                case AF_DIST_NORMAL: return (m > 0.0 ? m : 0.0) + 6.7 * sg;
-                case AF_DIST_UNIFORM: return 1.0;
-                default: return 25.3 * m;
-            }
-        };
-        double tail_full = in_server;
-        {
-            size_t worst = 0;
-            for (size_t h = 1; h < hops.size(); ++h)
-                if (lat_q(hops[h]) > lat_q(hops[worst])) worst = h;
-            for (size_t h = 0; h < hops.size(); ++h)
-                tail_full += e->edge_spike[hops[h]] + (h == worst ? lat_q(hops[h]) : lat_mean(hops[h]) + 3.0 * lat_sd(hops[h]));
-        }
-        const double tail = in_server;
-        uint32_t rows = e->flow_ring_rows, win_rows = 0u;
-        const uint32_t pitch = a.series_pitch;
-        const double tail_rows = std::ceil(tail / a.sample_period) + 2.0;
-        if (out->samples == nullptr) {
-            rows = 0u;    // no series: neither ring nor rows are touched
-        } else if (rows == AF_FLOW_RING_IN_HBM) {
-            rows = 0u;
-        } else if (rows == 0u) {
-            // the ring covers the generator's window (enough ticks for a full batch of arrivals at the heaviest load,
-            // at least 8) + the server time; 8 KB of LDS keep 16 waves per CU, 24 KB are the limit before HBM takes over
-            const double want_win = std::fmin(std::fmax(std::ceil(96.0 / rate / a.sample_period), 8.0), 4096.0);
-            const uint32_t cap_pref = aff::pow2_ge(8u * 1024u / (pitch * 4u) + 1u) / 2u, cap_max = aff::pow2_ge(24u * 1024u / (pitch * 4u) + 1u) / 2u;
-            if (tail_rows + 8.0 > (double)cap_max) {
-                rows = 0u;   // a request stays in its server longer than any ring that fits reaches: differences in HBM
-            } else {
-                rows = aff::pow2_ge((uint32_t)(tail_rows + want_win));
-                if (rows > cap_pref) rows = cap_pref >= aff::pow2_ge((uint32_t)(tail_rows + 8.0)) ? cap_pref : aff::pow2_ge((uint32_t)(tail_rows + 8.0));
-                if (rows < 16u) rows = 16u;
-                // a window of two or three batches binds less often: take it where it costs no occupancy (16 waves per CU
-                // leave 10 KB each)
-                if (!flow_big) {
-                    const uint32_t no_ring = a.blob_bytes + aff::make_flow_layout(entries, 0u, e->fargs.L.g_ring, e->fargs.L.c_ring, a.n_edges,
-                                                                                  a.n_servers, a.n_edge_marks).n_words * 8u;
-                    while (rows < aff::pow2_ge((uint32_t)(tail_rows + 2.0 * want_win)) && no_ring + 2u * rows * pitch * 4u <= 10u * 1024u) rows *= 2u;
-                }
-            }
-        } else {
-            rows = aff::pow2_ge(rows);
-        }
-        if (rows != 0u) {
-            const double full_rows = std::ceil(tail_full / a.sample_period) + 2.0;
-            flow_far = (double)rows - full_rows < std::fmin(8.0, (double)(rows / 2u)) || std::getenv("AF_FLOW_FORCE_FAR") != nullptr;   // (env: experiment hook)
-            const double w = (double)rows - (flow_far ? tail_rows : full_rows);
-            win_rows = w >= (double)(rows / 2u) ? (uint32_t)w : rows / 2u;   // an explicit small ring: half of it, overflow -> hand-back
-        }
-        // long lists have to fit the LDS of a compute unit next to everything else: halve the longest until they do
-        auto big_layout = [&](uint32_t ring) {
-            aff::FlowLayout L = aff::make_flow_layout(0u, ring, e->fargs.L.g_ring, e->fargs.L.c_ring, a.n_edges, a.n_servers, a.n_edge_marks, true, big_caps);
-            while (a.blob_bytes + L.n_words * 8u > kLdsLimit) {
-                uint32_t m = 0;
-                for (uint32_t s = 1; s < 4u; ++s)
-                    if (big_caps[s] > big_caps[m]) m = s;
-                if (big_caps[m] <= 256u) break;
-                big_caps[m] = (big_caps[m] / 2u + 63u) & ~63u;
-                L = aff::make_flow_layout(0u, ring, e->fargs.L.g_ring, e->fargs.L.c_ring, a.n_edges, a.n_servers, a.n_edge_marks, true, big_caps);
-            }
-            return L;
-        };
-        if (flow_big) {
-            if (rows * pitch * 4u > 8u * 1024u) {   // the lists need the LDS more than the tick ring does
-                rows = 0u;
-                win_rows = 0u;
-            }
-            FL = big_layout(rows);
-        } else {
-            FL = aff::make_flow_layout(entries, rows, e->fargs.L.g_ring, e->fargs.L.c_ring, a.n_edges, a.n_servers, a.n_edge_marks);
-        }
-        FL.win_rows = win_rows;
-        FL2 = big_layout(0u);   // second chance: tick differences in HBM (no reach limit)
-        FL2.win_rows = 0u;
-        flow_lds = a.blob_bytes + FL.n_words * 8u;
-        if (flow_lds > kLdsLimit) return fail(AF_ERR_CAPACITY, "flow kernel layout exceeds the LDS of a compute unit");
-    }
+    FlowPlan FP;
+    if (use_flow)
+        if (int rc = plan_flow(e, a, sweep, out, FP)) return rc;
+    aff::FlowLayout& FL = FP.FL;
+    aff::FlowLayout& FL2 = FP.FL2;
+    const bool flow_big = FP.big;
+    const uint32_t flow_lds = FP.lds;
 
     const size_t tie_words = a.L.tie_words;
     const bool hetero_load = (mask & ((1u << AF_PARAM_GEN_USERS_MEAN) | (1u << AF_PARAM_GEN_RPM_MEAN))) != 0u;
@@ -1286,8 +1474,22 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     auto run_sequential = [&](uint32_t count, const uint32_t* h_map, const KArgs& chunk_args) -> int {
         size_t mf = 0, mt = 0;
         HIP_TRY(hipMemGetInfo(&mf, &mt));
-        const uint32_t piece = chunk_size(e, count, draw_bytes_per_scen, mf);
+        uint32_t piece = chunk_size(e, count, draw_bytes_per_scen, mf);
         if (piece == 0) return fail(AF_ERR_CAPACITY, "draw_capacity too large for the device memory budget");
+        if (const char* env = std::getenv("AF_SEQ_PIECE")) {   // test hook: force a whole chunk to run in pieces
+            const uint32_t v = (uint32_t)std::atoi(env);
+            if (v != 0u && v < piece) piece = v;
+        }
+        // A whole chunk (no list) that does not fit the draw budget in one piece -- the free memory is measured again
+        // here, after the scratch buffers of the chunk were allocated -- runs as pieces over an identity list: piece
+        // p0 simulates scenarios [p0, p0 + cnt) with its draws in slots [0, cnt).  (Round 2 ran [0, cnt) again: ADVICE r2.)
+        std::vector<uint32_t> ident;
+        if (h_map == nullptr && piece < count) {
+            ident.resize(count);
+            for (uint32_t i = 0; i < count; ++i) ident[i] = i;
+            h_map = ident.data();
+        }
+        const bool listed_subset = h_map != nullptr && ident.empty();
         for (uint32_t p0 = 0; p0 < count; p0 += piece) {
             const uint32_t cnt = count - p0 < piece ? count - p0 : piece;
             a = chunk_args;
@@ -1314,7 +1516,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
             hipLaunchKernelGGL(af_pregen_edges, dim3((n_draw + 255u) / 256u, cnt, a.n_edges), dim3(256), 0, e->stream, a);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(e->ev3, e->stream));
-            if (h_map && (a.online_hist || a.online_rps)) {   // scenarios that start over: their online counters are cleared
+            if (listed_subset && (a.online_hist || a.online_rps)) {   // scenarios that start over: their online counters are cleared
                 hipLaunchKernelGGL(af_zero_online, dim3(cnt), dim3(256), 0, e->stream, a, cnt);
                 HIP_TRY(hipGetLastError());
             }
@@ -1323,7 +1525,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
             // path; engines whose plan keeps producing such scenarios go straight to that kernel.
             // (a handful of scenarios handed back by the stage-parallel kernel -- usually for a tie -- go straight to the
             // SimPy-order kernel: a second pass over them would cost a whole latency-bound launch more)
-            const bool faithful_first = e->shared_instants_likely || (h_map != nullptr && (uint64_t)count * 50u < chunk_args.n_scen);
+            const bool faithful_first = e->shared_instants_likely || (listed_subset && (uint64_t)count * 50u < chunk_args.n_scen);
             HIP_TRY(hipMemsetAsync(e->d_n_shared, 0, 4, e->stream));
             if (int rc = launch_des(cnt, faithful_first)) return rc;
             if (!faithful_first) {
@@ -1431,35 +1633,25 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
         f.n_fallback = e->d_fb;
         HIP_TRY(hipMemsetAsync(e->d_fb, 0, 10u * 4u, e->stream));
         {
-            // the leanest instantiation that covers this launch (a compiled-in feature costs wave-uniform registers)
-            const bool lean = a.n_edge_marks == 0u && a.n_srv_marks == 0u && !f.online_hist && !f.online_rps &&
-                              (FL.ring_rows != 0u || f.samples == nullptr);
-            flow_lean = lean && !flow_big && f.lb_least_connections == 0u;
-            // injected spikes / outages, but neither the kernel-side summary nor tick differences in HBM (BASELINE config 4)
-            const bool marks_only = !lean && !f.online_hist && !f.online_rps && (FL.ring_rows != 0u || f.samples == nullptr);
-            constexpr uint32_t kRobust = aff::FEAT_ALL | aff::FEAT_TIEBREAK | aff::FEAT_BIGLIST, kLC = aff::FEAT_LC;
-            const bool lc = f.lb_least_connections != 0u;
-            const void* fn = flow_big         ? (lc ? reinterpret_cast<const void*>(af_flow_kernel<1, kRobust | kLC>)
-                                                    : reinterpret_cast<const void*>(af_flow_kernel<1, kRobust>))
-                             : lc             ? (FL.cap == 64u    ? reinterpret_cast<const void*>(af_flow_kernel<1, aff::FEAT_ALL | kLC>)
-                                                 : FL.cap == 128u ? reinterpret_cast<const void*>(af_flow_kernel<2, aff::FEAT_ALL | kLC>)
-                                                                  : reinterpret_cast<const void*>(af_flow_kernel<4, aff::FEAT_ALL | kLC>))
-                             : FL.cap == 64u  ? (lean ? (flow_far ? reinterpret_cast<const void*>(af_flow_kernel<1, aff::FEAT_FAR>)
-                                                                  : reinterpret_cast<const void*>(af_flow_kernel<1, 0u>))
-                                                 : marks_only ? reinterpret_cast<const void*>(af_flow_kernel<1, aff::FEAT_MARKS | aff::FEAT_FAR>)
-                                                      : reinterpret_cast<const void*>(af_flow_kernel<1, aff::FEAT_ALL>))
-                             : FL.cap == 128u ? (lean ? (flow_far ? reinterpret_cast<const void*>(af_flow_kernel<2, aff::FEAT_FAR>)
-                                                                  : reinterpret_cast<const void*>(af_flow_kernel<2, 0u>))
-                                                 : marks_only ? reinterpret_cast<const void*>(af_flow_kernel<2, aff::FEAT_MARKS | aff::FEAT_FAR>)
-                                                      : reinterpret_cast<const void*>(af_flow_kernel<2, aff::FEAT_ALL>))
-                                              : reinterpret_cast<const void*>(af_flow_kernel<4, aff::FEAT_ALL>);
             const uint32_t flow_lds_launch = spread_lds_bytes(flow_lds);
-            if (flow_lds_launch > 48u * 1024u) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flow_lds_launch));
             void* kargs[] = {&f};
+            // plan-specialised build of exactly this launch (af_engine_set_kernels), else the library's generic instantiation
+            const bool jit = e->flow_jit_fn != nullptr && flow_lds_launch <= 64u * 1024u &&
+                             flow_jit_spec_string(e, FP, out, sweep->n_overrides != 0u) == e->flow_jit_spec;
+            if (e->flow_jit_fn != nullptr && !jit) n_jit_miss += 1u;
             if (std::getenv("AF_DEBUG"))
-                std::fprintf(stderr, "[af] flow launch: %u scenarios, %u list entries%s, %u ring rows, %u B LDS per wave%s\n", nc, FL.cap,
-                             flow_big ? " (long-list instantiation)" : "", FL.ring_rows, flow_lds, flow_lean ? (flow_far ? ", lean instantiation with far edges" : ", lean instantiation") : "");
-            HIP_TRY(hipLaunchKernel(fn, dim3(nc), dim3(kWave), kargs, flow_lds_launch, e->stream));
+                std::fprintf(stderr, "[af] flow launch: %u scenarios, %u list entries%s, %u ring rows, %u B LDS per wave, af_flow_kernel<%u, %#x>%s%s\n", nc,
+                             FL.cap, flow_big ? " (long-list instantiation)" : "", FL.ring_rows, flow_lds, FP.ipl, FP.feat,
+                             FP.lean ? (FP.far ? ", lean instantiation with far edges" : ", lean instantiation") : "", jit ? ", plan-specialised" : "");
+            if (jit) {
+                HIP_TRY(hipModuleLaunchKernel(e->flow_jit_fn, nc, 1, 1, kWave, 1, 1, flow_lds_launch, e->stream, kargs, nullptr));
+                n_jit += 1u;
+            } else {
+                const void* fn = flow_kernel_for(FP.ipl, FP.feat);
+                if (fn == nullptr) return fail(AF_ERR_INVALID, "no stage-parallel instantiation for this launch");
+                if (flow_lds_launch > 48u * 1024u) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flow_lds_launch));
+                HIP_TRY(hipLaunchKernel(fn, dim3(nc), dim3(kWave), kargs, flow_lds_launch, e->stream));
+            }
         }
         HIP_TRY(hipEventRecord(e->ev4, e->stream));
         uint32_t fb[5] = {0, 0, 0, 0, 0};
@@ -1553,7 +1745,6 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     e->stats.flow_list_entries = use_flow ? FL.cap : 0u;
     e->stats.flow_ring_rows = use_flow ? FL.ring_rows : 0u;
     e->stats.flow_lds_bytes = flow_lds;
-    (void)flow_lean;
     e->stats.jit_fallbacks = n_jit_miss;
     e->stats.pregen_ms = ms_pregen;
     e->stats.h2d_ms = ms_h2d;
@@ -1590,6 +1781,16 @@ int af_engine_jit_spec(af_engine_t* e, const af_sweep_t* sweep, const af_outputs
     a.online_rps = out->online_rps;
     a.n_draw = sweep->draw_capacity ? sweep->draw_capacity : out->clock_capacity;
     if (a.n_draw == 0) return fail(AF_ERR_INVALID, "draw_capacity (or clock_capacity) must be > 0");
+    if (e->flow_ok && e->flow_mode == 0u) {   // the sweep runs on the stage-parallel kernel: its spec
+        for (uint32_t k = 0; k < sweep->n_overrides; ++k)
+            if (!sweep->overrides[k].values) return fail(AF_ERR_INVALID, "bad override");
+        FlowPlan FP;
+        if (int rc = plan_flow(e, a, sweep, out, FP)) return rc;
+        const std::string spec = flow_jit_spec_string(e, FP, out, sweep->n_overrides != 0u);
+        if (spec.size() + 1 > cap) return fail(AF_ERR_CAPACITY, "spec buffer too small");
+        std::memcpy(buf, spec.c_str(), spec.size() + 1);
+        return AF_OK;
+    }
     size_t mem_free = 0, mem_total = 0;
     HIP_TRY(hipMemGetInfo(&mem_free, &mem_total));
     const uint32_t chunk = chunk_size(e, sweep->n_scenarios, (size_t)(1u + a.n_edges) * a.n_draw * sizeof(double), mem_free);
@@ -1608,6 +1809,28 @@ int af_engine_jit_spec(af_engine_t* e, const af_sweep_t* sweep, const af_outputs
 int af_engine_set_kernels(af_engine_t* e, const char* spec, const void* image, size_t size) {
     if (!e) return fail(AF_ERR_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(e->device));
+    const bool unload_all = !spec || !image || size == 0;
+    const bool is_flow = spec && std::strstr(spec, "-DAF_FLOW_JIT=1") != nullptr;
+    if (e->flow_jit_module && (unload_all || is_flow)) {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        (void)hipModuleUnload(e->flow_jit_module);
+        e->flow_jit_module = nullptr;
+        e->flow_jit_fn = nullptr;
+        e->flow_jit_spec.clear();
+    }
+    if (is_flow && !unload_all) {   // a plan-specialised stage-parallel kernel (one entry point)
+        hipModule_t mod = nullptr;
+        HIP_TRY(hipModuleLoadData(&mod, image));
+        hipFunction_t fn = nullptr;
+        if (hipModuleGetFunction(&fn, mod, "af_flow_jit") != hipSuccess) {
+            (void)hipModuleUnload(mod);
+            return fail(AF_ERR_INVALID, "code object lacks af_flow_jit");
+        }
+        e->flow_jit_module = mod;
+        e->flow_jit_fn = fn;
+        e->flow_jit_spec = spec;
+        return AF_OK;
+    }
     if (e->jit_module) {
         HIP_TRY(hipStreamSynchronize(e->stream));
         (void)hipModuleUnload(e->jit_module);
@@ -1719,6 +1942,7 @@ void af_engine_destroy(af_engine_t* e) {
     if (e->d_fb) (void)hipFree(e->d_fb);
     if (e->d_slot) (void)hipFree(e->d_slot);
     if (e->jit_module) (void)hipModuleUnload(e->jit_module);
+    if (e->flow_jit_module) (void)hipModuleUnload(e->flow_jit_module);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -1832,15 +2056,52 @@ int af_engine_gather(af_engine_t* e, void* comm, int world_size, const af_summar
         return fail(AF_ERR_INVALID, "local / gathered row lengths differ");
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
     RCCL_TRY(g_rccl.GroupStart());
+    // (an error inside the group must not leave it open: every later collective of this thread would be queued
+    // behind a GroupEnd that never comes -- record the first failure, always close the group, then report)
+    int first_err = 0;
+    const char* first_what = "";
     for (const Part& p : parts)
-        if (p.src && p.row_bytes)
-            RCCL_TRY(g_rccl.AllGather(p.src, p.dst, n * p.row_bytes, /* ncclInt8 */ 0, comm, e->stream));
-    RCCL_TRY(g_rccl.GroupEnd());
+        if (p.src && p.row_bytes && first_err == 0) {
+            first_err = g_rccl.AllGather(p.src, p.dst, n * p.row_bytes, /* ncclInt8 */ 0, comm, e->stream);
+            first_what = p.what;
+        }
+    const int end_err = g_rccl.GroupEnd();
+    if (first_err != 0)
+        return fail(AF_ERR_HIP, std::string("ncclAllGather(") + first_what + "): " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(first_err) : "rccl error"));
+    RCCL_TRY(end_err);
     HIP_TRY(hipEventRecord(e->ev1, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
     e->stats.gather_ms = ms;
+    return AF_OK;
+}
+
+int af_probe_store(int device, int pattern, uint32_t n_waves, uint64_t bytes_per_wave, uint32_t lanes, double* ms_out) {
+    if (n_waves == 0 || bytes_per_wave < 1024u || pattern < 0 || pattern > 2) return fail(AF_ERR_INVALID, "bad probe arguments");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return fail(AF_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= n_dev) return fail(AF_ERR_NO_DEVICE, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    const size_t words = (size_t)(bytes_per_wave / 4u) & ~size_t(3);
+    uint32_t* buf = nullptr;
+    HIP_TRY(hipMalloc((void**)&buf, (size_t)n_waves * words * 4u));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, 0));
+    if (pattern == 0) hipLaunchKernelGGL(af_probe_store_wide, dim3(n_waves), dim3(64), 0, 0, buf, words);
+    else if (pattern == 1) hipLaunchKernelGGL(af_probe_store_pairs16, dim3(n_waves), dim3(64), 0, 0, buf, words, lanes ? (lanes > 64u ? 64u : lanes) : 57u);
+    else hipLaunchKernelGGL(af_probe_store_rows48, dim3(n_waves), dim3(64), 0, 0, buf, words);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e1, 0));
+    HIP_TRY(hipDeviceSynchronize());
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (ms_out) *ms_out = ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(buf);
     return AF_OK;
 }
 

@@ -136,17 +136,19 @@ class Engine:
     def run(self, seeds: np.ndarray, overrides: Sequence[tuple[int, int, np.ndarray]], *,
             clock_ptr: int, clock_capacity: int, samples_ptr: int, tick_capacity: int, counts_ptr: int,
             draw_capacity: int = 0, specialise: bool = False, online_hist_ptr: int = 0, online_hist_bins: int = 0,
-            online_hist_max: float = 0.0, online_rps_ptr: int = 0, online_rps_buckets: int = 0) -> _abi.AfStats:
+            online_hist_max: float = 0.0, online_rps_ptr: int = 0, online_rps_buckets: int = 0,
+            specialise_build: bool = True) -> _abi.AfStats:
         """Launch the sweep; output pointers are DEVICE addresses owned by the caller.
 
         ``specialise``: build (or fetch from the cache) kernels with this plan's shape as compile-time
-        constants and use them for this sweep (asyncflow_amd/jit.py; worth it for long sweeps).
+        constants and use them for this sweep (asyncflow_amd/jit.py; worth it for long sweeps);
+        ``specialise_build=False``: only from the cache, never a hipcc run.
         """
         sweep, out, _keep = self._sweep_structs(seeds, overrides, clock_ptr, clock_capacity, samples_ptr, tick_capacity,
                                                 counts_ptr, draw_capacity, online_hist_ptr, online_hist_bins,
                                                 online_hist_max, online_rps_ptr, online_rps_buckets)
         if specialise:
-            self._specialise(sweep, out)
+            self._specialise(sweep, out, build=specialise_build)
         _check(self._lib, self._lib.af_engine_run(self._h, C.byref(sweep), C.byref(out)), "af_engine_run")
         return self.stats()
 
@@ -164,7 +166,7 @@ class Engine:
                                                 defaults["online_rps_ptr"], defaults["online_rps_buckets"])
         self._specialise(sweep, out)
 
-    def _specialise(self, sweep: _abi.AfSweep, out: _abi.AfOutputs) -> None:
+    def _specialise(self, sweep: _abi.AfSweep, out: _abi.AfOutputs, build: bool = True) -> None:
         import warnings
 
         from . import jit
@@ -176,8 +178,10 @@ class Engine:
         if spec == self._jit_spec:
             return
         try:
-            image = jit.code_object(spec.decode())
+            image = jit.code_object(spec.decode(), build=build)
         except jit.JitUnavailableError as exc:      # not an error: the generic kernels do the same job
+            if not build:
+                return
             warnings.warn(f"plan-specialised kernels unavailable, using the generic ones: {exc}", RuntimeWarning,
                           stacklevel=3)
             return

@@ -1,10 +1,12 @@
 """Plan-specialised kernels: compile csrc/engine.hip once more with the plan's shape baked in.
 
-The shared library ships generic next-event kernels.  For long sweeps it pays to build the same
-source again with the plan's constants as ``-D`` flags (``af_engine_jit_spec`` produces them): state
-offsets become instruction immediates, loops over edges / servers / series unroll, branches on the
-plan's shape disappear -- about 8 % less kernel time on the 10 000-replica LB-2 sweep.  Results are
-bit-identical (tests/test_gpu_parity.py).
+The shared library ships generic kernels.  For long sweeps it pays to build the same source again
+with the plan's constants as ``-D`` flags (``af_engine_jit_spec`` produces them for whatever the sweep
+would launch): the stage-parallel kernel as ONE entry point ``af_flow_jit`` (instantiation, plan shape,
+horizon / tick constants and the whole LDS layout as immediates: its ~100 wave-uniform launch
+arguments no longer spill through VGPR lanes), or the next-event kernels as ``af_jit_lean /
+af_jit_order3 / af_jit_order2`` (state offsets become instruction immediates, loops over edges /
+servers / series unroll).  Results are bit-identical (tests/test_gpu_parity.py, tests/test_gpu_flow.py).
 
 One ``hipcc --genco`` call (~4 s) per distinct spec; code objects are cached in
 ``$ASYNCFLOW_JIT_CACHE`` (default ``asyncflow_amd/csrc/_jit/``; ``~/.cache/asyncflow_amd/jit`` when the
@@ -60,14 +62,19 @@ def _writable_cache_dir() -> Path:
     raise JitUnavailableError(msg)
 
 
-def code_object(spec: str) -> bytes:
-    """The code object for ``spec`` (the ``-D`` flags from ``af_engine_jit_spec``), built on demand."""
+def code_object(spec: str, build: bool = True) -> bytes:
+    """The code object for ``spec`` (the ``-D`` flags from ``af_engine_jit_spec``), built on demand.
+
+    ``build=False``: only a cached object is returned (a sweep too short to repay a hipcc run still
+    takes the specialised kernels when an earlier, longer one left them in the cache)."""
     key = hashlib.sha1((_sources_digest() + "\n" + spec + "\n" + " ".join(_FLAGS)).encode()).hexdigest()
     for cand in (CACHE_DIR, _FALLBACK_CACHE_DIR):
         try:
             return (cand / f"{key}.hsaco").read_bytes()
         except OSError:
             continue
+    if not build:
+        raise JitUnavailableError("not in the cache (and this sweep is too short to repay a build)")
     try:
         hipcc = hipcc_path()
     except RuntimeError as exc:

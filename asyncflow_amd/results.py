@@ -212,6 +212,8 @@ class BatchedResults:
         #: kernel-side summary (SimulationRunner(online_summary=...)): int32 [n, bins] / [n, floor(T)] on the device
         self.online_hist, self.online_rps, self.online_hist_max = online_hist, online_rps, float(online_hist_max)
         self._summ_engine: Any = None      # one af_engine_t serves every summary() call of this object
+        #: '' when the stage-parallel kernel ran the plan, else why the next-event kernels did (Engine.flow_reason())
+        self.flow_reason: str = ""
 
     def close(self) -> None:
         """Release the analyzer engine kept by :meth:`summary` (also done on garbage collection)."""
@@ -376,7 +378,9 @@ class BatchedResults:
             cols[f"param:{k}"] = np.asarray(v, dtype=np.float64)
         for name, slot in (("generated", _abi.CNT_GENERATED), ("completed", _abi.CNT_COMPLETED),
                            ("dropped", _abi.CNT_DROPPED), ("request_events", _abi.CNT_EVENTS),
-                           ("ticks", _abi.CNT_TICKS), ("flags", _abi.CNT_FLAGS), ("max_live", _abi.CNT_MAX_LIVE)):
+                           ("ticks", _abi.CNT_TICKS), ("flags", _abi.CNT_FLAGS)):
+            # (counts[CNT_MAX_LIVE] is a diagnostic of the next-event kernels only -- the stage-parallel kernel writes 0 --
+            # and is not part of the on-disk summary: one sweep may mix both paths)
             cols[name] = self.counts[:, slot].copy()
         stats = summ["stats"].cpu().numpy()
         for j, k in enumerate(LATENCY_KEYS):
@@ -477,6 +481,61 @@ class ShardedResults:
             self.counts[ix] = shards[k].counts
             self.seeds[ix] = shards[k].seeds
         self.kernel_ms = max(s.kernel_ms for s in shards)
+        self.flow_reason = shards[0].flow_reason
+        #: per-scenario parameter columns, in the order of the original sweep
+        self.overrides: dict[str, np.ndarray] = {}
+        for key in shards[0].overrides:
+            col = np.zeros(n, dtype=np.float64)
+            for k, ix in enumerate(index):
+                col[ix] = shards[k].overrides[key]
+            self.overrides[key] = col
+
+    @property
+    def engine_stats(self) -> list[_abi.AfStats]:
+        """One ``af_stats_t`` per shard (per device), in shard order."""
+        return [s.engine_stats for s in self.shards]
+
+    def series_names(self) -> list[str]:
+        return self.shards[0].series_names()
+
+    def decode_series_max(self, words: np.ndarray) -> np.ndarray:
+        return self.shards[0].decode_series_max(words)
+
+    def save_summary(self, path: str, **kw: Any) -> dict[str, np.ndarray]:
+        """:meth:`BatchedResults.save_summary` over every shard: the shards' columns are merged behind the indices of
+        the original sweep and written once (``.npz`` / ``.parquet``)."""
+        import tempfile
+
+        if kw.get("hist_bins", 256) and kw.get("hist_max") is None:      # one histogram range for the whole sweep
+            mx = 0.0
+            for s in self.shards:
+                st = s.summary(rps=False)["stats"].cpu().numpy()[:, 7]
+                mx = max(mx, float(np.nanmax(st)) if np.isfinite(st).any() else 0.0)
+            kw["hist_max"] = mx * 1.25 or 1.0
+        n = len(self)
+        cols: dict[str, np.ndarray] = {}
+        with tempfile.TemporaryDirectory() as tmp:
+            for k, (s, ix) in enumerate(zip(self.shards, self.index)):
+                part = s.save_summary(f"{tmp}/shard{k}.npz", **kw)
+                for name, v in part.items():
+                    if v.shape[:1] == (len(ix),) and name not in ("latency_hist_edges", "series_names"):
+                        if name not in cols:
+                            cols[name] = np.zeros((n, *v.shape[1:]), dtype=v.dtype)
+                        cols[name][ix] = v
+                    else:
+                        cols[name] = v
+        path = str(path)
+        if path.endswith(".parquet"):
+            import pyarrow as pa
+            import pyarrow.parquet as pq
+
+            table = {k: (pa.array(list(v)) if v.ndim == 2 and v.shape[0] == n else pa.array(v))
+                     for k, v in cols.items() if v.shape[:1] == (n,)}
+            meta = {k: ",".join(map(str, v.tolist())) for k, v in cols.items() if v.shape[:1] != (n,)}
+            pq.write_table(pa.table(table).replace_schema_metadata(meta), path)
+        else:
+            np.savez_compressed(path, **cols)
+        return cols
 
     def __len__(self) -> int:
         return int(self.counts.shape[0])

@@ -158,8 +158,10 @@ class SimulationRunner:
         #: several timed events; None: start lean, hand such scenarios over, and remember (per
         #: payload, in this process) that this topology produces them
         self.expect_shared_instants = expect_shared_instants
-        #: build plan-specialised kernels (asyncflow_amd/jit.py, ~4 s once per plan shape, cached on disk):
-        #: None = when the sweep is expected to process more than 5e8 request-events
+        #: plan-specialised kernels (asyncflow_amd/jit.py, ~3 s of hipcc once per plan shape, cached on disk):
+        #: True = build them, False = the library's generic kernels, None = take them from the cache when an earlier
+        #: sweep left them there and build only when the sweep is long enough to repay it (> 1e9 request-events on the
+        #: next-event kernels, > 5e10 on the stage-parallel kernel)
         self.specialise = specialise
         #: stage-parallel kernel (one wave per scenario, 64 requests per step) for plans in its range
         #: (Engine.flow_reason()); False = always the next-event kernels.  Results are bit-identical.
@@ -198,9 +200,9 @@ class SimulationRunner:
         clock_cap = int(self.clock_capacity or self.plan.clock_capacity(users_max, rpm_max))
         return cap, fifo, clock_cap
 
-    def _want_specialised(self, n: int, clock_cap: int) -> bool:
+    def _want_specialised(self, n: int, clock_cap: int, on_flow_kernel: bool = False) -> bool:
         # ~7 request-events per completed request; clock_cap bounds the completions of one scenario
-        return 7.0 * clock_cap * n > 5e8 * 2.0
+        return 7.0 * clock_cap * n > (5e10 if on_flow_kernel else 1e9)
 
     def _plan_key(self) -> str:
         import hashlib
@@ -249,10 +251,14 @@ class SimulationRunner:
         """Lower once, launch the HIP kernel over every scenario, return results."""
         import torch
 
-        if self.devices is not None and (len(self.devices) > 1 or self.device is None):
-            if len(self.devices) > 1:
+        if self.devices is not None:
+            if self.device is not None and int(self.device) not in self.devices:
+                msg = f"device={self.device} is not one of devices={self.devices}: pass one or the other"
+                raise ValueError(msg)
+            if len(self.devices) > 1 and int(self.seeds.size) > 1:
                 return self._run_sharded()
-            self.device = self.devices[0]
+            if self.device is None:          # one scenario (or one device): nothing to deal out
+                self.device = self.devices[0]
 
         if not torch.cuda.is_available():
             from .engine import EngineUnavailableError
@@ -300,27 +306,37 @@ class SimulationRunner:
                 tick_capacity=ticks,
                 counts_ptr=counts.data_ptr(),
                 draw_capacity=clock_cap,
-                specialise=self._want_specialised(n, clock_cap) if self.specialise is None else bool(self.specialise),
+                specialise=True if self.specialise is None else bool(self.specialise),
+                specialise_build=(self._want_specialised(n, clock_cap, self.flow and not eng.flow_reason())
+                                  if self.specialise is None else True),
                 online_hist_ptr=online_hist.data_ptr() if online_hist is not None else 0, online_hist_bins=o_bins,
                 online_hist_max=o_max,
                 online_rps_ptr=online_rps.data_ptr() if online_rps is not None and o_buckets else 0,
                 online_rps_buckets=o_buckets,
             )
+            flow_reason = eng.flow_reason() if self.flow else "flow=False"
             eng.close()
             if int(stats.shared_instant_scenarios) > 0:
                 _SHARED_INSTANTS_SEEN[self._plan_key()] = True
             res = BatchedResults(self.plan, self.seeds, counts, clock, samples, stats,
                                  time.perf_counter() - t0, {k: v for _, _, v, k in overrides},
                                  online_hist=online_hist, online_rps=online_rps, online_hist_max=o_max)
+            res.flow_reason = flow_reason
             over = int(np.bitwise_or.reduce(res.flags)) & _abi.FATAL_FLAGS
             if not over or attempt == 3 or not self.auto_grow:
                 break
             # capacities are estimates (Little's law); overflow is flagged by the
-            # kernel, never silent -> grow the overflowing pool and run again.
-            if over & (_abi.FLAG_POOL_OVERFLOW | _abi.FLAG_FIFO_OVERFLOW):
-                if cap >= _abi.MAX_REQUEST_CAPACITY and fifo >= _abi.MAX_FIFO_CAPACITY:
-                    break           # both pools at their real maxima: raise_on_overflow() below reports it
-                cap, fifo = min(_abi.MAX_REQUEST_CAPACITY, cap * 4), _fifo_pow2(fifo * 4)
+            # kernel, never silent -> grow the overflowing pool and run again.  A pool that overflowed at its real
+            # maximum cannot be helped by another run: raise_on_overflow() below reports it.
+            if (over & _abi.FLAG_POOL_OVERFLOW and cap >= _abi.MAX_REQUEST_CAPACITY) or \
+                    (over & _abi.FLAG_FIFO_OVERFLOW and fifo >= _abi.MAX_FIFO_CAPACITY):
+                break
+            if over & _abi.FLAG_POOL_OVERFLOW:
+                cap = min(_abi.MAX_REQUEST_CAPACITY, cap * 4)
+            if over & _abi.FLAG_FIFO_OVERFLOW:
+                # (the wait queues hold request slots: a FIFO larger than the pool is never needed)
+                fifo = _fifo_pow2(fifo * 4)
+                cap = min(_abi.MAX_REQUEST_CAPACITY, max(cap, fifo))
             if over & (_abi.FLAG_CLOCK_OVERFLOW | _abi.FLAG_DRAW_OVERFLOW):
                 clock_cap *= 2
             warnings.warn(

@@ -265,6 +265,48 @@ def cpu_baseline(payload: dict, seed_base: int, label: str, budget_s: float = 8.
     return out
 
 
+def parity_spot_check(sw: "RankSweep", k: int = 4) -> dict:
+    """AFTER the timed region, outside every timing: k scenarios of the batch that was just benched -- the first, the
+    last and evenly spaced ones of the slice still resident in HBM -- against the CPU oracle (oracle/des_oracle.c, the
+    CHECKER, pinned on the reference's fixtures): counts, every (start, finish) pair bit for bit, every sample.
+    Makes the headline line self-certifying: `ok` false = the benched kernel did not compute the reference's results."""
+    from asyncflow_amd import _abi
+    from asyncflow_amd.plan import lower
+    from oracle import oracle_lib as ol
+
+    code_name = {v: name for name, v in _abi.PARAM_CODES.items()}
+    lo = (sw.n_slices - 1) * sw.slice
+    hi = sw.n
+    m = hi - lo
+    picks = sorted({lo + int(round(j * (m - 1) / max(k - 1, 1))) for j in range(min(k, m))})
+    counts = sw.counts.cpu().numpy().view(np.uint32)
+    bad: list[str] = []
+    t0 = time.perf_counter()
+    for i in picks:
+        plan = lower(sw.plan.payload)
+        ol.apply_overrides(plan, {(code_name[c], idx): float(col[i]) for c, idx, col, _ in sw.over})
+        want = ol.simulate(plan, int(sw.seeds[i]), clock_capacity=sw.clock_cap, want_clock=sw.clock is not None,
+                           want_samples=sw.samples is not None)
+        if not np.array_equal(counts[i, :5].astype(np.uint64), want.counts[:5]):
+            bad.append(f"scenario {i}: counts {counts[i, :5].tolist()} != {want.counts[:5].tolist()}")
+            continue
+        n_done = int(counts[i, _abi.CNT_COMPLETED])
+        if sw.clock is not None:
+            got = sw.clock[i - lo, :n_done].cpu().numpy()
+            if not np.array_equal(got.view(np.uint64), want.clock.view(np.uint64)):
+                bad.append(f"scenario {i}: rqs_clock differs")
+        if sw.samples is not None:
+            ticks = int(counts[i, _abi.CNT_TICKS])
+            got = sw.samples[i - lo, :ticks, : sw.plan.n_series].cpu().numpy().view(np.uint32).T
+            if not np.array_equal(got, want.samples):
+                bad.append(f"scenario {i}: sampled series differ")
+    return {"scenarios": len(picks), "indices": picks, "ok": not bad, "mismatches": bad[:4],
+            "compared": "counts[:5]" + (", rqs_clock (bit patterns)" if sw.clock is not None else "")
+                        + (", every sampled series" if sw.samples is not None else ""),
+            "checker": "oracle/des_oracle.c (CPU restatement pinned on the reference's fixtures), after the timed region",
+            "check_s": time.perf_counter() - t0}
+
+
 # --------------------------------------------------------------------------- #
 # the rank's sweep: engine + HBM-resident outputs, run as slices                 #
 # --------------------------------------------------------------------------- #
@@ -334,11 +376,15 @@ class RankSweep:
         return seeds, over, kw
 
     def prepare(self) -> None:
-        # plan-specialised builds exist for the next-event kernels only; when the stage-parallel kernel runs the plan
-        # (AOT instantiations in the library) nothing is compiled at run time -- hand-backs use the generic kernels
-        if self.specialise and (self.args.no_flow or self.flow_reason):
+        # plan-specialised build of what the sweep launches (asyncflow_amd/jit.py): the stage-parallel kernel when it runs the
+        # plan (one entry point, ~3 s of hipcc once per plan shape and layout, then a cache hit), else the next-event
+        # kernels; hand-backs use the library's generic kernels
+        self.jit_build_s = 0.0
+        if self.specialise:
             seeds, over, kw = self._slice_args(0, min(self.slice, self.n))
+            t0 = time.perf_counter()
             self.eng.prepare(seeds, over, **kw)     # hipcc run or cache hit: never inside the timed region
+            self.jit_build_s = time.perf_counter() - t0
 
     def step(self) -> dict:
         """One pass over the rank's batch; returns the engine's own timings summed over the slices."""
@@ -350,7 +396,7 @@ class RankSweep:
             if self.online:
                 self.o_hist.zero_()
                 self.o_rps.zero_()
-            st = self.eng.run(seeds, over, specialise=self.specialise and bool(self.args.no_flow or self.flow_reason), **kw)
+            st = self.eng.run(seeds, over, specialise=self.specialise, **kw)
             acc["kernel_ms"] += float(st.kernel_ms)
             acc["pregen_ms"] += float(st.pregen_ms)
             acc["shared"] += int(st.shared_instant_scenarios)
@@ -448,6 +494,7 @@ def main() -> int:  # noqa: C901, PLR0912, PLR0915
                     help="scenarios per GPU (configs 1-3) or in total (configs 4, 5); 0 = the BASELINE size")
     ap.add_argument("--horizon", type=int, default=0, help="simulated seconds (0 = the BASELINE horizon)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the post-run oracle comparison of 4 benched scenarios")
     ap.add_argument("--no-series", action="store_true", help="do not store the sampled series")
     ap.add_argument("--lanes", type=int, default=0, help="scenario lanes per wave of the sequential kernel (0 = engine default)")
     ap.add_argument("--global-state", action="store_true", help="keep per-scenario state in HBM")
@@ -618,11 +665,13 @@ def main() -> int:  # noqa: C901, PLR0912, PLR0915
                 "flow": {"scenarios": accs[-1]["flow_scen"], "list_entries": rs["flow_list_entries"], "ring_rows": rs["flow_ring_rows"],
                          "lds_bytes_per_wave": rs["flow_lds_bytes"],
                          "handed_back": dict(zip(("total", "tie", "list", "ring", "ram"), accs[-1]["flow_fallback"])),
+                         "plan_specialised_kernel": bool(flow_on and accs[-1]["jit"]), "jit_fallbacks": int(accs[-1]["jit_fallbacks"]),
+                         "jit_build_or_cache_load_s": sw.jit_build_s,
                          "not_used_because": sw.flow_reason or None},
                 "next_event": {"state": "LDS" if rs["state_in_lds"] else "HBM", "request_capacity": rs["request_capacity"],
                                "lds_bytes_per_wave": rs["lds_bytes_per_wave"], "lanes_per_wave": rs["lanes_per_wave"],
                                "waves": rs["waves"], "shared_instant_scenarios": int(accs[-1]["shared"]),
-                               "plan_specialised_kernels": bool(accs[-1]["jit"]), "jit_fallbacks": int(accs[-1]["jit_fallbacks"])},
+                               "plan_specialised_kernels": bool(accs[-1]["jit"]) and not flow_on, "jit_fallbacks": int(accs[-1]["jit_fallbacks"])},
             },
             "events_per_step": events_total,
             "per_gpu_value": total_events / elapsed / world,
@@ -658,13 +707,18 @@ def main() -> int:  # noqa: C901, PLR0912, PLR0915
                 "note": "achieved = SURVEY 8d's algorithmic bytes (80 B of per-event state traffic + outputs, a state-in-HBM model) / "
                         "the dominant kernel's time; the kernel keeps that state in LDS, so the bytes it really moves are "
                         "`traffic` (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE) and `frac_traffic` is the fraction of the HBM peak it uses",
-                "kernel": "af_flow_kernel" if flow_on else
+                "kernel": ("af_flow_jit (plan-specialised build of af_flow_kernel)" if accs[-1]["jit"] else "af_flow_kernel") if flow_on else
                           "af_jit_lean (plan-specialised build of af_des_kernel)" if accs[-1]["jit"] else "af_des_kernel",
                 "kernel_ms": float(np.mean([a["flow_ms"] for a in accs])) if flow_on else k_ms,
             },
         }
         if base is not None:
             line["cpu_baseline"] = base
+        if not args.no_parity_check:
+            try:
+                line["parity_spot_check"] = parity_spot_check(sw)
+            except Exception as exc:  # noqa: BLE001 - a broken checker build must not eat the measured line; it says so
+                line["parity_spot_check"] = {"scenarios": 0, "ok": None, "why": f"{type(exc).__name__}: {exc}"}
         # HBM bytes per launch of the dominant kernel, from the committed PMC passes of THIS command
         # (rocprofv3 cannot run inside the timed bench): newest profiles/rNN/**/traffic.json
         if args.config == 2 and n == 10_000 and not args.no_series and wl["horizon"] == 600:

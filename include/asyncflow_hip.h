@@ -391,6 +391,18 @@ int af_abi_version(void);
 int af_probe_math(int device, int kind, uint64_t seed, const double* in, const double* in2,
                   double* out, size_t n);
 
+/* Measurement probe (device): one launch of n_waves wavefronts, each filling its own contiguous region of
+ * bytes_per_wave bytes exactly once with the store shape of
+ *   pattern 0: wide coalesced stores (16 B per lane, 1 KB per instruction) -- the shape rocprofv3's WRITE_SIZE is
+ *              calibrated for (MI355X_MICROARCH.md);
+ *   pattern 1: the stage-parallel kernel's rqs_clock store: 16 B per lane over `lanes` consecutive lanes (0 = 57,
+ *              the average batch of BASELINE config 2), batch after batch;
+ *   pattern 2: its sampled-series store for a 12-word pitch: 4 B per lane over 60 lanes = five 48-byte rows.
+ * Run under `rocprofv3 --pmc WRITE_SIZE` (scripts/calibrate_write_size.py) it tells how many counter units a byte
+ * of each shape costs, i.e. whether WRITE_SIZE above the output size is traffic or counting granularity.
+ * ms_out (may be NULL): HIP-event time of the launch. */
+int af_probe_store(int device, int pattern, uint32_t n_waves, uint64_t bytes_per_wave, uint32_t lanes, double* ms_out);
+
 #ifdef __cplusplus
 }
 #endif

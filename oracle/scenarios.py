@@ -412,4 +412,6 @@ GOLDEN = {
     "fanout8_t20": (lambda: fanout8(users=120, horizon=20), 11),
     "stress_mixed_t40": (lambda: stress_mixed(40), 3),
     "overload_t30": (lambda: overload(30), 5),
+    # BASELINE config 2 at its FULL horizon, scenario 0 of the benched batch (seed 0x5EED0000): 75 861 completions
+    "lb2_rr_t600": (lambda: lb_two_servers(horizon=600), 0x5EED0000),
 }

@@ -293,6 +293,24 @@ def test_a_delivery_that_does_not_advance_the_clock_stays_on_the_flow_kernel():
     res = _runner(lb_two_servers(), seeds=[seed, seed + 1]).run()
     assert res.engine_stats.flow_scenarios == 2 and res.engine_stats.flow_fallback == 0
     _assert_scenario(res[0], ol.simulate(lower(lb_two_servers()), seed))
+    _assert_scenario(res[1], ol.simulate(lower(lb_two_servers()), seed + 1))
+
+
+def test_config2_replicas_at_full_horizon_match_the_oracle_bit_for_bit():
+    """BASELINE config 2 at its real size per scenario (T = 600 s, ~76 000 completions, 11 999 ticks): replicas from the
+    head, the middle and the end of the benched seed range 0x5EED0000 + [0, 10 000), every (start, finish) pair and every
+    sample against the oracle, and scenario 0 against what the UNMODIFIED reference produced (tests/golden/lb2_rr_t600)."""
+    picks = np.array([0, 1, 2, 3, 63, 64, 4095, 4096, 5000, 8191, 9998, 9999], dtype=np.uint64)
+    seeds = BASELINE_SEED_BASE[2] + picks
+    payload = lb_two_servers()
+    res = _runner(payload, seeds=seeds).run()
+    assert res.engine_stats.flow_scenarios == len(seeds) and res.engine_stats.flow_fallback == 0
+    plan = lower(payload)
+    for i, s in enumerate(seeds):
+        _assert_scenario(res[i], ol.simulate(plan, int(s)), f"replica {int(picks[i])}")
+    fx = np.load(GOLDEN_DIR / "lb2_rr_t600.npz", allow_pickle=False)
+    assert int(fx["seed"]) == int(seeds[0])
+    assert np.array_equal(res[0].rqs_clock, fx["clock"]) and np.array_equal(res[0]._samples, fx["samples"])  # noqa: SLF001
 
 
 @pytest.mark.parametrize("per_wave", [4, 5, 8])
@@ -352,6 +370,39 @@ def test_least_connections_runs_on_the_flow_kernel():
         res = _runner(payload, seeds=seeds).run()
         assert res.engine_stats.flow_scenarios == 64 and res.engine_stats.flow_to_next_event == 0
         _same_batches(res, _runner(payload, seeds=seeds, flow=False).run())
+
+
+def test_plan_specialised_flow_kernel_gives_identical_results():
+    """asyncflow_amd/jit.py: af_flow_kernel compiled once more with the plan's shape, the horizon / tick constants and the
+    LDS layout as immediates (`af_flow_jit`), for every kind of instantiation the launcher picks: plain lean (LB-2),
+    marks + far (injected events), 128-entry lists with far edges (fan-out), least connections, per-scenario parameter
+    columns (the blob is still patched per scenario), no sampled series, kernel-side summary."""
+    cases = [
+        (lb_two_servers(horizon=30), {}),
+        (lb_with_events(users=200, horizon=40, scale=0.05), {}),
+        (fanout8(horizon=30), {}),
+        (lb_two_servers(horizon=30, algo="least_connection"), {}),
+        (single_server(horizon=40), {"collect_samples": False}),
+        (lb_two_servers(horizon=20), {"online_summary": {"hist_bins": 512, "hist_max": 0.256}}),
+        (lb_two_servers(horizon=20), {"sweep": {"rqs_input.avg_active_users.mean": np.linspace(20.0, 700.0, 70),
+                                                "topology_graph.edges[*].latency.mean": np.linspace(0.0005, 0.02, 70)}}),
+    ]
+    for k, (payload, kw) in enumerate(cases):
+        seeds = np.arange(70, dtype=np.uint64) + 31 + 100 * k
+        generic = _runner(payload, seeds=seeds, specialise=False, **kw).run()
+        special = _runner(payload, seeds=seeds, specialise=True, **kw).run()
+        assert generic.engine_stats.specialised_launches == 0, k
+        assert special.engine_stats.specialised_launches >= 1 and special.engine_stats.jit_fallbacks == 0, k
+        assert special.engine_stats.flow_scenarios == 70
+        assert np.array_equal(generic.counts, special.counts), k
+        for i in (0, 33, 69):
+            assert np.array_equal(generic[i].rqs_clock, special[i].rqs_clock), (k, i)
+            if kw.get("collect_samples", True):
+                assert np.array_equal(generic[i]._samples, special[i]._samples), (k, i)  # noqa: SLF001
+        if "online_summary" in kw:
+            assert np.array_equal(generic.online_hist.cpu().numpy(), special.online_hist.cpu().numpy())
+        if "sweep" not in kw and kw.get("collect_samples", True):
+            _assert_scenario(special[5], ol.simulate(lower(payload), int(seeds[5])), f"case {k}")
 
 
 def test_far_and_near_lean_instantiations_agree(monkeypatch):

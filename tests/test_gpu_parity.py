@@ -1,8 +1,10 @@
 """Parity tests proper: the HIP engine (through the C ABI) vs the oracle, on a real MI355X.
 
 This file pins the sequential next-event kernels (af_core.hpp; `flow=False`): they run every plan and
-take over whatever the stage-parallel kernel hands back.  tests/test_gpu_flow.py pins the
-stage-parallel kernel and the hand-over between the two."""
+take over whatever the stage-parallel kernel hands back.  The reference-generated fixtures are asserted on
+BOTH kernel families (`flow` parametrised): the stage-parallel kernel -- the one bench.py times -- is compared
+with what the unmodified reference produced directly, not only through the oracle.  tests/test_gpu_flow.py
+pins the rest of the stage-parallel kernel and the hand-over between the two."""
 
 from __future__ import annotations
 
@@ -64,12 +66,22 @@ def test_device_math_matches_oracle_bit_for_bit():
 
 
 # ------------------------------------------------------------- golden fixtures
+@pytest.mark.parametrize("flow", [True, False], ids=["flow", "next-event"])
 @pytest.mark.parametrize("name", golden_names())
-def test_engine_reproduces_reference_fixtures(name):
+def test_engine_reproduces_reference_fixtures(name, flow):
+    """Every fixture written by the UNMODIFIED reference (oracle/make_golden.py) on both kernel families.  flow=True is
+    the engine's default path: af_flow_kernel for the feed-forward plans (lb2_rr_t30 / _t600, lb2_lc_t20, lb2_events_t60,
+    fanout8_t20, single_server_t30), its hand-over to the next-event kernels for the plans outside its range
+    (stress_mixed_t40, overload_t30: several endpoints per server, Poisson latencies)."""
     fx = np.load(GOLDEN_DIR / f"{name}.npz", allow_pickle=False)
     payload = json.loads(str(fx["payload_json"]))
     seed = int(fx["seed"])
-    res = _runner(payload, seeds=[seed, seed + 1, seed]).run()
+    res = _runner(payload, seeds=[seed, seed + 1, seed], flow=flow).run()
+    st = res.engine_stats
+    if flow and not res.flow_reason:
+        assert st.flow_scenarios == 3, "a feed-forward plan must run on the stage-parallel kernel"
+    else:
+        assert st.flow_scenarios == 0
     plan = lower(payload)
     want = ol.simulate(plan, seed)
     _assert_scenario(res[0], want)

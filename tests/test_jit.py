@@ -16,6 +16,31 @@ LB2_SPEC = (
 )
 
 
+# what af_engine_jit_spec writes for the BASELINE config-2 sweep on the stage-parallel kernel (af_flow_kernel<1, 0>, 64-entry
+# lists, a 32-row LDS tick ring: 9 512 B of LDS per wave)
+LB2_FLOW_SPEC = (
+    "-DAF_JIT=1 -DAF_FLOW_JIT=1 -DAF_FJ_IPL=1 -DAF_FJ_FEAT=0 -DAF_FJ_TOTAL_TIME=0x4082c00000000000ull "
+    "-DAF_FJ_PERIOD=0x3fa999999999999aull -DAF_FJ_INV_PERIOD=0x4034000000000000ull "
+    "-DAF_FJ_TICK_EPS=0x3e112e0be826d695ull -DAF_FJ_METRICS=15 -DAF_FJ_GEN_EDGE=0 -DAF_FJ_CLIENT_EDGE=1 "
+    "-DAF_FJ_N_EDGES=6 -DAF_FJ_N_SERVERS=2 -DAF_FJ_HAS_LB=1 -DAF_FJ_N_LB=2 -DAF_FJ_N_EMARKS=0 "
+    "-DAF_FJ_N_SMARKS=0 -DAF_FJ_LC=0 -DAF_FJ_MAX_PRE=0 -DAF_FJ_MAX_CPU=1 -DAF_FJ_MAX_POST=1 -DAF_FJ_OFF_EDGE=0 "
+    "-DAF_FJ_OFF_SRV=24 -DAF_FJ_OFF_EP=28 -DAF_FJ_OFF_ROW=32 -DAF_FJ_OFF_EMARK=50 -DAF_FJ_OFF_SMARK=50 "
+    "-DAF_FJ_OFF_LB=50 -DAF_FJ_BLOB_BYTES=416 -DAF_FJ_N_TICKS=11999 -DAF_FJ_HAS_CLOCK=1 -DAF_FJ_HAS_SAMPLES=1 "
+    "-DAF_FJ_HAS_ONLINE=0 -DAF_FJ_HAS_OVR=0 "
+    "-DAF_FJ_LAYOUT=64,32,16,16,1,12,2,0,0,512,528,544,704,768,544,864,866,898,945,1137,64,64,64,64,0,128,256,384,840"
+)
+
+
+def test_specialised_flow_kernel_builds_with_one_entry_point(tmp_path, monkeypatch):
+    monkeypatch.setattr(jit, "CACHE_DIR", tmp_path)
+    image = jit.code_object(LB2_FLOW_SPEC)
+    assert image.startswith(b"__CLANG_OFFLOAD_BUNDLE__") and b"gfx950" in image[:4096]
+    assert b"af_flow_jit" in image and b"af_jit_lean" not in image
+    with pytest.raises(jit.JitUnavailableError, match="not in the cache"):
+        jit.code_object(LB2_FLOW_SPEC.replace("-DAF_FJ_IPL=1", "-DAF_FJ_IPL=2"), build=False)
+    assert jit.code_object(LB2_FLOW_SPEC, build=False) == image     # cache hit without a build
+
+
 def test_specialised_code_object_builds_caches_and_exports_the_three_entry_points(tmp_path, monkeypatch):
     monkeypatch.setattr(jit, "CACHE_DIR", tmp_path)
     image = jit.code_object(LB2_SPEC)
