@@ -161,7 +161,11 @@ struct FlowArgs {
     double online_hist_scale;
     uint32_t* n_fallback;   // [5]: scenarios handed over, then by reason (tie, list, ring, ram)
     const uint32_t* scen_map;  // second-chance launch: wave j simulates scenario scen_map[j] (null = j)
+    unsigned long long* prof;  // FEAT_PROF builds: [n_scen][kProfSections] shader-clock cycles per section of run()
 };
+// FEAT_PROF: where a wave's time goes (measurement builds only: AF_FLOW_PROF)
+enum : uint32_t { PROF_SETUP, PROF_GEN, PROF_SELECT, PROF_SERIES_RECV, PROF_STATION, PROF_SERVERS, PROF_SERVER_SERIES, PROF_DRAW, PROF_SEND_SERIES,
+                  PROF_APPEND, PROF_COMPLETE, PROF_FLUSH, kProfSections = 16u };
 
 // ---- the algorithm, written against a wave backend W ---------------------------------------------
 //   W::lane()                       0..63
@@ -194,13 +198,27 @@ struct FlowArgs {
 //   FEAT_FAR       edges slower than the LDS tick ring reaches: the sender enters only the send of such a message and
 //                  marks it, the receiving station enters the delivery (file header, "Sampled series").  Without it the
 //                  sender enters both ends and a delivery beyond the ring hands the scenario back.
+//   FEAT_PROF      measurement builds only: the wave's shader-clock time per section of run() (FlowArgs::prof)
 enum : uint32_t { FEAT_MARKS = 1u, FEAT_ONLINE = 2u, FEAT_HBM_RING = 4u, FEAT_FAR = 64u, FEAT_ALL = 7u | FEAT_FAR, FEAT_TIEBREAK = 8u,
-                  FEAT_BIGLIST = 16u, FEAT_LC = 32u };
+                  FEAT_BIGLIST = 16u, FEAT_LC = 32u, FEAT_PROF = 128u };
 template <class W, uint32_t IPL = 1u, uint32_t FEAT = FEAT_ALL>
 struct Flow {
     static constexpr bool kMarks = (FEAT & FEAT_MARKS) != 0u, kOnline = (FEAT & FEAT_ONLINE) != 0u,
                           kHbmRing = (FEAT & FEAT_HBM_RING) != 0u, kTieBreak = (FEAT & FEAT_TIEBREAK) != 0u,
-                          kBig = (FEAT & FEAT_BIGLIST) != 0u, kLC = (FEAT & FEAT_LC) != 0u, kFar = (FEAT & FEAT_FAR) != 0u;
+                          kBig = (FEAT & FEAT_BIGLIST) != 0u, kLC = (FEAT & FEAT_LC) != 0u, kFar = (FEAT & FEAT_FAR) != 0u,
+                          kProf = (FEAT & FEAT_PROF) != 0u;
+    // FEAT_PROF: the time since the previous mark belongs to `section` (marks sit at the END of a section, in
+    // wave-uniform control flow, with a compile-time section: the accumulators stay in scalar registers)
+    unsigned long long prof_t, prof_acc[kProfSections];
+    AF_CORE void prof(uint32_t section) {
+        if (kProf) {
+            const unsigned long long t = W::clock();
+#pragma unroll
+            for (uint32_t k = 0u; k < kProfSections; ++k)
+                if (k == section) prof_acc[k] += t - prof_t;
+            prof_t = t;
+        }
+    }
     const FlowArgs& A;
     AF_PLAN_AS uint64_t* blob;   // plan blob (LDS copy, patched)
     AF_PLAN_AS uint64_t* M;      // layout words behind it
@@ -301,16 +319,24 @@ struct Flow {
     }
 
     // ---- ticks ------------------------------------------------------------------------------------
-    // number of ticks strictly before x, clipped to n_ticks (tick k = 1.. at tick_t[k-1])
+    // number of ticks strictly before x, clipped to n_ticks (tick k = 1.. at tick_t[k-1]): floor(x / period) when x is
+    // safely between two ticks, else a look-up in the table of the collector's own tick times.
+    // (Measured, round 3: the same thing without the two early returns -- clamps and one predicate instead of exec-mask
+    // branches, so that the two rows of an interval are worked out side by side -- is SLOWER: 48.5 -> 50.1 ms on BASELINE
+    // config 2.  The selects it needs become v_cndmask on VCC, which this chip issues at ~12 cycles against 2.7 for the
+    // compare that feeds it: scripts/microbench/valu_cost.hip, profiles/r03/valu_cost.txt.)
     AF_CORE uint32_t tick_index(double x, bool flag_ties) {
         const uint32_t N = A.n_ticks;
         if (!(x > 0.0)) return 0u;
         const double q = x * A.inv_period;
         if (q >= (double)N + 1.0) return N;
-        uint32_t g = (uint32_t)q;
+        const uint32_t g = (uint32_t)q;
         const double frac = q - (double)g;
         if (frac > A.tick_eps && frac < 1.0 - A.tick_eps) return g < N ? g : N;   // safely between two ticks
-        if (g > N) g = N;                                                             // next to a tick: look it up
+        return tick_lookup(x, g < N ? g : N, flag_ties);                          // next to a tick
+    }
+    AF_CORE uint32_t tick_lookup(double x, uint32_t g, bool flag_ties) {
+        const uint32_t N = A.n_ticks;
         while (g < N && A.tick_t[g] < x) ++g;
         while (g > 0u && A.tick_t[g - 1u] >= x) --g;
         if (flag_ties && g < N && A.tick_t[g] == x) why |= FLOW_WHY_TIE;
@@ -332,21 +358,7 @@ struct Flow {
     // the counter of `series` is larger by w during [a, b)
     AF_CORE void add_interval(uint32_t series, double a, double b, int32_t w) {
         const uint32_t ia = tick_index(a, true), ib = tick_index(b, true);
-        if (ia == ib) return;
-        const uint32_t R = A.L.ring_rows, N = A.n_ticks < A.tick_cap ? A.n_ticks : A.tick_cap;
-        if (kHbmRing && R == 0u) {
-            if (ia < N) W::global_add(samples + (size_t)ia * A.L.pitch + series, (uint32_t)w);
-            if (ib < N) W::global_add(samples + (size_t)ib * A.L.pitch + series, (uint32_t)(-w));
-            return;
-        }
-        if (ia < N) {
-            if (ia - tick_base >= R) why |= FLOW_WHY_RING;
-            else W::lds_add((AF_PLAN_AS uint32_t*)(ring() + (ia & (R - 1u)) * A.L.pitch + series), (uint32_t)w);
-        }
-        if (ib < N) {
-            if (ib - tick_base >= R) why |= FLOW_WHY_RING;
-            else W::lds_add((AF_PLAN_AS uint32_t*)(ring() + (ib & (R - 1u)) * A.L.pitch + series), (uint32_t)(-w));
-        }
+        add_span(series, ia, ib, w);
     }
     // ... is larger by w between the events whose tick rows are ia and ib (nothing to enter when no tick lies between)
     AF_CORE void add_span(uint32_t series, uint32_t ia, uint32_t ib, int32_t w) {
@@ -509,15 +521,15 @@ struct Flow {
     // `pre`: the draws were made earlier (lb_pick_lc): `pre_transit` < 0 = dropped.
     // Sampled series, FEAT_FAR: `row_now` = tick row of `now` (worked out by the caller); `counted` = only the send was
     // entered in the edge's series, the receiving station enters the delivery.  Otherwise both ends are entered here.
-    AF_CORE bool edge_send(uint32_t e, uint32_t idx, double now, uint32_t row_now, double& key, bool& counted, bool pre = false,
-                           double pre_transit = 0.0) {
-        counted = false;
-        double transit = pre_transit;
+    // (two steps: send_draw -- dropped? transit time -- and, for the messages that were sent, send_finish)
+    AF_CORE bool send_draw(uint32_t e, uint32_t idx, double& transit, bool pre = false, double pre_transit = 0.0) {
+        transit = pre_transit;
         const bool sent = (kLC && pre) ? !(pre_transit < 0.0) : edge_draw(e, idx, transit);
-        if (!sent) {
-            drops += 1u;
-            return false;
-        }
+        if (!sent) drops += 1u;
+        return sent;
+    }
+    AF_CORE bool send_finish(uint32_t e, double now, uint32_t row_now, bool have_row, double transit, double& key, bool& counted) {
+        counted = false;
         const double spike = (kMarks && A.n_edge_marks != 0u) ? spike_at(e, now) : 0.0;
         key = now + (transit + spike);
         // A transit time that does not advance the f64 clock (an exponential draw below half an ulp of `now`, a normal
@@ -525,8 +537,8 @@ struct Flow {
         // if the next station has another event at that instant the equal keys are seen there.  A NEGATIVE delay
         // (spike residue after += / -=) raises in the reference (simpy: "Negative delay"): handed back.
         if (key < now) why |= FLOW_WHY_TIE;
-        if (!kFar) {
-            if (samples != nullptr) add_interval(e, now, key, 1);
+        if (!kFar) {   // (have_row: the server station worked the row of the send time out for its own intervals)
+            if (samples != nullptr) add_span(e, have_row ? row_now : tick_index(now, true), tick_index(key, true), 1);
         } else if (samples != nullptr) {   // (row_now: the caller needed it for the delivery it handled)
             const uint32_t ib = tick_index(key, true);
             if (ib != row_now) {
@@ -1219,6 +1231,11 @@ struct Flow {
         }
         W::sync();
 
+        if (kProf) {
+#pragma unroll
+            for (uint32_t k = 0u; k < kProfSections; ++k) prof_acc[k] = 0ull;
+            prof_t = W::clock();
+        }
         cursor = n_comp = tick_base = 0u;
         ev = drops = 0u;
         why = info = 0u;
@@ -1231,6 +1248,7 @@ struct Flow {
 
         // Every round walks the five stations in order.  The code of select() and of edge_send() exists ONCE
         // (the loop is not unrolled): the kernel stays small enough for the instruction cache.
+        prof(PROF_SETUP);
         for (;;) {
             uint32_t work = 0u;
             moved = false;
@@ -1240,7 +1258,15 @@ struct Flow {
             if (kFar) t_lim = (samples != nullptr && (!kHbmRing || A.L.ring_rows != 0u)) ? (double)(tick_base + A.L.win_rows) * A.sample_period : AF_INF;
             const double h_done_before = h3;
             double H_in = AF_INF, h_gen = AF_INF;
+            // (plan-specialised builds unroll the five stations: `st` becomes a constant in each copy -- list addresses fold,
+            // the select chains over nl0..nl3 / h0..h3 and their scratch copy disappear: 58.8 -> 49.2 ms on BASELINE config 2,
+            // 5 500 instructions = 36 KB of code.  The generic instantiations stay a loop: with run-time plan shapes the
+            // unrolled body was 13 000 instructions and fell out of the instruction cache)
+#if defined(AF_FLOW_JIT) && !defined(AF_FLOW_LOOP_STATIONS)
+#pragma unroll
+#else
 #pragma nounroll
+#endif
             for (uint32_t st = 0u; st < 5u; ++st) {
                 if (st == 2u && !A.has_lb) continue;
                 // ---- the station's batch: lane r < n_sel holds (key = event time, t0 = start time, aux)
@@ -1261,6 +1287,8 @@ struct Flow {
                 } else {
                     n_sel = select(st - 1u, H_in, st == 4u ? 64u : (kBig ? cap_of(nxt) : cap) - n_list_get(nxt), key, t0, aux);
                 }
+                if (st == 0u) prof(PROF_GEN);
+                else prof(PROF_SELECT);
                 const bool have = lane < n_sel;
                 if (have) ev += 1u;                       // one timed event per message: arrival / delivery
                 work += n_sel;
@@ -1273,6 +1301,7 @@ struct Flow {
                 if (kFar && series_on && have && (st <= 2u || cnt_in)) row = tick_index(key, true);
                 if (kFar && cnt_in) add_point(st == 1u ? A.gen_out_edge : st == 2u ? A.client_out_edge : st == 3u ? aux >> 8 : aux, row, -1);
                 // ---- what the station does with it: the out-edge, the message's index on it, the send time
+                prof(PROF_SERIES_RECV);
                 bool sending = have, pre = false;
                 uint32_t e = 0u, idx = 0u, tgt = 0u;
                 double ts = key, pre_tr = 0.0;
@@ -1315,6 +1344,7 @@ struct Flow {
                         }
                         W::sync();   // select()'s scratch is dead from here on: the segments reuse it
                         const SrvTimes r = servers_solve(have, sv, pos, key);
+                        prof(PROF_SERVERS);
                         if (have) {
                             const uint64_t meta = blob[A.off_srv + af::SREC * sv + 1u];
                             e = (uint32_t)(meta >> 16) & 0xFFFFu;
@@ -1324,13 +1354,9 @@ struct Flow {
                             ts = r.g;
                             // ready queue: waited for a core (server.py:215-225); leading / trailing I/O steps; RAM held from
                             // admission to the end (server.py:146-149, 270-273)
-                            if (!kFar && series_on) {
-                                if (r.s > r.b) add_interval(s0, r.b, r.s, 1);
-                                if (r.b > r.adm) add_interval(s0 + 1u, r.adm, r.b, 1);
-                                if (r.g > r.f) add_interval(s0 + 1u, r.f, r.g, 1);
-                                if (ram > 0.0) add_interval(s0 + 2u, r.adm, r.g, (int32_t)ram);
-                            }
-                            if (kFar && series_on) {   // (one tick row per distinct time: the send below starts at G's)
+                            // (round 3: also in the instantiations without FEAT_FAR, which used to call add_interval per
+                            // interval -- 12 tick rows per request instead of 10: 49.7 -> 48.5 ms on BASELINE config 2)
+                            if (series_on) {   // (one tick row per distinct time: the send below starts at G's)
                                 const bool q_ready = r.s > r.b, q_pre = r.b > r.adm, q_post = r.g > r.f, q_ram = ram > 0.0;
                                 uint32_t t_adm = 0u, t_b = 0u, t_s = 0u, t_f = 0u, t_g = 0u;
                                 if (q_pre || q_ram) t_adm = tick_index(r.adm, true);
@@ -1346,6 +1372,7 @@ struct Flow {
                             }
                         }
                         sending = have && ts < T;      // transport() on the server's out-edge at G (server.py:276), if the horizon allows
+                        prof(PROF_SERVER_SERIES);
                         idx = claim_send_index(sending, e, true);
                     }
                 } else {   // client, second visit (client.py:62-69): the request is complete
@@ -1353,14 +1380,22 @@ struct Flow {
                     n_comp += n_sel;
                     sending = false;
                 }
+                if (st == 3u) prof(PROF_SERVERS);
+                else if (st == 4u) prof(PROF_COMPLETE);
+                else prof(PROF_STATION);
                 if (st < 4u) {
                     double k2 = 0.0;
                     bool counted = false;
-                    const bool ok = sending && edge_send(e, idx, ts, row, k2, counted, kLC && pre, pre_tr);
+                    double transit = 0.0;
+                    const bool sent = sending && send_draw(e, idx, transit, kLC && pre, pre_tr);
+                    prof(PROF_DRAW);
+                    const bool ok = sent && send_finish(e, ts, row, st == 3u, transit, k2, counted);
+                    prof(PROF_SEND_SERIES);
                     // (server list: the server and the edge the message comes by; completion list: the server's out-edge)
                     append(nxt, ok, k2, (kFar && counted) ? -t0 : t0, !kFar ? tgt : st == 3u ? e : tgt | (e << 8), ts);
                     if (st > 0u) H_in = H_get(st - 1u);
                     H_in = send_floor(st, H_in);   // what the next station may touch: everything delivered before this
+                    prof(PROF_APPEND);
                 }
             }
             // ---- ticks that can no longer change
@@ -1376,6 +1411,7 @@ struct Flow {
             W::sync();
             flush_ticks(finished ? A.n_ticks : tick_index(h_min, false));
             W::sync();
+            prof(PROF_FLUSH);
             const bool stuck = work == 0u && !finished && !(kMarks ? moved : h3 > h_done_before);
             if (stuck) why |= FLOW_WHY_LIST;   // nothing moved, no horizon advanced: a list is full of later messages
             if (finished || W::any(why != 0u)) break;
@@ -1400,6 +1436,12 @@ struct Flow {
             c[af::CNT_FLAGS] = flags;
             c[af::CNT_MAX_LIVE] = 0u;   // a diagnostic of the sequential kernels (peak of live requests)
             c[af::CNT_MARKS] = marks;
+        }
+        if (kProf) {
+            prof(PROF_SETUP);
+            if (lane == 0u && A.prof != nullptr)
+#pragma unroll
+                for (uint32_t k = 0u; k < kProfSections; ++k) A.prof[(size_t)sc * kProfSections + k] = prof_acc[k];
         }
     }
 };

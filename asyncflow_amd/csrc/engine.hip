@@ -327,6 +327,7 @@ struct WaveHip {
     static __device__ __forceinline__ uint32_t mbcnt(uint64_t m) {
         return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     }
+    static __device__ __forceinline__ unsigned long long clock() { return __builtin_amdgcn_s_memtime(); }   // shader cycles
 };
 
 // Register budget as waves per SIMD (measured on MI355X, profiles/r02: see DESIGN.md section 4e).
@@ -1124,7 +1125,7 @@ std::string flow_jit_spec_string(const af_engine* e, const FlowPlan& P, const af
                   "-DAF_FJ_OFF_EP=%u -DAF_FJ_OFF_ROW=%u -DAF_FJ_OFF_EMARK=%u -DAF_FJ_OFF_SMARK=%u -DAF_FJ_OFF_LB=%u -DAF_FJ_BLOB_BYTES=%u "
                   "-DAF_FJ_N_TICKS=%u -DAF_FJ_HAS_CLOCK=%d -DAF_FJ_HAS_SAMPLES=%d -DAF_FJ_HAS_ONLINE=%d -DAF_FJ_HAS_OVR=%d "
                   "-DAF_FJ_LAYOUT=%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u",
-                  P.ipl, P.feat, bits(f.total_time), bits(f.sample_period), bits(f.inv_period), bits(f.tick_eps), f.metrics_mask,
+                  P.ipl, P.feat | (std::getenv("AF_FLOW_PROF") ? (uint32_t)aff::FEAT_PROF : 0u), bits(f.total_time), bits(f.sample_period), bits(f.inv_period), bits(f.tick_eps), f.metrics_mask,
                   f.gen_out_edge, f.client_out_edge, f.n_edges, f.n_servers, f.has_lb, f.n_lb_edges, f.n_edge_marks, f.n_srv_marks,
                   f.lb_least_connections, f.max_pre, f.max_cpu, f.max_post, f.off_edge, f.off_srv, f.off_ep, f.off_row, f.off_emark,
                   f.off_smark, f.off_lb, f.blob_bytes, f.n_ticks, out->clock ? 1 : 0, out->samples ? 1 : 0,
@@ -1632,6 +1633,14 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
         f.online_hist_scale = a.online_hist_scale;
         f.n_fallback = e->d_fb;
         HIP_TRY(hipMemsetAsync(e->d_fb, 0, 10u * 4u, e->stream));
+        // measurement hook (AF_FLOW_PROF=<file>, plan-specialised builds only): shader-clock time per section of Flow::run
+        unsigned long long* d_prof = nullptr;
+        const char* prof_path = std::getenv("AF_FLOW_PROF");
+        if (prof_path != nullptr) {
+            HIP_TRY(hipMalloc((void**)&d_prof, (size_t)nc * aff::kProfSections * 8u));
+            HIP_TRY(hipMemsetAsync(d_prof, 0, (size_t)nc * aff::kProfSections * 8u, e->stream));
+            f.prof = d_prof;
+        }
         {
             const uint32_t flow_lds_launch = spread_lds_bytes(flow_lds);
             void* kargs[] = {&f};
@@ -1639,6 +1648,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
             const bool jit = e->flow_jit_fn != nullptr && flow_lds_launch <= 64u * 1024u &&
                              flow_jit_spec_string(e, FP, out, sweep->n_overrides != 0u) == e->flow_jit_spec;
             if (e->flow_jit_fn != nullptr && !jit) n_jit_miss += 1u;
+            if (std::getenv("AF_DEBUG")) std::fprintf(stderr, "[af] flow jit spec: %s\n", flow_jit_spec_string(e, FP, out, sweep->n_overrides != 0u).c_str());
             if (std::getenv("AF_DEBUG"))
                 std::fprintf(stderr, "[af] flow launch: %u scenarios, %u list entries%s, %u ring rows, %u B LDS per wave, af_flow_kernel<%u, %#x>%s%s\n", nc,
                              FL.cap, flow_big ? " (long-list instantiation)" : "", FL.ring_rows, flow_lds, FP.ipl, FP.feat,
@@ -1657,6 +1667,24 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
         uint32_t fb[5] = {0, 0, 0, 0, 0};
         HIP_TRY(hipMemcpyAsync(fb, e->d_fb, sizeof fb, hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
+        if (d_prof != nullptr) {
+            std::vector<unsigned long long> hp((size_t)nc * aff::kProfSections);
+            HIP_TRY(hipMemcpy(hp.data(), d_prof, hp.size() * 8u, hipMemcpyDeviceToHost));
+            (void)hipFree(d_prof);
+            static const char* names[aff::kProfSections] = {"setup+end", "generator batch", "select", "series: delivery end (FAR)", "station logic",
+                                                            "servers_solve + claim", "server series", "draws (Philox, log)", "send: spike + series",
+                                                            "append + send_floor", "complete", "flush_ticks + round end"};
+            double acc[aff::kProfSections] = {}, total = 0.0;
+            for (uint32_t i = 0; i < nc; ++i)
+                for (uint32_t k = 0; k < aff::kProfSections; ++k) acc[k] += (double)hp[(size_t)i * aff::kProfSections + k];
+            for (double v : acc) total += v;
+            if (FILE* fp = std::fopen(prof_path, "a")) {
+                std::fprintf(fp, "af_flow_kernel<%u, %#x> sections, %u waves, mean cycles per wave %.0f:\n", FP.ipl, FP.feat, nc, total / nc);
+                for (uint32_t k = 0; k < aff::kProfSections; ++k)
+                    if (names[k]) std::fprintf(fp, "  %-28s %6.2f %%  %12.0f cycles per wave\n", names[k], 100.0 * acc[k] / total, acc[k] / nc);
+                std::fclose(fp);
+            }
+        }
         float ms_p = 0.f, ms_f = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms_p, e->ev2, e->ev3));
         HIP_TRY(hipEventElapsedTime(&ms_f, e->ev3, e->ev4));

@@ -136,6 +136,7 @@ struct WaveEmu {
         return s;
     }
     static uint32_t mbcnt(uint64_t m) { return (uint32_t)__builtin_popcountll(m & ((1ull << lane()) - 1ull)); }
+    static unsigned long long clock() { return 0ull; }   // (FEAT_PROF is a device-only measurement build)
 };
 
 }  // namespace emu
