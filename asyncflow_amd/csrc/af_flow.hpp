@@ -323,8 +323,7 @@ struct Flow {
     // safely between two ticks, else a look-up in the table of the collector's own tick times.
     // (Measured, round 3: the same thing without the two early returns -- clamps and one predicate instead of exec-mask
     // branches, so that the two rows of an interval are worked out side by side -- is SLOWER: 48.5 -> 50.1 ms on BASELINE
-    // config 2.  The selects it needs become v_cndmask on VCC, which this chip issues at ~12 cycles against 2.7 for the
-    // compare that feeds it: scripts/microbench/valu_cost.hip, profiles/r03/valu_cost.txt.)
+    // config 2: most calls leave by the first or the third return, and the straight-line form executes everything always.)
     AF_CORE uint32_t tick_index(double x, bool flag_ties) {
         const uint32_t N = A.n_ticks;
         if (!(x > 0.0)) return 0u;

@@ -168,6 +168,20 @@ def _time_serial(fn, budget_s: float) -> tuple[float, int, float]:
             return float(ev), k, dt
 
 
+def committed_python_reference() -> dict | None:
+    """The newest profiles/rNN/python_reference.json: the UNMODIFIED Python reference timed in the build container."""
+    found = sorted((ROOT / "profiles").glob("r*/python_reference.json"))
+    if not found:
+        return None
+    pj = json.loads(found[-1].read_text())
+    return {"value": pj["value_single_core"], "unit": "request-events/s", "cores": 1, "kind": "reference",
+            "measured_in_this_run": False, "where": pj["where"], "cpu_model": pj["cpu_model"], "simpy_flavour": pj["simpy_flavour"],
+            "all_cores": {"value": pj["value_all_procs"], "cores": pj["procs"], "replicas_per_s": pj["replicas_per_s_all_procs"],
+                          "extrapolated_10k_sweep_hours": pj["extrapolated_10k_sweep_hours"]},
+            "sample": f"{pj['workload']}; {pj['what']}; one replica alone {pj['one_replica_alone_s']:.2f} s",
+            "source": str(found[-1].relative_to(ROOT)) + " (scripts/measure_python_reference.py)"}
+
+
 def cpu_baseline(payload: dict, seed_base: int, label: str, budget_s: float = 8.0) -> dict:
     """CPU legs timed in THIS run on the host cores of this box, on a bounded sample of the same workload:
     (a) the SimPy-faithful C restatement (oracle/des_oracle.c) on ONE unloaded core,
@@ -242,8 +256,9 @@ def cpu_baseline(payload: dict, seed_base: int, label: str, budget_s: float = 8.
                             "what": "asyncflow_amd/csrc/af_core.hpp (the sequential next-event core) compiled by g++ for one lane"}
     except Exception as exc:  # noqa: BLE001 - a missing g++ must not take the bench down
         out["port_lean"] = {"value": None, "why": f"{type(exc).__name__}: {exc}"}
-    # (d) the Python reference itself, only where it exists (never on the GPU box)
-    out["python_reference"] = None
+    # (d) the Python reference itself: timed HERE only where it exists (never on the GPU box); otherwise the committed
+    # build-container measurement of scripts/measure_python_reference.py is carried, labelled as such
+    out["python_reference"] = committed_python_reference()
     if ref_env.reference_available():
         try:
             from oracle.reference_runner import run_reference_numpy
@@ -258,11 +273,111 @@ def cpu_baseline(payload: dict, seed_base: int, label: str, budget_s: float = 8.
             dt = time.perf_counter() - t0
             ev_short = ev1 / runs1 * (T_short / T_full)        # request-events of the same scenario length
             out["python_reference"] = {"value": ev_short / dt, "unit": "request-events/s", "cores": 1, "kind": "reference",
+                                       "measured_in_this_run": True, "where": "this box",
                                        "sample": f"1 replica, T={int(T_short)} s, unmodified reference actors on "
-                                                 f"{ref_env.simpy_flavour()} SimPy, numpy PCG64 via runner.rng, wall {dt:.2f} s"}
+                                                 f"{ref_env.simpy_flavour()} SimPy, numpy PCG64 via runner.rng, wall {dt:.2f} s",
+                                       "committed": committed_python_reference()}
         except Exception as exc:  # noqa: BLE001
             out["python_reference"] = {"value": None, "why": f"{type(exc).__name__}: {exc}"}
     return out
+
+
+def kernel_sources_sha1() -> str:
+    import hashlib
+
+    h = hashlib.sha1()
+    for name in ("engine.hip", "af_flow.hpp", "af_flow_host.hpp", "af_core.hpp", "af_math.hpp", "af_plan_pack.hpp", "af_summary.hpp"):
+        h.update((ROOT / "asyncflow_amd" / "csrc" / name).read_bytes())
+    return h.hexdigest()
+
+
+def attach_binding(roof: dict, dom_ms: float, events_rank: float, args, n: int, wl: dict) -> None:
+    """What limits the dominant kernel, from the committed PMC passes of THIS command (rocprofv3 cannot run inside the
+    timed bench): newest profiles/rNN/binding.json (scripts/profile_round3.sh + make_binding_json.py).  `stale` says
+    whether the kernel sources changed since the profile was taken; times are this run's."""
+    roof["binding"] = "valu_issue"
+    if not (args.config == 2 and n == 10_000 and not args.no_series and wl["horizon"] == 600):
+        roof["binding_detail"] = {"why": "PMC passes are committed for the default command only (BASELINE config 2)"}
+        return
+    found = sorted((ROOT / "profiles").glob("r*/binding.json"))
+    if not found:
+        roof["binding_detail"] = {"why": "no profiles/rNN/binding.json"}
+        return
+    bj = json.loads(found[-1].read_text())
+    stale = bj.get("sources_sha1") != kernel_sources_sha1()
+    same_kernel = bj["kernel"].split("_jit")[0].split("_kernel")[0] in roof["kernel"]
+    roof["binding_detail"] = {
+        "source": f"{found[-1].relative_to(ROOT)} (rocprofv3 --pmc passes of the same command, one counter set per run)",
+        "profiled_kernel": bj["kernel"], "stale": bool(stale or not same_kernel),
+        "valu_wave_insts_per_request_event": bj["valu_wave_insts_per_request_event"],
+        "all_wave_insts_per_request_event": bj.get("all_wave_insts_per_request_event"),
+        "valu_issue_frac": bj["valu_issue_frac"],
+        "valu_issue_frac_is": "SQ_ACTIVE_INST_VALU x 4 / (1 024 SIMDs x kernel cycles)",
+        "valu_lane_utilisation": bj["valu_lane_utilisation"],
+        "wait_any_frac_of_wave_cycles": bj.get("wait_any_frac_of_wave_cycles"),
+        "wave_lifetime_ms": bj.get("wave_lifetime_ms"),
+        "hbm_read_bytes_FETCH_SIZE_x2": bj.get("hbm_read_bytes"), "l2_write_bytes_WRITE_SIZE": bj.get("l2_write_bytes"),
+        "profiled_kernel_ms": bj.get("kernel_avg_ms_trace"),
+    }
+    cal = sorted((ROOT / "profiles").glob("r*/write_calibration.json"))
+    if cal:
+        cj = json.loads(cal[-1].read_text())
+        roof["binding_detail"]["write_size_calibration"] = {
+            "source": str(cal[-1].relative_to(ROOT)),
+            "counter_bytes_per_stored_byte": {k: v.get("counter_bytes_per_stored_byte") for k, v in cj["patterns"].items()},
+            "reading": "WRITE_SIZE counts the kernel's store shapes exactly (1.00 B per stored byte): what it shows above the "
+                       "output size are the kernel's scratch stores (an L2-level counter) and lines shared by the chunks of "
+                       "consecutive rounds, not a counting artefact"}
+    if bj.get("hbm_read_bytes") is not None and bj.get("l2_write_bytes") is not None:
+        roof["traffic"] = bj["hbm_read_bytes"] + bj["l2_write_bytes"]
+        roof["traffic_source"] = roof["binding_detail"]["source"]
+        roof["frac_traffic"] = roof["traffic"] / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+
+
+def end_to_end_sweep(sw: "RankSweep", wl: dict, dev) -> dict:
+    """BASELINE.md 4.3's wall-clock of ONE sweep, outside the timed region: lowering the payload, engine creation, the
+    step itself (seed / column upload, kernels, analyzer) and the D2H copy of the per-scenario summaries."""
+    import torch
+
+    from asyncflow_amd.plan import lower
+
+    t0 = time.perf_counter()
+    plan = lower(wl["payload"])
+    t_lower = time.perf_counter() - t0
+    del plan
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    sw.step()
+    torch.cuda.synchronize(dev)
+    t_step = time.perf_counter() - t1
+    t2 = time.perf_counter()
+    host = [sw.s_stats.cpu(), sw.s_rps.cpu(), sw.s_hist.cpu()]
+    if sw.s_mean is not None:
+        host += [sw.s_mean.cpu(), sw.s_max.cpu()]
+    t_d2h = time.perf_counter() - t2
+    nbytes = sum(t.numel() * t.element_size() for t in host)
+    return {"total_s": t_lower + t_step + t_d2h, "lowering_s": t_lower, "step_s": t_step, "summary_d2h_s": t_d2h,
+            "summary_d2h_bytes": nbytes, "jit_build_or_cache_load_s_not_included": sw.jit_build_s,
+            "what": "lower(payload) + one step (H2D of seeds / columns, kernels, analyzer) + D2H of the per-scenario summaries; "
+                    "the full outputs stay in HBM (their D2H would add 18 GB / PCIe)"}
+
+
+def residency_tail(sw: "RankSweep", flow_ms: float) -> dict | None:
+    """How much the partial last residency round of the one-wave-per-scenario launch costs: the same kernel over the
+    largest multiple of the resident wave slots (256 CUs x waves per CU) that fits the batch, per scenario."""
+    lds = int(sw.run_stats["flow_lds_bytes"]) or 1
+    per_cu = max(1, min(16, (160 * 1024) // ((lds + 511) // 512 * 512)))
+    slots = 256 * per_cu
+    n = sw.slice if sw.n_slices > 1 else sw.n
+    m = (n // slots) * slots
+    if m == 0 or m == n:
+        return {"waves_per_cu": per_cu, "resident_slots": slots, "rounds": n / slots, "loss_frac": 0.0 if m == n else None}
+    seeds, over, kw = sw._slice_args(0, m)   # noqa: SLF001
+    st = sw.eng.run(seeds, over, specialise=sw.specialise, **kw)
+    full = float(st.flow_kernel_ms) / m
+    return {"waves_per_cu": per_cu, "resident_slots": slots, "rounds": n / slots, "full_rounds_scenarios": m,
+            "full_rounds_kernel_ms": float(st.flow_kernel_ms), "us_per_scenario_full_rounds": full * 1e3,
+            "us_per_scenario_this_batch": flow_ms / n * 1e3, "loss_frac": 1.0 - full * n / flow_ms}
 
 
 def parity_spot_check(sw: "RankSweep", k: int = 4) -> dict:
@@ -495,6 +610,7 @@ def main() -> int:  # noqa: C901, PLR0912, PLR0915
     ap.add_argument("--horizon", type=int, default=0, help="simulated seconds (0 = the BASELINE horizon)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the post-run oracle comparison of 4 benched scenarios")
+    ap.add_argument("--no-diagnostics", action="store_true", help="skip the post-run end-to-end / residency-tail measurements")
     ap.add_argument("--no-series", action="store_true", help="do not store the sampled series")
     ap.add_argument("--lanes", type=int, default=0, help="scenario lanes per wave of the sequential kernel (0 = engine default)")
     ap.add_argument("--global-state", action="store_true", help="keep per-scenario state in HBM")
@@ -630,6 +746,19 @@ def main() -> int:  # noqa: C901, PLR0912, PLR0915
     cdf = np.cumsum(pooled) / max(pooled.sum(), 1.0)
     pooled_p95_ms = float((np.searchsorted(cdf, 0.95) + 1) * sw.hist_max / 256 * 1e3)
 
+    # ---- diagnostics after the timed region (rank 0, single GPU): end-to-end wall of one sweep, residency tail
+    e2e = tail = parity = None
+    if rank == 0 and not args.no_parity_check:      # (first: the diagnostics below reuse the output buffers)
+        try:
+            parity = parity_spot_check(sw)
+        except Exception as exc:  # noqa: BLE001 - a broken checker build must not eat the measured line; it says so
+            parity = {"scenarios": 0, "ok": None, "why": f"{type(exc).__name__}: {exc}"}
+    if rank == 0 and world == 1 and not args.no_diagnostics:
+        e2e = end_to_end_sweep(sw, wl, dev)
+        if flow_on:
+            tail = residency_tail(sw, float(np.mean([a["flow_ms"] for a in accs])))
+        c = sw.counts.cpu().numpy().view(np.uint32)     # (the diagnostics ran the same scenarios again: same counts)
+
     if rank == 0:
         total_events = events_total * args.steps
         alg_bytes = algorithmic_bytes(c, plan.n_series, int(rs["lds_bytes_per_wave"] - rs["lanes_per_wave"] * rs["state_bytes_per_scenario"])
@@ -676,6 +805,10 @@ def main() -> int:  # noqa: C901, PLR0912, PLR0915
             "events_per_step": events_total,
             "per_gpu_value": total_events / elapsed / world,
             "sweep_wall_s_per_10k": elapsed / args.steps * (10_000 / max(n, 1)),
+            # lowering + H2D + kernels + summary D2H of ONE sweep (measured once after the timed region;
+            # the one-off hipcc build of the plan-specialised kernel is listed beside it, never inside)
+            "sweep_wall_s_per_10k_end_to_end": None if e2e is None else e2e["total_s"] * (10_000 / max(n, 1)),
+            "end_to_end": e2e,
             "kernel_ms": k_ms,
             "kernel_ms_ranks_min_max": kernel_ms_ranks,
             "pregen_ms": float(np.mean([a["pregen_ms"] for a in accs])),
@@ -704,33 +837,21 @@ def main() -> int:  # noqa: C901, PLR0912, PLR0915
                 "traffic": None,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "bytes_per_event": alg_bytes / max(events_rank, 1.0),
-                "note": "achieved = SURVEY 8d's algorithmic bytes (80 B of per-event state traffic + outputs, a state-in-HBM model) / "
-                        "the dominant kernel's time; the kernel keeps that state in LDS, so the bytes it really moves are "
-                        "`traffic` (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE) and `frac_traffic` is the fraction of the HBM peak it uses",
+                "note": "achieved = SURVEY 8d's algorithmic bytes (80 B of per-event state traffic + outputs, a state-in-HBM MODEL) / "
+                        "the dominant kernel's time.  The kernel keeps that state in LDS: this fraction says how fast the model's "
+                        "bytes WOULD have to move, not what HBM does -- `traffic` / `frac_traffic` are the measured bytes, and "
+                        "`binding` names the resource that limits the kernel (instruction issue) with its counters",
                 "kernel": ("af_flow_jit (plan-specialised build of af_flow_kernel)" if accs[-1]["jit"] else "af_flow_kernel") if flow_on else
                           "af_jit_lean (plan-specialised build of af_des_kernel)" if accs[-1]["jit"] else "af_des_kernel",
-                "kernel_ms": float(np.mean([a["flow_ms"] for a in accs])) if flow_on else k_ms,
+                "kernel_ms": dom_ms,
+                "residency_tail": tail,
             },
         }
+        attach_binding(line["roofline"], dom_ms, events_rank, args, n, wl)
         if base is not None:
             line["cpu_baseline"] = base
-        if not args.no_parity_check:
-            try:
-                line["parity_spot_check"] = parity_spot_check(sw)
-            except Exception as exc:  # noqa: BLE001 - a broken checker build must not eat the measured line; it says so
-                line["parity_spot_check"] = {"scenarios": 0, "ok": None, "why": f"{type(exc).__name__}: {exc}"}
-        # HBM bytes per launch of the dominant kernel, from the committed PMC passes of THIS command
-        # (rocprofv3 cannot run inside the timed bench): newest profiles/rNN/**/traffic.json
-        if args.config == 2 and n == 10_000 and not args.no_series and wl["horizon"] == 600:
-            found = sorted((ROOT / "profiles").glob("r*/**/traffic.json"))
-            for tpath in reversed(found):
-                tj = json.loads(tpath.read_text())
-                if tj.get("kernel", "") and tj["kernel"] not in line["roofline"]["kernel"]:
-                    continue
-                line["roofline"]["traffic"] = tj["bytes_per_launch"]
-                line["roofline"]["traffic_source"] = f"{tpath.relative_to(ROOT)} (2 x FETCH_SIZE + WRITE_SIZE, KB=1024 B)"
-                line["roofline"]["frac_traffic"] = tj["bytes_per_launch"] / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-                break
+        if parity is not None:
+            line["parity_spot_check"] = parity
         print(json.dumps(line), flush=True)
     sw.eng.close()
     if dist is not None:
