@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-AF_ABI_VERSION = 3
+AF_ABI_VERSION = 4
 
 # af_status
 MAX_REQUEST_CAPACITY = 65535   # include/asyncflow_hip.h AF_MAX_REQUEST_CAPACITY
@@ -46,6 +46,15 @@ PARAM_CODES = {
     "edge_sigma": 4,
     "edge_dropout": 5,
     "step_time": 6,
+    "gen_window": 7,
+    "srv_cores": 8,
+    "srv_ram_mb": 9,
+    "emark_time": 10,
+    "emark_delta": 11,
+    "emark_edge": 12,
+    "smark_time": 13,
+    "smark_lb_edge": 14,
+    "smark_down": 15,
 }
 # af_count_slot
 CNT_GENERATED, CNT_COMPLETED, CNT_DROPPED, CNT_EVENTS, CNT_TICKS, CNT_FLAGS, CNT_MAX_LIVE, CNT_MARKS = range(8)

@@ -68,8 +68,13 @@ enum : uint32_t {
 };
 enum : uint32_t {
     PARAM_GEN_USERS_MEAN = 0, PARAM_GEN_USERS_SIGMA, PARAM_GEN_RPM_MEAN, PARAM_EDGE_MEAN, PARAM_EDGE_SIGMA,
-    PARAM_EDGE_DROPOUT, PARAM_STEP_TIME, PARAM_COUNT
+    PARAM_EDGE_DROPOUT, PARAM_STEP_TIME,
+    // round 3: sampling window, server resources, the injected events' timelines
+    PARAM_GEN_WINDOW, PARAM_SRV_CORES, PARAM_SRV_RAM_MB, PARAM_EMARK_TIME, PARAM_EMARK_DELTA, PARAM_EMARK_EDGE,
+    PARAM_SMARK_TIME, PARAM_SMARK_LB_EDGE, PARAM_SMARK_DOWN, PARAM_COUNT
 };
+constexpr uint32_t kParamMarkBits = (1u << PARAM_EMARK_TIME) | (1u << PARAM_EMARK_DELTA) | (1u << PARAM_EMARK_EDGE) |
+                                    (1u << PARAM_SMARK_TIME) | (1u << PARAM_SMARK_LB_EDGE) | (1u << PARAM_SMARK_DOWN);
 
 // ---- request state (low 32 bits of a heap / queue entry's B word) -----------
 //   kind[0:1] | idx[2:9] (edge while in transit, server otherwise) | hops[10:12] (saturating:
@@ -126,6 +131,7 @@ struct Layout {
     uint32_t fcap;      // per-server wait-queue capacity (power of two, <= 16384: rq_n is a 15-bit field)
     uint32_t ovr_mask;  // bit p set: af_param class p is overridden per scenario
     uint32_t hk, ha, hb, edge, ring, stime, srv, cq, rq, lb, n_words;
+    uint32_t srvram, marks;   // per-scenario ram_mb [S] / timeline marks [MREC n_emarks + NREC n_smarks] (only when overridden)
     // per-scenario HBM scratch of the shared-timestamp path (64-bit words, plain array):
     //   zero-time event FIFO [tcap][2] | node inbox items [tcap][2] | forwarder-busy bits
     uint32_t tcap, tie_words;
@@ -136,7 +142,7 @@ struct Layout {
 enum : uint32_t { LEDGE = 2, LSRV = 5, RING = 4, RING_LOW = AF_RING_LOW };
 
 AF_HD Layout make_layout(uint32_t cap, uint32_t fcap, uint32_t n_edges, uint32_t n_servers, uint32_t n_lb,
-                         uint32_t n_rows, uint32_t ovr_mask) {
+                         uint32_t n_rows, uint32_t ovr_mask, uint32_t n_emarks = 0u, uint32_t n_smarks = 0u) {
     Layout L{};
     L.cap = cap;
     L.fcap = fcap;
@@ -152,6 +158,8 @@ AF_HD Layout make_layout(uint32_t cap, uint32_t fcap, uint32_t n_edges, uint32_t
     L.cq = w; w += 2u * n_servers * fcap;
     L.rq = w; w += 2u * n_servers * fcap;
     L.lb = w; w += n_lb > 8u ? n_lb : 0u;
+    L.srvram = w; if (ovr_mask & (1u << PARAM_SRV_RAM_MB)) w += n_servers;
+    L.marks = w; if (ovr_mask & kParamMarkBits) w += 3u * n_emarks + 2u * n_smarks;   // MREC, NREC
     L.n_words = w;
     uint32_t tc = 16u;
     while (tc < 2u * cap + 8u) tc <<= 1;
@@ -328,6 +336,16 @@ struct Lane : LaneRegs {
         : P(p), L(l), M(m), O(o), D(d), seed(s) {}
 
     // ---- parameter accessor (plan value or per-scenario column) ---------------
+    // per-scenario server RAM / timeline marks when the sweep has such columns, else the plan's
+    AF_CORE double ram_cap(uint32_t sv) const {
+        return (L.ovr_mask & (1u << PARAM_SRV_RAM_MB)) ? u2d(M.ld(L.srvram + sv)) : u2d(P.srv[SREC * sv]);
+    }
+    AF_CORE uint64_t emark_w(uint32_t i, uint32_t k) const {
+        return (L.ovr_mask & kParamMarkBits) ? M.ld(L.marks + MREC * i + k) : P.emark[MREC * i + k];
+    }
+    AF_CORE uint64_t smark_w(uint32_t i, uint32_t k) const {
+        return (L.ovr_mask & kParamMarkBits) ? M.ld(L.marks + MREC * P.n_edge_marks + NREC * i + k) : P.smark[NREC * i + k];
+    }
     AF_CORE double row_time(uint32_t r) const {
         return (L.ovr_mask & (1u << PARAM_STEP_TIME)) ? u2d(M.ld(L.stime + r)) : u2d(P.row[TREC * r]);
     }
@@ -653,7 +671,7 @@ struct Lane : LaneRegs {
         const uint32_t step0 = (uint32_t)P.ep[PREC * ep + 1u];
         if (ram > 0.0) {  // server.py:146-149
             const uint64_t q = M.ld(at + 4u);
-            if (ram > u2d(P.srv[SREC * sv]) || (q >> 63)) {
+            if (ram > ram_cap(sv) || (q >> 63)) {
                 // can never be served: it (and everything queued behind it) waits
                 // forever in the reference, observable nowhere -> dropped here.
                 flags |= FLAG_RAM_STARVED;
@@ -767,18 +785,18 @@ struct Lane : LaneRegs {
     AF_CORE void apply_emarks() {
         for (;;) {
             const uint32_t i = emark_i++;
-            const uint32_t at = L.edge + LEDGE * (uint32_t)P.emark[MREC * i + 2u] + 1u;
-            M.st(at, d2u(u2d(M.ld(at)) + u2d(P.emark[MREC * i + 1u])));
+            const uint32_t at = L.edge + LEDGE * (uint32_t)emark_w(i, 2u) + 1u;
+            M.st(at, d2u(u2d(M.ld(at)) + u2d(emark_w(i, 1u))));
             n_marks += 1u;
-            if (emark_i >= P.n_edge_marks || u2d(P.emark[MREC * emark_i]) > now) break;
+            if (emark_i >= P.n_edge_marks || u2d(emark_w(emark_i, 0u)) > now) break;
         }
-        t_emark = emark_i < P.n_edge_marks ? u2d(P.emark[MREC * emark_i]) : AF_INF;
+        t_emark = emark_i < P.n_edge_marks ? u2d(emark_w(emark_i, 0u)) : AF_INF;
         q_emark = seq++;
     }
     AF_CORE void apply_smarks() {
         for (;;) {
             const uint32_t i = smark_i++;
-            const uint64_t meta = P.smark[NREC * i + 1u];
+            const uint64_t meta = smark_w(i, 1u);
             const uint32_t e1 = (uint32_t)meta;  // lb edge + 1, 0 = server not behind the LB
             n_marks += 1u;
             if (e1 != 0u) {
@@ -795,9 +813,9 @@ struct Lane : LaneRegs {
                     lb_n += 1u;
                 }
             }
-            if (smark_i >= P.n_srv_marks || u2d(P.smark[NREC * smark_i]) > now) break;
+            if (smark_i >= P.n_srv_marks || u2d(smark_w(smark_i, 0u)) > now) break;
         }
-        t_smark = smark_i < P.n_srv_marks ? u2d(P.smark[NREC * smark_i]) : AF_INF;
+        t_smark = smark_i < P.n_srv_marks ? u2d(smark_w(smark_i, 0u)) : AF_INF;
         q_smark = seq++;
     }
 
@@ -1049,7 +1067,7 @@ struct Lane : LaneRegs {
         const uint32_t step0 = (uint32_t)P.ep[PREC * ep + 1u];
         if (ram > 0.0) {
             const uint64_t q = M.ld(at + 4u);
-            if (ram > u2d(P.srv[SREC * sv]) || (q >> 63)) {  // same treatment as server_arrival
+            if (ram > ram_cap(sv) || (q >> 63)) {  // same treatment as server_arrival
                 flags |= FLAG_RAM_STARVED;
                 M.st(at + 4u, q | (1ull << 63));
                 live -= 1u;
@@ -1246,10 +1264,29 @@ struct Lane : LaneRegs {
         lb_n = P.n_lb_edges;
         lb_list = 0ull;
         for (uint32_t i = 0u; i < lb_n; ++i) lb_set(i, (uint32_t)P.lb[i]);
+        if (L.ovr_mask & (1u << PARAM_SRV_RAM_MB))
+            for (uint32_t v = 0u; v < P.n_servers; ++v) M.st(L.srvram + v, P.srv[SREC * v]);
+        if (L.ovr_mask & kParamMarkBits) {
+            for (uint32_t i = 0u; i < MREC * P.n_edge_marks; ++i) M.st(L.marks + i, P.emark[i]);
+            for (uint32_t i = 0u; i < NREC * P.n_srv_marks; ++i) M.st(L.marks + MREC * P.n_edge_marks + i, P.smark[i]);
+        }
         for (uint32_t k = 0u; k < n_ovr; ++k) {
             const double v = ovr(k);
-            const uint32_t idx = ovr_index[k];
-            if (ovr_param[k] == PARAM_STEP_TIME) M.st(L.stime + idx, d2u(v));  // the others only shape the draws
+            const uint32_t idx = ovr_index[k], prm = ovr_param[k];
+            if (prm == PARAM_STEP_TIME) M.st(L.stime + idx, d2u(v));
+            else if (prm == PARAM_SRV_CORES) M.st(L.srv + LSRV * idx, (uint64_t)(uint32_t)v);            // cpu_free = cores, ready = 0
+            else if (prm == PARAM_SRV_RAM_MB) { M.st(L.srvram + idx, d2u(v)); M.st(L.srv + LSRV * idx + 2u, d2u(v)); }   // capacity, level
+            else if (prm == PARAM_EMARK_TIME) M.st(L.marks + MREC * idx, d2u(v));
+            else if (prm == PARAM_EMARK_DELTA) M.st(L.marks + MREC * idx + 1u, d2u(v));
+            else if (prm == PARAM_EMARK_EDGE) M.st(L.marks + MREC * idx + 2u, (uint64_t)(uint32_t)v);
+            else if (prm == PARAM_SMARK_TIME) M.st(L.marks + MREC * P.n_edge_marks + NREC * idx, d2u(v));
+            else if (prm == PARAM_SMARK_LB_EDGE) {   // value = LB out-edge index, -1 = the server is not behind the LB
+                const uint32_t at = L.marks + MREC * P.n_edge_marks + NREC * idx + 1u;
+                M.st(at, (M.ld(at) & ~0xFFFFFFFFull) | (uint64_t)(uint32_t)((int32_t)v + 1));
+            } else if (prm == PARAM_SMARK_DOWN) {
+                const uint32_t at = L.marks + MREC * P.n_edge_marks + NREC * idx + 1u;
+                M.st(at, (M.ld(at) & 0xFFFFFFFFull) | ((uint64_t)(v != 0.0 ? 1u : 0u) << 32));
+            }   // (the others only shape the draws)
         }
         dirty_edge = -1;
         {   // blocking first fill of every ring (once per scenario)
@@ -1259,8 +1296,8 @@ struct Lane : LaneRegs {
             for (uint32_t e = 0u; e < P.n_edges; ++e) topup_end_edge(topup_begin(true, 1u + e, 0u));
         }
         t_tick = 0.0 + P.sample_period;
-        t_emark = P.n_edge_marks ? u2d(P.emark[0]) : AF_INF;
-        t_smark = P.n_srv_marks ? u2d(P.smark[0]) : AF_INF;
+        t_emark = P.n_edge_marks ? u2d(emark_w(0u, 0u)) : AF_INF;
+        t_smark = P.n_srv_marks ? u2d(smark_w(0u, 0u)) : AF_INF;
     }
 
     // One next-event round.  Returns false once the scenario reached the horizon.

@@ -1192,6 +1192,22 @@ struct Flow {
                 else if (p == af::PARAM_EDGE_SIGMA) blob[A.off_edge + af::EREC * idx + 1u] = v;
                 else if (p == af::PARAM_EDGE_DROPOUT) blob[A.off_edge + af::EREC * idx + 2u] = v;
                 else if (p == af::PARAM_STEP_TIME) blob[A.off_row + af::TREC * idx] = v;   // idx is a step ROW
+                // server resources, timeline marks (sweeps over server_resources and over the injected events)
+                else if (p == af::PARAM_SRV_CORES) {
+                    const uint32_t at = A.off_srv + af::SREC * idx + 1u;
+                    blob[at] = (blob[at] & ~0xFFFFull) | (uint64_t)((uint32_t)u2d(v) & 0xFFFFu);
+                } else if (p == af::PARAM_SRV_RAM_MB) blob[A.off_srv + af::SREC * idx] = v;
+                else if (p == af::PARAM_EMARK_TIME) blob[A.off_emark + af::MREC * idx] = v;
+                else if (p == af::PARAM_EMARK_DELTA) blob[A.off_emark + af::MREC * idx + 1u] = v;
+                else if (p == af::PARAM_EMARK_EDGE) blob[A.off_emark + af::MREC * idx + 2u] = (uint64_t)(uint32_t)u2d(v);
+                else if (p == af::PARAM_SMARK_TIME) blob[A.off_smark + af::NREC * idx] = v;
+                else if (p == af::PARAM_SMARK_LB_EDGE) {
+                    const uint32_t at = A.off_smark + af::NREC * idx + 1u;
+                    blob[at] = (blob[at] & ~0xFFFFFFFFull) | (uint64_t)(uint32_t)((int32_t)u2d(v) + 1);
+                } else if (p == af::PARAM_SMARK_DOWN) {
+                    const uint32_t at = A.off_smark + af::NREC * idx + 1u;
+                    blob[at] = (blob[at] & 0xFFFFFFFFull) | ((uint64_t)(u2d(v) != 0.0 ? 1u : 0u) << 32);
+                }
             }
             // cumulative spike per edge after every mark, the reference's own += / -= in f64 (injection.py:191-198)
             for (uint32_t i = 0u; i < A.n_edge_marks; ++i) {

@@ -175,7 +175,7 @@ __device__ __forceinline__ void des_body(const KArgs& a_in) {
     a.off_smark = AF_JIT_OFF_SMARK;
     a.off_lb = AF_JIT_OFF_LB;
     a.blob_bytes = AF_JIT_BLOB_BYTES;
-    a.L = af::make_layout(AF_JIT_CAP, AF_JIT_FCAP, AF_JIT_N_EDGES, AF_JIT_N_SERVERS, AF_JIT_N_LB, AF_JIT_N_ROWS, AF_JIT_OVR_MASK);
+    a.L = af::make_layout(AF_JIT_CAP, AF_JIT_FCAP, AF_JIT_N_EDGES, AF_JIT_N_SERVERS, AF_JIT_N_LB, AF_JIT_N_ROWS, AF_JIT_OVR_MASK, AF_JIT_N_EMARKS, AF_JIT_N_SMARKS);
     // (clock / tick / draw capacities stay run-time values: they change with replicas, horizon and the runner's
     // auto-grow, and a key that contains them recompiles -- or silently misses -- for every such change)
     a.n_series = AF_JIT_N_EDGES + 3 * AF_JIT_N_SERVERS;
@@ -474,6 +474,7 @@ __global__ void __launch_bounds__(64) af_pregen_arrivals(const KArgs a, uint32_t
     const double users_mean = ovr_or(a, af::PARAM_GEN_USERS_MEAN, 0u, scen, a.gen_users_mean);
     const double users_sigma = ovr_or(a, af::PARAM_GEN_USERS_SIGMA, 0u, scen, a.gen_users_sigma);
     const double rpm = ovr_or(a, af::PARAM_GEN_RPM_MEAN, 0u, scen, a.gen_rpm_mean);
+    const double window_s = ovr_or(a, af::PARAM_GEN_WINDOW, 0u, scen, a.gen_window_s);
     const double rps_per_user = rpm / 60.0;
     const double T = a.total_time;
     double* out = a.draws + (size_t)slot * stride;  // stream 0 of this slot
@@ -483,7 +484,7 @@ __global__ void __launch_bounds__(64) af_pregen_arrivals(const KArgs a, uint32_t
     while (__any(run)) {
         run = run && g_now < T;
         if (run && g_now >= g_wend) {  // new window: the number of active users
-            g_wend = g_now + a.gen_window_s;
+            g_wend = g_now + window_s;
             const uint32_t idx = draws++;
             double users;
             if (a.gen_users_dist == af::DIST_NORMAL) {
@@ -741,6 +742,7 @@ struct af_engine {
     // host copy of what the layout heuristics need
     uint32_t has_lb = 0, cores_max = 1, ram_slots_max = 1;
     std::vector<double> edge_mean, edge_sigma, edge_spike;   // per edge: latency law, largest cumulative spike
+    std::vector<double> srv_ram_mb;
     std::vector<uint8_t> edge_dist;
     std::vector<int32_t> lb_edges, srv_out_edge;
     double service_max = 0.0, cpu_max = 0.0;
@@ -891,7 +893,8 @@ int plan_flow(const af_engine* e, const KArgs& a, const af_sweep_t* sweep, const
     bool& flow_far = P.far;
     uint32_t (&big_caps)[4] = P.big_caps;
     uint32_t& flow_lds = P.lds;
-    double users = e->users_mean, rpm = e->rpm_mean;
+    double users = e->users_mean, rpm = e->rpm_mean, ram_mb_scale = 1.0, spike_extra = 0.0;
+    uint32_t cores_max = e->cores_max, cores_min = e->cores_max;
     std::vector<double> emean = e->edge_mean;
     for (uint32_t k = 0; k < sweep->n_overrides; ++k) {
         const af_override_t& o = sweep->overrides[k];
@@ -900,7 +903,24 @@ int plan_flow(const af_engine* e, const KArgs& a, const af_sweep_t* sweep, const
         if (o.param == AF_PARAM_GEN_USERS_MEAN) users = mx;
         else if (o.param == AF_PARAM_GEN_RPM_MEAN) rpm = mx;
         else if (o.param == AF_PARAM_EDGE_MEAN) emean[o.index] = mx;
+        else if (o.param == AF_PARAM_SRV_CORES) {
+            double mn = o.values[0];
+            for (uint32_t i = 1; i < n; ++i) mn = o.values[i] < mn ? o.values[i] : mn;
+            cores_max = std::max(cores_max, (uint32_t)mx);
+            cores_min = std::min(cores_min, (uint32_t)mn);
+        } else if (o.param == AF_PARAM_SRV_RAM_MB) ram_mb_scale = std::max(ram_mb_scale, mx / std::max(e->srv_ram_mb[o.index], 1e-9));
+        else if (o.param == AF_PARAM_EMARK_DELTA && mx > 0.0) spike_extra += mx;   // (an upper bound: every swept spike on every hop)
     }
+    std::vector<double> edge_spike = e->edge_spike;
+    for (double& sp : edge_spike) sp += spike_extra;
+    // per-server rings: core releases of the widest server of the sweep, departures of as many requests as its RAM admits
+    uint32_t g_ring = e->fargs.L.g_ring, c_ring = std::max(e->fargs.L.c_ring, cores_max);
+    if (ram_mb_scale > 1.0) {
+        const double lim = a.n_servers <= 4u ? 256.0 : 128.0;
+        const double want = std::min(lim, std::ceil((double)g_ring * ram_mb_scale));
+        g_ring = aff::pow2_ge((uint32_t)want);
+    }
+    if (c_ring > 64u) return fail(AF_ERR_CAPACITY, "cpu_cores column: the stage-parallel kernel handles at most 64 cores per server");
     const double sd = e->users_dist == AF_DIST_POISSON ? std::sqrt(users > 0.0 ? users : 0.0) : e->users_sigma;
     const double rate = (users + 4.0 * sd) * rpm / 60.0 + 1e-9;
     auto lat_mean = [&](int32_t ed) {
@@ -917,14 +937,14 @@ int plan_flow(const af_engine* e, const KArgs& a, const af_sweep_t* sweep, const
     auto slowest = [&](const std::vector<int32_t>& es) {
         int32_t best = -1;
         for (int32_t ed : es)
-            if (best < 0 || lat_mean(ed) + e->edge_spike[ed] > lat_mean(best) + e->edge_spike[best]) best = ed;
+            if (best < 0 || lat_mean(ed) + edge_spike[ed] > lat_mean(best) + edge_spike[best]) best = ed;
         return best;
     };
     if (!e->lb_edges.empty()) hops.push_back(slowest(e->lb_edges));
     hops.push_back(slowest(e->srv_out_edge));
     // time in a server: service + the M/D/1 wait for a core at the heaviest load of the sweep
     const double n_active = e->has_lb ? (double)(e->lb_edges.size() > 1 && a.n_srv_marks ? e->lb_edges.size() - 1 : e->lb_edges.size()) : 1.0;
-    const double rho = rate / n_active * e->cpu_max / (double)e->cores_max;
+    const double rho = rate / n_active * e->cpu_max / (double)cores_min;
     const double wait = rho < 0.9 ? rho * e->cpu_max / (2.0 * (1.0 - rho)) : 20.0 * e->cpu_max + 1.0;
     const double in_server = e->service_max + 4.0 * wait;
     // messages pending at a station ~ rate x time in flight towards it (the completion list also holds the server time)
@@ -934,8 +954,8 @@ int plan_flow(const af_engine* e, const KArgs& a, const af_sweep_t* sweep, const
     double pend = 0.0, burst = 0.0;
     std::vector<double> pend_of(hops.size(), 0.0);
     for (size_t h = 0; h < hops.size(); ++h) {
-        const double fly = lat_mean(hops[h]) + e->edge_spike[hops[h]] + (h + 1 == hops.size() ? in_server : 0.0);
-        burst = std::fmax(burst, rate * e->edge_spike[hops[h]]);
+        const double fly = lat_mean(hops[h]) + edge_spike[hops[h]] + (h + 1 == hops.size() ? in_server : 0.0);
+        burst = std::fmax(burst, rate * edge_spike[hops[h]]);
         pend_of[h] = rate * fly;
         pend = std::fmax(pend, rate * fly);
     }
@@ -993,7 +1013,7 @@ int plan_flow(const af_engine* e, const KArgs& a, const af_sweep_t* sweep, const
         for (size_t h = 1; h < hops.size(); ++h)
             if (lat_q(hops[h]) > lat_q(hops[worst])) worst = h;
         for (size_t h = 0; h < hops.size(); ++h)
-            tail_full += e->edge_spike[hops[h]] + (h == worst ? lat_q(hops[h]) : lat_mean(hops[h]) + 3.0 * lat_sd(hops[h]));
+            tail_full += edge_spike[hops[h]] + (h == worst ? lat_q(hops[h]) : lat_mean(hops[h]) + 3.0 * lat_sd(hops[h]));
     }
     const double tail = in_server;
     uint32_t rows = e->flow_ring_rows, win_rows = 0u;
@@ -1017,7 +1037,7 @@ int plan_flow(const af_engine* e, const KArgs& a, const af_sweep_t* sweep, const
             // a window of two or three batches binds less often: take it where it costs no occupancy (16 waves per CU
             // leave 10 KB each)
             if (!flow_big) {
-                const uint32_t no_ring = a.blob_bytes + aff::make_flow_layout(entries, 0u, e->fargs.L.g_ring, e->fargs.L.c_ring, a.n_edges,
+                const uint32_t no_ring = a.blob_bytes + aff::make_flow_layout(entries, 0u, g_ring, c_ring, a.n_edges,
                                                                               a.n_servers, a.n_edge_marks).n_words * 8u;
                 while (rows < aff::pow2_ge((uint32_t)(tail_rows + 2.0 * want_win)) && no_ring + 2u * rows * pitch * 4u <= 10u * 1024u) rows *= 2u;
             }
@@ -1033,14 +1053,14 @@ int plan_flow(const af_engine* e, const KArgs& a, const af_sweep_t* sweep, const
     }
     // long lists have to fit the LDS of a compute unit next to everything else: halve the longest until they do
     auto big_layout = [&](uint32_t ring) {
-        aff::FlowLayout L = aff::make_flow_layout(0u, ring, e->fargs.L.g_ring, e->fargs.L.c_ring, a.n_edges, a.n_servers, a.n_edge_marks, true, big_caps);
+        aff::FlowLayout L = aff::make_flow_layout(0u, ring, g_ring, c_ring, a.n_edges, a.n_servers, a.n_edge_marks, true, big_caps);
         while (a.blob_bytes + L.n_words * 8u > kLdsLimit) {
             uint32_t m = 0;
             for (uint32_t s = 1; s < 4u; ++s)
                 if (big_caps[s] > big_caps[m]) m = s;
             if (big_caps[m] <= 256u) break;
             big_caps[m] = (big_caps[m] / 2u + 63u) & ~63u;
-            L = aff::make_flow_layout(0u, ring, e->fargs.L.g_ring, e->fargs.L.c_ring, a.n_edges, a.n_servers, a.n_edge_marks, true, big_caps);
+            L = aff::make_flow_layout(0u, ring, g_ring, c_ring, a.n_edges, a.n_servers, a.n_edge_marks, true, big_caps);
         }
         return L;
     };
@@ -1051,7 +1071,7 @@ int plan_flow(const af_engine* e, const KArgs& a, const af_sweep_t* sweep, const
         }
         FL = big_layout(rows);
     } else {
-        FL = aff::make_flow_layout(entries, rows, e->fargs.L.g_ring, e->fargs.L.c_ring, a.n_edges, a.n_servers, a.n_edge_marks);
+        FL = aff::make_flow_layout(entries, rows, g_ring, c_ring, a.n_edges, a.n_servers, a.n_edge_marks);
     }
     FL.win_rows = win_rows;
     FL2 = big_layout(0u);   // second chance: tick differences in HBM (no reach limit)
@@ -1252,6 +1272,7 @@ int af_engine_create(const af_plan_t* plan, int device, const af_engine_options_
     e->edge_dist.assign(plan->edge_dist, plan->edge_dist + plan->n_edges);
     e->lb_edges.assign(plan->lb_edges, plan->lb_edges + plan->n_lb_edges);
     e->srv_out_edge.assign(plan->srv_out_edge, plan->srv_out_edge + plan->n_servers);
+    e->srv_ram_mb.assign(plan->srv_ram_mb, plan->srv_ram_mb + plan->n_servers);
     e->edge_spike.assign(plan->n_edges, 0.0);
     {
         std::vector<double> acc(plan->n_edges, 0.0);
@@ -1341,11 +1362,26 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
         if (o.param >= AF_PARAM_COUNT_ || !o.values) return fail(AF_ERR_INVALID, "bad override");
         const uint32_t lim = (o.param >= AF_PARAM_EDGE_MEAN && o.param <= AF_PARAM_EDGE_DROPOUT) ? a.n_edges
                              : (o.param == AF_PARAM_STEP_TIME)                                   ? (uint32_t)e->row_of_step.size()
+                             : (o.param == AF_PARAM_SRV_CORES || o.param == AF_PARAM_SRV_RAM_MB)  ? a.n_servers
+                             : (o.param >= AF_PARAM_EMARK_TIME && o.param <= AF_PARAM_EMARK_EDGE) ? a.n_edge_marks
+                             : (o.param >= AF_PARAM_SMARK_TIME && o.param <= AF_PARAM_SMARK_DOWN) ? a.n_srv_marks
                                                                                                  : 1u;
         if (o.index >= lim) return fail(AF_ERR_INVALID, "override index out of range");
+        // integral columns are checked here: the kernels only ever see values inside the plan's ranges
+        for (uint32_t i = 0; i < n; ++i) {
+            const double v = o.values[i];
+            if (o.param == AF_PARAM_SRV_CORES && !(v >= 1.0 && v <= 65535.0 && v == std::floor(v)))
+                return fail(AF_ERR_INVALID, "cpu_cores column: integral values within 1..65535");
+            if (o.param == AF_PARAM_EMARK_EDGE && !(v >= 0.0 && v < (double)a.n_edges && v == std::floor(v)))
+                return fail(AF_ERR_INVALID, "edge-mark column names an unknown edge");
+            if (o.param == AF_PARAM_SMARK_LB_EDGE && !(v >= -1.0 && v < (double)a.n_edges && v == std::floor(v)))
+                return fail(AF_ERR_INVALID, "server-mark column names an unknown LB edge");
+            if (o.param == AF_PARAM_GEN_WINDOW && !(v > 0.0)) return fail(AF_ERR_INVALID, "user_sampling_window column must be positive");
+            if (o.param == AF_PARAM_SRV_RAM_MB && !(v > 0.0)) return fail(AF_ERR_INVALID, "ram_mb column must be positive");
+        }
         mask |= 1u << o.param;
     }
-    a.L = af::make_layout(e->request_capacity, e->fifo_capacity, a.n_edges, a.n_servers, a.n_lb_edges, a.n_rows, mask);
+    a.L = af::make_layout(e->request_capacity, e->fifo_capacity, a.n_edges, a.n_servers, a.n_lb_edges, a.n_rows, mask, a.n_edge_marks, a.n_srv_marks);
     const uint64_t bytes_per_lane = af::layout_bytes_per_lane(a.L);
 
     // ---- upload seeds + override tables (one staging buffer) -------------------
@@ -1800,7 +1836,7 @@ int af_engine_jit_spec(af_engine_t* e, const af_sweep_t* sweep, const af_outputs
         if (sweep->overrides[k].param >= AF_PARAM_COUNT_) return fail(AF_ERR_INVALID, "bad override");
         mask |= 1u << sweep->overrides[k].param;
     }
-    a.L = af::make_layout(e->request_capacity, e->fifo_capacity, a.n_edges, a.n_servers, a.n_lb_edges, a.n_rows, mask);
+    a.L = af::make_layout(e->request_capacity, e->fifo_capacity, a.n_edges, a.n_servers, a.n_lb_edges, a.n_rows, mask, a.n_edge_marks, a.n_srv_marks);
     a.clock_cap = out->clock_capacity;
     a.tick_cap = out->tick_capacity;
     a.clock = out->clock;      // only their presence enters the spec

@@ -34,41 +34,150 @@ DEFAULT_SEED_BASE = 0x5EED0000  # BASELINE config 2: scenario i uses Philox key 
 
 _EDGE_RE = re.compile(r"^topology_graph\.edges\[(?P<id>[^\]]+)\]\.(?P<f>latency\.mean|latency\.variance|dropout_rate)$")
 _STEP_RE = re.compile(
-    r"^topology_graph\.nodes\.servers\[(?P<sid>[^\]]+)\]\.endpoints\[(?P<ep>\d+)\]\.steps\[(?P<k>\d+)\]\.(cpu_time|io_waiting_time)$"
+    r"^topology_graph\.nodes\.servers\[(?P<sid>[^\]]+)\]\.endpoints\[(?P<ep>\d+)\]\.steps\[(?P<k>\d+)\]\.(?P<f>cpu_time|io_waiting_time)$"
 )
+_RES_RE = re.compile(r"^topology_graph\.nodes\.servers\[(?P<sid>[^\]]+)\]\.server_resources\.(?P<f>cpu_cores|ram_mb)$")
+_EVENT_RE = re.compile(r"^events\[(?P<id>[^\]]+)\]\.(?P<f>start\.t_start|end\.t_end|start\.spike_s)$")
 
 
 #: payloads (by content hash) whose sweeps met instants shared by several timed events
 _SHARED_INSTANTS_SEEN: dict[str, bool] = {}
 
 
+def _as_int(key: str, value: float) -> int:
+    if float(value) != int(value):
+        msg = f"sweep key {key!r}: {value!r} is not an integer"
+        raise ValueError(msg)
+    return int(value)
+
+
+def write_point(payload: dict, key: str, value: float) -> None:
+    """Write ONE sweep value into a (deep-copied, normalised) payload dict at its YAML-style path: the payload a user
+    of the reference would have built for that grid point.  Used for per-point validation through the payload models
+    and to lower the event timelines of each distinct combination of event parameters."""
+    value = float(value)
+    if key.startswith("rqs_input.avg_active_users."):
+        payload["rqs_input"]["avg_active_users"][key.rsplit(".", 1)[1]] = value
+    elif key == "rqs_input.avg_request_per_minute_per_user.mean":
+        payload["rqs_input"]["avg_request_per_minute_per_user"]["mean"] = value
+    elif key == "rqs_input.user_sampling_window":
+        payload["rqs_input"]["user_sampling_window"] = _as_int(key, value)       # an int field (rqs_generator.py:17-27)
+    elif m := _EDGE_RE.match(key):
+        hit = False
+        for e in payload["topology_graph"]["edges"]:
+            if m["id"] in ("*", e["id"]):
+                hit = True
+                if m["f"] == "dropout_rate":
+                    e["dropout_rate"] = value
+                else:
+                    e["latency"][m["f"].split(".")[1]] = value
+        if not hit:
+            msg = f"sweep key {key!r}: unknown edge id {m['id']!r}"
+            raise ValueError(msg)
+    elif m := _STEP_RE.match(key):
+        srv = next((s for s in payload["topology_graph"]["nodes"]["servers"] if s["id"] == m["sid"]), None)
+        if srv is None:
+            msg = f"sweep key {key!r}: unknown server id"
+            raise ValueError(msg)
+        try:
+            step = srv["endpoints"][int(m["ep"])]["steps"][int(m["k"])]
+        except IndexError:
+            msg = f"sweep key {key!r}: no such step"
+            raise ValueError(msg) from None
+        if m["f"] not in step["step_operation"]:
+            msg = f"sweep key {key!r}: not a CPU or I/O step"
+            raise ValueError(msg)
+        step["step_operation"] = {m["f"]: value}
+    elif m := _RES_RE.match(key):
+        srv = next((s for s in payload["topology_graph"]["nodes"]["servers"] if s["id"] == m["sid"]), None)
+        if srv is None:
+            msg = f"sweep key {key!r}: unknown server id"
+            raise ValueError(msg)
+        srv["server_resources"][m["f"]] = _as_int(key, value)                  # PositiveInt fields (nodes.py:58-69)
+    elif m := _EVENT_RE.match(key):
+        ev = next((v for v in (payload.get("events") or []) if v["event_id"] == m["id"]), None)
+        if ev is None:
+            msg = f"sweep key {key!r}: unknown event id {m['id']!r}"
+            raise ValueError(msg)
+        part, field = m["f"].split(".")
+        if field == "spike_s" and ev["start"].get("spike_s") is None:
+            msg = f"sweep key {key!r}: the event is not a network spike"
+            raise ValueError(msg)
+        ev[part][field] = value
+    else:
+        msg = f"unsupported sweep key {key!r}"
+        raise ValueError(msg)
+
+
+def validate_points(plan: DevicePlan, columns: Mapping[str, np.ndarray], n: int) -> int:
+    """Per-point validation of a sweep through the payload models -- the reference's own
+    ``SimulationPayload.model_validate`` when ``asyncflow`` is importable, else the structural validators of
+    asyncflow_amd/payload.py (``normalize_payload`` picks) -- at the points that carry every axis's extremes: the
+    scenarios holding the minimum and the maximum of each column, plus the first and the last one.  Every column is a
+    monotone constraint of the schema (positivity, ranges, t_start < t_end against the other columns of the SAME
+    scenario), so a sweep whose extremes validate cannot hide an invalid interior point except through cross-column
+    constraints, which the event columns cover exhaustively (every distinct combination is lowered, `resolve_sweep`).
+    Returns the number of payloads validated; raises ``ValueError`` (pydantic's ValidationError is one)."""
+    import copy
+
+    from .payload import normalize_payload
+
+    picks = {0, n - 1}
+    for col in columns.values():
+        picks.add(int(np.argmin(col)))
+        picks.add(int(np.argmax(col)))
+    for i in sorted(picks):
+        point = copy.deepcopy(plan.payload)
+        for key, col in columns.items():
+            write_point(point, key, col[i])
+        try:
+            normalize_payload(point)
+        except ValueError as exc:
+            msg = f"sweep point {i} ({ {k: float(c[i]) for k, c in columns.items()} }) is not a valid payload: {exc}"
+            raise ValueError(msg) from exc
+    return len(picks)
+
+
 def resolve_sweep(plan: DevicePlan, sweep: Mapping[str, Any] | None, n: int) -> list[tuple[int, int, np.ndarray, str]]:
     """Map YAML-style paths to ``af_override_t`` columns.
 
-    Accepted keys (values: one float per scenario):
+    Accepted keys (values: one float per scenario, or one for all):
       rqs_input.avg_active_users.mean | .variance
       rqs_input.avg_request_per_minute_per_user.mean
+      rqs_input.user_sampling_window
       topology_graph.edges[<edge id>|*].latency.mean | .latency.variance | .dropout_rate
       topology_graph.nodes.servers[<id>].endpoints[<j>].steps[<k>].cpu_time | .io_waiting_time
+      topology_graph.nodes.servers[<id>].server_resources.cpu_cores | .ram_mb
+      events[<event id>].start.t_start | .end.t_end | .start.spike_s
+
+    Every point is validated by the payload models (`validate_points`).  Event columns do not map one to one to engine
+    columns: the reference sorts the marks of all events into two timelines (injection.py:142-151) and re-accumulates
+    the waits between them (:181-188), so each DISTINCT combination of event values is lowered on its own (`lower()`:
+    validation + timelines) and every mark slot of the plan gets its (time, delta, edge) / (time, LB edge, down)
+    columns -- scenarios whose marks sort differently are exact too.
     """
     out: list[tuple[int, int, np.ndarray, str]] = []
-    for key, values in (sweep or {}).items():
-        col = np.ascontiguousarray(np.broadcast_to(np.asarray(values, dtype=np.float64), (n,)))
+    cols = {key: np.ascontiguousarray(np.broadcast_to(np.asarray(values, dtype=np.float64), (n,))) for key, values in (sweep or {}).items()}
+    code = _abi.PARAM_CODES
+    event_cols: dict[str, np.ndarray] = {}
+    for key, col in cols.items():
         if key == "rqs_input.avg_active_users.mean":
-            out.append((_abi.PARAM_CODES["gen_users_mean"], 0, col, key))
+            out.append((code["gen_users_mean"], 0, col, key))
         elif key == "rqs_input.avg_active_users.variance":
-            out.append((_abi.PARAM_CODES["gen_users_sigma"], 0, col, key))
+            out.append((code["gen_users_sigma"], 0, col, key))
         elif key == "rqs_input.avg_request_per_minute_per_user.mean":
-            out.append((_abi.PARAM_CODES["gen_rpm_mean"], 0, col, key))
+            out.append((code["gen_rpm_mean"], 0, col, key))
+        elif key == "rqs_input.user_sampling_window":
+            out.append((code["gen_window"], 0, col, key))
         elif m := _EDGE_RE.match(key):
-            code = {"latency.mean": "edge_mean", "latency.variance": "edge_sigma", "dropout_rate": "edge_dropout"}[m["f"]]
+            name = {"latency.mean": "edge_mean", "latency.variance": "edge_sigma", "dropout_rate": "edge_dropout"}[m["f"]]
             ids = plan.edge_ids if m["id"] == "*" else [m["id"]]
             for eid in ids:
                 if eid not in plan.edge_ids:
                     msg = f"sweep key {key!r}: unknown edge id {eid!r}"
                     raise ValueError(msg)
-                out.append((_abi.PARAM_CODES[code], plan.edge_ids.index(eid), col, key))
-            if code == "edge_mean" and np.any(col <= 0):
+                out.append((code[name], plan.edge_ids.index(eid), col, key))
+            if name == "edge_mean" and np.any(col <= 0):
                 msg = f"sweep key {key!r}: edge latency mean must be positive"  # edges.py:79-81
                 raise ValueError(msg)
         elif m := _STEP_RE.match(key):
@@ -82,10 +191,68 @@ def resolve_sweep(plan: DevicePlan, sweep: Mapping[str, Any] | None, n: int) -> 
             if np.any(col <= 0):
                 msg = f"sweep key {key!r}: step times must be positive"   # PositiveFloat in the reference schema
                 raise ValueError(msg)
-            out.append((_abi.PARAM_CODES["step_time"], idx, col, key))
+            out.append((code["step_time"], idx, col, key))
+        elif m := _RES_RE.match(key):
+            if m["sid"] not in plan.server_ids:
+                msg = f"sweep key {key!r}: unknown server id"
+                raise ValueError(msg)
+            if np.any(col != np.floor(col)) or np.any(col < 1):
+                msg = f"sweep key {key!r}: positive integers expected"     # PositiveInt (nodes.py:58-69)
+                raise ValueError(msg)
+            out.append((code["srv_cores" if m["f"] == "cpu_cores" else "srv_ram_mb"], plan.server_ids.index(m["sid"]), col, key))
+        elif _EVENT_RE.match(key):
+            event_cols[key] = col
         else:
             msg = f"unsupported sweep key {key!r}"
             raise ValueError(msg)
+    if cols:
+        validate_points(plan, cols, n)
+    if event_cols:
+        out.extend(_event_columns(plan, event_cols, n))
+    return out
+
+
+def _event_columns(plan: DevicePlan, event_cols: Mapping[str, np.ndarray], n: int) -> list[tuple[int, int, np.ndarray, str]]:
+    """Timeline columns of a sweep over event parameters: one `lower()` per distinct combination of event values."""
+    import copy
+
+    keys = list(event_cols)
+    table = np.stack([event_cols[k] for k in keys], axis=1)                     # [n, k]
+    uniq, inverse = np.unique(table, axis=0, return_inverse=True)
+    inverse = np.asarray(inverse).reshape(-1)
+    if len(uniq) > 20_000:
+        msg = f"{len(uniq)} distinct combinations of event parameters: each is validated and lowered on its own (limit 20 000)"
+        raise ValueError(msg)
+    n_em, n_sm = len(plan.emark_time), len(plan.smark_time)
+    em = np.zeros((len(uniq), 3, n_em))
+    sm = np.zeros((len(uniq), 3, n_sm))
+    for u, row in enumerate(uniq):
+        point = copy.deepcopy(plan.payload)
+        for key, value in zip(keys, row):
+            write_point(point, key, value)
+        try:
+            lp = lower(point)                 # validates (payload models) and builds the two sorted timelines
+        except ValueError as exc:
+            msg = f"event sweep point { {k: float(v) for k, v in zip(keys, row)} } is not a valid payload: {exc}"
+            raise ValueError(msg) from exc
+        if len(lp.emark_time) != n_em or len(lp.smark_time) != n_sm:
+            msg = "an event sweep must not change the number of timeline marks"
+            raise ValueError(msg)
+        em[u] = np.stack([lp.emark_time, lp.emark_delta, lp.emark_edge.astype(np.float64)]) if n_em else em[u]
+        sm[u] = np.stack([lp.smark_time, lp.smark_lb_edge.astype(np.float64), lp.smark_down.astype(np.float64)]) if n_sm else sm[u]
+    out: list[tuple[int, int, np.ndarray, str]] = []
+    code = _abi.PARAM_CODES
+    label = "events[...]: " + ", ".join(keys)
+    for i in range(n_em):     # (a slot that equals the plan's in every scenario needs no column)
+        for j, name in enumerate(("emark_time", "emark_delta", "emark_edge")):
+            colv = np.ascontiguousarray(em[inverse, j, i])
+            if np.any(colv != (plan.emark_time, plan.emark_delta, plan.emark_edge)[j][i]):
+                out.append((code[name], i, colv, f"{label} -> {name}[{i}]"))
+    for i in range(n_sm):
+        for j, name in enumerate(("smark_time", "smark_lb_edge", "smark_down")):
+            colv = np.ascontiguousarray(sm[inverse, j, i])
+            if np.any(colv != (plan.smark_time, plan.smark_lb_edge, plan.smark_down)[j][i]):
+                out.append((code[name], i, colv, f"{label} -> {name}[{i}]"))
     return out
 
 
@@ -318,8 +485,9 @@ class SimulationRunner:
             eng.close()
             if int(stats.shared_instant_scenarios) > 0:
                 _SHARED_INSTANTS_SEEN[self._plan_key()] = True
+            user_cols = {k: np.ascontiguousarray(np.broadcast_to(np.asarray(v, dtype=np.float64), (n,))) for k, v in self.sweep.items()}
             res = BatchedResults(self.plan, self.seeds, counts, clock, samples, stats,
-                                 time.perf_counter() - t0, {k: v for _, _, v, k in overrides},
+                                 time.perf_counter() - t0, user_cols,
                                  online_hist=online_hist, online_rps=online_rps, online_hist_max=o_max)
             res.flow_reason = flow_reason
             over = int(np.bitwise_or.reduce(res.flags)) & _abi.FATAL_FLAGS

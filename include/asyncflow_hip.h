@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define AF_ABI_VERSION 3
+#define AF_ABI_VERSION 4
 
 /* ---- status codes ------------------------------------------------------ */
 enum af_status {
@@ -142,7 +142,20 @@ enum af_param {
     AF_PARAM_EDGE_SIGMA = 4,    /* index = edge  */
     AF_PARAM_EDGE_DROPOUT = 5,  /* index = edge  */
     AF_PARAM_STEP_TIME = 6,     /* index = step  */
-    AF_PARAM_COUNT_ = 7
+    /* ABI 4 -- sweeps over the sampling window, server resources and the injected events
+     * (schemas/workload/rqs_generator.py:33-45, schemas/topology/nodes.py:58-69, schemas/events/injection.py:25-119).
+     * Timeline columns address mark SLOTS of the plan's pre-sorted timelines: a scenario whose event
+     * times sort differently passes its own (time, delta, edge) per slot, so any order is exact. */
+    AF_PARAM_GEN_WINDOW = 7,    /* user_sampling_window (s)                                  */
+    AF_PARAM_SRV_CORES = 8,     /* index = server; integral value within 1..65535            */
+    AF_PARAM_SRV_RAM_MB = 9,    /* index = server                                            */
+    AF_PARAM_EMARK_TIME = 10,   /* index = edge-mark slot: emark_time                        */
+    AF_PARAM_EMARK_DELTA = 11,  /*                         emark_delta (+spike_s / -spike_s) */
+    AF_PARAM_EMARK_EDGE = 12,   /*                         emark_edge (integral value)       */
+    AF_PARAM_SMARK_TIME = 13,   /* index = server-mark slot: smark_time                      */
+    AF_PARAM_SMARK_LB_EDGE = 14,/*                           smark_lb_edge (-1 = not behind the LB) */
+    AF_PARAM_SMARK_DOWN = 15,   /*                           smark_down (0 / 1)              */
+    AF_PARAM_COUNT_ = 16
 };
 
 typedef struct af_override {

@@ -124,6 +124,20 @@ def apply_overrides(plan: DevicePlan, overrides: dict[tuple[str, int], float]) -
             plan.edge_dropout[index] = value
         elif name == "step_time":
             plan.step_time[index] = value
+        elif name == "gen_window":
+            plan.gen_window_s = float(value)
+        elif name == "srv_cores":
+            plan.srv_cores[index] = int(value)
+        elif name == "srv_ram_mb":
+            plan.srv_ram_mb[index] = value
+        elif name in ("emark_time", "emark_delta", "smark_time"):
+            getattr(plan, name)[index] = value
+        elif name == "emark_edge":
+            plan.emark_edge[index] = int(value)
+        elif name == "smark_lb_edge":
+            plan.smark_lb_edge[index] = int(value)
+        elif name == "smark_down":
+            plan.smark_down[index] = int(value != 0)
         else:
             msg = f"unknown override {name!r}"
             raise KeyError(msg)

@@ -7,6 +7,8 @@
 // tests/hostcheck/build.py, loaded only by tests/, and is NOT a fallback: the
 // asyncflow_amd package neither builds, loads nor knows about it, and raises if
 // the HIP library or a GPU is missing.
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -49,7 +51,7 @@ extern "C" int hc_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ovr, co
 
     uint32_t mask = 0;
     std::vector<uint32_t> idx(n_ovr ? n_ovr : 1, 0u);
-    double users_mean = p->gen_users_mean, users_sigma = p->gen_users_sigma, rpm = p->gen_rpm_mean;
+    double users_mean = p->gen_users_mean, users_sigma = p->gen_users_sigma, rpm = p->gen_rpm_mean, window_s = p->gen_window_s;
     std::vector<double> e_mean(p->edge_mean, p->edge_mean + p->n_edges), e_sig(p->edge_sigma, p->edge_sigma + p->n_edges),
         e_drop(p->edge_dropout, p->edge_dropout + p->n_edges);
     for (uint32_t k = 0; k < n_ovr; ++k) {
@@ -62,6 +64,7 @@ extern "C" int hc_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ovr, co
             case AF_PARAM_EDGE_MEAN: e_mean[ovr_index[k]] = ovr_value[k]; break;
             case AF_PARAM_EDGE_SIGMA: e_sig[ovr_index[k]] = ovr_value[k]; break;
             case AF_PARAM_EDGE_DROPOUT: e_drop[ovr_index[k]] = ovr_value[k]; break;
+            case AF_PARAM_GEN_WINDOW: window_s = ovr_value[k]; break;
             default: break;
         }
     }
@@ -75,13 +78,13 @@ extern "C" int hc_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ovr, co
         uint32_t k = 0;
         for (; k < n_draw; ++k) {
             const double gap = af::gen_next_gap(g, seed, p->gen_users_dist, users_mean, users_sigma, rpm,
-                                                p->gen_window_s, p->total_time);
+                                                window_s, p->total_time);
             if (gap < 0.0) break;
             t = t + gap;
             draws[k] = t;
         }
         if (k == n_draw) {
-            if (af::gen_next_gap(g, seed, p->gen_users_dist, users_mean, users_sigma, rpm, p->gen_window_s,
+            if (af::gen_next_gap(g, seed, p->gen_users_dist, users_mean, users_sigma, rpm, window_s,
                                  p->total_time) >= 0.0)
                 flags_in |= AF_FLAG_DRAW_OVERFLOW;
         }
@@ -91,7 +94,7 @@ extern "C" int hc_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ovr, co
         for (uint32_t i = 0; i < n_draw; ++i)
             draws[(size_t)(1 + e) * n_draw + i] = af::pre_edge_draw(seed, e, i, p->edge_dist[e], e_mean[e], e_sig[e], e_drop[e]);
 
-    const af::Layout L = af::make_layout(cap, fcap, p->n_edges, p->n_servers, p->n_lb_edges, pk.n_rows, mask);
+    const af::Layout L = af::make_layout(cap, fcap, p->n_edges, p->n_servers, p->n_lb_edges, pk.n_rows, mask, p->n_edge_marks, p->n_srv_marks);
     std::vector<uint64_t> w(L.n_words ? L.n_words : 1, 0ull);
     const uint32_t pitch = (p->n_edges + 3u * p->n_servers + 3u) & ~3u;
     af::LaneOut O{clock, samples, counts, clock_cap, tick_cap, pitch, g_online_hist, g_online_rps, g_online_bins, g_online_buckets,
@@ -167,10 +170,11 @@ extern "C" int hc_flow_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ov
     af::PackedPlan pk;
     if (!af::pack_plan(*p, pk).empty()) return AF_ERR_INVALID;
 
-    double users_mean = p->gen_users_mean, users_sigma = p->gen_users_sigma, rpm = p->gen_rpm_mean;
+    double users_mean = p->gen_users_mean, users_sigma = p->gen_users_sigma, rpm = p->gen_rpm_mean, window_s = p->gen_window_s;
     std::vector<uint32_t> idx(n_ovr ? n_ovr : 1, 0u);
     for (uint32_t k = 0; k < n_ovr; ++k) {
         idx[k] = ovr_param[k] == AF_PARAM_STEP_TIME ? pk.row_of_step[ovr_index[k]] : ovr_index[k];
+        if (ovr_param[k] == AF_PARAM_GEN_WINDOW) window_s = ovr_value[k];
         if (ovr_param[k] == AF_PARAM_GEN_USERS_MEAN) users_mean = ovr_value[k];
         if (ovr_param[k] == AF_PARAM_GEN_USERS_SIGMA) users_sigma = ovr_value[k];
         if (ovr_param[k] == AF_PARAM_GEN_RPM_MEAN) rpm = ovr_value[k];
@@ -184,12 +188,12 @@ extern "C" int hc_flow_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ov
         double t = 0.0;
         uint32_t k = 0;
         for (; k < n_draw; ++k) {
-            const double gap = af::gen_next_gap(g, seed, p->gen_users_dist, users_mean, users_sigma, rpm, p->gen_window_s, p->total_time);
+            const double gap = af::gen_next_gap(g, seed, p->gen_users_dist, users_mean, users_sigma, rpm, window_s, p->total_time);
             if (gap < 0.0) break;
             t = t + gap;
             arrivals[k] = t;
         }
-        if (k == n_draw && af::gen_next_gap(g, seed, p->gen_users_dist, users_mean, users_sigma, rpm, p->gen_window_s, p->total_time) >= 0.0)
+        if (k == n_draw && af::gen_next_gap(g, seed, p->gen_users_dist, users_mean, users_sigma, rpm, window_s, p->total_time) >= 0.0)
             flags_in |= AF_FLAG_DRAW_OVERFLOW;
     }
     const aff::TickTable tt = aff::make_tick_table(p->sample_period, p->total_time);
@@ -215,6 +219,19 @@ extern "C" int hc_flow_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ov
     a.blob_bytes = (uint32_t)(pk.words.size() * 8u);
     a.blob = reinterpret_cast<const unsigned char*>(pk.words.data());
     a.L = aff::choose_flow_layout(*p, ipl, ring_rows);
+    {   // per-scenario server resources (AF_PARAM_SRV_CORES / _RAM_MB): the rings must hold the overridden sizes (af_engine_run: plan_flow)
+        uint32_t c_ring = a.L.c_ring, g_ring = a.L.g_ring;
+        for (uint32_t k = 0; k < n_ovr; ++k) {
+            if (ovr_param[k] == AF_PARAM_SRV_CORES && (uint32_t)ovr_value[k] > c_ring) c_ring = (uint32_t)ovr_value[k];
+            if (ovr_param[k] == AF_PARAM_SRV_RAM_MB) {
+                const double scale = ovr_value[k] / p->srv_ram_mb[ovr_index[k]];
+                const double want = std::min(256.0, std::ceil((double)a.L.g_ring * scale));
+                if (want > (double)g_ring) g_ring = aff::pow2_ge((uint32_t)want);
+            }
+        }
+        if (c_ring != a.L.c_ring || g_ring != a.L.g_ring)
+            a.L = aff::make_flow_layout(a.L.cap, a.L.ring_rows, g_ring, c_ring, p->n_edges, p->n_servers, p->n_edge_marks);
+    }
     if (robust) {
         uint32_t caps4[4];
         for (uint32_t s = 0; s < 4u; ++s) caps4[s] = (big_which == 0u || big_which == s + 1u) ? big_cap : 256u;

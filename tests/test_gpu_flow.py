@@ -416,3 +416,38 @@ def test_far_and_near_lean_instantiations_agree(monkeypatch):
     assert near.engine_stats.flow_fallback == 0 and far.engine_stats.flow_fallback == 0
     _same_batches(near, far)
     _assert_scenario(far[5], ol.simulate(lower(payload), int(seeds[5])), "scenario 5")
+
+
+# ---------------------------------------------------------------- sweeps over events / resources / window
+def test_sweep_over_spike_size_and_outage_window_matches_the_oracle_per_point():
+    """BASELINE config 4's topology and events (event_inj_lb.yml): a grid spike size x outage window x users, plus the
+    server-resource and sampling-window axes; every scenario against the oracle run on the payload with that point's
+    values WRITTEN INTO it (the reference's way of running the point), on both kernel families."""
+    from asyncflow_amd.runner import write_point
+    from asyncflow_amd.sweep import expand_grid
+
+    base = lb_with_events(users=300, horizon=120, scale=0.2)
+    ev = {e["event_id"]: e for e in lower(base).payload["events"]}
+    t0, t1 = ev["ev-srv1-down"]["start"]["t_start"], ev["ev-srv1-down"]["end"]["t_end"]
+    grid = expand_grid({"events[ev-spike-1].start.spike_s": [0.005, 0.02, 0.08],
+                        "events[ev-srv1-down].end.t_end": [t1 - 5.0, t1, t1 + 10.0],
+                        "rqs_input.avg_active_users.mean": [80.0, 300.0]}, replicas=2, seed_base=0xC0F40000)
+    n = len(grid)
+    cols = dict(grid.columns)
+    cols["events[ev-srv1-down].start.t_start"] = np.where(cols["events[ev-srv1-down].end.t_end"] > t1, t0 + 4.0, t0)
+    cols["topology_graph.nodes.servers[srv-1].server_resources.cpu_cores"] = np.tile([1.0, 2.0, 3.0], n // 3)
+    cols["topology_graph.nodes.servers[srv-2].server_resources.ram_mb"] = np.tile([512.0, 2048.0], n // 2)
+    cols["rqs_input.user_sampling_window"] = np.tile([5.0, 60.0, 20.0, 1.0], n // 4)
+    res = _runner(base, seeds=grid.seeds, sweep=cols).run()
+    st = res.engine_stats
+    assert st.flow_scenarios == n and st.flow_to_next_event <= 2
+    plan = lower(base)
+    for i in range(n):
+        point = copy.deepcopy(plan.payload)
+        for key, col in cols.items():
+            write_point(point, key, col[i])
+        _assert_scenario(res[i], ol.simulate(lower(point), int(grid.seeds[i])), f"point {i}")
+    _same_batches(res, _runner(base, seeds=grid.seeds, sweep=cols, flow=False).run())
+    special = _runner(base, seeds=grid.seeds, sweep=cols, specialise=True).run()     # the plan-specialised build patches the same blob
+    assert special.engine_stats.specialised_launches >= 1
+    _same_batches(res, special)

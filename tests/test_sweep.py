@@ -49,3 +49,128 @@ def test_columns_resolve_against_a_plan_and_are_validated():
         expand_grid({USERS: []})
     with pytest.raises(ValueError):
         expand_grid({USERS: [1.0]}, order_by_load=RTT)
+
+
+# ------------------------------------------------------------------------------------------------
+# round 3: event parameters, server resources and the sampling window as sweep axes
+# ------------------------------------------------------------------------------------------------
+import copy  # noqa: E402
+
+from asyncflow_amd.runner import write_point  # noqa: E402
+from asyncflow_amd.workloads import lb_with_events  # noqa: E402
+from oracle import oracle_lib as ol  # noqa: E402
+from tests.hostcheck import build as hc  # noqa: E402
+
+SPIKE = "events[ev-spike-1].start.spike_s"
+DOWN_T0 = "events[ev-srv1-down].start.t_start"
+DOWN_T1 = "events[ev-srv1-down].end.t_end"
+CORES = "topology_graph.nodes.servers[srv-1].server_resources.cpu_cores"
+RAM = "topology_graph.nodes.servers[srv-2].server_resources.ram_mb"
+WINDOW = "rqs_input.user_sampling_window"
+
+
+def _point_payload(plan, columns, i):
+    """The payload a user of the reference would have written for sweep point i."""
+    p = copy.deepcopy(plan.payload)
+    for key, col in columns.items():
+        write_point(p, key, np.broadcast_to(np.asarray(col, dtype=np.float64), (len(col),))[i] if np.ndim(col) else col)
+    return p
+
+
+def _engine_overrides(cols, i):
+    names = {v: k for k, v in __import__("asyncflow_amd")._abi.PARAM_CODES.items()}
+    return [(names[c], idx, float(v[i])) for c, idx, v, _ in cols]
+
+
+def test_event_resource_and_window_axes_become_engine_columns():
+    plan = lower(lb_with_events(users=200, horizon=60, scale=0.1))
+    n = 6
+    sweep = {SPIKE: np.linspace(0.01, 0.06, n), CORES: [1, 2, 3, 1, 2, 3], RAM: [1024, 2048] * 3, WINDOW: 30}
+    cols = resolve_sweep(plan, sweep, n)
+    by_code = {}
+    for c, idx, v, _ in cols:
+        by_code.setdefault(c, []).append((idx, v))
+    code = __import__("asyncflow_amd")._abi.PARAM_CODES
+    assert [i for i, _ in by_code[code["srv_cores"]]] == [0] and [i for i, _ in by_code[code["srv_ram_mb"]]] == [1]
+    assert by_code[code["gen_window"]][0][1].tolist() == [30.0] * n
+    # the spike of ev-spike-1 sits in two mark slots (start: +spike, end: -spike); nothing else changes
+    deltas = sorted(by_code[code["emark_delta"]])
+    assert len(deltas) == 2 and np.allclose(deltas[0][1], -deltas[1][1]) and code["emark_time"] not in by_code
+    assert code["smark_time"] not in by_code
+
+
+def test_an_outage_window_that_overtakes_another_event_reorders_the_timeline_slots():
+    """srv-1's outage is swept from before to after the second spike's start: the server timeline keeps its slots,
+    but WHICH event a slot belongs to changes with the scenario -- every slot gets its own columns."""
+    base = lb_with_events(users=200, horizon=60, scale=0.1)
+    plan = lower(base)
+    t0 = np.array([18.0, 43.0, 50.0])     # (srv-2 is down during [36, 42]: both down at once is invalid)
+    sweep = {DOWN_T0: t0, DOWN_T1: t0 + 3.0}
+    cols = resolve_sweep(plan, sweep, 3)
+    code = __import__("asyncflow_amd")._abi.PARAM_CODES
+    edges = [v for c, _, v, _ in cols if c == code["smark_lb_edge"]]
+    assert edges, "the slots change owner: their LB-edge columns must be present"
+    for i in range(3):
+        want = lower(_point_payload(plan, sweep, i))
+        got = copy.deepcopy(plan)
+        ol.apply_overrides(got, {(k, idx): v for k, idx, v in _engine_overrides(cols, i)})
+        assert np.array_equal(got.smark_time, want.smark_time) and np.array_equal(got.smark_lb_edge, want.smark_lb_edge)
+        assert np.array_equal(got.smark_down, want.smark_down)
+
+
+def test_invalid_points_are_rejected_by_the_payload_models():
+    plan = lower(lb_with_events(users=200, horizon=60, scale=0.1))
+    with pytest.raises(ValueError, match="not a valid payload"):
+        resolve_sweep(plan, {DOWN_T0: [18.0, 30.0], DOWN_T1: [24.0, 29.0]}, 2)          # t_start >= t_end (injection.py:94-98)
+    with pytest.raises(ValueError, match="not a valid payload"):
+        resolve_sweep(plan, {RAM: [2048, 128]}, 2)                                      # ram_mb >= 256 (nodes.py:65-68)
+    with pytest.raises(ValueError, match="integer"):
+        resolve_sweep(plan, {CORES: [1.5, 2]}, 2)
+    with pytest.raises(ValueError, match="not a valid payload"):
+        resolve_sweep(plan, {WINDOW: [30, 500]}, 2)                                     # window within [1, 120] s
+    with pytest.raises(ValueError, match="not a network spike"):
+        resolve_sweep(plan, {"events[ev-srv1-down].start.spike_s": [0.1, 0.2]}, 2)
+    with pytest.raises(ValueError, match="unknown event"):
+        resolve_sweep(plan, {"events[nope].start.t_start": [1.0, 2.0]}, 2)
+    # both servers down at once leaves the load balancer without a target (payload.py / plan.lower)
+    with pytest.raises(ValueError, match="not a valid payload"):
+        resolve_sweep(plan, {DOWN_T0: [18.0, 36.5], DOWN_T1: [24.0, 41.0]}, 2)
+
+
+@pytest.mark.parametrize("kernel", ["next-event", "flow"])
+def test_swept_points_match_the_oracle_run_on_the_written_out_payload(kernel):
+    """Every new axis at once, on both kernel families (host builds: the next-event core for one lane, the
+    stage-parallel kernel on the wave emulator): scenario i of the sweep == the oracle on the payload with the values
+    of point i written into it -- the reference's own way of running that point."""
+    base = lb_with_events(users=150, horizon=30, scale=0.05)
+    base["topology_graph"]["nodes"]["servers"][0]["server_resources"]["cpu_cores"] = 2
+    plan = lower(base)
+    ev = {e["event_id"]: e for e in plan.payload["events"]}
+    s1 = ev["ev-spike-1"]["start"]["t_start"]
+    n = 5
+    sweep = {
+        SPIKE: np.array([0.004, 0.02, 0.05, 0.03, 0.01]),
+        "events[ev-spike-1].start.t_start": s1 + np.array([0.0, 0.2, -0.3, 0.1, 0.0]),
+        # (srv-2 is down during [18, 21]: point 2 moves srv-1's outage BEHIND it -- the timeline slots change owner)
+        DOWN_T0: ev["ev-srv1-down"]["start"]["t_start"] + np.array([0.0, 0.5, 12.5, -1.0, 2.0]),
+        DOWN_T1: ev["ev-srv1-down"]["end"]["t_end"] + np.array([0.0, 0.5, 13.0, 0.0, 3.0]),
+        CORES: [1, 2, 3, 2, 1],
+        RAM: [512, 2048, 1024, 640, 4096],
+        WINDOW: [1, 7, 30, 60, 2],
+    }
+    cols = resolve_sweep(plan, sweep, n)
+    for i in range(n):
+        want = ol.simulate(lower(_point_payload(plan, sweep, i)), 1000 + i)
+        ov = _engine_overrides(cols, i)
+        if kernel == "flow":
+            res = hc.flow_simulate(plan, 1000 + i, overrides=ov, ring_rows=256)
+            assert res is not None, hc.flow_reason()
+            counts, clock, samples = res
+            if int(counts[5]) & hc.FLOW_FALLBACK:       # handed back (a tie): the next-event kernels take it on the GPU
+                continue
+        else:
+            counts, clock, samples = hc.simulate(plan, 1000 + i, overrides=ov)
+        assert np.array_equal(counts[:5].astype(np.uint64), want.counts[:5]), (i, counts, want.counts)
+        assert int(counts[7]) == int(want.counts[7]), "injection marks applied"
+        assert np.array_equal(clock.view(np.uint64), want.clock.view(np.uint64)), f"point {i}: rqs_clock"
+        assert np.array_equal(samples, want.samples), f"point {i}: sampled series"
