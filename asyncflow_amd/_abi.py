@@ -67,6 +67,7 @@ FLAG_TICK_OVERFLOW = 8
 FLAG_RAM_STARVED = 16
 FLAG_TIME_TIE = 32
 FLAG_DRAW_OVERFLOW = 64
+FLAG_NEGATIVE_DELAY = 1 << 13
 FLAG_NAMES = {
     FLAG_POOL_OVERFLOW: "request pool overflow (raise request_capacity)",
     FLAG_FIFO_OVERFLOW: "server wait-queue overflow (raise fifo_capacity)",
@@ -75,6 +76,7 @@ FLAG_NAMES = {
     FLAG_RAM_STARVED: "a request needs more RAM than the server owns (queue blocked, as in the reference)",
     FLAG_TIME_TIE: "a zero-delay timeout was created in the middle of a zero-time cascade (SimPy may order the pending steps differently)",
     FLAG_DRAW_OVERFLOW: "more arrivals than draw_capacity (raise clock_capacity)",
+    FLAG_NEGATIVE_DELAY: "a message was sent with transit + spike < 0 (the reference raises ValueError 'Negative delay')",
 }
 FATAL_FLAGS = (
     FLAG_POOL_OVERFLOW | FLAG_FIFO_OVERFLOW | FLAG_CLOCK_OVERFLOW | FLAG_TICK_OVERFLOW | FLAG_DRAW_OVERFLOW

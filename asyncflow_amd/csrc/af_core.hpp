@@ -62,6 +62,7 @@ enum : uint32_t {
     FLAG_TIME_TIE = 1u << 5,
     FLAG_DRAW_OVERFLOW = 1u << 6,
     FLAG_SHARED_INSTANT = 1u << 7,  // internal: never visible in the outputs of af_engine_run
+    FLAG_NEGATIVE_DELAY = 1u << 13, // transit + spike < 0 at a send (the reference raises "Negative delay")
 };
 enum : uint32_t {
     CNT_GENERATED = 0, CNT_COMPLETED, CNT_DROPPED, CNT_EVENTS, CNT_TICKS, CNT_FLAGS, CNT_MAX_LIVE, CNT_MARKS, CNT_SLOTS
@@ -546,6 +547,7 @@ struct Lane : LaneRegs {
         }
         M.st(at, ncs + 1ull);  // conn += 1 (edge.py:88)
         const double effective = transit + spike;  // spike read at SEND time (edge.py:94-106)
+        if (effective < 0.0) flags |= FLAG_NEGATIVE_DELAY;   // env.timeout(effective) raises in the reference (edge.py:107)
         if constexpr (kMicro) m_emit(now + effective, a, st_pack(RK_TRANSIT, e, hops, 0u, 0u), MK_EDGE_TIMEOUT);
         else emit(now + effective, a, st_pack(RK_TRANSIT, e, hops, 0u, 0u));
     }

@@ -535,7 +535,7 @@ struct Flow {
         // truncated at 0) delivers at the send instant: an event of the NEXT station, which commutes with this one;
         // if the next station has another event at that instant the equal keys are seen there.  A NEGATIVE delay
         // (spike residue after += / -=) raises in the reference (simpy: "Negative delay"): handed back.
-        if (key < now) why |= FLOW_WHY_TIE;
+        if (transit + spike < 0.0) why |= FLOW_WHY_TIE;   // (the next-event kernels report it: AF_FLAG_NEGATIVE_DELAY)
         if (!kFar) {   // (have_row: the server station worked the row of the send time out for its own intervals)
             if (samples != nullptr) add_span(e, have_row ? row_now : tick_index(now, true), tick_index(key, true), 1);
         } else if (samples != nullptr) {   // (row_now: the caller needed it for the delivery it handled)

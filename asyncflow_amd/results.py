@@ -246,6 +246,17 @@ class BatchedResults:
             msg = f"{len(bad)} scenario(s) overflowed an engine capacity (first: #{int(bad[0])}): {why}"
             raise OverflowError(msg)
 
+    def raise_on_negative_delay(self) -> None:
+        """The reference's error behaviour for a send whose ``transit + spike`` is negative (the residue of overlapping
+        spikes under a zero transit time): ``env.timeout`` raises ``ValueError("Negative delay ...")`` (edge.py:107) and
+        the run produces nothing.  The engine reports such scenarios (``AF_FLAG_NEGATIVE_DELAY``); this raises for them."""
+        bad = np.nonzero(self.flags & _abi.FLAG_NEGATIVE_DELAY)[0]
+        if len(bad):
+            msg = (f"Negative delay: {len(bad)} scenario(s) sent a message with transit + spike < 0 (first: #{int(bad[0])}, seed "
+                   f"{int(self.seeds[bad[0]])}); the reference raises the same error for them "
+                   "(SimulationRunner(on_negative_delay='flag') keeps the results and the flag)")
+            raise ValueError(msg)
+
     def __getitem__(self, i: int) -> ScenarioResults:
         i = int(i)
         if not 0 <= i < len(self):
@@ -558,6 +569,10 @@ class ShardedResults:
     def raise_on_overflow(self) -> None:
         for s in self.shards:
             s.raise_on_overflow()
+
+    def raise_on_negative_delay(self) -> None:
+        for s in self.shards:
+            s.raise_on_negative_delay()
 
     def summary(self, **kw: Any) -> dict[str, Any]:
         """Per-scenario summaries of every shard (each computed on its own device), concatenated on the

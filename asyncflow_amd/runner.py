@@ -292,6 +292,7 @@ class SimulationRunner:
         flow_list_entries: int = 0,
         flow_ring_rows: int = 0,
         devices: Sequence[int] | None = None,
+        on_negative_delay: str = "raise",
     ) -> None:
         self.env = env  # accepted for signature compatibility; unused
         self.simulation_input = simulation_input
@@ -339,13 +340,19 @@ class SimulationRunner:
         #: has a users column; contiguous otherwise), one engine per device runs in its own host
         #: thread, no exchange during simulation.  (One process per GPU + the RCCL gather: bench.py --gpus N.)
         self.devices = [int(d) for d in devices] if devices else None
+        #: "raise" (the reference's behaviour: ValueError "Negative delay", edge.py:107 / simpy) or "flag" (keep the results,
+        #: the scenario carries AF_FLAG_NEGATIVE_DELAY) for a send whose transit + spike is negative
+        if on_negative_delay not in ("raise", "flag"):
+            msg = "on_negative_delay must be 'raise' or 'flag'"
+            raise ValueError(msg)
+        self.on_negative_delay = on_negative_delay
         self._init_kwargs = dict(replicas=replicas, device=device, request_capacity=request_capacity,
                                  fifo_capacity=fifo_capacity, clock_capacity=clock_capacity, collect_clock=collect_clock,
                                  collect_samples=collect_samples, force_global_state=force_global_state, auto_grow=auto_grow,
                                  lanes_per_wave=lanes_per_wave, draw_memory_mb=draw_memory_mb,
                                  expect_shared_instants=expect_shared_instants, specialise=specialise,
                                  online_summary=online_summary, flow=flow, flow_list_entries=flow_list_entries,
-                                 flow_ring_rows=flow_ring_rows)
+                                 flow_ring_rows=flow_ring_rows, on_negative_delay=on_negative_delay)
         self._single = seeds is None and int(replicas) == 1 and not self.sweep
         self._engine: Engine | None = None
 
@@ -512,6 +519,8 @@ class SimulationRunner:
                 f"fifo_capacity={fifo}, clock_capacity={clock_cap}", RuntimeWarning, stacklevel=2)
             del counts, clock, samples, res, online_hist, online_rps
         res.raise_on_overflow()
+        if self.on_negative_delay == "raise":
+            res.raise_on_negative_delay()
         return res[0] if self._single else res
 
     @classmethod

@@ -572,26 +572,27 @@ def selftest_cpu(args, rank: int, world: int) -> int:
     seeds = wl["seeds"].astype(np.float64)
     users = wl["columns"].get("rqs_input.avg_active_users.mean", np.full(wl["n"], 400.0))
     local = torch.tensor(np.stack([seeds, users, np.full(wl["n"], float(rank))], axis=1), dtype=torch.float64)
+    # the bench's own scheme: shard sizes computed locally (a pure function of config and world), every rank's scalars
+    # in one extra row of its payload, ONE all-gather
+    sizes = [wl["n"] if r == rank else build_workload(args.config, r, world, args.scenarios, args.horizon)["n"] for r in range(world)]
+    rows = max(sizes) + 1
+    padded = torch.zeros((rows, 3), dtype=torch.float64)
+    padded[: wl["n"]] = local
+    padded[rows - 1] = torch.tensor([float(wl["n"]), float(users.sum()), float(rank)], dtype=torch.float64)
     t0 = time.perf_counter()
-    sizes = None
-    if world > 1:
-        sz = torch.zeros(world, dtype=torch.int64)
-        sz[rank] = wl["n"]
-        dist.all_reduce(sz)
-        sizes = [int(x) for x in sz.tolist()]
-    full = gather_summaries(local, sizes)
+    out = gather_summaries(padded, [rows] * world if world > 1 else None)
     gather_ms = (time.perf_counter() - t0) * 1e3
-    load = torch.tensor([float(users.sum())], dtype=torch.float64)
-    loads = [load.clone() for _ in range(world)]
-    if world > 1:
-        dist.all_gather(loads, load)
+    per_rank = out[torch.arange(world) * rows + rows - 1]
+    assert [int(x) for x in per_rank[:, 0].tolist()] == sizes and [int(x) for x in per_rank[:, 2].tolist()] == list(range(world))
+    full = torch.cat([out[r * rows: r * rows + sizes[r]] for r in range(world)], dim=0)
+    loads = [per_rank[:, 1]]
     if rank == 0:
         got = np.sort(full[:, 0].numpy().astype(np.uint64))
         total = int(full.shape[0])
         line = {"selftest": True, "metric": "launcher selftest (no engine)", "value": float(total), "unit": "scenarios",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": wl["scaling"],
                 "config": {"workload": wl["label"]}, "scenarios_total": total, "unique_seeds": int(np.unique(got).size),
-                "scenarios_per_rank": sizes or [wl["n"]], "gather_ms": gather_ms,
+                "scenarios_per_rank": sizes, "gather_ms": gather_ms, "collectives": 1 if world > 1 else 0,
                 "load_per_rank": [float(x) for x in torch.cat(loads).tolist()]}
         print(json.dumps(line), flush=True)
     if world > 1:
@@ -698,46 +699,51 @@ def main() -> int:  # noqa: C901, PLR0912, PLR0915
     stats_all, hist_all = sw.s_stats, sw.s_hist.to(torch.float32)
     kernel_ms_ranks = [k_ms]
     n_total = n
+    gather_fallback = False
     if dist is not None:
         from asyncflow_amd.distributed import gather_summaries
 
-        sizes_t = torch.zeros(world, dtype=torch.int64, device=dev)
-        sizes_t[rank] = n
-        dist.all_reduce(sizes_t)
-        sizes = [int(x) for x in sizes_t.tolist()]
+        # ONE collective: every rank's shard size is a pure function of (config, world) -- no size exchange --, and the
+        # rank's own scalars (scenarios, elapsed, events, kernel ms) ride in one extra row of the stats array instead of
+        # three all-reduces behind the gather (DESIGN says ONE)
+        sizes = [n if r == rank else build_workload(args.config, r, world, args.scenarios, args.horizon)["n"] for r in range(world)]
         n_max = max(sizes)
+        rows = n_max + 1
+        rank_row = torch.tensor([[float(n), elapsed, events_rank, k_ms, float(rank), 0.0, 0.0, 0.0]], dtype=torch.float64, device=dev)
+        pad = lambda t: torch.cat([t, torch.zeros((rows - t.shape[0], *t.shape[1:]), dtype=t.dtype, device=dev)], dim=0)  # noqa: E731
+        stats_x = pad(sw.s_stats)
+        stats_x[n_max] = rank_row[0]
         gather_path = "af_engine_gather (RCCL through the C ABI, one grouped all-gather on the engine's stream)"
         torch.cuda.synchronize(dev)
-        t2 = time.perf_counter()
         try:
             from asyncflow_amd.distributed import EngineComm, gather_engine_summaries
 
             comm = EngineComm(rank, world, local_rank)
             t2 = time.perf_counter()                       # the communicator's setup is not part of the collective
-            got = gather_engine_summaries(sw.eng, comm, {"stats": sw.s_stats, "rps": sw.s_rps, "hist": sw.s_hist}, n_max)
+            got = gather_engine_summaries(sw.eng, comm, {"stats": stats_x, "rps": sw.s_rps, "hist": sw.s_hist}, rows)
             torch.cuda.synchronize(dev)
             gather_ms = (time.perf_counter() - t2) * 1e3
             comm.close()
-            keep = torch.cat([torch.arange(r * n_max, r * n_max + sizes[r], device=dev) for r in range(world)])
-            stats_all = got["stats"].index_select(0, keep)
-            hist_all = got["hist"].index_select(0, keep).to(torch.float32)
-        except Exception as exc:  # noqa: BLE001 - the bench line must survive a broken RCCL install: same collective through torch
-            gather_path = f"torch.distributed.all_gather_into_tensor (af_engine_gather failed: {type(exc).__name__}: {exc})"
-            packed = torch.cat([sw.s_stats.to(torch.float32), sw.s_rps, sw.s_hist.to(torch.float32)], dim=1).contiguous()
+            stats_g, hist_g = got["stats"], got["hist"]
+        except Exception as exc:  # noqa: BLE001 - the bench line must survive a broken RCCL install: same collective through torch, LOUDLY
+            gather_fallback = True
+            gather_path = f"FALLBACK torch.distributed.all_gather_into_tensor (af_engine_gather failed: {type(exc).__name__}: {exc})"
+            print(f"[bench] rank {rank}: {gather_path}", file=sys.stderr, flush=True)
+            packed = torch.cat([stats_x, pad(sw.s_rps).to(torch.float64), pad(sw.s_hist).to(torch.float64)], dim=1).contiguous()
             torch.cuda.synchronize(dev)
             t2 = time.perf_counter()
-            out = gather_summaries(packed, sizes)          # ONE all_gather over xGMI (RCCL)
+            out = gather_summaries(packed, [rows] * world)          # ONE all_gather over xGMI (RCCL)
             torch.cuda.synchronize(dev)
             gather_ms = (time.perf_counter() - t2) * 1e3
-            stats_all, hist_all = out[:, :8], out[:, 8 + sw.T:]
+            stats_g, hist_g = out[:, :8], out[:, 8 + sw.T:]
+        per_rank = stats_g[torch.arange(world, device=dev) * rows + n_max].cpu().numpy()      # the ranks' scalar rows
+        assert [int(x) for x in per_rank[:, 0]] == sizes and [int(x) for x in per_rank[:, 4]] == list(range(world)), "gather order"
+        keep = torch.cat([torch.arange(r * rows, r * rows + sizes[r], device=dev) for r in range(world)])
+        stats_all = stats_g.index_select(0, keep)
+        hist_all = hist_g.index_select(0, keep).to(torch.float32)
         n_total = int(stats_all.shape[0])
-        tot = torch.tensor([elapsed, events_rank, k_ms], dtype=torch.float64, device=dev)
-        mx, mn, sm = tot.clone(), tot.clone(), tot.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        dist.all_reduce(mn, op=dist.ReduceOp.MIN)
-        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        elapsed, events_total = float(mx[0]), float(sm[1])
-        kernel_ms_ranks = [float(mn[2]), float(mx[2])]
+        elapsed, events_total = float(per_rank[:, 1].max()), float(per_rank[:, 2].sum())
+        kernel_ms_ranks = [float(per_rank[:, 3].min()), float(per_rank[:, 3].max())]
     else:
         events_total = events_rank
 
@@ -824,6 +830,9 @@ def main() -> int:  # noqa: C901, PLR0912, PLR0915
             },
             "gather_ms": gather_ms,
             "gather_path": gather_path,
+            "gather_fallback": gather_fallback,
+            "collectives": None if dist is None else "barriers around the timed region + ONE grouped all-gather after it (shard sizes are "
+                                                     "computed locally, per-rank scalars ride in the gathered stats array)",
             "p95_ms_mean": None if sw.online else float(np.nanmean(sa[:, 4]) * 1e3),
             "p95_ms_pooled_hist": None if sw.online else pooled_p95_ms,
             "p50_ms_mean": None if sw.online else float(np.nanmean(sa[:, 2]) * 1e3),

@@ -205,7 +205,13 @@ enum af_flag {
                                           servers (poisson / truncated normal) are NOT flagged,
                                           they follow SimPy's event order exactly
                                           (DESIGN.md "Ties"; informational) */
-    AF_FLAG_DRAW_OVERFLOW = 1u << 6    /* more arrivals than draw_capacity            */
+    AF_FLAG_DRAW_OVERFLOW = 1u << 6,   /* more arrivals than draw_capacity            */
+    /* (bits 7..12 are internal to the engine and never visible in the outputs) */
+    AF_FLAG_NEGATIVE_DELAY = 1u << 13  /* a message was sent with transit + spike < 0: the residue of overlapping
+                                          spikes' += / -= (injection.py:191-198) under a zero transit time.  The
+                                          reference raises there (simpy: ValueError "Negative delay", edge.py:107);
+                                          the engine delivers at now + (transit + spike) and reports the scenario:
+                                          asyncflow_amd.SimulationRunner raises the same ValueError for it */
 };
 
 typedef struct af_outputs {

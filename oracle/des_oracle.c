@@ -317,6 +317,7 @@ static void edge_init(sim_t* s, int r) {
     double transit = test_quant(orc_variate(p->edge_dist[e], p->edge_mean[e], p->edge_sigma[e], s->seed,
                                             ORC_STREAM_EDGE(e), idx, 1));
     double effective = transit + ed->spike; /* edge.py:94-106, spike read at SEND time */
+    if (effective < 0.0) s->flags |= AF_FLAG_NEGATIVE_DELAY; /* edge.py:107 -> simpy raises ValueError("Negative delay") */
     sched(s, effective, PRIO_NORMAL, EV_EDGE_TIMEOUT, r, 0);
 }
 

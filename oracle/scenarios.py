@@ -415,3 +415,22 @@ GOLDEN = {
     # BASELINE config 2 at its FULL horizon, scenario 0 of the benched batch (seed 0x5EED0000): 75 861 completions
     "lb2_rr_t600": (lambda: lb_two_servers(horizon=600), 0x5EED0000),
 }
+
+
+def negative_spike_residue(horizon: int = 10, shift: float = 0.0) -> dict:
+    """Two overlapping spikes on the client -> server edge whose f64 `+=` / `-=` (injection.py:191-198) leave a NEGATIVE
+    residue: ((0 + 0.3) + 0.4) - 0.3 - 0.4 = -5.55e-17.  The edge's latency is a normal law truncated at 0 (about half
+    of its draws are exactly 0.0): the first such message after t = 4 has transit + spike < 0 and the reference's
+    `env.timeout(effective)` raises ValueError("Negative delay") (edge.py:107)."""
+    p = single_server(users=40, rpm=60, horizon=horizon, period=0.05)
+    for e in p["topology_graph"]["edges"]:
+        if e["source"] == "client-1":
+            e["latency"] = {"mean": 0.001, "distribution": "normal", "variance": 0.01}
+            edge_id = e["id"]
+    p["events"] = [
+        {"event_id": "s1", "target_id": edge_id, "start": {"kind": "network_spike_start", "t_start": 1.0 + shift, "spike_s": 0.3},
+         "end": {"kind": "network_spike_end", "t_end": 3.0 + shift}},
+        {"event_id": "s2", "target_id": edge_id, "start": {"kind": "network_spike_start", "t_start": 2.0 + shift, "spike_s": 0.4},
+         "end": {"kind": "network_spike_end", "t_end": 4.0 + shift}},
+    ]
+    return p

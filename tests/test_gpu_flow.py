@@ -451,3 +451,26 @@ def test_sweep_over_spike_size_and_outage_window_matches_the_oracle_per_point():
     special = _runner(base, seeds=grid.seeds, sweep=cols, specialise=True).run()     # the plan-specialised build patches the same blob
     assert special.engine_stats.specialised_launches >= 1
     _same_batches(res, special)
+
+
+def test_negative_delay_raises_like_the_reference_or_is_flagged():
+    """transit + spike < 0 (negative residue of overlapping spikes under a zero transit time): the reference raises
+    ValueError("Negative delay") (edge.py:107); so does the runner -- or, with on_negative_delay="flag", the scenario keeps
+    its results (equal to the oracle's) and carries AF_FLAG_NEGATIVE_DELAY.  The stage-parallel kernel hands such scenarios
+    to the next-event kernels, which report them."""
+    from oracle.scenarios import negative_spike_residue
+
+    payload = negative_spike_residue(horizon=10)
+    seeds = np.arange(6, dtype=np.uint64) + 3
+    with pytest.raises(ValueError, match="Negative delay"):
+        _runner(payload, seeds=seeds).run()
+    res = _runner(payload, seeds=seeds, on_negative_delay="flag").run()
+    assert res.engine_stats.flow_scenarios == 6 and res.engine_stats.flow_to_next_event >= 1
+    plan = lower(payload)
+    flagged = 0
+    for i, s in enumerate(seeds):
+        want = ol.simulate(plan, int(s))
+        _assert_scenario(res[i], want, f"scenario {i}")
+        assert (int(res.flags[i]) & _abi.FLAG_NEGATIVE_DELAY) == (int(want.counts[_abi.CNT_FLAGS]) & _abi.FLAG_NEGATIVE_DELAY)
+        flagged += bool(int(res.flags[i]) & _abi.FLAG_NEGATIVE_DELAY)
+    assert flagged >= 1

@@ -54,3 +54,87 @@ def test_devices_option_shards_in_process_and_keeps_the_sweep_order():
     assert np.array_equal(a["stats"].cpu().numpy(), b["stats"].cpu().numpy(), equal_nan=True)
     assert np.array_equal(a["rps"].cpu().numpy(), b["rps"].cpu().numpy())
     assert two.aggregate()["mean"]["p95"] == one.aggregate()["mean"]["p95"]
+
+
+# ------------------------------------------------------------------------------------------------ N ranks, N devices
+def _rccl_rank(rank: int, world: int, tmp: str) -> None:
+    """One rank of the N-GPU smoke test (spawned): af_comm_init_rank on ITS device from an id shared through a file,
+    af_engine_gather of fabricated summary rows, the same rows through torch.distributed for comparison."""
+    import os
+    import time
+    from pathlib import Path
+
+    import torch
+    import torch.distributed as dist
+
+    from asyncflow_amd.distributed import EngineComm, gather_engine_summaries
+    from asyncflow_amd.engine import Engine
+    from asyncflow_amd.plan import lower
+
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    id_file = Path(tmp) / "rccl_id"
+
+    def share(ident):
+        if rank == 0:
+            id_file.with_suffix(".tmp").write_bytes(ident)
+            id_file.with_suffix(".tmp").rename(id_file)
+            return ident
+        for _ in range(600):
+            if id_file.exists():
+                return id_file.read_bytes()
+            time.sleep(0.1)
+        raise TimeoutError("rank 0 never published the RCCL id")
+
+    n = 40 + rank                                            # ragged shards, padded to n_max by the caller
+    n_max = 40 + world - 1
+    g = torch.Generator().manual_seed(1000 + rank)
+    tensors = {"stats": (torch.rand((n, 8), generator=g, dtype=torch.float64) + rank).to(dev),
+               "rps": torch.rand((n, 30), generator=g, dtype=torch.float32).to(dev),
+               "hist": torch.randint(0, 1000, (n, 64), generator=g, dtype=torch.int32).to(dev)}
+    eng = Engine(lower(lb_two_servers(horizon=30)), rank)
+    comm = EngineComm(rank, world, rank, share=share)
+    got = gather_engine_summaries(eng, comm, tensors, n_max)
+    dist.init_process_group(backend="nccl", init_method=f"file://{tmp}/pg", rank=rank, world_size=world, device_id=dev)
+    for k, t in tensors.items():
+        padded = torch.cat([t, torch.zeros((n_max - n, *t.shape[1:]), dtype=t.dtype, device=dev)], dim=0).contiguous()
+        ref = torch.empty((world * n_max, *t.shape[1:]), dtype=t.dtype, device=dev)
+        dist.all_gather_into_tensor(ref, padded)
+        assert torch.equal(got[k], ref), f"rank {rank}: af_engine_gather and torch.distributed disagree on {k}"
+        assert torch.equal(got[k][rank * n_max: rank * n_max + n], t)
+    dist.destroy_process_group()
+    comm.close()
+    eng.close()
+
+
+def test_engine_gather_over_every_visible_gpu(tmp_path):
+    """af_comm_init_rank + af_engine_gather with one rank per GPU (the path bench.py --gpus N takes), checked against
+    torch.distributed's all-gather.  Needs >= 2 GPUs: the 1-GPU boxes of this pool skip it with that reason."""
+    import torch
+
+    world = torch.cuda.device_count()
+    if world < 2:
+        pytest.skip(f"{world} GPU visible: the N-rank RCCL path needs at least 2 (world size 1 is covered above)")
+    import torch.multiprocessing as mp
+
+    mp.spawn(_rccl_rank, args=(world, str(tmp_path)), nprocs=world, join=True)
+
+
+def test_bench_rank_rows_ride_in_the_one_gather(tmp_path):
+    """bench.py's N > 1 path on ONE GPU (AF_BENCH_FORCE_DIST: a process group of size 1): the RCCL gather through the C ABI
+    is taken (no fallback), and the rank's scalars come back from the extra row of the gathered stats array."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, AF_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, str(root / "bench.py"), "--scenarios", "256", "--horizon", "30", "--steps", "1", "--warmup", "0",
+                          "--no-cpu-baseline", "--no-diagnostics"], env=env, capture_output=True, text=True, timeout=600, check=False)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["gather_fallback"] is False and "af_engine_gather" in line["gather_path"] and line["gather_ms"] > 0.0
+    assert line["config"]["scenarios_total"] == 256 and line["parity_spot_check"]["ok"] is True

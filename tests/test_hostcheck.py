@@ -164,6 +164,28 @@ def test_ram_starved_endpoint_blocks_like_the_reference():
     assert np.array_equal(a.clock, clock) and np.array_equal(a.samples, samples)
 
 
+def test_negative_spike_residue_is_reported_where_the_reference_raises():
+    """DESIGN section 2, documented deviation: `transit + spike < 0` (residue of overlapping spikes under a zero transit time)
+    raises ValueError("Negative delay") in the reference (edge.py:107, simpy) and yields no results; the engine delivers
+    at now + (transit + spike) and REPORTS the scenario (AF_FLAG_NEGATIVE_DELAY; the Python runner raises the same
+    ValueError for it).  Oracle, next-event core and stage-parallel kernel agree on the flag; the live reference's
+    ValueError is shown in tests/test_reference_live.py."""
+    from oracle.scenarios import negative_spike_residue
+
+    plan = lower(negative_spike_residue(horizon=10))
+    a = ol.simulate(plan, 3)
+    assert int(a.counts[_abi.CNT_FLAGS]) & _abi.FLAG_NEGATIVE_DELAY
+    counts, clock, samples = hc.simulate(plan, 3)
+    assert int(counts[_abi.CNT_FLAGS]) & _abi.FLAG_NEGATIVE_DELAY
+    assert np.array_equal(a.counts[:5].astype(np.uint32), counts[:5]) and np.array_equal(a.clock, clock)
+    res = hc.flow_simulate(plan, 3, ring_rows=256)
+    assert res is not None and int(res[0][_abi.CNT_FLAGS]) & hc.FLOW_FALLBACK, "the stage-parallel kernel hands such a scenario back"
+    # before the residue exists (the second spike ends after the horizon) nothing is reported
+    early = lower(negative_spike_residue(horizon=6, shift=2.0))
+    assert not int(ol.simulate(early, 3).counts[_abi.CNT_FLAGS]) & _abi.FLAG_NEGATIVE_DELAY
+    assert not int(hc.simulate(early, 3)[0][_abi.CNT_FLAGS]) & _abi.FLAG_NEGATIVE_DELAY
+
+
 def test_zero_users_produces_ticks_only():
     payload = lb_two_servers(users=0.0, horizon=6)
     plan = lower(payload)

@@ -149,3 +149,34 @@ def test_results_feed_the_reference_plot_helpers(tmp_path):
     assert lines and np.array_equal(np.asarray(lines[0].get_ydata(), dtype=np.float64),
                                     np.asarray(sc.get_sampled_metrics()["ram_in_use"][sid], dtype=np.float64))
     plt.close(fig)
+
+
+# ------------------------------------------------------------- documented deviations, shown on the reference itself
+def test_reference_raises_negative_delay_where_the_engine_reports_a_flag():
+    """edge.py:107: `yield self.env.timeout(effective)` with effective = transit + spike < 0 -> simpy raises ValueError
+    ("Negative delay"); the oracle (and the engine: tests/test_hostcheck.py) carry AF_FLAG_NEGATIVE_DELAY instead, and
+    asyncflow_amd.SimulationRunner raises the same ValueError for such a scenario."""
+    from asyncflow_amd import _abi
+    from oracle.reference_runner import run_reference
+    from oracle.scenarios import negative_spike_residue
+
+    payload = negative_spike_residue(horizon=10)
+    with pytest.raises(ValueError, match="Negative delay"):
+        run_reference(payload, 3)
+    assert int(ol.simulate(lower(payload), 3).counts[_abi.CNT_FLAGS]) & _abi.FLAG_NEGATIVE_DELAY
+    early = negative_spike_residue(horizon=6, shift=2.0)          # no residue yet: reference and oracle agree bit for bit
+    _same(early, 3)
+
+
+def test_reference_blocks_a_ram_starved_server_and_the_engine_reports_it():
+    """server.py:146-149: a request whose endpoint needs more RAM than `ram_mb` waits in `RAM.get()` for good, and -- the
+    container's gets being FIFO -- so does everything that reaches that server after it: observably, those requests
+    never complete.  Oracle / engine: the same clock and samples (the request and its followers are dropped from the
+    model at that point) plus AF_FLAG_RAM_STARVED."""
+    from asyncflow_amd import _abi
+    from oracle.scenarios import stress_mixed
+
+    payload = stress_mixed(30)
+    payload["topology_graph"]["nodes"]["servers"][2]["endpoints"][1]["steps"][1]["step_operation"]["necessary_ram"] = 5000
+    _same(payload, 1)
+    assert int(ol.simulate(lower(payload), 1).counts[_abi.CNT_FLAGS]) & _abi.FLAG_RAM_STARVED
