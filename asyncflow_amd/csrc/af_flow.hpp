@@ -63,7 +63,13 @@ enum : uint32_t {
     FLOW_WHY_RAM = 1u << 12,        // a request would have to wait for RAM
     FLOW_WHY_MASK = FLOW_WHY_TIE | FLOW_WHY_LIST | FLOW_WHY_RING | FLOW_WHY_RAM,
 };
-constexpr uint32_t kMaxServers = 8;    // lane k < n_servers runs server k's core / RAM recurrence
+constexpr uint32_t kMaxServers = 8;    // least connections: in-flight counts of <= 8 servers in two 64-bit words, 8 draws in registers
+// servers behind a round-robin LB: 16 slots per per-server array of lbw() (what binds first is the 64 sampled series a wave's
+// lanes carry: 2 + 5 S series -> S <= 12)
+constexpr uint32_t kSrvSlots = 16;
+enum : uint32_t { LBW_ARRIVALS = 24u, LBW_SEG_OFF = LBW_ARRIVALS + kSrvSlots, LBW_SEG_LEN = LBW_SEG_OFF + kSrvSlots,
+                  LBW_PROG = LBW_SEG_LEN + kSrvSlots, LBW_SLOTS = LBW_PROG + kSrvSlots, LBW_U32 = LBW_SLOTS + kSrvSlots };
+static_assert(LBW_U32 % 2u == 0u, "lbw() is carved out of 64-bit words");
 
 // LDS layout behind the plan blob, in 8-byte words; computed on the host (make_flow_layout).
 struct FlowLayout {
@@ -117,7 +123,7 @@ inline FlowLayout make_flow_layout(uint32_t cap, uint32_t ring_rows, uint32_t g_
     if (w < scratch0 + 5u * 64u) w = scratch0 + 5u * 64u;
     L.off_fr = w; w += n_servers * c_ring;
     L.off_gr = w; w += n_servers * g_ring;
-    L.off_cnt = w; w += (n_edges + 1u) / 2u + 32u + 12u;   // u32 sends per edge; 64 u32: lb order, head, n_live, mark cursor, per-server counters; send_floor's 4 x 3 f64
+    L.off_cnt = w; w += (n_edges + 1u) / 2u + LBW_U32 / 2u + 12u;   // u32 sends per edge; LBW_U32 u32: lb order, head, n_live, mark cursor, per-server counters; send_floor's 4 x 3 f64
     L.off_ring = w; w += (ring_rows * L.pitch + 1u) / 2u;
     L.n_words = w;
     return L;
@@ -290,8 +296,8 @@ struct Flow {
     AF_CORE AF_PLAN_AS double* fr(uint32_t sv) const { return (AF_PLAN_AS double*)(M + o_fr()) + sv * A.L.c_ring; }
     AF_CORE AF_PLAN_AS double* gr(uint32_t sv) const { return (AF_PLAN_AS double*)(M + A.L.off_gr) + sv * A.L.g_ring; }
     AF_CORE AF_PLAN_AS uint32_t* sends() const { return (AF_PLAN_AS uint32_t*)(M + A.L.off_cnt); }
-    AF_CORE AF_PLAN_AS uint32_t* lbw() const { return sends() + ((A.n_edges + 1u) & ~1u); }  // [0..15] order, 16 head, 17 n_live, 18 mark cursor, 19 ceil(2^32 / n_live), [24..31] arrivals per server, [32..39] / [40..47] segment start / length, [48..55] step counts (leading I/O | CPU << 8 | trailing I/O << 16), [56..63] RAM slots (requests that fit at once)
-    AF_CORE AF_PLAN_AS double* fcache() const { return (AF_PLAN_AS double*)(M + A.L.off_cnt + (A.n_edges + 1u) / 2u + 32u); }   // [4][3], send_floor
+    AF_CORE AF_PLAN_AS uint32_t* lbw() const { return sends() + ((A.n_edges + 1u) & ~1u); }  // [0..15] order, 16 head, 17 n_live, 18 mark cursor, 19 ceil(2^32 / n_live), then kSrvSlots each: LBW_ARRIVALS per server, LBW_SEG_OFF / LBW_SEG_LEN segment start / length, LBW_PROG step counts (leading I/O | CPU << 8 | trailing I/O << 16), LBW_SLOTS RAM slots (requests that fit at once)
+    AF_CORE AF_PLAN_AS double* fcache() const { return (AF_PLAN_AS double*)(M + A.L.off_cnt + (A.n_edges + 1u) / 2u + LBW_U32 / 2u); }   // [4][3], send_floor
     AF_CORE AF_PLAN_AS int32_t* ring() const { return (AF_PLAN_AS int32_t*)(M + A.L.off_ring); }
     AF_CORE AF_PLAN_AS double* spike_cum() const { return (AF_PLAN_AS double*)(M + A.L.off_spike); }
 
@@ -1054,24 +1060,24 @@ struct Flow {
         r.events = e_cnt;
         return r;
     }
-    // `have` lanes: arrival `a` at server `sv`, position `pos` in seg (its server's segment starts at lbw()[32+sv] and
-    // holds lbw()[40+sv] arrivals).  Returns the lane's times; advances the server's counters and rings.
+    // `have` lanes: arrival `a` at server `sv`, position `pos` in seg (its server's segment starts at lbw()[LBW_SEG_OFF + sv] and
+    // holds lbw()[LBW_SEG_LEN + sv] arrivals).  Returns the lane's times; advances the server's counters and rings.
     AF_CORE SrvTimes servers_solve(bool arrived, uint32_t sv, uint32_t pos, double a) {
         AF_PLAN_AS uint32_t* lw = lbw();
         // A server whose endpoint needs more RAM than the server has never admits anybody: the first request blocks in
         // RAM.get() for good and everything behind it queues up (server.py:146-149; Container gets are FIFO).  Such
         // arrivals are timed events and nothing else.
-        const bool have = arrived && lw[56u + sv] != 0u;
-        const uint32_t off = have ? lw[32u + sv] : 0u, n_k = have ? lw[40u + sv] : 0u;
+        const bool have = arrived && lw[LBW_SLOTS + sv] != 0u;
+        const uint32_t off = have ? lw[LBW_SEG_OFF + sv] : 0u, n_k = have ? lw[LBW_SEG_LEN + sv] : 0u;
         const uint32_t li = pos - off;                         // my index among this window's arrivals of my server
-        const uint32_t j = have ? lw[24u + sv] + li : 0u;      // ... and among all of them
+        const uint32_t j = have ? lw[LBW_ARRIVALS + sv] + li : 0u;      // ... and among all of them
         const uint64_t meta = blob[A.off_srv + af::SREC * sv + 1u];
         const uint32_t cores = (uint32_t)meta & 0xFFFFu;
         const uint32_t ep = (uint32_t)(meta >> 32) & 0xFFFFu;
         const double ram = u2d(blob[A.off_ep + af::PREC * ep]);
         const uint32_t row0 = (uint32_t)blob[A.off_ep + af::PREC * ep + 1u];
         const uint32_t G = A.L.g_ring;
-        const uint32_t slots = lw[56u + sv];   // requests that fit the RAM at once
+        const uint32_t slots = lw[LBW_SLOTS + sv];   // requests that fit the RAM at once
         // where my predecessors' times come from: this window's segment, or the rings of earlier windows
         const bool ram_gate = have && ram > 0.0 && slots != 0u && slots <= G && j >= slots;
         const bool core_gate = have && j >= cores;
@@ -1085,7 +1091,7 @@ struct Flow {
                 if (!(gq < a)) why |= FLOW_WHY_RAM;
             }
         }
-        const uint32_t prog = lw[48u + sv];
+        const uint32_t prog = lw[LBW_PROG + sv];
         SrvTimes r = srv_program(row0, prog, a, g_prev, f_prev);
         for (;;) {
             if (have) {
@@ -1122,7 +1128,7 @@ struct Flow {
             ev += r.events;
         }
         W::sync();
-        if (lane < A.n_servers) lw[24u + lane] += lw[40u + lane];
+        if (lane < A.n_servers) lw[LBW_ARRIVALS + lane] += lw[LBW_SEG_LEN + lane];
         if (arrived && !have) {   // never admitted (the sequential kernels and the oracle report the same, informational, flag)
             r.adm = r.b = r.s = r.f = r.g = AF_INF;
             info |= af::FLAG_RAM_STARVED;
@@ -1228,7 +1234,7 @@ struct Flow {
                     else if (phase == 1u && kind == af::STEP_IO) phase = 2u;
                     cnt[phase] += 1u;
                 }
-                lw[48u + v] = cnt[0] | (cnt[1] << 8) | (cnt[2] << 16);
+                lw[LBW_PROG + v] = cnt[0] | (cnt[1] << 8) | (cnt[2] << 16);
                 const double ram = u2d(blob[A.off_ep + af::PREC * ep]), ram_mb = u2d(blob[A.off_srv + af::SREC * v]);
                 uint32_t slots = 0xFFFFFFFFu;   // requests that fit the RAM at once
                 if (ram > 0.0) {
@@ -1236,7 +1242,7 @@ struct Flow {
                     slots = q < 4.0e9 ? (uint32_t)q : 0xFFFFFFFFu;
                     while ((double)slots * ram > ram_mb && slots > 0u) --slots;
                 }
-                lw[56u + v] = slots;
+                lw[LBW_SLOTS + v] = slots;
             }
             for (uint32_t i = 0u; i < A.n_lb_edges; ++i) lw[i] = (uint32_t)blob[A.off_lb + i];
             lw[16] = 0u;
@@ -1352,8 +1358,8 @@ struct Flow {
                             const uint64_t m = W::ballot(have && sv == k);
                             if (have && sv == k) pos = off + W::mbcnt(m);
                             if (lane == k) {
-                                lbw()[32u + k] = off;
-                                lbw()[40u + k] = popc64(m);
+                                lbw()[LBW_SEG_OFF + k] = off;
+                                lbw()[LBW_SEG_LEN + k] = popc64(m);
                             }
                             off += popc64(m);
                         }

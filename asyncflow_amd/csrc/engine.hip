@@ -929,6 +929,7 @@ int plan_flow(const af_engine* e, const KArgs& a, const af_sweep_t* sweep, const
             case AF_DIST_LOG_NORMAL: return std::exp(m + 0.5 * sg * sg < 50.0 ? m + 0.5 * sg * sg : 50.0);
             case AF_DIST_NORMAL: return (m > 0.0 ? m : 0.0) + 0.4 * sg;
             case AF_DIST_UNIFORM: return 0.5;
+            case AF_DIST_POISSON: return m + 0.5;   // whole seconds: what is in flight is at least the next second's worth
             default: return m;
         }
     };
@@ -995,6 +996,7 @@ int plan_flow(const af_engine* e, const KArgs& a, const af_sweep_t* sweep, const
             }
             case AF_DIST_NORMAL: return sg;
             case AF_DIST_UNIFORM: return 0.29;
+            case AF_DIST_POISSON: return std::sqrt(m > 0.0 ? m : 0.0);
             default: return m;
         }
     };
@@ -1004,6 +1006,7 @@ int plan_flow(const af_engine* e, const KArgs& a, const af_sweep_t* sweep, const
             case AF_DIST_LOG_NORMAL: return std::exp(m + 6.7 * sg < 50.0 ? m + 6.7 * sg : 50.0);
             case AF_DIST_NORMAL: return (m > 0.0 ? m : 0.0) + 6.7 * sg;
             case AF_DIST_UNIFORM: return 1.0;
+            case AF_DIST_POISSON: return m + 7.0 * std::sqrt(m > 0.0 ? m : 0.0) + 12.0;   // (Poisson tail beyond 1e-11)
             default: return 25.3 * m;
         }
     };

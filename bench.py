@@ -861,6 +861,12 @@ def main() -> int:  # noqa: C901, PLR0912, PLR0915
             line["cpu_baseline"] = base
         if parity is not None:
             line["parity_spot_check"] = parity
+        try:      # (RCCL prints a version banner through C stdio, block-buffered on a pipe: out with it BEFORE the one JSON line)
+            import ctypes
+
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
         print(json.dumps(line), flush=True)
     sw.eng.close()
     if dist is not None:

@@ -114,7 +114,7 @@ def test_small_lists_hand_the_scenario_back_instead_of_dropping_messages():
 
 
 def test_plans_outside_the_feed_forward_range_are_refused():
-    for payload, word in ((stress_mixed(40), "Poisson"), (wide_fanout(horizon=12), "8 servers"),
+    for payload, word in ((stress_mixed(40), "several endpoints"), (wide_fanout(horizon=12), "16 servers"),
                           (server_chain("exponential", 0.003), "server chain")):
         assert hc.flow_simulate(lower(payload), 1) is None
         assert word in hc.flow_reason()
@@ -213,3 +213,43 @@ def test_least_connections_is_a_decision_of_the_lb_station_alone(kw):
     p = fanout8(horizon=20)
     p["topology_graph"]["nodes"]["load_balancer"]["algorithms"] = "least_connection"
     assert _run(p, 11, **dict(kw, ring_rows=0, ipl=2))[0] == "exact"      # (~1-s hops: 128-entry lists, differences in HBM)
+
+
+def test_poisson_integer_second_latencies_run_on_the_flow_kernel():
+    """Round 3: Poisson edge latencies (samplers/common_helpers.py:67-70: whole seconds, zero included)
+    are inside the stage-parallel kernel's range.  Fuzzed feed-forward payloads with 1-3 Poisson edges: wherever the
+    kernel does not hand the scenario back (lists too short for rate x 1 s of waiting messages, a genuine tie) it
+    equals the oracle bit for bit, and with long lists most of them stay."""
+    import random
+
+    from oracle.scenarios import flow_payload
+
+    exact = back = 0
+    for case in range(40):
+        rng = random.Random(52000 + case)
+        p = flow_payload(rng, horizon=8)
+        edges = p["topology_graph"]["edges"]
+        for e in rng.sample(edges, k=min(len(edges), rng.randint(1, 3))):
+            e["latency"] = {"mean": rng.choice([0.05, 0.2, 0.5, 0.8]), "distribution": "poisson"}
+        status, _ = _run(p, 900 + case, ipl=4, ring_rows=0, robust=True, long_list_entries=1024)
+        exact += status == "exact"
+        back += status == "fallback"
+    assert exact >= 30 and exact + back == 40
+
+
+@pytest.mark.parametrize("n_srv", [9, 12])
+def test_round_robin_fan_out_beyond_eight_servers(n_srv):
+    """Round 3: 9..12 servers behind a round-robin load balancer run on the stage-parallel kernel (16 slots
+    per per-server array; the 64 sampled series of a wave's lanes bound the count: 2 + 5 S <= 64).  wide_fanout's topology
+    with ONE endpoint per server: multi-core servers, RAM, outages and a spike."""
+    from oracle.scenarios import wide_fanout
+
+    payload = wide_fanout(n_srv, "round_robin", horizon=12, users=100)     # (odd servers answer over ~1-s log-normal hops)
+    for s in payload["topology_graph"]["nodes"]["servers"]:
+        s["endpoints"] = s["endpoints"][:1]
+    assert _run(payload, 77, ipl=4, ring_rows=0)[0] == "exact"
+    assert _run(payload, 78, ipl=4, ring_rows=128)[0] == "exact"
+    thirteen = wide_fanout(13, "round_robin", horizon=12)
+    for s in thirteen["topology_graph"]["nodes"]["servers"]:
+        s["endpoints"] = s["endpoints"][:1]
+    assert hc.flow_simulate(lower(thirteen), 1) is None and "64 sampled series" in hc.flow_reason()

@@ -474,3 +474,38 @@ def test_negative_delay_raises_like_the_reference_or_is_flagged():
         assert (int(res.flags[i]) & _abi.FLAG_NEGATIVE_DELAY) == (int(want.counts[_abi.CNT_FLAGS]) & _abi.FLAG_NEGATIVE_DELAY)
         flagged += bool(int(res.flags[i]) & _abi.FLAG_NEGATIVE_DELAY)
     assert flagged >= 1
+
+
+# ------------------------------------------------------------------------- round 3: f3 stragglers on the fast path
+def test_poisson_latencies_and_wide_round_robin_fan_out_run_on_the_flow_kernel():
+    """Poisson (whole-second, zero included) edge latencies and 9..12 servers behind a round-robin LB are inside the
+    stage-parallel kernel's range since round 3: bit-identical to the oracle and to the next-event kernels, hand-backs
+    (lists that overflow under 1-s hops, the odd genuine tie) invisible in the results."""
+    from oracle.scenarios import wide_fanout
+
+    p = lb_two_servers(horizon=40, users=60)
+    for e in p["topology_graph"]["edges"]:
+        if e["id"] in ("client-lb", "srv1-client"):
+            e["latency"] = {"mean": 0.3, "distribution": "poisson"}
+    seeds = np.arange(48, dtype=np.uint64) + 700
+    res = _runner(p, seeds=seeds).run()
+    st = res.engine_stats
+    assert res.flow_reason == "" and st.flow_scenarios == 48 and st.flow_to_next_event <= 4
+    plan = lower(p)
+    for i in (0, 11, 47):
+        _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])), f"poisson scenario {i}")
+    _same_batches(res, _runner(p, seeds=seeds, flow=False).run())
+
+    wide = wide_fanout(10, "round_robin", horizon=20, users=100)
+    for s in wide["topology_graph"]["nodes"]["servers"]:
+        s["endpoints"] = s["endpoints"][:1]
+    seeds = np.arange(32, dtype=np.uint64) + 70
+    res = _runner(wide, seeds=seeds).run()
+    assert res.flow_reason == "" and res.engine_stats.flow_scenarios == 32
+    plan = lower(wide)
+    for i in (0, 31):
+        _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])), f"10-server scenario {i}")
+    _same_batches(res, _runner(wide, seeds=seeds, flow=False).run())
+    special = _runner(wide, seeds=seeds, specialise=True).run()
+    assert special.engine_stats.specialised_launches >= 1
+    _same_batches(res, special)

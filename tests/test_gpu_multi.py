@@ -135,6 +135,7 @@ def test_bench_rank_rows_ride_in_the_one_gather(tmp_path):
     out = subprocess.run([sys.executable, str(root / "bench.py"), "--scenarios", "256", "--horizon", "30", "--steps", "1", "--warmup", "0",
                           "--no-cpu-baseline", "--no-diagnostics"], env=env, capture_output=True, text=True, timeout=600, check=False)
     assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1].startswith('{"metric"'), "the JSON line must be the LAST line of stdout"
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["gather_fallback"] is False and "af_engine_gather" in line["gather_path"] and line["gather_ms"] > 0.0
     assert line["config"]["scenarios_total"] == 256 and line["parity_spot_check"]["ok"] is True

@@ -234,18 +234,23 @@ def test_plan_specialised_kernels_give_identical_results():
 def test_fuzz_sweep_of_topologies_all_scenarios_checked():
     """60 random topologies x 5 seeds, every scenario compared with the oracle (all distributions,
     multi-core servers, RAM queues, LB algorithms, spikes and outages)."""
-    checked = shared = 0
+    checked = shared = negative = 0
     for case in range(60):
         payload = random_payload(random.Random(31000 + case), horizon=6)
         seeds = np.arange(5, dtype=np.uint64) + 17 * case
-        res = _runner(payload, seeds=seeds, lanes_per_wave=[0, 1, 2, 8][case % 4]).run()
+        # (topology 12 has overlapping spikes with a negative f64 residue under zero transit times: the reference RAISES
+        # "Negative delay" there -- confirmed on the live reference --, the engine reports AF_FLAG_NEGATIVE_DELAY like the oracle)
+        res = _runner(payload, seeds=seeds, lanes_per_wave=[0, 1, 2, 8][case % 4], on_negative_delay="flag").run()
         plan = lower(payload)
         shared += int(res.engine_stats.shared_instant_scenarios)
         for i in range(5):
-            _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])))
+            want = ol.simulate(plan, int(seeds[i]))
+            _assert_scenario(res[i], want)
+            assert (int(res.flags[i]) & _abi.FLAG_NEGATIVE_DELAY) == (int(want.counts[_abi.CNT_FLAGS]) & _abi.FLAG_NEGATIVE_DELAY)
+            negative += bool(int(res.flags[i]) & _abi.FLAG_NEGATIVE_DELAY)
             checked += 1
         assert not int(np.bitwise_or.reduce(res.flags)) & _abi.FLAG_TIME_TIE
-    assert checked == 300 and shared > 0
+    assert checked == 300 and shared > 0 and negative == 5
 
 
 def test_shared_timestamps_follow_simpy_order():
