@@ -513,12 +513,18 @@ struct Flow {
     AF_CORE bool edge_draw(uint32_t e, uint32_t idx, double& transit) const {
         const AF_PLAN_AS uint64_t* r = erec(e);
         const double mean = u2d(r[0]), sigma = u2d(r[1]), dropout = u2d(r[2]);
-        const uint32_t dist = (uint32_t)(r[3] >> 16) & 0xFFu;
         const uint32_t stream = af::stream_edge(e);
         const af::U4 rr = af::draw_block(seed, stream, idx, 0u);
         if (af::u53(rr.x, rr.y) < dropout) return false;   // dropped: no latency draw
         const double u1 = af::u53(rr.z, rr.w);
+#if defined(AF_FJ_DIST_ALL) && (AF_FJ_DIST_ALL != 255)
+        // plan-specialised build of a plan whose edges all follow ONE law: the law is a constant, its variate code is
+        // inlined and the call (with the registers it pins around the call site) is gone
+        transit = af::test_quant(af::variate_from_u1(AF_FJ_DIST_ALL, mean, sigma, u1, seed, stream, idx));
+#else
+        const uint32_t dist = (uint32_t)(r[3] >> 16) & 0xFFu;
         transit = af::test_quant(dist == af::DIST_EXPONENTIAL ? -(mean * af::af_log(1.0 - u1)) : cold_variate(dist, mean, sigma, u1, seed, stream, idx));
+#endif
         return true;
     }
     // EdgeRuntime._deliver (edge.py:73-116) for the idx-th message of edge e, sent at `now`.

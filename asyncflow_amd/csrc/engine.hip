@@ -552,6 +552,102 @@ __global__ void __launch_bounds__(64) af_pregen_arrivals(const KArgs a, uint32_t
     }
 }
 
+// Round 3: the same kernel with ONE DPP ROW (16 lanes) per scenario.  The order-dependent part -- lane l adds gaps 0..l to
+// the row's two running sums one by one -- used to fetch gap j of its group through the LDS crossbar (ds_bpermute, two
+// per step and ~100+ cycles each, 12-16 dependent steps per batch: ~1 500 of a batch's ~2 000 cycles were this chain;
+// the kernel was bound by that latency at 2 waves per SIMD, not by issue).  A group that IS a DPP row gets gap j as
+// `v_mov_b32_dpp ... row_newbcast:j` (gfx90a+): register-file latency, no LDS.  Same draws, same f64 additions in the
+// same order: bit-identical arrival times (tests/test_gpu_flow.py::test_arrival_pregeneration_group_widths_are_equivalent).
+// The once-a-window user draw (Poisson by chunked inversion / normal quantile) sits behind a call so that the hot loop
+// keeps <= 128 VGPRs: 2 500 waves of 4 scenarios are then all resident (4 per SIMD).
+template <int J>
+__device__ __forceinline__ double row_bcast(double v) {
+    const uint64_t u = af::d2u(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, 0x150 + J, 0xF, 0xF, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), 0x150 + J, 0xF, 0xF, false);
+    return af::u2d(((uint64_t)hi << 32) | lo);
+}
+__device__ __noinline__ double pregen_users_draw(uint32_t dist, double mean, double sigma, uint64_t seed, uint32_t idx) {
+    if (dist == af::DIST_NORMAL) {
+        const double v = mean + sigma * af::af_norminv(af::uniform_j(seed, af::STREAM_GENERATOR, idx, 0u));
+        return v > 0.0 ? v : 0.0;
+    }
+    return (double)af::af_poisson(mean, seed, af::STREAM_GENERATOR, idx, 0u);
+}
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) af_pregen_arrivals_rows(const KArgs a, uint32_t stride) {
+    constexpr uint32_t G = 16u, S = 4u;
+    const uint32_t lane = threadIdx.x, grp = lane >> 4, l = lane & 15u, gbase = grp * G;
+    const uint32_t slot = blockIdx.x * S + grp;
+    const bool valid = slot < a.n_scen;
+    const uint32_t scen = valid ? (a.scen_map ? a.scen_map[slot] : slot) : 0u;
+    const uint64_t seed = a.seeds[scen];
+    const double users_mean = ovr_or(a, af::PARAM_GEN_USERS_MEAN, 0u, scen, a.gen_users_mean);
+    const double users_sigma = ovr_or(a, af::PARAM_GEN_USERS_SIGMA, 0u, scen, a.gen_users_sigma);
+    const double rpm = ovr_or(a, af::PARAM_GEN_RPM_MEAN, 0u, scen, a.gen_rpm_mean);
+    const double window_s = ovr_or(a, af::PARAM_GEN_WINDOW, 0u, scen, a.gen_window_s);
+    const double rps_per_user = rpm / 60.0;
+    const double T = a.total_time;
+    double* out = a.draws + (size_t)slot * stride;
+    double g_now = 0.0, g_wend = 0.0, lam = 0.0, t = 0.0;   // identical in the 16 lanes of a row
+    uint32_t draws = 0u, k = 0u, flags = 0u;
+    bool run = valid;
+    while (__any(run)) {
+        run = run && g_now < T;
+        if (run && g_now >= g_wend) {  // new window: the number of active users
+            g_wend = g_now + window_s;
+            lam = pregen_users_draw(a.gen_users_dist, users_mean, users_sigma, seed, draws++) * rps_per_user;
+        }
+        const bool idle = run && lam <= 0.0;   // nobody active in this window
+        if (idle) g_now = g_wend;
+        const bool draw = run && !idle;
+        const af::U4 r = af::draw_block(seed, af::STREAM_GENERATOR, draws + l, 0u);
+        double u = af::u53(r.x, r.y);
+        if (u < 1e-15) u = 1e-15;
+        const double dt = -af::af_log(1.0 - u) / (draw ? lam : 1.0);
+        // prefixes in draw order: Gs = sampler clock after gap l, Ss = simulation clock after gap l (x + 0.0 == x exactly)
+        double Gs = g_now, Ss = t;
+#define AF_ROW_STEP(J) { const double dj = row_bcast<J>(dt); const double m = l >= (J) ? dj : 0.0; Gs += m; Ss = Ss + m; }
+        AF_ROW_STEP(0) AF_ROW_STEP(1) AF_ROW_STEP(2) AF_ROW_STEP(3) AF_ROW_STEP(4) AF_ROW_STEP(5) AF_ROW_STEP(6) AF_ROW_STEP(7)
+        AF_ROW_STEP(8) AF_ROW_STEP(9) AF_ROW_STEP(10) AF_ROW_STEP(11) AF_ROW_STEP(12) AF_ROW_STEP(13) AF_ROW_STEP(14) AF_ROW_STEP(15)
+#undef AF_ROW_STEP
+        const bool over = Gs > T;                  // the sampler is exhausted at this draw
+        const bool cross = !over && Gs >= g_wend;  // this draw crosses the window end: discarded
+        const uint64_t stops = __ballot(draw && (over || cross));
+        const uint32_t mine = (uint32_t)(stops >> gbase) & 0xFFFFu;
+        const uint32_t first = mine ? (uint32_t)__builtin_ctz(mine) : G;   // draws before it are arrivals
+        uint32_t n_acc = first;
+        bool full = false;
+        if (draw && k + n_acc > a.n_draw) {  // more arrivals than the array holds
+            n_acc = a.n_draw - k;
+            full = true;
+        }
+        if (draw && l < n_acc) out[k + l] = Ss;
+        const double Glast = row_bcast<15>(Gs), Slast = row_bcast<15>(Ss);
+        const double Sprev = __shfl(Ss, (int)((gbase + (first > 0u ? first - 1u : 0u)) & 63u), 64);
+        const bool over_first = ((__ballot(over) >> gbase) >> (first & 15u)) & 1ull;
+        if (draw) {
+            k += n_acc;
+            if (full) {
+                flags = AF_FLAG_DRAW_OVERFLOW;
+                run = false;
+            } else if (first == G) {
+                g_now = Glast;
+                t = Slast;
+                draws += G;
+            } else {
+                if (first > 0u) t = Sprev;
+                draws += first + 1u;
+                if (over_first) run = false;
+                else g_now = g_wend;
+            }
+        }
+    }
+    if (valid) {
+        for (uint32_t i = k + l; i < a.n_draw; i += G) out[i] = af::AF_INF;
+        if (l == 0u) a.pre_flags[slot] = flags;
+    }
+}
+
 // launch helper: the group width with the shortest issue-bound time for `n` scenarios (see the kernel's comment).
 // Measured (10 000 / 8 192 LB-2 replicas): 4 per wave 15.2 / 9.5 ms, 5 per wave 11.7 / -, 8 per wave - / 15.1 ms (one wave
 // per SIMD: nothing hides its latencies).  More than 4 per wave only when the SIMDs still get ~2 waves each and the
@@ -568,9 +664,17 @@ static void launch_pregen_arrivals(const KArgs& a, uint32_t n, uint32_t stride, 
             best_s = s;
         }
     }
+    bool rows = true;   // round 3: one DPP row per scenario (af_pregen_arrivals_rows) unless an older variant is asked for
     if (const char* env = std::getenv("AF_PREGEN_SCEN_PER_WAVE")) {
         const uint32_t v = (uint32_t)std::atoi(env);
-        if (v == 4u || v == 5u || v == 8u) best_s = v;
+        if (v == 4u || v == 5u || v == 8u) {
+            best_s = v;
+            rows = false;
+        }
+    }
+    if (rows) {
+        hipLaunchKernelGGL(af_pregen_arrivals_rows, dim3((n + 3u) / 4u), dim3(64), 0, stream, a, stride);
+        return;
     }
     const dim3 grid((n + best_s - 1u) / best_s);
     if (best_s == 4u) hipLaunchKernelGGL(af_pregen_arrivals<16>, grid, dim3(64), 0, stream, a, stride);
@@ -1139,6 +1243,13 @@ std::string flow_jit_spec_string(const af_engine* e, const FlowPlan& P, const af
         std::memcpy(&u, &v, 8);
         return (unsigned long long)u;
     };
+    uint32_t dist_all = e->edge_dist.empty() ? 255u : e->edge_dist[0];     // the ONE latency law of every edge, else 255
+    for (uint8_t d : e->edge_dist)
+        if (d != dist_all) dist_all = 255u;
+    // (measured, round 3: the constant pays for the laws behind the call -- BASELINE config 5, log-normal: 245.4 -> 235.5 ms per
+    // 50 000 replicas -- but NOT for the exponential law, whose variate is inline anyway: without the call site the compiler
+    // allocates 72 instead of 110 VGPRs and the kernel is 6 % SLOWER (48.5 -> 51.6 ms on config 2), five waves per SIMD included)
+    if (dist_all == AF_DIST_EXPONENTIAL || std::getenv("AF_FLOW_NO_DIST_CONST")) dist_all = 255u;
     char buf[2048];
     std::snprintf(buf, sizeof buf,
                   "-DAF_JIT=1 -DAF_FLOW_JIT=1 -DAF_FJ_IPL=%u -DAF_FJ_FEAT=%u -DAF_FJ_TOTAL_TIME=0x%llxull -DAF_FJ_PERIOD=0x%llxull "
@@ -1146,13 +1257,13 @@ std::string flow_jit_spec_string(const af_engine* e, const FlowPlan& P, const af
                   "-DAF_FJ_N_EDGES=%u -DAF_FJ_N_SERVERS=%u -DAF_FJ_HAS_LB=%u -DAF_FJ_N_LB=%u -DAF_FJ_N_EMARKS=%u -DAF_FJ_N_SMARKS=%u "
                   "-DAF_FJ_LC=%u -DAF_FJ_MAX_PRE=%u -DAF_FJ_MAX_CPU=%u -DAF_FJ_MAX_POST=%u -DAF_FJ_OFF_EDGE=%u -DAF_FJ_OFF_SRV=%u "
                   "-DAF_FJ_OFF_EP=%u -DAF_FJ_OFF_ROW=%u -DAF_FJ_OFF_EMARK=%u -DAF_FJ_OFF_SMARK=%u -DAF_FJ_OFF_LB=%u -DAF_FJ_BLOB_BYTES=%u "
-                  "-DAF_FJ_N_TICKS=%u -DAF_FJ_HAS_CLOCK=%d -DAF_FJ_HAS_SAMPLES=%d -DAF_FJ_HAS_ONLINE=%d -DAF_FJ_HAS_OVR=%d "
+                  "-DAF_FJ_N_TICKS=%u -DAF_FJ_HAS_CLOCK=%d -DAF_FJ_HAS_SAMPLES=%d -DAF_FJ_HAS_ONLINE=%d -DAF_FJ_HAS_OVR=%d -DAF_FJ_DIST_ALL=%u "
                   "-DAF_FJ_LAYOUT=%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u",
                   P.ipl, P.feat | (std::getenv("AF_FLOW_PROF") ? (uint32_t)aff::FEAT_PROF : 0u), bits(f.total_time), bits(f.sample_period), bits(f.inv_period), bits(f.tick_eps), f.metrics_mask,
                   f.gen_out_edge, f.client_out_edge, f.n_edges, f.n_servers, f.has_lb, f.n_lb_edges, f.n_edge_marks, f.n_srv_marks,
                   f.lb_least_connections, f.max_pre, f.max_cpu, f.max_post, f.off_edge, f.off_srv, f.off_ep, f.off_row, f.off_emark,
                   f.off_smark, f.off_lb, f.blob_bytes, f.n_ticks, out->clock ? 1 : 0, out->samples ? 1 : 0,
-                  (out->online_hist || out->online_rps) ? 1 : 0, has_ovr ? 1 : 0,
+                  (out->online_hist || out->online_rps) ? 1 : 0, has_ovr ? 1 : 0, dist_all,
                   L.cap, L.ring_rows, L.win_rows, L.g_ring, L.c_ring, L.pitch, L.list_arrays, L.off_spike, L.off_list, L.off_aux, L.off_aux3,
                   L.off_out, L.off_sorted, L.off_hist, L.off_seg, L.off_fr, L.off_gr, L.off_cnt, L.off_ring, L.n_words, L.cap_of[0],
                   L.cap_of[1], L.cap_of[2], L.cap_of[3], L.off_list_of[0], L.off_list_of[1], L.off_list_of[2], L.off_list_of[3], L.off_eb);

@@ -313,12 +313,14 @@ def test_config2_replicas_at_full_horizon_match_the_oracle_bit_for_bit():
     assert np.array_equal(res[0].rqs_clock, fx["clock"]) and np.array_equal(res[0]._samples, fx["samples"])  # noqa: SLF001
 
 
-@pytest.mark.parametrize("per_wave", [4, 5, 8])
+@pytest.mark.parametrize("per_wave", [0, 4, 5, 8])
 def test_arrival_pregeneration_group_widths_are_equivalent(monkeypatch, per_wave):
-    """af_pregen_arrivals packs 4, 5 or 8 scenarios into a wave (16 / 12 / 8 lanes each; the engine picks by sweep size):
-    same arrival times whichever it is -- tiny sampling windows (window ends inside most batches), Gaussian users, a
-    scenario count that leaves the last wave ragged."""
-    monkeypatch.setenv("AF_PREGEN_SCEN_PER_WAVE", str(per_wave))
+    """The arrival pre-generation as the engine launches it since round 3 (0: one DPP row of 16 lanes per scenario, the gaps
+    of a batch handed along the row by `row_newbcast`) and in its round-2 forms (4, 5 or 8 scenarios per wave through the
+    LDS crossbar): same arrival times whichever it is -- tiny sampling windows (window ends inside most batches),
+    Gaussian users, a scenario count that leaves the last wave ragged."""
+    if per_wave:
+        monkeypatch.setenv("AF_PREGEN_SCEN_PER_WAVE", str(per_wave))
     payload = lb_two_servers(horizon=40)
     payload["rqs_input"]["user_sampling_window"] = 1
     payload["rqs_input"]["avg_active_users"] = {"mean": 150, "distribution": "normal", "variance": 60}
