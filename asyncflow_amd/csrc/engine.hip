@@ -648,6 +648,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) af
     }
 }
 
+// (Round 3 also built VERDICT r2's item 4 -- the variates of every draw index by a fully parallel kernel at 8 waves per SIMD,
+// the order-dependent sums by a chain kernel with 8 lanes and 8 draws per scenario and batch, variates prefetched four batches
+// ahead -- and removed it again: af_arrival_variates 3.3 ms + af_arrival_chain 11.9 ms against 11.0 ms for the fused row kernel.
+// The counters say why: the chain kernel alone executes 2.9e9 VALU wave-instructions (233 per batch of 64 draws: the masked
+// sums, the per-group state updates behind `v_cndmask`, address arithmetic), the fused kernel 4.0e9 INCLUDING the variates --
+// the serial bookkeeping, not Philox + log, is what the pre-generation costs, and it does not shrink by being alone.
+// DESIGN.md section 4f.)
 // launch helper: the group width with the shortest issue-bound time for `n` scenarios (see the kernel's comment).
 // Measured (10 000 / 8 192 LB-2 replicas): 4 per wave 15.2 / 9.5 ms, 5 per wave 11.7 / -, 8 per wave - / 15.1 ms (one wave
 // per SIMD: nothing hides its latencies).  More than 4 per wave only when the SIMDs still get ~2 waves each and the
