@@ -86,11 +86,20 @@ struct FlowLayout {
     // FEAT_BIGLIST: every list has its own capacity (a list behind a spiked edge holds rate x spike messages when the
     // spike ends); cap is then the largest of them
     uint32_t cap_of[4], off_list_of[4], off_eb;
+    uint32_t off_gsrv;   // FEAT_GENSRV: per-server state of the general server station (kGsWords words each), else 0
 };
+// FEAT_GENSRV: per-server state, in 8-byte words (Flow::gen_servers)
+constexpr uint32_t kGsSlots = 32u;   // requests inside one server at once (more: handed back)
+constexpr uint32_t kGsDeps = kGsSlots + 64u;   // departures of one round: at most what was inside plus the round's arrivals
+enum : uint32_t { GS_CPU = 0u /* cpu_free | ready << 32 */, GS_IO = 1u /* io | free-slot mask << 32 */, GS_RAM = 2u /* f64 free RAM */,
+                  GS_ARR = 3u /* arrivals | RAM queue blocked << 32 */, GS_CQ = 4u /* head | n << 32 */, GS_RQ = 5u, GS_EV = 6u, GS_DEP = 7u /* departures of this round */,
+                  GS_T0 = 8u, GS_NEED = GS_T0 + kGsSlots, GS_STATE = GS_NEED + kGsSlots /* row | holds core << 16 | in I/O << 17 */,
+                  GS_EVT = GS_STATE + kGsSlots /* sorted ring of pending step ends: time */, GS_BYTES = GS_EVT + kGsSlots /* 3 x kGsSlots bytes: event slots, CPU waiters, RAM waiters */,
+                  GS_DEPT = GS_BYTES + (3u * kGsSlots + 7u) / 8u, GS_DEPT0 = GS_DEPT + kGsDeps, kGsWords = GS_DEPT0 + kGsDeps };
 
 inline FlowLayout make_flow_layout(uint32_t cap, uint32_t ring_rows, uint32_t g_ring, uint32_t c_ring, uint32_t n_edges,
                                    uint32_t n_servers, uint32_t n_edge_marks, bool tiebreak = false,
-                                   const uint32_t* caps4 = nullptr) {
+                                   const uint32_t* caps4 = nullptr, bool general_servers = false) {
     FlowLayout L{};
     for (uint32_t s = 0; s < 4u; ++s) {
         L.cap_of[s] = caps4 ? caps4[s] : cap;
@@ -125,6 +134,8 @@ inline FlowLayout make_flow_layout(uint32_t cap, uint32_t ring_rows, uint32_t g_
     L.off_gr = w; w += n_servers * g_ring;
     L.off_cnt = w; w += (n_edges + 1u) / 2u + LBW_U32 / 2u + 12u;   // u32 sends per edge; LBW_U32 u32: lb order, head, n_live, mark cursor, per-server counters; send_floor's 4 x 3 f64
     L.off_ring = w; w += (ring_rows * L.pitch + 1u) / 2u;
+    L.off_gsrv = general_servers ? w : 0u;
+    if (general_servers) w += n_servers * kGsWords;
     L.n_words = w;
     return L;
 }
@@ -136,6 +147,10 @@ struct FlowArgs {
     uint32_t n_edges, n_servers, has_lb, n_lb_edges, n_edge_marks, n_srv_marks;
     uint32_t lb_least_connections;   // 0 round robin, 1 least connections (needs a FEAT_LC instantiation)
     uint32_t max_pre, max_cpu, max_post;   // longest leading-I/O / CPU / trailing-I/O run over the servers' endpoints
+    // ram_in_use is a sum of the requests' RAM needs; the tick ring holds integer differences.  Needs that are whole MB: scale 1;
+    // dyadic fractions (multiples of 1/256 MB: 100.25, 400.5 -- their sums are exact in f64 in any order, like the
+    // reference's += / -=): scale 256, and the value leaves the ring as (sum of differences) x ram_unit = 1 / ram_scale
+    double ram_scale, ram_unit;
     uint32_t off_edge, off_srv, off_ep, off_row, off_emark, off_smark, off_lb;  // word offsets in the blob
     uint32_t blob_bytes;
     const unsigned char* blob;
@@ -204,15 +219,22 @@ enum : uint32_t { PROF_SETUP, PROF_GEN, PROF_SELECT, PROF_SERIES_RECV, PROF_STAT
 //   FEAT_FAR       edges slower than the LDS tick ring reaches: the sender enters only the send of such a message and
 //                  marks it, the receiving station enters the delivery (file header, "Sampled series").  Without it the
 //                  sender enters both ends and a delivery beyond the ring hands the scenario back.
+//   FEAT_GENSRV    general servers (round 3): several endpoints per server (server.py:101), step programs that come back to the
+//                  core queue after an I/O step, RAM needs that differ per request.  The order in which requests reach a
+//                  server's queues is then no longer their arrival order, so the station cannot finalise an arrival when it
+//                  sees it: lane k runs server k as a little sequential next-event loop of its own (sorted ring of pending
+//                  step ends, FIFO of core waiters, FIFO of RAM waiters: Flow::gen_servers) up to the horizon of the station --
+//                  every arrival before it is known --, servers side by side in the lanes, and the departures it produced are
+//                  then sent by the whole wave like any other batch.  Two events of one server at one instant are handed back.
 //   FEAT_PROF      measurement builds only: the wave's shader-clock time per section of run() (FlowArgs::prof)
 enum : uint32_t { FEAT_MARKS = 1u, FEAT_ONLINE = 2u, FEAT_HBM_RING = 4u, FEAT_FAR = 64u, FEAT_ALL = 7u | FEAT_FAR, FEAT_TIEBREAK = 8u,
-                  FEAT_BIGLIST = 16u, FEAT_LC = 32u, FEAT_PROF = 128u };
+                  FEAT_BIGLIST = 16u, FEAT_LC = 32u, FEAT_PROF = 128u, FEAT_GENSRV = 256u };
 template <class W, uint32_t IPL = 1u, uint32_t FEAT = FEAT_ALL>
 struct Flow {
     static constexpr bool kMarks = (FEAT & FEAT_MARKS) != 0u, kOnline = (FEAT & FEAT_ONLINE) != 0u,
                           kHbmRing = (FEAT & FEAT_HBM_RING) != 0u, kTieBreak = (FEAT & FEAT_TIEBREAK) != 0u,
                           kBig = (FEAT & FEAT_BIGLIST) != 0u, kLC = (FEAT & FEAT_LC) != 0u, kFar = (FEAT & FEAT_FAR) != 0u,
-                          kProf = (FEAT & FEAT_PROF) != 0u;
+                          kProf = (FEAT & FEAT_PROF) != 0u, kGen = (FEAT & FEAT_GENSRV) != 0u;
     // FEAT_PROF: the time since the previous mark belongs to `section` (marks sit at the END of a section, in
     // wave-uniform control flow, with a compile-time section: the accumulators stay in scalar registers)
     unsigned long long prof_t, prof_acc[kProfSections];
@@ -397,7 +419,7 @@ struct Flow {
                         if (lane < pitch && r < stop) {
                             run_val += d[u];
                             uint32_t word = 0u;
-                            if (on) word = is_ram ? __builtin_bit_cast(uint32_t, (float)(double)run_val) : (uint32_t)run_val;
+                            if (on) word = is_ram ? __builtin_bit_cast(uint32_t, (float)((double)run_val * A.ram_unit)) : (uint32_t)run_val;
                             samples[(size_t)r * pitch + lane] = word;
                         }
                     }
@@ -428,7 +450,7 @@ struct Flow {
                     const int32_t value = (int32_t)W::shfl32((uint32_t)run_val, ser) + acc;
                     if (valid) {
                         uint32_t word = 0u;
-                        if (s_on) word = s_ram ? __builtin_bit_cast(uint32_t, (float)(double)value) : (uint32_t)value;
+                        if (s_on) word = s_ram ? __builtin_bit_cast(uint32_t, (float)((double)value * A.ram_unit)) : (uint32_t)value;
                         samples[(size_t)rr * pitch + ser] = word;
                     }
                     const int32_t last = (int32_t)W::shfl32((uint32_t)value, ((n_rows - 1u) * pitch + lane) & 63u);
@@ -441,7 +463,7 @@ struct Flow {
                         run_val += *cell;
                         *cell = 0;
                         uint32_t word = 0u;
-                        if (on) word = is_ram ? __builtin_bit_cast(uint32_t, (float)(double)run_val) : (uint32_t)run_val;
+                        if (on) word = is_ram ? __builtin_bit_cast(uint32_t, (float)((double)run_val * A.ram_unit)) : (uint32_t)run_val;
                         samples[(size_t)r * pitch + lane] = word;
                     }
                 }
@@ -1142,6 +1164,199 @@ struct Flow {
         return r;
     }
 
+
+    // ---- general servers (FEAT_GENSRV; server.py:79-313 without the tandem restriction) -------------------------------
+    // Lane sv < n_servers runs server sv: its arrivals of this round (seg(0) / seg(1): time, start time, time order, segment
+    // [LBW_SEG_OFF, + LBW_SEG_LEN)) merged with its pending step ends, in time order, up to `limit` (every arrival before it is
+    // known).  Plain per-lane code: no cross-lane operation in here.  Departures go to the server's GS_DEPT / GS_DEPT0 arrays.
+    AF_CORE AF_PLAN_AS uint64_t* gs(uint32_t sv) const { return M + A.L.off_gsrv + sv * kGsWords; }
+    AF_CORE static uint32_t lo32(uint64_t w) { return (uint32_t)w; }
+    AF_CORE static uint32_t hi32(uint64_t w) { return (uint32_t)(w >> 32); }
+    AF_CORE static uint64_t pack32(uint32_t lo, uint32_t hi) { return (uint64_t)lo | ((uint64_t)hi << 32); }
+    AF_CORE AF_PLAN_AS uint8_t* gs_bytes(AF_PLAN_AS uint64_t* g, uint32_t which) const { return (AF_PLAN_AS uint8_t*)(g + GS_BYTES) + which * kGsSlots; }
+    AF_CORE void gs_point(uint32_t series, uint32_t row, int32_t w) {
+        if (samples != nullptr) add_point(series, row, w);
+    }
+    // pending step end of `slot` at `t`: sorted ring (ascending; equal times are found when they reach the front)
+    AF_CORE void gs_schedule(AF_PLAN_AS uint64_t* g, double t, uint32_t slot) {
+        const uint32_t head = lo32(g[GS_EV]), n = hi32(g[GS_EV]);
+        AF_PLAN_AS uint8_t* es = gs_bytes(g, 0u);
+        uint32_t i = n;
+        while (i > 0u && u2d(g[GS_EVT + ((head + i - 1u) & (kGsSlots - 1u))]) > t) {
+            g[GS_EVT + ((head + i) & (kGsSlots - 1u))] = g[GS_EVT + ((head + i - 1u) & (kGsSlots - 1u))];
+            es[(head + i) & (kGsSlots - 1u)] = es[(head + i - 1u) & (kGsSlots - 1u)];
+            i -= 1u;
+        }
+        g[GS_EVT + ((head + i) & (kGsSlots - 1u))] = d2u(t);
+        es[(head + i) & (kGsSlots - 1u)] = (uint8_t)slot;
+        g[GS_EV] = pack32(head, n + 1u);
+    }
+    // a core became free: the first waiter gets it (Container FIFO, server.py:210-231) and starts its CPU step now
+    AF_CORE void gs_core_release(AF_PLAN_AS uint64_t* g, uint32_t s0, double now, uint32_t rown) {
+        const uint32_t head = lo32(g[GS_CQ]), n = hi32(g[GS_CQ]);
+        if (n == 0u) {
+            g[GS_CPU] = g[GS_CPU] + 1ull;   // cpu_free += 1
+            return;
+        }
+        const uint32_t slot = gs_bytes(g, 1u)[head];
+        g[GS_CQ] = pack32((head + 1u) & (kGsSlots - 1u), n - 1u);
+        g[GS_CPU] = g[GS_CPU] - (1ull << 32);   // ready -= 1
+        gs_point(s0, rown, -1);
+        const uint64_t st = g[GS_STATE + slot];
+        g[GS_STATE + slot] = st | (1ull << 16);   // holds the core
+        gs_schedule(g, now + u2d(blob[A.off_row + af::TREC * (uint32_t)(st & 0xFFFFu)]), slot);
+    }
+    // the request in `slot` stands before step row `row` (the for-loop of _handle_request, server.py:197-276)
+    AF_CORE void gs_advance(AF_PLAN_AS uint64_t* g, uint32_t sv, uint32_t slot, double now, uint32_t rown, bool& ram_released) {
+        const uint32_t s0 = A.n_edges + 3u * sv;
+        const uint64_t st = g[GS_STATE + slot];
+        const uint32_t row = (uint32_t)(st & 0xFFFFu);
+        const bool holds = (st >> 16) & 1ull, in_io = (st >> 17) & 1ull;
+        const uint32_t kind = (uint32_t)blob[A.off_row + af::TREC * row + 2u];
+        const double dur = u2d(blob[A.off_row + af::TREC * row]);
+        if (kind == af::STEP_CPU) {   // server.py:199-231
+            if (in_io) {
+                g[GS_IO] = g[GS_IO] - 1ull;
+                gs_point(s0 + 1u, rown, -1);
+            }
+            if (!holds) {
+                const uint32_t cq_n = hi32(g[GS_CQ]);
+                if (cq_n == 0u && lo32(g[GS_CPU]) > 0u) {
+                    g[GS_CPU] = g[GS_CPU] - 1ull;   // granted at once: never in the ready queue
+                } else {
+                    gs_bytes(g, 1u)[(lo32(g[GS_CQ]) + cq_n) & (kGsSlots - 1u)] = (uint8_t)slot;
+                    g[GS_CQ] = pack32(lo32(g[GS_CQ]), cq_n + 1u);
+                    g[GS_CPU] = g[GS_CPU] + (1ull << 32);   // ready += 1
+                    gs_point(s0, rown, 1);
+                    g[GS_STATE + slot] = (uint64_t)row;   // waiting: neither core nor I/O
+                    return;
+                }
+            }
+            g[GS_STATE + slot] = (uint64_t)row | (1ull << 16);
+            gs_schedule(g, now + dur, slot);
+            return;
+        }
+        if (kind == af::STEP_IO) {   // server.py:235-255
+            if (holds) gs_core_release(g, s0, now, rown);
+            if (!in_io) {
+                g[GS_IO] = g[GS_IO] + 1ull;
+                gs_point(s0 + 1u, rown, 1);
+            }
+            g[GS_STATE + slot] = (uint64_t)row | (1ull << 17);
+            gs_schedule(g, now + dur, slot);
+            return;
+        }
+        // the endpoint is through (server.py:257-276): core, RAM, the response
+        if (holds) gs_core_release(g, s0, now, rown);
+        if (in_io) {
+            g[GS_IO] = g[GS_IO] - 1ull;
+            gs_point(s0 + 1u, rown, -1);
+        }
+        const double need = u2d(g[GS_NEED + slot]);
+        if (need > 0.0) {
+            g[GS_RAM] = d2u(u2d(g[GS_RAM]) + need);
+            gs_point(s0 + 2u, rown, -(int32_t)(need * A.ram_scale));
+            ram_released = true;
+        }
+        const uint32_t nd = lo32(g[GS_DEP]);
+        g[GS_DEPT + nd] = d2u(now);
+        g[GS_DEPT0 + nd] = g[GS_T0 + slot];
+        g[GS_DEP] = pack32(nd + 1u, 0u);
+        g[GS_IO] = g[GS_IO] | (1ull << (32u + slot));   // the slot is free again
+    }
+    // RAM waiters, strictly FIFO with head-of-line blocking (Container._trigger_get, server.py:146-149)
+    AF_CORE void gs_ram_queue(AF_PLAN_AS uint64_t* g, uint32_t sv, double now, uint32_t rown) {
+        const uint32_t s0 = A.n_edges + 3u * sv;
+        for (;;) {
+            const uint32_t head = lo32(g[GS_RQ]), n = hi32(g[GS_RQ]);
+            if (n == 0u) return;
+            const uint32_t slot = gs_bytes(g, 2u)[head];
+            const double need = u2d(g[GS_NEED + slot]), free_ram = u2d(g[GS_RAM]);
+            if (free_ram < need) return;
+            g[GS_RQ] = pack32((head + 1u) & (kGsSlots - 1u), n - 1u);
+            g[GS_RAM] = d2u(free_ram - need);
+            gs_point(s0 + 2u, rown, (int32_t)(need * A.ram_scale));
+            bool again = false;
+            gs_advance(g, sv, slot, now, rown, again);   // (an endpoint of RAM steps only gives its RAM straight back: the loop looks again)
+        }
+    }
+    AF_CORE uint32_t gen_servers(uint32_t sv, double limit) {
+        AF_PLAN_AS uint64_t* g = gs(sv);
+        AF_PLAN_AS uint32_t* lw = lbw();
+        const uint32_t off = lw[LBW_SEG_OFF + sv], n_k = lw[LBW_SEG_LEN + sv], s0 = A.n_edges + 3u * sv;
+        const uint64_t meta = blob[A.off_srv + af::SREC * sv + 1u];
+        const uint32_t epb = (uint32_t)(meta >> 32) & 0xFFFFu, n_ep = (uint32_t)(meta >> 48);
+        const double ram_mb = u2d(blob[A.off_srv + af::SREC * sv]);
+        uint32_t ai = 0u, done = 0u;
+        g[GS_DEP] = 0ull;
+        for (;;) {
+            const double ta = ai < n_k ? seg(0)[off + ai] : AF_INF;
+            const uint32_t ev_head = lo32(g[GS_EV]), ev_n = hi32(g[GS_EV]);
+            const double te = ev_n ? u2d(g[GS_EVT + ev_head]) : AF_INF;
+            const double now = ta < te ? ta : te;
+            if (!(now < limit)) break;
+            if (ta == te || (ev_n > 1u && u2d(g[GS_EVT + ((ev_head + 1u) & (kGsSlots - 1u))]) == te && te < ta)) {
+                why |= FLOW_WHY_TIE;   // two events of this server at one instant: SimPy's order decides, the next-event kernels have it
+                break;
+            }
+            if (lo32(g[GS_DEP]) >= kGsDeps) {   // (cannot happen: a round's departures <= requests inside + its arrivals)
+                why |= FLOW_WHY_LIST;
+                break;
+            }
+            const uint32_t rown = samples != nullptr ? tick_index(now, true) : 0u;
+            bool ram_released = false;
+            done += 1u;
+            if (te < ta) {   // a CPU or I/O step ends
+                const uint32_t slot = gs_bytes(g, 0u)[ev_head];
+                g[GS_EV] = pack32((ev_head + 1u) & (kGsSlots - 1u), ev_n - 1u);
+                ev += 1u;
+                const uint64_t st = g[GS_STATE + slot];
+                g[GS_STATE + slot] = (st & ~0xFFFFull) | (uint64_t)(((uint32_t)st & 0xFFFFu) + 1u);   // next row; core / I/O as they were
+                gs_advance(g, sv, slot, now, rown, ram_released);
+            } else {         // a request arrives (server.py:303-313, 79-149)
+                const uint32_t idx = lo32(g[GS_ARR]);
+                g[GS_ARR] = g[GS_ARR] + 1ull;
+                const uint32_t pick = n_ep > 1u ? af::cold_endpoint_pick(seed, sv, idx, n_ep) : 0u;
+                const double need = u2d(blob[A.off_ep + af::PREC * (epb + pick)]);
+                const uint32_t row0 = (uint32_t)blob[A.off_ep + af::PREC * (epb + pick) + 1u];
+                const double t0a = seg(1)[off + ai];
+                ai += 1u;
+                const bool blocked = hi32(g[GS_ARR]) != 0u;
+                if (need > 0.0 && (need > ram_mb || blocked)) {   // waits for good, and so does every RAM request behind it
+                    info |= af::FLAG_RAM_STARVED;
+                    g[GS_ARR] = pack32(lo32(g[GS_ARR]), 1u);
+                } else {
+                    const uint32_t free_mask = hi32(g[GS_IO]);
+                    if (free_mask == 0u) {
+                        why |= FLOW_WHY_LIST;   // more requests inside this server than the station holds
+                        break;
+                    }
+                    const uint32_t slot = (uint32_t)__builtin_ctz(free_mask);
+                    g[GS_IO] = g[GS_IO] & ~(1ull << (32u + slot));
+                    g[GS_T0 + slot] = d2u(t0a);
+                    g[GS_NEED + slot] = d2u(need);
+                    g[GS_STATE + slot] = (uint64_t)row0;
+                    bool go = true;
+                    if (need > 0.0) {
+                        const uint32_t rq_n = hi32(g[GS_RQ]);
+                        const double free_ram = u2d(g[GS_RAM]);
+                        if (rq_n == 0u && free_ram >= need) {
+                            g[GS_RAM] = d2u(free_ram - need);
+                            gs_point(s0 + 2u, rown, (int32_t)(need * A.ram_scale));
+                        } else {
+                            gs_bytes(g, 2u)[(lo32(g[GS_RQ]) + rq_n) & (kGsSlots - 1u)] = (uint8_t)slot;
+                            g[GS_RQ] = pack32(lo32(g[GS_RQ]), rq_n + 1u);
+                            go = false;
+                        }
+                    }
+                    if (go) gs_advance(g, sv, slot, now, rown, ram_released);
+                }
+            }
+            if (ram_released) gs_ram_queue(g, sv, now, rown);
+        }
+        return done;
+    }
+
     // ---- completion (client.py:62-69) -------------------------------------------------------------------
     AF_CORE void complete(bool have, uint32_t r, double t0, double now) {
         if (!have) return;
@@ -1250,6 +1465,13 @@ struct Flow {
                 }
                 lw[LBW_SLOTS + v] = slots;
             }
+            if (kGen)
+                for (uint32_t v = 0u; v < A.n_servers; ++v) {   // build_containers (server_containers.py:61-68): full
+                    AF_PLAN_AS uint64_t* g = gs(v);
+                    g[GS_CPU] = blob[A.off_srv + af::SREC * v + 1u] & 0xFFFFull;   // cpu_free = cores, nobody ready
+                    g[GS_IO] = 0xFFFFFFFF00000000ull;                                  // every slot free
+                    g[GS_RAM] = blob[A.off_srv + af::SREC * v];
+                }
             for (uint32_t i = 0u; i < A.n_lb_edges; ++i) lw[i] = (uint32_t)blob[A.off_lb + i];
             lw[16] = 0u;
             lw[17] = A.n_lb_edges;
@@ -1356,6 +1578,63 @@ struct Flow {
                         idx = claim_send_index(have, e, false);
                         tgt = (uint32_t)(erec(e)[3] >> 8) & 0xFFu;
                     }
+                } else if (kGen && st == 3u) {   // servers, general form: lane k runs server k up to the station's horizon
+                    const uint32_t sv = aux & 0xFFu;
+                    uint32_t pos = 0u, off = 0u;
+                    for (uint32_t k = 0u; k < A.n_servers; ++k) {
+                        const uint64_t m = W::ballot(have && sv == k);
+                        if (have && sv == k) pos = off + W::mbcnt(m);
+                        if (lane == k) {
+                            lbw()[LBW_SEG_OFF + k] = off;
+                            lbw()[LBW_SEG_LEN + k] = popc64(m);
+                        }
+                        off += popc64(m);
+                    }
+                    W::sync();   // select()'s scratch is dead: the arrivals of the round, per server, in time order
+                    if (have) {
+                        seg(0)[pos] = key;
+                        seg(1)[pos] = t0;
+                    }
+                    W::sync();
+                    uint32_t done = 0u;
+                    if (lane < A.n_servers) done = gen_servers(lane, H_get(2u));
+                    W::sync();
+                    work += popc64(W::ballot(done != 0u));
+                    prof(PROF_SERVERS);
+                    // the departures the servers produced (each server's in time order), sent by the whole wave, 64 at a time
+                    uint32_t total = 0u;
+                    for (uint32_t k = 0u; k < A.n_servers; ++k) total += lo32(gs(k)[GS_DEP]);
+                    const bool too_many = total > cap_of(3u) - nl3;   // (wave-uniform)
+                    if (too_many) why |= FLOW_WHY_LIST;
+                    for (uint32_t base = 0u; base < total && !too_many; base += 64u) {
+                        const uint32_t want = base + lane;   // my departure, counted over the servers in order
+                        bool mine = false;
+                        uint32_t me = 0u, mj = 0u, first = 0u;
+                        for (uint32_t k = 0u; k < A.n_servers; ++k) {
+                            const uint32_t cnt = lo32(gs(k)[GS_DEP]);
+                            if (want >= first && want < first + cnt) {
+                                mine = true;
+                                me = k;
+                                mj = want - first;
+                            }
+                            first += cnt;
+                        }
+                        const uint32_t oe = (uint32_t)(blob[A.off_srv + af::SREC * me + 1u] >> 16) & 0xFFFFu;
+                        const double dts = mine ? u2d(gs(me)[GS_DEPT + mj]) : 0.0, dt0 = mine ? u2d(gs(me)[GS_DEPT0 + mj]) : 0.0;
+                        const uint32_t didx = sends()[oe] + mj;
+                        double k2 = 0.0, transit = 0.0;
+                        bool counted = false;
+                        const bool sent = mine && send_draw(oe, didx, transit);
+                        prof(PROF_DRAW);
+                        const uint32_t drow = (kFar && sent && samples != nullptr) ? tick_index(dts, true) : 0u;
+                        const bool ok = sent && send_finish(oe, dts, drow, kFar, transit, k2, counted);
+                        prof(PROF_SEND_SERIES);
+                        append(3u, ok, k2, (kFar && counted) ? -dt0 : dt0, oe, dts);
+                    }
+                    W::sync();
+                    if (lane < A.n_servers) sends()[(uint32_t)(blob[A.off_srv + af::SREC * lane + 1u] >> 16) & 0xFFFFu] += lo32(gs(lane)[GS_DEP]);
+                    W::sync();
+                    sending = false;   // (everything this station sends went out above)
                 } else if (st == 3u) {   // servers
                     if (n_sel > 0u) {
                         const uint32_t sv = aux & 0xFFu;
@@ -1394,7 +1673,7 @@ struct Flow {
                                 if (q_ready) add_span(s0, t_b, t_s, 1);
                                 if (q_pre) add_span(s0 + 1u, t_adm, t_b, 1);
                                 if (q_post) add_span(s0 + 1u, t_f, t_g, 1);
-                                if (q_ram) add_span(s0 + 2u, t_adm, t_g, (int32_t)ram);
+                                if (q_ram) add_span(s0 + 2u, t_adm, t_g, (int32_t)(ram * A.ram_scale));
                                 row = t_g;
                             }
                         }
@@ -1410,7 +1689,10 @@ struct Flow {
                 if (st == 3u) prof(PROF_SERVERS);
                 else if (st == 4u) prof(PROF_COMPLETE);
                 else prof(PROF_STATION);
-                if (st < 4u) {
+                if (kGen && st == 3u) {
+                    H_in = send_floor(3u, H_get(2u));
+                    prof(PROF_APPEND);
+                } else if (st < 4u) {
                     double k2 = 0.0;
                     bool counted = false;
                     double transit = 0.0;
@@ -1439,6 +1721,9 @@ struct Flow {
             flush_ticks(finished ? A.n_ticks : tick_index(h_min, false));
             W::sync();
             prof(PROF_FLUSH);
+#if defined(AF_FLOW_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
+            if (lane == 0u) std::fprintf(stderr, "round: work %u cursor %u nl %u %u %u %u h %.6f %.6f %.6f %.6f hgen %.6f hmin %.6f moved %d tick_base %u n_comp %u why %x\n", work, cursor, nl0, nl1, nl2, nl3, h0, h1, h2, h3, h_gen, h_min, (int)moved, tick_base, n_comp, why);
+#endif
             const bool stuck = work == 0u && !finished && !(kMarks ? moved : h3 > h_done_before);
             if (stuck) why |= FLOW_WHY_LIST;   // nothing moved, no horizon advanced: a list is full of later messages
             if (finished || W::any(why != 0u)) break;

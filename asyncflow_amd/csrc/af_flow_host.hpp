@@ -11,6 +11,24 @@
 
 namespace aff {
 
+// Servers the tandem recurrence of Flow::servers_solve cannot express (round 3, FEAT_GENSRV): several endpoints per server
+// (server.py:101), or a step program that is not IO* CPU* IO* (it comes back to the core queue after an I/O step).  Such plans
+// run on the instantiation whose server station simulates each server event by event (Flow::gen_servers).
+inline bool flow_needs_general_servers(const af_plan_t& p) {
+    for (uint32_t s = 0; s < p.n_servers; ++s) {
+        if (p.srv_ep_begin[s + 1] - p.srv_ep_begin[s] != 1u) return true;
+        const uint32_t ep = p.srv_ep_begin[s];
+        uint32_t phase = 0;  // 0 leading IO, 1 CPU, 2 trailing IO
+        for (uint32_t i = p.ep_step_begin[ep]; i < p.ep_step_begin[ep + 1]; ++i) {
+            const bool cpu = p.step_kind[i] == AF_STEP_CPU;
+            if (phase == 0 && cpu) phase = 1;
+            else if (phase == 1 && !cpu) phase = 2;
+            else if (phase == 2 && cpu) return true;
+        }
+    }
+    return false;
+}
+
 // Empty string: the plan's request path is the feed-forward chain the flow kernel implements.
 // Otherwise the reason it is not (the sequential next-event kernels run such plans).
 inline std::string flow_ineligible_reason(const af_plan_t& p) {
@@ -35,20 +53,14 @@ inline std::string flow_ineligible_reason(const af_plan_t& p) {
     // 150 fuzzed payloads with 1-3 Poisson edges on the wave emulator: 0 mismatches, 1 tie: tests/test_flow_hostcheck.py.)
     for (uint32_t s = 0; s < p.n_servers; ++s) {
         if (p.edge_target_kind[p.srv_out_edge[s]] != AF_NODE_CLIENT) return "server chain";
-        if (p.srv_ep_begin[s + 1] - p.srv_ep_begin[s] != 1u) return "several endpoints per server";
         if (p.srv_cores[s] > 64u) return "more than 64 cores";
-        const uint32_t ep = p.srv_ep_begin[s];
-        const double ram = p.ep_ram[ep];
-        if (ram != std::floor(ram) || ram < 0.0 || ram > 16777216.0) return "RAM need is not a small integer";
-        // step program must be IO* CPU* IO*: one contiguous CPU segment (no re-entry into the core queue)
-        uint32_t phase = 0;  // 0 leading IO, 1 CPU, 2 trailing IO
-        for (uint32_t i = p.ep_step_begin[ep]; i < p.ep_step_begin[ep + 1]; ++i) {
-            const bool cpu = p.step_kind[i] == AF_STEP_CPU;
-            if (phase == 0 && cpu) phase = 1;
-            else if (phase == 1 && !cpu) phase = 2;
-            else if (phase == 2 && cpu) return "endpoint re-enters the core queue after an I/O step";
+        // (the tick ring holds integer differences: RAM needs in whole MB, or in multiples of 1/256 MB -- flow_ram_scale)
+        for (uint32_t ep = p.srv_ep_begin[s]; ep < p.srv_ep_begin[s + 1]; ++ep) {
+            const double ram = p.ep_ram[ep], fine = ram * 256.0;
+            if (fine != std::floor(fine) || ram < 0.0 || ram > 4194304.0) return "RAM need is not a multiple of 1/256 MB";
         }
     }
+    if (flow_needs_general_servers(p) && p.n_endpoints + p.n_steps > 65535u) return "more step rows than a request record addresses";
     return std::string();
 }
 
@@ -76,6 +88,13 @@ inline TickTable make_tick_table(double period, double total_time) {
     tt.eps = 4.0 * dev + 1e-9;
     if (tt.eps > 0.25) tt.eps = 0.5;   // hopeless drift: every lookup goes through the table
     return tt;
+}
+
+// 1 when every endpoint needs whole MB of RAM, else 256 (dyadic fractions; flow_ineligible_reason refuses anything finer)
+inline double flow_ram_scale(const af_plan_t& p) {
+    for (uint32_t ep = 0; ep < p.n_endpoints; ++ep)
+        if (p.ep_ram[ep] != std::floor(p.ep_ram[ep])) return 256.0;
+    return 1.0;
 }
 
 // longest leading-I/O / CPU / trailing-I/O run over the servers' endpoints (eligible plans: IO* CPU* IO*)

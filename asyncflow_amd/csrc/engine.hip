@@ -394,6 +394,8 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
     a.max_pre = AF_FJ_MAX_PRE;
     a.max_cpu = AF_FJ_MAX_CPU;
     a.max_post = AF_FJ_MAX_POST;
+    a.ram_scale = AF_FJ_RAM_SCALE;
+    a.ram_unit = 1.0 / AF_FJ_RAM_SCALE;
     a.off_edge = AF_FJ_OFF_EDGE;
     a.off_srv = AF_FJ_OFF_SRV;
     a.off_ep = AF_FJ_OFF_EP;
@@ -837,7 +839,7 @@ struct af_engine {
     std::vector<uint32_t> row_of_step;
     af_stats_t stats{};
     // stage-parallel kernel (af_flow.hpp)
-    bool flow_ok = false;
+    bool flow_ok = false, flow_general_servers = false;
     std::string flow_reason;
     uint32_t flow_mode = 0, flow_list_entries = 0, flow_ring_rows = 0;
     aff::FlowArgs fargs{};
@@ -1166,18 +1168,20 @@ int plan_flow(const af_engine* e, const KArgs& a, const af_sweep_t* sweep, const
         win_rows = w >= (double)(rows / 2u) ? (uint32_t)w : rows / 2u;   // an explicit small ring: half of it, overflow -> hand-back
     }
     // long lists have to fit the LDS of a compute unit next to everything else: halve the longest until they do
+    const bool gen_srv = e->flow_general_servers;   // several endpoints per server / programs that come back to the core queue
     auto big_layout = [&](uint32_t ring) {
-        aff::FlowLayout L = aff::make_flow_layout(0u, ring, g_ring, c_ring, a.n_edges, a.n_servers, a.n_edge_marks, true, big_caps);
+        aff::FlowLayout L = aff::make_flow_layout(0u, ring, g_ring, c_ring, a.n_edges, a.n_servers, a.n_edge_marks, true, big_caps, gen_srv);
         while (a.blob_bytes + L.n_words * 8u > kLdsLimit) {
             uint32_t m = 0;
             for (uint32_t s = 1; s < 4u; ++s)
                 if (big_caps[s] > big_caps[m]) m = s;
             if (big_caps[m] <= 256u) break;
             big_caps[m] = (big_caps[m] / 2u + 63u) & ~63u;
-            L = aff::make_flow_layout(0u, ring, g_ring, c_ring, a.n_edges, a.n_servers, a.n_edge_marks, true, big_caps);
+            L = aff::make_flow_layout(0u, ring, g_ring, c_ring, a.n_edges, a.n_servers, a.n_edge_marks, true, big_caps, gen_srv);
         }
         return L;
     };
+    if (gen_srv) flow_big = true;   // (the general server station exists in the long-list instantiation only)
     if (flow_big) {
         if (rows * pitch * 4u > 8u * 1024u) {   // the lists need the LDS more than the tick ring does
             rows = 0u;
@@ -1204,7 +1208,7 @@ int plan_flow(const af_engine* e, const KArgs& a, const af_sweep_t* sweep, const
     P.lean = lean && !flow_big && !lc;
     if (flow_big) {
         P.ipl = 1u;
-        P.feat = kRobust | (lc ? (uint32_t)aff::FEAT_LC : 0u);
+        P.feat = kRobust | (lc ? (uint32_t)aff::FEAT_LC : 0u) | (gen_srv ? (uint32_t)aff::FEAT_GENSRV : 0u);
     } else if (lc) {
         P.ipl = FL.cap == 64u ? 1u : FL.cap == 128u ? 2u : 4u;
         P.feat = aff::FEAT_ALL | aff::FEAT_LC;
@@ -1225,6 +1229,8 @@ const void* flow_kernel_for(uint32_t ipl, uint32_t feat) {
 #define AF_FLOW_CASE(I, F) if (ipl == (I) && feat == (F)) return reinterpret_cast<const void*>(af_flow_kernel<(I), (F)>)
     AF_FLOW_CASE(1u, kRobust | kLC);
     AF_FLOW_CASE(1u, kRobust);
+    AF_FLOW_CASE(1u, kRobust | kLC | (uint32_t)aff::FEAT_GENSRV);
+    AF_FLOW_CASE(1u, kRobust | (uint32_t)aff::FEAT_GENSRV);
     AF_FLOW_CASE(1u, kAll | kLC);
     AF_FLOW_CASE(2u, kAll | kLC);
     AF_FLOW_CASE(4u, kAll | kLC);
@@ -1264,16 +1270,16 @@ std::string flow_jit_spec_string(const af_engine* e, const FlowPlan& P, const af
                   "-DAF_FJ_N_EDGES=%u -DAF_FJ_N_SERVERS=%u -DAF_FJ_HAS_LB=%u -DAF_FJ_N_LB=%u -DAF_FJ_N_EMARKS=%u -DAF_FJ_N_SMARKS=%u "
                   "-DAF_FJ_LC=%u -DAF_FJ_MAX_PRE=%u -DAF_FJ_MAX_CPU=%u -DAF_FJ_MAX_POST=%u -DAF_FJ_OFF_EDGE=%u -DAF_FJ_OFF_SRV=%u "
                   "-DAF_FJ_OFF_EP=%u -DAF_FJ_OFF_ROW=%u -DAF_FJ_OFF_EMARK=%u -DAF_FJ_OFF_SMARK=%u -DAF_FJ_OFF_LB=%u -DAF_FJ_BLOB_BYTES=%u "
-                  "-DAF_FJ_N_TICKS=%u -DAF_FJ_HAS_CLOCK=%d -DAF_FJ_HAS_SAMPLES=%d -DAF_FJ_HAS_ONLINE=%d -DAF_FJ_HAS_OVR=%d -DAF_FJ_DIST_ALL=%u "
-                  "-DAF_FJ_LAYOUT=%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u",
+                  "-DAF_FJ_N_TICKS=%u -DAF_FJ_HAS_CLOCK=%d -DAF_FJ_HAS_SAMPLES=%d -DAF_FJ_HAS_ONLINE=%d -DAF_FJ_HAS_OVR=%d -DAF_FJ_DIST_ALL=%u -DAF_FJ_RAM_SCALE=%.1f "
+                  "-DAF_FJ_LAYOUT=%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u",
                   P.ipl, P.feat | (std::getenv("AF_FLOW_PROF") ? (uint32_t)aff::FEAT_PROF : 0u), bits(f.total_time), bits(f.sample_period), bits(f.inv_period), bits(f.tick_eps), f.metrics_mask,
                   f.gen_out_edge, f.client_out_edge, f.n_edges, f.n_servers, f.has_lb, f.n_lb_edges, f.n_edge_marks, f.n_srv_marks,
                   f.lb_least_connections, f.max_pre, f.max_cpu, f.max_post, f.off_edge, f.off_srv, f.off_ep, f.off_row, f.off_emark,
                   f.off_smark, f.off_lb, f.blob_bytes, f.n_ticks, out->clock ? 1 : 0, out->samples ? 1 : 0,
-                  (out->online_hist || out->online_rps) ? 1 : 0, has_ovr ? 1 : 0, dist_all,
+                  (out->online_hist || out->online_rps) ? 1 : 0, has_ovr ? 1 : 0, dist_all, f.ram_scale,
                   L.cap, L.ring_rows, L.win_rows, L.g_ring, L.c_ring, L.pitch, L.list_arrays, L.off_spike, L.off_list, L.off_aux, L.off_aux3,
                   L.off_out, L.off_sorted, L.off_hist, L.off_seg, L.off_fr, L.off_gr, L.off_cnt, L.off_ring, L.n_words, L.cap_of[0],
-                  L.cap_of[1], L.cap_of[2], L.cap_of[3], L.off_list_of[0], L.off_list_of[1], L.off_list_of[2], L.off_list_of[3], L.off_eb);
+                  L.cap_of[1], L.cap_of[2], L.cap_of[3], L.off_list_of[0], L.off_list_of[1], L.off_list_of[2], L.off_list_of[3], L.off_eb, L.off_gsrv);
     return buf;
 }
 }  // namespace
@@ -1381,6 +1387,7 @@ int af_engine_create(const af_plan_t* plan, int device, const af_engine_options_
     }
     e->flow_reason = aff::flow_ineligible_reason(*plan);
     e->flow_ok = e->flow_reason.empty();
+    e->flow_general_servers = e->flow_ok && aff::flow_needs_general_servers(*plan);
     e->has_lb = plan->has_lb;
     e->gen_edge = plan->gen_out_edge;
     e->client_edge = plan->client_out_edge;
@@ -1433,6 +1440,8 @@ int af_engine_create(const af_plan_t* plan, int device, const af_engine_options_
         f.n_edge_marks = plan->n_edge_marks;
         f.n_srv_marks = plan->n_srv_marks;
         aff::flow_step_maxima(*plan, f.max_pre, f.max_cpu, f.max_post);
+        f.ram_scale = aff::flow_ram_scale(*plan);
+        f.ram_unit = 1.0 / f.ram_scale;
         f.off_edge = pk.off_edge; f.off_srv = pk.off_srv; f.off_ep = pk.off_ep; f.off_row = pk.off_row;
         f.off_emark = pk.off_emark; f.off_smark = pk.off_smark; f.off_lb = pk.off_lb;
         f.blob_bytes = a.blob_bytes;

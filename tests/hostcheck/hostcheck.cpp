@@ -159,7 +159,8 @@ extern "C" int hc_flow_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ov
     if (!p || p->abi_version != AF_ABI_VERSION || p->struct_size != sizeof(af_plan_t)) return AF_ERR_ABI;
     // the second-chance instantiation (FEAT_TIEBREAK | FEAT_BIGLIST): send times + lists of their own lengths;
     // bits 16..31 = entries of the long list(s) (0: 256), bits 12..14 = which list is long (0: all four; else index + 1, the others hold 256)
-    const bool robust = (ipl & 0x100u) != 0u;
+    const bool gen_srv = aff::flow_needs_general_servers(*p);   // (several endpoints per server, ...: the long-list instantiation with the general server station)
+    const bool robust = (ipl & 0x100u) != 0u || gen_srv;
     const bool near_only = (ipl & 0x200u) != 0u;   // the lean instantiations without FEAT_FAR (the sender enters both ends of every message)
     const uint32_t big_cap = (ipl >> 16) ? (ipl >> 16) : 256u, big_which = (ipl >> 12) & 7u;
     ipl &= 0xFFu;
@@ -214,6 +215,8 @@ extern "C" int hc_flow_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ov
     a.n_edge_marks = p->n_edge_marks;
     a.n_srv_marks = p->n_srv_marks;
     aff::flow_step_maxima(*p, a.max_pre, a.max_cpu, a.max_post);
+    a.ram_scale = aff::flow_ram_scale(*p);
+    a.ram_unit = 1.0 / a.ram_scale;
     a.off_edge = pk.off_edge; a.off_srv = pk.off_srv; a.off_ep = pk.off_ep; a.off_row = pk.off_row;
     a.off_emark = pk.off_emark; a.off_smark = pk.off_smark; a.off_lb = pk.off_lb;
     a.blob_bytes = (uint32_t)(pk.words.size() * 8u);
@@ -235,7 +238,7 @@ extern "C" int hc_flow_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ov
     if (robust) {
         uint32_t caps4[4];
         for (uint32_t s = 0; s < 4u; ++s) caps4[s] = (big_which == 0u || big_which == s + 1u) ? big_cap : 256u;
-        a.L = aff::make_flow_layout(0u, a.L.ring_rows, a.L.g_ring, a.L.c_ring, p->n_edges, p->n_servers, p->n_edge_marks, true, caps4);
+        a.L = aff::make_flow_layout(0u, a.L.ring_rows, a.L.g_ring, a.L.c_ring, p->n_edges, p->n_servers, p->n_edge_marks, true, caps4, gen_srv);
         a.L.win_rows = a.L.ring_rows / 2u;
     }
     a.tick_t = tt.t.data();
@@ -270,8 +273,11 @@ extern "C" int hc_flow_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ov
     const bool lc = a.lb_least_connections != 0u;
     const bool marks_only = !lean && !g_online_hist && !g_online_rps && (a.L.ring_rows != 0 || !samples);   // (engine.hip: config-4-like launches)
     constexpr uint32_t kAll = aff::FEAT_ALL, kRobust = aff::FEAT_ALL | aff::FEAT_TIEBREAK | aff::FEAT_BIGLIST, kLC = aff::FEAT_LC;
+    constexpr uint32_t kGen = aff::FEAT_GENSRV;
     auto body = [&]() {
-        if (robust && lc) { aff::Flow<emu::WaveEmu, 1, kRobust | kLC> f(a); f.run(lds.data(), 0u); }
+        if (gen_srv && lc) { aff::Flow<emu::WaveEmu, 1, kRobust | kLC | kGen> f(a); f.run(lds.data(), 0u); }
+        else if (gen_srv) { aff::Flow<emu::WaveEmu, 1, kRobust | kGen> f(a); f.run(lds.data(), 0u); }
+        else if (robust && lc) { aff::Flow<emu::WaveEmu, 1, kRobust | kLC> f(a); f.run(lds.data(), 0u); }
         else if (robust) { aff::Flow<emu::WaveEmu, 1, kRobust> f(a); f.run(lds.data(), 0u); }
         else if (lc && ipl == 1) { aff::Flow<emu::WaveEmu, 1, kAll | kLC> f(a); f.run(lds.data(), 0u); }
         else if (lc && ipl == 2) { aff::Flow<emu::WaveEmu, 2, kAll | kLC> f(a); f.run(lds.data(), 0u); }

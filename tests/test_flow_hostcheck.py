@@ -114,7 +114,9 @@ def test_small_lists_hand_the_scenario_back_instead_of_dropping_messages():
 
 
 def test_plans_outside_the_feed_forward_range_are_refused():
-    for payload, word in ((stress_mixed(40), "several endpoints"), (wide_fanout(horizon=12), "16 servers"),
+    odd_ram = lb_two_servers(horizon=10)
+    odd_ram["topology_graph"]["nodes"]["servers"][0]["endpoints"][0]["steps"][1]["step_operation"]["necessary_ram"] = 100.1
+    for payload, word in ((odd_ram, "1/256 MB"), (wide_fanout(horizon=12), "16 servers"),
                           (server_chain("exponential", 0.003), "server chain")):
         assert hc.flow_simulate(lower(payload), 1) is None
         assert word in hc.flow_reason()
@@ -253,3 +255,26 @@ def test_round_robin_fan_out_beyond_eight_servers(n_srv):
     for s in thirteen["topology_graph"]["nodes"]["servers"]:
         s["endpoints"] = s["endpoints"][:1]
     assert hc.flow_simulate(lower(thirteen), 1) is None and "64 sampled series" in hc.flow_reason()
+
+
+def test_general_servers_several_endpoints_and_core_re_entry():
+    """Round 3: several endpoints per server (server.py:101: one uniform draw per arriving request), step
+    programs that come back to the core queue after an I/O step, RAM needs that differ per request (also in dyadic
+    fractions of a MB) run on the stage-parallel kernel: its server station then simulates each server event by event
+    (Flow::gen_servers, lane k = server k) up to the station's horizon.  The reference's own generality payloads and the
+    fuzzed topologies of the next-event tests: exact, or handed back (two events of one server at one instant, more than
+    32 requests inside one server, lists) -- never different."""
+    import random
+
+    from oracle.scenarios import overload, random_payload
+
+    kw = dict(ipl=1, ring_rows=0, robust=True, long_list_entries=1024)
+    assert _run(stress_mixed(40), 3, **kw)[0] in ("exact", "fallback")
+    assert _run(overload(12), 5, **kw)[0] in ("exact", "fallback")
+    two_ep = wide_fanout(8, "round_robin", horizon=12, users=100)         # two endpoints per server, multi-core, outages, a spike
+    assert _run(two_ep, 1, **kw)[0] == "exact"
+    exact = 0
+    for case in range(40):
+        status, _ = _run(random_payload(random.Random(31000 + case), horizon=8), 17 * case, **kw)
+        exact += status == "exact"
+    assert exact >= 25, f"only {exact} of 40 fuzzed topologies stayed on the stage-parallel kernel"

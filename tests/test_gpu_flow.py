@@ -511,3 +511,31 @@ def test_poisson_latencies_and_wide_round_robin_fan_out_run_on_the_flow_kernel()
     special = _runner(wide, seeds=seeds, specialise=True).run()
     assert special.engine_stats.specialised_launches >= 1
     _same_batches(res, special)
+
+
+def test_several_endpoints_per_server_run_on_the_flow_kernel():
+    """Round 3: plans whose servers have several endpoints, come back to the core queue after an I/O step or need
+    different amounts of RAM per request run on the stage-parallel kernel (its server station simulates each server event by
+    event, Flow::gen_servers); scenarios it hands back (two events of one server at one instant, > 32 requests inside one
+    server) are invisible in the results."""
+    from oracle.scenarios import overload, random_payload, stress_mixed, wide_fanout
+
+    stayed = total = 0
+    for k, payload in enumerate([stress_mixed(40), overload(20), wide_fanout(8, "round_robin", horizon=12, users=100)]
+                                + [random_payload(random.Random(31000 + c), horizon=8) for c in range(12)]):
+        seeds = np.arange(6, dtype=np.uint64) + 40 * k
+        res = _runner(payload, seeds=seeds, on_negative_delay="flag").run()
+        st = res.engine_stats
+        assert res.flow_reason == "" and st.flow_scenarios == 6, res.flow_reason
+        stayed += 6 - st.flow_to_next_event
+        total += 6
+        plan = lower(payload)
+        for i in (0, 5):
+            _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])), f"payload {k} scenario {i}")
+        _same_batches(res, _runner(payload, seeds=seeds, flow=False, on_negative_delay="flag").run())
+    assert stayed >= total // 2, f"{stayed} of {total} scenarios stayed on the stage-parallel kernel"
+    two_ep = wide_fanout(8, "round_robin", horizon=12, users=100)
+    seeds = np.arange(24, dtype=np.uint64) + 900
+    generic = _runner(two_ep, seeds=seeds, specialise=False).run()
+    special = _runner(two_ep, seeds=seeds, specialise=True).run()     # (launches above 64 KB of LDS per wave keep the generic build)
+    _same_batches(generic, special)
