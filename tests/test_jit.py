@@ -26,8 +26,8 @@ LB2_FLOW_SPEC = (
     "-DAF_FJ_N_SMARKS=0 -DAF_FJ_LC=0 -DAF_FJ_MAX_PRE=0 -DAF_FJ_MAX_CPU=1 -DAF_FJ_MAX_POST=1 -DAF_FJ_OFF_EDGE=0 "
     "-DAF_FJ_OFF_SRV=24 -DAF_FJ_OFF_EP=28 -DAF_FJ_OFF_ROW=32 -DAF_FJ_OFF_EMARK=50 -DAF_FJ_OFF_SMARK=50 "
     "-DAF_FJ_OFF_LB=50 -DAF_FJ_BLOB_BYTES=416 -DAF_FJ_N_TICKS=11999 -DAF_FJ_HAS_CLOCK=1 -DAF_FJ_HAS_SAMPLES=1 "
-    "-DAF_FJ_HAS_ONLINE=0 -DAF_FJ_HAS_OVR=0 "
-    "-DAF_FJ_LAYOUT=64,32,16,16,1,12,2,0,0,512,528,544,704,768,544,864,866,898,945,1137,64,64,64,64,0,128,256,384,840"
+    "-DAF_FJ_HAS_ONLINE=0 -DAF_FJ_HAS_OVR=0 -DAF_FJ_DIST_ALL=255 -DAF_FJ_RAM_SCALE=1.0 "
+    "-DAF_FJ_LAYOUT=64,32,16,16,1,12,2,0,0,512,528,544,704,768,544,864,866,898,965,1157,64,64,64,64,0,128,256,384,840,0"
 )
 
 
