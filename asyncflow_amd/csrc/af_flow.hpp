@@ -92,10 +92,11 @@ struct FlowLayout {
 constexpr uint32_t kGsSlots = 32u;   // requests inside one server at once (more: handed back)
 constexpr uint32_t kGsDeps = kGsSlots + 64u;   // departures of one round: at most what was inside plus the round's arrivals
 enum : uint32_t { GS_CPU = 0u /* cpu_free | ready << 32 */, GS_IO = 1u /* io | free-slot mask << 32 */, GS_RAM = 2u /* f64 free RAM */,
-                  GS_ARR = 3u /* arrivals | RAM queue blocked << 32 */, GS_CQ = 4u /* head | n << 32 */, GS_RQ = 5u, GS_EV = 6u, GS_DEP = 7u /* departures of this round */,
-                  GS_T0 = 8u, GS_NEED = GS_T0 + kGsSlots, GS_STATE = GS_NEED + kGsSlots /* row | holds core << 16 | in I/O << 17 */,
-                  GS_EVT = GS_STATE + kGsSlots /* sorted ring of pending step ends: time */, GS_BYTES = GS_EVT + kGsSlots /* 3 x kGsSlots bytes: event slots, CPU waiters, RAM waiters */,
-                  GS_DEPT = GS_BYTES + (3u * kGsSlots + 7u) / 8u, GS_DEPT0 = GS_DEPT + kGsDeps, kGsWords = GS_DEPT0 + kGsDeps };
+                  GS_ARR = 3u /* arrivals | RAM queue blocked << 32 */, GS_CQ = 4u /* head | n << 32 */, GS_RQ = 5u, GS_EV = 6u, GS_DEP = 7u /* departures of this round | tie instants so far << 32 */,
+                  GS_LAST = 8u /* f64 time of the server's previous event */, GS_LASTDEP = 9u /* f64 time of its previous departure */,
+                  GS_T0 = 10u, GS_NEED = GS_T0 + kGsSlots, GS_STATE = GS_NEED + kGsSlots /* row | holds core << 16 | in I/O << 17 */,
+                  GS_EVT = GS_STATE + kGsSlots /* sorted ring of pending step ends: time */, GS_BYTES = GS_EVT + kGsSlots /* 4 x kGsSlots bytes: event slots, CPU waiters, RAM waiters, where each pending step end was created */,
+                  GS_DEPT = GS_BYTES + (4u * kGsSlots + 7u) / 8u, GS_DEPT0 = GS_DEPT + kGsDeps, kGsWords = GS_DEPT0 + kGsDeps };
 
 inline FlowLayout make_flow_layout(uint32_t cap, uint32_t ring_rows, uint32_t g_ring, uint32_t c_ring, uint32_t n_edges,
                                    uint32_t n_servers, uint32_t n_edge_marks, bool tiebreak = false,
@@ -1178,17 +1179,28 @@ struct Flow {
         if (samples != nullptr) add_point(series, row, w);
     }
     // pending step end of `slot` at `t`: sorted ring (ascending; equal times are found when they reach the front)
+    // Step ends that share an instant are handled in the order their Timeouts were created (SimPy's heap key: time, priority,
+    // event id): equal times go BEHIND what is there, and the calls below come in the order the reference creates the
+    // Timeouts of one event's cascade (the request's own, then the core waiter's, then the RAM waiters': af_core.hpp, "stages").
+    // `gs_born` says where: 0 = in an instant this server had to itself; 0x80 | id = in an instant it shared between several
+    // of its step ends -- SimPy then interleaves the zero-time steps of the tied cascades, the resources end up the same
+    // (both containers are FIFO) but the creation order of the new Timeouts does not follow from ours: two of THOSE that tie
+    // later are handed back (gen_servers).
+    uint8_t gs_born;
     AF_CORE void gs_schedule(AF_PLAN_AS uint64_t* g, double t, uint32_t slot) {
         const uint32_t head = lo32(g[GS_EV]), n = hi32(g[GS_EV]);
         AF_PLAN_AS uint8_t* es = gs_bytes(g, 0u);
+        AF_PLAN_AS uint8_t* eb = gs_bytes(g, 3u);
         uint32_t i = n;
         while (i > 0u && u2d(g[GS_EVT + ((head + i - 1u) & (kGsSlots - 1u))]) > t) {
             g[GS_EVT + ((head + i) & (kGsSlots - 1u))] = g[GS_EVT + ((head + i - 1u) & (kGsSlots - 1u))];
             es[(head + i) & (kGsSlots - 1u)] = es[(head + i - 1u) & (kGsSlots - 1u)];
+            eb[(head + i) & (kGsSlots - 1u)] = eb[(head + i - 1u) & (kGsSlots - 1u)];
             i -= 1u;
         }
         g[GS_EVT + ((head + i) & (kGsSlots - 1u))] = d2u(t);
         es[(head + i) & (kGsSlots - 1u)] = (uint8_t)slot;
+        eb[(head + i) & (kGsSlots - 1u)] = gs_born;
         g[GS_EV] = pack32(head, n + 1u);
     }
     // a core became free: the first waiter gets it (Container FIFO, server.py:210-231) and starts its CPU step now
@@ -1236,14 +1248,14 @@ struct Flow {
             gs_schedule(g, now + dur, slot);
             return;
         }
-        if (kind == af::STEP_IO) {   // server.py:235-255
-            if (holds) gs_core_release(g, s0, now, rown);
+        if (kind == af::STEP_IO) {   // server.py:235-255 (its own Timeout is created before the core waiter's)
             if (!in_io) {
                 g[GS_IO] = g[GS_IO] + 1ull;
                 gs_point(s0 + 1u, rown, 1);
             }
             g[GS_STATE + slot] = (uint64_t)row | (1ull << 17);
             gs_schedule(g, now + dur, slot);
+            if (holds) gs_core_release(g, s0, now, rown);
             return;
         }
         // the endpoint is through (server.py:257-276): core, RAM, the response
@@ -1259,9 +1271,11 @@ struct Flow {
             ram_released = true;
         }
         const uint32_t nd = lo32(g[GS_DEP]);
+        if (u2d(g[GS_LASTDEP]) == now) why |= FLOW_WHY_TIE;   // two responses at one instant: their order on the out-edge is SimPy's
+        g[GS_LASTDEP] = d2u(now);
         g[GS_DEPT + nd] = d2u(now);
         g[GS_DEPT0 + nd] = g[GS_T0 + slot];
-        g[GS_DEP] = pack32(nd + 1u, 0u);
+        g[GS_DEP] = pack32(nd + 1u, hi32(g[GS_DEP]));
         g[GS_IO] = g[GS_IO] | (1ull << (32u + slot));   // the slot is free again
     }
     // RAM waiters, strictly FIFO with head-of-line blocking (Container._trigger_get, server.py:146-149)
@@ -1288,17 +1302,31 @@ struct Flow {
         const uint32_t epb = (uint32_t)(meta >> 32) & 0xFFFFu, n_ep = (uint32_t)(meta >> 48);
         const double ram_mb = u2d(blob[A.off_srv + af::SREC * sv]);
         uint32_t ai = 0u, done = 0u;
-        g[GS_DEP] = 0ull;
+        bool ram_pending = false;
+        g[GS_DEP] = pack32(0u, hi32(g[GS_DEP]));
         for (;;) {
             const double ta = ai < n_k ? seg(0)[off + ai] : AF_INF;
             const uint32_t ev_head = lo32(g[GS_EV]), ev_n = hi32(g[GS_EV]);
             const double te = ev_n ? u2d(g[GS_EVT + ev_head]) : AF_INF;
             const double now = ta < te ? ta : te;
             if (!(now < limit)) break;
-            if (ta == te || (ev_n > 1u && u2d(g[GS_EVT + ((ev_head + 1u) & (kGsSlots - 1u))]) == te && te < ta)) {
-                why |= FLOW_WHY_TIE;   // two events of this server at one instant: SimPy's order decides, the next-event kernels have it
+            const bool tie_next = te < ta && ev_n > 1u && u2d(g[GS_EVT + ((ev_head + 1u) & (kGsSlots - 1u))]) == te;
+            const bool tie_prev = now == u2d(g[GS_LAST]);
+            bool give_up = ta == te || (tie_prev && !(te < ta));   // an arrival exactly at a step end: SimPy's order decides
+            if (tie_next) {   // this step end shares its instant with the next one: created where?
+                const uint8_t bx = gs_bytes(g, 3u)[ev_head], by = gs_bytes(g, 3u)[(ev_head + 1u) & (kGsSlots - 1u)];
+                give_up = give_up || ((bx & 0x80u) != 0u && bx == by);   // both in the same shared instant: their order is not ours to know
+                if (!tie_prev) g[GS_DEP] = pack32(lo32(g[GS_DEP]), hi32(g[GS_DEP]) + 1u);   // a new shared instant begins
+            }
+            if (give_up) {
+#if defined(AF_FLOW_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
+                std::fprintf(stderr, "gen tie: sv %u ta %.17g te %.17g ev_n %u\n", sv, ta, te, ev_n);
+#endif
+                why |= FLOW_WHY_TIE;   // the next-event kernels replay SimPy's event-by-event order
                 break;
             }
+            gs_born = (tie_next || tie_prev) ? (uint8_t)(0x80u | (hi32(g[GS_DEP]) & 0x7Fu)) : (uint8_t)0u;
+            g[GS_LAST] = d2u(now);
             if (lo32(g[GS_DEP]) >= kGsDeps) {   // (cannot happen: a round's departures <= requests inside + its arrivals)
                 why |= FLOW_WHY_LIST;
                 break;
@@ -1352,7 +1380,14 @@ struct Flow {
                     if (go) gs_advance(g, sv, slot, now, rown, ram_released);
                 }
             }
-            if (ram_released) gs_ram_queue(g, sv, now, rown);
+            // RAM waiters come in when every step end of this instant has had its turn: in SimPy the Put that frees the RAM
+            // is processed one or two zero-time events after the Timeout, behind the other Timeouts of the instant -- a request
+            // of THOSE for a core stands in the queue before the admitted waiter's (tests/test_flow_hostcheck.py, tie storm 30)
+            ram_pending = ram_pending || ram_released;
+            if (ram_pending && !tie_next) {
+                gs_ram_queue(g, sv, now, rown);
+                ram_pending = false;
+            }
         }
         return done;
     }
