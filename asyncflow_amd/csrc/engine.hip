@@ -988,6 +988,18 @@ uint32_t chunk_size(const af_engine* e, uint32_t n, size_t draw_bytes_per_scen, 
 // List capacity and tick ring from what will be in flight at the heaviest point of the sweep, the instantiation
 // (IPL, FEAT) that covers the launch.  Shared by af_engine_run and af_engine_jit_spec (the plan-specialised build
 // bakes exactly this in).
+// Does this sweep run on the stage-parallel kernel?  flow_mode 0: whenever the plan is in its range -- except that plans whose
+// servers need the event-by-event station (FEAT_GENSRV) go there only as sweeps of a few scenarios: that station is one busy lane
+// per server, 18 x slower per event than the tandem recurrence, and every scenario it hands back costs a full next-event pass
+// whose time does not depend on how many scenarios share it (2 048 two-endpoint LB-2 replicas, T = 120 s: 512 ms with 114
+// hand-backs against 358 ms on the next-event kernels alone; ONE scenario: 84 ms against ~350).  2 = always, 1 = never.
+constexpr uint32_t kGeneralServersAutoScenarios = 8;
+static bool flow_wanted(const af_engine_t* e, uint32_t n_scenarios) {
+    if (!e->flow_ok || e->flow_mode == 1u) return false;
+    if (e->flow_general_servers && e->flow_mode != 2u) return n_scenarios <= kGeneralServersAutoScenarios;
+    return true;
+}
+
 struct FlowPlan {
     aff::FlowLayout FL{}, FL2{};   // first launch; second chance (long lists with send times)
     bool big = false;              // the first launch already runs the long-list instantiation
@@ -1554,7 +1566,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     const uint32_t n_draw = sweep->draw_capacity ? sweep->draw_capacity : out->clock_capacity;
     if (n_draw == 0) return fail(AF_ERR_INVALID, "draw_capacity (or clock_capacity) must be > 0");
     const size_t draw_bytes_per_scen = (size_t)(1u + a.n_edges) * n_draw * sizeof(double);
-    const bool use_flow = e->flow_ok && e->flow_mode == 0u;
+    const bool use_flow = flow_wanted(e, n);
     size_t mem_free = 0, mem_total = 0;
     HIP_TRY(hipMemGetInfo(&mem_free, &mem_total));
     // the stage-parallel kernel only needs the arrival times of a chunk; the next-event kernels every draw
@@ -1975,7 +1987,7 @@ int af_engine_jit_spec(af_engine_t* e, const af_sweep_t* sweep, const af_outputs
     a.online_rps = out->online_rps;
     a.n_draw = sweep->draw_capacity ? sweep->draw_capacity : out->clock_capacity;
     if (a.n_draw == 0) return fail(AF_ERR_INVALID, "draw_capacity (or clock_capacity) must be > 0");
-    if (e->flow_ok && e->flow_mode == 0u) {   // the sweep runs on the stage-parallel kernel: its spec
+    if (flow_wanted(e, sweep->n_scenarios)) {   // the sweep runs on the stage-parallel kernel: its spec
         for (uint32_t k = 0; k < sweep->n_overrides; ++k)
             if (!sweep->overrides[k].values) return fail(AF_ERR_INVALID, "bad override");
         FlowPlan FP;

@@ -91,19 +91,30 @@ def _check(lib: C.CDLL, rc: int, what: str) -> None:
     raise EngineError(f"{what} failed ({rc}): {text}")
 
 
+def flow_mode(flow: bool | str) -> int:
+    """`af_engine_options_t.flow_mode` of the `flow=` keyword: True = the engine's choice (0), False = never (1),
+    "always" = whenever the plan is in the stage-parallel kernel's range (2)."""
+    if flow == "always":
+        return 2
+    if isinstance(flow, str):
+        msg = f"flow must be True, False or 'always', not {flow!r}"
+        raise ValueError(msg)
+    return 0 if flow else 1
+
+
 class Engine:
     """One ``af_engine_t``: a lowered plan resident on one GPU."""
 
     def __init__(self, plan: DevicePlan, device: int = 0, *, request_capacity: int = 0,
                  fifo_capacity: int = 0, force_global_state: bool = False, lanes_per_wave: int = 0,
-                 draw_memory_mb: int = 0, expect_shared_instants: bool = False, flow: bool = True,
+                 draw_memory_mb: int = 0, expect_shared_instants: bool = False, flow: bool | str = True,
                  flow_list_entries: int = 0, flow_ring_rows: int = 0) -> None:
         self._lib = load_library()
         self.plan = plan
         self.device = device
         self._cplan = plan.as_ctypes()
         opts = _abi.AfEngineOptions(request_capacity, fifo_capacity, int(force_global_state), int(lanes_per_wave),
-                                    int(draw_memory_mb), int(expect_shared_instants), 0 if flow else 1,
+                                    int(draw_memory_mb), int(expect_shared_instants), flow_mode(flow),
                                     int(flow_list_entries), int(flow_ring_rows))
         handle = C.c_void_p()
         _check(self._lib, self._lib.af_engine_create(C.byref(self._cplan), device, C.byref(opts), C.byref(handle)),

@@ -288,7 +288,7 @@ class SimulationRunner:
         expect_shared_instants: bool | None = None,
         specialise: bool | None = None,
         online_summary: Mapping[str, Any] | None = None,
-        flow: bool = True,
+        flow: bool | str = True,
         flow_list_entries: int = 0,
         flow_ring_rows: int = 0,
         devices: Sequence[int] | None = None,
@@ -332,7 +332,10 @@ class SimulationRunner:
         #: next-event kernels, > 5e10 on the stage-parallel kernel)
         self.specialise = specialise
         #: stage-parallel kernel (one wave per scenario, 64 requests per step) for plans in its range
-        #: (Engine.flow_reason()); False = always the next-event kernels.  Results are bit-identical.
+        #: (Engine.flow_reason()); False = always the next-event kernels.  Results are bit-identical.  True leaves
+        #: one choice to the engine: plans whose servers need the event-by-event station (several endpoints per
+        #: server, step programs that come back to the core queue) run there only as sweeps of <= 8 scenarios --
+        #: above that the next-event kernels are faster for them; "always" overrides it.
         self.flow = flow
         self.flow_list_entries = flow_list_entries
         self.flow_ring_rows = flow_ring_rows
@@ -489,6 +492,9 @@ class SimulationRunner:
                 online_rps_buckets=o_buckets,
             )
             flow_reason = eng.flow_reason() if self.flow else "flow=False"
+            if self.flow and not flow_reason and int(stats.flow_scenarios) == 0:
+                flow_reason = ("servers with several endpoints / core re-entry: the next-event kernels are faster for sweeps of "
+                               "more than 8 scenarios (flow='always' overrides)")
             eng.close()
             if int(stats.shared_instant_scenarios) > 0:
                 _SHARED_INSTANTS_SEEN[self._plan_key()] = True

@@ -266,7 +266,10 @@ typedef struct af_engine_options {
      * with IO* CPU* IO* endpoints -> client).  Bit-identical to the next-event kernels; a scenario
      * it cannot express (two events of one station at one instant, a list / tick-ring overflow) is
      * simulated again by them.  af_engine_flow_reason() tells why a plan is outside its range. */
-    uint32_t flow_mode;         /* 0 = use it whenever the plan is in range, 1 = never          */
+    uint32_t flow_mode;         /* 0 = use it whenever the plan is in range -- plans whose servers need the
+                                   event-by-event station (several endpoints per server, step programs that come
+                                   back to the core queue) only for sweeps of <= 8 scenarios, above that the
+                                   next-event kernels are faster for them; 1 = never; 2 = whenever in range  */
     uint32_t flow_list_entries; /* capacity of each station's message list: 64, 128 or 256
                                    (0 = from the expected number of messages in flight)         */
     uint32_t flow_ring_rows;    /* rows of the LDS ring of per-tick differences (power of two);

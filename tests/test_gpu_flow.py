@@ -536,6 +536,33 @@ def test_several_endpoints_per_server_run_on_the_flow_kernel():
     assert stayed >= total // 2, f"{stayed} of {total} scenarios stayed on the stage-parallel kernel"
     two_ep = wide_fanout(8, "round_robin", horizon=12, users=100)
     seeds = np.arange(24, dtype=np.uint64) + 900
-    generic = _runner(two_ep, seeds=seeds, specialise=False).run()
-    special = _runner(two_ep, seeds=seeds, specialise=True).run()     # (launches above 64 KB of LDS per wave keep the generic build)
+    generic = _runner(two_ep, seeds=seeds, specialise=False, flow="always").run()
+    special = _runner(two_ep, seeds=seeds, specialise=True, flow="always").run()     # (launches above 64 KB of LDS per wave keep the generic build)
+    assert generic.engine_stats.flow_scenarios == 24
     _same_batches(generic, special)
+    # the engine's own choice (flow=True): such plans take the stage-parallel kernel only as sweeps of <= 8 scenarios -- the
+    # event-by-event station is one busy lane per server, and above that the next-event kernels are faster
+    auto = _runner(two_ep, seeds=seeds).run()
+    assert auto.engine_stats.flow_scenarios == 0 and "flow='always'" in auto.flow_reason
+    _same_batches(generic, auto)
+
+
+def test_round_step_times_share_instants_inside_a_general_server():
+    """LB-2 with a second endpoint whose steps are round numbers of milliseconds: step ends of different requests of one server
+    coincide as soon as requests queue for the core.  The station resolves those instants in SimPy's order (Timeout creation
+    order; RAM waiters when the instant's step ends are through) instead of handing the scenario back: 19 of 20 scenarios
+    stay at T = 60 (it used to be 13), and every result equals the next-event kernels' and the oracle's."""
+    from asyncflow_amd.workloads import _endpoint
+
+    p = lb_two_servers(horizon=60)
+    for s in p["topology_graph"]["nodes"]["servers"]:
+        s["endpoints"].append(_endpoint("/report", [("io_db", 0.004), ("ram", 64), ("cpu_bound_operation", 0.0015),
+                                                     ("io_wait", 0.006), ("cpu_bound_operation", 0.0005)]))
+    seeds = 0x5EED0000 + np.arange(20, dtype=np.uint64)
+    res = _runner(p, seeds=seeds, flow="always").run()
+    st = res.engine_stats
+    assert st.flow_scenarios == 20 and st.flow_to_next_event <= 4, (st.flow_scenarios, st.flow_to_next_event)
+    plan = lower(p)
+    for i in (0, 7, 19):
+        _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])), f"scenario {i}")
+    _same_batches(res, _runner(p, seeds=seeds, flow=False).run())
