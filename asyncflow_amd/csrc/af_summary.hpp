@@ -19,8 +19,11 @@
 //           MSB-first radix select, all wanted ranks at once
 //   last    gather the <= kCand candidates of every wanted rank into LDS, accumulate the squared
 //           deviations, then select by counting
-// No sort, no scratch memory in HBM, no atomics on floating point (results are run-to-run
-// deterministic).
+// Round 3: with a scratch array of one 16-bit code per completion (SumArgs::codes: which guessed exponent bin, which of its
+// 1 024 digit bins) pass 1 leaves behind what the last pass needs to FIND the candidates, and carries the squared deviations
+// itself (about a shift taken from the first 512 latencies): the last pass then reads 2 bytes per completion instead of 16
+// and fetches only the candidates' rows -- 1.25 reads of the clock's bytes instead of 2.
+// No sort, no atomics on floating point (results are run-to-run deterministic).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -48,6 +51,8 @@ struct SumArgs {
     uint32_t* hist;  // [n][hist_bins] or null
     uint32_t hist_bins;
     double hist_scale;  // hist_bins / hist_max
+    uint16_t* codes;      // [n][code_pitch] scratch or null (then the last pass reads the clock again)
+    uint32_t code_pitch;  // multiple of 8
 };
 
 __device__ inline double wave_sum(double v) {
@@ -72,7 +77,7 @@ __device__ inline void wave_agg_add(uint32_t* base, uint32_t idx, bool active) {
     const int lane = threadIdx.x & 63;
     for (int it = 0; it < 4 && todo; ++it) {
         const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t v = __shfl(idx, leader, 64);
+        const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)idx, leader);   // (the leader is wave-uniform: v_readlane, not an LDS shuffle)
         const unsigned long long same = __ballot(active && idx == v) & todo;
         if (lane == leader) atomicAdd(&base[v], (uint32_t)__popcll(same));
         todo &= ~same;
@@ -130,8 +135,9 @@ __device__ inline void wave_select(const uint32_t* hist, int nbins, uint32_t k, 
 __global__ __launch_bounds__(kThreads) void af_summary_kernel(SumArgs a) {
     extern __shared__ uint32_t dyn[];  // [rps_buckets] then [hist_bins]
     __shared__ uint32_t exp_hist[kExpBins];
-    __shared__ uint32_t dig_hist[kRanks][kDigBins];
-    __shared__ double cand[kRanks][kCand];
+    __shared__ __attribute__((aligned(16))) uint32_t dig_hist[kRanks][kDigBins];
+    static_assert(sizeof(double) * kCand == sizeof(uint32_t) * kDigBins, "the candidates take the digit histograms' place");
+    double (*cand)[kCand] = reinterpret_cast<double (*)[kCand]>(&dig_hist[0][0]);   // (dead by the last pass: 35 instead of 59 KB, 4 scenarios per CU)
     __shared__ uint32_t cand_n[kRanks];
     __shared__ double scratch[kWaves];
     __shared__ unsigned long long pfx[kRanks];       // key >> shift of the bin holding rank r
@@ -143,6 +149,8 @@ __global__ __launch_bounds__(kThreads) void af_summary_kernel(SumArgs a) {
     __shared__ double val[kRanks];
     __shared__ uint32_t g_pfx[3];   // exponent bins guessed from the first 512 latencies
     __shared__ uint32_t g_n, g_hit;
+    __shared__ double shift_s;      // the squared deviations of pass 1 are taken about this value (mean of the first 512 latencies)
+    __shared__ uint32_t slot_code[kRanks];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t sc = blockIdx.x;
@@ -160,10 +168,14 @@ __global__ __launch_bounds__(kThreads) void af_summary_kernel(SumArgs a) {
     // ---- guess: in which exponent bins do the first 512 latencies put the median / p95 / p99? ------------
     {
         const uint32_t m = n < (uint32_t)kThreads ? n : (uint32_t)kThreads;
+        double first = 0.0;
         if ((uint32_t)tid < m) {
             const double2 c = ck[tid];
-            atomicAdd(&exp_hist[((unsigned long long)__double_as_longlong(c.y - c.x) >> 52) & (kExpBins - 1)], 1u);
+            first = c.y - c.x;
+            atomicAdd(&exp_hist[((unsigned long long)__double_as_longlong(first) >> 52) & (kExpBins - 1)], 1u);
         }
+        const double first_sum = block_sum(first, scratch);
+        if (tid == 0) shift_s = m ? first_sum / (double)m : 0.0;
         __syncthreads();
         if (wave < 3 && m > 0u) {
             const uint32_t k = wave == 0 ? m / 2u : wave == 1 ? (uint32_t)((double)(m - 1u) * 0.95) : (uint32_t)((double)(m - 1u) * 0.99);
@@ -186,9 +198,11 @@ __global__ __launch_bounds__(kThreads) void af_summary_kernel(SumArgs a) {
         __syncthreads();
     }
     const uint32_t gn = g_n, gp0 = g_pfx[0], gp1 = g_pfx[1], gp2 = g_pfx[2];
+    const double shift_v = shift_s;
+    uint16_t* cd = a.codes ? a.codes + (size_t)sc * a.code_pitch : nullptr;
 
     // ---- pass 1 -----------------------------------------------------------------------------
-    double s = 0.0, mn = __builtin_inf(), mx = -__builtin_inf();
+    double s = 0.0, mn = __builtin_inf(), mx = -__builtin_inf(), sd1 = 0.0, sq1 = 0.0;
     for (uint32_t base = 0; base < n; base += kThreads * 4u) {
         double2 c4[4];
 #pragma unroll
@@ -206,15 +220,28 @@ __global__ __launch_bounds__(kThreads) void af_summary_kernel(SumArgs a) {
                 s += lat;
                 mn = fmin(mn, lat);
                 mx = fmax(mx, lat);
+                const double d = lat - shift_v;
+                sd1 += d;
+                sq1 += d * d;
             }
             const unsigned long long key = (unsigned long long)__double_as_longlong(lat);
             const uint32_t ebin = (uint32_t)(key >> 52) & (kExpBins - 1);
-            wave_agg_add(exp_hist, ebin, act);
             if (act) {
                 const uint32_t dig = (uint32_t)(key >> (52 - kDigBits)) & (kDigBins - 1);
-                if (gn > 0u && ebin == gp0) atomicAdd(&dig_hist[0][dig], 1u);
-                else if (gn > 1u && ebin == gp1) atomicAdd(&dig_hist[1][dig], 1u);
-                else if (gn > 2u && ebin == gp2) atomicAdd(&dig_hist[2][dig], 1u);
+                uint32_t code = 0u;   // (guessed bin + 1) << 10 | digit; 0 = in none of the guessed bins
+                if (gn > 0u && ebin == gp0) {
+                    atomicAdd(&dig_hist[0][dig], 1u);
+                    code = (1u << kDigBits) | dig;
+                } else if (gn > 1u && ebin == gp1) {
+                    atomicAdd(&dig_hist[1][dig], 1u);
+                    code = (2u << kDigBits) | dig;
+                } else if (gn > 2u && ebin == gp2) {
+                    atomicAdd(&dig_hist[2][dig], 1u);
+                    code = (3u << kDigBits) | dig;
+                } else {
+                    atomicAdd(&exp_hist[ebin], 1u);   // (rare: the guessed bins hold nearly everything, and THEIR counts are the sums of their digit bins, below)
+                }
+                if (cd) cd[i] = (uint16_t)code;
             }
             if (a.rps) {
                 // window (k-1, k]; a finish at exactly 0 belongs to the first window (analyzer.py:112-121)
@@ -229,7 +256,15 @@ __global__ __launch_bounds__(kThreads) void af_summary_kernel(SumArgs a) {
             }
         }
     }
-    const double total = block_sum(s, scratch);
+    const double total = block_sum(s, scratch);   // (its barriers also close pass 1's histogram updates)
+    if ((uint32_t)wave < gn) {   // exponent bin q of the guess: as many as its digit bins hold together
+        uint32_t c = 0;
+        for (int j = lane; j < kDigBins; j += 64) c += dig_hist[wave][j];
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+        if (lane == 0) exp_hist[g_pfx[wave]] = c;
+    }
+    const double sd1_total = block_sum(sd1, scratch);
+    const double sq1_total = block_sum(sq1, scratch);
     mn = wave_min(mn);
     mx = wave_max(mx);
     __syncthreads();
@@ -370,33 +405,72 @@ __global__ __launch_bounds__(kThreads) void af_summary_kernel(SumArgs a) {
     __syncthreads();
     const uint32_t ns = n_slots;
     double sq = 0.0;
-    // (back to front: the rows pass 1 read last are the ones most likely still in the Infinity Cache -- 1 024 scenarios in
-    // flight x 1.2 MB is five times its 256 MB, so the tail of each scenario's clock is what survives)
-    const uint32_t n_blocks = (n + kThreads * 4u - 1u) / (kThreads * 4u);
-    for (uint32_t blk = n_blocks; blk-- > 0u;) {
-        const uint32_t base = blk * kThreads * 4u;
-        double2 c4[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t i = base + (uint32_t)u * kThreads + tid;
-            c4[u] = i < n ? ck[i] : double2{0.0, 0.0};
+    // every wanted rank sits in a guessed exponent bin and its digit bin is small enough: the codes of pass 1 say which
+    // completions are candidates, and only their rows are read again
+    const bool by_code = cd != nullptr && g_hit != 0u && shift == 52 - kDigBits;
+    if (by_code) {
+        if ((uint32_t)tid < ns) {
+            const uint32_t ebin = (uint32_t)(slot_pfx[tid] >> kDigBits), dig = (uint32_t)slot_pfx[tid] & (kDigBins - 1);
+            uint32_t j = 0;
+            for (uint32_t q = 0; q < g_n; ++q)
+                if (g_pfx[q] == ebin) j = q;
+            slot_code[tid] = ((j + 1u) << kDigBits) | dig;
         }
+        __syncthreads();
+        uint32_t sc_q[kRanks];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t i = base + (uint32_t)u * kThreads + tid;
-            if (i >= n) continue;
-            const double lat = c4[u].y - c4[u].x;
-            const double d = lat - mean;
-            sq += d * d;
-            const unsigned long long hi = (unsigned long long)__double_as_longlong(lat) >> shift;
-            for (uint32_t q = 0; q < ns; ++q)
-                if (hi == slot_pfx[q]) {
-                    const uint32_t pos = atomicAdd(&cand_n[q], 1u);
-                    if (pos < (uint32_t)kCand) cand[q][pos] = lat;
-                }
+        for (int q = 0; q < kRanks; ++q) sc_q[q] = (uint32_t)q < ns ? slot_code[q] : 0xFFFFFFFFu;
+        const uint4* cd4 = reinterpret_cast<const uint4*>(cd);
+        for (uint32_t i8 = (uint32_t)tid * 8u; i8 < n; i8 += kThreads * 8u) {
+            const uint4 w = cd4[i8 >> 3];
+            const uint32_t word[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                const uint32_t i = i8 + (uint32_t)h;
+                const uint32_t code = (word[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
+                if (code == 0u || i >= n) continue;
+#pragma unroll
+                for (int q = 0; q < kRanks; ++q)
+                    if (code == sc_q[q]) {
+                        const double2 c = ck[i];
+                        const uint32_t pos = atomicAdd(&cand_n[q], 1u);
+                        if (pos < (uint32_t)kCand) cand[q][pos] = c.y - c.x;
+                    }
+            }
+        }
+    } else {
+        // (back to front: the rows pass 1 read last are the ones most likely still in the Infinity Cache -- 1 024 scenarios in
+        // flight x 1.2 MB is five times its 256 MB, so the tail of each scenario's clock is what survives)
+        const uint32_t n_blocks = (n + kThreads * 4u - 1u) / (kThreads * 4u);
+        for (uint32_t blk = n_blocks; blk-- > 0u;) {
+            const uint32_t base = blk * kThreads * 4u;
+            double2 c4[4];
+    #pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = base + (uint32_t)u * kThreads + tid;
+                c4[u] = i < n ? ck[i] : double2{0.0, 0.0};
+            }
+    #pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = base + (uint32_t)u * kThreads + tid;
+                if (i >= n) continue;
+                const double lat = c4[u].y - c4[u].x;
+                const double d = lat - mean;
+                sq += d * d;
+                const unsigned long long hi = (unsigned long long)__double_as_longlong(lat) >> shift;
+                for (uint32_t q = 0; q < ns; ++q)
+                    if (hi == slot_pfx[q]) {
+                        const uint32_t pos = atomicAdd(&cand_n[q], 1u);
+                        if (pos < (uint32_t)kCand) cand[q][pos] = lat;
+                    }
+            }
         }
     }
-    const double sq_total = block_sum(sq, scratch);
+    double sq_total = block_sum(sq, scratch);
+    if (by_code) {   // sum (x - mean)^2 = sum d^2 - (sum d)^2 / n with d = x - shift (shift ~ mean: no cancellation to speak of)
+        sq_total = sq1_total - sd1_total * sd1_total / (double)n;
+        if (!(sq_total > 0.0)) sq_total = 0.0;
+    }
     __syncthreads();
     for (int r = 0; r < kRanks; ++r) {
         const uint32_t q = slot_of[r];

@@ -839,6 +839,8 @@ struct af_engine {
     std::vector<uint32_t> row_of_step;
     af_stats_t stats{};
     // stage-parallel kernel (af_flow.hpp)
+    void* d_codes = nullptr;   // analyzer scratch (af_engine_summarize)
+    size_t codes_bytes = 0;
     bool flow_ok = false, flow_general_servers = false;
     std::string flow_reason;
     uint32_t flow_mode = 0, flow_list_entries = 0, flow_ring_rows = 0;
@@ -2090,6 +2092,20 @@ int af_engine_summarize(af_engine_t* e, const af_outputs_t* out, const af_summar
         s.hist = sum->hist;
         s.hist_bins = sum->hist ? sum->hist_bins : 0u;
         s.hist_scale = sum->hist ? (double)sum->hist_bins / sum->hist_max : 0.0;
+        // scratch for the analyzer's 16-bit codes (af_summary.hpp): kept for the engine's later calls; without it (no memory,
+        // AF_SUMMARY_NO_CODES) the last pass reads the clock again
+        s.code_pitch = (out->clock_capacity + 7u) & ~7u;
+        const size_t code_bytes = (size_t)sum->n_scenarios * s.code_pitch * sizeof(uint16_t);
+        if (std::getenv("AF_SUMMARY_NO_CODES") == nullptr) {
+            if (e->codes_bytes < code_bytes) {
+                if (e->d_codes) (void)hipFree(e->d_codes);
+                e->d_codes = nullptr;
+                e->codes_bytes = 0;
+                if (hipMalloc(&e->d_codes, code_bytes) == hipSuccess) e->codes_bytes = code_bytes;
+                else (void)hipGetLastError();
+            }
+            s.codes = e->codes_bytes >= code_bytes ? static_cast<uint16_t*>(e->d_codes) : nullptr;
+        }
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(afs::af_summary_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes));
         hipLaunchKernelGGL(afs::af_summary_kernel, dim3(sum->n_scenarios), dim3(afs::kThreads), dyn_bytes, e->stream, s);
@@ -2130,6 +2146,7 @@ void af_engine_destroy(af_engine_t* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->d_blob) (void)hipFree(e->d_blob);
+    if (e->d_codes) (void)hipFree(e->d_codes);
     if (e->d_state) (void)hipFree(e->d_state);
     if (e->d_sweep) (void)hipFree(e->d_sweep);
     if (e->ev0) (void)hipEventDestroy(e->ev0);

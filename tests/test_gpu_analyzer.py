@@ -77,7 +77,18 @@ def _summarize_synthetic(lats_list, starts_list=None, total_time=50, hist_bins=0
     return clocks, stats.cpu().numpy(), rps.cpu().numpy(), hist.cpu().numpy().view(np.uint32)
 
 
-def test_order_statistics_are_exact_on_adversarial_latency_sets():
+@pytest.fixture(params=["codes", "clock_again"])
+def last_pass(request, monkeypatch):
+    """Both forms of the analyzer's last pass: candidates found through the 16-bit codes pass 1 left in the engine's scratch
+    array (round 3; the default), or by reading the clock again (no scratch memory: AF_SUMMARY_NO_CODES)."""
+    if request.param == "clock_again":
+        monkeypatch.setenv("AF_SUMMARY_NO_CODES", "1")
+    else:
+        monkeypatch.delenv("AF_SUMMARY_NO_CODES", raising=False)
+    return request.param
+
+
+def test_order_statistics_are_exact_on_adversarial_latency_sets(last_pass):
     rng = np.random.default_rng(2026)
     cases = [
         [],                                                     # no completion at all
@@ -94,6 +105,8 @@ def test_order_statistics_are_exact_on_adversarial_latency_sets():
         rng.lognormal(-4.0, 0.5, 75_861),                       # LB-2 sized
         np.arange(1, 101) * 0.001,                              # n = 100: p95 / p99 interpolate with t < 0.5 and t >= 0.5
         np.arange(1, 34) * 0.5,
+        np.concatenate([rng.lognormal(-4.0, 0.3, 60_000), rng.lognormal(2.0, 0.3, 4_000)]),   # p95 / p99 in binades the first 512 may miss
+        1.0 + rng.uniform(0, 1e-9, 50_000),                    # deviations 1e-9 of the mean: the shifted sum of squares must hold
     ]
     clocks, stats, rps, _ = _summarize_synthetic(cases, random_starts=(4, 5, 6, 7, 13))
     for i, ck in enumerate(clocks):
@@ -101,7 +114,7 @@ def test_order_statistics_are_exact_on_adversarial_latency_sets():
         assert np.array_equal(rps[i].astype(np.float64), ao.throughput_series(ck, 50)[1]), f"rps case {i}"
 
 
-def test_window_edges_histogram_and_capacity_clamp():
+def test_window_edges_histogram_and_capacity_clamp(last_pass):
     starts = [np.zeros(6)]
     lats = [np.array([0.0, 1.0, 1.0000000000000002, 2.0, 49.99, 50.0])]
     clocks, stats, rps, hist = _summarize_synthetic(lats, starts, hist_bins=8, hist_max=4.0)
@@ -116,7 +129,7 @@ def test_window_edges_histogram_and_capacity_clamp():
 
 
 @pytest.mark.parametrize("payload_fn", [lambda: lb_two_servers(horizon=30), lambda: lb_with_events(users=150, horizon=40, scale=0.05)])
-def test_summary_of_a_simulated_batch_matches_the_oracle(payload_fn):
+def test_summary_of_a_simulated_batch_matches_the_oracle(payload_fn, last_pass):
     from asyncflow_amd.runner import SimulationRunner
 
     payload = payload_fn()
