@@ -36,6 +36,8 @@ constexpr int kThreads = 512;   // (1 024 threads, two scenarios per CU, in the 
 constexpr int kWaves = kThreads / 64;
 constexpr int kRanks = 6;       // median lo/hi, p95 lo/hi, p99 lo/hi
 constexpr int kCand = 512;      // candidates per rank resolved in LDS
+constexpr int kPerThread = 8;   // completions per thread and step of pass 1
+constexpr uint32_t kBlock = kThreads * kPerThread;   // ... per workgroup: the codes of one step are stored thread by thread
 constexpr int kExpBins = 2048;  // level 0: bits 62..52 (latencies are >= +0.0, the sign bit is clear)
 constexpr int kDigBits = 10;    // deeper levels: 10 key bits each
 constexpr int kDigBins = 1 << kDigBits;
@@ -52,7 +54,7 @@ struct SumArgs {
     uint32_t hist_bins;
     double hist_scale;  // hist_bins / hist_max
     uint16_t* codes;      // [n][code_pitch] scratch or null (then the last pass reads the clock again)
-    uint32_t code_pitch;  // multiple of 8
+    uint32_t code_pitch;  // multiple of kBlock
 };
 
 __device__ inline double wave_sum(double v) {
@@ -203,17 +205,19 @@ __global__ __launch_bounds__(kThreads) void af_summary_kernel(SumArgs a) {
 
     // ---- pass 1 -----------------------------------------------------------------------------
     double s = 0.0, mn = __builtin_inf(), mx = -__builtin_inf(), sd1 = 0.0, sq1 = 0.0;
-    for (uint32_t base = 0; base < n; base += kThreads * 4u) {
-        double2 c4[4];
+    for (uint32_t base = 0; base < n; base += kBlock) {
+        double2 c4[kPerThread];
+        uint32_t codes8[kPerThread / 2];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {  // four 16-byte loads in flight per thread
+        for (int u = 0; u < kPerThread; ++u) {  // eight 16-byte loads in flight per thread
             const uint32_t i = base + (uint32_t)u * kThreads + tid;
             c4[u] = i < n ? ck[i] : double2{0.0, 0.0};
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kPerThread; ++u) {
             const uint32_t i = base + (uint32_t)u * kThreads + tid;
             const bool act = i < n;
+            uint32_t code = 0u;   // (guessed bin + 1) << 10 | digit; 0 = in none of the guessed bins
             const double2 c = c4[u];
             const double lat = c.y - c.x;
             if (act) {
@@ -228,7 +232,6 @@ __global__ __launch_bounds__(kThreads) void af_summary_kernel(SumArgs a) {
             const uint32_t ebin = (uint32_t)(key >> 52) & (kExpBins - 1);
             if (act) {
                 const uint32_t dig = (uint32_t)(key >> (52 - kDigBits)) & (kDigBins - 1);
-                uint32_t code = 0u;   // (guessed bin + 1) << 10 | digit; 0 = in none of the guessed bins
                 if (gn > 0u && ebin == gp0) {
                     atomicAdd(&dig_hist[0][dig], 1u);
                     code = (1u << kDigBits) | dig;
@@ -241,8 +244,9 @@ __global__ __launch_bounds__(kThreads) void af_summary_kernel(SumArgs a) {
                 } else {
                     atomicAdd(&exp_hist[ebin], 1u);   // (rare: the guessed bins hold nearly everything, and THEIR counts are the sums of their digit bins, below)
                 }
-                if (cd) cd[i] = (uint16_t)code;
             }
+            if (u & 1) codes8[u >> 1] |= code << 16;
+            else codes8[u >> 1] = code;
             if (a.rps) {
                 // window (k-1, k]; a finish at exactly 0 belongs to the first window (analyzer.py:112-121)
                 const double kf = ceil(c.y);
@@ -255,6 +259,8 @@ __global__ __launch_bounds__(kThreads) void af_summary_kernel(SumArgs a) {
                 atomicAdd(&hist_l[b], 1u);
             }
         }
+        // the thread's eight codes side by side: one 16-byte store (position base + 8 tid + u holds completion base + 512 u + tid)
+        if (cd) *reinterpret_cast<uint4*>(cd + base + 8u * (uint32_t)tid) = uint4{codes8[0], codes8[1], codes8[2], codes8[3]};
     }
     const double total = block_sum(s, scratch);   // (its barriers also close pass 1's histogram updates)
     if ((uint32_t)wave < gn) {   // exponent bin q of the guess: as many as its digit bins hold together
@@ -421,14 +427,14 @@ __global__ __launch_bounds__(kThreads) void af_summary_kernel(SumArgs a) {
 #pragma unroll
         for (int q = 0; q < kRanks; ++q) sc_q[q] = (uint32_t)q < ns ? slot_code[q] : 0xFFFFFFFFu;
         const uint4* cd4 = reinterpret_cast<const uint4*>(cd);
-        for (uint32_t i8 = (uint32_t)tid * 8u; i8 < n; i8 += kThreads * 8u) {
-            const uint4 w = cd4[i8 >> 3];
+        for (uint32_t base = 0; base < n; base += kBlock) {   // (every position of a started step was written: no completion, code 0)
+            const uint4 w = cd4[(base >> 3) + (uint32_t)tid];
             const uint32_t word[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
             for (int h = 0; h < 8; ++h) {
-                const uint32_t i = i8 + (uint32_t)h;
+                const uint32_t i = base + (uint32_t)h * kThreads + (uint32_t)tid;
                 const uint32_t code = (word[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
-                if (code == 0u || i >= n) continue;
+                if (code == 0u) continue;
 #pragma unroll
                 for (int q = 0; q < kRanks; ++q)
                     if (code == sc_q[q]) {

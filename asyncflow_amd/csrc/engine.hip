@@ -2094,7 +2094,7 @@ int af_engine_summarize(af_engine_t* e, const af_outputs_t* out, const af_summar
         s.hist_scale = sum->hist ? (double)sum->hist_bins / sum->hist_max : 0.0;
         // scratch for the analyzer's 16-bit codes (af_summary.hpp): kept for the engine's later calls; without it (no memory,
         // AF_SUMMARY_NO_CODES) the last pass reads the clock again
-        s.code_pitch = (out->clock_capacity + 7u) & ~7u;
+        s.code_pitch = (out->clock_capacity + afs::kBlock - 1u) / afs::kBlock * afs::kBlock;
         const size_t code_bytes = (size_t)sum->n_scenarios * s.code_pitch * sizeof(uint16_t);
         if (std::getenv("AF_SUMMARY_NO_CODES") == nullptr) {
             if (e->codes_bytes < code_bytes) {
