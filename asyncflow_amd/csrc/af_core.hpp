@@ -261,7 +261,7 @@ AF_HD double gen_next_gap(GenState& g, uint64_t seed, uint32_t users_dist, doubl
         const U4 r = draw_block(seed, STREAM_GENERATOR, g.draws++, 0u);
         double u = u53(r.x, r.y);
         if (u < 1e-15) u = 1e-15;
-        const double dt = test_quant(-af_log(1.0 - u) / g.g_lam);
+        const double dt = test_quant(-af_log_unit(1.0 - u) / g.g_lam);
         if (g.g_now + dt > T) break;
         if (g.g_now + dt >= g.g_wend) {
             g.g_now = g.g_wend;

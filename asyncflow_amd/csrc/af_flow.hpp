@@ -546,7 +546,7 @@ struct Flow {
         transit = af::test_quant(af::variate_from_u1(AF_FJ_DIST_ALL, mean, sigma, u1, seed, stream, idx));
 #else
         const uint32_t dist = (uint32_t)(r[3] >> 16) & 0xFFu;
-        transit = af::test_quant(dist == af::DIST_EXPONENTIAL ? -(mean * af::af_log(1.0 - u1)) : cold_variate(dist, mean, sigma, u1, seed, stream, idx));
+        transit = af::test_quant(dist == af::DIST_EXPONENTIAL ? -(mean * af::af_log_unit(1.0 - u1)) : cold_variate(dist, mean, sigma, u1, seed, stream, idx));
 #endif
         return true;
     }

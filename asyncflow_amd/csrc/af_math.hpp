@@ -108,6 +108,34 @@ AF_HD double af_log(double x) {
     return s * (hfsq + R) + dk * ln2_lo - hfsq + f + dk * ln2_hi;
 }
 
+// af_log for a NORMAL x in (0, 1] -- one minus a uniform of [0, 1), the argument of every exponential variate --: the same
+// operations without the checks for zero / negative / subnormal / infinite arguments (and without the x == 1 shortcut, whose
+// result the general path gives too: f = 0 makes every term +0).  Same bits as af_log on that domain
+// (tests/test_gpu_parity.py::test_device_math_matches_oracle_bit_for_bit, kind 7).
+AF_HD double af_log_unit(double x) {
+    constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    constexpr double L1 = 6.666666666666735130e-01, L2 = 3.999999999940941908e-01,
+                     L3 = 2.857142874366239149e-01, L4 = 2.222219843214978396e-01,
+                     L5 = 1.818357216161805012e-01, L6 = 1.531383769920937332e-01,
+                     L7 = 1.479819860511658591e-01;
+    const uint64_t u = f64_bits(x);
+    uint32_t hx = (uint32_t)(u >> 32);
+    hx += 0x3ff00000u - 0x3fe6a09eu;
+    const int k = (int)(hx >> 20) - 0x3ff;
+    hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
+    x = bits_f64(((uint64_t)hx << 32) | (u & 0xffffffffull));
+    const double f = x - 1.0;
+    const double hfsq = 0.5 * f * f;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * (L2 + w * (L4 + w * L6));
+    const double t2 = z * (L1 + w * (L3 + w * (L5 + w * L7)));
+    const double R = t2 + t1;
+    const double dk = (double)k;
+    return s * (hfsq + R) + dk * ln2_lo - hfsq + f + dk * ln2_hi;
+}
+
 AF_HD double af_exp(double x) {
     constexpr double ln2hi = 6.93147180369123816490e-01, ln2lo = 1.90821492927058770002e-10,
                      invln2 = 1.44269504088896338700e+00;
@@ -232,7 +260,7 @@ AF_HD double variate_from_u1(uint32_t dist, double mean, double sigma, double u1
                              uint32_t index) {
     switch (dist) {
         case DIST_EXPONENTIAL:
-            return -(mean * af_log(1.0 - u1));
+            return -(mean * af_log_unit(1.0 - u1));
         case DIST_UNIFORM:
             return u1;
         case DIST_NORMAL: {

@@ -504,7 +504,7 @@ __global__ void __launch_bounds__(64) af_pregen_arrivals(const KArgs a, uint32_t
         const af::U4 r = af::draw_block(seed, af::STREAM_GENERATOR, draws + l, 0u);
         double u = af::u53(r.x, r.y);
         if (u < 1e-15) u = 1e-15;
-        const double dt = -af::af_log(1.0 - u) / (draw ? lam : 1.0);
+        const double dt = -af::af_log_unit(1.0 - u) / (draw ? lam : 1.0);
         // prefixes in draw order: Gs = sampler clock after gap l, Ss = simulation clock after gap l
         double Gs = g_now, Ss = t;
 #pragma unroll
@@ -605,7 +605,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) af
         const af::U4 r = af::draw_block(seed, af::STREAM_GENERATOR, draws + l, 0u);
         double u = af::u53(r.x, r.y);
         if (u < 1e-15) u = 1e-15;
-        const double dt = -af::af_log(1.0 - u) / (draw ? lam : 1.0);
+        const double dt = -af::af_log_unit(1.0 - u) / (draw ? lam : 1.0);
         // prefixes in draw order: Gs = sampler clock after gap l, Ss = simulation clock after gap l (x + 0.0 == x exactly)
         double Gs = g_now, Ss = t;
 #define AF_ROW_STEP(J) { const double dj = row_bcast<J>(dt); const double m = l >= (J) ? dj : 0.0; Gs += m; Ss = Ss + m; }
@@ -615,6 +615,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) af
         const bool over = Gs > T;                  // the sampler is exhausted at this draw
         const bool cross = !over && Gs >= g_wend;  // this draw crosses the window end: discarded
         const uint64_t stops = __ballot(draw && (over || cross));
+        const double Glast = row_bcast<15>(Gs), Slast = row_bcast<15>(Ss);
+        if (stops == 0ull && !__any(draw && k + G > a.n_draw)) {   // the usual batch: 16 arrivals per drawing row, nothing else
+            if (draw) {
+                out[k + l] = Ss;
+                k += G;
+                g_now = Glast;
+                t = Slast;
+                draws += G;
+            }
+            continue;
+        }
         const uint32_t mine = (uint32_t)(stops >> gbase) & 0xFFFFu;
         const uint32_t first = mine ? (uint32_t)__builtin_ctz(mine) : G;   // draws before it are arrivals
         uint32_t n_acc = first;
@@ -624,7 +635,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) af
             full = true;
         }
         if (draw && l < n_acc) out[k + l] = Ss;
-        const double Glast = row_bcast<15>(Gs), Slast = row_bcast<15>(Ss);
         const double Sprev = __shfl(Ss, (int)((gbase + (first > 0u ? first - 1u : 0u)) & 63u), 64);
         const bool over_first = ((__ballot(over) >> gbase) >> (first & 15u)) & 1ull;
         if (draw) {
@@ -736,6 +746,7 @@ __global__ void af_probe_kernel(int kind, uint64_t seed, const double* in, const
         case 4: r = af::af_sqrt(x); break;
         case 5: r = x / y; break;
         case 6: r = (double)af::af_poisson(x, seed, (uint32_t)y >> 16, (uint32_t)y & 0xFFFFu, 0u); break;
+        case 7: r = af::af_log_unit(x); break;
         default: r = 0.0;
     }
     out[i] = r;

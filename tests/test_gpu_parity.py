@@ -45,6 +45,10 @@ def test_device_math_matches_oracle_bit_for_bit():
     rng = np.random.default_rng(0)
     x = np.concatenate([rng.random(20000), 1.0 - rng.random(2000) * 1e-9, np.exp(rng.uniform(-300, 300, 4000))])
     assert np.array_equal(probe_math(1, x), np.array([L.orc_x_log(float(v)) for v in x]))
+    # af_log_unit: the logarithm of the exponential variates (argument 1 - u in [2^-53, 1]) without af_log's special cases
+    xu = np.concatenate([1.0 - rng.random(20000), 1.0 - rng.random(2000) * 1e-9, rng.random(2000) * 1e-9 + 2.0 ** -53,
+                         [1.0, 2.0 ** -53, 1.0 - 2.0 ** -53, 0.5, 0.7071067811865476, 0.7071067811865475]])
+    assert np.array_equal(probe_math(7, xu).view(np.uint64), np.array([L.orc_x_log(float(v)) for v in xu]).view(np.uint64))
     e = np.concatenate([rng.uniform(-30, 30, 20000), rng.uniform(-700, 700, 2000)])
     assert np.array_equal(probe_math(2, e), np.array([L.orc_x_exp(float(v)) for v in e]))
     p = np.concatenate([rng.random(20000), rng.random(2000) * 1e-12])
