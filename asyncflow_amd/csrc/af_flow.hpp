@@ -373,15 +373,18 @@ struct Flow {
     // the counter of `series` changes by w at the first tick after an event: tick row `row` (tick_index of the event's
     // time).  Differences go to the LDS ring, or -- ring_rows == 0 -- straight into the scenario's (zeroed) rows of the
     // sample array in HBM, which flush_ticks() then prefix-sums in place.
-    AF_CORE void add_point(uint32_t series, uint32_t row, int32_t w) {
+    // (`on`: the caller's own condition, folded into the one divergent region around the atomic -- every region costs the
+    // wave a handful of scalar instructions, and this is called ten times per request)
+    AF_CORE void add_point(uint32_t series, uint32_t row, int32_t w, bool on = true) {
         const uint32_t R = A.L.ring_rows, N = A.n_ticks < A.tick_cap ? A.n_ticks : A.tick_cap;
-        if (row >= N) return;
+        const bool in = on && row < N;
         if (kHbmRing && R == 0u) {
-            W::global_add(samples + (size_t)row * A.L.pitch + series, (uint32_t)w);
+            if (in) W::global_add(samples + (size_t)row * A.L.pitch + series, (uint32_t)w);
             return;
         }
-        if (row - tick_base >= R) why |= FLOW_WHY_RING;
-        else W::lds_add((AF_PLAN_AS uint32_t*)(ring() + (row & (R - 1u)) * A.L.pitch + series), (uint32_t)w);
+        const bool reach = row - tick_base < R;
+        why |= (in && !reach) ? FLOW_WHY_RING : 0u;
+        if (in && reach) W::lds_add((AF_PLAN_AS uint32_t*)(ring() + (row & (R - 1u)) * A.L.pitch + series), (uint32_t)w);
     }
     // the counter of `series` is larger by w during [a, b)
     AF_CORE void add_interval(uint32_t series, double a, double b, int32_t w) {
@@ -389,10 +392,10 @@ struct Flow {
         add_span(series, ia, ib, w);
     }
     // ... is larger by w between the events whose tick rows are ia and ib (nothing to enter when no tick lies between)
-    AF_CORE void add_span(uint32_t series, uint32_t ia, uint32_t ib, int32_t w) {
-        if (ia == ib) return;
-        add_point(series, ia, w);
-        add_point(series, ib, -w);
+    AF_CORE void add_span(uint32_t series, uint32_t ia, uint32_t ib, int32_t w, bool on = true) {
+        const bool span = on && ia != ib;
+        add_point(series, ia, w, span);
+        add_point(series, ib, -w, span);
     }
     // rows [tick_base, upto) are final: prefix-sum the differences and stream the rows out
     AF_CORE void flush_ticks(uint32_t upto) {
@@ -538,7 +541,7 @@ struct Flow {
         const double mean = u2d(r[0]), sigma = u2d(r[1]), dropout = u2d(r[2]);
         const uint32_t stream = af::stream_edge(e);
         const af::U4 rr = af::draw_block(seed, stream, idx, 0u);
-        if (af::u53(rr.x, rr.y) < dropout) return false;   // dropped: no latency draw
+        const bool sent = !(af::u53(rr.x, rr.y) < dropout);   // dropped: no latency draw (worked out all the same: one region less)
         const double u1 = af::u53(rr.z, rr.w);
 #if defined(AF_FJ_DIST_ALL) && (AF_FJ_DIST_ALL != 255)
         // plan-specialised build of a plan whose edges all follow ONE law: the law is a constant, its variate code is
@@ -548,7 +551,7 @@ struct Flow {
         const uint32_t dist = (uint32_t)(r[3] >> 16) & 0xFFu;
         transit = af::test_quant(dist == af::DIST_EXPONENTIAL ? -(mean * af::af_log_unit(1.0 - u1)) : cold_variate(dist, mean, sigma, u1, seed, stream, idx));
 #endif
-        return true;
+        return sent;
     }
     // EdgeRuntime._deliver (edge.py:73-116) for the idx-th message of edge e, sent at `now`.
     // Returns false if the message is dropped; else `key` = delivery time.
@@ -636,21 +639,19 @@ struct Flow {
             k[q] = t[q] = sent[q] = 0.0;
             a[q] = b[q] = slot[q] = 0u;
             {
+                // (entries past the list's end are read too -- the arrays hold 64 x IPL -- and masked by `valid`: the loads and
+                // the bucket arithmetic run for every lane, only the atomic sits in a divergent region)
                 const uint32_t i = q * 64u + lane;
                 valid[q] = i < n;
-                if (valid[q]) {
-                    k[q] = K[i];
-                    t[q] = T0[i];
-                    if (kTieBreak) sent[q] = TS[i];
-                    a[q] = (s == 2u || (kFar && s == 3u)) ? AX[i] : 0u;
-                    elig[q] = k[q] < hi;
-                    if (elig[q]) {
-                        double x = (k[q] - lo) * sc;
-                        x = x < 63.0 ? x : 63.0;
-                        b[q] = x > 0.0 ? (uint32_t)x : 0u;
-                        slot[q] = W::lds_add(hist() + b[q], 1u);
-                    }
-                }
+                k[q] = K[i];
+                t[q] = T0[i];
+                if (kTieBreak) sent[q] = TS[i];
+                a[q] = (s == 2u || (kFar && s == 3u)) ? AX[i] : 0u;
+                elig[q] = valid[q] && k[q] < hi;
+                double x = (k[q] - lo) * sc;
+                x = x < 63.0 ? x : 63.0;        // (also what a NaN from a stale entry becomes)
+                b[q] = x > 0.0 ? (uint32_t)x : 0u;
+                if (elig[q]) slot[q] = W::lds_add(hist() + b[q], 1u);
             }
         }
         W::sync();
@@ -1394,14 +1395,14 @@ struct Flow {
 
     // ---- completion (client.py:62-69) -------------------------------------------------------------------
     AF_CORE void complete(bool have, uint32_t r, double t0, double now) {
-        if (!have) return;
         const uint32_t at = n_comp + r;
         if (clock != nullptr) {
-            if (at < A.clock_cap) {
+            if (have && at < A.clock_cap) {
                 clock[2u * (size_t)at] = t0;
                 clock[2u * (size_t)at + 1u] = now;
             }
         }
+        if (!kOnline || !have) return;
         if (kOnline && o_hist != nullptr) {
             const double bf = (now - t0) * A.online_hist_scale;
             AF_BUMP(o_hist + (bf >= (double)(A.online_hist_bins - 1u) ? A.online_hist_bins - 1u : (uint32_t)bf));
@@ -1705,10 +1706,10 @@ struct Flow {
                                 if (q_ready) t_s = tick_index(r.s, true);
                                 if (q_post) t_f = tick_index(r.f, true);
                                 if (q_post || q_ram || ts < T) t_g = tick_index(r.g, true);
-                                if (q_ready) add_span(s0, t_b, t_s, 1);
-                                if (q_pre) add_span(s0 + 1u, t_adm, t_b, 1);
-                                if (q_post) add_span(s0 + 1u, t_f, t_g, 1);
-                                if (q_ram) add_span(s0 + 2u, t_adm, t_g, (int32_t)(ram * A.ram_scale));
+                                add_span(s0, t_b, t_s, 1, q_ready);
+                                add_span(s0 + 1u, t_adm, t_b, 1, q_pre);
+                                add_span(s0 + 1u, t_f, t_g, 1, q_post);
+                                add_span(s0 + 2u, t_adm, t_g, (int32_t)(ram * A.ram_scale), q_ram);
                                 row = t_g;
                             }
                         }
