@@ -363,12 +363,17 @@ struct Flow {
         if (frac > A.tick_eps && frac < 1.0 - A.tick_eps) return g < N ? g : N;   // safely between two ticks
         return tick_lookup(x, g < N ? g : N, flag_ties);                          // next to a tick
     }
+    // (behind a call: one event in ~1e8 lies this close to a tick, and the two table walks were 550 of the unrolled kernel's
+    // 4 700 instructions -- 42 at each of tick_index's 13 inlined sites; bit 31 of the result: the event is AT a tick)
     AF_CORE uint32_t tick_lookup(double x, uint32_t g, bool flag_ties) {
-        const uint32_t N = A.n_ticks;
-        while (g < N && A.tick_t[g] < x) ++g;
-        while (g > 0u && A.tick_t[g - 1u] >= x) --g;
-        if (flag_ties && g < N && A.tick_t[g] == x) why |= FLOW_WHY_TIE;
-        return g;
+        const uint32_t r = cold_tick_lookup(A.tick_t, A.n_ticks, x, g);
+        if (flag_ties && (r >> 31)) why |= FLOW_WHY_TIE;
+        return r & 0x7FFFFFFFu;
+    }
+    AF_CORE_NOINLINE static uint32_t cold_tick_lookup(const double* tick_t, uint32_t N, double x, uint32_t g) {
+        while (g < N && tick_t[g] < x) ++g;
+        while (g > 0u && tick_t[g - 1u] >= x) --g;
+        return g | ((g < N && tick_t[g] == x) ? 0x80000000u : 0u);
     }
     // the counter of `series` changes by w at the first tick after an event: tick row `row` (tick_index of the event's
     // time).  Differences go to the LDS ring, or -- ring_rows == 0 -- straight into the scenario's (zeroed) rows of the
@@ -674,6 +679,7 @@ struct Flow {
             if (elig[q]) {
                 const uint32_t p0 = bbase()[b[q]], p1 = p0 + hist()[b[q]], me = p0 + slot[q];
                 uint32_t r = p0;
+#pragma nounroll   // (a bucket holds one or two messages: the unrolled-by-eight form was 115 instructions per site for ~1.5 trips)
                 for (uint32_t p = p0; p < p1; ++p) {
                     const double kk = sorted()[p];
                     r += kk < k[q] ? 1u : 0u;
