@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-AF_ABI_VERSION = 4
+AF_ABI_VERSION = 5
 
 # af_status
 MAX_REQUEST_CAPACITY = 65535   # include/asyncflow_hip.h AF_MAX_REQUEST_CAPACITY
@@ -210,6 +210,8 @@ class AfStats(C.Structure):
         ("flow_lds_bytes", C.c_uint32),
         ("jit_fallbacks", C.c_uint32),
         ("gather_ms", C.c_double),
+        ("pregen_group", C.c_uint32),
+        ("reserved0", C.c_uint32),
     ]
 
 

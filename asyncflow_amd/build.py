@@ -15,7 +15,7 @@ from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB_PATH = CSRC / "libasyncflow_hip.so"
-SOURCES = ("engine.hip", "af_flow.hpp", "af_flow_host.hpp", "af_core.hpp", "af_math.hpp", "af_plan_pack.hpp", "af_summary.hpp")
+SOURCES = ("engine.hip", "af_flow.hpp", "af_flow_host.hpp", "af_core.hpp", "af_math.hpp", "af_plan_pack.hpp", "af_summary.hpp", "af_pregen.hpp")
 ARCH = "gfx950"
 
 # -ffp-contract=off / -fno-fast-math: every f64 expression is evaluated exactly as

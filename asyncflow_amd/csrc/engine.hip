@@ -36,6 +36,7 @@
 #include "af_core.hpp"
 #include "af_flow_host.hpp"
 #include "af_plan_pack.hpp"
+#include "af_pregen.hpp"
 #include "af_summary.hpp"
 
 #define LDS_AS __attribute__((address_space(3)))
@@ -660,18 +661,61 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) af
     }
 }
 
-// (Round 3 also built VERDICT r2's item 4 -- the variates of every draw index by a fully parallel kernel at 8 waves per SIMD,
-// the order-dependent sums by a chain kernel with 8 lanes and 8 draws per scenario and batch, variates prefetched four batches
-// ahead -- and removed it again: af_arrival_variates 3.3 ms + af_arrival_chain 11.9 ms against 11.0 ms for the fused row kernel.
-// The counters say why: the chain kernel alone executes 2.9e9 VALU wave-instructions (233 per batch of 64 draws: the masked
-// sums, the per-group state updates behind `v_cndmask`, address arithmetic), the fused kernel 4.0e9 INCLUDING the variates --
-// the serial bookkeeping, not Philox + log, is what the pre-generation costs, and it does not shrink by being alone.
-// DESIGN.md section 4f.)
+// ---- the grouped form (round 3, af_pregen.hpp: af_arrival_groups) -- one LANE per scenario for the order-dependent part,
+// the variates worked out beside it by the other waves of the workgroup ------------------------------------------------
+// (A first split -- the variates by a parallel kernel into HBM, the sums by 8 lanes and 8 draws per scenario and step, the
+// same masked-sum formulation as above -- was built and removed: its chain kernel alone executed 2.9e9 VALU wave-
+// instructions, 233 per 64 draws, 11.9 ms against 11.0 ms for the fused row kernel.  The serial bookkeeping is what the
+// pre-generation costs, and it only goes away when a lane does nothing but its own scenario's additions: 16 adds + 24
+// instructions of division per 64 draws.  af_pregen.hpp tells what that lane must NOT do: touch HBM.)
+
 // launch helper: the group width with the shortest issue-bound time for `n` scenarios (see the kernel's comment).
 // Measured (10 000 / 8 192 LB-2 replicas): 4 per wave 15.2 / 9.5 ms, 5 per wave 11.7 / -, 8 per wave - / 15.1 ms (one wave
 // per SIMD: nothing hides its latencies).  More than 4 per wave only when the SIMDs still get ~2 waves each and the
 // scenarios are alike (`uniform_load`: no per-scenario users / rpm column -- a wave is as slow as its heaviest scenario).
-static void launch_pregen_arrivals(const KArgs& a, uint32_t n, uint32_t stride, bool uniform_load, hipStream_t stream) {
+// `grouped`: af_arrival_groups instead (af_engine_run decides: sweeps of alike scenarios from a few thousand on, long
+// sampling windows; AF_PREGEN_MODE=rows / groups overrides, AF_PREGEN_GROUP = scenarios per workgroup).
+static int launch_pregen_arrivals(const KArgs& a, uint32_t n, uint32_t stride, bool uniform_load, hipStream_t stream,
+                                  bool grouped = false, uint32_t* group_out = nullptr) {
+    if (grouped) {
+        afp::ArrivalArgs g{};
+        g.total_time = a.total_time;
+        g.users_mean = a.gen_users_mean;
+        g.users_sigma = a.gen_users_sigma;
+        g.rpm = a.gen_rpm_mean;
+        g.window_s = a.gen_window_s;
+        g.users_dist = a.gen_users_dist;
+        g.n_scen = n;
+        g.n_draw = a.n_draw;
+        g.stride = stride;
+        // one workgroup per CU while that leaves it <= 64 scenarios: the chain wave of a workgroup is as long as ONE
+        // scenario's chain however many lanes it has, the producers' work grows with them
+        g.group = (n + 255u) / 256u < 64u ? (n + 255u) / 256u : 64u;
+        if (const char* env = std::getenv("AF_PREGEN_GROUP")) {
+            const int v = std::atoi(env);
+            if (v >= 1 && v <= 64) g.group = (uint32_t)v;
+        }
+        if (group_out) *group_out = g.group;
+        g.seeds = a.seeds;
+        g.scen_map = a.scen_map;
+        g.n_ovr = a.n_ovr;
+        g.ovr_param = a.ovr_param;
+        g.ovr_index = a.ovr_index;
+        g.ovr_values = a.ovr_values;
+        g.ovr_stride = a.ovr_stride;
+        g.out = a.draws;
+        g.pre_flags = a.pre_flags;
+        static bool lds_set = false;
+        if (!lds_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(afp::af_arrival_groups), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)sizeof(afp::GroupLds)) != hipSuccess)
+                return 1;
+            lds_set = true;
+        }
+        hipLaunchKernelGGL(afp::af_arrival_groups, dim3((n + g.group - 1u) / g.group), dim3(afp::kGroupThreads),
+                           sizeof(afp::GroupLds), stream, g);
+        return 0;
+    }
     double best = 1e300;
     uint32_t best_s = 4u;
     for (uint32_t s : {4u, 5u, 8u}) {
@@ -693,12 +737,13 @@ static void launch_pregen_arrivals(const KArgs& a, uint32_t n, uint32_t stride, 
     }
     if (rows) {
         hipLaunchKernelGGL(af_pregen_arrivals_rows, dim3((n + 3u) / 4u), dim3(64), 0, stream, a, stride);
-        return;
+        return 0;
     }
     const dim3 grid((n + best_s - 1u) / best_s);
     if (best_s == 4u) hipLaunchKernelGGL(af_pregen_arrivals<16>, grid, dim3(64), 0, stream, a, stride);
     else if (best_s == 5u) hipLaunchKernelGGL(af_pregen_arrivals<12>, grid, dim3(64), 0, stream, a, stride);
     else hipLaunchKernelGGL(af_pregen_arrivals<8>, grid, dim3(64), 0, stream, a, stride);
+    return 0;
 }
 
 // second pass: the online counters of the scenarios that start over are cleared first
@@ -1606,6 +1651,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     uint32_t fb_total[5] = {0, 0, 0, 0, 0}, flow_scen = 0;
     uint32_t flow_retried = 0, flow_to_next = 0;
     size_t draw_bytes = 0;
+    uint32_t pregen_group = 0;
     bool lds_state = false;
 
     FlowPlan FP;
@@ -1796,8 +1842,16 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
         if ((size_t)nc * n_draw * sizeof(double) > draw_bytes) draw_bytes = (size_t)nc * n_draw * sizeof(double);
         a.draws = e->d_arr;
         a.pre_flags = e->d_arr_flags;
+        // grouped pre-generation (af_pregen.hpp): sweeps of alike scenarios -- a workgroup is as slow as its heaviest one -- with
+        // sampling windows long enough that a window start (a user draw by one wave, the pipeline refilled) does not count
+        const char* pregen_mode = std::getenv("AF_PREGEN_MODE");   // rows | groups: tests and measurements
+        const bool force_groups = pregen_mode && std::strcmp(pregen_mode, "groups") == 0;
+        const bool force_rows = pregen_mode && std::strcmp(pregen_mode, "rows") == 0;
+        const bool grouped = !force_rows && a.gen_window_s > 0.0 &&
+                             (force_groups || (!hetero_load && !(mask & (1u << AF_PARAM_GEN_WINDOW)) && nc >= 3072u &&
+                                               (double)n_draw * a.gen_window_s >= 512.0 * a.total_time));
         HIP_TRY(hipEventRecord(e->ev2, e->stream));
-        launch_pregen_arrivals(a, nc, n_draw, !hetero_load, e->stream);
+        if (launch_pregen_arrivals(a, nc, n_draw, !hetero_load, e->stream, grouped, &pregen_group)) return fail(AF_ERR_HIP, "af_arrival_groups: LDS attribute");
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(e->ev3, e->stream));
         aff::FlowArgs f = e->fargs;
@@ -1965,6 +2019,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     e->stats.flow_ring_rows = use_flow ? FL.ring_rows : 0u;
     e->stats.flow_lds_bytes = flow_lds;
     e->stats.jit_fallbacks = n_jit_miss;
+    e->stats.pregen_group = pregen_group;
     e->stats.pregen_ms = ms_pregen;
     e->stats.h2d_ms = ms_h2d;
     e->stats.draw_bytes = draw_bytes;

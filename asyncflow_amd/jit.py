@@ -28,7 +28,7 @@ from .build import ARCH, CSRC, hipcc_path
 
 CACHE_DIR = Path(os.environ["ASYNCFLOW_JIT_CACHE"]) if os.environ.get("ASYNCFLOW_JIT_CACHE") else CSRC / "_jit"
 _FALLBACK_CACHE_DIR = Path.home() / ".cache" / "asyncflow_amd" / "jit"
-_SOURCES = ("engine.hip", "af_flow.hpp", "af_flow_host.hpp", "af_core.hpp", "af_math.hpp", "af_plan_pack.hpp", "af_summary.hpp")
+_SOURCES = ("engine.hip", "af_flow.hpp", "af_flow_host.hpp", "af_core.hpp", "af_math.hpp", "af_plan_pack.hpp", "af_summary.hpp", "af_pregen.hpp")
 _FLAGS = (f"--offload-arch={ARCH}", "--genco", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
           "-Wno-unused-function",
           # the five stations of af_flow_jit are unrolled by pragma (af_flow.hpp, Flow::run): no size limit on that

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define AF_ABI_VERSION 4
+#define AF_ABI_VERSION 5
 
 /* ---- status codes ------------------------------------------------------ */
 enum af_status {
@@ -317,6 +317,9 @@ typedef struct af_stats {
     uint32_t flow_lds_bytes;       /* LDS per wavefront                                             */
     uint32_t jit_fallbacks;        /* launches that wanted plan-specialised kernels but ran the generic ones */
     double gather_ms;              /* last af_engine_gather (HIP events around the grouped all-gather)        */
+    uint32_t pregen_group;         /* arrival pre-generation of the stage-parallel path: scenarios per workgroup of
+                                      af_arrival_groups, 0 = the row kernel                                   */
+    uint32_t reserved0;
 } af_stats_t;
 
 typedef struct af_engine af_engine_t;

@@ -9,7 +9,7 @@ import csv, collections
 for i in (1,2):
     acc=collections.defaultdict(dict)
     for r in csv.DictReader(open(f"gpurun_out/r3p/pmc{i}.csv")):
-        k = 'chain' if 'chain' in r['Kernel_Name'] else 'variates' if 'variates' in r['Kernel_Name'] else 'other'
+        k = 'chain' if 'chain' in r['Kernel_Name'] else 'units' if 'units' in r['Kernel_Name'] else 'other'
         acc[k][r['Counter_Name']] = float(r['Counter_Value'])
     for k,v in acc.items(): print(i, k, v)
 PY

@@ -21,6 +21,7 @@ def build(force: bool = False) -> Path:
     srcs = [HERE / "hostcheck.cpp", HERE / "wave_emul.hpp", ROOT / "asyncflow_amd/csrc/af_core.hpp",
             ROOT / "asyncflow_amd/csrc/af_math.hpp", ROOT / "asyncflow_amd/csrc/af_plan_pack.hpp",
             ROOT / "asyncflow_amd/csrc/af_flow.hpp", ROOT / "asyncflow_amd/csrc/af_flow_host.hpp",
+            ROOT / "asyncflow_amd/csrc/af_pregen.hpp",
             ROOT / "include/asyncflow_hip.h"]
     newest = max(p.stat().st_mtime for p in srcs)
     if force or not LIB.exists() or LIB.stat().st_mtime < newest:
@@ -63,8 +64,22 @@ def lib() -> C.CDLL:
         L.hc_flow_reason.restype = C.c_char_p
         L.hc_flow_lds_bytes.argtypes = [C.POINTER(_abi.AfPlan), C.c_uint32, C.c_uint32]
         L.hc_flow_lds_bytes.restype = C.c_uint64
+        L.hc_arrivals.argtypes = [C.c_int, C.c_uint64, C.c_uint32] + [C.c_double] * 5 + [C.c_uint32, C.POINTER(C.c_double),
+                                  C.POINTER(C.c_uint32)]
+        L.hc_arrivals.restype = C.c_int64
         _lib = L
     return _lib
+
+
+def arrivals(which: int, seed: int, *, dist: int, mean: float, sigma: float, rpm: float, window_s: float, horizon: float,
+             n_draw: int) -> tuple[int, np.ndarray, int]:
+    """The arrival sampler on the host: 0 = af::gen_next_gap (sequential statement), 1 / 2 = the per-lane functions of
+    af_arrival_groups (af_pregen.hpp) with the hoisted-reciprocal / plain division.  -> (arrivals, times[n_draw], flags)"""
+    out = np.empty(n_draw, dtype=np.float64)
+    flags = C.c_uint32(0)
+    n = lib().hc_arrivals(which, C.c_uint64(seed), dist, mean, sigma, rpm, window_s, horizon, n_draw,
+                          out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(flags))
+    return int(n), out, int(flags.value)
 
 
 def simulate(plan: DevicePlan, seed: int, *, cap: int = 4096, fcap: int = 4096,

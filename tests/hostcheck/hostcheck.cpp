@@ -14,6 +14,7 @@
 
 #include "../../asyncflow_amd/csrc/af_plan_pack.hpp"
 #include "../../asyncflow_amd/csrc/af_flow_host.hpp"
+#include "../../asyncflow_amd/csrc/af_pregen.hpp"
 #include "wave_emul.hpp"
 
 namespace {
@@ -300,4 +301,43 @@ extern "C" uint64_t hc_flow_lds_bytes(const af_plan_t* p, uint32_t ipl, uint32_t
     af::PackedPlan pk;
     if (!p || !af::pack_plan(*p, pk).empty()) return 0;
     return 8ull * (pk.words.size() + aff::choose_flow_layout(*p, ipl, ring_rows).n_words);
+}
+
+// ---- the arrival sampler (af_pregen.hpp) ------------------------------------------------------------------------------
+// which = 0: af::gen_next_gap, the sequential statement (what the oracle follows); which = 1 / 2: the per-lane functions of
+// af_arrival_groups driven the way the kernel drives ONE lane (window_start, then steps of eight unit variates), with the
+// hoisted-reciprocal division (1) or the plain one (2).  Returns the number of arrivals.
+extern "C" int64_t hc_arrivals(int which, uint64_t seed, uint32_t dist, double mean, double sigma, double rpm, double window_s,
+                               double T, uint32_t n_draw, double* out, uint32_t* flags) {
+    *flags = 0u;
+    for (uint32_t i = 0; i < n_draw; ++i) out[i] = af::AF_INF;
+    if (which == 0) {
+        af::GenState g;
+        double t = 0.0;
+        uint32_t k = 0;
+        for (; k < n_draw; ++k) {
+            const double gap = af::gen_next_gap(g, seed, dist, mean, sigma, rpm, window_s, T);
+            if (gap < 0.0) break;
+            t = t + gap;
+            out[k] = t;
+        }
+        if (k == n_draw && af::gen_next_gap(g, seed, dist, mean, sigma, rpm, window_s, T) >= 0.0) *flags |= AF_FLAG_DRAW_OVERFLOW;
+        return k;
+    }
+    afp::Lane L;
+    afp::lane_init(L);
+    const double rps_per_user = rpm / 60.0;
+    while (L.state != afp::LANE_DONE) {
+        if (L.state == afp::LANE_WAIT) {
+            afp::window_start(L, T, window_s, rps_per_user,
+                              [&](uint32_t idx) { return afp::users_draw(dist, mean, sigma, seed, idx); });
+            continue;
+        }
+        double e[afp::kBatch];
+        for (uint32_t j = 0; j < afp::kBatch; ++j) e[j] = afp::unit_variate(seed, L.draws + j);
+        if (which == 1 && L.fast_div) afp::lane_step<true>(L, e, T, n_draw, out);
+        else afp::lane_step<false>(L, e, T, n_draw, out);
+    }
+    *flags = L.flags;
+    return L.k;
 }

@@ -313,14 +313,23 @@ def test_config2_replicas_at_full_horizon_match_the_oracle_bit_for_bit():
     assert np.array_equal(res[0].rqs_clock, fx["clock"]) and np.array_equal(res[0]._samples, fx["samples"])  # noqa: SLF001
 
 
-@pytest.mark.parametrize("per_wave", [0, 4, 5, 8])
+@pytest.mark.parametrize("per_wave", [0, 4, 5, 8, "groups", "groups64", "groups5"])
 def test_arrival_pregeneration_group_widths_are_equivalent(monkeypatch, per_wave):
     """The arrival pre-generation as the engine launches it since round 3 (0: one DPP row of 16 lanes per scenario, the gaps
     of a batch handed along the row by `row_newbcast`) and in its round-2 forms (4, 5 or 8 scenarios per wave through the
     LDS crossbar): same arrival times whichever it is -- tiny sampling windows (window ends inside most batches),
-    Gaussian users, a scenario count that leaves the last wave ragged."""
-    if per_wave:
+    Gaussian users, a scenario count that leaves the last wave ragged.  "groups*": the form large sweeps of alike scenarios
+    with long windows get (af_pregen.hpp, af_arrival_groups: one LANE per scenario for the sums and the window logic, the
+    other waves of the workgroup work out the variates), one scenario per workgroup / all in one / ragged groups of five."""
+    if str(per_wave).startswith("groups"):
+        monkeypatch.setenv("AF_PREGEN_MODE", "groups")
+        if per_wave != "groups":
+            monkeypatch.setenv("AF_PREGEN_GROUP", per_wave[6:])
+    elif per_wave:
+        monkeypatch.setenv("AF_PREGEN_MODE", "rows")
         monkeypatch.setenv("AF_PREGEN_SCEN_PER_WAVE", str(per_wave))
+    else:
+        monkeypatch.setenv("AF_PREGEN_MODE", "rows")
     payload = lb_two_servers(horizon=40)
     payload["rqs_input"]["user_sampling_window"] = 1
     payload["rqs_input"]["avg_active_users"] = {"mean": 150, "distribution": "normal", "variance": 60}
@@ -331,6 +340,8 @@ def test_arrival_pregeneration_group_widths_are_equivalent(monkeypatch, per_wave
         _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])), f"{per_wave} per wave, scenario {i}")
     want = np.array([ol.simulate(plan, int(s), want_clock=False, want_samples=False).counts[:5] for s in seeds])
     assert np.array_equal(res.counts[:, :5].astype(np.uint64), want)
+    want_group = {"groups": 1, "groups64": 64, "groups5": 5}.get(per_wave, 0)
+    assert res.engine_stats.pregen_group == want_group
 
 
 # ------------------------------------------------------------------- seconds-long spikes (reference examples)
