@@ -29,7 +29,7 @@
 namespace afp {
 
 constexpr uint32_t kBatch = 8u;   // draws per lane and step
-constexpr uint32_t kRound = 4u;   // steps per round: variates and arrival times change hands a round's worth at a time
+constexpr uint32_t kRound = 8u;   // steps per round: variates and arrival times change hands a round's worth at a time
 constexpr uint32_t kChunk = kBatch * kRound;   // draws per lane and round
 
 // -log(1 - u) of draw `idx` of the generator's stream: the gap's numerator (poisson_poisson.py:69-70, u clamped at 1e-15)
@@ -229,9 +229,9 @@ __device__ __noinline__ double users_draw_call(uint32_t dist, double mean, doubl
 // was the cost); and the same with rows touched 256 contiguous bytes at a time and LDS doing the transposition: 8.3 ms, half
 // of the wave's instructions were then data movement.  Here the variates never exist in HBM: inside a window all running
 // lanes consume eight per step in lockstep, so while the chain wave sums round r (kRound steps) out of one LDS buffer the
-// producer waves fill the other with the variates of round r + 1 -- draw indices d0[s] + 32 (r + 1) .. + 31 of every scenario
+// producer waves fill the other with the variates of round r + 1 -- draw indices d0[s] + 64 (r + 1) .. + 63 of every scenario
 // s, d0 = where the scenario's window began -- and store the sums of round r - 1, which the chain wave left in LDS, to the
-// scenarios' rows (32 consecutive lanes per row: 256 contiguous bytes).  One barrier per round.  The once-a-window user draw
+// scenarios' rows (a wave per row: 512 contiguous bytes).  One barrier per round.  The once-a-window user draw
 // -- Poisson by chunked inversion, thousands of instructions -- is made by all lanes of the chain wave together: a lane that
 // crossed its window end (or found nobody active) waits until every lane of the wave has.
 //
@@ -251,31 +251,46 @@ struct GroupLds {
     uint32_t run[2];                   // [round parity] a lane still runs after the round
     uint32_t window[2];                // [window parity] 0: every scenario is done, 1: nobody runs in this window, 2: rounds follow
 };
+// (a wave's 64 variates of one pass belong to ONE scenario -- kChunk = 64 -- so seed and window start are scalars and the
+// Philox key schedule is scalar work beside the vector instructions)
+static_assert(kChunk == 64u, "group_produce / group_store: one wave, one scenario per pass");
 __device__ __forceinline__ void group_produce(GroupLds& M, uint32_t buf, uint32_t round, uint32_t n_here, uint32_t ptid) {
-    for (uint32_t t = ptid; t < n_here * kChunk; t += kProducers * 64u) {
-        const uint32_t s = t / kChunk, j = t % kChunk;
-        const uint32_t d0 = M.d0[s];
-        if (d0 != kIdle) M.in[buf][s][j] = unit_variate(M.seed[s], d0 + round * kChunk + j);
+    const uint32_t j = ptid & 63u;
+    for (uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ptid >> 6)); s < n_here; s += kProducers) {
+        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)M.d0[s]);
+        if (d0 == kIdle) continue;
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)M.seed[s]);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(M.seed[s] >> 32));
+        M.in[buf][s][j] = unit_variate(((uint64_t)hi << 32) | lo, d0 + round * kChunk + j);
     }
 }
 __device__ __forceinline__ void group_store(const GroupLds& M, uint32_t buf, double* rows, uint32_t stride, uint32_t n_here,
                                             uint32_t ptid) {
-    for (uint32_t t = ptid; t < n_here * kChunk; t += kProducers * 64u) {
-        const uint32_t s = t / kChunk, j = t % kChunk;
-        if (j < M.sums_n[buf][s]) rows[(size_t)s * stride + M.sums_k[buf][s] + j] = M.sums[buf][s][j];
+    const uint32_t j = ptid & 63u;
+    for (uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ptid >> 6)); s < n_here; s += kProducers) {
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)M.sums_n[buf][s]);
+        const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)M.sums_k[buf][s]);
+        if (j < n) rows[(size_t)s * stride + k + j] = M.sums[buf][s][j];
     }
 }
 template <bool FAST_DIV>
 __device__ __forceinline__ void group_chain_round(Lane& L, GroupLds& M, uint32_t buf, uint32_t lane, double T, uint32_t n_draw) {
     const uint32_t k0 = L.k;
+    // (the variates of step st + 1 are asked for before step st is summed: an LDS latency per step otherwise)
+    d2_t cur[kBatch / 2u], nxt[kBatch / 2u];
+#pragma unroll
+    for (uint32_t j = 0u; j < kBatch; j += 2u) cur[j / 2u] = *(const d2_t*)&M.in[buf][lane][j];
 #pragma unroll
     for (uint32_t st = 0u; st < kRound; ++st) {
+        if (st + 1u < kRound) {
+#pragma unroll
+            for (uint32_t j = 0u; j < kBatch; j += 2u) nxt[j / 2u] = *(const d2_t*)&M.in[buf][lane][(st + 1u) * kBatch + j];
+        }
         double e[kBatch], G[kBatch], S[kBatch];
 #pragma unroll
         for (uint32_t j = 0u; j < kBatch; j += 2u) {
-            const d2_t v = *(const d2_t*)&M.in[buf][lane][st * kBatch + j];
-            e[j] = v.x;
-            e[j + 1u] = v.y;
+            e[j] = cur[j / 2u].x;
+            e[j + 1u] = cur[j / 2u].y;
         }
         lane_sums<FAST_DIV>(L, e, G, S);
         if (L.state == LANE_RUN) {
@@ -286,6 +301,8 @@ __device__ __forceinline__ void group_chain_round(Lane& L, GroupLds& M, uint32_t
             if (lane_usual(L, G, T, n_draw)) lane_commit(L, G, S);
             else lane_slow(L, G, S, T, n_draw, nullptr, true);
         }
+#pragma unroll
+        for (uint32_t j = 0u; j < kBatch / 2u; ++j) cur[j] = nxt[j];
     }
     M.sums_k[buf][lane] = k0;
     M.sums_n[buf][lane] = L.k - k0;
@@ -317,6 +334,8 @@ __global__ void __launch_bounds__(kGroupThreads) af_arrival_groups(const Arrival
         rps_per_user = arrival_param(a, af::PARAM_GEN_RPM_MEAN, scen, a.rpm) / 60.0;
         if (valid) L.state = LANE_WAIT;
         M.seed[lane] = seed;
+        // (the chain wave is the critical path of the workgroup: it issues before the producers it shares its SIMD with)
+        __builtin_amdgcn_s_setprio(3);
     }
     for (uint32_t w = 0u;; ++w) {   // windows
         if (chain) {
