@@ -237,7 +237,10 @@ __device__ __noinline__ double users_draw_call(uint32_t dist, double mean, doubl
 //
 // 10 000 scenarios = 250 workgroups of 40 (one per CU): the producers' ~110 instructions per variate are spread over the
 // whole chip, the chain wave's round (~1 400 cycles) is what a round takes.
-constexpr uint32_t kProducers = 11u;
+#if !defined(AF_PREGEN_PRODUCERS)
+#define AF_PREGEN_PRODUCERS 11   /* measurement builds: -DAF_PREGEN_PRODUCERS=n (<= 15: a workgroup is at most 16 waves) */
+#endif
+constexpr uint32_t kProducers = AF_PREGEN_PRODUCERS;
 constexpr uint32_t kGroupThreads = 64u * (1u + kProducers);
 constexpr uint32_t kIdle = 0xFFFFFFFFu;
 typedef double d2_t __attribute__((ext_vector_type(2)));

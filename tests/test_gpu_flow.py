@@ -344,6 +344,33 @@ def test_arrival_pregeneration_group_widths_are_equivalent(monkeypatch, per_wave
     assert res.engine_stats.pregen_group == want_group
 
 
+@pytest.mark.parametrize("column", ["blocks", "alternating", "outliers"])
+def test_grouped_pregeneration_on_sweeps_over_the_load(column):
+    """A users column does not rule `af_arrival_groups` out: its time follows the HEAVIEST scenario of the launch whatever the
+    others are (a workgroup's chain wave walks its heaviest scenario's draws, the lighter lanes idle), the row kernel's the total
+    number of draws -- engine.hip, load_spread_suits_groups: grouped while heaviest <= 2.5 x mean (a grid written out
+    users-major like BASELINE configs 3 / 4; two loads dealt out alternately), rows when a few scenarios are far heavier than
+    the rest.  Either way the arrival times are the sequential sampler's: scenarios against the oracle run on the payload with
+    the value written into it."""
+    n = 3200
+    if column == "blocks":
+        users = np.repeat(np.linspace(60.0, 140.0, 32), 100)
+    elif column == "alternating":
+        users = np.where(np.arange(n) % 2 == 0, 40.0, 140.0)
+    else:
+        users = np.where(np.arange(n) % 400 == 7, 400.0, 20.0)
+    base = lb_two_servers(horizon=20)
+    seeds = 0x5EED0000 + np.arange(n, dtype=np.uint64)
+    res = _runner(base, seeds=seeds, sweep={"rqs_input.avg_active_users.mean": users}).run()
+    st = res.engine_stats
+    assert st.flow_scenarios == n and st.flow_to_next_event == 0
+    assert st.pregen_group == (0 if column == "outliers" else 13)   # the row kernel / ceil(3200 / 256) scenarios per workgroup
+    for i in (0, 7, 99, 100, 1337, 3199):
+        p = copy.deepcopy(base)
+        p["rqs_input"]["avg_active_users"]["mean"] = float(users[i])
+        _assert_scenario(res[i], ol.simulate(lower(p), int(seeds[i])), f"{column} scenario {i}")
+
+
 # ------------------------------------------------------------------- seconds-long spikes (reference examples)
 @pytest.mark.parametrize("heavy", [False, True])
 def test_reference_spike_examples_stay_on_the_flow_kernel(heavy):
