@@ -881,6 +881,8 @@ struct af_engine {
     uint32_t* d_n_shared = nullptr;
     uint32_t* d_map = nullptr;
     size_t map_cap = 0;
+    uint32_t* d_order = nullptr;   // launch order of the stage-parallel kernel for sweeps over the load (heaviest scenario first)
+    size_t order_cap = 0;
     bool shared_instants_likely = false;
     hipModule_t jit_module = nullptr;  // plan-specialised kernels (af_engine_set_kernels), valid for jit_spec only
     hipFunction_t jit_lean = nullptr, jit_order3 = nullptr, jit_order2 = nullptr;
@@ -1063,6 +1065,22 @@ static bool flow_wanted(const af_engine_t* e, uint32_t n_scenarios) {
 // workgroup -- one per CU, all resident --, so its time follows the HEAVIEST scenario of the chunk whatever the others are,
 // while the row kernel's follows the TOTAL number of draws at about twice the cost per draw.
 // Measured (MI355X): config 3 (users 10 .. 1000, heaviest / mean = 1.98): rows 14.8 ms, groups 11.3 ms; config 4: 103 -> 90 ms.
+// launch order of a chunk's scenarios for sweeps with a users / rpm column: heaviest first (stable)
+static std::vector<uint32_t> heaviest_first(const af_engine_t* e, const af_sweep_t* sweep, uint32_t lo, uint32_t nc) {
+    const double* users = nullptr;
+    const double* rpm = nullptr;
+    for (uint32_t k = 0; k < sweep->n_overrides; ++k) {
+        const af_override_t& o = sweep->overrides[k];
+        if (o.param == AF_PARAM_GEN_USERS_MEAN) users = o.values + lo;
+        else if (o.param == AF_PARAM_GEN_RPM_MEAN) rpm = o.values + lo;
+    }
+    std::vector<double> load(nc);
+    for (uint32_t i = 0; i < nc; ++i) load[i] = (users ? users[i] : e->users_mean) * (rpm ? rpm[i] : e->rpm_mean);
+    std::vector<uint32_t> order(nc);
+    for (uint32_t i = 0; i < nc; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return load[x] > load[y]; });
+    return order;
+}
 static bool load_spread_suits_groups(const af_engine_t* e, const af_sweep_t* sweep, uint32_t lo, uint32_t nc) {
     const double* users = nullptr;
     const double* rpm = nullptr;
@@ -1875,6 +1893,18 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
                              (force_groups || (!(mask & (1u << AF_PARAM_GEN_WINDOW)) && nc >= 3072u &&
                                                (double)n_draw * a.gen_window_s >= 512.0 * a.total_time &&
                                                (!hetero_load || load_spread_suits_groups(e, sweep, lo, nc))));
+        // Sweeps over the load: waves are dispatched in blockIdx order as slots free up, and a wave lasts as long as its scenario
+        // has events.  A users-major grid (BASELINE configs 3 / 4: users ascending with the index) is then the WORST order --
+        // the heaviest scenarios start last and the launch ends with a few long waves on an empty chip (list scheduling of
+        // 10 000 waves with times ~ users on 4 096 slots: 3.54 mean wave times ascending, 2.73 heaviest first, 2.44 ideal).  Wave j
+        // simulates scenario order[j]; everything the kernel reads or writes is indexed by the scenario.
+        const bool ordered = hetero_load && std::getenv("AF_FLOW_ORDER_OFF") == nullptr;
+        if (ordered) {
+            std::vector<uint32_t> order = heaviest_first(e, sweep, lo, nc);
+            if (int rc = grow((void**)&e->d_order, e->order_cap, (size_t)nc * 4u)) return rc;
+            HIP_TRY(hipMemcpyAsync(e->d_order, order.data(), (size_t)nc * 4u, hipMemcpyHostToDevice, e->stream));
+            HIP_TRY(hipStreamSynchronize(e->stream));   // (`order` leaves scope; 40 KB, before anything of this chunk is enqueued)
+        }
         HIP_TRY(hipEventRecord(e->ev2, e->stream));
         if (launch_pregen_arrivals(a, nc, n_draw, !hetero_load, e->stream, grouped, &pregen_group)) return fail(AF_ERR_HIP, "af_arrival_groups: LDS attribute");
         HIP_TRY(hipGetLastError());
@@ -1891,6 +1921,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
         f.arrivals = e->d_arr;
         f.n_draw = n_draw;
         f.pre_flags = e->d_arr_flags;
+        if (ordered) f.scen_map = e->d_order;
         f.clock = a.clock;
         f.clock_cap = a.clock_cap;
         f.samples = a.samples;
@@ -2250,6 +2281,7 @@ void af_engine_destroy(af_engine_t* e) {
     if (e->d_tie) (void)hipFree(e->d_tie);
     if (e->d_n_shared) (void)hipFree(e->d_n_shared);
     if (e->d_map) (void)hipFree(e->d_map);
+    if (e->d_order) (void)hipFree(e->d_order);
     if (e->d_tick) (void)hipFree(e->d_tick);
     if (e->d_arr) (void)hipFree(e->d_arr);
     if (e->d_arr_flags) (void)hipFree(e->d_arr_flags);
