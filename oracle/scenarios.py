@@ -340,6 +340,105 @@ def server_chain(dist: str = "poisson", mean: float = 0.7, cores: int = 2, horiz
     }
 
 
+def shared_backend(users: float = 200, horizon: int = 120) -> dict:
+    """client -> LB -> {a1, a2} -> b (a backend both front servers call) -> client: the deterministic server-tier payload of
+    the round-3 measurements (scripts/gpu_r3_chain.py)."""
+    ep_a = [_endpoint("/a", [("initial_parsing", 0.002), ("ram", 64), ("io_wait", 0.006)])]
+    ep_b = [_endpoint("/b", [("io_db", 0.003), ("ram", 32), ("cpu_bound_operation", 0.0015), ("io_wait", 0.002)])]
+    servers = [_server("a1", 1, 1024, ep_a), _server("a2", 2, 1024, ep_a), _server("b", 2, 2048, ep_b)]
+    edges = [_edge("g-c", "gen", "cli", 0.003), _edge("c-lb", "cli", "lb", 0.002), _edge("lb-a1", "lb", "a1", 0.003),
+             _edge("lb-a2", "lb", "a2", 0.003), _edge("a1-b", "a1", "b", 0.002), _edge("a2-b", "a2", "b", 0.004), _edge("b-c", "b", "cli", 0.003)]
+    return {
+        "rqs_input": {"id": "gen", "avg_active_users": {"mean": users}, "avg_request_per_minute_per_user": {"mean": 30}, "user_sampling_window": 60},
+        "topology_graph": {"nodes": {"client": {"id": "cli"}, "servers": servers,
+                                     "load_balancer": {"id": "lb", "algorithms": "round_robin", "server_covered": ["a1", "a2"]}}, "edges": edges},
+        "sim_settings": {"total_simulation_time": horizon, "sample_period_s": 0.05},
+    }
+
+
+def server_tiers(rng: random.Random, horizon: int = 15) -> dict:
+    """Feed-forward topologies in which servers feed servers (round 3: FEAT_CHAIN of the stage-parallel kernel):
+    client -> [LB ->] front servers -> [middle ->] backend -> client, up to three levels, a front server may also
+    answer the client directly and the LB may also feed the backend; continuous latencies (exponential / normal /
+    uniform / log-normal), tandem endpoints (IO* CPU* IO*), optional RAM pressure, spikes on any edge and outages of
+    front servers.  TEST-ONLY payload generator."""
+    cpu = ["initial_parsing", "cpu_bound_operation"]
+    io = ["io_wait", "io_db", "io_cache"]
+
+    def endpoint(name: str) -> dict:
+        steps: list[tuple[str, float]] = [(rng.choice(io), rng.choice([0.001, 0.002, 0.004])) for _ in range(rng.randint(0, 2))]
+        if rng.random() < 0.7:
+            steps.append(("ram", rng.choice([32, 64, 100.25, 128])))
+        steps += [(rng.choice(cpu), rng.choice([0.0005, 0.001, 0.002, 0.003])) for _ in range(rng.randint(1, 2))]
+        steps += [(rng.choice(io), rng.choice([0.001, 0.003, 0.006])) for _ in range(rng.randint(0, 2))]
+        return _endpoint(name, steps)
+
+    def edge(eid: str, src: str, tgt: str) -> dict:
+        dist = rng.choice(["exponential"] * 4 + ["normal", "normal", "uniform", "log_normal"])
+        mean = rng.choice([0.001, 0.003, 0.008])
+        if dist == "uniform":
+            mean = rng.choice([0.002, 0.01])
+        elif dist == "log_normal":
+            mean = 0.001                       # (the schema wants a positive mean: a hop of about a second)
+        var = {"normal": mean / 4.0, "log_normal": 0.3}.get(dist)
+        return _edge(eid, src, tgt, mean, dist, var, rng.choice([None, None, 0.01]))
+
+    n_front = rng.randint(1, 3)
+    use_lb = n_front > 1 or rng.random() < 0.4
+    depth = rng.randint(2, 3)
+    tight = rng.random() < 0.3
+    servers, edges = [], [edge("g-c", "gen", "cli")]
+    front = [f"f{i}" for i in range(n_front)]
+    for sid in front:
+        servers.append(_server(sid, rng.randint(1, 3), 256 if tight else 2048, [endpoint("/front")]))
+    servers.append(_server("back", rng.randint(1, 4), 512 if tight else 4096, [endpoint("/back")]))
+    middle = None
+    if depth == 3:
+        middle = "mid"
+        servers.append(_server(middle, rng.randint(1, 2), 2048, [endpoint("/mid")]))
+    rng.shuffle(servers)                       # (server indices in any order: levels do not follow the numbering)
+    covered = list(front)
+    if use_lb:
+        edges.append(edge("c-lb", "cli", "lb"))
+        if rng.random() < 0.3:
+            covered.append("back")             # the LB also feeds the backend directly
+        for sid in covered:
+            edges.append(edge(f"lb-{sid}", "lb", sid))
+    else:
+        edges.append(edge("c-f0", "cli", "f0"))
+    for i, sid in enumerate(front):
+        if i > 0 and rng.random() < 0.25:
+            edges.append(edge(f"{sid}-c", sid, "cli"))          # this front server answers the client itself
+        else:
+            edges.append(edge(f"{sid}-n", sid, middle or "back"))
+    if middle:
+        edges.append(edge("mid-back", middle, "back"))
+    edges.append(edge("back-c", "back", "cli"))
+    nodes: dict[str, Any] = {"client": {"id": "cli"}, "servers": servers}
+    if use_lb:
+        nodes["load_balancer"] = {"id": "lb", "algorithms": "round_robin", "server_covered": covered}
+    p: dict[str, Any] = {
+        "rqs_input": {"id": "gen", "avg_active_users": {"mean": rng.choice([20, 60, 150])},
+                      "avg_request_per_minute_per_user": {"mean": rng.choice([30, 60])}, "user_sampling_window": rng.choice([3, 10])},
+        "topology_graph": {"nodes": nodes, "edges": edges},
+        "sim_settings": {"total_simulation_time": horizon, "sample_period_s": rng.choice([0.05, 0.0625, 0.1])},
+    }
+    events = []
+    if rng.random() < 0.5:
+        tgt = rng.choice(edges)["id"]
+        t0 = rng.uniform(0.1, 0.5) * horizon
+        events.append({"event_id": "spike", "target_id": tgt,
+                       "start": {"kind": "network_spike_start", "t_start": t0, "spike_s": rng.choice([0.004, 0.02])},
+                       "end": {"kind": "network_spike_end", "t_end": t0 + rng.uniform(0.1, 0.3) * horizon}})
+    if use_lb and n_front > 1 and rng.random() < 0.4:
+        t0 = rng.uniform(0.2, 0.6) * horizon
+        events.append({"event_id": "down", "target_id": rng.choice(front),
+                       "start": {"kind": "server_down", "t_start": t0}, "end": {"kind": "server_up", "t_end": t0 + 0.2 * horizon}})
+    if events:
+        p["events"] = events
+    return p
+
+
 def tie_storm(rng: random.Random, horizon: int = 12) -> dict:
     """Payloads built to make timed events COLLIDE: dyadic step times on multi-core servers with a
     tight RAM budget, Poisson (integer, often zero) edge latencies, sampler period and event marks on

@@ -33,7 +33,7 @@ def short(k: str) -> str:
 
 def sources_sha1() -> str:
     h = hashlib.sha1()
-    for name in ("engine.hip", "af_flow.hpp", "af_flow_host.hpp", "af_core.hpp", "af_math.hpp", "af_plan_pack.hpp", "af_summary.hpp"):
+    for name in ("engine.hip", "af_flow.hpp", "af_flow_host.hpp", "af_core.hpp", "af_math.hpp", "af_plan_pack.hpp", "af_summary.hpp", "af_pregen.hpp"):
         h.update((ROOT / "asyncflow_amd" / "csrc" / name).read_bytes())
     return h.hexdigest()
 
