@@ -227,21 +227,15 @@ enum : uint32_t { PROF_SETUP, PROF_GEN, PROF_SELECT, PROF_SERIES_RECV, PROF_STAT
 //                  step ends, FIFO of core waiters, FIFO of RAM waiters: Flow::gen_servers) up to the horizon of the station --
 //                  every arrival before it is known --, servers side by side in the lanes, and the departures it produced are
 //                  then sent by the whole wave like any other batch.  Two events of one server at one instant are handed back.
-//   FEAT_CHAIN     servers that feed servers (round 3): the servers are put in LEVELS (0: fed by the client / the LB; k: fed by a
-//                  server of level k - 1 at the latest) and the server station runs once per level and round, in level order, each
-//                  with its own horizon over the ONE server list: everything a server of level k receives before the horizon of
-//                  level k - 1 is in the list, because a request leaves a server no earlier than it arrived.  Not together with a
-//                  least-connections LB or general servers.
 //   FEAT_PROF      measurement builds only: the wave's shader-clock time per section of run() (FlowArgs::prof)
 enum : uint32_t { FEAT_MARKS = 1u, FEAT_ONLINE = 2u, FEAT_HBM_RING = 4u, FEAT_FAR = 64u, FEAT_ALL = 7u | FEAT_FAR, FEAT_TIEBREAK = 8u,
-                  FEAT_BIGLIST = 16u, FEAT_LC = 32u, FEAT_PROF = 128u, FEAT_GENSRV = 256u, FEAT_CHAIN = 512u };
+                  FEAT_BIGLIST = 16u, FEAT_LC = 32u, FEAT_PROF = 128u, FEAT_GENSRV = 256u };
 template <class W, uint32_t IPL = 1u, uint32_t FEAT = FEAT_ALL>
 struct Flow {
     static constexpr bool kMarks = (FEAT & FEAT_MARKS) != 0u, kOnline = (FEAT & FEAT_ONLINE) != 0u,
                           kHbmRing = (FEAT & FEAT_HBM_RING) != 0u, kTieBreak = (FEAT & FEAT_TIEBREAK) != 0u,
                           kBig = (FEAT & FEAT_BIGLIST) != 0u, kLC = (FEAT & FEAT_LC) != 0u, kFar = (FEAT & FEAT_FAR) != 0u,
-                          kProf = (FEAT & FEAT_PROF) != 0u, kGen = (FEAT & FEAT_GENSRV) != 0u, kChain = (FEAT & FEAT_CHAIN) != 0u;
-    static_assert(!(kChain && (kGen || kLC)), "server levels: round-robin LB, tandem servers");
+                          kProf = (FEAT & FEAT_PROF) != 0u, kGen = (FEAT & FEAT_GENSRV) != 0u;
     // FEAT_PROF: the time since the previous mark belongs to `section` (marks sit at the END of a section, in
     // wave-uniform control flow, with a compile-time section: the accumulators stay in scalar registers)
     unsigned long long prof_t, prof_acc[kProfSections];
@@ -270,27 +264,11 @@ struct Flow {
     AF_CORE void n_list_set(uint32_t s, uint32_t v) {
         if (s == 0u) nl0 = v; else if (s == 1u) nl1 = v; else if (s == 2u) nl2 = v; else nl3 = v;
     }
-    AF_CORE double H_get(uint32_t s) const {
-        if (kChain && s == 2u && sel_level != 0u) {
-            if (sel_level == 1u) return h2b;
-            return h2c;
-        }
-        return s == 0u ? h0 : s == 1u ? h1 : s == 2u ? h2 : h3;
-    }
+    AF_CORE double H_get(uint32_t s) const { return s == 0u ? h0 : s == 1u ? h1 : s == 2u ? h2 : h3; }
     AF_CORE void H_set(uint32_t s, double v) {
         if (kMarks) moved = moved || v > H_get(s);   // (without lookahead the last horizon is the slowest: run() watches h3)
-        if (kChain && s == 2u && sel_level != 0u) {
-            if (sel_level == 1u) h2b = v; else h2c = v;
-            return;
-        }
         if (s == 0u) h0 = v; else if (s == 1u) h1 = v; else if (s == 2u) h2 = v; else h3 = v;
     }
-    // FEAT_CHAIN: horizons of the server list for the levels behind the first (h2 is level 0's), the level select() works on,
-    // the number of levels (wave-uniform); a server's level sits in bits 24..31 of its lbw()[LBW_PROG] word
-    static constexpr uint32_t kMaxLevels = 3u;
-    double h2b, h2c;
-    uint32_t sel_level, n_levels;
-    AF_CORE uint32_t level_of(uint32_t sv) const { return lbw()[LBW_PROG + sv] >> 24; }
     uint32_t n_comp, tick_base;
     double t_lim;                // FEAT_FAR: no station handles an event at or after this time in the current round (the tick ring's window)
     bool gen_done, moved;        // moved: a horizon advanced in this round
@@ -674,7 +652,7 @@ struct Flow {
                 t[q] = T0[i];
                 if (kTieBreak) sent[q] = TS[i];
                 a[q] = (s == 2u || (kFar && s == 3u)) ? AX[i] : 0u;
-                elig[q] = valid[q] && k[q] < hi && (!(kChain && s == 2u) || level_of(a[q] & (kSrvSlots - 1u)) == sel_level);
+                elig[q] = valid[q] && k[q] < hi;
                 double x = (k[q] - lo) * sc;
                 x = x < 63.0 ? x : 63.0;        // (also what a NaN from a stale entry becomes)
                 b[q] = x > 0.0 ? (uint32_t)x : 0u;
@@ -790,7 +768,7 @@ struct Flow {
             if (i < n) {
                 const double k = K[i];
                 uint32_t w = kNone;
-                if (k < hi && (!(kChain && s == 2u) || level_of(AX[i] & (kSrvSlots - 1u)) == sel_level)) {
+                if (k < hi) {
                     double x = (k - lo) * sc;
                     x = x < 63.0 ? x : 63.0;
                     const uint32_t b = x > 0.0 ? (uint32_t)x : 0u;
@@ -1536,18 +1514,6 @@ struct Flow {
                     g[GS_IO] = 0xFFFFFFFF00000000ull;                                  // every slot free
                     g[GS_RAM] = blob[A.off_srv + af::SREC * v];
                 }
-            if (kChain) {   // levels: a server fed by a server of level k is of level k + 1 at least (the host checked: a DAG, <= kMaxLevels)
-                uint32_t deepest = 0u;
-                for (uint32_t pass = 0u; pass + 1u < kMaxLevels; ++pass)
-                    for (uint32_t v = 0u; v < A.n_servers; ++v) {
-                        const uint64_t tw = erec((uint32_t)(blob[A.off_srv + af::SREC * v + 1u] >> 16) & 0xFFFFu)[3];
-                        if (((uint32_t)tw & 0xFFu) != af::NODE_SERVER) continue;
-                        const uint32_t w = (uint32_t)(tw >> 8) & 0xFFu, want = (lw[LBW_PROG + v] >> 24) + 1u;
-                        if ((lw[LBW_PROG + w] >> 24) < want) lw[LBW_PROG + w] = (lw[LBW_PROG + w] & 0xFFFFFFu) | (want << 24);
-                        deepest = want > deepest ? want : deepest;
-                    }
-                lw[20] = deepest + 1u;
-            }
             for (uint32_t i = 0u; i < A.n_lb_edges; ++i) lw[i] = (uint32_t)blob[A.off_lb + i];
             lw[16] = 0u;
             lw[17] = A.n_lb_edges;
@@ -1568,22 +1534,13 @@ struct Flow {
         gen_done = false;
         nl0 = nl1 = nl2 = nl3 = 0u;
         h0 = h1 = h2 = h3 = 0.0;
-        h2b = h2c = 0.0;
-        sel_level = 0u;
-        n_levels = kChain ? lbw()[20] : 1u;
         const uint32_t cap = kCt ? kCap : A.L.cap;
         const uint32_t first_srv_stage = A.has_lb ? 1u : 2u;   // where the client's out-edge leads
 
         // Every round walks the five stations in order.  The code of select() and of edge_send() exists ONCE
         // (the loop is not unrolled): the kernel stays small enough for the instruction cache.
         prof(PROF_SETUP);
-#if defined(AF_FLOW_ROUNDS_DIAG)
-        uint32_t n_rounds = 0u;   // measurement builds: rounds of this scenario, reported in counts[CNT_MAX_LIVE]
-#endif
         for (;;) {
-#if defined(AF_FLOW_ROUNDS_DIAG)
-            n_rounds += 1u;
-#endif
             uint32_t work = 0u;
             moved = false;
             // With an LDS tick ring the generator does not run further ahead of the completed ticks than the ring's window;
@@ -1601,13 +1558,7 @@ struct Flow {
 #else
 #pragma nounroll
 #endif
-            for (uint32_t stx = 0u; stx < (kChain ? 4u + kMaxLevels : 5u); ++stx) {
-                // (FEAT_CHAIN: the server station once per level, in level order; H_in runs through them like through any station)
-                const uint32_t st = !kChain ? stx : stx < 3u ? stx : stx < 3u + kMaxLevels ? 3u : 4u;
-                if (kChain) {
-                    sel_level = st == 3u ? stx - 3u : n_levels - 1u;   // (station 4 reads the horizon of the last level)
-                    if (st == 3u && sel_level >= n_levels) continue;
-                }
+            for (uint32_t st = 0u; st < 5u; ++st) {
                 if (st == 2u && !A.has_lb) continue;
                 // ---- the station's batch: lane r < n_sel holds (key = event time, t0 = start time, aux)
                 double key = 0.0, t0 = 0.0;
@@ -1625,7 +1576,6 @@ struct Flow {
                     n_sel = popc64(vm);
                     key = t0;
                 } else {
-                    // (FEAT_CHAIN: what a level sends back into the server list takes the places its own selection left there)
                     n_sel = select(st - 1u, H_in, st == 4u ? 64u : (kBig ? cap_of(nxt) : cap) - n_list_get(nxt), key, t0, aux);
                 }
                 if (st == 0u) prof(PROF_GEN);
@@ -1633,4 +1583,221 @@ struct Flow {
                 const bool have = lane < n_sel;
                 if (have) ev += 1u;                       // one timed event per message: arrival / delivery
                 work += n_sel;
-                // -
+                // ---- sampled series: the delivery ends the message's stay on the edge it came by (edge.py:115), if the
+                // sender entered it (sign of t0); `row` = tick row of the station's event, which the send below starts at
+                const bool series_on = samples != nullptr;
+                const bool cnt_in = kFar && series_on && have && st > 0u && __builtin_signbit(t0);
+                if (kFar && st > 0u) t0 = __builtin_fabs(t0);
+                uint32_t row = 0u;
+                if (kFar && series_on && have && (st <= 2u || cnt_in)) row = tick_index(key, true);
+                if (kFar && cnt_in) add_point(st == 1u ? A.gen_out_edge : st == 2u ? A.client_out_edge : st == 3u ? aux >> 8 : aux, row, -1);
+                // ---- what the station does with it: the out-edge, the message's index on it, the send time
+                prof(PROF_SERIES_RECV);
+                bool sending = have, pre = false;
+                uint32_t e = 0u, idx = 0u, tgt = 0u;
+                double ts = key, pre_tr = 0.0;
+                if (st == 0u) {
+                    e = A.gen_out_edge;
+                    idx = cursor + lane;
+                    cursor += n_sel;
+                    H_in = cursor < A.n_draw ? arr[cursor] : AF_INF;   // next arrival not yet generated
+                    gen_done = !(H_in < T);
+                    h_gen = H_in;
+                } else if (st == 1u) {   // client, first visit (client.py:46-60): forward on the client's out-edge
+                    e = A.client_out_edge;
+                    idx = sends()[e] + lane;
+                    W::sync();
+                    if (lane == 0u) sends()[e] += n_sel;
+                    tgt = (uint32_t)(erec(e)[3] >> 8) & 0xFFu;
+                } else if (st == 2u) {   // load balancer
+                    if (n_sel > 0u) {
+                        if (kLC && A.lb_least_connections) {
+                            e = lb_pick_lc(n_sel, key, pre_tr);
+                            pre = true;
+                        } else {
+                            e = lb_pick(n_sel, key);
+                        }
+                        idx = claim_send_index(have, e, false);
+                        tgt = (uint32_t)(erec(e)[3] >> 8) & 0xFFu;
+                    }
+                } else if (kGen && st == 3u) {   // servers, general form: lane k runs server k up to the station's horizon
+                    const uint32_t sv = aux & 0xFFu;
+                    uint32_t pos = 0u, off = 0u;
+                    for (uint32_t k = 0u; k < A.n_servers; ++k) {
+                        const uint64_t m = W::ballot(have && sv == k);
+                        if (have && sv == k) pos = off + W::mbcnt(m);
+                        if (lane == k) {
+                            lbw()[LBW_SEG_OFF + k] = off;
+                            lbw()[LBW_SEG_LEN + k] = popc64(m);
+                        }
+                        off += popc64(m);
+                    }
+                    W::sync();   // select()'s scratch is dead: the arrivals of the round, per server, in time order
+                    if (have) {
+                        seg(0)[pos] = key;
+                        seg(1)[pos] = t0;
+                    }
+                    W::sync();
+                    uint32_t done = 0u;
+                    if (lane < A.n_servers) done = gen_servers(lane, H_get(2u));
+                    W::sync();
+                    work += popc64(W::ballot(done != 0u));
+                    prof(PROF_SERVERS);
+                    // the departures the servers produced (each server's in time order), sent by the whole wave, 64 at a time
+                    uint32_t total = 0u;
+                    for (uint32_t k = 0u; k < A.n_servers; ++k) total += lo32(gs(k)[GS_DEP]);
+                    const bool too_many = total > cap_of(3u) - nl3;   // (wave-uniform)
+                    if (too_many) why |= FLOW_WHY_LIST;
+                    for (uint32_t base = 0u; base < total && !too_many; base += 64u) {
+                        const uint32_t want = base + lane;   // my departure, counted over the servers in order
+                        bool mine = false;
+                        uint32_t me = 0u, mj = 0u, first = 0u;
+                        for (uint32_t k = 0u; k < A.n_servers; ++k) {
+                            const uint32_t cnt = lo32(gs(k)[GS_DEP]);
+                            if (want >= first && want < first + cnt) {
+                                mine = true;
+                                me = k;
+                                mj = want - first;
+                            }
+                            first += cnt;
+                        }
+                        const uint32_t oe = (uint32_t)(blob[A.off_srv + af::SREC * me + 1u] >> 16) & 0xFFFFu;
+                        const double dts = mine ? u2d(gs(me)[GS_DEPT + mj]) : 0.0, dt0 = mine ? u2d(gs(me)[GS_DEPT0 + mj]) : 0.0;
+                        const uint32_t didx = sends()[oe] + mj;
+                        double k2 = 0.0, transit = 0.0;
+                        bool counted = false;
+                        const bool sent = mine && send_draw(oe, didx, transit);
+                        prof(PROF_DRAW);
+                        const uint32_t drow = (kFar && sent && samples != nullptr) ? tick_index(dts, true) : 0u;
+                        const bool ok = sent && send_finish(oe, dts, drow, kFar, transit, k2, counted);
+                        prof(PROF_SEND_SERIES);
+                        append(3u, ok, k2, (kFar && counted) ? -dt0 : dt0, oe, dts);
+                    }
+                    W::sync();
+                    if (lane < A.n_servers) sends()[(uint32_t)(blob[A.off_srv + af::SREC * lane + 1u] >> 16) & 0xFFFFu] += lo32(gs(lane)[GS_DEP]);
+                    W::sync();
+                    sending = false;   // (everything this station sends went out above)
+                } else if (st == 3u) {   // servers
+                    if (n_sel > 0u) {
+                        const uint32_t sv = aux & 0xFFu;
+                        uint32_t pos = 0u, off = 0u;   // per-server segments of the time-ordered arrivals
+                        for (uint32_t k = 0u; k < A.n_servers; ++k) {
+                            const uint64_t m = W::ballot(have && sv == k);
+                            if (have && sv == k) pos = off + W::mbcnt(m);
+                            if (lane == k) {
+                                lbw()[LBW_SEG_OFF + k] = off;
+                                lbw()[LBW_SEG_LEN + k] = popc64(m);
+                            }
+                            off += popc64(m);
+                        }
+                        W::sync();   // select()'s scratch is dead from here on: the segments reuse it
+                        const SrvTimes r = servers_solve(have, sv, pos, key);
+                        prof(PROF_SERVERS);
+                        if (have) {
+                            const uint64_t meta = blob[A.off_srv + af::SREC * sv + 1u];
+                            e = (uint32_t)(meta >> 16) & 0xFFFFu;
+                            const uint32_t ep = (uint32_t)(meta >> 32) & 0xFFFFu;
+                            const double ram = u2d(blob[A.off_ep + af::PREC * ep]);
+                            const uint32_t s0 = A.n_edges + 3u * sv;
+                            ts = r.g;
+                            // ready queue: waited for a core (server.py:215-225); leading / trailing I/O steps; RAM held from
+                            // admission to the end (server.py:146-149, 270-273)
+                            // (round 3: also in the instantiations without FEAT_FAR, which used to call add_interval per
+                            // interval -- 12 tick rows per request instead of 10: 49.7 -> 48.5 ms on BASELINE config 2)
+                            if (series_on) {   // (one tick row per distinct time: the send below starts at G's)
+                                const bool q_ready = r.s > r.b, q_pre = r.b > r.adm, q_post = r.g > r.f, q_ram = ram > 0.0;
+                                uint32_t t_adm = 0u, t_b = 0u, t_s = 0u, t_f = 0u, t_g = 0u;
+                                if (q_pre || q_ram) t_adm = tick_index(r.adm, true);
+                                if (q_ready || q_pre) t_b = tick_index(r.b, true);
+                                if (q_ready) t_s = tick_index(r.s, true);
+                                if (q_post) t_f = tick_index(r.f, true);
+                                if (q_post || q_ram || ts < T) t_g = tick_index(r.g, true);
+                                add_span(s0, t_b, t_s, 1, q_ready);
+                                add_span(s0 + 1u, t_adm, t_b, 1, q_pre);
+                                add_span(s0 + 1u, t_f, t_g, 1, q_post);
+                                add_span(s0 + 2u, t_adm, t_g, (int32_t)(ram * A.ram_scale), q_ram);
+                                row = t_g;
+                            }
+                        }
+                        sending = have && ts < T;      // transport() on the server's out-edge at G (server.py:276), if the horizon allows
+                        prof(PROF_SERVER_SERIES);
+                        idx = claim_send_index(sending, e, true);
+                    }
+                } else {   // client, second visit (client.py:62-69): the request is complete
+                    complete(have, lane, t0, key);
+                    n_comp += n_sel;
+                    sending = false;
+                }
+                if (st == 3u) prof(PROF_SERVERS);
+                else if (st == 4u) prof(PROF_COMPLETE);
+                else prof(PROF_STATION);
+                if (kGen && st == 3u) {
+                    H_in = send_floor(3u, H_get(2u));
+                    prof(PROF_APPEND);
+                } else if (st < 4u) {
+                    double k2 = 0.0;
+                    bool counted = false;
+                    double transit = 0.0;
+                    const bool sent = sending && send_draw(e, idx, transit, kLC && pre, pre_tr);
+                    prof(PROF_DRAW);
+                    const bool ok = sent && send_finish(e, ts, row, st == 3u, transit, k2, counted);
+                    prof(PROF_SEND_SERIES);
+                    // (server list: the server and the edge the message comes by; completion list: the server's out-edge)
+                    append(nxt, ok, k2, (kFar && counted) ? -t0 : t0, !kFar ? tgt : st == 3u ? e : tgt | (e << 8), ts);
+                    if (st > 0u) H_in = H_get(st - 1u);
+                    H_in = send_floor(st, H_in);   // what the next station may touch: everything delivered before this
+                    prof(PROF_APPEND);
+                }
+            }
+            // ---- ticks that can no longer change
+            // (a station behind a spiked edge runs AHEAD of the one that feeds it: the slowest horizon bounds what is final)
+            double h_min = h3;
+            if (kMarks && A.n_edge_marks != 0u) {
+                h_min = h_min < h_gen ? h_min : h_gen;
+                h_min = h_min < h0 ? h_min : h0;
+                h_min = (A.has_lb && h1 < h_min) ? h1 : h_min;
+                h_min = h_min < h2 ? h_min : h2;
+            }
+            const bool finished = gen_done && work == 0u && !(h_min < T);
+            W::sync();
+            flush_ticks(finished ? A.n_ticks : tick_index(h_min, false));
+            W::sync();
+            prof(PROF_FLUSH);
+#if defined(AF_FLOW_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
+            if (lane == 0u) std::fprintf(stderr, "round: work %u cursor %u nl %u %u %u %u h %.6f %.6f %.6f %.6f hgen %.6f hmin %.6f moved %d tick_base %u n_comp %u why %x\n", work, cursor, nl0, nl1, nl2, nl3, h0, h1, h2, h3, h_gen, h_min, (int)moved, tick_base, n_comp, why);
+#endif
+            const bool stuck = work == 0u && !finished && !(kMarks ? moved : h3 > h_done_before);
+            if (stuck) why |= FLOW_WHY_LIST;   // nothing moved, no horizon advanced: a list is full of later messages
+            if (finished || W::any(why != 0u)) break;
+        }
+
+        // ---- counts
+        const uint32_t ev_all = wave_sum(ev), drop_all = wave_sum(drops), why_all = wave_or(why), info_all = wave_or(info);
+        if (lane == 0u) {
+            uint32_t flags = A.pre_flags[sc] | info_all;
+            if (n_comp > A.clock_cap && clock != nullptr) flags |= af::FLAG_CLOCK_OVERFLOW;
+            if (A.n_ticks > A.tick_cap && samples != nullptr) flags |= af::FLAG_TICK_OVERFLOW;
+            if (why_all != 0u) flags |= FLAG_FLOW_FALLBACK | why_all;
+            uint32_t marks = 0u;
+            for (uint32_t i = 0u; i < A.n_edge_marks; ++i) marks += u2d(emark(i)[0]) < T ? 1u : 0u;
+            for (uint32_t i = 0u; i < A.n_srv_marks; ++i) marks += u2d(smark(i)[0]) < T ? 1u : 0u;
+            uint32_t* c = A.counts + (size_t)sc * af::CNT_SLOTS;
+            c[af::CNT_GENERATED] = cursor;
+            c[af::CNT_COMPLETED] = n_comp;
+            c[af::CNT_DROPPED] = drop_all;
+            c[af::CNT_EVENTS] = ev_all;
+            c[af::CNT_TICKS] = A.n_ticks;
+            c[af::CNT_FLAGS] = flags;
+            c[af::CNT_MAX_LIVE] = 0u;   // a diagnostic of the sequential kernels (peak of live requests)
+            c[af::CNT_MARKS] = marks;
+        }
+        if (kProf) {
+            prof(PROF_SETUP);
+            if (lane == 0u && A.prof != nullptr)
+#pragma unroll
+                for (uint32_t k = 0u; k < kProfSections; ++k) A.prof[(size_t)sc * kProfSections + k] = prof_acc[k];
+        }
+    }
+};
+
+}  // namespace aff

@@ -899,7 +899,7 @@ struct af_engine {
     // stage-parallel kernel (af_flow.hpp)
     void* d_codes = nullptr;   // analyzer scratch (af_engine_summarize)
     size_t codes_bytes = 0;
-    bool flow_ok = false, flow_general_servers = false, flow_chain = false;   // flow_chain: servers feed servers (FEAT_CHAIN)
+    bool flow_ok = false, flow_general_servers = false;
     std::string flow_reason;
     uint32_t flow_mode = 0, flow_list_entries = 0, flow_ring_rows = 0;
     aff::FlowArgs fargs{};
@@ -1315,15 +1315,10 @@ int plan_flow(const af_engine* e, const KArgs& a, const af_sweep_t* sweep, const
     // injected spikes / outages, but neither the kernel-side summary nor tick differences in HBM (BASELINE config 4)
     const bool marks_only = !lean && !has_online && ring_ok;
     constexpr uint32_t kRobust = aff::FEAT_ALL | aff::FEAT_TIEBREAK | aff::FEAT_BIGLIST;
-    const bool chain = e->flow_chain;   // (never with lc / gen_srv: flow_ineligible_reason)
-    P.lean = lean && !flow_big && !lc && !chain;
+    P.lean = lean && !flow_big && !lc;
     if (flow_big) {
         P.ipl = 1u;
-        P.feat = kRobust | (lc ? (uint32_t)aff::FEAT_LC : 0u) | (gen_srv ? (uint32_t)aff::FEAT_GENSRV : 0u) | (chain ? (uint32_t)aff::FEAT_CHAIN : 0u);
-    } else if (chain) {   // (the leanest form like below; FEAT_FAR always: the instantiations without it are FEAT == 0)
-        P.ipl = FL.cap == 64u ? 1u : FL.cap == 128u ? 2u : 4u;
-        P.feat = (P.ipl == 4u ? (uint32_t)aff::FEAT_ALL : lean ? (uint32_t)aff::FEAT_FAR : marks_only ? (uint32_t)(aff::FEAT_MARKS | aff::FEAT_FAR) : (uint32_t)aff::FEAT_ALL) |
-                 aff::FEAT_CHAIN;
+        P.feat = kRobust | (lc ? (uint32_t)aff::FEAT_LC : 0u) | (gen_srv ? (uint32_t)aff::FEAT_GENSRV : 0u);
     } else if (lc) {
         P.ipl = FL.cap == 64u ? 1u : FL.cap == 128u ? 2u : 4u;
         P.feat = aff::FEAT_ALL | aff::FEAT_LC;
@@ -1334,7 +1329,6 @@ int plan_flow(const af_engine* e, const KArgs& a, const af_sweep_t* sweep, const
         P.ipl = 4u;
         P.feat = aff::FEAT_ALL;
     }
-    if (std::getenv("AF_FLOW_FORCE_ALL") && !flow_big && !lc) P.feat |= aff::FEAT_ALL;   // measurement hook: what the optional features cost
     return AF_OK;
 }
 
@@ -1347,14 +1341,6 @@ const void* flow_kernel_for(uint32_t ipl, uint32_t feat) {
     AF_FLOW_CASE(1u, kRobust);
     AF_FLOW_CASE(1u, kRobust | kLC | (uint32_t)aff::FEAT_GENSRV);
     AF_FLOW_CASE(1u, kRobust | (uint32_t)aff::FEAT_GENSRV);
-    AF_FLOW_CASE(1u, kRobust | (uint32_t)aff::FEAT_CHAIN);
-    AF_FLOW_CASE(1u, kAll | (uint32_t)aff::FEAT_CHAIN);
-    AF_FLOW_CASE(2u, kAll | (uint32_t)aff::FEAT_CHAIN);
-    AF_FLOW_CASE(1u, kFar | (uint32_t)aff::FEAT_CHAIN);
-    AF_FLOW_CASE(2u, kFar | (uint32_t)aff::FEAT_CHAIN);
-    AF_FLOW_CASE(1u, kMarksFar | (uint32_t)aff::FEAT_CHAIN);
-    AF_FLOW_CASE(2u, kMarksFar | (uint32_t)aff::FEAT_CHAIN);
-    AF_FLOW_CASE(4u, kAll | (uint32_t)aff::FEAT_CHAIN);
     AF_FLOW_CASE(1u, kAll | kLC);
     AF_FLOW_CASE(2u, kAll | kLC);
     AF_FLOW_CASE(4u, kAll | kLC);
@@ -1512,7 +1498,6 @@ int af_engine_create(const af_plan_t* plan, int device, const af_engine_options_
     e->flow_reason = aff::flow_ineligible_reason(*plan);
     e->flow_ok = e->flow_reason.empty();
     e->flow_general_servers = e->flow_ok && aff::flow_needs_general_servers(*plan);
-    e->flow_chain = e->flow_ok && aff::flow_needs_chain(*plan);
     e->has_lb = plan->has_lb;
     e->gen_edge = plan->gen_out_edge;
     e->client_edge = plan->client_out_edge;
@@ -2041,7 +2026,6 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
                 }
                 constexpr uint32_t kRobust = aff::FEAT_ALL | aff::FEAT_TIEBREAK | aff::FEAT_BIGLIST;
                 const void* fn2 = f2.lb_least_connections ? reinterpret_cast<const void*>(af_flow_kernel<1, kRobust | aff::FEAT_LC>)
-                                  : e->flow_chain         ? reinterpret_cast<const void*>(af_flow_kernel<1, kRobust | aff::FEAT_CHAIN>)
                                                           : reinterpret_cast<const void*>(af_flow_kernel<1, kRobust>);
                 if (lds2 > 48u * 1024u) HIP_TRY(hipFuncSetAttribute(fn2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
                 HIP_TRY(hipEventRecord(e->ev3, e->stream));
