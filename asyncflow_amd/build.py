@@ -8,6 +8,7 @@ git-ignored but travels with the repository snapshot to the GPU box.
 
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
@@ -39,25 +40,59 @@ def hipcc_path() -> str:
     raise RuntimeError(msg)
 
 
+STAMP_PATH = CSRC / "libasyncflow_hip.so.stamp"   # sha1 of the sources the library was built from (git-ignored, travels to the GPU box)
+INCLUDE = CSRC.parent.parent / "include" / "asyncflow_hip.h"
+
+
+def sources_sha1() -> str:
+    """Content hash of everything the library is compiled from (mtimes do not survive a snapshot copy)."""
+    h = hashlib.sha1()  # noqa: S324 - a change detector, not a security boundary
+    for path in [*(CSRC / s for s in SOURCES), INCLUDE]:
+        h.update(path.name.encode())
+        h.update(path.read_bytes())
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
-    if not LIB_PATH.exists():
+    """True when the library is missing or was built from other sources than the ones in the tree."""
+    if not LIB_PATH.exists() or not STAMP_PATH.exists():
         return True
-    include = CSRC.parent.parent / "include" / "asyncflow_hip.h"
-    newest = max([(CSRC / s).stat().st_mtime for s in SOURCES] + [include.stat().st_mtime])
-    return LIB_PATH.stat().st_mtime < newest
+    return STAMP_PATH.read_text().strip() != sources_sha1()
+
+
+def have_hipcc() -> bool:
+    try:
+        hipcc_path()
+    except RuntimeError:
+        return False
+    return True
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile the library unless it is up to date.  Safe to call from several processes at once (pytest-xdist,
+    one rank per GPU): an exclusive file lock serialises the builds and the late comers find the stamp current."""
     if not force and not needs_build():
         return LIB_PATH
-    cmd = [hipcc_path(), *HIPCC_FLAGS, "-o", str(LIB_PATH), str(CSRC / "engine.hip")]
-    res = subprocess.run(cmd, capture_output=True, text=True, check=False)
-    if verbose or res.returncode != 0:
-        print(" ".join(cmd))
-        print(res.stdout, res.stderr)
-    if res.returncode != 0:
-        msg = f"hipcc failed ({res.returncode}):\n{res.stderr[-4000:]}"
-        raise RuntimeError(msg)
+    import fcntl
+
+    with open(CSRC / ".build.lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not needs_build():
+            return LIB_PATH
+        want = sources_sha1()
+        tmp = LIB_PATH.with_suffix(f".so.tmp{os.getpid()}")
+        cmd = [hipcc_path(), *HIPCC_FLAGS, "-o", str(tmp), str(CSRC / "engine.hip")]
+        res = subprocess.run(cmd, capture_output=True, text=True, check=False)
+        if verbose or res.returncode != 0:
+            print(" ".join(cmd))
+            print(res.stdout, res.stderr)
+        if res.returncode != 0:
+            tmp.unlink(missing_ok=True)
+            msg = f"hipcc failed ({res.returncode}):\n{res.stderr[-4000:]}"
+            raise RuntimeError(msg)
+        os.replace(tmp, LIB_PATH)      # (a process that has the old library mapped keeps its inode)
+        STAMP_PATH.write_text(want + "\n")
     return LIB_PATH
 
 

@@ -14,6 +14,7 @@ from typing import Sequence
 import numpy as np
 
 from . import _abi
+from . import build as af_build
 from .build import LIB_PATH
 from .plan import DevicePlan
 
@@ -62,12 +63,24 @@ def _load_hip_runtime() -> None:
 def load_library(path: str | Path | None = None) -> C.CDLL:
     global _lib  # noqa: PLW0603
     if _lib is None:
-        p = Path(path or os.environ.get("ASYNCFLOW_HIP_LIB") or LIB_PATH)  # env override: A/B builds in experiments
+        override = path or os.environ.get("ASYNCFLOW_HIP_LIB")            # env override: A/B builds in experiments
+        p = Path(override or LIB_PATH)
+        if not override and af_build.needs_build():
+            # Build on demand: the library is git-ignored, so a fresh checkout (or a tree whose sources changed since the
+            # last build -- content hash, not mtime) has none.  Without hipcc a stale library is an error as well: running
+            # other code than the sources say is worse than not running.
+            if not af_build.have_hipcc():
+                what = "not found" if not p.exists() else "was built from other sources than the tree holds"
+                msg = (f"{p} {what} and hipcc is not available to rebuild it (`python -m asyncflow_amd.build`, "
+                       "hipcc --offload-arch=gfx950). asyncflow_amd has no CPU fallback.")
+                raise EngineUnavailableError(msg)
+            try:
+                af_build.build()
+            except RuntimeError as exc:
+                msg = f"building {p} failed: {exc}"
+                raise EngineUnavailableError(msg) from exc
         if not p.exists():
-            msg = (
-                f"{p} not found: build it with `python -m asyncflow_amd.build` "
-                "(hipcc --offload-arch=gfx950). asyncflow_amd has no CPU fallback."
-            )
+            msg = f"{p} not found. asyncflow_amd has no CPU fallback."
             raise EngineUnavailableError(msg)
         _load_hip_runtime()
         try:

@@ -653,6 +653,8 @@ def main() -> int:  # noqa: C901, PLR0912, PLR0915
 
     if not torch.cuda.is_available():
         print("bench.py needs an MI355X: the engine has no CPU fallback", file=sys.stderr)
+        if rank == 0:
+            print(json.dumps(error_line("no GPU visible (torch.cuda.is_available() is False): the engine has no CPU fallback")), flush=True)
         return 2
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -874,5 +876,23 @@ def main() -> int:  # noqa: C901, PLR0912, PLR0915
     return 0
 
 
+def error_line(message: str) -> dict:
+    """The ONE JSON line of a run that could not measure anything: the driver's record then names the reason
+    instead of holding `parsed: null`."""
+    return {"metric": "simulated request-events/sec", "value": None, "unit": "request-events/s", "error": message[-2000:],
+            "kernel_sources_sha1": kernel_sources_sha1()}
+
+
 if __name__ == "__main__":
-    raise SystemExit(main())
+    try:
+        rc = main()
+    except SystemExit:
+        raise
+    except BaseException as exc:  # noqa: BLE001 - whatever it is, the driver gets one parseable line
+        import traceback
+
+        traceback.print_exc()
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps(error_line(f"{type(exc).__name__}: {exc}")), flush=True)
+        rc = 1
+    raise SystemExit(rc)
