@@ -18,6 +18,7 @@ COMM_ID_BYTES = 128            # AF_COMM_ID_BYTES
 AF_OK = 0
 AF_ERR_INVALID = -1
 AF_ERR_NO_DEVICE = -2
+DEVICE_PLAN_ONLY = -1          # AF_DEVICE_PLAN_ONLY
 AF_ERR_HIP = -3
 AF_ERR_CAPACITY = -4
 AF_ERR_ABI = -5

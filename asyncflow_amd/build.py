@@ -33,6 +33,9 @@ HIPCC_FLAGS = (
 
 
 def hipcc_path() -> str:
+    if os.environ.get("ASYNCFLOW_NO_HIPCC"):      # (tests / measurements: behave like a box without a compiler)
+        msg = "hipcc disabled by ASYNCFLOW_NO_HIPCC"
+        raise RuntimeError(msg)
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and Path(cand).exists():
             return cand

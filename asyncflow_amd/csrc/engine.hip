@@ -705,13 +705,11 @@ static int launch_pregen_arrivals(const KArgs& a, uint32_t n, uint32_t stride, b
         g.ovr_stride = a.ovr_stride;
         g.out = a.draws;
         g.pre_flags = a.pre_flags;
-        static bool lds_set = false;
-        if (!lds_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(afp::af_arrival_groups), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)sizeof(afp::GroupLds)) != hipSuccess)
-                return 1;
-            lds_set = true;
-        }
+        // (set before every launch: the attribute is per device, engines of several devices run in threads of one process,
+        // and the call costs microseconds next to a kernel of milliseconds -- ADVICE r3)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(afp::af_arrival_groups), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)sizeof(afp::GroupLds)) != hipSuccess)
+            return 1;
         hipLaunchKernelGGL(afp::af_arrival_groups, dim3((n + g.group - 1u) / g.group), dim3(afp::kGroupThreads),
                            sizeof(afp::GroupLds), stream, g);
         return 0;
@@ -864,6 +862,7 @@ const void* des_kernel_for(bool lds, bool faithful, uint32_t klog, bool roomy) {
 
 struct af_engine {
     int device = 0;
+    bool plan_only = false;   // created with AF_DEVICE_PLAN_ONLY: af_engine_jit_spec and the pure queries only
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     KArgs args{};
@@ -1419,14 +1418,20 @@ int af_engine_create(const af_plan_t* plan, int device, const af_engine_options_
     if (!out) return fail(AF_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (int rc = validate_plan(plan)) return rc;
-    int n_dev = 0;
-    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
-        return fail(AF_ERR_NO_DEVICE, "no HIP device visible: the asyncflow_amd engine has no CPU fallback");
-    if (device < 0 || device >= n_dev) return fail(AF_ERR_NO_DEVICE, "device index out of range");
-    HIP_TRY(hipSetDevice(device));
+    // AF_DEVICE_PLAN_ONLY: a planning-only engine -- everything af_engine_jit_spec needs (plan facts, layout heuristics)
+    // and no device state: it cannot run, and no HIP call is made on its behalf (build machines without a GPU)
+    const bool plan_only = device == AF_DEVICE_PLAN_ONLY;
+    if (!plan_only) {
+        int n_dev = 0;
+        if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+            return fail(AF_ERR_NO_DEVICE, "no HIP device visible: the asyncflow_amd engine has no CPU fallback");
+        if (device < 0 || device >= n_dev) return fail(AF_ERR_NO_DEVICE, "device index out of range");
+        HIP_TRY(hipSetDevice(device));
+    }
 
     af_engine* e = new af_engine();
     e->device = device;
+    e->plan_only = plan_only;
     KArgs& a = e->args;
     a.total_time = plan->total_time;
     a.sample_period = plan->sample_period;
@@ -1559,6 +1564,10 @@ int af_engine_create(const af_plan_t* plan, int device, const af_engine_options_
         f.L = aff::choose_flow_layout(*plan, 1u, 64u);   // g_ring / c_ring; entries and rows are chosen per run
     }
 
+    if (plan_only) {
+        *out = e;
+        return AF_OK;
+    }
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (err == hipSuccess && e->flow_ok) err = hipMalloc((void**)&e->d_tick, (e->tick.t.size() + 1u) * 8u);
     if (err == hipSuccess && e->flow_ok && !e->tick.t.empty())
@@ -1592,6 +1601,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     if (out->online_hist && (out->online_hist_bins == 0 || !(out->online_hist_max > 0.0)))
         return fail(AF_ERR_INVALID, "online_hist needs online_hist_bins > 0 and online_hist_max > 0");
     if (out->online_rps && out->online_rps_buckets == 0) return fail(AF_ERR_INVALID, "online_rps with zero buckets");
+    if (e->plan_only) return fail(AF_ERR_NO_DEVICE, "planning-only engine (AF_DEVICE_PLAN_ONLY): it cannot run");
     HIP_TRY(hipSetDevice(e->device));
     KArgs a = e->args;
     const uint32_t n = sweep->n_scenarios;
@@ -1664,7 +1674,15 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     const uint32_t n_draw = sweep->draw_capacity ? sweep->draw_capacity : out->clock_capacity;
     if (n_draw == 0) return fail(AF_ERR_INVALID, "draw_capacity (or clock_capacity) must be > 0");
     const size_t draw_bytes_per_scen = (size_t)(1u + a.n_edges) * n_draw * sizeof(double);
-    const bool use_flow = flow_wanted(e, n);
+    // (a sweep the stage-parallel kernel cannot be sized for -- a cpu_cores column above 64, lists that do not fit the LDS --
+    // runs on the next-event kernels like a plan outside its range does, unless flow_mode 2 asked for that kernel: ADVICE r3)
+    bool use_flow = flow_wanted(e, n);
+    FlowPlan FP;
+    if (use_flow) {
+        const int rc = plan_flow(e, a, sweep, out, FP);
+        if (rc == AF_ERR_CAPACITY && e->flow_mode != 2u) use_flow = false;
+        else if (rc) return rc;
+    }
     size_t mem_free = 0, mem_total = 0;
     HIP_TRY(hipMemGetInfo(&mem_free, &mem_total));
     // the stage-parallel kernel only needs the arrival times of a chunk; the next-event kernels every draw
@@ -1694,9 +1712,6 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     uint32_t pregen_group = 0;
     bool lds_state = false;
 
-    FlowPlan FP;
-    if (use_flow)
-        if (int rc = plan_flow(e, a, sweep, out, FP)) return rc;
     aff::FlowLayout& FL = FP.FL;
     aff::FlowLayout& FL2 = FP.FL2;
     const bool flow_big = FP.big;
@@ -2095,7 +2110,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
 int af_engine_jit_spec(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* out, char* buf, size_t cap) {
     if (!e || !sweep || !out || !buf || cap == 0) return fail(AF_ERR_INVALID, "NULL argument");
     if (sweep->n_scenarios == 0) return fail(AF_ERR_INVALID, "empty sweep");
-    HIP_TRY(hipSetDevice(e->device));
+    if (!e->plan_only) HIP_TRY(hipSetDevice(e->device));
     KArgs a = e->args;
     uint32_t mask = 0;
     for (uint32_t k = 0; k < sweep->n_overrides; ++k) {
@@ -2111,16 +2126,23 @@ int af_engine_jit_spec(af_engine_t* e, const af_sweep_t* sweep, const af_outputs
     a.online_rps = out->online_rps;
     a.n_draw = sweep->draw_capacity ? sweep->draw_capacity : out->clock_capacity;
     if (a.n_draw == 0) return fail(AF_ERR_INVALID, "draw_capacity (or clock_capacity) must be > 0");
-    if (flow_wanted(e, sweep->n_scenarios)) {   // the sweep runs on the stage-parallel kernel: its spec
+    bool on_flow = flow_wanted(e, sweep->n_scenarios);
+    FlowPlan FP;
+    if (on_flow) {
         for (uint32_t k = 0; k < sweep->n_overrides; ++k)
             if (!sweep->overrides[k].values) return fail(AF_ERR_INVALID, "bad override");
-        FlowPlan FP;
-        if (int rc = plan_flow(e, a, sweep, out, FP)) return rc;
+        const int rc = plan_flow(e, a, sweep, out, FP);
+        if (rc == AF_ERR_CAPACITY && e->flow_mode != 2u) on_flow = false;   // (af_engine_run: the next-event kernels then)
+        else if (rc) return rc;
+    }
+    if (on_flow) {   // the sweep runs on the stage-parallel kernel: its spec
         const std::string spec = flow_jit_spec_string(e, FP, out, sweep->n_overrides != 0u);
         if (spec.size() + 1 > cap) return fail(AF_ERR_CAPACITY, "spec buffer too small");
         std::memcpy(buf, spec.c_str(), spec.size() + 1);
         return AF_OK;
     }
+    // (the next-event kernels' spec depends on the chunking, i.e. on the free device memory: not known without a device)
+    if (e->plan_only) return fail(AF_ERR_NO_DEVICE, "planning-only engine: only sweeps of the stage-parallel kernel have a device-independent spec");
     size_t mem_free = 0, mem_total = 0;
     HIP_TRY(hipMemGetInfo(&mem_free, &mem_total));
     const uint32_t chunk = chunk_size(e, sweep->n_scenarios, (size_t)(1u + a.n_edges) * a.n_draw * sizeof(double), mem_free);
@@ -2138,6 +2160,7 @@ int af_engine_jit_spec(af_engine_t* e, const af_sweep_t* sweep, const af_outputs
 
 int af_engine_set_kernels(af_engine_t* e, const char* spec, const void* image, size_t size) {
     if (!e) return fail(AF_ERR_INVALID, "NULL argument");
+    if (e->plan_only) return fail(AF_ERR_NO_DEVICE, "planning-only engine (AF_DEVICE_PLAN_ONLY)");
     HIP_TRY(hipSetDevice(e->device));
     const bool unload_all = !spec || !image || size == 0;
     const bool is_flow = spec && std::strstr(spec, "-DAF_FLOW_JIT=1") != nullptr;
@@ -2187,6 +2210,7 @@ int af_engine_set_kernels(af_engine_t* e, const char* spec, const void* image, s
 
 int af_engine_summarize(af_engine_t* e, const af_outputs_t* out, const af_summary_t* sum) {
     if (!e || !out || !sum) return fail(AF_ERR_INVALID, "NULL argument");
+    if (e->plan_only) return fail(AF_ERR_NO_DEVICE, "planning-only engine (AF_DEVICE_PLAN_ONLY)");
     if (sum->n_scenarios == 0) return fail(AF_ERR_INVALID, "empty summary request");
     if (!out->counts) return fail(AF_ERR_INVALID, "outputs.counts is required");
     const bool want_lat = sum->stats || sum->rps || sum->hist;
@@ -2266,6 +2290,10 @@ int af_engine_stats(const af_engine_t* e, af_stats_t* stats) {
 
 void af_engine_destroy(af_engine_t* e) {
     if (!e) return;
+    if (e->plan_only) {   // (owns no device state)
+        delete e;
+        return;
+    }
     (void)hipSetDevice(e->device);
     if (e->d_blob) (void)hipFree(e->d_blob);
     if (e->d_codes) (void)hipFree(e->d_codes);
@@ -2384,6 +2412,7 @@ int af_engine_gather(af_engine_t* e, void* comm, int world_size, const af_summar
     if (local->n_scenarios == 0) return fail(AF_ERR_INVALID, "empty shard");
     if (out->n_scenarios != local->n_scenarios * (uint32_t)world_size)
         return fail(AF_ERR_INVALID, "gathered.n_scenarios must be world_size * local.n_scenarios");
+    if (e->plan_only) return fail(AF_ERR_NO_DEVICE, "planning-only engine (AF_DEVICE_PLAN_ONLY)");
     if (int rc = rccl_need()) return rc;
     HIP_TRY(hipSetDevice(e->device));
     const size_t n = local->n_scenarios;

@@ -115,6 +115,9 @@ def flow_mode(flow: bool | str) -> int:
     return 0 if flow else 1
 
 
+PLAN_ONLY = _abi.DEVICE_PLAN_ONLY   # Engine(plan, PLAN_ONLY): a planning-only engine (include/asyncflow_hip.h, AF_DEVICE_PLAN_ONLY)
+
+
 class Engine:
     """One ``af_engine_t``: a lowered plan resident on one GPU."""
 
@@ -190,15 +193,33 @@ class Engine:
                                                 defaults["online_rps_ptr"], defaults["online_rps_buckets"])
         self._specialise(sweep, out)
 
+    def jit_spec(self, seeds: np.ndarray, overrides: Sequence[tuple[int, int, np.ndarray]], **kw) -> str:
+        """The ``-D`` flags of the plan-specialised kernels a sweep of this shape launches (same keyword arguments as
+        :meth:`run`; of the pointers only their PRESENCE enters).  Works on a planning-only engine
+        (``device=PLAN_ONLY``: no GPU needed) for sweeps the stage-parallel kernel runs."""
+        kw.pop("specialise", None)
+        defaults = {"draw_capacity": 0, "online_hist_ptr": 0, "online_hist_bins": 0, "online_hist_max": 0.0,
+                    "online_rps_ptr": 0, "online_rps_buckets": 0}
+        defaults.update(kw)
+        sweep, out, _keep = self._sweep_structs(seeds, overrides, defaults["clock_ptr"], defaults["clock_capacity"],
+                                                defaults["samples_ptr"], defaults["tick_capacity"], defaults["counts_ptr"],
+                                                defaults["draw_capacity"], defaults["online_hist_ptr"],
+                                                defaults["online_hist_bins"], defaults["online_hist_max"],
+                                                defaults["online_rps_ptr"], defaults["online_rps_buckets"])
+        return self._spec_of(sweep, out).decode()
+
+    def _spec_of(self, sweep: _abi.AfSweep, out: _abi.AfOutputs) -> bytes:
+        buf = C.create_string_buffer(2048)
+        _check(self._lib, self._lib.af_engine_jit_spec(self._h, C.byref(sweep), C.byref(out), buf, len(buf)),
+               "af_engine_jit_spec")
+        return buf.value
+
     def _specialise(self, sweep: _abi.AfSweep, out: _abi.AfOutputs, build: bool = True) -> None:
         import warnings
 
         from . import jit
 
-        buf = C.create_string_buffer(2048)
-        _check(self._lib, self._lib.af_engine_jit_spec(self._h, C.byref(sweep), C.byref(out), buf, len(buf)),
-               "af_engine_jit_spec")
-        spec = buf.value
+        spec = self._spec_of(sweep, out)
         if spec == self._jit_spec:
             return
         try:

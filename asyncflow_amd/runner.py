@@ -109,23 +109,43 @@ def write_point(payload: dict, key: str, value: float) -> None:
         raise ValueError(msg)
 
 
+VALIDATE_EVERY_POINT_UP_TO = 10_000   # distinct points; the reference's model costs ~0.2 ms per payload
+
+
 def validate_points(plan: DevicePlan, columns: Mapping[str, np.ndarray], n: int) -> int:
     """Per-point validation of a sweep through the payload models -- the reference's own
-    ``SimulationPayload.model_validate`` when ``asyncflow`` is importable, else the structural validators of
-    asyncflow_amd/payload.py (``normalize_payload`` picks) -- at the points that carry every axis's extremes: the
-    scenarios holding the minimum and the maximum of each column, plus the first and the last one.  Every column is a
-    monotone constraint of the schema (positivity, ranges, t_start < t_end against the other columns of the SAME
-    scenario), so a sweep whose extremes validate cannot hide an invalid interior point except through cross-column
-    constraints, which the event columns cover exhaustively (every distinct combination is lowered, `resolve_sweep`).
+    ``SimulationPayload.model_validate`` when ``asyncflow`` is importable (payload.py:20-252 validates every payload it
+    runs), else the structural validators of asyncflow_amd/payload.py (``normalize_payload`` picks).
+
+    * Up to ``VALIDATE_EVERY_POINT_UP_TO`` DISTINCT points (rows of the column table; seed replicas of one point count
+      once): every one of them is validated, like the reference would.
+    * Beyond that: the points that carry every column's extremes (the scenarios holding its minimum and its maximum) plus
+      the first and the last one.  That argument covers the RANGE constraints of the schema, which are monotone in each
+      column; the constraints that are not -- integrality of the int fields -- are checked over the whole column here and in
+      `resolve_sweep`, and cross-column constraints of the event columns are covered exhaustively by `_event_columns`
+      (every distinct combination is lowered).
     Returns the number of payloads validated; raises ``ValueError`` (pydantic's ValidationError is one)."""
     import copy
 
     from .payload import normalize_payload
 
-    picks = {0, n - 1}
-    for col in columns.values():
-        picks.add(int(np.argmin(col)))
-        picks.add(int(np.argmax(col)))
+    keys = list(columns)
+    for key in keys:                      # integrality is not monotone: whole column, whatever the number of points
+        if key == "rqs_input.user_sampling_window" or _RES_RE.match(key):
+            col = columns[key]
+            if np.any(col != np.floor(col)):
+                bad = int(np.argmax(col != np.floor(col)))
+                msg = f"sweep key {key!r}: an integer field of the schema, but scenario {bad} has {float(col[bad])!r}"
+                raise ValueError(msg)
+    table = np.stack([np.asarray(columns[k], dtype=np.float64) for k in keys], axis=1) if keys else np.zeros((n, 0))
+    _, first = np.unique(table, axis=0, return_index=True)
+    if len(first) <= VALIDATE_EVERY_POINT_UP_TO:
+        picks = {int(i) for i in first}
+    else:
+        picks = {0, n - 1}
+        for col in columns.values():
+            picks.add(int(np.argmin(col)))
+            picks.add(int(np.argmax(col)))
     for i in sorted(picks):
         point = copy.deepcopy(plan.payload)
         for key, col in columns.items():
@@ -474,18 +494,22 @@ class SimulationRunner:
                 online_hist = torch.zeros((n, o_bins), dtype=torch.int32, device=dev)
                 online_rps = torch.zeros((n, max(o_buckets, 1)), dtype=torch.int32, device=dev)
             torch.cuda.synchronize(dev)
+            run_kw = dict(clock_ptr=clock.data_ptr() if clock is not None else 0, clock_capacity=clock_cap,
+                          samples_ptr=samples.data_ptr() if samples is not None else 0, tick_capacity=ticks,
+                          counts_ptr=counts.data_ptr(), draw_capacity=clock_cap)
+            cols = [(c, i, v) for c, i, v, _ in overrides]
+            build = True
+            if self.specialise is None:
+                # which kernel family this sweep runs on is the ENGINE's decision (plan range, general servers above a
+                # few scenarios, a sweep it cannot be sized for): read it off the spec it would launch
+                on_flow_kernel = "-DAF_FLOW_JIT=1" in eng.jit_spec(self.seeds, cols, **run_kw)
+                build = self._want_specialised(n, clock_cap, on_flow_kernel)
             stats = eng.run(
                 self.seeds,
-                [(c, i, v) for c, i, v, _ in overrides],
-                clock_ptr=clock.data_ptr() if clock is not None else 0,
-                clock_capacity=clock_cap,
-                samples_ptr=samples.data_ptr() if samples is not None else 0,
-                tick_capacity=ticks,
-                counts_ptr=counts.data_ptr(),
-                draw_capacity=clock_cap,
+                cols,
+                **run_kw,
                 specialise=True if self.specialise is None else bool(self.specialise),
-                specialise_build=(self._want_specialised(n, clock_cap, self.flow and not eng.flow_reason())
-                                  if self.specialise is None else True),
+                specialise_build=build,
                 online_hist_ptr=online_hist.data_ptr() if online_hist is not None else 0, online_hist_bins=o_bins,
                 online_hist_max=o_max,
                 online_rps_ptr=online_rps.data_ptr() if online_rps is not None and o_buckets else 0,

@@ -425,6 +425,80 @@ def parity_spot_check(sw: "RankSweep", k: int = 4) -> dict:
 # --------------------------------------------------------------------------- #
 # the rank's sweep: engine + HBM-resident outputs, run as slices                 #
 # --------------------------------------------------------------------------- #
+def rank_shape(wl: dict, args) -> dict:
+    """Everything about a rank's sweep that does not need a device: the lowered plan, the engine columns, the capacities,
+    the slicing and the engine options -- what RankSweep runs and what `prebuild_kernels` asks the specialised kernel for."""
+    from asyncflow_amd import _abi
+    from asyncflow_amd.plan import estimate_capacities, lower
+    from asyncflow_amd.runner import _fifo_pow2, resolve_sweep
+
+    plan = lower(wl["payload"])
+    n = wl["n"]
+    over = resolve_sweep(plan, wl["columns"], n)
+    users = wl["columns"].get("rqs_input.avg_active_users.mean")
+    lat = wl["columns"].get("topology_graph.edges[*].latency.mean")
+    users_max = float(users.max()) if users is not None else None
+    lat_scale = float(lat.max() / plan.edge_mean.min()) if lat is not None else 1.0
+    cap, fifo = estimate_capacities(plan, users_max, lat_scale)
+    clock_cap = plan.clock_capacity(users_max)
+    ticks = max(plan.tick_count, 1)
+    # slices: outputs of one slice must fit the HBM budget (clock + samples; the engine's own buffers on top)
+    online = bool(args.online_summary)
+    if online:
+        args.no_series = True
+    per_scen = (0 if online else clock_cap * 16) + (0 if args.no_series else ticks * plan.series_pitch * 4) + 8192
+    budget = int(args.hbm_budget_gb * (1 << 30))
+    slice_n = max(1, min(n, budget // max(per_scen, 1), 65535 if n > 65535 else n))
+    n_slices = (n + slice_n - 1) // slice_n
+    slice_n = (n + n_slices - 1) // n_slices
+    engine_kw = dict(request_capacity=min(cap, _abi.MAX_REQUEST_CAPACITY), fifo_capacity=_fifo_pow2(min(fifo, cap)),
+                     lanes_per_wave=args.lanes, force_global_state=args.global_state,
+                     expect_shared_instants=args.expect_shared_instants, flow=not args.no_flow,
+                     flow_list_entries=args.flow_list_entries,
+                     flow_ring_rows=_abi.FLOW_RING_IN_HBM if args.flow_ring_rows < 0 else args.flow_ring_rows)
+    return {"plan": plan, "n": n, "seeds": wl["seeds"], "over": over, "clock_cap": clock_cap, "ticks": ticks,
+            "T": int(plan.total_time), "online": online, "slice": slice_n, "n_slices": n_slices, "engine_kw": engine_kw}
+
+
+def prebuild_kernels(configs: tuple[int, ...] = (2, 3, 4, 5), worlds: tuple[int, ...] = (1, 2, 4, 8), verbose: bool = True) -> list[str]:
+    """Compile, WITHOUT a GPU, the plan-specialised stage-parallel kernel of every default bench line (`--config C` at
+    `--gpus N`) into the JIT cache (asyncflow_amd/csrc/_jit/, which travels to the GPU box with the tree): the headline
+    then does not depend on hipcc being present where the bench runs.  A planning-only engine (AF_DEVICE_PLAN_ONLY) answers
+    `af_engine_jit_spec` -- a pure function of plan, sweep columns and output shape -- and `jit.code_object` builds what is
+    not cached yet.  Called by `__graft_entry__.build()`.  Returns the distinct specs."""
+    from asyncflow_amd import jit
+    from asyncflow_amd.engine import PLAN_ONLY, Engine
+
+    specs: dict[str, str] = {}
+    for cfg in configs:
+        for world in worlds:
+            if cfg in (2, 3) and world != 1:
+                continue            # weak scaling: every rank runs the same shape as the single GPU
+            for rank in sorted({0, world - 1}):
+                args = make_parser().parse_args(["--config", str(cfg), "--gpus", str(world)])
+                args.horizon = None
+                wl = build_workload(cfg, rank, world, 0, None)
+                shape = rank_shape(wl, args)
+                eng = Engine(shape["plan"], PLAN_ONLY, **shape["engine_kw"])
+                try:
+                    if eng.flow_reason():
+                        continue
+                    hi = min(shape["slice"], shape["n"])
+                    over = [(c, i, np.ascontiguousarray(v[:hi])) for c, i, v, _ in shape["over"]]
+                    spec = eng.jit_spec(shape["seeds"][:hi], over, clock_ptr=8, clock_capacity=shape["clock_cap"],
+                                        samples_ptr=8, tick_capacity=shape["ticks"], counts_ptr=8,
+                                        draw_capacity=shape["clock_cap"])
+                finally:
+                    eng.close()
+                if spec not in specs:
+                    t0 = time.perf_counter()
+                    jit.code_object(spec)
+                    specs[spec] = f"config {cfg}, {world} GPU(s), rank {rank}"
+                    if verbose:
+                        print(f"prebuilt af_flow_jit for {specs[spec]} in {time.perf_counter() - t0:.1f} s", flush=True)
+    return list(specs)
+
+
 class RankSweep:
     """Engine, output buffers and per-scenario summaries of this rank's share of the workload."""
 
@@ -433,36 +507,14 @@ class RankSweep:
 
         from asyncflow_amd import _abi
         from asyncflow_amd.engine import Engine
-        from asyncflow_amd.plan import estimate_capacities, lower
-        from asyncflow_amd.runner import _fifo_pow2, resolve_sweep
 
         self.torch, self._abi, self.args, self.dev = torch, _abi, args, dev
-        self.plan = plan = lower(wl["payload"])
-        self.n = n = wl["n"]
-        self.seeds = wl["seeds"]
-        self.over = resolve_sweep(plan, wl["columns"], n)
-        users = wl["columns"].get("rqs_input.avg_active_users.mean")
-        lat = wl["columns"].get("topology_graph.edges[*].latency.mean")
-        users_max = float(users.max()) if users is not None else None
-        lat_scale = float(lat.max() / plan.edge_mean.min()) if lat is not None else 1.0
-        cap, fifo = estimate_capacities(plan, users_max, lat_scale)
-        self.clock_cap = plan.clock_capacity(users_max)
-        self.ticks = max(plan.tick_count, 1)
-        self.T = int(plan.total_time)
-        # slices: outputs of one slice must fit the HBM budget (clock + samples; the engine's own buffers on top)
-        self.online = bool(args.online_summary)
-        if self.online:
-            args.no_series = True
-        per_scen = (0 if self.online else self.clock_cap * 16) + (0 if args.no_series else self.ticks * plan.series_pitch * 4) + 8192
-        budget = int(args.hbm_budget_gb * (1 << 30))
-        self.slice = max(1, min(n, budget // max(per_scen, 1), 65535 if n > 65535 else n))
-        self.n_slices = (n + self.slice - 1) // self.slice
-        self.slice = (n + self.n_slices - 1) // self.n_slices
-        self.eng = Engine(plan, dev.index, request_capacity=min(cap, _abi.MAX_REQUEST_CAPACITY),
-                          fifo_capacity=_fifo_pow2(min(fifo, cap)), lanes_per_wave=args.lanes,
-                          force_global_state=args.global_state, expect_shared_instants=args.expect_shared_instants,
-                          flow=not args.no_flow, flow_list_entries=args.flow_list_entries,
-                          flow_ring_rows=_abi.FLOW_RING_IN_HBM if args.flow_ring_rows < 0 else args.flow_ring_rows)
+        shape = rank_shape(wl, args)
+        self.plan, self.n, self.seeds, self.over = shape["plan"], shape["n"], shape["seeds"], shape["over"]
+        self.clock_cap, self.ticks, self.T, self.online = shape["clock_cap"], shape["ticks"], shape["T"], shape["online"]
+        self.slice, self.n_slices = shape["slice"], shape["n_slices"]
+        plan, n = self.plan, self.n
+        self.eng = Engine(plan, dev.index, **shape["engine_kw"])
         self.flow_reason = self.eng.flow_reason()
         m = self.slice
         self.counts = torch.zeros((n, _abi.CNT_SLOTS), dtype=torch.int32, device=dev)
@@ -600,7 +652,7 @@ def selftest_cpu(args, rank: int, world: int) -> int:
     return 0
 
 
-def main() -> int:  # noqa: C901, PLR0912, PLR0915
+def make_parser() -> argparse.ArgumentParser:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -628,6 +680,11 @@ def main() -> int:  # noqa: C901, PLR0912, PLR0915
     ap.add_argument("--flow-ring-rows", type=int, default=0, help="rows of the LDS tick ring (0 = auto, -1 = keep the differences in HBM)")
     ap.add_argument("--hbm-budget-gb", type=float, default=96.0, help="HBM for the output buffers of one slice")
     ap.add_argument("--selftest-cpu", action="store_true", help="launcher / sharding / gather path on CPU (gloo), no engine")
+    return ap
+
+
+def main() -> int:  # noqa: C901, PLR0912, PLR0915
+    ap = make_parser()
     args = ap.parse_args()
     args.horizon = args.horizon or None
 

@@ -324,7 +324,13 @@ typedef struct af_stats {
 
 typedef struct af_engine af_engine_t;
 
-/* Replaces: SimulationRunner.__init__ + _build_* (simulation_runner.py:52-294). */
+/* Replaces: SimulationRunner.__init__ + _build_* (simulation_runner.py:52-294).
+ * device = AF_DEVICE_PLAN_ONLY makes a planning-only engine: it owns no device state and no HIP call is made for it, so it
+ * can be created on a machine without a GPU.  It answers af_engine_jit_spec for sweeps of the stage-parallel kernel (the
+ * spec is a pure function of plan, sweep and output shape), af_engine_flow_reason and af_engine_stats; every call that
+ * would touch the device returns AF_ERR_NO_DEVICE.  Used to pre-build plan-specialised kernels where hipcc is (the build
+ * machine) for a box where it may not be. */
+#define AF_DEVICE_PLAN_ONLY (-1)
 int af_engine_create(const af_plan_t* plan, int device, const af_engine_options_t* opts,
                      af_engine_t** out);
 /* Plan-specialised kernels (optional).  The library contains generic next-event kernels; for long

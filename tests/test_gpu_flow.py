@@ -466,6 +466,36 @@ def test_plan_specialised_flow_kernel_gives_identical_results():
             _assert_scenario(special[5], ol.simulate(lower(payload), int(seeds[5])), f"case {k}")
 
 
+def test_prebuilt_kernels_serve_a_box_without_hipcc(tmp_path, monkeypatch):
+    """The headline must not depend on a compiler where the bench runs: a planning-only engine
+    (AF_DEVICE_PLAN_ONLY, no device) writes the same spec as the engine on the GPU, `bench.prebuild_kernels` compiles it
+    ahead of time, and with hipcc out of reach the run still launches the plan-specialised kernel: no fallback."""
+    import bench
+    from asyncflow_amd import jit
+    from asyncflow_amd.engine import PLAN_ONLY, Engine
+
+    args = bench.make_parser().parse_args(["--config", "2"])
+    args.horizon = None
+    shape = bench.rank_shape(bench.build_workload(2, 0, 1, 0, None), args)
+    kw = dict(clock_ptr=8, clock_capacity=shape["clock_cap"], samples_ptr=8, tick_capacity=shape["ticks"], counts_ptr=8,
+              draw_capacity=shape["clock_cap"])
+    specs = []
+    for device in (PLAN_ONLY, 0):
+        eng = Engine(shape["plan"], device, **shape["engine_kw"])
+        specs.append(eng.jit_spec(shape["seeds"], [], **kw))
+        eng.close()
+    assert specs[0] == specs[1]
+    monkeypatch.setattr(jit, "CACHE_DIR", tmp_path)
+    monkeypatch.setattr(jit, "_FALLBACK_CACHE_DIR", tmp_path / "none")
+    assert bench.prebuild_kernels(configs=(2,), worlds=(1,), verbose=False) == [specs[0]]
+    monkeypatch.setenv("ASYNCFLOW_NO_HIPCC", "1")
+    # a short run of the same plan shape + layout (the horizon is part of the spec: the full one, 256 replicas)
+    res = _runner(lb_two_servers(), seeds=np.arange(256, dtype=np.uint64) + 0x5EED0000, specialise=True).run()
+    st = res.engine_stats
+    assert st.specialised_launches >= 1 and st.jit_fallbacks == 0 and st.flow_scenarios == 256
+    _assert_scenario(res[255], ol.simulate(lower(lb_two_servers()), 0x5EED0000 + 255), "prebuilt kernel")
+
+
 def test_far_and_near_lean_instantiations_agree(monkeypatch):
     """LB-2's hops are fast: the engine launches the plain lean instantiation (the sender enters both ends of every
     message); AF_FLOW_FORCE_FAR makes it launch the FEAT_FAR one with the window rule of slow-hop plans.  Same results."""
@@ -512,6 +542,28 @@ def test_sweep_over_spike_size_and_outage_window_matches_the_oracle_per_point():
     special = _runner(base, seeds=grid.seeds, sweep=cols, specialise=True).run()     # the plan-specialised build patches the same blob
     assert special.engine_stats.specialised_launches >= 1
     _same_batches(res, special)
+
+
+def test_a_sweep_the_flow_kernel_cannot_be_sized_for_runs_on_the_next_event_kernels():
+    """a cpu_cores column above the stage-parallel kernel's 64 cores per server used to fail the whole run with
+    AF_ERR_CAPACITY, while a PLAN with that many cores simply ran on the next-event kernels.  Now the sweep does too
+    (and the runner's spec query with it); flow="always" still says why it cannot."""
+    from asyncflow_amd.engine import EngineError
+    from asyncflow_amd.runner import write_point
+
+    base = lb_two_servers(horizon=20)
+    key = "topology_graph.nodes.servers[srv-1].server_resources.cpu_cores"
+    cols = {key: np.array([1.0, 2.0, 80.0, 65.0])}
+    seeds = np.arange(4, dtype=np.uint64) + 11
+    res = _runner(base, seeds=seeds, sweep=cols).run()
+    assert res.engine_stats.flow_scenarios == 0
+    plan = lower(base)
+    for i in range(4):
+        point = copy.deepcopy(plan.payload)
+        write_point(point, key, cols[key][i])
+        _assert_scenario(res[i], ol.simulate(lower(point), int(seeds[i])), f"point {i}")
+    with pytest.raises(EngineError, match="64 cores"):
+        _runner(base, seeds=seeds, sweep=cols, flow="always").run()
 
 
 def test_negative_delay_raises_like_the_reference_or_is_flagged():

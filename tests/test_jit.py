@@ -81,3 +81,58 @@ def test_the_runner_never_asks_for_a_fifo_the_engine_refuses():
     cap, fifo, _ = r._capacities([])  # noqa: SLF001
     assert cap <= _abi.MAX_REQUEST_CAPACITY and fifo <= _abi.MAX_FIFO_CAPACITY and fifo & (fifo - 1) == 0
     assert _fifo_pow2(10**9) == _abi.MAX_FIFO_CAPACITY and _fifo_pow2(9) == 16
+
+
+# ---- planning-only engine (AF_DEVICE_PLAN_ONLY): the spec without a device -------------------------------------------
+def _lb2_spec_on(device: int, n: int = 10_000) -> str:
+    import numpy as np
+
+    from asyncflow_amd.engine import Engine
+    from asyncflow_amd.plan import lower
+    from oracle.scenarios import lb_two_servers
+
+    plan = lower(lb_two_servers())
+    eng = Engine(plan, device)
+    try:
+        return eng.jit_spec(0x5EED0000 + np.arange(n, dtype=np.uint64), [], clock_ptr=8, clock_capacity=plan.clock_capacity(None),
+                            samples_ptr=8, tick_capacity=plan.tick_count, counts_ptr=8, draw_capacity=plan.clock_capacity(None))
+    finally:
+        eng.close()
+
+
+def test_a_planning_only_engine_writes_the_flow_spec_without_a_device():
+    from asyncflow_amd.engine import PLAN_ONLY
+
+    spec = _lb2_spec_on(PLAN_ONLY)
+    assert spec.startswith("-DAF_JIT=1 -DAF_FLOW_JIT=1 -DAF_FJ_IPL=1 -DAF_FJ_FEAT=0 ") and "-DAF_FJ_N_TICKS=11999 " in spec
+    assert spec == _lb2_spec_on(PLAN_ONLY, n=64)            # (replica sweeps: the scenario count is a launch argument)
+
+
+def test_a_planning_only_engine_cannot_run():
+    import numpy as np
+
+    from asyncflow_amd.engine import PLAN_ONLY, Engine, EngineUnavailableError
+    from asyncflow_amd.plan import lower
+    from oracle.scenarios import lb_two_servers
+
+    eng = Engine(lower(lb_two_servers(horizon=5)), PLAN_ONLY)
+    counts = np.zeros((1, 8), dtype=np.uint32)
+    with pytest.raises(EngineUnavailableError, match="planning-only"):
+        eng.run(np.array([1], dtype=np.uint64), [], clock_ptr=0, clock_capacity=0, samples_ptr=0, tick_capacity=0,
+                counts_ptr=counts.ctypes.data)
+    assert eng.flow_reason() == ""
+    eng.close()
+
+
+def test_prebuild_fills_the_cache_for_every_default_bench_line(tmp_path, monkeypatch):
+    """`__graft_entry__.build()` calls bench.prebuild_kernels(): afterwards a box without hipcc still finds the kernels."""
+    import bench
+
+    monkeypatch.setattr(jit, "CACHE_DIR", tmp_path)
+    monkeypatch.setattr(jit, "_FALLBACK_CACHE_DIR", tmp_path / "none")
+    specs = bench.prebuild_kernels(configs=(2,), worlds=(1,), verbose=False)
+    assert len(specs) == 1 and len(list(tmp_path.glob("*.hsaco"))) == 1
+    monkeypatch.setenv("ASYNCFLOW_NO_HIPCC", "1")
+    assert jit.code_object(specs[0]).startswith(b"__CLANG_OFFLOAD_BUNDLE__")     # a cache hit needs no compiler
+    with pytest.raises(jit.JitUnavailableError, match="ASYNCFLOW_NO_HIPCC"):
+        jit.code_object(specs[0].replace("-DAF_FJ_IPL=1", "-DAF_FJ_IPL=2"))

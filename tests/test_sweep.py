@@ -137,6 +137,25 @@ def test_invalid_points_are_rejected_by_the_payload_models():
         resolve_sweep(plan, {DOWN_T0: [18.0, 36.5], DOWN_T1: [24.0, 41.0]}, 2)
 
 
+def test_interior_points_are_validated_too():
+    """The reference validates every payload it runs (schemas/payload.py:20-252): so does a sweep of up to 10 000 distinct
+    points -- an invalid point between two valid extremes does not slip through (a fractional window)."""
+    from asyncflow_amd import runner
+
+    plan = lower(lb_with_events(users=200, horizon=60, scale=0.1))
+    with pytest.raises(ValueError, match="integer field"):
+        resolve_sweep(plan, {WINDOW: [60, 90.5, 120]}, 3)                              # an int field (rqs_generator.py:17-27)
+    # both outages overlap only at the MIDDLE point: the extremes are valid payloads
+    with pytest.raises(ValueError, match="not a valid payload"):
+        resolve_sweep(plan, {DOWN_T0: [18.0, 36.5, 20.0], DOWN_T1: [24.0, 41.0, 25.0]}, 3)
+    cols = {"rqs_input.avg_active_users.mean": np.repeat(np.arange(1.0, 41.0), 5)}    # 40 distinct points x 5 seeds
+    assert runner.validate_points(plan, {k: np.asarray(v) for k, v in cols.items()}, 200) == 40
+    many = {"rqs_input.avg_active_users.mean": np.linspace(10.0, 500.0, runner.VALIDATE_EVERY_POINT_UP_TO + 1)}
+    assert runner.validate_points(plan, many, len(many["rqs_input.avg_active_users.mean"])) == 2     # beyond: the extremes
+    with pytest.raises(ValueError, match="integer field"):                               # ... and integrality, whole column
+        resolve_sweep(plan, {WINDOW: np.where(np.arange(10_002) == 5_000, 60.5, 60.0)}, 10_002)
+
+
 @pytest.mark.parametrize("kernel", ["next-event", "flow"])
 def test_swept_points_match_the_oracle_run_on_the_written_out_payload(kernel):
     """Every new axis at once, on both kernel families (host builds: the next-event core for one lane, the
