@@ -227,15 +227,26 @@ enum : uint32_t { PROF_SETUP, PROF_GEN, PROF_SELECT, PROF_SERIES_RECV, PROF_STAT
 //                  step ends, FIFO of core waiters, FIFO of RAM waiters: Flow::gen_servers) up to the horizon of the station --
 //                  every arrival before it is known --, servers side by side in the lanes, and the departures it produced are
 //                  then sent by the whole wave like any other batch.  Two events of one server at one instant are handed back.
+//   FEAT_CHAIN     servers that feed servers (round 4; graph.py:135-157 forbids fan-out except at the LB, not server -> server
+//                  edges).  The servers are put in LEVELS (0: fed by the client / the LB only; k: its deepest feeding server is of
+//                  level k - 1) and the server station runs once per level and round, in level order, over the ONE server list:
+//                  a level's select() takes the entries whose target server is of that level, with the level's own horizon.
+//                  Everything a server of level k receives before min(horizon of the station in front of the servers, send floor
+//                  of every level below k) is in the list, because a request leaves a server no earlier than it arrived.  What a
+//                  level sends goes to the completion list or back into the server list, lane by lane.  Not together with a
+//                  least-connections LB or general servers.
 //   FEAT_PROF      measurement builds only: the wave's shader-clock time per section of run() (FlowArgs::prof)
 enum : uint32_t { FEAT_MARKS = 1u, FEAT_ONLINE = 2u, FEAT_HBM_RING = 4u, FEAT_FAR = 64u, FEAT_ALL = 7u | FEAT_FAR, FEAT_TIEBREAK = 8u,
-                  FEAT_BIGLIST = 16u, FEAT_LC = 32u, FEAT_PROF = 128u, FEAT_GENSRV = 256u };
+                  FEAT_BIGLIST = 16u, FEAT_LC = 32u, FEAT_PROF = 128u, FEAT_GENSRV = 256u, FEAT_CHAIN = 512u };
+constexpr uint32_t kMaxLevels = 3u;      // FEAT_CHAIN: server levels (af_flow_host.hpp refuses deeper plans)
+constexpr uint32_t kAnyLevel = 0xFFu;    // select(): no level filter
 template <class W, uint32_t IPL = 1u, uint32_t FEAT = FEAT_ALL>
 struct Flow {
     static constexpr bool kMarks = (FEAT & FEAT_MARKS) != 0u, kOnline = (FEAT & FEAT_ONLINE) != 0u,
                           kHbmRing = (FEAT & FEAT_HBM_RING) != 0u, kTieBreak = (FEAT & FEAT_TIEBREAK) != 0u,
                           kBig = (FEAT & FEAT_BIGLIST) != 0u, kLC = (FEAT & FEAT_LC) != 0u, kFar = (FEAT & FEAT_FAR) != 0u,
-                          kProf = (FEAT & FEAT_PROF) != 0u, kGen = (FEAT & FEAT_GENSRV) != 0u;
+                          kProf = (FEAT & FEAT_PROF) != 0u, kGen = (FEAT & FEAT_GENSRV) != 0u, kChain = (FEAT & FEAT_CHAIN) != 0u;
+    static_assert(!(kChain && (kGen || kLC)), "server levels: round-robin LB (or none), tandem servers");
     // FEAT_PROF: the time since the previous mark belongs to `section` (marks sit at the END of a section, in
     // wave-uniform control flow, with a compile-time section: the accumulators stay in scalar registers)
     unsigned long long prof_t, prof_acc[kProfSections];
@@ -264,11 +275,25 @@ struct Flow {
     AF_CORE void n_list_set(uint32_t s, uint32_t v) {
         if (s == 0u) nl0 = v; else if (s == 1u) nl1 = v; else if (s == 2u) nl2 = v; else nl3 = v;
     }
-    AF_CORE double H_get(uint32_t s) const { return s == 0u ? h0 : s == 1u ? h1 : s == 2u ? h2 : h3; }
+    // horizon slots: 0..3 = the four lists' stations; FEAT_CHAIN: 4, 5 = the server station of levels 1, 2 (level 0 is slot 2)
+    double h2b, h2c;
+    uint32_t n_levels;           // FEAT_CHAIN: levels the plan's servers form (wave-uniform), else 1
+    AF_CORE static constexpr uint32_t level_slot(uint32_t level) { return level == 0u ? 2u : 3u + level; }
+    AF_CORE double H_get(uint32_t s) const {
+        if (kChain && s >= 4u) return s == 4u ? h2b : h2c;
+        return s == 0u ? h0 : s == 1u ? h1 : s == 2u ? h2 : h3;
+    }
     AF_CORE void H_set(uint32_t s, double v) {
         if (kMarks) moved = moved || v > H_get(s);   // (without lookahead the last horizon is the slowest: run() watches h3)
+        if (kChain && s >= 4u) {
+            if (s == 4u) h2b = v; else h2c = v;
+            return;
+        }
         if (s == 0u) h0 = v; else if (s == 1u) h1 = v; else if (s == 2u) h2 = v; else h3 = v;
     }
+    // FEAT_CHAIN: a server's level, one byte per server in lbw()[20..23] (written once by run())
+    AF_CORE AF_PLAN_AS uint8_t* srv_levels() const { return (AF_PLAN_AS uint8_t*)(lbw() + 20); }
+    AF_CORE uint32_t level_of(uint32_t sv) const { return srv_levels()[sv]; }
     uint32_t n_comp, tick_base;
     double t_lim;                // FEAT_FAR: no station handles an event at or after this time in the current round (the tick ring's window)
     bool gen_done, moved;        // moved: a horizon advanced in this round
@@ -319,7 +344,7 @@ struct Flow {
     AF_CORE AF_PLAN_AS double* fr(uint32_t sv) const { return (AF_PLAN_AS double*)(M + o_fr()) + sv * A.L.c_ring; }
     AF_CORE AF_PLAN_AS double* gr(uint32_t sv) const { return (AF_PLAN_AS double*)(M + A.L.off_gr) + sv * A.L.g_ring; }
     AF_CORE AF_PLAN_AS uint32_t* sends() const { return (AF_PLAN_AS uint32_t*)(M + A.L.off_cnt); }
-    AF_CORE AF_PLAN_AS uint32_t* lbw() const { return sends() + ((A.n_edges + 1u) & ~1u); }  // [0..15] order, 16 head, 17 n_live, 18 mark cursor, 19 ceil(2^32 / n_live), then kSrvSlots each: LBW_ARRIVALS per server, LBW_SEG_OFF / LBW_SEG_LEN segment start / length, LBW_PROG step counts (leading I/O | CPU << 8 | trailing I/O << 16), LBW_SLOTS RAM slots (requests that fit at once)
+    AF_CORE AF_PLAN_AS uint32_t* lbw() const { return sends() + ((A.n_edges + 1u) & ~1u); }  // [0..15] order, 16 head, 17 n_live, 18 mark cursor, 19 ceil(2^32 / n_live), 20..23 FEAT_CHAIN: a level byte per server, then kSrvSlots each: LBW_ARRIVALS per server, LBW_SEG_OFF / LBW_SEG_LEN segment start / length, LBW_PROG step counts (leading I/O | CPU << 8 | trailing I/O << 16), LBW_SLOTS RAM slots (requests that fit at once)
     AF_CORE AF_PLAN_AS double* fcache() const { return (AF_PLAN_AS double*)(M + A.L.off_cnt + (A.n_edges + 1u) / 2u + LBW_U32 / 2u); }   // [4][3], send_floor
     AF_CORE AF_PLAN_AS int32_t* ring() const { return (AF_PLAN_AS int32_t*)(M + A.L.off_ring); }
     AF_CORE AF_PLAN_AS double* spike_cum() const { return (AF_PLAN_AS double*)(M + A.L.off_spike); }
@@ -498,14 +523,16 @@ struct Flow {
     // the spike its out-edges carry then, or a later mark's time plus the spike left after it.  A spike of s seconds
     // lets the next station run s seconds AHEAD of this one instead of piling up s seconds' worth of messages it may
     // not touch yet (conservative lookahead; f64 addition is monotone, so now >= h gives key >= the floor bit for bit).
-    AF_CORE double send_floor(uint32_t st, double h) {
+    // `cached` = false: work it out afresh and leave the station's cache alone (FEAT_CHAIN: the server levels call this with
+    // three different horizons per round, and the cache belongs to ONE non-decreasing sequence of them)
+    AF_CORE double send_floor(uint32_t st, double h, bool cached = true) {
         if (!(kMarks && A.n_edge_marks != 0u) || !(h < AF_INF)) return h;
         if (kLC && st == 2u) return h;   // lb_pick_lc counts the server list as "everything not delivered before t"
         // per station: [0] the next mark of its out-edges at or after the h this was worked out for, [1] the smallest
         // spike its out-edges carry until then, [2] the smallest (mark time + spike left after it) over the later marks
         AF_PLAN_AS double* c = fcache() + 3u * st;
         double until = c[0], sp_min = c[1], cand = c[2];
-        if (!(h < until)) {   // h passed a mark (or first call: the words start at 0): walk the marks again
+        if (!cached || !(h < until)) {   // h passed a mark (or first call: the words start at 0): walk the marks again
             until = cand = sp_min = AF_INF;
             const uint32_t n_out = st == 2u ? A.n_lb_edges : st == 3u ? A.n_servers : 1u;
             for (uint32_t k = 0u; k < n_out; ++k) {
@@ -526,7 +553,7 @@ struct Flow {
                 }
                 sp_min = sp < sp_min ? sp : sp_min;
             }
-            if (lane == 0u) {   // (read again a round later at the earliest: many W::sync() in between)
+            if (cached && lane == 0u) {   // (read again a round later at the earliest: many W::sync() in between)
                 c[0] = until;
                 c[1] = sp_min;
                 c[2] = cand;
@@ -610,10 +637,12 @@ struct Flow {
 
     // Rank the messages of list s with time < min(H_in, T); hand the `n_sel` earliest (<= room, <= 64) to
     // lanes 0..n_sel-1 in time order; keep the rest.  Returns n_sel.
-    AF_CORE uint32_t select(uint32_t s, double H_in, uint32_t room, double& okey, double& ot0, uint32_t& oaux) {
-        if (kBig) return select_big(s, H_in, room, okey, ot0, oaux);
+    // `hs`: the horizon slot of the station that selects (= s, except for the server levels of FEAT_CHAIN: level_slot());
+    // `level` != kAnyLevel: only the entries of the server list whose target server is of that level.
+    AF_CORE uint32_t select(uint32_t s, double H_in, uint32_t room, double& okey, double& ot0, uint32_t& oaux, uint32_t hs, uint32_t level = kAnyLevel) {
+        if (kBig) return select_big(s, H_in, room, okey, ot0, oaux, hs, level);
         W::sync();   // appends of the previous station are visible
-        const double lo = H_get(s);
+        const double lo = H_get(hs);
         const double hi_t = H_in < A.total_time ? H_in : A.total_time, hi = (kFar && t_lim < hi_t) ? t_lim : hi_t;   // (t_lim: run())
         const uint32_t n = n_list_get(s);
         okey = AF_INF;
@@ -621,7 +650,7 @@ struct Flow {
         oaux = 0u;
         if (!(hi > lo)) return 0u;
         if (n == 0u) {
-            H_set(s, hi);
+            H_set(hs, hi);
             return 0u;
         }
         AF_PLAN_AS double* K = list_key(s);
@@ -652,7 +681,7 @@ struct Flow {
                 t[q] = T0[i];
                 if (kTieBreak) sent[q] = TS[i];
                 a[q] = (s == 2u || (kFar && s == 3u)) ? AX[i] : 0u;
-                elig[q] = valid[q] && k[q] < hi;
+                elig[q] = valid[q] && k[q] < hi && (!kChain || level == kAnyLevel || level_of(a[q] & (kSrvSlots - 1u)) == level);
                 double x = (k[q] - lo) * sc;
                 x = x < 63.0 ? x : 63.0;        // (also what a NaN from a stale entry becomes)
                 b[q] = x > 0.0 ? (uint32_t)x : 0u;
@@ -727,7 +756,7 @@ struct Flow {
         }
         n_list_set(s, kept);
         W::sync();
-        H_set(s, n_sel < E ? scal()[0] : hi);
+        H_set(hs, n_sel < E ? scal()[0] : hi);
         if (lane < n_sel) {
             okey = out_key()[lane];
             ot0 = out_t0()[lane];
@@ -739,9 +768,9 @@ struct Flow {
     // The same selection for lists of any length (FEAT_BIGLIST): the list is walked in chunks of 64, what select()
     // keeps in registers lives in a u32 per entry (bucket | slot, then the rank), and exact ranks are only worked out
     // for the buckets that can reach the first n_sel places (or hold the first message left behind).
-    AF_CORE uint32_t select_big(uint32_t s, double H_in, uint32_t room, double& okey, double& ot0, uint32_t& oaux) {
+    AF_CORE uint32_t select_big(uint32_t s, double H_in, uint32_t room, double& okey, double& ot0, uint32_t& oaux, uint32_t hs, uint32_t level) {
         W::sync();
-        const double lo = H_get(s);
+        const double lo = H_get(hs);
         const double hi_t = H_in < A.total_time ? H_in : A.total_time, hi = (kFar && t_lim < hi_t) ? t_lim : hi_t;   // (t_lim: run())
         const uint32_t n = n_list_get(s);
         okey = AF_INF;
@@ -749,7 +778,7 @@ struct Flow {
         oaux = 0u;
         if (!(hi > lo)) return 0u;
         if (n == 0u) {
-            H_set(s, hi);
+            H_set(hs, hi);
             return 0u;
         }
         AF_PLAN_AS double* K = list_key(s);
@@ -768,7 +797,7 @@ struct Flow {
             if (i < n) {
                 const double k = K[i];
                 uint32_t w = kNone;
-                if (k < hi) {
+                if (k < hi && (!kChain || level == kAnyLevel || level_of(AX[i] & (kSrvSlots - 1u)) == level)) {
                     double x = (k - lo) * sc;
                     x = x < 63.0 ? x : 63.0;
                     const uint32_t b = x > 0.0 ? (uint32_t)x : 0u;
@@ -854,7 +883,7 @@ struct Flow {
         }
         n_list_set(s, kept);
         W::sync();
-        H_set(s, n_sel < E ? scal()[0] : hi);
+        H_set(hs, n_sel < E ? scal()[0] : hi);
         if (lane < n_sel) {
             okey = out_key()[lane];
             ot0 = out_t0()[lane];
@@ -1514,6 +1543,16 @@ struct Flow {
                     g[GS_IO] = 0xFFFFFFFF00000000ull;                                  // every slot free
                     g[GS_RAM] = blob[A.off_srv + af::SREC * v];
                 }
+            if (kChain) {   // levels: a server fed by a server of level k is of level k + 1 at least (the host checked: no cycle, <= kMaxLevels)
+                AF_PLAN_AS uint8_t* lv = srv_levels();   // (zeroed with the layout words)
+                for (uint32_t pass = 0u; pass + 1u < kMaxLevels; ++pass)
+                    for (uint32_t v = 0u; v < A.n_servers; ++v) {
+                        const uint64_t tw = erec((uint32_t)(blob[A.off_srv + af::SREC * v + 1u] >> 16) & 0xFFFFu)[3];
+                        if (((uint32_t)tw & 0xFFu) != af::NODE_SERVER) continue;
+                        const uint32_t w = (uint32_t)(tw >> 8) & 0xFFu;
+                        if (lv[w] < lv[v] + 1u) lv[w] = (uint8_t)(lv[v] + 1u);
+                    }
+            }
             for (uint32_t i = 0u; i < A.n_lb_edges; ++i) lw[i] = (uint32_t)blob[A.off_lb + i];
             lw[16] = 0u;
             lw[17] = A.n_lb_edges;
@@ -1534,6 +1573,10 @@ struct Flow {
         gen_done = false;
         nl0 = nl1 = nl2 = nl3 = 0u;
         h0 = h1 = h2 = h3 = 0.0;
+        h2b = h2c = 0.0;
+        n_levels = 1u;
+        if (kChain)
+            for (uint32_t v = 0u; v < A.n_servers; ++v) n_levels = level_of(v) + 1u > n_levels ? level_of(v) + 1u : n_levels;
         const uint32_t cap = kCt ? kCap : A.L.cap;
         const uint32_t first_srv_stage = A.has_lb ? 1u : 2u;   // where the client's out-edge leads
 
@@ -1558,12 +1601,16 @@ struct Flow {
 #else
 #pragma nounroll
 #endif
-            for (uint32_t st = 0u; st < 5u; ++st) {
+            // (FEAT_CHAIN: the server station once per level, in level order -- stx counts the passes, st is the station)
+            for (uint32_t stx = 0u; stx < (kChain ? 4u + kMaxLevels : 5u); ++stx) {
+                const uint32_t st = !kChain ? stx : stx < 3u ? stx : stx < 3u + kMaxLevels ? 3u : 4u;
+                const uint32_t level = (kChain && st == 3u) ? stx - 3u : 0u;
+                if (kChain && st == 3u && level >= n_levels) continue;
                 if (st == 2u && !A.has_lb) continue;
                 // ---- the station's batch: lane r < n_sel holds (key = event time, t0 = start time, aux)
                 double key = 0.0, t0 = 0.0;
                 uint32_t aux = 0u, n_sel;
-                const uint32_t nxt = st == 0u ? 0u : st == 1u ? first_srv_stage : st;   // list the results go to (st < 4)
+                const uint32_t nxt = st == 0u ? 0u : st == 1u ? first_srv_stage : st;   // list the results go to (st < 4; FEAT_CHAIN, servers: see the appends)
                 if (st == 0u) {   // generator (rqs_generator.py:97-119): up to 64 arrivals
                     uint32_t room = (kBig ? cap_of(0u) : cap) - nl0;
                     room = room < 64u ? room : 64u;
@@ -1576,7 +1623,10 @@ struct Flow {
                     n_sel = popc64(vm);
                     key = t0;
                 } else {
-                    n_sel = select(st - 1u, H_in, st == 4u ? 64u : (kBig ? cap_of(nxt) : cap) - n_list_get(nxt), key, t0, aux);
+                    // (FEAT_CHAIN: what a level sends back into the server list takes the places its own selection left there,
+                    // so the room that binds is the completion list's)
+                    n_sel = select(st - 1u, H_in, st == 4u ? 64u : (kBig ? cap_of(nxt) : cap) - n_list_get(nxt), key, t0, aux,
+                                   (kChain && st == 3u) ? level_slot(level) : st - 1u, (kChain && st == 3u) ? level : kAnyLevel);
                 }
                 if (st == 0u) prof(PROF_GEN);
                 else prof(PROF_SELECT);
@@ -1593,7 +1643,7 @@ struct Flow {
                 if (kFar && cnt_in) add_point(st == 1u ? A.gen_out_edge : st == 2u ? A.client_out_edge : st == 3u ? aux >> 8 : aux, row, -1);
                 // ---- what the station does with it: the out-edge, the message's index on it, the send time
                 prof(PROF_SERIES_RECV);
-                bool sending = have, pre = false;
+                bool sending = have, pre = false, to_srv = false;   // to_srv (FEAT_CHAIN): my server's out-edge leads to a server
                 uint32_t e = 0u, idx = 0u, tgt = 0u;
                 double ts = key, pre_tr = 0.0;
                 if (st == 0u) {
@@ -1696,6 +1746,11 @@ struct Flow {
                         if (have) {
                             const uint64_t meta = blob[A.off_srv + af::SREC * sv + 1u];
                             e = (uint32_t)(meta >> 16) & 0xFFFFu;
+                            if (kChain) {
+                                const uint64_t tw = erec(e)[3];
+                                to_srv = ((uint32_t)tw & 0xFFu) == af::NODE_SERVER;
+                                tgt = (uint32_t)(tw >> 8) & 0xFFu;
+                            }
                             const uint32_t ep = (uint32_t)(meta >> 32) & 0xFFFFu;
                             const double ram = u2d(blob[A.off_ep + af::PREC * ep]);
                             const uint32_t s0 = A.n_edges + 3u * sv;
@@ -1743,9 +1798,18 @@ struct Flow {
                     const bool ok = sent && send_finish(e, ts, row, st == 3u, transit, k2, counted);
                     prof(PROF_SEND_SERIES);
                     // (server list: the server and the edge the message comes by; completion list: the server's out-edge)
-                    append(nxt, ok, k2, (kFar && counted) ? -t0 : t0, !kFar ? tgt : st == 3u ? e : tgt | (e << 8), ts);
-                    if (st > 0u) H_in = H_get(st - 1u);
-                    H_in = send_floor(st, H_in);   // what the next station may touch: everything delivered before this
+                    if (kChain && st == 3u) {   // lane by lane: to the client, or to a server of a deeper level
+                        append(3u, ok && !to_srv, k2, (kFar && counted) ? -t0 : t0, e, ts);
+                        append(2u, ok && to_srv, k2, (kFar && counted) ? -t0 : t0, !kFar ? tgt : tgt | (e << 8), ts);
+                        // what the deeper levels (and the client) may touch: everything the station in front of the servers AND
+                        // every level so far delivered before it (the cache of send_floor belongs to level 0's horizon)
+                        const double fl = send_floor(3u, H_get(level_slot(level)), level == 0u);
+                        H_in = fl < H_in ? fl : H_in;
+                    } else {
+                        append(nxt, ok, k2, (kFar && counted) ? -t0 : t0, !kFar ? tgt : st == 3u ? e : tgt | (e << 8), ts);
+                        if (st > 0u) H_in = H_get(st - 1u);
+                        H_in = send_floor(st, H_in);   // what the next station may touch: everything delivered before this
+                    }
                     prof(PROF_APPEND);
                 }
             }
@@ -1757,6 +1821,8 @@ struct Flow {
                 h_min = h_min < h0 ? h_min : h0;
                 h_min = (A.has_lb && h1 < h_min) ? h1 : h_min;
                 h_min = h_min < h2 ? h_min : h2;
+                if (kChain && n_levels > 1u) h_min = h_min < h2b ? h_min : h2b;
+                if (kChain && n_levels > 2u) h_min = h_min < h2c ? h_min : h2c;
             }
             const bool finished = gen_done && work == 0u && !(h_min < T);
             W::sync();

@@ -29,6 +29,37 @@ inline bool flow_needs_general_servers(const af_plan_t& p) {
     return false;
 }
 
+// Servers that feed servers (FEAT_CHAIN, round 4): level 0 = fed by the client / the load balancer only, level k = its deepest
+// feeding server is of level k - 1.  Returns the number of levels (1: no server feeds a server), 0 when the servers feed each
+// other in a cycle; `level` (may be null) gets each server's level.  (Flow::run works the same levels out on the device.)
+inline uint32_t flow_server_levels(const af_plan_t& p, uint32_t* level) {
+    std::vector<uint32_t> lv(p.n_servers, 0u);
+    uint32_t deepest = 0u;
+    for (uint32_t pass = 0; pass <= p.n_servers; ++pass) {
+        bool changed = false;
+        for (uint32_t s = 0; s < p.n_servers; ++s) {
+            const int32_t e = p.srv_out_edge[s];
+            if (p.edge_target_kind[e] != AF_NODE_SERVER) continue;
+            const uint32_t w = (uint32_t)p.edge_target_idx[e];
+            if (lv[w] < lv[s] + 1u) {
+                lv[w] = lv[s] + 1u;
+                changed = true;
+                deepest = lv[w] > deepest ? lv[w] : deepest;
+            }
+        }
+        if (!changed) break;
+        if (pass == p.n_servers) return 0u;   // still growing after n_servers passes: a cycle
+    }
+    if (level)
+        for (uint32_t s = 0; s < p.n_servers; ++s) level[s] = lv[s];
+    return deepest + 1u;
+}
+inline bool flow_needs_chain(const af_plan_t& p) {
+    for (uint32_t s = 0; s < p.n_servers; ++s)
+        if (p.edge_target_kind[p.srv_out_edge[s]] == AF_NODE_SERVER) return true;
+    return false;
+}
+
 // Empty string: the plan's request path is the feed-forward chain the flow kernel implements.
 // Otherwise the reason it is not (the sequential next-event kernels run such plans).
 inline std::string flow_ineligible_reason(const af_plan_t& p) {
@@ -52,13 +83,20 @@ inline std::string flow_ineligible_reason(const af_plan_t& p) {
     // room: rate x 1 s messages wait at a station -- plan_flow sizes the lists for it, an overflow is handed back.
     // 150 fuzzed payloads with 1-3 Poisson edges on the wave emulator: 0 mismatches, 1 tie: tests/test_flow_hostcheck.py.)
     for (uint32_t s = 0; s < p.n_servers; ++s) {
-        if (p.edge_target_kind[p.srv_out_edge[s]] != AF_NODE_CLIENT) return "server chain";
+        if (p.edge_target_kind[p.srv_out_edge[s]] == AF_NODE_LB) return "a server feeds the load balancer";
         if (p.srv_cores[s] > 64u) return "more than 64 cores";
         // (the tick ring holds integer differences: RAM needs in whole MB, or in multiples of 1/256 MB -- flow_ram_scale)
         for (uint32_t ep = p.srv_ep_begin[s]; ep < p.srv_ep_begin[s + 1]; ++ep) {
             const double ram = p.ep_ram[ep], fine = ram * 256.0;
             if (fine != std::floor(fine) || ram < 0.0 || ram > 4194304.0) return "RAM need is not a multiple of 1/256 MB";
         }
+    }
+    if (flow_needs_chain(p)) {   // (round 4: the server station once per level -- af_flow.hpp, FEAT_CHAIN)
+        if (p.has_lb && p.lb_algo == AF_LB_LEAST_CONNECTIONS) return "server chain behind a least-connections load balancer";
+        if (flow_needs_general_servers(p)) return "server chain with several endpoints per server";
+        const uint32_t levels = flow_server_levels(p, nullptr);
+        if (levels == 0u) return "servers feed each other in a cycle";
+        if (levels > kMaxLevels) return "server chain deeper than three levels";
     }
     if (flow_needs_general_servers(p) && p.n_endpoints + p.n_steps > 65535u) return "more step rows than a request record addresses";
     return std::string();

@@ -898,7 +898,7 @@ struct af_engine {
     // stage-parallel kernel (af_flow.hpp)
     void* d_codes = nullptr;   // analyzer scratch (af_engine_summarize)
     size_t codes_bytes = 0;
-    bool flow_ok = false, flow_general_servers = false;
+    bool flow_ok = false, flow_general_servers = false, flow_chain = false;   // flow_chain: servers feed servers (FEAT_CHAIN)
     std::string flow_reason;
     uint32_t flow_mode = 0, flow_list_entries = 0, flow_ring_rows = 0;
     aff::FlowArgs fargs{};
@@ -1314,10 +1314,14 @@ int plan_flow(const af_engine* e, const KArgs& a, const af_sweep_t* sweep, const
     // injected spikes / outages, but neither the kernel-side summary nor tick differences in HBM (BASELINE config 4)
     const bool marks_only = !lean && !has_online && ring_ok;
     constexpr uint32_t kRobust = aff::FEAT_ALL | aff::FEAT_TIEBREAK | aff::FEAT_BIGLIST;
-    P.lean = lean && !flow_big && !lc;
+    const bool chain = e->flow_chain;   // (never with lc / gen_srv: flow_ineligible_reason)
+    P.lean = lean && !flow_big && !lc && !chain;
     if (flow_big) {
         P.ipl = 1u;
-        P.feat = kRobust | (lc ? (uint32_t)aff::FEAT_LC : 0u) | (gen_srv ? (uint32_t)aff::FEAT_GENSRV : 0u);
+        P.feat = kRobust | (lc ? (uint32_t)aff::FEAT_LC : 0u) | (gen_srv ? (uint32_t)aff::FEAT_GENSRV : 0u) | (chain ? (uint32_t)aff::FEAT_CHAIN : 0u);
+    } else if (chain) {   // one generic instantiation per list length (every optional feature in); the plan-specialised build is the same FEAT
+        P.ipl = FL.cap == 64u ? 1u : FL.cap == 128u ? 2u : 4u;
+        P.feat = aff::FEAT_ALL | aff::FEAT_CHAIN;
     } else if (lc) {
         P.ipl = FL.cap == 64u ? 1u : FL.cap == 128u ? 2u : 4u;
         P.feat = aff::FEAT_ALL | aff::FEAT_LC;
@@ -1340,6 +1344,10 @@ const void* flow_kernel_for(uint32_t ipl, uint32_t feat) {
     AF_FLOW_CASE(1u, kRobust);
     AF_FLOW_CASE(1u, kRobust | kLC | (uint32_t)aff::FEAT_GENSRV);
     AF_FLOW_CASE(1u, kRobust | (uint32_t)aff::FEAT_GENSRV);
+    AF_FLOW_CASE(1u, kRobust | (uint32_t)aff::FEAT_CHAIN);   // servers that feed servers: the second-chance form and one per list length
+    AF_FLOW_CASE(1u, kAll | (uint32_t)aff::FEAT_CHAIN);
+    AF_FLOW_CASE(2u, kAll | (uint32_t)aff::FEAT_CHAIN);
+    AF_FLOW_CASE(4u, kAll | (uint32_t)aff::FEAT_CHAIN);
     AF_FLOW_CASE(1u, kAll | kLC);
     AF_FLOW_CASE(2u, kAll | kLC);
     AF_FLOW_CASE(4u, kAll | kLC);
@@ -1503,6 +1511,7 @@ int af_engine_create(const af_plan_t* plan, int device, const af_engine_options_
     e->flow_reason = aff::flow_ineligible_reason(*plan);
     e->flow_ok = e->flow_reason.empty();
     e->flow_general_servers = e->flow_ok && aff::flow_needs_general_servers(*plan);
+    e->flow_chain = e->flow_ok && aff::flow_needs_chain(*plan);
     e->has_lb = plan->has_lb;
     e->gen_edge = plan->gen_out_edge;
     e->client_edge = plan->client_out_edge;
@@ -2041,6 +2050,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
                 }
                 constexpr uint32_t kRobust = aff::FEAT_ALL | aff::FEAT_TIEBREAK | aff::FEAT_BIGLIST;
                 const void* fn2 = f2.lb_least_connections ? reinterpret_cast<const void*>(af_flow_kernel<1, kRobust | aff::FEAT_LC>)
+                                  : e->flow_chain         ? reinterpret_cast<const void*>(af_flow_kernel<1, kRobust | aff::FEAT_CHAIN>)
                                                           : reinterpret_cast<const void*>(af_flow_kernel<1, kRobust>);
                 if (lds2 > 48u * 1024u) HIP_TRY(hipFuncSetAttribute(fn2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
                 HIP_TRY(hipEventRecord(e->ev3, e->stream));

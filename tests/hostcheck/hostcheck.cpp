@@ -275,8 +275,14 @@ extern "C" int hc_flow_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ov
     const bool marks_only = !lean && !g_online_hist && !g_online_rps && (a.L.ring_rows != 0 || !samples);   // (engine.hip: config-4-like launches)
     constexpr uint32_t kAll = aff::FEAT_ALL, kRobust = aff::FEAT_ALL | aff::FEAT_TIEBREAK | aff::FEAT_BIGLIST, kLC = aff::FEAT_LC;
     constexpr uint32_t kGen = aff::FEAT_GENSRV;
+    const bool chain = aff::flow_needs_chain(*p);   // servers feed servers: the FEAT_CHAIN instantiations (engine.hip: plan_flow)
+    constexpr uint32_t kChain = aff::FEAT_CHAIN;
     auto body = [&]() {
-        if (gen_srv && lc) { aff::Flow<emu::WaveEmu, 1, kRobust | kLC | kGen> f(a); f.run(lds.data(), 0u); }
+        if (chain && robust) { aff::Flow<emu::WaveEmu, 1, kRobust | kChain> f(a); f.run(lds.data(), 0u); }
+        else if (chain && ipl == 1) { aff::Flow<emu::WaveEmu, 1, kAll | kChain> f(a); f.run(lds.data(), 0u); }
+        else if (chain && ipl == 2) { aff::Flow<emu::WaveEmu, 2, kAll | kChain> f(a); f.run(lds.data(), 0u); }
+        else if (chain) { aff::Flow<emu::WaveEmu, 4, kAll | kChain> f(a); f.run(lds.data(), 0u); }
+        else if (gen_srv && lc) { aff::Flow<emu::WaveEmu, 1, kRobust | kLC | kGen> f(a); f.run(lds.data(), 0u); }
         else if (gen_srv) { aff::Flow<emu::WaveEmu, 1, kRobust | kGen> f(a); f.run(lds.data(), 0u); }
         else if (robust && lc) { aff::Flow<emu::WaveEmu, 1, kRobust | kLC> f(a); f.run(lds.data(), 0u); }
         else if (robust) { aff::Flow<emu::WaveEmu, 1, kRobust> f(a); f.run(lds.data(), 0u); }

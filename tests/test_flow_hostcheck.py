@@ -24,7 +24,7 @@ from asyncflow_amd import _abi
 from asyncflow_amd.plan import lower
 from asyncflow_amd.workloads import fanout8, lb_two_servers, lb_with_events, single_server, single_server_with_spike
 from oracle import oracle_lib as ol
-from oracle.scenarios import flow_payload, server_chain, stress_mixed, wide_fanout
+from oracle.scenarios import flow_payload, server_chain, server_tiers, stress_mixed, wide_fanout
 from tests.conftest import GOLDEN_DIR
 from tests.hostcheck import build as hc
 
@@ -116,10 +116,52 @@ def test_small_lists_hand_the_scenario_back_instead_of_dropping_messages():
 def test_plans_outside_the_feed_forward_range_are_refused():
     odd_ram = lb_two_servers(horizon=10)
     odd_ram["topology_graph"]["nodes"]["servers"][0]["endpoints"][0]["steps"][1]["step_operation"]["necessary_ram"] = 100.1
-    for payload, word in ((odd_ram, "1/256 MB"), (wide_fanout(horizon=12), "16 servers"),
-                          (server_chain("exponential", 0.003), "server chain")):
+    lc_chain = server_chain("exponential", 0.003)        # servers feeding servers run there since round 3 -- behind a round-robin LB
+    lc_chain["topology_graph"]["nodes"]["load_balancer"] = {"id": "lb", "algorithms": "least_connection", "server_covered": ["s0"]}
+    for e in lc_chain["topology_graph"]["edges"]:
+        if e["id"] == "c-s0":
+            e["target"] = "lb"
+    lc_chain["topology_graph"]["edges"].append({"id": "lb-s0", "source": "lb", "target": "s0", "latency": {"mean": 0.003, "distribution": "exponential"}})
+    for payload, word in ((odd_ram, "1/256 MB"), (wide_fanout(horizon=12), "16 servers"), (lc_chain, "least-connections")):
         assert hc.flow_simulate(lower(payload), 1) is None
         assert word in hc.flow_reason()
+
+
+# ------------------------------------------------------------------------------------------------ servers that feed servers
+def test_server_tiers_run_level_by_level():
+    """FEAT_CHAIN (round 3): client -> s0 -> s1 -> client.  The servers are put in levels and the server station runs once
+    per level and round over the ONE server list, each level with its own horizon: everything a level-k server receives
+    before the horizon of level k - 1 is in the list, because a request leaves a server no earlier than it arrived.
+    Every instantiation the engine would launch (64- / 128-entry lists, LDS ring / differences in HBM, the second-chance
+    form) against the oracle: counts, every (start, finish) pair, every sample."""
+    p = server_chain("exponential", 0.003, cores=2, horizon=20)
+    for s in p["topology_graph"]["nodes"]["servers"]:                     # (continuous step times: server_chain's are dyadic tie makers)
+        for st in s["endpoints"][0]["steps"]:
+            op = st["step_operation"]
+            for k in ("cpu_time", "io_waiting_time"):
+                if k in op:
+                    op[k] = op[k] * 0.013
+    p["rqs_input"]["avg_active_users"]["mean"] = 80
+    for kw in (dict(ipl=1, ring_rows=64), dict(ipl=2, ring_rows=0), dict(robust=True, ring_rows=0)):
+        status, want = _run(p, 7, **kw)
+        assert status == "exact" and want.completed > 1000, (kw, status)
+
+
+@pytest.mark.parametrize("block", range(3))
+def test_fuzzed_server_tiers_are_exact_or_handed_back(block):
+    """oracle/scenarios.py::server_tiers: [LB ->] front servers -> [middle ->] backend -> client in up to three levels, server
+    indices in any order, a front server may answer the client itself, the LB may feed the backend too, four latency
+    laws, RAM pressure, dyadic RAM needs, a spike on any edge, outages.  The lean form may hand back (second-long
+    log-normal hops outgrow 128-entry lists); the second-chance form with long lists must not."""
+    exact = 0
+    for case in range(block * 20, block * 20 + 20):
+        rng = random.Random(91000 + case)
+        p = server_tiers(rng)
+        status, _ = _run(p, 300 + case, ipl=2, ring_rows=64)
+        assert status in ("exact", "fallback")
+        exact += status == "exact"
+        assert _run(p, 300 + case, robust=True, ring_rows=0, long_list_entries=1024)[0] == "exact", case
+    assert exact >= 14
 
 
 @pytest.mark.parametrize("block", range(6))

@@ -624,6 +624,34 @@ def test_poisson_latencies_and_wide_round_robin_fan_out_run_on_the_flow_kernel()
     _same_batches(res, special)
 
 
+def test_servers_that_feed_servers_run_on_the_flow_kernel():
+    """Round 4: server -> server edges are inside the stage-parallel kernel's range (FEAT_CHAIN: the servers in
+    levels, the server station once per level and round over the one server list, each level with its own horizon).
+    Fuzzed tiers -- [LB ->] front servers -> [middle ->] backend -> client, up to three levels, spikes and outages -- against the
+    oracle and against the next-event kernels, generic and plan-specialised builds; what the lean launch hands back (second-long
+    log-normal hops outgrow its lists) is caught by the second-chance launch, itself a FEAT_CHAIN instantiation."""
+    from oracle.scenarios import server_tiers
+
+    stayed = total = 0
+    for k in range(10):
+        payload = server_tiers(random.Random(91000 + k), horizon=12)
+        seeds = np.arange(8, dtype=np.uint64) + 50 * k
+        res = _runner(payload, seeds=seeds).run()
+        st = res.engine_stats
+        assert res.flow_reason == "" and st.flow_scenarios == 8, res.flow_reason
+        stayed += 8 - st.flow_to_next_event
+        total += 8
+        plan = lower(payload)
+        for i in (0, 7):
+            _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])), f"tiers {k} scenario {i}")
+        _same_batches(res, _runner(payload, seeds=seeds, flow=False).run())
+        if k < 3:
+            special = _runner(payload, seeds=seeds, specialise=True).run()
+            assert special.engine_stats.specialised_launches >= 1
+            _same_batches(res, special)
+    assert stayed >= total - 4, f"{stayed} of {total} scenarios stayed on the stage-parallel kernel"
+
+
 def test_several_endpoints_per_server_run_on_the_flow_kernel():
     """Round 3: plans whose servers have several endpoints, come back to the core queue after an I/O step or need
     different amounts of RAM per request run on the stage-parallel kernel (its server station simulates each server event by
