@@ -96,7 +96,9 @@ enum : uint32_t { GS_CPU = 0u /* cpu_free | ready << 32 */, GS_IO = 1u /* io | f
                   GS_LAST = 8u /* f64 time of the server's previous event */, GS_LASTDEP = 9u /* f64 time of its previous departure */,
                   GS_T0 = 10u, GS_NEED = GS_T0 + kGsSlots, GS_STATE = GS_NEED + kGsSlots /* row | holds core << 16 | in I/O << 17 */,
                   GS_EVT = GS_STATE + kGsSlots /* sorted ring of pending step ends: time */, GS_BYTES = GS_EVT + kGsSlots /* 4 x kGsSlots bytes: event slots, CPU waiters, RAM waiters, where each pending step end was created */,
-                  GS_DEPT = GS_BYTES + (4u * kGsSlots + 7u) / 8u, GS_DEPT0 = GS_DEPT + kGsDeps, kGsWords = GS_DEPT0 + kGsDeps };
+                  GS_DEPT = GS_BYTES + (4u * kGsSlots + 7u) / 8u, GS_DEPT0 = GS_DEPT + kGsDeps,
+                  GS_MQ = GS_DEPT0 + kGsDeps /* kGsMq bytes: the zero-time steps queued at a shared instant (Flow::gs_instant) */, kGsWords = GS_MQ + 8u };
+constexpr uint32_t kGsMq = 64u;   // zero-time steps queued at one instant of one server (more: handed back)
 
 inline FlowLayout make_flow_layout(uint32_t cap, uint32_t ring_rows, uint32_t g_ring, uint32_t c_ring, uint32_t n_edges,
                                    uint32_t n_servers, uint32_t n_edge_marks, bool tiebreak = false,
@@ -1330,6 +1332,185 @@ struct Flow {
             gs_advance(g, sv, slot, now, rown, again);   // (an endpoint of RAM steps only gives its RAM straight back: the loop looks again)
         }
     }
+    // ---- a SHARED instant of one server: several of its step ends at `now` (round 4) ----------------------------------------
+    // Step times are constants of the plan, so once requests queue for a core the step ends of different requests coincide bit
+    // for bit, and what happens next depends on the order SimPy runs the zero-time steps of the tied cascades in -- which request
+    // stands first in the core queue, whose Timeout is created first (and so wins the NEXT tie), whose response goes out first.
+    // SimPy's rule (heap key: time, priority, event id): every Timeout of the instant runs before anything the
+    // instant itself schedules (they were created earlier: smaller ids), in creation order; whatever a step schedules "now" --
+    // the Put that gives a core or the RAM back, the Get a waiter was granted -- goes to the back of ONE FIFO and its
+    // continuation runs when it reaches the front.  That is af_core.hpp's micro_mode, restricted to what one server sees: events
+    // of other nodes at the same instant touch other state, and a server's events only ever schedule events of that server, so
+    // the server's subsequence of the global FIFO evolves exactly like a FIFO of its own.  The steps, in the reference's words:
+    //   GM_STEP      a step's Timeout fires: the for-loop of _handle_request moves on (server.py:197-259)
+    //   GM_CPU_GOT   `yield cpu_req` returns (server.py:220-231; _W: the request had been counted in the ready queue)
+    //   GM_PUT_IO    `yield CPU.put(1)` before an I/O step returns: the Put's first callback grants waiters, then the step starts (:239-255)
+    //   GM_PUT_END   `yield CPU.put(1)` at the end of the endpoint returns (:257-259)
+    //   GM_RAM_PUT   `yield RAM.put(total_ram)` returns: waiters are admitted, the response leaves (:270-276)
+    //   GM_RAM_GOT   `yield RAM.get(total_ram)` returns (:146-150)
+    // The order in which this schedules new Timeouts IS their creation order, so later ties among them are exact too.
+    enum : uint32_t { GM_STEP = 0u, GM_CPU_GOT = 1u, GM_CPU_GOT_W = 2u, GM_PUT_IO = 3u, GM_PUT_END = 4u, GM_RAM_PUT = 5u, GM_RAM_GOT = 6u };
+    uint32_t gm_head, gm_n;
+    AF_CORE void gm_push(AF_PLAN_AS uint64_t* g, uint32_t kind, uint32_t slot) {
+        if (gm_n >= kGsMq) {
+            why |= FLOW_WHY_LIST;
+            return;
+        }
+        ((AF_PLAN_AS uint8_t*)(g + GS_MQ))[(gm_head + gm_n) & (kGsMq - 1u)] = (uint8_t)((kind << 5) | slot);
+        gm_n += 1u;
+    }
+    AF_CORE void gm_emit(AF_PLAN_AS uint64_t* g, uint32_t slot, double now, double dur) {
+        if (!(now + dur > now)) why |= FLOW_WHY_TIE;   // (a step too short to advance the f64 clock: SimPy queues it behind the instant's steps)
+        gs_schedule(g, now + dur, slot);
+    }
+    // Container._trigger_get of the CPU container: waiters are served FIFO while cores are free; the first n_old entries had
+    // been counted in the ready queue.  Returns the number of grants.
+    AF_CORE uint32_t gm_cpu_trigger(AF_PLAN_AS uint64_t* g, uint32_t n_old) {
+        uint32_t grants = 0u;
+        for (;;) {
+            const uint32_t head = lo32(g[GS_CQ]), n = hi32(g[GS_CQ]);
+            if (n == 0u || lo32(g[GS_CPU]) == 0u) return grants;
+            const uint32_t slot = gs_bytes(g, 1u)[head];
+            g[GS_CQ] = pack32((head + 1u) & (kGsSlots - 1u), n - 1u);
+            g[GS_CPU] = g[GS_CPU] - 1ull;   // level -= 1
+            gm_push(g, grants < n_old ? GM_CPU_GOT_W : GM_CPU_GOT, slot);
+            grants += 1u;
+        }
+    }
+    AF_CORE void gm_ram_trigger(AF_PLAN_AS uint64_t* g) {   // head-of-line blocking FIFO
+        for (;;) {
+            const uint32_t head = lo32(g[GS_RQ]), n = hi32(g[GS_RQ]);
+            if (n == 0u) return;
+            const uint32_t slot = gs_bytes(g, 2u)[head];
+            const double need = u2d(g[GS_NEED + slot]), free_ram = u2d(g[GS_RAM]);
+            if (free_ram < need) return;
+            g[GS_RQ] = pack32((head + 1u) & (kGsSlots - 1u), n - 1u);
+            g[GS_RAM] = d2u(free_ram - need);
+            gm_push(g, GM_RAM_GOT, slot);
+        }
+    }
+    AF_CORE void gm_depart(AF_PLAN_AS uint64_t* g, uint32_t slot, double now) {
+        const uint32_t nd = lo32(g[GS_DEP]);
+        if (nd >= kGsDeps) {
+            why |= FLOW_WHY_LIST;
+            return;
+        }
+        g[GS_LASTDEP] = d2u(now);
+        g[GS_DEPT + nd] = d2u(now);
+        g[GS_DEPT0 + nd] = g[GS_T0 + slot];
+        g[GS_DEP] = pack32(nd + 1u, hi32(g[GS_DEP]));
+        g[GS_IO] = g[GS_IO] | (1ull << (32u + slot));   // the slot is free again
+    }
+    AF_CORE void gm_finish(AF_PLAN_AS uint64_t* g, uint32_t s0, uint32_t slot, bool in_io, double now, uint32_t rown) {   // server.py:261-276
+        if (in_io) {
+            g[GS_IO] = g[GS_IO] - 1ull;
+            gs_point(s0 + 1u, rown, -1);
+        }
+        const double need = u2d(g[GS_NEED + slot]);
+        if (need > 0.0) {
+            g[GS_RAM] = d2u(u2d(g[GS_RAM]) + need);   // (ContainerPut succeeds at once; its continuation is queued)
+            gs_point(s0 + 2u, rown, -(int32_t)(need * A.ram_scale));
+            gm_push(g, GM_RAM_PUT, slot);
+            return;
+        }
+        gm_depart(g, slot, now);
+    }
+    // the for-loop of _handle_request from step row `row` up to its next yield (server.py:197-259)
+    AF_CORE void gm_continue(AF_PLAN_AS uint64_t* g, uint32_t s0, uint32_t slot, uint32_t row, bool holds, bool in_io, double now, uint32_t rown) {
+        const uint32_t kind = (uint32_t)blob[A.off_row + af::TREC * row + 2u];
+        const double dur = u2d(blob[A.off_row + af::TREC * row]);
+        if (kind == af::STEP_CPU) {
+            if (in_io) {
+                g[GS_IO] = g[GS_IO] - 1ull;
+                gs_point(s0 + 1u, rown, -1);
+            }
+            if (!holds) {   // cpu_req = CPU.get(1): append, trigger, `if not cpu_req.triggered` (server.py:210-217)
+                const uint32_t cq_n = hi32(g[GS_CQ]);
+                gs_bytes(g, 1u)[(lo32(g[GS_CQ]) + cq_n) & (kGsSlots - 1u)] = (uint8_t)slot;
+                g[GS_CQ] = pack32(lo32(g[GS_CQ]), cq_n + 1u);
+                g[GS_STATE + slot] = (uint64_t)row;
+                if (gm_cpu_trigger(g, cq_n) <= cq_n) {   // still queued: ready += 1
+                    g[GS_CPU] = g[GS_CPU] + (1ull << 32);
+                    gs_point(s0, rown, 1);
+                }
+                return;
+            }
+            g[GS_STATE + slot] = (uint64_t)row | (1ull << 16);
+            gm_emit(g, slot, now, dur);
+            return;
+        }
+        if (kind == af::STEP_IO) {
+            if (holds) {   // yield CPU.put(1)
+                g[GS_CPU] = g[GS_CPU] + 1ull;
+                g[GS_STATE + slot] = (uint64_t)row | (in_io ? 1ull << 17 : 0ull);
+                gm_push(g, GM_PUT_IO, slot);
+                return;
+            }
+            if (!in_io) {
+                g[GS_IO] = g[GS_IO] + 1ull;
+                gs_point(s0 + 1u, rown, 1);
+            }
+            g[GS_STATE + slot] = (uint64_t)row | (1ull << 17);
+            gm_emit(g, slot, now, dur);
+            return;
+        }
+        if (holds) {   // the endpoint is through while holding the core: yield CPU.put(1)
+            g[GS_CPU] = g[GS_CPU] + 1ull;
+            g[GS_STATE + slot] = (uint64_t)row | (in_io ? 1ull << 17 : 0ull);
+            gm_push(g, GM_PUT_END, slot);
+            return;
+        }
+        gm_finish(g, s0, slot, in_io, now, rown);
+    }
+    // every step end of server sv at `now` (the first n_now entries of its ring), then the FIFO until it is empty
+    AF_CORE void gs_instant(AF_PLAN_AS uint64_t* g, uint32_t sv, double now, uint32_t rown) {
+        const uint32_t s0 = A.n_edges + 3u * sv;
+        gm_head = gm_n = 0u;
+        for (;;) {   // the instant's Timeouts, in creation order (nothing scheduled in here lands at `now`: gm_emit)
+            const uint32_t ev_head = lo32(g[GS_EV]), ev_n = hi32(g[GS_EV]);
+            if (ev_n == 0u || u2d(g[GS_EVT + ev_head]) != now) break;
+            const uint32_t slot = gs_bytes(g, 0u)[ev_head];
+            g[GS_EV] = pack32((ev_head + 1u) & (kGsSlots - 1u), ev_n - 1u);
+            ev += 1u;
+            const uint64_t st = g[GS_STATE + slot];
+            gm_continue(g, s0, slot, ((uint32_t)st & 0xFFFFu) + 1u, (st >> 16) & 1ull, (st >> 17) & 1ull, now, rown);
+        }
+        while (gm_n != 0u && why == 0u) {
+            const uint32_t w = ((AF_PLAN_AS uint8_t*)(g + GS_MQ))[gm_head];
+            gm_head = (gm_head + 1u) & (kGsMq - 1u);
+            gm_n -= 1u;
+            const uint32_t kind = w >> 5, slot = w & 31u;
+            const uint64_t st = g[GS_STATE + slot];
+            const uint32_t row = (uint32_t)st & 0xFFFFu;
+            const bool in_io = (st >> 17) & 1ull;
+            if (kind == GM_CPU_GOT || kind == GM_CPU_GOT_W) {
+                if (kind == GM_CPU_GOT_W) {
+                    g[GS_CPU] = g[GS_CPU] - (1ull << 32);   // ready -= 1
+                    gs_point(s0, rown, -1);
+                }
+                g[GS_STATE + slot] = (uint64_t)row | (1ull << 16);
+                gm_emit(g, slot, now, u2d(blob[A.off_row + af::TREC * row]));
+            } else if (kind == GM_PUT_IO) {
+                gm_cpu_trigger(g, 0xFFFFFFFFu);
+                if (!in_io) {
+                    g[GS_IO] = g[GS_IO] + 1ull;
+                    gs_point(s0 + 1u, rown, 1);
+                }
+                g[GS_STATE + slot] = (uint64_t)row | (1ull << 17);
+                gm_emit(g, slot, now, u2d(blob[A.off_row + af::TREC * row]));
+            } else if (kind == GM_PUT_END) {
+                gm_cpu_trigger(g, 0xFFFFFFFFu);
+                gm_finish(g, s0, slot, in_io, now, rown);
+            } else if (kind == GM_RAM_PUT) {
+                gm_ram_trigger(g);
+                gm_depart(g, slot, now);
+            } else {   // GM_RAM_GOT (server.py:149-150)
+                gs_point(s0 + 2u, rown, (int32_t)(u2d(g[GS_NEED + slot]) * A.ram_scale));
+                gm_continue(g, s0, slot, row, false, false, now, rown);
+            }
+        }
+    }
+
     AF_CORE uint32_t gen_servers(uint32_t sv, double limit) {
         AF_PLAN_AS uint64_t* g = gs(sv);
         AF_PLAN_AS uint32_t* lw = lbw();
