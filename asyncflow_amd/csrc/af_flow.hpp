@@ -1209,6 +1209,20 @@ struct Flow {
     // [LBW_SEG_OFF, + LBW_SEG_LEN)) merged with its pending step ends, in time order, up to `limit` (every arrival before it is
     // known).  Plain per-lane code: no cross-lane operation in here.  Departures go to the server's GS_DEPT / GS_DEPT0 arrays.
     AF_CORE AF_PLAN_AS uint64_t* gs(uint32_t sv) const { return M + A.L.off_gsrv + sv * kGsWords; }
+    // The ten scalar words of the lane's server live in REGISTERS while gen_servers() runs (round 4): the station is a chain of
+    // dependent LDS round trips of one lane, and these words were half of them.  Loaded on entry, stored on exit; everything
+    // outside gen_servers() (run(): the departure counts, the setup) sees the LDS copy.
+    struct GsRegs {
+        uint64_t cpu, io, ram, arr, cq, rq, ev, dep, last, lastdep;
+    } GR;
+    AF_CORE void gs_load(const AF_PLAN_AS uint64_t* g) {
+        GR.cpu = g[GS_CPU]; GR.io = g[GS_IO]; GR.ram = g[GS_RAM]; GR.arr = g[GS_ARR]; GR.cq = g[GS_CQ];
+        GR.rq = g[GS_RQ]; GR.ev = g[GS_EV]; GR.dep = g[GS_DEP]; GR.last = g[GS_LAST]; GR.lastdep = g[GS_LASTDEP];
+    }
+    AF_CORE void gs_store(AF_PLAN_AS uint64_t* g) const {
+        g[GS_CPU] = GR.cpu; g[GS_IO] = GR.io; g[GS_RAM] = GR.ram; g[GS_ARR] = GR.arr; g[GS_CQ] = GR.cq;
+        g[GS_RQ] = GR.rq; g[GS_EV] = GR.ev; g[GS_DEP] = GR.dep; g[GS_LAST] = GR.last; g[GS_LASTDEP] = GR.lastdep;
+    }
     AF_CORE static uint32_t lo32(uint64_t w) { return (uint32_t)w; }
     AF_CORE static uint32_t hi32(uint64_t w) { return (uint32_t)(w >> 32); }
     AF_CORE static uint64_t pack32(uint32_t lo, uint32_t hi) { return (uint64_t)lo | ((uint64_t)hi << 32); }
@@ -1226,7 +1240,7 @@ struct Flow {
     // later are handed back (gen_servers).
     uint8_t gs_born;
     AF_CORE void gs_schedule(AF_PLAN_AS uint64_t* g, double t, uint32_t slot) {
-        const uint32_t head = lo32(g[GS_EV]), n = hi32(g[GS_EV]);
+        const uint32_t head = lo32(GR.ev), n = hi32(GR.ev);
         AF_PLAN_AS uint8_t* es = gs_bytes(g, 0u);
         AF_PLAN_AS uint8_t* eb = gs_bytes(g, 3u);
         uint32_t i = n;
@@ -1239,18 +1253,18 @@ struct Flow {
         g[GS_EVT + ((head + i) & (kGsSlots - 1u))] = d2u(t);
         es[(head + i) & (kGsSlots - 1u)] = (uint8_t)slot;
         eb[(head + i) & (kGsSlots - 1u)] = gs_born;
-        g[GS_EV] = pack32(head, n + 1u);
+        GR.ev = pack32(head, n + 1u);
     }
     // a core became free: the first waiter gets it (Container FIFO, server.py:210-231) and starts its CPU step now
     AF_CORE void gs_core_release(AF_PLAN_AS uint64_t* g, uint32_t s0, double now, uint32_t rown) {
-        const uint32_t head = lo32(g[GS_CQ]), n = hi32(g[GS_CQ]);
+        const uint32_t head = lo32(GR.cq), n = hi32(GR.cq);
         if (n == 0u) {
-            g[GS_CPU] = g[GS_CPU] + 1ull;   // cpu_free += 1
+            GR.cpu = GR.cpu + 1ull;   // cpu_free += 1
             return;
         }
         const uint32_t slot = gs_bytes(g, 1u)[head];
-        g[GS_CQ] = pack32((head + 1u) & (kGsSlots - 1u), n - 1u);
-        g[GS_CPU] = g[GS_CPU] - (1ull << 32);   // ready -= 1
+        GR.cq = pack32((head + 1u) & (kGsSlots - 1u), n - 1u);
+        GR.cpu = GR.cpu - (1ull << 32);   // ready -= 1
         gs_point(s0, rown, -1);
         const uint64_t st = g[GS_STATE + slot];
         g[GS_STATE + slot] = st | (1ull << 16);   // holds the core
@@ -1266,17 +1280,17 @@ struct Flow {
         const double dur = u2d(blob[A.off_row + af::TREC * row]);
         if (kind == af::STEP_CPU) {   // server.py:199-231
             if (in_io) {
-                g[GS_IO] = g[GS_IO] - 1ull;
+                GR.io = GR.io - 1ull;
                 gs_point(s0 + 1u, rown, -1);
             }
             if (!holds) {
-                const uint32_t cq_n = hi32(g[GS_CQ]);
-                if (cq_n == 0u && lo32(g[GS_CPU]) > 0u) {
-                    g[GS_CPU] = g[GS_CPU] - 1ull;   // granted at once: never in the ready queue
+                const uint32_t cq_n = hi32(GR.cq);
+                if (cq_n == 0u && lo32(GR.cpu) > 0u) {
+                    GR.cpu = GR.cpu - 1ull;   // granted at once: never in the ready queue
                 } else {
-                    gs_bytes(g, 1u)[(lo32(g[GS_CQ]) + cq_n) & (kGsSlots - 1u)] = (uint8_t)slot;
-                    g[GS_CQ] = pack32(lo32(g[GS_CQ]), cq_n + 1u);
-                    g[GS_CPU] = g[GS_CPU] + (1ull << 32);   // ready += 1
+                    gs_bytes(g, 1u)[(lo32(GR.cq) + cq_n) & (kGsSlots - 1u)] = (uint8_t)slot;
+                    GR.cq = pack32(lo32(GR.cq), cq_n + 1u);
+                    GR.cpu = GR.cpu + (1ull << 32);   // ready += 1
                     gs_point(s0, rown, 1);
                     g[GS_STATE + slot] = (uint64_t)row;   // waiting: neither core nor I/O
                     return;
@@ -1288,7 +1302,7 @@ struct Flow {
         }
         if (kind == af::STEP_IO) {   // server.py:235-255 (its own Timeout is created before the core waiter's)
             if (!in_io) {
-                g[GS_IO] = g[GS_IO] + 1ull;
+                GR.io = GR.io + 1ull;
                 gs_point(s0 + 1u, rown, 1);
             }
             g[GS_STATE + slot] = (uint64_t)row | (1ull << 17);
@@ -1299,34 +1313,34 @@ struct Flow {
         // the endpoint is through (server.py:257-276): core, RAM, the response
         if (holds) gs_core_release(g, s0, now, rown);
         if (in_io) {
-            g[GS_IO] = g[GS_IO] - 1ull;
+            GR.io = GR.io - 1ull;
             gs_point(s0 + 1u, rown, -1);
         }
         const double need = u2d(g[GS_NEED + slot]);
         if (need > 0.0) {
-            g[GS_RAM] = d2u(u2d(g[GS_RAM]) + need);
+            GR.ram = d2u(u2d(GR.ram) + need);
             gs_point(s0 + 2u, rown, -(int32_t)(need * A.ram_scale));
             ram_released = true;
         }
-        const uint32_t nd = lo32(g[GS_DEP]);
-        if (u2d(g[GS_LASTDEP]) == now) why |= FLOW_WHY_TIE;   // two responses at one instant: their order on the out-edge is SimPy's
-        g[GS_LASTDEP] = d2u(now);
+        const uint32_t nd = lo32(GR.dep);
+        if (u2d(GR.lastdep) == now) why |= FLOW_WHY_TIE;   // two responses at one instant: their order on the out-edge is SimPy's
+        GR.lastdep = d2u(now);
         g[GS_DEPT + nd] = d2u(now);
         g[GS_DEPT0 + nd] = g[GS_T0 + slot];
-        g[GS_DEP] = pack32(nd + 1u, hi32(g[GS_DEP]));
-        g[GS_IO] = g[GS_IO] | (1ull << (32u + slot));   // the slot is free again
+        GR.dep = pack32(nd + 1u, hi32(GR.dep));
+        GR.io = GR.io | (1ull << (32u + slot));   // the slot is free again
     }
     // RAM waiters, strictly FIFO with head-of-line blocking (Container._trigger_get, server.py:146-149)
     AF_CORE void gs_ram_queue(AF_PLAN_AS uint64_t* g, uint32_t sv, double now, uint32_t rown) {
         const uint32_t s0 = A.n_edges + 3u * sv;
         for (;;) {
-            const uint32_t head = lo32(g[GS_RQ]), n = hi32(g[GS_RQ]);
+            const uint32_t head = lo32(GR.rq), n = hi32(GR.rq);
             if (n == 0u) return;
             const uint32_t slot = gs_bytes(g, 2u)[head];
-            const double need = u2d(g[GS_NEED + slot]), free_ram = u2d(g[GS_RAM]);
+            const double need = u2d(g[GS_NEED + slot]), free_ram = u2d(GR.ram);
             if (free_ram < need) return;
-            g[GS_RQ] = pack32((head + 1u) & (kGsSlots - 1u), n - 1u);
-            g[GS_RAM] = d2u(free_ram - need);
+            GR.rq = pack32((head + 1u) & (kGsSlots - 1u), n - 1u);
+            GR.ram = d2u(free_ram - need);
             gs_point(s0 + 2u, rown, (int32_t)(need * A.ram_scale));
             bool again = false;
             gs_advance(g, sv, slot, now, rown, again);   // (an endpoint of RAM steps only gives its RAM straight back: the loop looks again)
@@ -1368,47 +1382,47 @@ struct Flow {
     AF_CORE uint32_t gm_cpu_trigger(AF_PLAN_AS uint64_t* g, uint32_t n_old) {
         uint32_t grants = 0u;
         for (;;) {
-            const uint32_t head = lo32(g[GS_CQ]), n = hi32(g[GS_CQ]);
-            if (n == 0u || lo32(g[GS_CPU]) == 0u) return grants;
+            const uint32_t head = lo32(GR.cq), n = hi32(GR.cq);
+            if (n == 0u || lo32(GR.cpu) == 0u) return grants;
             const uint32_t slot = gs_bytes(g, 1u)[head];
-            g[GS_CQ] = pack32((head + 1u) & (kGsSlots - 1u), n - 1u);
-            g[GS_CPU] = g[GS_CPU] - 1ull;   // level -= 1
+            GR.cq = pack32((head + 1u) & (kGsSlots - 1u), n - 1u);
+            GR.cpu = GR.cpu - 1ull;   // level -= 1
             gm_push(g, grants < n_old ? GM_CPU_GOT_W : GM_CPU_GOT, slot);
             grants += 1u;
         }
     }
     AF_CORE void gm_ram_trigger(AF_PLAN_AS uint64_t* g) {   // head-of-line blocking FIFO
         for (;;) {
-            const uint32_t head = lo32(g[GS_RQ]), n = hi32(g[GS_RQ]);
+            const uint32_t head = lo32(GR.rq), n = hi32(GR.rq);
             if (n == 0u) return;
             const uint32_t slot = gs_bytes(g, 2u)[head];
-            const double need = u2d(g[GS_NEED + slot]), free_ram = u2d(g[GS_RAM]);
+            const double need = u2d(g[GS_NEED + slot]), free_ram = u2d(GR.ram);
             if (free_ram < need) return;
-            g[GS_RQ] = pack32((head + 1u) & (kGsSlots - 1u), n - 1u);
-            g[GS_RAM] = d2u(free_ram - need);
+            GR.rq = pack32((head + 1u) & (kGsSlots - 1u), n - 1u);
+            GR.ram = d2u(free_ram - need);
             gm_push(g, GM_RAM_GOT, slot);
         }
     }
     AF_CORE void gm_depart(AF_PLAN_AS uint64_t* g, uint32_t slot, double now) {
-        const uint32_t nd = lo32(g[GS_DEP]);
+        const uint32_t nd = lo32(GR.dep);
         if (nd >= kGsDeps) {
             why |= FLOW_WHY_LIST;
             return;
         }
-        g[GS_LASTDEP] = d2u(now);
+        GR.lastdep = d2u(now);
         g[GS_DEPT + nd] = d2u(now);
         g[GS_DEPT0 + nd] = g[GS_T0 + slot];
-        g[GS_DEP] = pack32(nd + 1u, hi32(g[GS_DEP]));
-        g[GS_IO] = g[GS_IO] | (1ull << (32u + slot));   // the slot is free again
+        GR.dep = pack32(nd + 1u, hi32(GR.dep));
+        GR.io = GR.io | (1ull << (32u + slot));   // the slot is free again
     }
     AF_CORE void gm_finish(AF_PLAN_AS uint64_t* g, uint32_t s0, uint32_t slot, bool in_io, double now, uint32_t rown) {   // server.py:261-276
         if (in_io) {
-            g[GS_IO] = g[GS_IO] - 1ull;
+            GR.io = GR.io - 1ull;
             gs_point(s0 + 1u, rown, -1);
         }
         const double need = u2d(g[GS_NEED + slot]);
         if (need > 0.0) {
-            g[GS_RAM] = d2u(u2d(g[GS_RAM]) + need);   // (ContainerPut succeeds at once; its continuation is queued)
+            GR.ram = d2u(u2d(GR.ram) + need);   // (ContainerPut succeeds at once; its continuation is queued)
             gs_point(s0 + 2u, rown, -(int32_t)(need * A.ram_scale));
             gm_push(g, GM_RAM_PUT, slot);
             return;
@@ -1421,16 +1435,16 @@ struct Flow {
         const double dur = u2d(blob[A.off_row + af::TREC * row]);
         if (kind == af::STEP_CPU) {
             if (in_io) {
-                g[GS_IO] = g[GS_IO] - 1ull;
+                GR.io = GR.io - 1ull;
                 gs_point(s0 + 1u, rown, -1);
             }
             if (!holds) {   // cpu_req = CPU.get(1): append, trigger, `if not cpu_req.triggered` (server.py:210-217)
-                const uint32_t cq_n = hi32(g[GS_CQ]);
-                gs_bytes(g, 1u)[(lo32(g[GS_CQ]) + cq_n) & (kGsSlots - 1u)] = (uint8_t)slot;
-                g[GS_CQ] = pack32(lo32(g[GS_CQ]), cq_n + 1u);
+                const uint32_t cq_n = hi32(GR.cq);
+                gs_bytes(g, 1u)[(lo32(GR.cq) + cq_n) & (kGsSlots - 1u)] = (uint8_t)slot;
+                GR.cq = pack32(lo32(GR.cq), cq_n + 1u);
                 g[GS_STATE + slot] = (uint64_t)row;
                 if (gm_cpu_trigger(g, cq_n) <= cq_n) {   // still queued: ready += 1
-                    g[GS_CPU] = g[GS_CPU] + (1ull << 32);
+                    GR.cpu = GR.cpu + (1ull << 32);
                     gs_point(s0, rown, 1);
                 }
                 return;
@@ -1441,13 +1455,13 @@ struct Flow {
         }
         if (kind == af::STEP_IO) {
             if (holds) {   // yield CPU.put(1)
-                g[GS_CPU] = g[GS_CPU] + 1ull;
+                GR.cpu = GR.cpu + 1ull;
                 g[GS_STATE + slot] = (uint64_t)row | (in_io ? 1ull << 17 : 0ull);
                 gm_push(g, GM_PUT_IO, slot);
                 return;
             }
             if (!in_io) {
-                g[GS_IO] = g[GS_IO] + 1ull;
+                GR.io = GR.io + 1ull;
                 gs_point(s0 + 1u, rown, 1);
             }
             g[GS_STATE + slot] = (uint64_t)row | (1ull << 17);
@@ -1455,7 +1469,7 @@ struct Flow {
             return;
         }
         if (holds) {   // the endpoint is through while holding the core: yield CPU.put(1)
-            g[GS_CPU] = g[GS_CPU] + 1ull;
+            GR.cpu = GR.cpu + 1ull;
             g[GS_STATE + slot] = (uint64_t)row | (in_io ? 1ull << 17 : 0ull);
             gm_push(g, GM_PUT_END, slot);
             return;
@@ -1467,10 +1481,10 @@ struct Flow {
         const uint32_t s0 = A.n_edges + 3u * sv;
         gm_head = gm_n = 0u;
         for (;;) {   // the instant's Timeouts, in creation order (nothing scheduled in here lands at `now`: gm_emit)
-            const uint32_t ev_head = lo32(g[GS_EV]), ev_n = hi32(g[GS_EV]);
+            const uint32_t ev_head = lo32(GR.ev), ev_n = hi32(GR.ev);
             if (ev_n == 0u || u2d(g[GS_EVT + ev_head]) != now) break;
             const uint32_t slot = gs_bytes(g, 0u)[ev_head];
-            g[GS_EV] = pack32((ev_head + 1u) & (kGsSlots - 1u), ev_n - 1u);
+            GR.ev = pack32((ev_head + 1u) & (kGsSlots - 1u), ev_n - 1u);
             ev += 1u;
             const uint64_t st = g[GS_STATE + slot];
             gm_continue(g, s0, slot, ((uint32_t)st & 0xFFFFu) + 1u, (st >> 16) & 1ull, (st >> 17) & 1ull, now, rown);
@@ -1485,7 +1499,7 @@ struct Flow {
             const bool in_io = (st >> 17) & 1ull;
             if (kind == GM_CPU_GOT || kind == GM_CPU_GOT_W) {
                 if (kind == GM_CPU_GOT_W) {
-                    g[GS_CPU] = g[GS_CPU] - (1ull << 32);   // ready -= 1
+                    GR.cpu = GR.cpu - (1ull << 32);   // ready -= 1
                     gs_point(s0, rown, -1);
                 }
                 g[GS_STATE + slot] = (uint64_t)row | (1ull << 16);
@@ -1493,7 +1507,7 @@ struct Flow {
             } else if (kind == GM_PUT_IO) {
                 gm_cpu_trigger(g, 0xFFFFFFFFu);
                 if (!in_io) {
-                    g[GS_IO] = g[GS_IO] + 1ull;
+                    GR.io = GR.io + 1ull;
                     gs_point(s0 + 1u, rown, 1);
                 }
                 g[GS_STATE + slot] = (uint64_t)row | (1ull << 17);
@@ -1520,21 +1534,20 @@ struct Flow {
         const double ram_mb = u2d(blob[A.off_srv + af::SREC * sv]);
         uint32_t ai = 0u, done = 0u;
         bool ram_pending = false;
-        g[GS_DEP] = pack32(0u, hi32(g[GS_DEP]));
+        gs_load(g);
+        GR.dep = pack32(0u, hi32(GR.dep));
         for (;;) {
             const double ta = ai < n_k ? seg(0)[off + ai] : AF_INF;
-            const uint32_t ev_head = lo32(g[GS_EV]), ev_n = hi32(g[GS_EV]);
+            const uint32_t ev_head = lo32(GR.ev), ev_n = hi32(GR.ev);
             const double te = ev_n ? u2d(g[GS_EVT + ev_head]) : AF_INF;
             const double now = ta < te ? ta : te;
             if (!(now < limit)) break;
             const bool tie_next = te < ta && ev_n > 1u && u2d(g[GS_EVT + ((ev_head + 1u) & (kGsSlots - 1u))]) == te;
-            const bool tie_prev = now == u2d(g[GS_LAST]);
-            bool give_up = ta == te || (tie_prev && !(te < ta));   // an arrival exactly at a step end: SimPy's order decides
-            if (tie_next) {   // this step end shares its instant with the next one: created where?
-                const uint8_t bx = gs_bytes(g, 3u)[ev_head], by = gs_bytes(g, 3u)[(ev_head + 1u) & (kGsSlots - 1u)];
-                give_up = give_up || ((bx & 0x80u) != 0u && bx == by);   // both in the same shared instant: their order is not ours to know
-                if (!tie_prev) g[GS_DEP] = pack32(lo32(g[GS_DEP]), hi32(g[GS_DEP]) + 1u);   // a new shared instant begins
-            }
+            const bool tie_prev = now == u2d(GR.last);
+            // an arrival exactly at a step end (or at the instant a step end was handled in): the arrival's place among the
+            // instant's zero-time steps is decided by events of OTHER nodes (the edge's Timeout, the inbox Store): handed back.
+            // (With continuous edge latencies that is a null event; step ends sharing an instant are not: gs_instant.)
+            const bool give_up = ta == te || tie_prev;
             if (give_up) {
 #if defined(AF_FLOW_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
                 std::fprintf(stderr, "gen tie: sv %u ta %.17g te %.17g ev_n %u\n", sv, ta, te, ev_n);
@@ -1542,55 +1555,60 @@ struct Flow {
                 why |= FLOW_WHY_TIE;   // the next-event kernels replay SimPy's event-by-event order
                 break;
             }
-            gs_born = (tie_next || tie_prev) ? (uint8_t)(0x80u | (hi32(g[GS_DEP]) & 0x7Fu)) : (uint8_t)0u;
-            g[GS_LAST] = d2u(now);
-            if (lo32(g[GS_DEP]) >= kGsDeps) {   // (cannot happen: a round's departures <= requests inside + its arrivals)
+            gs_born = (uint8_t)0u;
+            GR.last = d2u(now);
+            if (lo32(GR.dep) >= kGsDeps) {   // (cannot happen: a round's departures <= requests inside + its arrivals)
                 why |= FLOW_WHY_LIST;
                 break;
             }
             const uint32_t rown = samples != nullptr ? tick_index(now, true) : 0u;
             bool ram_released = false;
             done += 1u;
+            if (tie_next) {   // several step ends of this server at one instant: SimPy's order of their zero-time steps
+                gs_instant(g, sv, now, rown);
+                if (why != 0u) break;
+                continue;
+            }
             if (te < ta) {   // a CPU or I/O step ends
                 const uint32_t slot = gs_bytes(g, 0u)[ev_head];
-                g[GS_EV] = pack32((ev_head + 1u) & (kGsSlots - 1u), ev_n - 1u);
+                GR.ev = pack32((ev_head + 1u) & (kGsSlots - 1u), ev_n - 1u);
                 ev += 1u;
                 const uint64_t st = g[GS_STATE + slot];
                 g[GS_STATE + slot] = (st & ~0xFFFFull) | (uint64_t)(((uint32_t)st & 0xFFFFu) + 1u);   // next row; core / I/O as they were
                 gs_advance(g, sv, slot, now, rown, ram_released);
             } else {         // a request arrives (server.py:303-313, 79-149)
-                const uint32_t idx = lo32(g[GS_ARR]);
-                g[GS_ARR] = g[GS_ARR] + 1ull;
+                const uint32_t idx = lo32(GR.arr);
+                GR.arr = GR.arr + 1ull;
                 const uint32_t pick = n_ep > 1u ? af::cold_endpoint_pick(seed, sv, idx, n_ep) : 0u;
                 const double need = u2d(blob[A.off_ep + af::PREC * (epb + pick)]);
                 const uint32_t row0 = (uint32_t)blob[A.off_ep + af::PREC * (epb + pick) + 1u];
                 const double t0a = seg(1)[off + ai];
                 ai += 1u;
-                const bool blocked = hi32(g[GS_ARR]) != 0u;
+                const bool blocked = hi32(GR.arr) != 0u;
                 if (need > 0.0 && (need > ram_mb || blocked)) {   // waits for good, and so does every RAM request behind it
                     info |= af::FLAG_RAM_STARVED;
-                    g[GS_ARR] = pack32(lo32(g[GS_ARR]), 1u);
+                    GR.arr = pack32(lo32(GR.arr), 1u);
                 } else {
-                    const uint32_t free_mask = hi32(g[GS_IO]);
+                    const uint32_t free_mask = hi32(GR.io);
                     if (free_mask == 0u) {
                         why |= FLOW_WHY_LIST;   // more requests inside this server than the station holds
                         break;
                     }
                     const uint32_t slot = (uint32_t)__builtin_ctz(free_mask);
-                    g[GS_IO] = g[GS_IO] & ~(1ull << (32u + slot));
+                    GR.io = GR.io & ~(1ull << (32u + slot));
                     g[GS_T0 + slot] = d2u(t0a);
                     g[GS_NEED + slot] = d2u(need);
                     g[GS_STATE + slot] = (uint64_t)row0;
                     bool go = true;
                     if (need > 0.0) {
-                        const uint32_t rq_n = hi32(g[GS_RQ]);
-                        const double free_ram = u2d(g[GS_RAM]);
+                        const uint32_t rq_n = hi32(GR.rq);
+                        const double free_ram = u2d(GR.ram);
                         if (rq_n == 0u && free_ram >= need) {
-                            g[GS_RAM] = d2u(free_ram - need);
+                            GR.ram = d2u(free_ram - need);
                             gs_point(s0 + 2u, rown, (int32_t)(need * A.ram_scale));
                         } else {
-                            gs_bytes(g, 2u)[(lo32(g[GS_RQ]) + rq_n) & (kGsSlots - 1u)] = (uint8_t)slot;
-                            g[GS_RQ] = pack32(lo32(g[GS_RQ]), rq_n + 1u);
+                            gs_bytes(g, 2u)[(lo32(GR.rq) + rq_n) & (kGsSlots - 1u)] = (uint8_t)slot;
+                            GR.rq = pack32(lo32(GR.rq), rq_n + 1u);
                             go = false;
                         }
                     }
@@ -1606,6 +1624,7 @@ struct Flow {
                 ram_pending = false;
             }
         }
+        gs_store(g);
         return done;
     }
 

@@ -324,14 +324,15 @@ def test_general_servers_several_endpoints_and_core_re_entry():
 
 def test_general_servers_shared_instants_follow_simpy_order():
     """Round step times (1 ms CPU, 10 ms I/O, ...) make step ends of DIFFERENT requests of one server coincide all the
-    time once requests queue for the core (their times are a common base + sums of step times): the general server
-    station resolves such instants itself instead of handing the scenario back -- step ends in the order their
-    Timeouts were created, RAM waiters admitted when every step end of the instant has had its turn (SimPy processes
-    the Put behind the instant's other Timeouts).  What it cannot know -- the creation order of two Timeouts BOTH
-    created inside one shared instant, two responses at one instant, an arrival exactly at a step end -- is handed
-    back.  LB-2 with a second endpoint: 19 of 20 seeds used to come back at T = 60; tie storms (dyadic step times,
-    Poisson latencies, tight RAM): exact or handed back, never different (storm 30 / seed 91 is the case that showed
-    the RAM-admission order)."""
+    time once requests queue for the core (their times are a common base + sums of step times).  Round 4: the general
+    server station runs such an instant the way SimPy does -- every Timeout of the instant in creation order, then ONE FIFO
+    of the zero-time steps they schedule (the Puts that give a core or the RAM back, the Gets that were granted):
+    Flow::gs_instant, af_core.hpp's micro_mode restricted to one server -- so the order in which new Timeouts are created,
+    waiters are served and responses leave is SimPy's, and later ties among THOSE are exact too.  What is still handed back:
+    an arrival exactly at a step end (its place is decided by events of other nodes), > 32 requests inside one server.
+    LB-2 with a second endpoint: round 3 handed back 5.6 % of the scenarios at T = 120 s and 42 % at 600 s; now none of
+    40 / 24 seeds (the 600-s run is scripts-only: 5 s per seed on the emulator).  Tie storms (dyadic step times, Poisson
+    latencies, tight RAM): exact or handed back, never different (storm 30 / seed 91 showed the RAM-admission order)."""
     from asyncflow_amd.workloads import _endpoint
     from oracle.scenarios import tie_storm
 
@@ -340,9 +341,13 @@ def test_general_servers_shared_instants_follow_simpy_order():
         s["endpoints"].append(_endpoint("/report", [("io_db", 0.004), ("ram", 64), ("cpu_bound_operation", 0.0015),
                                                      ("io_wait", 0.006), ("cpu_bound_operation", 0.0005)]))
     kw = dict(ipl=1, ring_rows=0, robust=True, long_list_entries=256)
-    stayed = sum(_run(report, 0x5EED0000 + seed, **kw)[0] == "exact" for seed in range(6))
-    assert stayed >= 5, f"only {stayed} of 6 two-endpoint LB-2 scenarios stayed on the stage-parallel kernel"
+    stayed = sum(_run(report, 0x5EED0000 + seed, **kw)[0] == "exact" for seed in range(8))
+    assert stayed == 8, f"only {stayed} of 8 two-endpoint LB-2 scenarios stayed on the stage-parallel kernel"
     kw["long_list_entries"] = 1024
     assert _run(tie_storm(random.Random(7030), horizon=8), 91, **kw)[0] == "exact"
-    exact = sum(_run(tie_storm(random.Random(7000 + case), horizon=8), 3 * case + 1, **kw)[0] == "exact" for case in range(24))
-    assert exact >= 8, f"only {exact} of 24 tie storms stayed on the stage-parallel kernel"
+    ties = exact = 0
+    for case in range(24):
+        status, info = _run(tie_storm(random.Random(7000 + case), horizon=8), 3 * case + 1, **kw)
+        exact += status == "exact"
+        ties += status == "fallback" and "tie" in info
+    assert exact >= 13 and ties <= 3, f"{exact} of 24 tie storms stayed on the stage-parallel kernel, {ties} handed back for a tie"
