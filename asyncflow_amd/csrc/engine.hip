@@ -1105,6 +1105,7 @@ struct FlowPlan {
     uint32_t lds = 0;              // bytes of LDS per wave of the first launch
     uint32_t ipl = 1u, feat = 0u;  // instantiation of the first launch
     bool lean = false;
+    bool gen_compact = false;      // general servers, first launch: long-list instantiation WITHOUT send times, lists sized by the load
 };
 
 int plan_flow(const af_engine* e, const KArgs& a, const af_sweep_t* sweep, const af_outputs_t* out, FlowPlan& P) {
@@ -1290,8 +1291,27 @@ int plan_flow(const af_engine* e, const KArgs& a, const af_sweep_t* sweep, const
         }
         return L;
     };
-    if (gen_srv) flow_big = true;   // (the general server station exists in the long-list instantiation only)
-    if (flow_big) {
+    // General servers, first launch (round 4): the station is one busy lane per server -- a chain of dependent LDS round trips --
+    // so what the launch needs is WAVES per compute unit, i.e. little LDS per wave: lists of what the load needs (>= 128
+    // entries: a batch of 64 must find room) without the send times of the second-chance form, instead of 4 x 256 x 3 words:
+    // 41 -> ~20 KB per wave, 3 -> 7 waves per CU.  What overflows or ties is caught by the second chance (FL2), as ever.
+    P.gen_compact = gen_srv && !flow_big && std::getenv("AF_FLOW_GEN_ROBUST_FIRST") == nullptr;   // (env: measurement hook)
+    if (gen_srv) flow_big = true;   // (the general server station exists in the long-list instantiations only)
+    if (P.gen_compact) {
+        uint32_t caps1[4];
+        for (uint32_t s = 0; s < 4u; ++s) caps1[s] = 128u;
+        for (size_t h = 0; h < hops.size(); ++h) {
+            const uint32_t s = h == 0 ? 0u : h + 1 == hops.size() ? 3u : (h == 1 && e->has_lb) ? 1u : 2u;
+            const double want = 1.5 * pend_of[h] + 64.0;
+            const uint32_t c = want < 1024.0 ? ((uint32_t)want + 63u) & ~63u : 1024u;
+            if (c > caps1[s]) caps1[s] = c;
+        }
+        if (rows * pitch * 4u > 4u * 1024u) {
+            rows = 0u;
+            win_rows = 0u;
+        }
+        FL = aff::make_flow_layout(0u, rows, g_ring, c_ring, a.n_edges, a.n_servers, a.n_edge_marks, false, caps1, true);
+    } else if (flow_big) {
         if (rows * pitch * 4u > 8u * 1024u) {   // the lists need the LDS more than the tick ring does
             rows = 0u;
             win_rows = 0u;
@@ -1316,7 +1336,10 @@ int plan_flow(const af_engine* e, const KArgs& a, const af_sweep_t* sweep, const
     constexpr uint32_t kRobust = aff::FEAT_ALL | aff::FEAT_TIEBREAK | aff::FEAT_BIGLIST;
     const bool chain = e->flow_chain;   // (never with lc / gen_srv: flow_ineligible_reason)
     P.lean = lean && !flow_big && !lc && !chain;
-    if (flow_big) {
+    if (P.gen_compact) {
+        P.ipl = 1u;
+        P.feat = aff::FEAT_ALL | aff::FEAT_BIGLIST | aff::FEAT_GENSRV | (lc ? (uint32_t)aff::FEAT_LC : 0u);
+    } else if (flow_big) {
         P.ipl = 1u;
         P.feat = kRobust | (lc ? (uint32_t)aff::FEAT_LC : 0u) | (gen_srv ? (uint32_t)aff::FEAT_GENSRV : 0u) | (chain ? (uint32_t)aff::FEAT_CHAIN : 0u);
     } else if (chain) {   // one generic instantiation per list length (every optional feature in); the plan-specialised build is the same FEAT
@@ -1344,6 +1367,8 @@ const void* flow_kernel_for(uint32_t ipl, uint32_t feat) {
     AF_FLOW_CASE(1u, kRobust);
     AF_FLOW_CASE(1u, kRobust | kLC | (uint32_t)aff::FEAT_GENSRV);
     AF_FLOW_CASE(1u, kRobust | (uint32_t)aff::FEAT_GENSRV);
+    AF_FLOW_CASE(1u, kAll | (uint32_t)aff::FEAT_BIGLIST | (uint32_t)aff::FEAT_GENSRV);          // general servers, first launch (compact lists)
+    AF_FLOW_CASE(1u, kAll | (uint32_t)aff::FEAT_BIGLIST | (uint32_t)aff::FEAT_GENSRV | kLC);
     AF_FLOW_CASE(1u, kRobust | (uint32_t)aff::FEAT_CHAIN);   // servers that feed servers: the second-chance form and one per list length
     AF_FLOW_CASE(1u, kAll | (uint32_t)aff::FEAT_CHAIN);
     AF_FLOW_CASE(2u, kAll | (uint32_t)aff::FEAT_CHAIN);
@@ -2029,7 +2054,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
             for (uint32_t i = 0; i < nc; ++i) {
                 const uint32_t fl = cnt_host[(size_t)i * AF_CNT_SLOTS + AF_CNT_FLAGS];
                 if (!(fl & aff::FLAG_FLOW_FALLBACK)) continue;
-                if ((fl & aff::FLOW_WHY_RAM) || flow_big) rest.push_back(i);   // (flow_big: that WAS the most tolerant form)
+                if ((fl & aff::FLOW_WHY_RAM) || (flow_big && !FP.gen_compact)) rest.push_back(i);   // (flow_big: that WAS the most tolerant form)
                 else retry.push_back(i);
             }
             if (!retry.empty()) {
@@ -2049,7 +2074,9 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
                     a.scen_map = nullptr;
                 }
                 constexpr uint32_t kRobust = aff::FEAT_ALL | aff::FEAT_TIEBREAK | aff::FEAT_BIGLIST;
-                const void* fn2 = f2.lb_least_connections ? reinterpret_cast<const void*>(af_flow_kernel<1, kRobust | aff::FEAT_LC>)
+                const void* fn2 = (FP.gen_compact && f2.lb_least_connections) ? reinterpret_cast<const void*>(af_flow_kernel<1, kRobust | aff::FEAT_LC | aff::FEAT_GENSRV>)
+                                  : FP.gen_compact        ? reinterpret_cast<const void*>(af_flow_kernel<1, kRobust | aff::FEAT_GENSRV>)
+                                  : f2.lb_least_connections ? reinterpret_cast<const void*>(af_flow_kernel<1, kRobust | aff::FEAT_LC>)
                                   : e->flow_chain         ? reinterpret_cast<const void*>(af_flow_kernel<1, kRobust | aff::FEAT_CHAIN>)
                                                           : reinterpret_cast<const void*>(af_flow_kernel<1, kRobust>);
                 if (lds2 > 48u * 1024u) HIP_TRY(hipFuncSetAttribute(fn2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));

@@ -236,6 +236,11 @@ extern "C" int hc_flow_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ov
         if (c_ring != a.L.c_ring || g_ring != a.L.g_ring)
             a.L = aff::make_flow_layout(a.L.cap, a.L.ring_rows, g_ring, c_ring, p->n_edges, p->n_servers, p->n_edge_marks);
     }
+    if (gen_srv && !robust) {   // general servers, first launch (engine.hip: plan_flow, gen_compact): 128-entry lists without send times
+        uint32_t caps4[4] = {128u, 128u, 128u, 128u};
+        a.L = aff::make_flow_layout(0u, a.L.ring_rows, a.L.g_ring, a.L.c_ring, p->n_edges, p->n_servers, p->n_edge_marks, false, caps4, true);
+        a.L.win_rows = a.L.ring_rows / 2u;
+    }
     if (robust) {
         uint32_t caps4[4];
         for (uint32_t s = 0; s < 4u; ++s) caps4[s] = (big_which == 0u || big_which == s + 1u) ? big_cap : 256u;
@@ -282,6 +287,8 @@ extern "C" int hc_flow_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ov
         else if (chain && ipl == 1) { aff::Flow<emu::WaveEmu, 1, kAll | kChain> f(a); f.run(lds.data(), 0u); }
         else if (chain && ipl == 2) { aff::Flow<emu::WaveEmu, 2, kAll | kChain> f(a); f.run(lds.data(), 0u); }
         else if (chain) { aff::Flow<emu::WaveEmu, 4, kAll | kChain> f(a); f.run(lds.data(), 0u); }
+        else if (gen_srv && lc && !robust) { aff::Flow<emu::WaveEmu, 1, kAll | aff::FEAT_BIGLIST | kLC | kGen> f(a); f.run(lds.data(), 0u); }
+        else if (gen_srv && !robust) { aff::Flow<emu::WaveEmu, 1, kAll | aff::FEAT_BIGLIST | kGen> f(a); f.run(lds.data(), 0u); }
         else if (gen_srv && lc) { aff::Flow<emu::WaveEmu, 1, kRobust | kLC | kGen> f(a); f.run(lds.data(), 0u); }
         else if (gen_srv) { aff::Flow<emu::WaveEmu, 1, kRobust | kGen> f(a); f.run(lds.data(), 0u); }
         else if (robust && lc) { aff::Flow<emu::WaveEmu, 1, kRobust | kLC> f(a); f.run(lds.data(), 0u); }

@@ -322,6 +322,29 @@ def test_general_servers_several_endpoints_and_core_re_entry():
     assert exact >= 25, f"only {exact} of 40 fuzzed topologies stayed on the stage-parallel kernel"
 
 
+def test_general_servers_compact_first_launch():
+    """Round 4: the FIRST launch of a plan with general servers uses the long-list instantiation WITHOUT send times and with
+    lists sized by the load (128 entries here) -- 20 instead of 41 KB of LDS per wave, 7 instead of 3 waves per compute unit for a
+    station that is one busy lane per server (engine.hip: plan_flow, gen_compact).  Exact or handed back to the second-chance
+    form (256-entry lists with send times), never different; LDS tick ring or differences in HBM."""
+    import random
+
+    from asyncflow_amd.workloads import _endpoint
+    from oracle.scenarios import random_payload, tie_storm
+
+    report = lb_two_servers(horizon=40)
+    for s in report["topology_graph"]["nodes"]["servers"]:
+        s["endpoints"].append(_endpoint("/report", [("io_db", 0.004), ("ram", 64), ("cpu_bound_operation", 0.0015),
+                                                     ("io_wait", 0.006), ("cpu_bound_operation", 0.0005)]))
+    for ring in (0, 32):
+        assert all(_run(report, 0x5EED0000 + seed, ipl=1, ring_rows=ring)[0] == "exact" for seed in range(4))
+    exact = 0
+    for case in range(16):
+        exact += _run(random_payload(random.Random(31000 + case), horizon=8), 17 * case, ipl=1, ring_rows=0)[0] == "exact"
+        exact += _run(tie_storm(random.Random(7000 + case), horizon=8), 3 * case + 1, ipl=1, ring_rows=32)[0] == "exact"
+    assert exact >= 16, f"only {exact} of 32 fuzzed general-server payloads stayed on the compact form"
+
+
 def test_general_servers_shared_instants_follow_simpy_order():
     """Round step times (1 ms CPU, 10 ms I/O, ...) make step ends of DIFFERENT requests of one server coincide all the
     time once requests queue for the core (their times are a common base + sums of step times).  Round 4: the general
