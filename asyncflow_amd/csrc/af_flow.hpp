@@ -1234,25 +1234,19 @@ struct Flow {
     // Step ends that share an instant are handled in the order their Timeouts were created (SimPy's heap key: time, priority,
     // event id): equal times go BEHIND what is there, and the calls below come in the order the reference creates the
     // Timeouts of one event's cascade (the request's own, then the core waiter's, then the RAM waiters': af_core.hpp, "stages").
-    // `gs_born` says where: 0 = in an instant this server had to itself; 0x80 | id = in an instant it shared between several
-    // of its step ends -- SimPy then interleaves the zero-time steps of the tied cascades, the resources end up the same
-    // (both containers are FIFO) but the creation order of the new Timeouts does not follow from ours: two of THOSE that tie
-    // later are handed back (gen_servers).
-    uint8_t gs_born;
+    // In an instant the server shares between several of its step ends SimPy interleaves the zero-time steps of the tied
+    // cascades: gs_instant() runs those in SimPy's order, so the order of the calls below is the creation order there too.
     AF_CORE void gs_schedule(AF_PLAN_AS uint64_t* g, double t, uint32_t slot) {
         const uint32_t head = lo32(GR.ev), n = hi32(GR.ev);
         AF_PLAN_AS uint8_t* es = gs_bytes(g, 0u);
-        AF_PLAN_AS uint8_t* eb = gs_bytes(g, 3u);
         uint32_t i = n;
         while (i > 0u && u2d(g[GS_EVT + ((head + i - 1u) & (kGsSlots - 1u))]) > t) {
             g[GS_EVT + ((head + i) & (kGsSlots - 1u))] = g[GS_EVT + ((head + i - 1u) & (kGsSlots - 1u))];
             es[(head + i) & (kGsSlots - 1u)] = es[(head + i - 1u) & (kGsSlots - 1u)];
-            eb[(head + i) & (kGsSlots - 1u)] = eb[(head + i - 1u) & (kGsSlots - 1u)];
             i -= 1u;
         }
         g[GS_EVT + ((head + i) & (kGsSlots - 1u))] = d2u(t);
         es[(head + i) & (kGsSlots - 1u)] = (uint8_t)slot;
-        eb[(head + i) & (kGsSlots - 1u)] = gs_born;
         GR.ev = pack32(head, n + 1u);
     }
     // a core became free: the first waiter gets it (Container FIFO, server.py:210-231) and starts its CPU step now
@@ -1555,7 +1549,6 @@ struct Flow {
                 why |= FLOW_WHY_TIE;   // the next-event kernels replay SimPy's event-by-event order
                 break;
             }
-            gs_born = (uint8_t)0u;
             GR.last = d2u(now);
             if (lo32(GR.dep) >= kGsDeps) {   // (cannot happen: a round's departures <= requests inside + its arrivals)
                 why |= FLOW_WHY_LIST;

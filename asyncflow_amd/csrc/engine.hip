@@ -1299,10 +1299,12 @@ int plan_flow(const af_engine* e, const KArgs& a, const af_sweep_t* sweep, const
     if (gen_srv) flow_big = true;   // (the general server station exists in the long-list instantiations only)
     if (P.gen_compact) {
         uint32_t caps1[4];
-        for (uint32_t s = 0; s < 4u; ++s) caps1[s] = 128u;
+        // (64 entries where little is pending -- what the tandem kernel's lists hold for the same load --, 128 for the completion
+        // list: it takes a whole round's departures of every server at once)
+        for (uint32_t s = 0; s < 4u; ++s) caps1[s] = s == 3u ? 128u : 64u;
         for (size_t h = 0; h < hops.size(); ++h) {
             const uint32_t s = h == 0 ? 0u : h + 1 == hops.size() ? 3u : (h == 1 && e->has_lb) ? 1u : 2u;
-            const double want = 1.5 * pend_of[h] + 64.0;
+            const double want = pend_of[h] <= 24.0 ? 64.0 : 1.5 * pend_of[h] + 64.0;
             const uint32_t c = want < 1024.0 ? ((uint32_t)want + 63u) & ~63u : 1024u;
             if (c > caps1[s]) caps1[s] = c;
         }
