@@ -1047,16 +1047,16 @@ uint32_t chunk_size(const af_engine* e, uint32_t n, size_t draw_bytes_per_scen, 
 // List capacity and tick ring from what will be in flight at the heaviest point of the sweep, the instantiation
 // (IPL, FEAT) that covers the launch.  Shared by af_engine_run and af_engine_jit_spec (the plan-specialised build
 // bakes exactly this in).
-// Does this sweep run on the stage-parallel kernel?  flow_mode 0: whenever the plan is in its range -- except that plans whose
-// servers need the event-by-event station (FEAT_GENSRV) go there only as sweeps of a few scenarios: that station is one busy lane
-// per server, 18 x slower per event than the tandem recurrence, and every scenario it hands back costs a full next-event pass
-// whose time does not depend on how many scenarios share it (2 048 two-endpoint LB-2 replicas, T = 120 s: 512 ms with 114
-// hand-backs against 358 ms on the next-event kernels alone; ONE scenario: 84 ms against ~350).  2 = always, 1 = never.
-constexpr uint32_t kGeneralServersAutoScenarios = 8;
+// Does this sweep run on the stage-parallel kernel?  flow_mode 0: whenever the plan is in its range; 2 = the same, but a sweep
+// it cannot be sized for is an error instead of a fall-back; 1 = never.
+// (Round 3 sent plans with general servers -- several endpoints per server, core re-entry -- there only as sweeps of <= 8
+// scenarios: the event-by-event station handed 42 % of the two-endpoint LB-2 scenarios back at T = 600 s and ran at 3 waves
+// per CU.  Round 4: shared instants are resolved in the station (Flow::gs_instant: no hand-backs on that plan) and the first
+// launch needs 17.6 instead of 41 KB of LDS per wave: 512 / 10 000 / 40 000 scenarios x 600 s take 0.30 / 1.52 / 5.46 s against
+// 1.48 / 2.45 / 13.35 s on the next-event kernels -- profiles/r04/gensrv_*.json -- so they take it at every sweep size.)
 static bool flow_wanted(const af_engine_t* e, uint32_t n_scenarios) {
-    if (!e->flow_ok || e->flow_mode == 1u) return false;
-    if (e->flow_general_servers && e->flow_mode != 2u) return n_scenarios <= kGeneralServersAutoScenarios;
-    return true;
+    (void)n_scenarios;
+    return e->flow_ok && e->flow_mode != 1u;
 }
 
 // Sweeps with a users / rpm column: does af_arrival_groups still pay?  Its workgroup is as slow as its heaviest scenario (the

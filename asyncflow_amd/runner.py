@@ -352,10 +352,9 @@ class SimulationRunner:
         #: next-event kernels, > 5e10 on the stage-parallel kernel)
         self.specialise = specialise
         #: stage-parallel kernel (one wave per scenario, 64 requests per step) for plans in its range
-        #: (Engine.flow_reason()); False = always the next-event kernels.  Results are bit-identical.  True leaves
-        #: one choice to the engine: plans whose servers need the event-by-event station (several endpoints per
-        #: server, step programs that come back to the core queue) run there only as sweeps of <= 8 scenarios --
-        #: above that the next-event kernels are faster for them; "always" overrides it.
+        #: (Engine.flow_reason()); False = always the next-event kernels.  Results are bit-identical.  True also lets a
+        #: sweep the kernel cannot be sized for (a cpu_cores column above 64) fall back to the next-event kernels;
+        #: "always" makes that an error.
         self.flow = flow
         self.flow_list_entries = flow_list_entries
         self.flow_ring_rows = flow_ring_rows
@@ -517,8 +516,7 @@ class SimulationRunner:
             )
             flow_reason = eng.flow_reason() if self.flow else "flow=False"
             if self.flow and not flow_reason and int(stats.flow_scenarios) == 0:
-                flow_reason = ("servers with several endpoints / core re-entry: the next-event kernels are faster for sweeps of "
-                               "more than 8 scenarios (flow='always' overrides)")
+                flow_reason = "the stage-parallel kernel could not be sized for this sweep (flow='always' reports why)"
             eng.close()
             if int(stats.shared_instant_scenarios) > 0:
                 _SHARED_INSTANTS_SEEN[self._plan_key()] = True

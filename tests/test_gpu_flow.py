@@ -679,29 +679,30 @@ def test_several_endpoints_per_server_run_on_the_flow_kernel():
     special = _runner(two_ep, seeds=seeds, specialise=True, flow="always").run()     # (launches above 64 KB of LDS per wave keep the generic build)
     assert generic.engine_stats.flow_scenarios == 24
     _same_batches(generic, special)
-    # the engine's own choice (flow=True): such plans take the stage-parallel kernel only as sweeps of <= 8 scenarios -- the
-    # event-by-event station is one busy lane per server, and above that the next-event kernels are faster
+    # the engine's own choice (flow=True) is the stage-parallel kernel at every sweep size since round 4 (shared instants are
+    # resolved in the station, the first launch needs 17.6 instead of 41 KB of LDS per wave: profiles/r04/gensrv_*.json)
     auto = _runner(two_ep, seeds=seeds).run()
-    assert auto.engine_stats.flow_scenarios == 0 and "flow='always'" in auto.flow_reason
+    assert auto.engine_stats.flow_scenarios == 24 and auto.flow_reason == ""
     _same_batches(generic, auto)
 
 
 def test_round_step_times_share_instants_inside_a_general_server():
     """LB-2 with a second endpoint whose steps are round numbers of milliseconds: step ends of different requests of one server
-    coincide as soon as requests queue for the core.  The station resolves those instants in SimPy's order (Timeout creation
-    order; RAM waiters when the instant's step ends are through) instead of handing the scenario back: 19 of 20 scenarios
-    stay at T = 60 (it used to be 13), and every result equals the next-event kernels' and the oracle's."""
+    coincide as soon as requests queue for the core.  The station runs those instants the way SimPy does (Flow::gs_instant:
+    the instant's Timeouts in creation order, then one FIFO of the zero-time steps they schedule) instead of handing the
+    scenario back: all 64 scenarios stay at T = 120 s (round 3: 5.6 % came back at 120 s, 42 % at 600 s), on the compact
+    first-launch form the engine picks by itself, and every result equals the next-event kernels' and the oracle's."""
     from asyncflow_amd.workloads import _endpoint
 
-    p = lb_two_servers(horizon=60)
+    p = lb_two_servers(horizon=120)
     for s in p["topology_graph"]["nodes"]["servers"]:
         s["endpoints"].append(_endpoint("/report", [("io_db", 0.004), ("ram", 64), ("cpu_bound_operation", 0.0015),
                                                      ("io_wait", 0.006), ("cpu_bound_operation", 0.0005)]))
-    seeds = 0x5EED0000 + np.arange(20, dtype=np.uint64)
-    res = _runner(p, seeds=seeds, flow="always").run()
+    seeds = 0x5EED0000 + np.arange(64, dtype=np.uint64)
+    res = _runner(p, seeds=seeds).run()
     st = res.engine_stats
-    assert st.flow_scenarios == 20 and st.flow_to_next_event <= 4, (st.flow_scenarios, st.flow_to_next_event)
+    assert st.flow_scenarios == 64 and st.flow_fallback == 0 and st.flow_to_next_event == 0, (st.flow_scenarios, st.flow_fallback)
     plan = lower(p)
-    for i in (0, 7, 19):
+    for i in (0, 7, 19, 63):
         _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])), f"scenario {i}")
     _same_batches(res, _runner(p, seeds=seeds, flow=False).run())
