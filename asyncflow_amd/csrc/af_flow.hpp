@@ -1524,7 +1524,7 @@ struct Flow {
         AF_PLAN_AS uint32_t* lw = lbw();
         const uint32_t off = lw[LBW_SEG_OFF + sv], n_k = lw[LBW_SEG_LEN + sv], s0 = A.n_edges + 3u * sv;
         const uint64_t meta = blob[A.off_srv + af::SREC * sv + 1u];
-        const uint32_t epb = (uint32_t)(meta >> 32) & 0xFFFFu, n_ep = (uint32_t)(meta >> 48);
+        const uint32_t epb = (uint32_t)(meta >> 32) & 0xFFFFu;
         const double ram_mb = u2d(blob[A.off_srv + af::SREC * sv]);
         uint32_t ai = 0u, done = 0u;
         bool ram_pending = false;
@@ -1554,7 +1554,9 @@ struct Flow {
                 why |= FLOW_WHY_LIST;
                 break;
             }
-            const uint32_t rown = samples != nullptr ? tick_index(now, true) : 0u;
+            // (an arrival's tick row and endpoint draw were worked out by its own lane: run())
+            const uint64_t pre = te < ta ? 0ull : d2u(seg(2)[off + ai]);
+            const uint32_t rown = samples == nullptr ? 0u : te < ta ? tick_index(now, true) : hi32(pre);
             bool ram_released = false;
             done += 1u;
             if (tie_next) {   // several step ends of this server at one instant: SimPy's order of their zero-time steps
@@ -1572,7 +1574,7 @@ struct Flow {
             } else {         // a request arrives (server.py:303-313, 79-149)
                 const uint32_t idx = lo32(GR.arr);
                 GR.arr = GR.arr + 1ull;
-                const uint32_t pick = n_ep > 1u ? af::cold_endpoint_pick(seed, sv, idx, n_ep) : 0u;
+                const uint32_t pick = lo32(pre);
                 const double need = u2d(blob[A.off_ep + af::PREC * (epb + pick)]);
                 const uint32_t row0 = (uint32_t)blob[A.off_ep + af::PREC * (epb + pick) + 1u];
                 const double t0a = seg(1)[off + ai];
@@ -1879,6 +1881,14 @@ struct Flow {
                     if (have) {
                         seg(0)[pos] = key;
                         seg(1)[pos] = t0;
+                        // what does not depend on the server's state is worked out here, one arrival per lane, instead of by the
+                        // server's one lane: the endpoint draw (server.py:101; its index = the server's arrival count) and the
+                        // arrival's tick row
+                        const uint32_t n_ep = (uint32_t)(blob[A.off_srv + af::SREC * sv + 1u] >> 48);
+                        const uint32_t a_idx = lo32(gs(sv)[GS_ARR]) + (pos - lbw()[LBW_SEG_OFF + sv]);
+                        const uint32_t pick = n_ep > 1u ? af::cold_endpoint_pick(seed, sv, a_idx, n_ep) : 0u;
+                        const uint32_t a_row = samples != nullptr ? tick_index(key, true) : 0u;
+                        seg(2)[pos] = u2d(pack32(pick, a_row));
                     }
                     W::sync();
                     uint32_t done = 0u;

@@ -337,8 +337,10 @@ struct WaveHip {
 #endif
 #endif
 #ifndef AF_JIT
+// (general servers: the LDS of that form admits ~2 waves per SIMD anyway, so its serial station gets the registers of a
+// 3-waves-per-SIMD budget instead of spilling: 128 VGPRs + 112 B of scratch at 4)
 template <uint32_t IPL, uint32_t FEAT>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AF_FLOW_WPE))) af_flow_kernel(const aff::FlowArgs a) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FEAT & aff::FEAT_GENSRV) ? 3 : AF_FLOW_WPE))) af_flow_kernel(const aff::FlowArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (blockIdx.x >= a.n_scen) return;
     const uint32_t sc = a.scen_map ? a.scen_map[blockIdx.x] : blockIdx.x;
@@ -374,7 +376,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) 
 // What stays a run-time argument: every pointer, the scenario count and the clock / tick / draw capacities (they
 // change with replicas and the runner's auto-grow; a key that contained them would recompile for every such change).
 #define AF_FJ_F64(bits) __builtin_bit_cast(double, (uint64_t)(bits))
-extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AF_FLOW_WPE))) af_flow_jit(const aff::FlowArgs a_in) {
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(((AF_FJ_FEAT) & aff::FEAT_GENSRV) ? 3 : AF_FLOW_WPE))) af_flow_jit(const aff::FlowArgs a_in) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (blockIdx.x >= a_in.n_scen) return;
     aff::FlowArgs a = a_in;
