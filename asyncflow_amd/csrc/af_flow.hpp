@@ -235,8 +235,9 @@ enum : uint32_t { PROF_SETUP, PROF_GEN, PROF_SELECT, PROF_SERIES_RECV, PROF_STAT
 //                  a level's select() takes the entries whose target server is of that level, with the level's own horizon.
 //                  Everything a server of level k receives before min(horizon of the station in front of the servers, send floor
 //                  of every level below k) is in the list, because a request leaves a server no earlier than it arrived.  What a
-//                  level sends goes to the completion list or back into the server list, lane by lane.  Not together with a
-//                  least-connections LB or general servers.
+//                  level sends goes to the completion list or back into the server list, lane by lane.  Tandem or general
+//                  servers (FEAT_GENSRV: the event-by-event station runs the servers of the pass's level); not behind a
+//                  least-connections LB.
 //   FEAT_PROF      measurement builds only: the wave's shader-clock time per section of run() (FlowArgs::prof)
 enum : uint32_t { FEAT_MARKS = 1u, FEAT_ONLINE = 2u, FEAT_HBM_RING = 4u, FEAT_FAR = 64u, FEAT_ALL = 7u | FEAT_FAR, FEAT_TIEBREAK = 8u,
                   FEAT_BIGLIST = 16u, FEAT_LC = 32u, FEAT_PROF = 128u, FEAT_GENSRV = 256u, FEAT_CHAIN = 512u };
@@ -248,7 +249,7 @@ struct Flow {
                           kHbmRing = (FEAT & FEAT_HBM_RING) != 0u, kTieBreak = (FEAT & FEAT_TIEBREAK) != 0u,
                           kBig = (FEAT & FEAT_BIGLIST) != 0u, kLC = (FEAT & FEAT_LC) != 0u, kFar = (FEAT & FEAT_FAR) != 0u,
                           kProf = (FEAT & FEAT_PROF) != 0u, kGen = (FEAT & FEAT_GENSRV) != 0u, kChain = (FEAT & FEAT_CHAIN) != 0u;
-    static_assert(!(kChain && (kGen || kLC)), "server levels: round-robin LB (or none), tandem servers");
+    static_assert(!(kChain && kLC), "server levels: round-robin LB (or none)");
     // FEAT_PROF: the time since the previous mark belongs to `section` (marks sit at the END of a section, in
     // wave-uniform control flow, with a compile-time section: the accumulators stay in scalar registers)
     unsigned long long prof_t, prof_acc[kProfSections];
@@ -1892,21 +1893,25 @@ struct Flow {
                     }
                     W::sync();
                     uint32_t done = 0u;
-                    if (lane < A.n_servers) done = gen_servers(lane, H_get(2u));
+                    // (FEAT_CHAIN: the servers of this pass's level, up to the level's horizon; the others keep their state)
+                    const bool my_pass = lane < A.n_servers && (!kChain || level_of(lane) == level);
+                    if (my_pass) done = gen_servers(lane, H_get(kChain ? level_slot(level) : 2u));
                     W::sync();
                     work += popc64(W::ballot(done != 0u));
                     prof(PROF_SERVERS);
                     // the departures the servers produced (each server's in time order), sent by the whole wave, 64 at a time
+                    auto dep_cnt = [&](uint32_t k) { return (!kChain || level_of(k) == level) ? lo32(gs(k)[GS_DEP]) : 0u; };
                     uint32_t total = 0u;
-                    for (uint32_t k = 0u; k < A.n_servers; ++k) total += lo32(gs(k)[GS_DEP]);
-                    const bool too_many = total > cap_of(3u) - nl3;   // (wave-uniform)
+                    for (uint32_t k = 0u; k < A.n_servers; ++k) total += dep_cnt(k);
+                    // (wave-uniform; FEAT_CHAIN: a departure goes to the completion list or back into the server list)
+                    const bool too_many = total > cap_of(3u) - nl3 || (kChain && total > cap_of(2u) - nl2);
                     if (too_many) why |= FLOW_WHY_LIST;
                     for (uint32_t base = 0u; base < total && !too_many; base += 64u) {
                         const uint32_t want = base + lane;   // my departure, counted over the servers in order
                         bool mine = false;
                         uint32_t me = 0u, mj = 0u, first = 0u;
                         for (uint32_t k = 0u; k < A.n_servers; ++k) {
-                            const uint32_t cnt = lo32(gs(k)[GS_DEP]);
+                            const uint32_t cnt = dep_cnt(k);
                             if (want >= first && want < first + cnt) {
                                 mine = true;
                                 me = k;
@@ -1924,10 +1929,18 @@ struct Flow {
                         const uint32_t drow = (kFar && sent && samples != nullptr) ? tick_index(dts, true) : 0u;
                         const bool ok = sent && send_finish(oe, dts, drow, kFar, transit, k2, counted);
                         prof(PROF_SEND_SERIES);
-                        append(3u, ok, k2, (kFar && counted) ? -dt0 : dt0, oe, dts);
+                        if (kChain) {   // to the client, or to a server of a deeper level (aux: the server | the edge the message comes by)
+                            const uint64_t tw = erec(oe)[3];
+                            const bool dep_to_srv = ((uint32_t)tw & 0xFFu) == af::NODE_SERVER;
+                            const uint32_t dep_tgt = (uint32_t)(tw >> 8) & 0xFFu;
+                            append(3u, ok && !dep_to_srv, k2, (kFar && counted) ? -dt0 : dt0, oe, dts);
+                            append(2u, ok && dep_to_srv, k2, (kFar && counted) ? -dt0 : dt0, !kFar ? dep_tgt : dep_tgt | (oe << 8), dts);
+                        } else {
+                            append(3u, ok, k2, (kFar && counted) ? -dt0 : dt0, oe, dts);
+                        }
                     }
                     W::sync();
-                    if (lane < A.n_servers) sends()[(uint32_t)(blob[A.off_srv + af::SREC * lane + 1u] >> 16) & 0xFFFFu] += lo32(gs(lane)[GS_DEP]);
+                    if (my_pass) sends()[(uint32_t)(blob[A.off_srv + af::SREC * lane + 1u] >> 16) & 0xFFFFu] += lo32(gs(lane)[GS_DEP]);
                     W::sync();
                     sending = false;   // (everything this station sends went out above)
                 } else if (st == 3u) {   // servers
@@ -1990,7 +2003,12 @@ struct Flow {
                 else if (st == 4u) prof(PROF_COMPLETE);
                 else prof(PROF_STATION);
                 if (kGen && st == 3u) {
-                    H_in = send_floor(3u, H_get(2u));
+                    if (kChain) {   // (as for the tandem levels below: the running minimum of the send floors)
+                        const double fl = send_floor(3u, H_get(level_slot(level)), level == 0u);
+                        H_in = fl < H_in ? fl : H_in;
+                    } else {
+                        H_in = send_floor(3u, H_get(2u));
+                    }
                     prof(PROF_APPEND);
                 } else if (st < 4u) {
                     double k2 = 0.0;

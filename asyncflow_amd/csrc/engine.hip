@@ -1338,11 +1338,11 @@ int plan_flow(const af_engine* e, const KArgs& a, const af_sweep_t* sweep, const
     // injected spikes / outages, but neither the kernel-side summary nor tick differences in HBM (BASELINE config 4)
     const bool marks_only = !lean && !has_online && ring_ok;
     constexpr uint32_t kRobust = aff::FEAT_ALL | aff::FEAT_TIEBREAK | aff::FEAT_BIGLIST;
-    const bool chain = e->flow_chain;   // (never with lc / gen_srv: flow_ineligible_reason)
+    const bool chain = e->flow_chain;   // (never with lc: flow_ineligible_reason)
     P.lean = lean && !flow_big && !lc && !chain;
     if (P.gen_compact) {
         P.ipl = 1u;
-        P.feat = aff::FEAT_ALL | aff::FEAT_BIGLIST | aff::FEAT_GENSRV | (lc ? (uint32_t)aff::FEAT_LC : 0u);
+        P.feat = aff::FEAT_ALL | aff::FEAT_BIGLIST | aff::FEAT_GENSRV | (lc ? (uint32_t)aff::FEAT_LC : 0u) | (chain ? (uint32_t)aff::FEAT_CHAIN : 0u);
     } else if (flow_big) {
         P.ipl = 1u;
         P.feat = kRobust | (lc ? (uint32_t)aff::FEAT_LC : 0u) | (gen_srv ? (uint32_t)aff::FEAT_GENSRV : 0u) | (chain ? (uint32_t)aff::FEAT_CHAIN : 0u);
@@ -1373,6 +1373,8 @@ const void* flow_kernel_for(uint32_t ipl, uint32_t feat) {
     AF_FLOW_CASE(1u, kRobust | (uint32_t)aff::FEAT_GENSRV);
     AF_FLOW_CASE(1u, kAll | (uint32_t)aff::FEAT_BIGLIST | (uint32_t)aff::FEAT_GENSRV);          // general servers, first launch (compact lists)
     AF_FLOW_CASE(1u, kAll | (uint32_t)aff::FEAT_BIGLIST | (uint32_t)aff::FEAT_GENSRV | kLC);
+    AF_FLOW_CASE(1u, kAll | (uint32_t)aff::FEAT_BIGLIST | (uint32_t)aff::FEAT_GENSRV | (uint32_t)aff::FEAT_CHAIN);   // general servers in tiers
+    AF_FLOW_CASE(1u, kRobust | (uint32_t)aff::FEAT_GENSRV | (uint32_t)aff::FEAT_CHAIN);
     AF_FLOW_CASE(1u, kRobust | (uint32_t)aff::FEAT_CHAIN);   // servers that feed servers: the second-chance form and one per list length
     AF_FLOW_CASE(1u, kAll | (uint32_t)aff::FEAT_CHAIN);
     AF_FLOW_CASE(2u, kAll | (uint32_t)aff::FEAT_CHAIN);
@@ -2078,7 +2080,8 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
                     a.scen_map = nullptr;
                 }
                 constexpr uint32_t kRobust = aff::FEAT_ALL | aff::FEAT_TIEBREAK | aff::FEAT_BIGLIST;
-                const void* fn2 = (FP.gen_compact && f2.lb_least_connections) ? reinterpret_cast<const void*>(af_flow_kernel<1, kRobust | aff::FEAT_LC | aff::FEAT_GENSRV>)
+                const void* fn2 = (FP.gen_compact && e->flow_chain) ? reinterpret_cast<const void*>(af_flow_kernel<1, kRobust | aff::FEAT_GENSRV | aff::FEAT_CHAIN>)
+                                  : (FP.gen_compact && f2.lb_least_connections) ? reinterpret_cast<const void*>(af_flow_kernel<1, kRobust | aff::FEAT_LC | aff::FEAT_GENSRV>)
                                   : FP.gen_compact        ? reinterpret_cast<const void*>(af_flow_kernel<1, kRobust | aff::FEAT_GENSRV>)
                                   : f2.lb_least_connections ? reinterpret_cast<const void*>(af_flow_kernel<1, kRobust | aff::FEAT_LC>)
                                   : e->flow_chain         ? reinterpret_cast<const void*>(af_flow_kernel<1, kRobust | aff::FEAT_CHAIN>)

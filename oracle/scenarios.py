@@ -356,8 +356,9 @@ def shared_backend(users: float = 200, horizon: int = 120) -> dict:
     }
 
 
-def server_tiers(rng: random.Random, horizon: int = 15) -> dict:
-    """Feed-forward topologies in which servers feed servers (round 3: FEAT_CHAIN of the stage-parallel kernel):
+def server_tiers(rng: random.Random, horizon: int = 15, general: bool = False) -> dict:
+    """Feed-forward topologies in which servers feed servers (FEAT_CHAIN of the stage-parallel kernel; `general`: some
+    servers with two endpoints or a step program that comes back to the core queue -- FEAT_GENSRV | FEAT_CHAIN):
     client -> [LB ->] front servers -> [middle ->] backend -> client, up to three levels, a front server may also
     answer the client directly and the LB may also feed the backend; continuous latencies (exponential / normal /
     uniform / log-normal), tandem endpoints (IO* CPU* IO*), optional RAM pressure, spikes on any edge and outages of
@@ -371,7 +372,15 @@ def server_tiers(rng: random.Random, horizon: int = 15) -> dict:
             steps.append(("ram", rng.choice([32, 64, 100.25, 128])))
         steps += [(rng.choice(cpu), rng.choice([0.0005, 0.001, 0.002, 0.003])) for _ in range(rng.randint(1, 2))]
         steps += [(rng.choice(io), rng.choice([0.001, 0.003, 0.006])) for _ in range(rng.randint(0, 2))]
+        if general and rng.random() < 0.5:      # back to the core queue after the I/O (server.py:197-231)
+            steps += [(rng.choice(io), 0.0015), (rng.choice(cpu), rng.choice([0.0005, 0.0011]))]
         return _endpoint(name, steps)
+
+    def endpoints(name: str) -> list:
+        eps = [endpoint(name)]
+        if general and rng.random() < 0.6:      # a second endpoint: one uniform draw per arrival (server.py:101)
+            eps.append(endpoint(name + "-2"))
+        return eps
 
     def edge(eid: str, src: str, tgt: str) -> dict:
         dist = rng.choice(["exponential"] * 4 + ["normal", "normal", "uniform", "log_normal"])
@@ -390,12 +399,12 @@ def server_tiers(rng: random.Random, horizon: int = 15) -> dict:
     servers, edges = [], [edge("g-c", "gen", "cli")]
     front = [f"f{i}" for i in range(n_front)]
     for sid in front:
-        servers.append(_server(sid, rng.randint(1, 3), 256 if tight else 2048, [endpoint("/front")]))
-    servers.append(_server("back", rng.randint(1, 4), 512 if tight else 4096, [endpoint("/back")]))
+        servers.append(_server(sid, rng.randint(1, 3), 256 if tight else 2048, endpoints("/front")))
+    servers.append(_server("back", rng.randint(1, 4), 512 if tight else 4096, endpoints("/back")))
     middle = None
     if depth == 3:
         middle = "mid"
-        servers.append(_server(middle, rng.randint(1, 2), 2048, [endpoint("/mid")]))
+        servers.append(_server(middle, rng.randint(1, 2), 2048, endpoints("/mid")))
     rng.shuffle(servers)                       # (server indices in any order: levels do not follow the numbering)
     covered = list(front)
     if use_lb:

@@ -283,7 +283,9 @@ extern "C" int hc_flow_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ov
     const bool chain = aff::flow_needs_chain(*p);   // servers feed servers: the FEAT_CHAIN instantiations (engine.hip: plan_flow)
     constexpr uint32_t kChain = aff::FEAT_CHAIN;
     auto body = [&]() {
-        if (chain && robust) { aff::Flow<emu::WaveEmu, 1, kRobust | kChain> f(a); f.run(lds.data(), 0u); }
+        if (chain && gen_srv && !robust) { aff::Flow<emu::WaveEmu, 1, kAll | aff::FEAT_BIGLIST | kGen | kChain> f(a); f.run(lds.data(), 0u); }
+        else if (chain && gen_srv) { aff::Flow<emu::WaveEmu, 1, kRobust | kGen | kChain> f(a); f.run(lds.data(), 0u); }
+        else if (chain && robust) { aff::Flow<emu::WaveEmu, 1, kRobust | kChain> f(a); f.run(lds.data(), 0u); }
         else if (chain && ipl == 1) { aff::Flow<emu::WaveEmu, 1, kAll | kChain> f(a); f.run(lds.data(), 0u); }
         else if (chain && ipl == 2) { aff::Flow<emu::WaveEmu, 2, kAll | kChain> f(a); f.run(lds.data(), 0u); }
         else if (chain) { aff::Flow<emu::WaveEmu, 4, kAll | kChain> f(a); f.run(lds.data(), 0u); }

@@ -164,6 +164,21 @@ def test_fuzzed_server_tiers_are_exact_or_handed_back(block):
     assert exact >= 14
 
 
+@pytest.mark.parametrize("block", range(2))
+def test_fuzzed_tiers_of_general_servers_are_exact_or_handed_back(block):
+    """Round 4: server tiers whose servers have two endpoints or come back to the core queue (FEAT_GENSRV | FEAT_CHAIN): the
+    event-by-event station runs the servers of each level up to that level's horizon, and what they send goes to the
+    completion list or back into the server list.  The compact first-launch form and the second-chance form."""
+    exact = 0
+    for case in range(block * 15, block * 15 + 15):
+        p = server_tiers(random.Random(93000 + case), general=True)
+        status, _ = _run(p, 500 + case, ipl=1, ring_rows=32)
+        assert status in ("exact", "fallback")
+        exact += status == "exact"
+        assert _run(p, 500 + case, robust=True, ring_rows=0, long_list_entries=1024)[0] == "exact", case
+    assert exact >= 12
+
+
 @pytest.mark.parametrize("block", range(6))
 def test_fuzzed_feed_forward_payloads_are_exact_or_handed_back(block):
     """Idle to saturated, multi-core, leading / trailing I/O, dyadic step times, tight RAM, spikes, outages."""

@@ -652,6 +652,28 @@ def test_servers_that_feed_servers_run_on_the_flow_kernel():
     assert stayed >= total - 4, f"{stayed} of {total} scenarios stayed on the stage-parallel kernel"
 
 
+def test_tiers_of_general_servers_run_on_the_flow_kernel():
+    """Round 4: server tiers whose servers have two endpoints or come back to the core queue after an I/O step
+    (FEAT_GENSRV | FEAT_CHAIN: the event-by-event station runs the servers of each level up to that level's horizon) against
+    the oracle and the next-event kernels; first launch in the compact form, hand-backs to the second-chance form."""
+    from oracle.scenarios import server_tiers
+
+    stayed = total = 0
+    for k in range(8):
+        payload = server_tiers(random.Random(93000 + k), horizon=12, general=True)
+        seeds = np.arange(8, dtype=np.uint64) + 70 * k
+        res = _runner(payload, seeds=seeds).run()
+        st = res.engine_stats
+        assert res.flow_reason == "" and st.flow_scenarios == 8, res.flow_reason
+        stayed += 8 - st.flow_to_next_event
+        total += 8
+        plan = lower(payload)
+        for i in (0, 7):
+            _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])), f"general tiers {k} scenario {i}")
+        _same_batches(res, _runner(payload, seeds=seeds, flow=False).run())
+    assert stayed >= total - 4, f"{stayed} of {total} scenarios stayed on the stage-parallel kernel"
+
+
 def test_several_endpoints_per_server_run_on_the_flow_kernel():
     """Round 3: plans whose servers have several endpoints, come back to the core queue after an I/O step or need
     different amounts of RAM per request run on the stage-parallel kernel (its server station simulates each server event by
