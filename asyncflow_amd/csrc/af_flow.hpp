@@ -383,6 +383,19 @@ struct Flow {
     // config 2: most calls leave by the first or the third return, and the straight-line form executes everything always.)
     AF_CORE uint32_t tick_index(double x, bool flag_ties) {
         const uint32_t N = A.n_ticks;
+#if defined(AF_TICK_ONE_REGION)
+        // Experiment (round 4): ONE divergent region.  The fractional part straight from v_fract_f64 (= q - floor(q), exact for
+        // q >= 0: no u32 -> f64 conversion and subtraction), and neither early return: x = +0 has fraction 0 and goes through
+        // the table (which answers 0), an event beyond the last tick is clamped to N + 1.5 (fraction 0.5: row N at once).
+        {
+            const double q0 = x * A.inv_period, top = (double)N + 1.5;
+            const double q = q0 < top ? q0 : top;     // (also what a NaN becomes)
+            const uint32_t g0 = q > 0.0 ? (uint32_t)q : 0u, g = g0 < N ? g0 : N;
+            const double frac = W::fract(q);
+            if (frac > A.tick_eps && frac < 1.0 - A.tick_eps) return g;
+            return tick_lookup(x, g, flag_ties);
+        }
+#endif
         if (!(x > 0.0)) return 0u;
         const double q = x * A.inv_period;
         if (q >= (double)N + 1.0) return N;
@@ -1573,8 +1586,7 @@ struct Flow {
                 g[GS_STATE + slot] = (st & ~0xFFFFull) | (uint64_t)(((uint32_t)st & 0xFFFFu) + 1u);   // next row; core / I/O as they were
                 gs_advance(g, sv, slot, now, rown, ram_released);
             } else {         // a request arrives (server.py:303-313, 79-149)
-                const uint32_t idx = lo32(GR.arr);
-                GR.arr = GR.arr + 1ull;
+                GR.arr = GR.arr + 1ull;   // (the arrival count: index of the next arrival's endpoint draw, run())
                 const uint32_t pick = lo32(pre);
                 const double need = u2d(blob[A.off_ep + af::PREC * (epb + pick)]);
                 const uint32_t row0 = (uint32_t)blob[A.off_ep + af::PREC * (epb + pick) + 1u];

@@ -304,6 +304,7 @@ struct WaveHip {
     }
     static __device__ __forceinline__ void global_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); }
     static __device__ __forceinline__ double rcp(double x) { return __builtin_amdgcn_rcp(x); }
+    static __device__ __forceinline__ double fract(double x) { return __builtin_amdgcn_fract(x); }   // v_fract_f64: x - floor(x), exact for x >= 0
     static __device__ __forceinline__ uint32_t bcast32(uint32_t v, uint32_t src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src); }
     static __device__ __forceinline__ uint64_t bcast64(uint64_t v, uint32_t src) {
         const uint32_t lo = bcast32((uint32_t)v, src), hi = bcast32((uint32_t)(v >> 32), src);

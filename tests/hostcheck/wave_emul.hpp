@@ -127,6 +127,7 @@ struct WaveEmu {
     static uint32_t global_load(const uint32_t* p) { return *p; }
     static void global_fence() {}
     static double rcp(double x) { return 1.0 / x; }
+    static double fract(double x) { return x - __builtin_floor(x); }   // (x >= 0: exact, like v_fract_f64)
     static uint32_t bcast32(uint32_t v, uint32_t src) { return shfl32(v, src); }
     static uint64_t bcast64(uint64_t v, uint32_t src) { return shfl64(v, src); }
     static uint32_t scan_incl_u32(uint32_t v) {
