@@ -378,31 +378,19 @@ struct Flow {
     // ---- ticks ------------------------------------------------------------------------------------
     // number of ticks strictly before x, clipped to n_ticks (tick k = 1.. at tick_t[k-1]): floor(x / period) when x is
     // safely between two ticks, else a look-up in the table of the collector's own tick times.
-    // (Measured, round 3: the same thing without the two early returns -- clamps and one predicate instead of exec-mask
-    // branches, so that the two rows of an interval are worked out side by side -- is SLOWER: 48.5 -> 50.1 ms on BASELINE
-    // config 2: most calls leave by the first or the third return, and the straight-line form executes everything always.)
+    // ONE divergent region (round 4: 43.45 -> 41.94 ms on BASELINE config 2): the fractional part straight from v_fract_f64
+    // (= q - floor(q), exact for q >= 0: no u32 -> f64 conversion and subtraction) and no early return -- x = +0 has fraction
+    // 0 and goes through the table (which answers 0), an event beyond the last tick is clamped to N + 1.5 (fraction 0.5:
+    // row N at once), a NaN too.  (Round 3 had measured the opposite -- two early returns beat clamps, 48.5 vs 50.1 ms -- with
+    // the fraction worked out as q - (double)(uint32_t)q and three more compares.)
     AF_CORE uint32_t tick_index(double x, bool flag_ties) {
         const uint32_t N = A.n_ticks;
-#if defined(AF_TICK_ONE_REGION)
-        // Experiment (round 4): ONE divergent region.  The fractional part straight from v_fract_f64 (= q - floor(q), exact for
-        // q >= 0: no u32 -> f64 conversion and subtraction), and neither early return: x = +0 has fraction 0 and goes through
-        // the table (which answers 0), an event beyond the last tick is clamped to N + 1.5 (fraction 0.5: row N at once).
-        {
-            const double q0 = x * A.inv_period, top = (double)N + 1.5;
-            const double q = q0 < top ? q0 : top;     // (also what a NaN becomes)
-            const uint32_t g0 = q > 0.0 ? (uint32_t)q : 0u, g = g0 < N ? g0 : N;
-            const double frac = W::fract(q);
-            if (frac > A.tick_eps && frac < 1.0 - A.tick_eps) return g;
-            return tick_lookup(x, g, flag_ties);
-        }
-#endif
-        if (!(x > 0.0)) return 0u;
-        const double q = x * A.inv_period;
-        if (q >= (double)N + 1.0) return N;
-        const uint32_t g = (uint32_t)q;
-        const double frac = q - (double)g;
-        if (frac > A.tick_eps && frac < 1.0 - A.tick_eps) return g < N ? g : N;   // safely between two ticks
-        return tick_lookup(x, g < N ? g : N, flag_ties);                          // next to a tick
+        const double q0 = x * A.inv_period, top = (double)N + 1.5;
+        const double q = q0 < top ? q0 : top;
+        const uint32_t g0 = q > 0.0 ? (uint32_t)q : 0u, g = g0 < N ? g0 : N;
+        const double frac = W::fract(q);
+        if (frac > A.tick_eps && frac < 1.0 - A.tick_eps) return g;   // safely between two ticks
+        return tick_lookup(x, g, flag_ties);                          // next to a tick
     }
     // (behind a call: one event in ~1e8 lies this close to a tick, and the two table walks were 550 of the unrolled kernel's
     // 4 700 instructions -- 42 at each of tick_index's 13 inlined sites; bit 31 of the result: the event is AT a tick)
