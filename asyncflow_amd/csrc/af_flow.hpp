@@ -428,6 +428,23 @@ struct Flow {
     // ... is larger by w between the events whose tick rows are ia and ib (nothing to enter when no tick lies between)
     AF_CORE void add_span(uint32_t series, uint32_t ia, uint32_t ib, int32_t w, bool on = true) {
         const bool span = on && ia != ib;
+#if defined(AF_EXP_SPAN1)
+        // Experiment (round 4): ONE divergent region for both ends.  An end that is not entered (beyond the last tick: only
+        // at the very end of the horizon) adds 0 to a cell of the ring instead of being skipped.
+        const uint32_t R = A.L.ring_rows;
+        if (!(kHbmRing && R == 0u)) {
+            const uint32_t N = A.n_ticks < A.tick_cap ? A.n_ticks : A.tick_cap;
+            const bool in_a = ia < N, in_b = ib < N, reach_a = ia - tick_base < R, reach_b = ib - tick_base < R;
+            why |= (span && ((in_a && !reach_a) || (in_b && !reach_b))) ? FLOW_WHY_RING : 0u;
+            const bool go_a = in_a && reach_a, go_b = in_b && reach_b;
+            if (span) {
+                AF_PLAN_AS uint32_t* base = (AF_PLAN_AS uint32_t*)ring();
+                W::lds_add(base + (go_a ? (ia & (R - 1u)) * A.L.pitch + series : 0u), go_a ? (uint32_t)w : 0u);
+                W::lds_add(base + (go_b ? (ib & (R - 1u)) * A.L.pitch + series : 0u), go_b ? (uint32_t)-w : 0u);
+            }
+            return;
+        }
+#endif
         add_point(series, ia, w, span);
         add_point(series, ib, -w, span);
     }
@@ -741,20 +758,37 @@ struct Flow {
         for (uint32_t q = 0u; q < IPL; ++q) {
             {
                 const bool sel = elig[q] && rank[q] < n_sel;
+                const bool keep = valid[q] && !sel;
+                const uint64_t m = W::ballot(keep);
+                const uint32_t pos = kept + W::mbcnt(m);
+#if defined(AF_EXP_SELW)
+                // Experiment (round 4): the selected and the kept entries leave through ONE region and one computed address
+                // each (batch buffer at its rank, or the list at its new place); the aux word only where a list has one
+                const bool has_aux = s == 2u || (kFar && s == 3u);
+                if (valid[q]) {
+                    AF_PLAN_AS double* dk = sel ? out_key() + rank[q] : K + pos;
+                    AF_PLAN_AS double* dt = sel ? out_t0() + rank[q] : T0 + pos;
+                    *dk = k[q];
+                    *dt = t[q];
+                    if (kTieBreak && keep) TS[pos] = sent[q];
+                    if (has_aux) {
+                        if (sel) out_aux()[rank[q]] = a[q];
+                        else AX[pos] = (uint16_t)a[q];
+                    }
+                }
+#else
                 if (sel) {
                     out_key()[rank[q]] = k[q];
                     out_t0()[rank[q]] = t[q];
                     out_aux()[rank[q]] = a[q];
                 }
-                const bool keep = valid[q] && !sel;
-                const uint64_t m = W::ballot(keep);
-                const uint32_t pos = kept + W::mbcnt(m);
                 if (keep) {
                     K[pos] = k[q];
                     T0[pos] = t[q];
                     if (kTieBreak) TS[pos] = sent[q];
                     if (s == 2u || (kFar && s == 3u)) AX[pos] = (uint16_t)a[q];
                 }
+#endif
                 kept += popc64(m);
             }
         }
@@ -764,7 +798,11 @@ struct Flow {
         if (lane < n_sel) {
             okey = out_key()[lane];
             ot0 = out_t0()[lane];
+#if defined(AF_EXP_SELW)
+            if (s == 2u || (kFar && s == 3u)) oaux = out_aux()[lane];
+#else
             oaux = out_aux()[lane];
+#endif
         }
         return n_sel;
     }
