@@ -428,23 +428,6 @@ struct Flow {
     // ... is larger by w between the events whose tick rows are ia and ib (nothing to enter when no tick lies between)
     AF_CORE void add_span(uint32_t series, uint32_t ia, uint32_t ib, int32_t w, bool on = true) {
         const bool span = on && ia != ib;
-#if defined(AF_EXP_SPAN1)
-        // Experiment (round 4): ONE divergent region for both ends.  An end that is not entered (beyond the last tick: only
-        // at the very end of the horizon) adds 0 to a cell of the ring instead of being skipped.
-        const uint32_t R = A.L.ring_rows;
-        if (!(kHbmRing && R == 0u)) {
-            const uint32_t N = A.n_ticks < A.tick_cap ? A.n_ticks : A.tick_cap;
-            const bool in_a = ia < N, in_b = ib < N, reach_a = ia - tick_base < R, reach_b = ib - tick_base < R;
-            why |= (span && ((in_a && !reach_a) || (in_b && !reach_b))) ? FLOW_WHY_RING : 0u;
-            const bool go_a = in_a && reach_a, go_b = in_b && reach_b;
-            if (span) {
-                AF_PLAN_AS uint32_t* base = (AF_PLAN_AS uint32_t*)ring();
-                W::lds_add(base + (go_a ? (ia & (R - 1u)) * A.L.pitch + series : 0u), go_a ? (uint32_t)w : 0u);
-                W::lds_add(base + (go_b ? (ib & (R - 1u)) * A.L.pitch + series : 0u), go_b ? (uint32_t)-w : 0u);
-            }
-            return;
-        }
-#endif
         add_point(series, ia, w, span);
         add_point(series, ib, -w, span);
     }
@@ -729,6 +712,21 @@ struct Flow {
             if (elig[q]) {
                 const uint32_t p0 = bbase()[b[q]], p1 = p0 + hist()[b[q]], me = p0 + slot[q];
                 uint32_t r = p0;
+#if defined(AF_EXP_RANKLE)
+                // Experiment (round 4): no region inside the loop -- count the bucket's keys below mine and the ones not above
+                // it; they differ by exactly one (me) unless another message of the station shares my instant
+                if (!kTieBreak) {
+                    uint32_t c = p0;
+#pragma nounroll
+                    for (uint32_t p = p0; p < p1; ++p) {
+                        const double kk = sorted()[p];
+                        r += kk < k[q] ? 1u : 0u;
+                        c += kk <= k[q] ? 1u : 0u;
+                    }
+                    why |= c != r + 1u ? FLOW_WHY_TIE : 0u;
+                    (void)me;
+                } else
+#endif
 #pragma nounroll   // (a bucket holds one or two messages: the unrolled-by-eight form was 115 instructions per site for ~1.5 trips)
                 for (uint32_t p = p0; p < p1; ++p) {
                     const double kk = sorted()[p];
@@ -748,11 +746,23 @@ struct Flow {
         }
         uint32_t n_sel = E < room ? E : room;
         n_sel = n_sel < 64u ? n_sel : 64u;
-        if (n_sel < E) {   // the first message left behind bounds the horizon
+        double h_left = 0.0;   // the first message left behind bounds the horizon
+#if defined(AF_EXP_HREAD)
+        // Experiment (round 4): its key straight from the lane that holds it (ballot + v_readlane) instead of through LDS
+        if (n_sel < E) {
+#pragma unroll
+            for (uint32_t q = 0u; q < IPL; ++q) {
+                const uint64_t mb = W::ballot(elig[q] && rank[q] == n_sel);
+                if (mb != 0ull) h_left = bcast_f64(k[q], (uint32_t)__builtin_ctzll(mb));
+            }
+        }
+#else
+        if (n_sel < E) {
 #pragma unroll
             for (uint32_t q = 0u; q < IPL; ++q)
                 if (elig[q] && rank[q] == n_sel) scal()[0] = k[q];
         }
+#endif
         uint32_t kept = 0u;
 #pragma unroll
         for (uint32_t q = 0u; q < IPL; ++q) {
@@ -761,9 +771,8 @@ struct Flow {
                 const bool keep = valid[q] && !sel;
                 const uint64_t m = W::ballot(keep);
                 const uint32_t pos = kept + W::mbcnt(m);
-#if defined(AF_EXP_SELW)
-                // Experiment (round 4): the selected and the kept entries leave through ONE region and one computed address
-                // each (batch buffer at its rank, or the list at its new place); the aux word only where a list has one
+                // the selected and the kept entries leave through ONE divergent region and one computed address each (batch buffer
+                // at its rank, or the list at its new place); the aux word only where a list has one (round 4: 41.87 -> 41.46 ms)
                 const bool has_aux = s == 2u || (kFar && s == 3u);
                 if (valid[q]) {
                     AF_PLAN_AS double* dk = sel ? out_key() + rank[q] : K + pos;
@@ -776,33 +785,19 @@ struct Flow {
                         else AX[pos] = (uint16_t)a[q];
                     }
                 }
-#else
-                if (sel) {
-                    out_key()[rank[q]] = k[q];
-                    out_t0()[rank[q]] = t[q];
-                    out_aux()[rank[q]] = a[q];
-                }
-                if (keep) {
-                    K[pos] = k[q];
-                    T0[pos] = t[q];
-                    if (kTieBreak) TS[pos] = sent[q];
-                    if (s == 2u || (kFar && s == 3u)) AX[pos] = (uint16_t)a[q];
-                }
-#endif
                 kept += popc64(m);
             }
         }
         n_list_set(s, kept);
         W::sync();
-        H_set(hs, n_sel < E ? scal()[0] : hi);
+#if !defined(AF_EXP_HREAD)
+        if (n_sel < E) h_left = scal()[0];
+#endif
+        H_set(hs, n_sel < E ? h_left : hi);
         if (lane < n_sel) {
             okey = out_key()[lane];
             ot0 = out_t0()[lane];
-#if defined(AF_EXP_SELW)
             if (s == 2u || (kFar && s == 3u)) oaux = out_aux()[lane];
-#else
-            oaux = out_aux()[lane];
-#endif
         }
         return n_sel;
     }
