@@ -645,6 +645,9 @@ struct Flow {
     // `level` != kAnyLevel: only the entries of the server list whose target server is of that level.
     AF_CORE uint32_t select(uint32_t s, double H_in, uint32_t room, double& okey, double& ot0, uint32_t& oaux, uint32_t hs, uint32_t level = kAnyLevel) {
         if (kBig) return select_big(s, H_in, room, okey, ot0, oaux, hs, level);
+#if defined(AF_EXP_S1)
+        hist()[lane] = 0u;   // (experiment, round 4: the bucket counts are zeroed in front of the sync every select() starts with)
+#endif
         W::sync();   // appends of the previous station are visible
         const double lo = H_get(hs);
         const double hi_t = H_in < A.total_time ? H_in : A.total_time, hi = (kFar && t_lim < hi_t) ? t_lim : hi_t;   // (t_lim: run())
@@ -665,8 +668,10 @@ struct Flow {
         // approximate reciprocal is as good as a division here)
         double sc = 64.0 * W::rcp(hi - lo);
         if (!(sc < 1e300)) sc = 1e300;
+#if !defined(AF_EXP_S1)
         hist()[lane] = 0u;
         W::sync();
+#endif
         // my (up to 4) entries; bucket counts
         double k[IPL], t[IPL], sent[IPL];
         uint32_t a[IPL], b[IPL], slot[IPL];
@@ -696,6 +701,22 @@ struct Flow {
         uint32_t E;
         const uint32_t cnt = hist()[lane];
         const uint32_t base = excl_scan(cnt, E);
+#if defined(AF_EXP_S2)
+        // (experiment, round 4: a lane's bucket start and count straight from the bucket's lane -- two ds_bpermute -- instead of
+        // an LDS array written, synchronised and read back)
+        uint32_t bb[IPL], bc[IPL];
+#pragma unroll
+        for (uint32_t q = 0u; q < IPL; ++q) {
+            bb[q] = W::shfl32(base, b[q]);
+            bc[q] = W::shfl32(cnt, b[q]);
+        }
+#pragma unroll
+        for (uint32_t q = 0u; q < IPL; ++q)
+            if (elig[q]) {
+                sorted()[bb[q] + slot[q]] = k[q];
+                if (kTieBreak) sorted_ts()[bb[q] + slot[q]] = sent[q];
+            }
+#else
         bbase()[lane] = base;
         W::sync();
 #pragma unroll
@@ -704,17 +725,21 @@ struct Flow {
                 sorted()[bbase()[b[q]] + slot[q]] = k[q];
                 if (kTieBreak) sorted_ts()[bbase()[b[q]] + slot[q]] = sent[q];
             }
+#endif
         W::sync();
         uint32_t rank[IPL];
 #pragma unroll
         for (uint32_t q = 0u; q < IPL; ++q) {
             rank[q] = 0u;
             if (elig[q]) {
+#if defined(AF_EXP_S2)
+                const uint32_t p0 = bb[q], p1 = p0 + bc[q], me = p0 + slot[q];
+#else
                 const uint32_t p0 = bbase()[b[q]], p1 = p0 + hist()[b[q]], me = p0 + slot[q];
+#endif
                 uint32_t r = p0;
-#if defined(AF_EXP_RANKLE)
-                // Experiment (round 4): no region inside the loop -- count the bucket's keys below mine and the ones not above
-                // it; they differ by exactly one (me) unless another message of the station shares my instant
+                // no region inside the loop (round 4): count the bucket's keys below mine and the ones not above it; they differ
+                // by exactly one (me) unless another message of the station shares my instant
                 if (!kTieBreak) {
                     uint32_t c = p0;
 #pragma nounroll
@@ -726,7 +751,6 @@ struct Flow {
                     why |= c != r + 1u ? FLOW_WHY_TIE : 0u;
                     (void)me;
                 } else
-#endif
 #pragma nounroll   // (a bucket holds one or two messages: the unrolled-by-eight form was 115 instructions per site for ~1.5 trips)
                 for (uint32_t p = p0; p < p1; ++p) {
                     const double kk = sorted()[p];
@@ -746,23 +770,14 @@ struct Flow {
         }
         uint32_t n_sel = E < room ? E : room;
         n_sel = n_sel < 64u ? n_sel : 64u;
-        double h_left = 0.0;   // the first message left behind bounds the horizon
-#if defined(AF_EXP_HREAD)
-        // Experiment (round 4): its key straight from the lane that holds it (ballot + v_readlane) instead of through LDS
-        if (n_sel < E) {
+        double h_left = 0.0;   // the first message left behind bounds the horizon: its key straight from the lane that
+        if (n_sel < E) {       // holds it (ballot + v_readlane), not through LDS (round 4)
 #pragma unroll
             for (uint32_t q = 0u; q < IPL; ++q) {
                 const uint64_t mb = W::ballot(elig[q] && rank[q] == n_sel);
                 if (mb != 0ull) h_left = bcast_f64(k[q], (uint32_t)__builtin_ctzll(mb));
             }
         }
-#else
-        if (n_sel < E) {
-#pragma unroll
-            for (uint32_t q = 0u; q < IPL; ++q)
-                if (elig[q] && rank[q] == n_sel) scal()[0] = k[q];
-        }
-#endif
         uint32_t kept = 0u;
 #pragma unroll
         for (uint32_t q = 0u; q < IPL; ++q) {
@@ -790,9 +805,6 @@ struct Flow {
         }
         n_list_set(s, kept);
         W::sync();
-#if !defined(AF_EXP_HREAD)
-        if (n_sel < E) h_left = scal()[0];
-#endif
         H_set(hs, n_sel < E ? h_left : hi);
         if (lane < n_sel) {
             okey = out_key()[lane];
