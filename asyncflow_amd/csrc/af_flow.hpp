@@ -645,9 +645,6 @@ struct Flow {
     // `level` != kAnyLevel: only the entries of the server list whose target server is of that level.
     AF_CORE uint32_t select(uint32_t s, double H_in, uint32_t room, double& okey, double& ot0, uint32_t& oaux, uint32_t hs, uint32_t level = kAnyLevel) {
         if (kBig) return select_big(s, H_in, room, okey, ot0, oaux, hs, level);
-#if defined(AF_EXP_S1)
-        hist()[lane] = 0u;   // (experiment, round 4: the bucket counts are zeroed in front of the sync every select() starts with)
-#endif
         W::sync();   // appends of the previous station are visible
         const double lo = H_get(hs);
         const double hi_t = H_in < A.total_time ? H_in : A.total_time, hi = (kFar && t_lim < hi_t) ? t_lim : hi_t;   // (t_lim: run())
@@ -668,10 +665,8 @@ struct Flow {
         // approximate reciprocal is as good as a division here)
         double sc = 64.0 * W::rcp(hi - lo);
         if (!(sc < 1e300)) sc = 1e300;
-#if !defined(AF_EXP_S1)
-        hist()[lane] = 0u;
+        hist()[lane] = 0u;   // (zeroing them in front of the entry sync instead -- one sync less -- measured: no gain)
         W::sync();
-#endif
         // my (up to 4) entries; bucket counts
         double k[IPL], t[IPL], sent[IPL];
         uint32_t a[IPL], b[IPL], slot[IPL];
@@ -701,9 +696,8 @@ struct Flow {
         uint32_t E;
         const uint32_t cnt = hist()[lane];
         const uint32_t base = excl_scan(cnt, E);
-#if defined(AF_EXP_S2)
-        // (experiment, round 4: a lane's bucket start and count straight from the bucket's lane -- two ds_bpermute -- instead of
-        // an LDS array written, synchronised and read back)
+        // a lane's bucket start and count straight from the bucket's lane (two ds_bpermute) instead of an LDS array written,
+        // synchronised and read back (round 4: -0.4 %)
         uint32_t bb[IPL], bc[IPL];
 #pragma unroll
         for (uint32_t q = 0u; q < IPL; ++q) {
@@ -716,27 +710,13 @@ struct Flow {
                 sorted()[bb[q] + slot[q]] = k[q];
                 if (kTieBreak) sorted_ts()[bb[q] + slot[q]] = sent[q];
             }
-#else
-        bbase()[lane] = base;
-        W::sync();
-#pragma unroll
-        for (uint32_t q = 0u; q < IPL; ++q)
-            if (elig[q]) {
-                sorted()[bbase()[b[q]] + slot[q]] = k[q];
-                if (kTieBreak) sorted_ts()[bbase()[b[q]] + slot[q]] = sent[q];
-            }
-#endif
         W::sync();
         uint32_t rank[IPL];
 #pragma unroll
         for (uint32_t q = 0u; q < IPL; ++q) {
             rank[q] = 0u;
             if (elig[q]) {
-#if defined(AF_EXP_S2)
                 const uint32_t p0 = bb[q], p1 = p0 + bc[q], me = p0 + slot[q];
-#else
-                const uint32_t p0 = bbase()[b[q]], p1 = p0 + hist()[b[q]], me = p0 + slot[q];
-#endif
                 uint32_t r = p0;
                 // no region inside the loop (round 4): count the bucket's keys below mine and the ones not above it; they differ
                 // by exactly one (me) unless another message of the station shares my instant
