@@ -78,7 +78,7 @@ struct FlowLayout {
     uint32_t win_rows;   // how many ticks past the completed ones the generator may run (the rest of the ring is for
                          // intervals that end later: the in-flight time of the slowest message)
     uint32_t g_ring;     // per-server ring of departure times (power of two >= RAM slots looked back)
-    uint32_t c_ring;     // per-server ring of core-release times (>= max cpu_cores)
+    uint32_t c_ring;     // per-server ring of core-release times (power of two >= max cpu_cores)
     uint32_t pitch;      // 4-byte words per tick row (n_series rounded up to 4)
     uint32_t list_arrays;  // f64 arrays per station list: key, t0 [, send time (FEAT_TIEBREAK)]
     uint32_t off_spike, off_list, off_aux, off_aux3, off_out, off_sorted, off_hist, off_seg, off_fr, off_gr, off_cnt, off_ring;
@@ -112,7 +112,9 @@ inline FlowLayout make_flow_layout(uint32_t cap, uint32_t ring_rows, uint32_t g_
     L.ring_rows = ring_rows;
     L.win_rows = ring_rows / 2u;
     L.g_ring = g_ring;
-    L.c_ring = c_ring;
+    L.c_ring = 1u;   // a power of two >= the widest server: the ring is indexed by a mask (a modulo by `cores` was 60 instructions per round)
+    while (L.c_ring < c_ring) L.c_ring *= 2u;
+    c_ring = L.c_ring;
     L.pitch = (n_edges + 3u * n_servers + 3u) & ~3u;
     uint32_t w = 0;
     L.off_spike = w; w += n_edge_marks;                 // cumulative spike after each edge mark
@@ -958,7 +960,10 @@ struct Flow {
             const uint32_t q = nl > 1u ? (uint32_t)(((uint64_t)x * lw[19]) >> 32) : x;   // lw[19] = ceil(2^32 / nl), kept with nl
             if (lane < n_sel) pick = lw[x - q * nl];
             W::sync();
-            if (lane == 0u) lw[16] = (head + n_sel) % nl;
+            if (lane == 0u) {   // (head + n_sel) mod nl by the same multiplication as above: a u32 division was 25 instructions per round
+                const uint32_t y = head + n_sel, qy = nl > 1u ? (uint32_t)(((uint64_t)y * lw[19]) >> 32) : y;
+                lw[16] = y - qy * nl;
+            }
         } else {
             W::sync();
             if (lane == 0u) {   // rare (one round per outage mark): one lane walks the messages in time order
@@ -1178,7 +1183,7 @@ struct Flow {
         const bool g_in_seg = ram_gate && li >= slots, f_in_seg = core_gate && li >= cores;
         double g_prev = -AF_INF, f_prev = -AF_INF;
         if (ram_gate && !g_in_seg) g_prev = gr(sv)[(j - slots) & (G - 1u)];
-        if (core_gate && !f_in_seg) f_prev = fr(sv)[cores == 1u ? 0u : (j - cores) % cores];
+        if (core_gate && !f_in_seg) f_prev = fr(sv)[(j - cores) & (A.L.c_ring - 1u)];   // (the release `cores` requests earlier: c_ring >= cores slots)
         if (have && ram > 0.0) {
             if (slots > G && j >= G) {         // more slots than the ring remembers: fine while fewer than G requests are inside
                 const double gq = li >= G ? AF_INF : gr(sv)[(j - G) & (G - 1u)];   // (li >= G: G arrivals of one server in one window)
@@ -1217,7 +1222,7 @@ struct Flow {
             // (a tick at that very instant is flagged by tick_index).  A RAM-bound server with deterministic step
             // times produces such instants all the time: F[j-1] = G[j-1-slots] + cpu and G[j-slots] = F[j-slots] + io
             // are the same sum.
-            if (li + cores >= n_k) fr(sv)[cores == 1u ? 0u : j % cores] = r.f;   // the last `cores` releases / G departures feed later windows
+            if (li + cores >= n_k) fr(sv)[j & (A.L.c_ring - 1u)] = r.f;   // the last `cores` releases / G departures feed later windows
             if (li + G >= n_k) gr(sv)[j & (G - 1u)] = r.g;
             ev += r.events;
         }
