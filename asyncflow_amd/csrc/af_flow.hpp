@@ -576,10 +576,14 @@ struct Flow {
     // time; the exponential law -- the reference's default -- inline and the other laws behind one call
     AF_CORE bool edge_draw(uint32_t e, uint32_t idx, double& transit) const {
         const AF_PLAN_AS uint64_t* r = erec(e);
-        const double mean = u2d(r[0]), sigma = u2d(r[1]), dropout = u2d(r[2]);
+        const double mean = u2d(r[0]), sigma = u2d(r[1]);
         const uint32_t stream = af::stream_edge(e);
         const af::U4 rr = af::draw_block(seed, stream, idx, 0u);
-        const bool sent = !(af::u53(rr.x, rr.y) < dropout);   // dropped: no latency draw (worked out all the same: one region less)
+        // dropped (edge.py:78-86)?  u < dropout_rate with u = k x 2^-53, k the draw's 53 bits: the same test on integers,
+        // k < ceil(dropout x 2^53) -- run() turned the blob's dropout word into that threshold -- without the two u32 -> f64
+        // conversions, the multiply-add and the scaling of af::u53 (round 4)
+        const uint64_t k53 = ((uint64_t)(rr.x >> 5) << 26) | (uint64_t)(rr.y >> 6);
+        const bool sent = !(k53 < r[2]);   // (the latency draw is worked out all the same: one region less)
         const double u1 = af::u53(rr.z, rr.w);
 #if defined(AF_FJ_DIST_ALL) && (AF_FJ_DIST_ALL != 255)
         // plan-specialised build of a plan whose edges all follow ONE law: the law is a constant, its variate code is
@@ -1732,6 +1736,12 @@ struct Flow {
                     const uint32_t at = A.off_smark + af::NREC * idx + 1u;
                     blob[at] = (blob[at] & 0xFFFFFFFFull) | ((uint64_t)(u2d(v) != 0.0 ? 1u : 0u) << 32);
                 }
+            }
+            // an edge's dropout rate as a threshold on the 53 bits of its uniform draw (edge_draw): ceil(rate x 2^53); the
+            // scaling by a power of two is exact, and for an integer k: k x 2^-53 < rate  <=>  k < ceil(rate x 2^53)
+            for (uint32_t e = 0u; e < A.n_edges; ++e) {
+                const double x = u2d(blob[A.off_edge + af::EREC * e + 2u]) * 9007199254740992.0;
+                blob[A.off_edge + af::EREC * e + 2u] = !(x > 0.0) ? 0ull : x >= 9007199254740992.0 ? (1ull << 53) : (uint64_t)__builtin_ceil(x);
             }
             // cumulative spike per edge after every mark, the reference's own += / -= in f64 (injection.py:191-198)
             for (uint32_t i = 0u; i < A.n_edge_marks; ++i) {
