@@ -1,0 +1,55 @@
+"""GPU fuzz of the round-4 additions to the stage-parallel kernel (FEAT_CHAIN, FEAT_GENSRV with shared instants, both together):
+every scenario of every payload against the next-event kernels (counts, every (start, finish) pair, every sample) and two of
+them against the oracle.  Prints one JSON line of tallies (profiles/r04/gpu_fuzz_f3.json).  A mismatch raises."""
+import json
+import random
+import sys
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from asyncflow_amd import _abi  # noqa: E402
+from asyncflow_amd.plan import lower  # noqa: E402
+from asyncflow_amd.runner import SimulationRunner  # noqa: E402
+from oracle import oracle_lib as ol  # noqa: E402
+from oracle.scenarios import random_payload, server_tiers, tie_storm  # noqa: E402
+
+n_payloads = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+families = {
+    "server tiers (tandem)": lambda k: server_tiers(random.Random(95000 + k), horizon=12),
+    "server tiers (general servers)": lambda k: server_tiers(random.Random(96000 + k), horizon=12, general=True),
+    "random topologies (general servers)": lambda k: random_payload(random.Random(97000 + k), horizon=8),
+    "tie storms": lambda k: tie_storm(random.Random(98000 + k), horizon=8),
+}
+out = {}
+for name, make in families.items():
+    t = {"payloads": 0, "scenarios": 0, "on_flow_kernel": 0, "handed_back_first": 0, "to_next_event": 0, "oracle_checks": 0, "not_in_range": 0}
+    for k in range(n_payloads):
+        payload = make(k)
+        seeds = np.arange(8, dtype=np.uint64) + 1000 * k + 7
+        res = SimulationRunner(simulation_input=payload, seeds=seeds, on_negative_delay="flag").run()
+        ref = SimulationRunner(simulation_input=payload, seeds=seeds, flow=False, on_negative_delay="flag").run()
+        st = res.engine_stats
+        t["payloads"] += 1
+        t["scenarios"] += 8
+        if res.flow_reason:
+            t["not_in_range"] += 1
+        t["on_flow_kernel"] += int(st.flow_scenarios)
+        t["handed_back_first"] += int(st.flow_fallback)
+        t["to_next_event"] += int(st.flow_to_next_event)
+        assert np.array_equal(res.counts[:, :6], ref.counts[:, :6]), (name, k)
+        assert np.array_equal(res.counts[:, _abi.CNT_MARKS], ref.counts[:, _abi.CNT_MARKS]), (name, k)
+        for i in range(8):
+            assert np.array_equal(res[i].rqs_clock.view(np.uint64), ref[i].rqs_clock.view(np.uint64)), (name, k, i)
+            assert np.array_equal(res[i]._samples, ref[i]._samples), (name, k, i)  # noqa: SLF001
+        plan = lower(payload)
+        for i in (0, 7):
+            want = ol.simulate(plan, int(seeds[i]))
+            assert np.array_equal(res[i].counts[:5].astype(np.uint64), want.counts[:5]), (name, k, i)
+            assert np.array_equal(res[i].rqs_clock.view(np.uint64), want.clock.view(np.uint64)), (name, k, i)
+            assert np.array_equal(res[i]._samples, want.samples), (name, k, i)  # noqa: SLF001
+            t["oracle_checks"] += 1
+    out[name] = t
+out["different"] = 0
+print(json.dumps(out))
