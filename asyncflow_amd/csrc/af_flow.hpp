@@ -300,6 +300,10 @@ struct Flow {
     AF_CORE AF_PLAN_AS uint8_t* srv_levels() const { return (AF_PLAN_AS uint8_t*)(lbw() + 20); }
     AF_CORE uint32_t level_of(uint32_t sv) const { return srv_levels()[sv]; }
     uint32_t n_comp, tick_base;
+    // send counter of edge e = index of its next random draw: in the REGISTER of lane e (round 4; n_edges <= 64 sampled series).
+    // A wave-uniform edge is read with v_readlane, a per-lane one through the crossbar; the LDS words of sends() are unused.
+    uint32_t my_sends;
+    AF_CORE uint32_t sends_of(uint32_t e_uniform) const { return W::bcast32(my_sends, e_uniform); }
     double t_lim;                // FEAT_FAR: no station handles an event at or after this time in the current round (the tick ring's window)
     bool gen_done, moved;        // moved: a horizon advanced in this round
     // per-lane accumulators (reduced at the end)
@@ -928,24 +932,19 @@ struct Flow {
     }
 
     // index of each lane's message on its edge: sends[e] + (messages of lower lanes on the same edge).
-    // Candidate edges: the LB's out-edges (payload order) or the servers' out-edges; lane c advances
-    // candidate c's counter afterwards.
+    // Candidate edges: the LB's out-edges (payload order) or the servers' out-edges; the lane that holds a candidate's
+    // counter advances it.
     AF_CORE uint32_t claim_send_index(bool have, uint32_t e, bool server_edges) {
         const uint32_t n_cand = server_edges ? A.n_servers : A.n_lb_edges;
-        uint32_t idx = 0u, add_for_lane = 0u, edge_for_lane = 0u;
+        uint32_t idx = 0u;
         for (uint32_t c = 0u; c < n_cand; ++c) {
             const uint32_t ce = server_edges ? (uint32_t)(blob[A.off_srv + af::SREC * c + 1u] >> 16) & 0xFFFFu
                                              : (uint32_t)blob[A.off_lb + c];
             const uint64_t m = W::ballot(have && e == ce);
-            if (have && e == ce) idx = sends()[ce] + W::mbcnt(m);
-            if (lane == c) {
-                add_for_lane = popc64(m);
-                edge_for_lane = ce;
-            }
+            const uint32_t at = sends_of(ce);
+            if (have && e == ce) idx = at + W::mbcnt(m);
+            if (lane == ce) my_sends += popc64(m);
         }
-        W::sync();
-        if (add_for_lane != 0u) sends()[edge_for_lane] += add_for_lane;
-        W::sync();
         return idx;
     }
 
@@ -1026,7 +1025,7 @@ struct Flow {
             if (c < A.n_lb_edges) {
                 const uint32_t e = (uint32_t)blob[A.off_lb + c];
                 double x = -1.0;
-                if (edge_draw(e, sends()[e] + lane, x)) xs[c] = x;
+                if (edge_draw(e, sends_of(e) + lane, x)) xs[c] = x;
             }
         }
         // What does not depend on the picks either: how many entries of the server list are still in flight towards
@@ -1165,13 +1164,15 @@ struct Flow {
     }
     // `have` lanes: arrival `a` at server `sv`, position `pos` in seg (its server's segment starts at lbw()[LBW_SEG_OFF + sv] and
     // holds lbw()[LBW_SEG_LEN + sv] arrivals).  Returns the lane's times; advances the server's counters and rings.
-    AF_CORE SrvTimes servers_solve(bool arrived, uint32_t sv, uint32_t pos, double a) {
+    // (`seg_off` / `seg_len`: where my server's segment starts and how many arrivals it holds; `srv_cnt`: lane k < n_servers --
+    // how many arrivals server k got in this window: registers, worked out where the segments are, not words of lbw())
+    AF_CORE SrvTimes servers_solve(bool arrived, uint32_t sv, uint32_t pos, double a, uint32_t seg_off, uint32_t seg_len, uint32_t srv_cnt) {
         AF_PLAN_AS uint32_t* lw = lbw();
         // A server whose endpoint needs more RAM than the server has never admits anybody: the first request blocks in
         // RAM.get() for good and everything behind it queues up (server.py:146-149; Container gets are FIFO).  Such
         // arrivals are timed events and nothing else.
         const bool have = arrived && lw[LBW_SLOTS + sv] != 0u;
-        const uint32_t off = have ? lw[LBW_SEG_OFF + sv] : 0u, n_k = have ? lw[LBW_SEG_LEN + sv] : 0u;
+        const uint32_t off = have ? seg_off : 0u, n_k = have ? seg_len : 0u;
         const uint32_t li = pos - off;                         // my index among this window's arrivals of my server
         const uint32_t j = have ? lw[LBW_ARRIVALS + sv] + li : 0u;      // ... and among all of them
         const uint64_t meta = blob[A.off_srv + af::SREC * sv + 1u];
@@ -1231,7 +1232,7 @@ struct Flow {
             ev += r.events;
         }
         W::sync();
-        if (lane < A.n_servers) lw[LBW_ARRIVALS + lane] += lw[LBW_SEG_LEN + lane];
+        if (lane < A.n_servers) lw[LBW_ARRIVALS + lane] += srv_cnt;
         if (arrived && !have) {   // never admitted (the sequential kernels and the oracle report the same, informational, flag)
             r.adm = r.b = r.s = r.f = r.g = AF_INF;
             info |= af::FLAG_RAM_STARVED;
@@ -1803,6 +1804,7 @@ struct Flow {
             prof_t = W::clock();
         }
         cursor = n_comp = tick_base = 0u;
+        my_sends = 0u;
         ev = drops = 0u;
         why = info = 0u;
         run_val = 0;
@@ -1891,9 +1893,8 @@ struct Flow {
                     h_gen = H_in;
                 } else if (st == 1u) {   // client, first visit (client.py:46-60): forward on the client's out-edge
                     e = A.client_out_edge;
-                    idx = sends()[e] + lane;
-                    W::sync();
-                    if (lane == 0u) sends()[e] += n_sel;
+                    idx = sends_of(e) + lane;
+                    if (lane == e) my_sends += n_sel;
                     tgt = (uint32_t)(erec(e)[3] >> 8) & 0xFFu;
                 } else if (st == 2u) {   // load balancer
                     if (n_sel > 0u) {
@@ -1961,7 +1962,7 @@ struct Flow {
                         }
                         const uint32_t oe = (uint32_t)(blob[A.off_srv + af::SREC * me + 1u] >> 16) & 0xFFFFu;
                         const double dts = mine ? u2d(gs(me)[GS_DEPT + mj]) : 0.0, dt0 = mine ? u2d(gs(me)[GS_DEPT0 + mj]) : 0.0;
-                        const uint32_t didx = sends()[oe] + mj;
+                        const uint32_t didx = W::shfl32(my_sends, oe) + mj;
                         double k2 = 0.0, transit = 0.0;
                         bool counted = false;
                         const bool sent = mine && send_draw(oe, didx, transit);
@@ -1980,24 +1981,28 @@ struct Flow {
                         }
                     }
                     W::sync();
-                    if (my_pass) sends()[(uint32_t)(blob[A.off_srv + af::SREC * lane + 1u] >> 16) & 0xFFFFu] += lo32(gs(lane)[GS_DEP]);
+                    for (uint32_t k = 0u; k < A.n_servers; ++k) {   // the servers' out-edges: as many sends as departures
+                        const uint32_t oe_k = (uint32_t)(blob[A.off_srv + af::SREC * k + 1u] >> 16) & 0xFFFFu;
+                        if (lane == oe_k) my_sends += dep_cnt(k);
+                    }
                     W::sync();
                     sending = false;   // (everything this station sends went out above)
                 } else if (st == 3u) {   // servers
                     if (n_sel > 0u) {
                         const uint32_t sv = aux & 0xFFu;
-                        uint32_t pos = 0u, off = 0u;   // per-server segments of the time-ordered arrivals
+                        uint32_t pos = 0u, off = 0u, seg_off = 0u, seg_len = 0u, srv_cnt = 0u;   // per-server segments of the time-ordered arrivals
                         for (uint32_t k = 0u; k < A.n_servers; ++k) {
                             const uint64_t m = W::ballot(have && sv == k);
-                            if (have && sv == k) pos = off + W::mbcnt(m);
-                            if (lane == k) {
-                                lbw()[LBW_SEG_OFF + k] = off;
-                                lbw()[LBW_SEG_LEN + k] = popc64(m);
+                            if (have && sv == k) {
+                                pos = off + W::mbcnt(m);
+                                seg_off = off;
+                                seg_len = popc64(m);
                             }
+                            if (lane == k) srv_cnt = popc64(m);
                             off += popc64(m);
                         }
                         W::sync();   // select()'s scratch is dead from here on: the segments reuse it
-                        const SrvTimes r = servers_solve(have, sv, pos, key);
+                        const SrvTimes r = servers_solve(have, sv, pos, key, seg_off, seg_len, srv_cnt);
                         prof(PROF_SERVERS);
                         if (have) {
                             const uint64_t meta = blob[A.off_srv + af::SREC * sv + 1u];
