@@ -950,24 +950,31 @@ struct Flow {
 
     // ---- load balancer (round robin, lb_algorithms.py:22-36; outages injection.py:201-226) -----------
     // picks for the n_sel messages now in out_key() (time order); lane r gets the out-edge of message r
+    // (round robin: head of the rotation, live out-edges, mark cursor and ceil(2^32 / n_live) are wave-uniform REGISTERS since
+    // round 4 -- lb_head .. lb_magic, written through to lbw()[16..19] only around the rare walk over an outage mark; the
+    // least-connections walk, which never runs in the same scenario, keeps using the LDS words)
+    uint32_t lb_head, lb_nl, lb_mark, lb_magic;
     AF_CORE uint32_t lb_pick(uint32_t n_sel, double my_key) {
         AF_PLAN_AS uint32_t* lw = lbw();
         uint32_t pick = 0u;
-        const uint32_t mi = lw[18];
+        const uint32_t mi = lb_mark;
         const double t_last = bcast_f64(my_key, n_sel - 1u);
         const bool marks_inside = kMarks && mi < A.n_srv_marks && u2d(smark(mi)[0]) <= t_last;
         if (!marks_inside) {
-            const uint32_t head = lw[16], nl = lw[17];
+            const uint32_t head = lb_head, nl = lb_nl;
             // (head + lane) mod nl by multiplication: head + lane < 2^16, magic = ceil(2^32 / nl)
             const uint32_t x = head + lane;
-            const uint32_t q = nl > 1u ? (uint32_t)(((uint64_t)x * lw[19]) >> 32) : x;   // lw[19] = ceil(2^32 / nl), kept with nl
+            const uint32_t q = nl > 1u ? (uint32_t)(((uint64_t)x * lb_magic) >> 32) : x;
             if (lane < n_sel) pick = lw[x - q * nl];
-            W::sync();
-            if (lane == 0u) {   // (head + n_sel) mod nl by the same multiplication as above: a u32 division was 25 instructions per round
-                const uint32_t y = head + n_sel, qy = nl > 1u ? (uint32_t)(((uint64_t)y * lw[19]) >> 32) : y;
-                lw[16] = y - qy * nl;
-            }
+            // (head + n_sel) mod nl by the same multiplication: a u32 division was 25 instructions per round
+            const uint32_t y = head + n_sel, qy = nl > 1u ? (uint32_t)(((uint64_t)y * lb_magic) >> 32) : y;
+            lb_head = y - qy * nl;
+            return pick;
         } else {
+            if (lane == 0u) {
+                lw[16] = lb_head;
+                lw[17] = lb_nl;
+            }
             W::sync();
             if (lane == 0u) {   // rare (one round per outage mark): one lane walks the messages in time order
                 uint32_t head = lw[16], nl = lw[17], cur = mi;
@@ -1000,6 +1007,10 @@ struct Flow {
             }
             W::sync();
             if (lane < n_sel) pick = out_aux()[lane];
+            lb_head = lw[16];
+            lb_nl = lw[17];
+            lb_mark = lw[18];
+            lb_magic = lw[19];
         }
         W::sync();
         return pick;
@@ -1805,6 +1816,9 @@ struct Flow {
         }
         cursor = n_comp = tick_base = 0u;
         my_sends = 0u;
+        lb_head = lb_mark = 0u;
+        lb_nl = A.n_lb_edges;
+        lb_magic = A.n_lb_edges ? 0xFFFFFFFFu / A.n_lb_edges + 1u : 0u;
         ev = drops = 0u;
         why = info = 0u;
         run_val = 0;
