@@ -300,6 +300,7 @@ struct Flow {
     AF_CORE AF_PLAN_AS uint8_t* srv_levels() const { return (AF_PLAN_AS uint8_t*)(lbw() + 20); }
     AF_CORE uint32_t level_of(uint32_t sv) const { return srv_levels()[sv]; }
     uint32_t n_comp, tick_base;
+    double gen_pre;              // arrival time cursor + lane, fetched ahead (AF_INF behind the last draw)
     // send counter of edge e = index of its next random draw: in the REGISTER of lane e (round 4; n_edges <= 64 sampled series).
     // A wave-uniform edge is read with v_readlane, a per-lane one through the crossbar; the LDS words of sends() are unused.
     uint32_t my_sends;
@@ -1815,6 +1816,7 @@ struct Flow {
             prof_t = W::clock();
         }
         cursor = n_comp = tick_base = 0u;
+        gen_pre = lane < A.n_draw ? arr[lane] : AF_INF;
         my_sends = 0u;
         lb_head = lb_mark = 0u;
         lb_nl = A.n_lb_edges;
@@ -1866,8 +1868,8 @@ struct Flow {
                 if (st == 0u) {   // generator (rqs_generator.py:97-119): up to 64 arrivals
                     uint32_t room = (kBig ? cap_of(0u) : cap) - nl0;
                     room = room < 64u ? room : 64u;
-                    const uint32_t i = cursor + lane;
-                    t0 = (lane < room && i < A.n_draw) ? arr[i] : AF_INF;
+                    // (arrival cursor + lane was fetched a round ago -- gen_pre -- so the station never waits for HBM: round 4)
+                    t0 = lane < room ? gen_pre : AF_INF;
                     const double t_cap = kFar ? t_lim
                                          : (samples != nullptr && (!kHbmRing || A.L.ring_rows != 0u)) ? (double)(tick_base + A.L.win_rows) * A.sample_period
                                                                                                        : AF_INF;
@@ -1902,7 +1904,9 @@ struct Flow {
                     e = A.gen_out_edge;
                     idx = cursor + lane;
                     cursor += n_sel;
-                    H_in = cursor < A.n_draw ? arr[cursor] : AF_INF;   // next arrival not yet generated
+                    // next arrival not yet generated: one of the fetched ones unless all 64 went out
+                    H_in = n_sel < 64u ? bcast_f64(gen_pre, n_sel) : cursor < A.n_draw ? arr[cursor] : AF_INF;
+                    gen_pre = cursor + lane < A.n_draw ? arr[cursor + lane] : AF_INF;   // (used a round later)
                     gen_done = !(H_in < T);
                     h_gen = H_in;
                 } else if (st == 1u) {   // client, first visit (client.py:46-60): forward on the client's out-edge
