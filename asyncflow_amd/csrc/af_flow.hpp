@@ -439,8 +439,7 @@ struct Flow {
         add_point(series, ib, -w, span);
     }
     // rows [tick_base, upto) are final: prefix-sum the differences and stream the rows out
-    AF_CORE void flush_ticks(uint32_t upto, bool final = true) {
-        uint32_t flushed = upto;
+    AF_CORE void flush_ticks(uint32_t upto) {
         if (samples != nullptr) {
             const uint32_t R = A.L.ring_rows, pitch = A.L.pitch, n_series = A.n_edges + 3u * A.n_servers;
             const bool edges_on = (A.metrics_mask & af::METRIC_EDGE) != 0u;
@@ -479,15 +478,9 @@ struct Flow {
                 const bool s_srv = ser >= A.n_edges && ser < n_series;
                 const bool s_ram = s_srv && (ser - A.n_edges) % 3u == 2u;
                 const bool s_on = ser < A.n_edges ? edges_on : (s_srv && servers_on);
-#if defined(AF_EXP_FLUSHFULL)
-                // Experiment (round 4): only FULL steps leave before the end of the run (a step is one contiguous store of rpi rows;
-                // ~8.6 rows become final per round of LB-2: two steps, the second one mostly empty); the rest waits a round
-                uint32_t r0 = tick_base;
-                // (a round with less than one full step of final rows lets them go all the same: the window of the generator hangs on tick_base)
-                for (const uint32_t first = r0; r0 < stop && (final || r0 + rpi <= stop || r0 == first); r0 += rpi) {
-#else
+                // (measured, round 4: letting only FULL steps leave before the end of the run -- ~8.6 rows become final per round of
+                // LB-2, i.e. two steps of five, the second mostly empty -- gains nothing: 37.74 vs 37.93 ms)
                 for (uint32_t r0 = tick_base; r0 < stop; r0 += rpi) {
-#endif
                     const uint32_t rr = r0 + q, n_rows = stop - r0 < rpi ? stop - r0 : rpi;
                     const bool valid = q < n_rows;
                     int32_t acc = 0;
@@ -510,9 +503,6 @@ struct Flow {
                     const int32_t last = (int32_t)W::shfl32((uint32_t)value, ((n_rows - 1u) * pitch + lane) & 63u);
                     if (lane < pitch) run_val = last;
                 }
-#if defined(AF_EXP_FLUSHFULL)
-                if (!final && r0 < upto) flushed = r0;
-#endif
             } else {
                 for (uint32_t r = tick_base; r < stop; ++r) {
                     if (lane < pitch) {
@@ -526,8 +516,7 @@ struct Flow {
                 }
             }
         }
-        (void)final;
-        tick_base = flushed;
+        tick_base = upto;
     }
 
     // ---- edges --------------------------------------------------------------------------------------
@@ -2123,7 +2112,7 @@ struct Flow {
             }
             const bool finished = gen_done && work == 0u && !(h_min < T);
             W::sync();
-            flush_ticks(finished ? A.n_ticks : tick_index(h_min, false), finished);
+            flush_ticks(finished ? A.n_ticks : tick_index(h_min, false));
             W::sync();
             prof(PROF_FLUSH);
 #if defined(AF_FLOW_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
