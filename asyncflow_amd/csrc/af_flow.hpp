@@ -238,8 +238,8 @@ enum : uint32_t { PROF_SETUP, PROF_GEN, PROF_SELECT, PROF_SERIES_RECV, PROF_STAT
 //                  Everything a server of level k receives before min(horizon of the station in front of the servers, send floor
 //                  of every level below k) is in the list, because a request leaves a server no earlier than it arrived.  What a
 //                  level sends goes to the completion list or back into the server list, lane by lane.  Tandem or general
-//                  servers (FEAT_GENSRV: the event-by-event station runs the servers of the pass's level); not behind a
-//                  least-connections LB.
+//                  servers (FEAT_GENSRV: the event-by-event station runs the servers of the pass's level); behind a
+//                  least-connections LB (tandem servers only) the LB counts the list entries that came by ITS edges.
 //   FEAT_PROF      measurement builds only: the wave's shader-clock time per section of run() (FlowArgs::prof)
 enum : uint32_t { FEAT_MARKS = 1u, FEAT_ONLINE = 2u, FEAT_HBM_RING = 4u, FEAT_FAR = 64u, FEAT_ALL = 7u | FEAT_FAR, FEAT_TIEBREAK = 8u,
                   FEAT_BIGLIST = 16u, FEAT_LC = 32u, FEAT_PROF = 128u, FEAT_GENSRV = 256u, FEAT_CHAIN = 512u };
@@ -251,7 +251,7 @@ struct Flow {
                           kHbmRing = (FEAT & FEAT_HBM_RING) != 0u, kTieBreak = (FEAT & FEAT_TIEBREAK) != 0u,
                           kBig = (FEAT & FEAT_BIGLIST) != 0u, kLC = (FEAT & FEAT_LC) != 0u, kFar = (FEAT & FEAT_FAR) != 0u,
                           kProf = (FEAT & FEAT_PROF) != 0u, kGen = (FEAT & FEAT_GENSRV) != 0u, kChain = (FEAT & FEAT_CHAIN) != 0u;
-    static_assert(!(kChain && kLC), "server levels: round-robin LB (or none)");
+    static_assert(!(kChain && kLC) || (kFar && !kGen), "server levels behind a least-connections LB: list entries carry their in-edge (FEAT_FAR); tandem servers");
     // FEAT_PROF: the time since the previous mark belongs to `section` (marks sit at the END of a section, in
     // wave-uniform control flow, with a compile-time section: the accumulators stay in scalar registers)
     unsigned long long prof_t, prof_acc[kProfSections];
@@ -1049,10 +1049,14 @@ struct Flow {
         const AF_PLAN_AS uint16_t* AX = list_aux();
         const uint32_t n2 = n_list_get(2u);
         uint64_t b_lo = 0ull, b_hi = 0ull;
+        uint64_t lb_edges = 0ull;   // FEAT_CHAIN: the server list also holds what servers send to servers -- not in flight on an LB edge
+        if (kChain)
+            for (uint32_t c = 0u; c < A.n_lb_edges; ++c) lb_edges |= 1ull << ((uint32_t)blob[A.off_lb + c] & 63u);
         for (uint32_t i2 = 0u; i2 < n2; ++i2) {
             const double k = K2[i2];
-            const uint32_t ax = W::bcast32(AX[i2], 0u) & 0xFFu;
-            const uint64_t inc = k > my_key ? 1ull << (16u * (ax & 3u)) : 0ull;
+            const uint32_t axw = W::bcast32(AX[i2], 0u), ax = axw & 0xFFu;
+            const bool by_lb = !kChain || ((lb_edges >> ((axw >> 8) & 63u)) & 1ull) != 0ull;
+            const uint64_t inc = (by_lb && k > my_key) ? 1ull << (16u * (ax & 3u)) : 0ull;
             if (ax < 4u) b_lo += inc;
             else b_hi += inc;
             if (k == my_key) why |= FLOW_WHY_TIE;   // a delivery by the LB's edges at the very instant of a decision

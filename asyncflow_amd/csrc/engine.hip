@@ -1339,7 +1339,7 @@ int plan_flow(const af_engine* e, const KArgs& a, const af_sweep_t* sweep, const
     // injected spikes / outages, but neither the kernel-side summary nor tick differences in HBM (BASELINE config 4)
     const bool marks_only = !lean && !has_online && ring_ok;
     constexpr uint32_t kRobust = aff::FEAT_ALL | aff::FEAT_TIEBREAK | aff::FEAT_BIGLIST;
-    const bool chain = e->flow_chain;   // (never with lc: flow_ineligible_reason)
+    const bool chain = e->flow_chain;
     P.lean = lean && !flow_big && !lc && !chain;
     if (P.gen_compact) {
         P.ipl = 1u;
@@ -1349,7 +1349,7 @@ int plan_flow(const af_engine* e, const KArgs& a, const af_sweep_t* sweep, const
         P.feat = kRobust | (lc ? (uint32_t)aff::FEAT_LC : 0u) | (gen_srv ? (uint32_t)aff::FEAT_GENSRV : 0u) | (chain ? (uint32_t)aff::FEAT_CHAIN : 0u);
     } else if (chain) {   // one generic instantiation per list length (every optional feature in); the plan-specialised build is the same FEAT
         P.ipl = FL.cap == 64u ? 1u : FL.cap == 128u ? 2u : 4u;
-        P.feat = aff::FEAT_ALL | aff::FEAT_CHAIN;
+        P.feat = aff::FEAT_ALL | aff::FEAT_CHAIN | (lc ? (uint32_t)aff::FEAT_LC : 0u);
     } else if (lc) {
         P.ipl = FL.cap == 64u ? 1u : FL.cap == 128u ? 2u : 4u;
         P.feat = aff::FEAT_ALL | aff::FEAT_LC;
@@ -1380,6 +1380,10 @@ const void* flow_kernel_for(uint32_t ipl, uint32_t feat) {
     AF_FLOW_CASE(1u, kAll | (uint32_t)aff::FEAT_CHAIN);
     AF_FLOW_CASE(2u, kAll | (uint32_t)aff::FEAT_CHAIN);
     AF_FLOW_CASE(4u, kAll | (uint32_t)aff::FEAT_CHAIN);
+    AF_FLOW_CASE(1u, kRobust | kLC | (uint32_t)aff::FEAT_CHAIN);   // ... behind a least-connections LB
+    AF_FLOW_CASE(1u, kAll | kLC | (uint32_t)aff::FEAT_CHAIN);
+    AF_FLOW_CASE(2u, kAll | kLC | (uint32_t)aff::FEAT_CHAIN);
+    AF_FLOW_CASE(4u, kAll | kLC | (uint32_t)aff::FEAT_CHAIN);
     AF_FLOW_CASE(1u, kAll | kLC);
     AF_FLOW_CASE(2u, kAll | kLC);
     AF_FLOW_CASE(4u, kAll | kLC);
@@ -2084,6 +2088,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
                 const void* fn2 = (FP.gen_compact && e->flow_chain) ? reinterpret_cast<const void*>(af_flow_kernel<1, kRobust | aff::FEAT_GENSRV | aff::FEAT_CHAIN>)
                                   : (FP.gen_compact && f2.lb_least_connections) ? reinterpret_cast<const void*>(af_flow_kernel<1, kRobust | aff::FEAT_LC | aff::FEAT_GENSRV>)
                                   : FP.gen_compact        ? reinterpret_cast<const void*>(af_flow_kernel<1, kRobust | aff::FEAT_GENSRV>)
+                                  : (f2.lb_least_connections && e->flow_chain) ? reinterpret_cast<const void*>(af_flow_kernel<1, kRobust | aff::FEAT_LC | aff::FEAT_CHAIN>)
                                   : f2.lb_least_connections ? reinterpret_cast<const void*>(af_flow_kernel<1, kRobust | aff::FEAT_LC>)
                                   : e->flow_chain         ? reinterpret_cast<const void*>(af_flow_kernel<1, kRobust | aff::FEAT_CHAIN>)
                                                           : reinterpret_cast<const void*>(af_flow_kernel<1, kRobust>);

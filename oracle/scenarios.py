@@ -356,7 +356,7 @@ def shared_backend(users: float = 200, horizon: int = 120) -> dict:
     }
 
 
-def server_tiers(rng: random.Random, horizon: int = 15, general: bool = False) -> dict:
+def server_tiers(rng: random.Random, horizon: int = 15, general: bool = False, algo: str = "round_robin") -> dict:
     """Feed-forward topologies in which servers feed servers (FEAT_CHAIN of the stage-parallel kernel; `general`: some
     servers with two endpoints or a step program that comes back to the core queue -- FEAT_GENSRV | FEAT_CHAIN):
     client -> [LB ->] front servers -> [middle ->] backend -> client, up to three levels, a front server may also
@@ -425,7 +425,7 @@ def server_tiers(rng: random.Random, horizon: int = 15, general: bool = False) -
     edges.append(edge("back-c", "back", "cli"))
     nodes: dict[str, Any] = {"client": {"id": "cli"}, "servers": servers}
     if use_lb:
-        nodes["load_balancer"] = {"id": "lb", "algorithms": "round_robin", "server_covered": covered}
+        nodes["load_balancer"] = {"id": "lb", "algorithms": algo, "server_covered": covered}
     p: dict[str, Any] = {
         "rqs_input": {"id": "gen", "avg_active_users": {"mean": rng.choice([20, 60, 150])},
                       "avg_request_per_minute_per_user": {"mean": rng.choice([30, 60])}, "user_sampling_window": rng.choice([3, 10])},

@@ -285,6 +285,10 @@ extern "C" int hc_flow_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ov
     auto body = [&]() {
         if (chain && gen_srv && !robust) { aff::Flow<emu::WaveEmu, 1, kAll | aff::FEAT_BIGLIST | kGen | kChain> f(a); f.run(lds.data(), 0u); }
         else if (chain && gen_srv) { aff::Flow<emu::WaveEmu, 1, kRobust | kGen | kChain> f(a); f.run(lds.data(), 0u); }
+        else if (chain && lc && robust) { aff::Flow<emu::WaveEmu, 1, kRobust | kLC | kChain> f(a); f.run(lds.data(), 0u); }
+        else if (chain && lc && ipl == 1) { aff::Flow<emu::WaveEmu, 1, kAll | kLC | kChain> f(a); f.run(lds.data(), 0u); }
+        else if (chain && lc && ipl == 2) { aff::Flow<emu::WaveEmu, 2, kAll | kLC | kChain> f(a); f.run(lds.data(), 0u); }
+        else if (chain && lc) { aff::Flow<emu::WaveEmu, 4, kAll | kLC | kChain> f(a); f.run(lds.data(), 0u); }
         else if (chain && robust) { aff::Flow<emu::WaveEmu, 1, kRobust | kChain> f(a); f.run(lds.data(), 0u); }
         else if (chain && ipl == 1) { aff::Flow<emu::WaveEmu, 1, kAll | kChain> f(a); f.run(lds.data(), 0u); }
         else if (chain && ipl == 2) { aff::Flow<emu::WaveEmu, 2, kAll | kChain> f(a); f.run(lds.data(), 0u); }

@@ -116,7 +116,10 @@ def test_small_lists_hand_the_scenario_back_instead_of_dropping_messages():
 def test_plans_outside_the_feed_forward_range_are_refused():
     odd_ram = lb_two_servers(horizon=10)
     odd_ram["topology_graph"]["nodes"]["servers"][0]["endpoints"][0]["steps"][1]["step_operation"]["necessary_ram"] = 100.1
-    lc_chain = server_chain("exponential", 0.003)        # servers feeding servers run there since round 3 -- behind a round-robin LB
+    # (servers feeding servers run there since round 4, behind a least-connections LB too -- but not such servers with several endpoints)
+    lc_chain = server_chain("exponential", 0.003)
+    lc_chain["topology_graph"]["nodes"]["servers"][0]["endpoints"].append(
+        copy.deepcopy(lc_chain["topology_graph"]["nodes"]["servers"][0]["endpoints"][0]) | {"endpoint_name": "/second"})
     lc_chain["topology_graph"]["nodes"]["load_balancer"] = {"id": "lb", "algorithms": "least_connection", "server_covered": ["s0"]}
     for e in lc_chain["topology_graph"]["edges"]:
         if e["id"] == "c-s0":
@@ -162,6 +165,23 @@ def test_fuzzed_server_tiers_are_exact_or_handed_back(block):
         exact += status == "exact"
         assert _run(p, 300 + case, robust=True, ring_rows=0, long_list_entries=1024)[0] == "exact", case
     assert exact >= 14
+
+
+def test_server_tiers_behind_a_least_connections_lb():
+    """Round 4: the least-connections walk counts the entries of the server list that came by the LB's OWN edges (a list
+    entry carries its in-edge): what the front servers send to the backend is in the same list and is not in flight on an
+    LB edge (lb_algorithms.py:10-20 counts edge.concurrent_connections of the LB's out-edges)."""
+    exact = with_lb = 0
+    for case in range(24):
+        p = server_tiers(random.Random(94000 + case), algo="least_connection")
+        if "load_balancer" not in p["topology_graph"]["nodes"]:
+            continue
+        with_lb += 1
+        status, _ = _run(p, 700 + case, ipl=2, ring_rows=64)
+        assert status in ("exact", "fallback")
+        exact += status == "exact"
+        assert _run(p, 700 + case, robust=True, ring_rows=0, long_list_entries=1024)[0] == "exact", case
+    assert with_lb >= 8 and exact >= with_lb - 4
 
 
 @pytest.mark.parametrize("block", range(2))

@@ -652,6 +652,27 @@ def test_servers_that_feed_servers_run_on_the_flow_kernel():
     assert stayed >= total - 4, f"{stayed} of {total} scenarios stayed on the stage-parallel kernel"
 
 
+def test_server_tiers_behind_a_least_connections_lb_run_on_the_flow_kernel():
+    """Round 4: server tiers behind a least-connections LB (FEAT_CHAIN | FEAT_LC): the walk counts the list entries that came by
+    the LB's own edges.  Against the oracle and the next-event kernels."""
+    from oracle.scenarios import server_tiers
+
+    ran = 0
+    for k in range(12):
+        payload = server_tiers(random.Random(94000 + k), horizon=12, algo="least_connection")
+        if "load_balancer" not in payload["topology_graph"]["nodes"]:
+            continue
+        ran += 1
+        seeds = np.arange(8, dtype=np.uint64) + 90 * k
+        res = _runner(payload, seeds=seeds).run()
+        assert res.flow_reason == "" and res.engine_stats.flow_scenarios == 8, res.flow_reason
+        plan = lower(payload)
+        for i in (0, 7):
+            _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])), f"least-connections tiers {k} scenario {i}")
+        _same_batches(res, _runner(payload, seeds=seeds, flow=False).run())
+    assert ran >= 4
+
+
 def test_tiers_of_general_servers_run_on_the_flow_kernel():
     """Round 4: server tiers whose servers have two endpoints or come back to the core queue after an I/O step
     (FEAT_GENSRV | FEAT_CHAIN: the event-by-event station runs the servers of each level up to that level's horizon) against
