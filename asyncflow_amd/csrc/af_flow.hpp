@@ -239,7 +239,7 @@ enum : uint32_t { PROF_SETUP, PROF_GEN, PROF_SELECT, PROF_SERIES_RECV, PROF_STAT
 //                  of every level below k) is in the list, because a request leaves a server no earlier than it arrived.  What a
 //                  level sends goes to the completion list or back into the server list, lane by lane.  Tandem or general
 //                  servers (FEAT_GENSRV: the event-by-event station runs the servers of the pass's level); behind a
-//                  least-connections LB (tandem servers only) the LB counts the list entries that came by ITS edges.
+//                  least-connections LB the walk counts the list entries that came by the LB's OWN edges.
 //   FEAT_PROF      measurement builds only: the wave's shader-clock time per section of run() (FlowArgs::prof)
 enum : uint32_t { FEAT_MARKS = 1u, FEAT_ONLINE = 2u, FEAT_HBM_RING = 4u, FEAT_FAR = 64u, FEAT_ALL = 7u | FEAT_FAR, FEAT_TIEBREAK = 8u,
                   FEAT_BIGLIST = 16u, FEAT_LC = 32u, FEAT_PROF = 128u, FEAT_GENSRV = 256u, FEAT_CHAIN = 512u };
@@ -251,7 +251,7 @@ struct Flow {
                           kHbmRing = (FEAT & FEAT_HBM_RING) != 0u, kTieBreak = (FEAT & FEAT_TIEBREAK) != 0u,
                           kBig = (FEAT & FEAT_BIGLIST) != 0u, kLC = (FEAT & FEAT_LC) != 0u, kFar = (FEAT & FEAT_FAR) != 0u,
                           kProf = (FEAT & FEAT_PROF) != 0u, kGen = (FEAT & FEAT_GENSRV) != 0u, kChain = (FEAT & FEAT_CHAIN) != 0u;
-    static_assert(!(kChain && kLC) || (kFar && !kGen), "server levels behind a least-connections LB: list entries carry their in-edge (FEAT_FAR); tandem servers");
+    static_assert(!(kChain && kLC) || kFar, "server levels behind a least-connections LB: list entries carry their in-edge (FEAT_FAR)");
     // FEAT_PROF: the time since the previous mark belongs to `section` (marks sit at the END of a section, in
     // wave-uniform control flow, with a compile-time section: the accumulators stay in scalar registers)
     unsigned long long prof_t, prof_acc[kProfSections];

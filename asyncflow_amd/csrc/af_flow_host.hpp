@@ -92,8 +92,6 @@ inline std::string flow_ineligible_reason(const af_plan_t& p) {
         }
     }
     if (flow_needs_chain(p)) {   // (round 4: the server station once per level -- af_flow.hpp, FEAT_CHAIN)
-        if (p.has_lb && p.lb_algo == AF_LB_LEAST_CONNECTIONS && flow_needs_general_servers(p))
-            return "server chain with several endpoints per server behind a least-connections load balancer";
         const uint32_t levels = flow_server_levels(p, nullptr);
         if (levels == 0u) return "servers feed each other in a cycle";
         if (levels > kMaxLevels) return "server chain deeper than three levels";

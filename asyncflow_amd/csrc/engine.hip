@@ -1376,6 +1376,8 @@ const void* flow_kernel_for(uint32_t ipl, uint32_t feat) {
     AF_FLOW_CASE(1u, kAll | (uint32_t)aff::FEAT_BIGLIST | (uint32_t)aff::FEAT_GENSRV | kLC);
     AF_FLOW_CASE(1u, kAll | (uint32_t)aff::FEAT_BIGLIST | (uint32_t)aff::FEAT_GENSRV | (uint32_t)aff::FEAT_CHAIN);   // general servers in tiers
     AF_FLOW_CASE(1u, kRobust | (uint32_t)aff::FEAT_GENSRV | (uint32_t)aff::FEAT_CHAIN);
+    AF_FLOW_CASE(1u, kAll | (uint32_t)aff::FEAT_BIGLIST | (uint32_t)aff::FEAT_GENSRV | kLC | (uint32_t)aff::FEAT_CHAIN);
+    AF_FLOW_CASE(1u, kRobust | (uint32_t)aff::FEAT_GENSRV | kLC | (uint32_t)aff::FEAT_CHAIN);
     AF_FLOW_CASE(1u, kRobust | (uint32_t)aff::FEAT_CHAIN);   // servers that feed servers: the second-chance form and one per list length
     AF_FLOW_CASE(1u, kAll | (uint32_t)aff::FEAT_CHAIN);
     AF_FLOW_CASE(2u, kAll | (uint32_t)aff::FEAT_CHAIN);
@@ -2085,7 +2087,8 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
                     a.scen_map = nullptr;
                 }
                 constexpr uint32_t kRobust = aff::FEAT_ALL | aff::FEAT_TIEBREAK | aff::FEAT_BIGLIST;
-                const void* fn2 = (FP.gen_compact && e->flow_chain) ? reinterpret_cast<const void*>(af_flow_kernel<1, kRobust | aff::FEAT_GENSRV | aff::FEAT_CHAIN>)
+                const void* fn2 = (FP.gen_compact && e->flow_chain && f2.lb_least_connections) ? reinterpret_cast<const void*>(af_flow_kernel<1, kRobust | aff::FEAT_GENSRV | aff::FEAT_LC | aff::FEAT_CHAIN>)
+                                  : (FP.gen_compact && e->flow_chain) ? reinterpret_cast<const void*>(af_flow_kernel<1, kRobust | aff::FEAT_GENSRV | aff::FEAT_CHAIN>)
                                   : (FP.gen_compact && f2.lb_least_connections) ? reinterpret_cast<const void*>(af_flow_kernel<1, kRobust | aff::FEAT_LC | aff::FEAT_GENSRV>)
                                   : FP.gen_compact        ? reinterpret_cast<const void*>(af_flow_kernel<1, kRobust | aff::FEAT_GENSRV>)
                                   : (f2.lb_least_connections && e->flow_chain) ? reinterpret_cast<const void*>(af_flow_kernel<1, kRobust | aff::FEAT_LC | aff::FEAT_CHAIN>)

@@ -283,7 +283,9 @@ extern "C" int hc_flow_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ov
     const bool chain = aff::flow_needs_chain(*p);   // servers feed servers: the FEAT_CHAIN instantiations (engine.hip: plan_flow)
     constexpr uint32_t kChain = aff::FEAT_CHAIN;
     auto body = [&]() {
-        if (chain && gen_srv && !robust) { aff::Flow<emu::WaveEmu, 1, kAll | aff::FEAT_BIGLIST | kGen | kChain> f(a); f.run(lds.data(), 0u); }
+        if (chain && gen_srv && lc && !robust) { aff::Flow<emu::WaveEmu, 1, kAll | aff::FEAT_BIGLIST | kGen | kLC | kChain> f(a); f.run(lds.data(), 0u); }
+        else if (chain && gen_srv && lc) { aff::Flow<emu::WaveEmu, 1, kRobust | kGen | kLC | kChain> f(a); f.run(lds.data(), 0u); }
+        else if (chain && gen_srv && !robust) { aff::Flow<emu::WaveEmu, 1, kAll | aff::FEAT_BIGLIST | kGen | kChain> f(a); f.run(lds.data(), 0u); }
         else if (chain && gen_srv) { aff::Flow<emu::WaveEmu, 1, kRobust | kGen | kChain> f(a); f.run(lds.data(), 0u); }
         else if (chain && lc && robust) { aff::Flow<emu::WaveEmu, 1, kRobust | kLC | kChain> f(a); f.run(lds.data(), 0u); }
         else if (chain && lc && ipl == 1) { aff::Flow<emu::WaveEmu, 1, kAll | kLC | kChain> f(a); f.run(lds.data(), 0u); }

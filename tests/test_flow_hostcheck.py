@@ -116,16 +116,13 @@ def test_small_lists_hand_the_scenario_back_instead_of_dropping_messages():
 def test_plans_outside_the_feed_forward_range_are_refused():
     odd_ram = lb_two_servers(horizon=10)
     odd_ram["topology_graph"]["nodes"]["servers"][0]["endpoints"][0]["steps"][1]["step_operation"]["necessary_ram"] = 100.1
-    # (servers feeding servers run there since round 4, behind a least-connections LB too -- but not such servers with several endpoints)
-    lc_chain = server_chain("exponential", 0.003)
-    lc_chain["topology_graph"]["nodes"]["servers"][0]["endpoints"].append(
-        copy.deepcopy(lc_chain["topology_graph"]["nodes"]["servers"][0]["endpoints"][0]) | {"endpoint_name": "/second"})
-    lc_chain["topology_graph"]["nodes"]["load_balancer"] = {"id": "lb", "algorithms": "least_connection", "server_covered": ["s0"]}
-    for e in lc_chain["topology_graph"]["edges"]:
-        if e["id"] == "c-s0":
+    feeds_lb = server_chain("exponential", 0.003)          # (servers feeding servers are in range since round 4; a server feeding the LB is not)
+    feeds_lb["topology_graph"]["nodes"]["load_balancer"] = {"id": "lb", "algorithms": "round_robin", "server_covered": ["s1"]}
+    for e in feeds_lb["topology_graph"]["edges"]:
+        if e["source"] == "s0" and e["target"] == "s1":
             e["target"] = "lb"
-    lc_chain["topology_graph"]["edges"].append({"id": "lb-s0", "source": "lb", "target": "s0", "latency": {"mean": 0.003, "distribution": "exponential"}})
-    for payload, word in ((odd_ram, "1/256 MB"), (wide_fanout(horizon=12), "16 servers"), (lc_chain, "least-connections")):
+    feeds_lb["topology_graph"]["edges"].append({"id": "lb-s1", "source": "lb", "target": "s1", "latency": {"mean": 0.003, "distribution": "exponential"}})
+    for payload, word in ((odd_ram, "1/256 MB"), (wide_fanout(horizon=12), "16 servers"), (feeds_lb, "load balancer")):
         assert hc.flow_simulate(lower(payload), 1) is None
         assert word in hc.flow_reason()
 
@@ -182,6 +179,11 @@ def test_server_tiers_behind_a_least_connections_lb():
         exact += status == "exact"
         assert _run(p, 700 + case, robust=True, ring_rows=0, long_list_entries=1024)[0] == "exact", case
     assert with_lb >= 8 and exact >= with_lb - 4
+    # ... and with general servers in the tiers (FEAT_GENSRV | FEAT_LC | FEAT_CHAIN)
+    for case in range(24, 40):
+        p = server_tiers(random.Random(94000 + case), general=True, algo="least_connection")
+        assert _run(p, 700 + case, ipl=1, ring_rows=32)[0] in ("exact", "fallback")
+        assert _run(p, 700 + case, robust=True, ring_rows=0, long_list_entries=1024)[0] == "exact", case
 
 
 @pytest.mark.parametrize("block", range(2))

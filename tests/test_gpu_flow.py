@@ -658,8 +658,8 @@ def test_server_tiers_behind_a_least_connections_lb_run_on_the_flow_kernel():
     from oracle.scenarios import server_tiers
 
     ran = 0
-    for k in range(12):
-        payload = server_tiers(random.Random(94000 + k), horizon=12, algo="least_connection")
+    for k in range(16):   # (the last four: general servers in the tiers -- FEAT_GENSRV | FEAT_LC | FEAT_CHAIN)
+        payload = server_tiers(random.Random(94000 + k), horizon=12, algo="least_connection", general=k >= 12)
         if "load_balancer" not in payload["topology_graph"]["nodes"]:
             continue
         ran += 1
