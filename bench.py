@@ -293,7 +293,7 @@ def kernel_sources_sha1() -> str:
 
 def attach_binding(roof: dict, dom_ms: float, events_rank: float, args, n: int, wl: dict) -> None:
     """What limits the dominant kernel, from the committed PMC passes of THIS command (rocprofv3 cannot run inside the
-    timed bench): newest profiles/rNN/binding.json (scripts/profile_round3.sh + make_binding_json.py).  `stale` says
+    timed bench): newest profiles/rNN/binding.json (scripts/profile_round4.sh + make_binding_json.py).  `stale` says
     whether the kernel sources changed since the profile was taken; times are this run's."""
     roof["binding"] = "valu_issue"
     if not (args.config == 2 and n == 10_000 and not args.no_series and wl["horizon"] == 600):

@@ -342,7 +342,7 @@ def server_chain(dist: str = "poisson", mean: float = 0.7, cores: int = 2, horiz
 
 def shared_backend(users: float = 200, horizon: int = 120) -> dict:
     """client -> LB -> {a1, a2} -> b (a backend both front servers call) -> client: the deterministic server-tier payload of
-    the round-3 measurements (scripts/gpu_r3_chain.py)."""
+    the server-tier measurements (scripts/gpu_chain.py)."""
     ep_a = [_endpoint("/a", [("initial_parsing", 0.002), ("ram", 64), ("io_wait", 0.006)])]
     ep_b = [_endpoint("/b", [("io_db", 0.003), ("ram", 32), ("cpu_bound_operation", 0.0015), ("io_wait", 0.002)])]
     servers = [_server("a1", 1, 1024, ep_a), _server("a2", 2, 1024, ep_a), _server("b", 2, 2048, ep_b)]

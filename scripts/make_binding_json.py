@@ -1,4 +1,4 @@
-"""profiles/rNN/binding.json + traffic.json from the passes of scripts/profile_round3.sh.
+"""profiles/rNN/binding.json + traffic.json from the passes of scripts/profile_round4.sh.
 
     python scripts/make_binding_json.py profiles/r03      (or gpurun_out/prof_r03 on the GPU box)
 
