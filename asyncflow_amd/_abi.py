@@ -19,7 +19,6 @@ AF_OK = 0
 AF_ERR_INVALID = -1
 AF_ERR_NO_DEVICE = -2
 DEVICE_PLAN_ONLY = -1          # AF_DEVICE_PLAN_ONLY
-FLOW_FEAT_GENSRV = 256         # aff::FEAT_GENSRV in the -DAF_FJ_FEAT=<n> flag of a stage-parallel spec (af_flow.hpp)
 AF_ERR_HIP = -3
 AF_ERR_CAPACITY = -4
 AF_ERR_ABI = -5

@@ -396,12 +396,12 @@ class SimulationRunner:
         clock_cap = int(self.clock_capacity or self.plan.clock_capacity(users_max, rpm_max))
         return cap, fifo, clock_cap
 
-    def _want_specialised(self, n: int, clock_cap: int, on_flow_kernel: bool = False, general_servers: bool = False) -> bool:
+    def _want_specialised(self, n: int, clock_cap: int, on_flow_kernel: bool = False) -> bool:
         # ~7 request-events per completed request; clock_cap bounds the completions of one scenario.  A hipcc run (~3 s) pays
-        # where it saves more: the tandem form of the stage-parallel kernel gains 0.05 ns per request-event (64 -> 43 ms per
-        # 5.5e9), its general-server form 0.22 ns (119 -> 54 ms per 2.9e8: the event-by-event station is a chain of LDS round
-        # trips whose offsets the build turns into immediates), the next-event kernels 0.04 ns but they run 50 x longer
-        return 7.0 * clock_cap * n > (1e10 if general_servers else 5e10 if on_flow_kernel else 1e9)
+        # where it saves more: the stage-parallel kernel gains ~0.05 ns per request-event in its tandem form (64 -> 43 ms per
+        # 5.5e9) and in its general-server form alike (1 360 -> 1 052 ms per 6.2e9, measured round 4), the next-event kernels
+        # 0.04 ns but they run 50 x longer per event
+        return 7.0 * clock_cap * n > (5e10 if on_flow_kernel else 1e9)
 
     def _plan_key(self) -> str:
         import hashlib
@@ -504,10 +504,8 @@ class SimulationRunner:
             if self.specialise is None:
                 # which kernel family this sweep runs on is the ENGINE's decision (plan range, general servers above a
                 # few scenarios, a sweep it cannot be sized for): read it off the spec it would launch
-                spec = eng.jit_spec(self.seeds, cols, **run_kw)
-                feat = re.search(r"-DAF_FJ_FEAT=(\d+)", spec)
-                build = self._want_specialised(n, clock_cap, "-DAF_FLOW_JIT=1" in spec,
-                                               feat is not None and (int(feat.group(1)) & _abi.FLOW_FEAT_GENSRV) != 0)
+                on_flow_kernel = "-DAF_FLOW_JIT=1" in eng.jit_spec(self.seeds, cols, **run_kw)
+                build = self._want_specialised(n, clock_cap, on_flow_kernel)
             stats = eng.run(
                 self.seeds,
                 cols,
