@@ -121,6 +121,25 @@ def test_a_ring_shorter_than_the_stay_in_a_server_hands_back():
     _assert_scenario(res[3], ol.simulate(lower(payload), int(seeds[3])), "scenario 3")
 
 
+def test_a_handed_back_scenario_costs_a_wave_not_a_next_event_pass():
+    """what the lean launch hands back is re-simulated by the second-chance launch of the same kernel -- one
+    WAVE per scenario, 256-entry lists with send times, tick differences in HBM -- and only what THAT hands back goes to the
+    next-event kernels (one lane per scenario, a latency-bound pass).  Eight LB-2 scenarios at the full 600-s horizon, forced
+    off the lean launch by a 2-row tick ring: all eight come back, all eight are caught by the second chance, the two launches
+    together take ~28 ms (the next-event kernels: ~970 ms; profiles/r04/handback_8_lb2_T600.json), bit-identical."""
+    payload = lb_two_servers()
+    seeds = 0x5EED0000 + np.arange(8, dtype=np.uint64)
+    _runner(payload, seeds=seeds, flow_ring_rows=2).run()       # (warm: library load, first launches)
+    res = _runner(payload, seeds=seeds, flow_ring_rows=2).run()
+    st = res.engine_stats
+    assert st.flow_fallback == 8 and st.flow_retried == 8 and st.flow_to_next_event == 0
+    assert st.flow_kernel_ms < 60.0, st.flow_kernel_ms           # measured 27.7 ms; a next-event pass is 30 x that
+    plan = lower(payload)
+    for i in (0, 5):
+        _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])), f"scenario {i}")
+    _same_batches(res, _runner(payload, seeds=seeds).run())
+
+
 def test_handed_back_scenarios_are_invisible_in_the_results():
     """Fuzzed feed-forward payloads (idle to saturated, dyadic step times, tight RAM, spikes, outages): most
     batches contain scenarios the flow kernel hands back; results equal the next-event kernels' everywhere."""
