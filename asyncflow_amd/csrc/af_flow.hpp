@@ -522,8 +522,20 @@ struct Flow {
     // ---- edges --------------------------------------------------------------------------------------
     // cumulative spike of edge e seen by a message sent at `now` (injection.py:191-198: marks applied
     // strictly before `now`; a mark AT `now` is a tie)
+    // (round 4: only the marks of THIS edge are walked -- a bit per mark in the edge's word of sends(), which the send
+    // counters no longer use, written by run() -- instead of all marks of the plan: config 4 has six marks on three of
+    // its six edges, so the walk is two steps for a spiked edge and none for the others)
     AF_CORE double spike_at(uint32_t e, double now) {
         double sp = 0.0;
+        if (A.n_edge_marks <= 32u) {
+            for (uint32_t m = sends()[e]; m != 0u; m &= m - 1u) {   // marks are in time order: the last one before `now` wins
+                const uint32_t i = (uint32_t)__builtin_ctz(m);
+                const double tm = u2d(emark(i)[0]);
+                if (tm < now) sp = spike_cum()[i];
+                else if (tm == now) why |= FLOW_WHY_TIE;
+            }
+            return sp;
+        }
         for (uint32_t i = 0u; i < A.n_edge_marks; ++i) {
             const double tm = u2d(emark(i)[0]);
             if ((uint32_t)emark(i)[2] != e) continue;
@@ -1769,6 +1781,7 @@ struct Flow {
                 for (uint32_t p = 0u; p < i; ++p)
                     if ((uint32_t)emark(p)[2] == e) acc = spike_cum()[p];
                 spike_cum()[i] = acc + u2d(emark(i)[1]);
+                if (i < 32u && e < A.n_edges) sends()[e] |= 1u << i;   // spike_at(): which marks belong to the edge
             }
             AF_PLAN_AS uint32_t* lw = lbw();
             for (uint32_t v = 0u; v < A.n_servers; ++v) {   // step counts of each server's (only) endpoint: IO* CPU* IO*
