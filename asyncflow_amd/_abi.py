@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-AF_ABI_VERSION = 5
+AF_ABI_VERSION = 6
 
 # af_status
 MAX_REQUEST_CAPACITY = 65535   # include/asyncflow_hip.h AF_MAX_REQUEST_CAPACITY
@@ -247,6 +247,7 @@ EXPORTED_SYMBOLS = (
     "af_comm_unique_id",
     "af_comm_init_rank",
     "af_comm_destroy",
+    "af_comm_count",
     "af_engine_destroy",
     "af_tick_count",
     "af_series_count",
@@ -286,6 +287,8 @@ def declare(lib: C.CDLL) -> C.CDLL:
     lib.af_comm_init_rank.restype = C.c_int
     lib.af_comm_destroy.argtypes = [C.c_void_p]
     lib.af_comm_destroy.restype = None
+    lib.af_comm_count.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.af_comm_count.restype = C.c_int
     lib.af_engine_destroy.argtypes = [C.c_void_p]
     lib.af_engine_destroy.restype = None
     lib.af_tick_count.argtypes = [C.c_double, C.c_double]

@@ -1852,7 +1852,8 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
             }
             a.n_scen = cnt;
             HIP_TRY(hipEventRecord(e->ev2, e->stream));
-            launch_pregen_arrivals(a, cnt, (uint32_t)((1u + a.n_edges) * n_draw), !hetero_load, e->stream);
+            if (launch_pregen_arrivals(a, cnt, (uint32_t)((1u + a.n_edges) * n_draw), !hetero_load, e->stream))
+                return fail(AF_ERR_HIP, "af_pregen_arrivals: LDS attribute");
             hipLaunchKernelGGL(af_pregen_edges, dim3((n_draw + 255u) / 256u, cnt, a.n_edges), dim3(256), 0, e->stream, a);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(e->ev3, e->stream));
@@ -2124,6 +2125,11 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
             flow_to_next += (uint32_t)rest.size();
             if (!rest.empty())
                 if (int rc = run_sequential((uint32_t)rest.size(), rest.data(), chunk_args)) return rc;
+            // A plan whose scenarios mostly end on the next-event kernels anyway (general servers fed by edges with discrete
+            // latencies: arrivals that coincide with step ends) pays a flow pass, a second chance AND a next-event pass
+            // per scenario: once a chunk handed more than a quarter of its scenarios over, the chunks still to come go to the
+            // next-event kernels directly (results are the same either way; flow_mode 2 = "always" keeps the stage-parallel kernel).
+            if ((uint64_t)rest.size() * 4u > (uint64_t)nc && e->flow_mode != 2u) use_flow = false;
         }
     }
 
@@ -2139,8 +2145,8 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     e->stats.flow_fallback_ram = fb_total[4];
     e->stats.flow_retried = flow_retried;
     e->stats.flow_to_next_event = flow_to_next;
-    e->stats.flow_list_entries = use_flow ? FL.cap : 0u;
-    e->stats.flow_ring_rows = use_flow ? FL.ring_rows : 0u;
+    e->stats.flow_list_entries = flow_scen ? FL.cap : 0u;
+    e->stats.flow_ring_rows = flow_scen ? FL.ring_rows : 0u;
     e->stats.flow_lds_bytes = flow_lds;
     e->stats.jit_fallbacks = n_jit_miss;
     e->stats.pregen_group = pregen_group;
@@ -2386,6 +2392,8 @@ struct RcclApi {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;      // (optional: af_comm_count)
+    int (*CommUserRank)(void*, int*) = nullptr;
     std::string origin;
     bool ok() const { return AllGather != nullptr; }
 };
@@ -2403,6 +2411,8 @@ bool rccl_bind(void* h, const std::string& origin) {
     r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(scope, "ncclGroupStart"));
     r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(scope, "ncclGroupEnd"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(scope, "ncclGetErrorString"));
+    r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(scope, "ncclCommCount"));
+    r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(dlsym(scope, "ncclCommUserRank"));
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GroupStart || !r.GroupEnd) return false;
     g_rccl = r;
     return true;
@@ -2458,6 +2468,18 @@ int af_comm_init_rank(const void* id, int world_size, int rank, int device, void
 
 void af_comm_destroy(void* comm) {
     if (comm && g_rccl.ok()) (void)g_rccl.CommDestroy(comm);
+}
+
+int af_comm_count(void* comm, int* world_size_out, int* rank_out) {
+    if (!comm) return fail(AF_ERR_INVALID, "NULL communicator");
+    if (int rc = rccl_need()) return rc;
+    if (!g_rccl.CommCount || !g_rccl.CommUserRank) return fail(AF_ERR_INVALID, "this RCCL exports neither ncclCommCount nor ncclCommUserRank");
+    int n = 0, r = 0;
+    RCCL_TRY(g_rccl.CommCount(comm, &n));
+    RCCL_TRY(g_rccl.CommUserRank(comm, &r));
+    if (world_size_out) *world_size_out = n;
+    if (rank_out) *rank_out = r;
+    return AF_OK;
 }
 
 int af_engine_gather(af_engine_t* e, void* comm, int world_size, const af_summary_t* local, const af_summary_t* out) {

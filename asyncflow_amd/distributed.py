@@ -110,6 +110,18 @@ class EngineComm:
             raise EngineError(f"af_comm_init_rank: {(lib.af_last_error() or b'').decode()}")
         self.handle = handle
 
+    def count(self) -> tuple[int, int]:
+        """(ranks, this rank) as RCCL reports them for the communicator (``ncclCommCount`` / ``ncclCommUserRank``)."""
+        import ctypes as C
+
+        from . import _abi
+        from .engine import EngineError
+
+        n, r = C.c_int(0), C.c_int(0)
+        if self._lib.af_comm_count(self.handle, C.byref(n), C.byref(r)) != _abi.AF_OK:
+            raise EngineError(f"af_comm_count: {(self._lib.af_last_error() or b'').decode()}")
+        return int(n.value), int(r.value)
+
     def close(self) -> None:
         if getattr(self, "handle", None):
             self._lib.af_comm_destroy(self.handle)

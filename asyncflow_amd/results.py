@@ -443,6 +443,49 @@ class BatchedResults:
         across scenarios per 1-s window)."""
         return aggregate_summary(self.summary(rps=True), level)
 
+    def differing_scenarios(self, other: "BatchedResults", chunk: int = 512) -> np.ndarray:
+        """Indices of the scenarios whose results differ from ``other``'s, compared ON THE DEVICE over the whole batch
+        (see :func:`differing_scenarios`): two runs of one sweep by different kernel families must return an empty array."""
+        return differing_scenarios(self._counts_t, self._clock_t, self._samples_t,
+                                   other._counts_t, other._clock_t, other._samples_t, chunk)  # noqa: SLF001
+
+
+def differing_scenarios(counts_a: Any, clock_a: Any, samples_a: Any, counts_b: Any, clock_b: Any, samples_b: Any,
+                        chunk: int = 512) -> np.ndarray:
+    """Whole-batch comparison of two result sets of one sweep without leaving HBM (10 000 LB-2 scenarios at T = 600 s
+    are 2 x 18 GB): the counts (generated, completed, dropped, request-events, ticks, flags, timeline marks), every
+    ``rqs_clock`` row a scenario completed (client.py:62-69) as BIT PATTERNS, and every sample word of every tick the
+    scenario reached (collector.py:50-66).  Rows behind a scenario's own counts are uninitialised memory and not looked
+    at.  Returns the differing scenario indices (sorted int64 array; empty = bit-identical)."""
+    import torch
+
+    n = int(counts_a.shape[0])
+    if int(counts_b.shape[0]) != n:
+        msg = f"batches of {n} and {int(counts_b.shape[0])} scenarios"
+        raise ValueError(msg)
+    ca, cb = counts_a.to(torch.int64) & 0xFFFFFFFF, counts_b.to(torch.int64) & 0xFFFFFFFF
+    cols = [_abi.CNT_GENERATED, _abi.CNT_COMPLETED, _abi.CNT_DROPPED, _abi.CNT_EVENTS, _abi.CNT_TICKS, _abi.CNT_FLAGS, _abi.CNT_MARKS]
+    bad = (ca[:, cols] != cb[:, cols]).any(dim=1)
+    if (clock_a is None) != (clock_b is None) or (samples_a is None) != (samples_b is None):
+        msg = "one batch kept an output the other did not"
+        raise ValueError(msg)
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk)
+        if clock_a is not None:
+            cap = min(int(clock_a.shape[1]), int(clock_b.shape[1]))
+            done = ca[lo:hi, _abi.CNT_COMPLETED].clamp(max=cap)
+            live = torch.arange(cap, device=done.device)[None, :] < done[:, None]
+            x = clock_a[lo:hi, :cap].view(torch.int64)
+            y = clock_b[lo:hi, :cap].view(torch.int64)
+            bad[lo:hi] |= ((x != y).any(dim=2) & live).any(dim=1)
+        if samples_a is not None:
+            cap = min(int(samples_a.shape[1]), int(samples_b.shape[1]))
+            pitch = min(int(samples_a.shape[2]), int(samples_b.shape[2]))
+            ticks = ca[lo:hi, _abi.CNT_TICKS].clamp(max=cap)
+            live = torch.arange(cap, device=ticks.device)[None, :] < ticks[:, None]
+            bad[lo:hi] |= ((samples_a[lo:hi, :cap, :pitch] != samples_b[lo:hi, :cap, :pitch]).any(dim=2) & live).any(dim=1)
+    return torch.nonzero(bad).reshape(-1).cpu().numpy()
+
 
 def aggregate_summary(summ: dict[str, Any], level: float = 0.95) -> dict[str, Any]:
     """Monte-Carlo aggregation of a ``summary()`` dict (see :meth:`BatchedResults.aggregate`)."""

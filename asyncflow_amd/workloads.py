@@ -7,6 +7,7 @@
                    (a 2 s / 3 s network spike on the client -> server edge: rate x spike messages pile up when it ends)
 ``fanout8``        8-server fan-out with log-normal edges     (config 5)
 ``grid_users_rtt`` the users x RTT grid of configs 3 / 4 as sweep columns
+``lb_two_servers_two_endpoints`` LB-2 with two endpoints per server and core re-entry (general servers; bench --config 6)
 
 Pure data: no engine and no oracle code.  bench.py, the tests and the oracle's scenario
 library all take the BASELINE workloads from here
@@ -102,6 +103,18 @@ def lb_two_servers(users: float = 400, rpm: float = 20, horizon: int = 600, peri
     }
 
 
+def lb_two_servers_two_endpoints(users: float = 400, horizon: int = 600) -> dict:
+    """LB-2 with a second endpoint on both servers whose step program comes BACK to the core queue after an I/O step
+    (io_db 4 ms, 64 MB, cpu 1.5 ms, io_wait 6 ms, cpu 0.5 ms): server.py:79-313 without the tandem restriction -- one
+    uniform endpoint draw per arrival (server.py:101), RAM needs that differ per request.  Not a BASELINE config: the
+    workload the general server station of the stage-parallel kernel is measured on (`bench.py --config 6`)."""
+    p = lb_two_servers(users=users, horizon=horizon)
+    for s in p["topology_graph"]["nodes"]["servers"]:
+        s["endpoints"].append(_endpoint("/report", [("io_db", 0.004), ("ram", 64), ("cpu_bound_operation", 0.0015),
+                                                    ("io_wait", 0.006), ("cpu_bound_operation", 0.0005)]))
+    return p
+
+
 def lb_with_events(users: float = 120, horizon: int = 600, scale: float = 1.0) -> dict:
     """examples/yaml_input/data/event_inj_lb.yml:73-102 (BASELINE config 4's events).
 
@@ -179,4 +192,4 @@ def grid_users_rtt(side: int = 100, users_max: float = 1000.0, hop_mean_max: flo
     return a.astype(np.float64), b.astype(np.float64)
 
 
-BASELINE_SEED_BASE = {1: 0, 2: 0x5EED0000, 3: 0xC0F30000, 4: 0xC0F40000, 5: 0xFA085000}
+BASELINE_SEED_BASE = {1: 0, 2: 0x5EED0000, 3: 0xC0F30000, 4: 0xC0F40000, 5: 0xFA085000, 6: 0x5EED0000}

@@ -12,6 +12,8 @@ written to HBM).  The other BASELINE configs are available with --config:
   4  the grid x 10 seeds = 100 000 scenarios with event_inj_lb.yml's spikes / outages, SHARDED over
      the ranks by expected load (strong scaling: the stated total is split, not replicated)
   5  8-server fan-out with log-normal edges, 50 000 replicas sharded over the ranks
+  6  (not a BASELINE config) LB-2 with two endpoints per server and core re-entry, 10 000 replicas per GPU: the
+     workload of the general server station (server.py:79-313 without the tandem restriction)
 
 A "step" is ONE pass of the hot path over the rank's batch: af_engine_run() (seed upload, the HIP
 kernels, stream sync) + af_engine_summarize() (the batched analyzer), inputs/outputs resident in
@@ -106,6 +108,12 @@ def build_workload(cfg: int, rank: int, world: int, scenarios: int, horizon: int
         lo, hi = shard_bounds(total, rank, world)
         seeds, n, scaling = base + np.arange(lo, hi, dtype=np.uint64), hi - lo, "strong"
         label = f"8-server fan-out, log-normal edges (120 users x 20 rpm, T={T} s), {total} replicas sharded over {world} GPU(s)"
+    elif cfg == 6:
+        T = horizon or 600
+        payload, n = w.lb_two_servers_two_endpoints(horizon=T), scenarios or 10_000
+        label = (f"NOT a BASELINE config: LB-2 with two endpoints per server and core re-entry (general servers), 400 users x 20 rpm, "
+                 f"T={T} s, {n} seed replicas per GPU")
+        seeds = base + rank * n + np.arange(n, dtype=np.uint64)
     else:
         raise ValueError(cfg)
     return {"payload": payload, "seeds": np.ascontiguousarray(seeds, dtype=np.uint64), "columns": cols, "n": int(n),
@@ -291,46 +299,67 @@ def kernel_sources_sha1() -> str:
     return h.hexdigest()
 
 
-def attach_binding(roof: dict, dom_ms: float, events_rank: float, args, n: int, wl: dict) -> None:
-    """What limits the dominant kernel, from the committed PMC passes of THIS command (rocprofv3 cannot run inside the
-    timed bench): newest profiles/rNN/binding.json (scripts/profile_round4.sh + make_binding_json.py).  `stale` says
-    whether the kernel sources changed since the profile was taken; times are this run's."""
-    roof["binding"] = "valu_issue"
-    if not (args.config == 2 and n == 10_000 and not args.no_series and wl["horizon"] == 600):
-        roof["binding_detail"] = {"why": "PMC passes are committed for the default command only (BASELINE config 2)"}
+BINDING_LABEL = {2: "c2", 3: "c3", 4: "c4", 5: "c5", 6: "gensrv"}
+
+
+def find_binding(config: int) -> Path | None:
+    """Newest committed profiles/rNN/binding_<label>.json of `--config` (config 2 also answers to rounds 3-4's binding.json)."""
+    label = BINDING_LABEL.get(config)
+    if label is None:
+        return None
+    found = sorted((ROOT / "profiles").glob(f"r*/binding_{label}.json"))
+    if not found and config == 2:
+        found = sorted((ROOT / "profiles").glob("r*/binding.json"))
+    return found[-1] if found else None
+
+
+def attach_binding(roof: dict, dom_ms: float, launches: int, args, n: int, wl: dict) -> None:
+    """What limits the dominant kernel and what HBM really moved, from the committed PMC passes of THIS command (rocprofv3
+    cannot run inside the timed bench): profiles/rNN/binding_<config>.json (scripts/profile_round5.sh + make_binding_json.py).
+    `stale` says whether the kernel sources changed since the profile was taken; times are this run's.  Sets
+    roof["traffic"] (HBM bytes per step = per-launch counter bytes x launches of the step) and roof["binding"]."""
+    default_n = {2: 10_000, 3: 10_000, 4: CONFIG_TOTALS[4], 5: CONFIG_TOTALS[5], 6: 10_000}.get(args.config)
+    if not (default_n == (n if args.config in (2, 3, 6) else args.scenarios or default_n) and not args.no_series and wl["horizon"] == 600
+            and not args.online_summary and args.gpus == 1):
+        roof["binding"] = {"why": "PMC passes are committed for the default single-GPU command of each config only"}
         return
-    found = sorted((ROOT / "profiles").glob("r*/binding.json"))
-    if not found:
-        roof["binding_detail"] = {"why": "no profiles/rNN/binding.json"}
+    path = find_binding(args.config)
+    if path is None:
+        roof["binding"] = {"why": f"no profiles/rNN/binding_{BINDING_LABEL.get(args.config)}.json"}
         return
-    bj = json.loads(found[-1].read_text())
+    bj = json.loads(path.read_text())
     stale = bj.get("sources_sha1") != kernel_sources_sha1()
     same_kernel = bj["kernel"].split("_jit")[0].split("_kernel")[0] in roof["kernel"]
-    roof["binding_detail"] = {
-        "source": f"{found[-1].relative_to(ROOT)} (rocprofv3 --pmc passes of the same command, one counter set per run)",
+    roof["binding"] = {
+        "resource": bj.get("binding", "valu_issue"),
+        "frac": bj.get("valu_busy_frac_calibrated", bj.get("valu_issue_frac")),
+        "frac_is": bj.get("valu_busy_frac_is", "SQ_ACTIVE_INST_VALU x 4 / (1 024 SIMDs x kernel cycles)"),
+        "source": f"{path.relative_to(ROOT)} (rocprofv3 --pmc passes of the same command, one counter set per run)",
         "profiled_kernel": bj["kernel"], "stale": bool(stale or not same_kernel),
         "valu_wave_insts_per_request_event": bj["valu_wave_insts_per_request_event"],
         "all_wave_insts_per_request_event": bj.get("all_wave_insts_per_request_event"),
-        "valu_issue_frac": bj["valu_issue_frac"],
-        "valu_issue_frac_is": "SQ_ACTIVE_INST_VALU x 4 / (1 024 SIMDs x kernel cycles)",
+        "valu_issue_frac_uncalibrated_x4": bj["valu_issue_frac"],
+        "valu_calibration": bj.get("valu_calibration"),
         "valu_lane_utilisation": bj["valu_lane_utilisation"],
         "wait_any_frac_of_wave_cycles": bj.get("wait_any_frac_of_wave_cycles"),
+        "lds_bank_conflict_frac": bj.get("lds_bank_conflict_frac"),
         "wave_lifetime_ms": bj.get("wave_lifetime_ms"),
-        "hbm_read_bytes_FETCH_SIZE_x2": bj.get("hbm_read_bytes"), "l2_write_bytes_WRITE_SIZE": bj.get("l2_write_bytes"),
+        "hbm_read_bytes_per_launch_FETCH_SIZE_x2": bj.get("hbm_read_bytes"), "l2_write_bytes_per_launch_WRITE_SIZE": bj.get("l2_write_bytes"),
         "profiled_kernel_ms": bj.get("kernel_avg_ms_trace"),
     }
     cal = sorted((ROOT / "profiles").glob("r*/write_calibration.json"))
     if cal:
         cj = json.loads(cal[-1].read_text())
-        roof["binding_detail"]["write_size_calibration"] = {
+        roof["binding"]["write_size_calibration"] = {
             "source": str(cal[-1].relative_to(ROOT)),
             "counter_bytes_per_stored_byte": {k: v.get("counter_bytes_per_stored_byte") for k, v in cj["patterns"].items()},
             "reading": "WRITE_SIZE counts the kernel's store shapes exactly (1.00 B per stored byte): what it shows above the "
                        "output size are the kernel's scratch stores (an L2-level counter) and lines shared by the chunks of "
                        "consecutive rounds, not a counting artefact"}
     if bj.get("hbm_read_bytes") is not None and bj.get("l2_write_bytes") is not None:
-        roof["traffic"] = bj["hbm_read_bytes"] + bj["l2_write_bytes"]
-        roof["traffic_source"] = roof["binding_detail"]["source"]
+        roof["traffic"] = (bj["hbm_read_bytes"] + bj["l2_write_bytes"]) * launches
+        roof["traffic_source"] = roof["binding"]["source"]
+        roof["traffic_over_algorithmic"] = roof["traffic"] / max(roof["algorithmic_bytes_per_step"], 1.0)
         roof["frac_traffic"] = roof["traffic"] / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
 
 
@@ -380,45 +409,54 @@ def residency_tail(sw: "RankSweep", flow_ms: float) -> dict | None:
             "us_per_scenario_this_batch": flow_ms / n * 1e3, "loss_frac": 1.0 - full * n / flow_ms}
 
 
-def parity_spot_check(sw: "RankSweep", k: int = 4) -> dict:
-    """AFTER the timed region, outside every timing: k scenarios of the batch that was just benched -- the first, the
-    last and evenly spaced ones of the slice still resident in HBM -- against the CPU oracle (oracle/des_oracle.c, the
-    CHECKER, pinned on the reference's fixtures): counts, every (start, finish) pair bit for bit, every sample.
+def parity_spot_check(sw: "RankSweep", k: int = 16) -> dict:
+    """AFTER the timed region, outside every timing: >= k scenarios of the batch that was just benched, spread over EVERY
+    slice of the step -- the first, the last and evenly spaced ones of each slice -- against the CPU oracle
+    (oracle/des_oracle.c, the CHECKER, pinned on the reference's fixtures): counts, every (start, finish) pair bit for
+    bit, every sample.  A step of several slices reuses its output buffers, so each slice is run again (same seeds,
+    same columns, same kernels; untimed) and checked while its outputs are resident.
     Makes the headline line self-certifying: `ok` false = the benched kernel did not compute the reference's results."""
     from asyncflow_amd import _abi
     from asyncflow_amd.plan import lower
     from oracle import oracle_lib as ol
 
     code_name = {v: name for name, v in _abi.PARAM_CODES.items()}
-    lo = (sw.n_slices - 1) * sw.slice
-    hi = sw.n
-    m = hi - lo
-    picks = sorted({lo + int(round(j * (m - 1) / max(k - 1, 1))) for j in range(min(k, m))})
-    counts = sw.counts.cpu().numpy().view(np.uint32)
+    per_slice = max(4, -(-k // sw.n_slices))
     bad: list[str] = []
+    all_picks: list[int] = []
     t0 = time.perf_counter()
-    for i in picks:
-        plan = lower(sw.plan.payload)
-        ol.apply_overrides(plan, {(code_name[c], idx): float(col[i]) for c, idx, col, _ in sw.over})
-        want = ol.simulate(plan, int(sw.seeds[i]), clock_capacity=sw.clock_cap, want_clock=sw.clock is not None,
-                           want_samples=sw.samples is not None)
-        if not np.array_equal(counts[i, :5].astype(np.uint64), want.counts[:5]):
-            bad.append(f"scenario {i}: counts {counts[i, :5].tolist()} != {want.counts[:5].tolist()}")
-            continue
-        n_done = int(counts[i, _abi.CNT_COMPLETED])
-        if sw.clock is not None:
-            got = sw.clock[i - lo, :n_done].cpu().numpy()
-            if not np.array_equal(got.view(np.uint64), want.clock.view(np.uint64)):
-                bad.append(f"scenario {i}: rqs_clock differs")
-        if sw.samples is not None:
-            ticks = int(counts[i, _abi.CNT_TICKS])
-            got = sw.samples[i - lo, :ticks, : sw.plan.n_series].cpu().numpy().view(np.uint32).T
-            if not np.array_equal(got, want.samples):
-                bad.append(f"scenario {i}: sampled series differ")
-    return {"scenarios": len(picks), "indices": picks, "ok": not bad, "mismatches": bad[:4],
+    for s_i, lo in enumerate(range(0, sw.n, sw.slice)):
+        hi = min(sw.n, lo + sw.slice)
+        m = hi - lo
+        if sw.n_slices > 1:            # (the buffers hold the LAST slice of the last step: bring this one back)
+            sw.run_slice(lo, hi)
+        sw.torch.cuda.synchronize(sw.dev)
+        picks = sorted({lo + int(round(j * (m - 1) / max(per_slice - 1, 1))) for j in range(min(per_slice, m))})
+        all_picks += picks
+        counts = sw.counts.cpu().numpy().view(np.uint32)
+        for i in picks:
+            plan = lower(sw.plan.payload)
+            ol.apply_overrides(plan, {(code_name[c], idx): float(col[i]) for c, idx, col, _ in sw.over})
+            want = ol.simulate(plan, int(sw.seeds[i]), clock_capacity=sw.clock_cap, want_clock=sw.clock is not None,
+                               want_samples=sw.samples is not None)
+            if not np.array_equal(counts[i, :5].astype(np.uint64), want.counts[:5]):
+                bad.append(f"scenario {i} (slice {s_i}): counts {counts[i, :5].tolist()} != {want.counts[:5].tolist()}")
+                continue
+            n_done = int(counts[i, _abi.CNT_COMPLETED])
+            if sw.clock is not None:
+                got = sw.clock[i - lo, :n_done].cpu().numpy()
+                if not np.array_equal(got.view(np.uint64), want.clock.view(np.uint64)):
+                    bad.append(f"scenario {i} (slice {s_i}): rqs_clock differs")
+            if sw.samples is not None:
+                ticks = int(counts[i, _abi.CNT_TICKS])
+                got = sw.samples[i - lo, :ticks, : sw.plan.n_series].cpu().numpy().view(np.uint32).T
+                if not np.array_equal(got, want.samples):
+                    bad.append(f"scenario {i} (slice {s_i}): sampled series differ")
+    return {"scenarios": len(all_picks), "indices": all_picks, "slices_covered": sw.n_slices, "ok": not bad, "mismatches": bad[:4],
             "compared": "counts[:5]" + (", rqs_clock (bit patterns)" if sw.clock is not None else "")
                         + (", every sampled series" if sw.samples is not None else ""),
-            "checker": "oracle/des_oracle.c (CPU restatement pinned on the reference's fixtures), after the timed region",
+            "checker": "oracle/des_oracle.c (CPU restatement pinned on the reference's fixtures), after the timed region; "
+                       "the whole benched batches are compared on the device by tests/test_gpu_full_batches.py",
             "check_s": time.perf_counter() - t0}
 
 
@@ -460,7 +498,7 @@ def rank_shape(wl: dict, args) -> dict:
             "T": int(plan.total_time), "online": online, "slice": slice_n, "n_slices": n_slices, "engine_kw": engine_kw}
 
 
-def prebuild_kernels(configs: tuple[int, ...] = (2, 3, 4, 5), worlds: tuple[int, ...] = (1, 2, 4, 8), verbose: bool = True) -> list[str]:
+def prebuild_kernels(configs: tuple[int, ...] = (2, 3, 4, 5, 6), worlds: tuple[int, ...] = (1, 2, 4, 8), verbose: bool = True) -> list[str]:
     """Compile, WITHOUT a GPU, the plan-specialised stage-parallel kernel of every default bench line (`--config C` at
     `--gpus N`) into the JIT cache (asyncflow_amd/csrc/_jit/, which travels to the GPU box with the tree): the headline
     then does not depend on hipcc being present where the bench runs.  A planning-only engine (AF_DEVICE_PLAN_ONLY) answers
@@ -472,7 +510,7 @@ def prebuild_kernels(configs: tuple[int, ...] = (2, 3, 4, 5), worlds: tuple[int,
     specs: dict[str, str] = {}
     for cfg in configs:
         for world in worlds:
-            if cfg in (2, 3) and world != 1:
+            if cfg in (2, 3, 6) and world != 1:
                 continue            # weak scaling: every rank runs the same shape as the single GPU
             for rank in sorted({0, world - 1}):
                 args = make_parser().parse_args(["--config", str(cfg), "--gpus", str(world)])
@@ -525,7 +563,7 @@ class RankSweep:
         # per-scenario summaries (the analyzer step of the path), kept for the whole rank
         self.s_stats = torch.full((n, 8), float("nan"), dtype=torch.float64, device=dev)
         self.s_rps = torch.zeros((n, self.T), dtype=torch.float32, device=dev)
-        self.hist_max = {1: 1.024, 2: 0.256, 3: 2.56, 4: 2.56, 5: 25.6}[args.config]
+        self.hist_max = {1: 1.024, 2: 0.256, 3: 2.56, 4: 2.56, 5: 25.6, 6: 0.256}[args.config]
         self.s_hist = torch.zeros((n, 256), dtype=torch.int32, device=dev)
         self.s_mean = None if self.samples is None else torch.empty((n, plan.n_series), dtype=torch.float64, device=dev)
         self.s_max = None if self.samples is None else torch.empty((n, plan.n_series), dtype=torch.int32, device=dev)
@@ -553,17 +591,21 @@ class RankSweep:
             self.eng.prepare(seeds, over, **kw)     # hipcc run or cache hit: never inside the timed region
             self.jit_build_s = time.perf_counter() - t0
 
+    def run_slice(self, lo: int, hi: int):
+        """af_engine_run over scenarios [lo, hi) of the rank's batch into the (reused) output buffers."""
+        seeds, over, kw = self._slice_args(lo, hi)
+        if self.online:
+            self.o_hist.zero_()
+            self.o_rps.zero_()
+        return self.eng.run(seeds, over, specialise=self.specialise, **kw)
+
     def step(self) -> dict:
         """One pass over the rank's batch; returns the engine's own timings summed over the slices."""
         acc = {"kernel_ms": 0.0, "pregen_ms": 0.0, "summary_ms": 0.0, "shared": 0, "jit": 0, "flow_ms": 0.0, "flow_scen": 0,
                "flow_fallback": [0, 0, 0, 0, 0], "jit_fallbacks": 0}
         for lo in range(0, self.n, self.slice):
             hi = min(self.n, lo + self.slice)
-            seeds, over, kw = self._slice_args(lo, hi)
-            if self.online:
-                self.o_hist.zero_()
-                self.o_rps.zero_()
-            st = self.eng.run(seeds, over, specialise=self.specialise, **kw)
+            st = self.run_slice(lo, hi)
             acc["kernel_ms"] += float(st.kernel_ms)
             acc["pregen_ms"] += float(st.pregen_ms)
             acc["shared"] += int(st.shared_instant_scenarios)
@@ -657,12 +699,12 @@ def make_parser() -> argparse.ArgumentParser:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3, 4, 5], help="BASELINE.json config (see module docstring)")
+    ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3, 4, 5, 6], help="BASELINE.json config (see module docstring; 6 = general servers, not a BASELINE config)")
     ap.add_argument("--scenarios", "--replicas", type=int, default=0, dest="scenarios",
                     help="scenarios per GPU (configs 1-3) or in total (configs 4, 5); 0 = the BASELINE size")
     ap.add_argument("--horizon", type=int, default=0, help="simulated seconds (0 = the BASELINE horizon)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-parity-check", action="store_true", help="skip the post-run oracle comparison of 4 benched scenarios")
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the post-run oracle comparison of >= 16 benched scenarios (every slice of the step)")
     ap.add_argument("--no-diagnostics", action="store_true", help="skip the post-run end-to-end / residency-tail measurements")
     ap.add_argument("--no-series", action="store_true", help="do not store the sampled series")
     ap.add_argument("--lanes", type=int, default=0, help="scenario lanes per wave of the sequential kernel (0 = engine default)")
@@ -757,6 +799,7 @@ def main() -> int:  # noqa: C901, PLR0912, PLR0915
     gather_path = None
     stats_all, hist_all = sw.s_stats, sw.s_hist.to(torch.float32)
     kernel_ms_ranks = [k_ms]
+    per_rank_line = None
     n_total = n
     gather_fallback = False
     if dist is not None:
@@ -768,7 +811,8 @@ def main() -> int:  # noqa: C901, PLR0912, PLR0915
         sizes = [n if r == rank else build_workload(args.config, r, world, args.scenarios, args.horizon)["n"] for r in range(world)]
         n_max = max(sizes)
         rows = n_max + 1
-        rank_row = torch.tensor([[float(n), elapsed, events_rank, k_ms, float(rank), 0.0, 0.0, 0.0]], dtype=torch.float64, device=dev)
+        flow_ms_rank = float(np.mean([a["flow_ms"] for a in accs]))
+        rank_row = torch.tensor([[float(n), elapsed, events_rank, k_ms, float(rank), flow_ms_rank, 0.0, 0.0]], dtype=torch.float64, device=dev)
         pad = lambda t: torch.cat([t, torch.zeros((rows - t.shape[0], *t.shape[1:]), dtype=t.dtype, device=dev)], dim=0)  # noqa: E731
         stats_x = pad(sw.s_stats)
         stats_x[n_max] = rank_row[0]
@@ -778,6 +822,9 @@ def main() -> int:  # noqa: C901, PLR0912, PLR0915
             from asyncflow_amd.distributed import EngineComm, gather_engine_summaries
 
             comm = EngineComm(rank, world, local_rank)
+            # what RCCL itself says about the communicator the collective runs on (ncclCommCount / ncclCommUserRank): rides in
+            # the gathered rank rows, so that the line of an N-GPU run certifies that RCCL saw N ranks
+            stats_x[n_max, 6], stats_x[n_max, 7] = (float(v) for v in comm.count())
             t2 = time.perf_counter()                       # the communicator's setup is not part of the collective
             got = gather_engine_summaries(sw.eng, comm, {"stats": stats_x, "rps": sw.s_rps, "hist": sw.s_hist}, rows)
             torch.cuda.synchronize(dev)
@@ -803,6 +850,14 @@ def main() -> int:  # noqa: C901, PLR0912, PLR0915
         n_total = int(stats_all.shape[0])
         elapsed, events_total = float(per_rank[:, 1].max()), float(per_rank[:, 2].sum())
         kernel_ms_ranks = [float(per_rank[:, 3].min()), float(per_rank[:, 3].max())]
+        per_rank_line = {"scenarios": [int(x) for x in per_rank[:, 0]], "elapsed_s": [float(x) for x in per_rank[:, 1]],
+                         "request_events_per_step": [float(x) for x in per_rank[:, 2]], "kernel_ms": [float(x) for x in per_rank[:, 3]],
+                         "flow_kernel_ms": [float(x) for x in per_rank[:, 5]],
+                         "rccl_comm_count": None if gather_fallback else [int(x) for x in per_rank[:, 6]],
+                         "rccl_comm_user_rank": None if gather_fallback else [int(x) for x in per_rank[:, 7]]}
+        if not gather_fallback:
+            assert per_rank_line["rccl_comm_count"] == [world] * world and per_rank_line["rccl_comm_user_rank"] == list(range(world)), \
+                f"RCCL saw {per_rank_line['rccl_comm_count']} ranks, the launcher {world}"
     else:
         events_total = events_rank
 
@@ -830,6 +885,9 @@ def main() -> int:  # noqa: C901, PLR0912, PLR0915
                                       if rs["state_in_lds"] and not flow_on else 0)
         dom_ms = float(np.mean([a["flow_ms"] for a in accs])) if flow_on else k_ms      # the dominant kernel's own duration
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+        generated_rank = float(c[:, _abi.CNT_GENERATED].astype(np.float64).sum())
+        reads = 8.0 * (generated_rank + n) if flow_on else 8.0 * (events_rank + generated_rank)
+        io_bytes = reads + (16.0 * completed_rank if sw.clock is not None else 0.0) + (4.0 * plan.series_pitch * ticks_rank if sw.samples is not None else 0.0) + 32.0 * n
         sa = stats_all.double().cpu().numpy()
         out_bytes = 16.0 * completed_rank + (4.0 * plan.series_pitch * ticks_rank if sw.samples is not None else 0.0)
         line = {
@@ -890,32 +948,47 @@ def main() -> int:  # noqa: C901, PLR0912, PLR0915
             "gather_ms": gather_ms,
             "gather_path": gather_path,
             "gather_fallback": gather_fallback,
+            "world_size_launcher": world,
+            "rccl_ranks": None if per_rank_line is None or per_rank_line["rccl_comm_count"] is None else per_rank_line["rccl_comm_count"][0],
+            "per_rank": per_rank_line,
             "collectives": None if dist is None else "barriers around the timed region + ONE grouped all-gather after it (shard sizes are "
                                                      "computed locally, per-rank scalars ride in the gathered stats array)",
             "p95_ms_mean": None if sw.online else float(np.nanmean(sa[:, 4]) * 1e3),
             "p95_ms_pooled_hist": None if sw.online else pooled_p95_ms,
             "p50_ms_mean": None if sw.online else float(np.nanmean(sa[:, 2]) * 1e3),
             "roofline": {
+                # The dominant kernel against the HBM roofline, by the bytes it cannot avoid: the arrival times it reads and every
+                # output word it writes (achieved = those bytes / the kernel's own HIP-event time).  The kernel keeps ALL per-scenario
+                # state in LDS, so this fraction is small by construction and `binding` names what limits the kernel instead.
                 "bound": "hbm",
-                "achieved": achieved,
+                "achieved": io_bytes / (dom_ms * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "frac_of_achievable_6290": achieved / HBM_ACHIEVABLE_GBS,
+                "frac": io_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "traffic": None,
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "bytes_per_event": alg_bytes / max(events_rank, 1.0),
-                "note": "achieved = SURVEY 8d's algorithmic bytes (80 B of per-event state traffic + outputs, a state-in-HBM MODEL) / "
-                        "the dominant kernel's time.  The kernel keeps that state in LDS: this fraction says how fast the model's "
-                        "bytes WOULD have to move, not what HBM does -- `traffic` / `frac_traffic` are the measured bytes, and "
-                        "`binding` names the resource that limits the kernel (instruction issue) with its counters",
+                "algorithmic_bytes_per_step": io_bytes,
+                "algorithmic_bytes_are": "compulsory I/O of the dominant kernel per step: 8 B per arrival time read (generated + 1 per "
+                                         "scenario) + 16 B per completed request + 4 B x series pitch x ticks + 32 B of counts"
+                                         if flow_on else
+                                         "compulsory I/O of the dominant kernel per step: 8 B per pre-generated draw consumed + 16 B per "
+                                         "completed request + 4 B x series pitch x ticks + 32 B of counts",
+                "launches_per_step": sw.n_slices,
+                "bytes_per_event": io_bytes / max(events_rank, 1.0),
+                "bound_actual": "instruction issue (VALU + scalar + LDS issue slots of the SIMDs), see `binding`",
+                # SURVEY 8d's model prices 80 B of per-event state traffic in HBM (north_star's "SoA in HBM"); this kernel has none
+                "model_frac_void": {"frac": achieved / HBM_PEAK_GBS, "achieved_GBps": achieved, "algorithmic_bytes_per_step": alg_bytes,
+                                    "bytes_per_event": alg_bytes / max(events_rank, 1.0),
+                                    "why_void": "SURVEY 8d: B = 80 N_events + 16 N_completed + 4 n_series N_ticks prices per-event state "
+                                                "traffic in HBM; the kernel keeps that state in LDS, so the model's bytes never move and "
+                                                "the quotient can exceed 1 -- it is not an HBM fraction"},
                 "kernel": ("af_flow_jit (plan-specialised build of af_flow_kernel)" if accs[-1]["jit"] else "af_flow_kernel") if flow_on else
                           "af_jit_lean (plan-specialised build of af_des_kernel)" if accs[-1]["jit"] else "af_des_kernel",
                 "kernel_ms": dom_ms,
+                "kernel_ms_is": "HIP events on the engine's stream around the kernel's launches of one step, averaged over the timed steps",
                 "residency_tail": tail,
             },
         }
-        attach_binding(line["roofline"], dom_ms, events_rank, args, n, wl)
+        attach_binding(line["roofline"], dom_ms, sw.n_slices, args, n, wl)
         if base is not None:
             line["cpu_baseline"] = base
         if parity is not None:

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define AF_ABI_VERSION 5
+#define AF_ABI_VERSION 6
 
 /* ---- status codes ------------------------------------------------------ */
 enum af_status {
@@ -387,6 +387,9 @@ int af_comm_load(const char* librccl_path);
 int af_comm_unique_id(void* id_out /* AF_COMM_ID_BYTES */);
 int af_comm_init_rank(const void* id, int world_size, int rank, int device, void** comm_out);
 void af_comm_destroy(void* comm);
+/* What RCCL itself says about a communicator: ncclCommCount / ncclCommUserRank (either output may be NULL).  A
+ * multi-GPU bench line carries these next to WORLD_SIZE so that the first run on N GPUs certifies that RCCL saw N ranks. */
+int af_comm_count(void* comm, int* world_size_out, int* rank_out);
 /* All-gather of per-scenario summaries: every non-NULL array of `local` (n_scenarios rows: the rank's
  * shard, padded by the caller to the same n on every rank) into the array of the same name in `gathered`
  * (world_size * n_scenarios rows, rank order).  rps_buckets / hist_bins give the row lengths; series

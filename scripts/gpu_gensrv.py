@@ -10,13 +10,11 @@ import numpy as np
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from asyncflow_amd.plan import lower  # noqa: E402
 from asyncflow_amd.runner import SimulationRunner  # noqa: E402
-from asyncflow_amd.workloads import _endpoint, lb_two_servers  # noqa: E402
+from asyncflow_amd.workloads import lb_two_servers_two_endpoints  # noqa: E402
 from oracle import oracle_lib as ol  # noqa: E402
 
 n, T = int(sys.argv[1]) if len(sys.argv) > 1 else 2048, int(sys.argv[2]) if len(sys.argv) > 2 else 120
-p = lb_two_servers(horizon=T)
-for s in p["topology_graph"]["nodes"]["servers"]:
-    s["endpoints"].append(_endpoint("/report", [("io_db", 0.004), ("ram", 64), ("cpu_bound_operation", 0.0015), ("io_wait", 0.006), ("cpu_bound_operation", 0.0005)]))
+p = lb_two_servers_two_endpoints(horizon=T)
 seeds = 0x5EED0000 + np.arange(n, dtype=np.uint64)
 out = {}
 for name, kw in (("flow", {"flow": "always", "specialise": False}), ("flow_specialised", {"specialise": True}), ("next_event", {"flow": False})):
