@@ -69,6 +69,7 @@ FLAG_RAM_STARVED = 16
 FLAG_TIME_TIE = 32
 FLAG_DRAW_OVERFLOW = 64
 FLAG_NEGATIVE_DELAY = 1 << 13
+FLAG_RAM_PUT_BLOCKED = 1 << 14
 FLAG_NAMES = {
     FLAG_POOL_OVERFLOW: "request pool overflow (raise request_capacity)",
     FLAG_FIFO_OVERFLOW: "server wait-queue overflow (raise fifo_capacity)",
@@ -78,6 +79,8 @@ FLAG_NAMES = {
     FLAG_TIME_TIE: "a zero-delay timeout was created in the middle of a zero-time cascade (SimPy may order the pending steps differently)",
     FLAG_DRAW_OVERFLOW: "more arrivals than draw_capacity (raise clock_capacity)",
     FLAG_NEGATIVE_DELAY: "a message was sent with transit + spike < 0 (the reference raises ValueError 'Negative delay')",
+    FLAG_RAM_PUT_BLOCKED: "a fractional RAM need: `capacity - level >= amount` failed by one rounding when a request gave its RAM back -- "
+                          "the reference's simpy Container.put waits there, the engine does not (results differ from that instant on)",
 }
 FATAL_FLAGS = (
     FLAG_POOL_OVERFLOW | FLAG_FIFO_OVERFLOW | FLAG_CLOCK_OVERFLOW | FLAG_TICK_OVERFLOW | FLAG_DRAW_OVERFLOW

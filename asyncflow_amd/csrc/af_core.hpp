@@ -63,6 +63,7 @@ enum : uint32_t {
     FLAG_DRAW_OVERFLOW = 1u << 6,
     FLAG_SHARED_INSTANT = 1u << 7,  // internal: never visible in the outputs of af_engine_run
     FLAG_NEGATIVE_DELAY = 1u << 13, // transit + spike < 0 at a send (the reference raises "Negative delay")
+    FLAG_RAM_PUT_BLOCKED = 1u << 14, // capacity - level < amount at a RAM put by one rounding: simpy's Container.put would wait (AF_FLAG_RAM_PUT_BLOCKED)
 };
 enum : uint32_t {
     CNT_GENERATED = 0, CNT_COMPLETED, CNT_DROPPED, CNT_EVENTS, CNT_TICKS, CNT_FLAGS, CNT_MAX_LIVE, CNT_MARKS, CNT_SLOTS
@@ -614,6 +615,7 @@ struct Lane : LaneRegs {
         const double ram = u2d(P.row[TREC * step + 1u]);
         if (ram > 0.0) {
             M.st(at + 3u, d2u(u2d(M.ld(at + 3u)) - ram));  // ram_in_use
+            if (ram_cap(sv) - u2d(M.ld(at + 2u)) < ram) flags |= FLAG_RAM_PUT_BLOCKED;   // (Container._do_put: the reference would wait)
             M.st(at + 2u, d2u(u2d(M.ld(at + 2u)) + ram));  // ram container level
             if (((M.ld(at + 4u) >> 48) & 0x7FFFu) > 0u) fu_ram_sv = (int32_t)sv;
         }
@@ -1014,7 +1016,8 @@ struct Lane : LaneRegs {
         const double ram = u2d(P.row[TREC * step + 1u]);
         if (ram > 0.0) {
             M.st(at + 3u, d2u(u2d(M.ld(at + 3u)) - ram));
-            M.st(at + 2u, d2u(u2d(M.ld(at + 2u)) + ram));  // ContainerPut succeeds at once
+            if (ram_cap(sv) - u2d(M.ld(at + 2u)) < ram) flags |= FLAG_RAM_PUT_BLOCKED;
+            M.st(at + 2u, d2u(u2d(M.ld(at + 2u)) + ram));  // ContainerPut succeeds at once (unless the flag says otherwise)
             mq_push(MK_RAM_PUT, a, st_pack(RK_WAIT, sv, hops, 0u, step));
             return;
         }

@@ -137,7 +137,7 @@ inline FlowLayout make_flow_layout(uint32_t cap, uint32_t ring_rows, uint32_t g_
     if (w < scratch0 + 5u * 64u) w = scratch0 + 5u * 64u;
     L.off_fr = w; w += n_servers * c_ring;
     L.off_gr = w; w += n_servers * g_ring;
-    L.off_cnt = w; w += (n_edges + 1u) / 2u + LBW_U32 / 2u + 12u;   // u32 sends per edge; LBW_U32 u32: lb order, head, n_live, mark cursor, per-server counters; send_floor's 4 x 3 f64
+    L.off_cnt = w; w += (n_edges + 1u) / 2u + LBW_U32 / 2u + 12u + 8u;   // u32 sends per edge; LBW_U32 u32: lb order, head, n_live, mark cursor, per-server counters; send_floor's 4 x 3 f64; 8 horizon slots (Flow::hz)
     L.off_ring = w; w += (ring_rows * L.pitch + 1u) / 2u;
     L.off_gsrv = general_servers ? w : 0u;
     if (general_servers) w += n_servers * kGsWords;
@@ -243,7 +243,7 @@ enum : uint32_t { PROF_SETUP, PROF_GEN, PROF_SELECT, PROF_SERIES_RECV, PROF_STAT
 //   FEAT_PROF      measurement builds only: the wave's shader-clock time per section of run() (FlowArgs::prof)
 enum : uint32_t { FEAT_MARKS = 1u, FEAT_ONLINE = 2u, FEAT_HBM_RING = 4u, FEAT_FAR = 64u, FEAT_ALL = 7u | FEAT_FAR, FEAT_TIEBREAK = 8u,
                   FEAT_BIGLIST = 16u, FEAT_LC = 32u, FEAT_PROF = 128u, FEAT_GENSRV = 256u, FEAT_CHAIN = 512u };
-constexpr uint32_t kMaxLevels = 3u;      // FEAT_CHAIN: server levels (af_flow_host.hpp refuses deeper plans)
+constexpr uint32_t kMaxLevels = 5u;      // FEAT_CHAIN: server levels (af_flow_host.hpp refuses deeper plans); round 4: 3
 constexpr uint32_t kAnyLevel = 0xFFu;    // select(): no level filter
 template <class W, uint32_t IPL = 1u, uint32_t FEAT = FEAT_ALL>
 struct Flow {
@@ -280,18 +280,34 @@ struct Flow {
     AF_CORE void n_list_set(uint32_t s, uint32_t v) {
         if (s == 0u) nl0 = v; else if (s == 1u) nl1 = v; else if (s == 2u) nl2 = v; else nl3 = v;
     }
-    // horizon slots: 0..3 = the four lists' stations; FEAT_CHAIN: 4, 5 = the server station of levels 1, 2 (level 0 is slot 2)
-    double h2b, h2c;
+    // horizon slots: 0..3 = the four lists' stations; FEAT_CHAIN: 4 .. 7 = the server station of levels 1 .. 4 (level 0 is slot 2)
+    double h2b, h2c, h2d, h2e;
     uint32_t n_levels;           // FEAT_CHAIN: levels the plan's servers form (wave-uniform), else 1
     AF_CORE static constexpr uint32_t level_slot(uint32_t level) { return level == 0u ? 2u : 3u + level; }
+    // The generic FEAT_CHAIN instantiations walk the stations in a LOOP, so the slot is a run-time value there -- and a select
+    // over eight members of this object makes the compiler address the object indirectly, which puts ALL of it (912 B per lane)
+    // in scratch memory: round 4's generic tiers ran at 437 ms against 66 ms for the plan-specialised build, which unrolls the
+    // stations.  Those forms keep the horizons in eight LDS words behind send_floor's cache instead (round 5).
+#if defined(AF_FLOW_JIT) && !defined(AF_FLOW_LOOP_STATIONS)
+    static constexpr bool kStationsUnrolled = true;
+#else
+    static constexpr bool kStationsUnrolled = false;
+#endif
+    static constexpr bool kHzLds = kChain && !kStationsUnrolled;
+    AF_CORE AF_PLAN_AS double* hz() const { return fcache() + 12; }
     AF_CORE double H_get(uint32_t s) const {
-        if (kChain && s >= 4u) return s == 4u ? h2b : h2c;
+        if (kHzLds) return hz()[s];
+        if (kChain && s >= 4u) return s == 4u ? h2b : s == 5u ? h2c : s == 6u ? h2d : h2e;
         return s == 0u ? h0 : s == 1u ? h1 : s == 2u ? h2 : h3;
     }
     AF_CORE void H_set(uint32_t s, double v) {
         if (kMarks) moved = moved || v > H_get(s);   // (without lookahead the last horizon is the slowest: run() watches h3)
+        if (kHzLds) {
+            hz()[s] = v;   // (every lane stores the same value)
+            return;
+        }
         if (kChain && s >= 4u) {
-            if (s == 4u) h2b = v; else h2c = v;
+            if (s == 4u) h2b = v; else if (s == 5u) h2c = v; else if (s == 6u) h2d = v; else h2e = v;
             return;
         }
         if (s == 0u) h0 = v; else if (s == 1u) h1 = v; else if (s == 2u) h2 = v; else h3 = v;
@@ -309,7 +325,7 @@ struct Flow {
     bool gen_done, moved;        // moved: a horizon advanced in this round
     // per-lane accumulators (reduced at the end)
     uint32_t ev, drops, why, info;   // info: informational result flags
-    int32_t run_val;             // lane s < n_series: current value of sampled series s
+    int32_t run_val, run_val2;   // lane s: current value of sampled series s and of series s + 64
 
     const double* arr;
     double* clock;
@@ -439,45 +455,31 @@ struct Flow {
         add_point(series, ib, -w, span);
     }
     // rows [tick_base, upto) are final: prefix-sum the differences and stream the rows out
+    // (a lane carries the running value of series `lane` and -- plans with more than 64 series: 13 .. 16 servers behind a
+    // round-robin load balancer, round 5 -- of series `lane + 64` in run_val2)
+    AF_CORE void series_kind(uint32_t ser, bool& on, bool& is_ram) const {
+        const uint32_t n_series = A.n_edges + 3u * A.n_servers;
+        constexpr uint32_t all = af::METRIC_READY | af::METRIC_IO | af::METRIC_RAM;
+        const bool is_srv = ser >= A.n_edges && ser < n_series;
+        is_ram = is_srv && (ser - A.n_edges) % 3u == 2u;
+        on = ser < A.n_edges ? (A.metrics_mask & af::METRIC_EDGE) != 0u : (is_srv && (A.metrics_mask & all) == all);
+    }
+    AF_CORE uint32_t series_word(int32_t value, bool on, bool is_ram) const {
+        if (!on) return 0u;
+        return is_ram ? __builtin_bit_cast(uint32_t, (float)((double)value * A.ram_unit)) : (uint32_t)value;
+    }
     AF_CORE void flush_ticks(uint32_t upto) {
         if (samples != nullptr) {
-            const uint32_t R = A.L.ring_rows, pitch = A.L.pitch, n_series = A.n_edges + 3u * A.n_servers;
-            const bool edges_on = (A.metrics_mask & af::METRIC_EDGE) != 0u;
-            constexpr uint32_t all = af::METRIC_READY | af::METRIC_IO | af::METRIC_RAM;
-            const bool servers_on = (A.metrics_mask & all) == all;
-            const bool is_srv = lane >= A.n_edges && lane < n_series;
-            const bool is_ram = is_srv && (lane - A.n_edges) % 3u == 2u;
-            const bool on = lane < A.n_edges ? edges_on : (is_srv && servers_on);
+            const uint32_t R = A.L.ring_rows, pitch = A.L.pitch;
             const uint32_t stop = upto < A.tick_cap ? upto : A.tick_cap;
-            if (kHbmRing && R == 0u) {
-                // the differences of kBatch rows are fetched before the first of them is summed: one HBM latency per batch
-                // instead of one per row (config 5: 32 rows per round; -2.5 % kernel time.  The LDS ring gains nothing.)
-                constexpr uint32_t kBatch = 8u;
-                for (uint32_t r0 = tick_base; r0 < stop; r0 += kBatch) {
-                    int32_t d[kBatch];
-#pragma unroll
-                    for (uint32_t u = 0u; u < kBatch; ++u)
-                        d[u] = (lane < pitch && r0 + u < stop) ? (int32_t)W::global_load(samples + (size_t)(r0 + u) * pitch + lane) : 0;
-#pragma unroll
-                    for (uint32_t u = 0u; u < kBatch; ++u) {
-                        const uint32_t r = r0 + u;
-                        if (lane < pitch && r < stop) {
-                            run_val += d[u];
-                            uint32_t word = 0u;
-                            if (on) word = is_ram ? __builtin_bit_cast(uint32_t, (float)((double)run_val * A.ram_unit)) : (uint32_t)run_val;
-                            samples[(size_t)r * pitch + lane] = word;
-                        }
-                    }
-                }
-            } else if (pitch <= 32u) {
+            if (pitch <= 32u && !(kHbmRing && R == 0u)) {
                 // several rows per step: lane = (row q of the step, series): the rows of a step are one contiguous store
                 // (5 rows = 240 B for LB-2 instead of five 48-byte stores), the running values of the series come from the
                 // lanes of row 0 and go back there from the step's last row
                 const uint32_t rpi = 64u / pitch;                                             // rows per step (2 .. 16)
                 const uint32_t q = (lane * (65536u / pitch + 1u)) >> 16, ser = lane - q * pitch;   // lane / pitch, lane % pitch
-                const bool s_srv = ser >= A.n_edges && ser < n_series;
-                const bool s_ram = s_srv && (ser - A.n_edges) % 3u == 2u;
-                const bool s_on = ser < A.n_edges ? edges_on : (s_srv && servers_on);
+                bool s_on, s_ram;
+                series_kind(ser, s_on, s_ram);
                 // (measured, round 4: letting only FULL steps leave before the end of the run -- ~8.6 rows become final per round of
                 // LB-2, i.e. two steps of five, the second mostly empty -- gains nothing: 37.74 vs 37.93 ms)
                 for (uint32_t r0 = tick_base; r0 < stop; r0 += rpi) {
@@ -495,23 +497,46 @@ struct Flow {
                         if (q >= k) acc += up;
                     }
                     const int32_t value = (int32_t)W::shfl32((uint32_t)run_val, ser) + acc;
-                    if (valid) {
-                        uint32_t word = 0u;
-                        if (s_on) word = s_ram ? __builtin_bit_cast(uint32_t, (float)((double)value * A.ram_unit)) : (uint32_t)value;
-                        samples[(size_t)rr * pitch + ser] = word;
-                    }
+                    if (valid) samples[(size_t)rr * pitch + ser] = series_word(value, s_on, s_ram);
                     const int32_t last = (int32_t)W::shfl32((uint32_t)value, ((n_rows - 1u) * pitch + lane) & 63u);
                     if (lane < pitch) run_val = last;
                 }
             } else {
-                for (uint32_t r = tick_base; r < stop; ++r) {
-                    if (lane < pitch) {
-                        AF_PLAN_AS int32_t* cell = ring() + (r & (R - 1u)) * pitch + lane;
-                        run_val += *cell;
-                        *cell = 0;
-                        uint32_t word = 0u;
-                        if (on) word = is_ram ? __builtin_bit_cast(uint32_t, (float)((double)run_val * A.ram_unit)) : (uint32_t)run_val;
-                        samples[(size_t)r * pitch + lane] = word;
+                // one row per lane set, the differences of kRows rows fetched before the first of them is summed: one latency (HBM
+                // for differences kept in the sample rows -- config 5's round-2 form, -2.5 % --, LDS for the ring) per kRows rows
+                // instead of one per row.  (Round 5: the row-by-row loop over the LDS ring was 17 % of config 5's kernel, ~290
+                // cycles per row at two waves per SIMD.)
+#if defined(AF_FLUSH_ROWS)
+                constexpr uint32_t kRows = AF_FLUSH_ROWS;
+#else
+                constexpr uint32_t kRows = 8u;
+#endif
+                const bool in_hbm = kHbmRing && R == 0u;
+#pragma unroll
+                for (uint32_t half = 0u; half < 2u; ++half) {
+                    const uint32_t ser = lane + 64u * half;
+                    if (half == 1u && pitch <= 64u) break;   // (wave-uniform)
+                    int32_t& value = half == 0u ? run_val : run_val2;
+                    bool on, is_ram;
+                    series_kind(ser, on, is_ram);
+                    for (uint32_t r0 = tick_base; r0 < stop; r0 += kRows) {
+                        int32_t d[kRows];
+#pragma unroll
+                        for (uint32_t u = 0u; u < kRows; ++u) {
+                            const uint32_t r = r0 + u;
+                            d[u] = 0;
+                            if (ser < pitch && r < stop)
+                                d[u] = in_hbm ? (int32_t)W::global_load(samples + (size_t)r * pitch + ser) : ring()[(r & (R - 1u)) * pitch + ser];
+                        }
+#pragma unroll
+                        for (uint32_t u = 0u; u < kRows; ++u) {
+                            const uint32_t r = r0 + u;
+                            if (ser < pitch && r < stop) {
+                                if (!in_hbm) ring()[(r & (R - 1u)) * pitch + ser] = 0;
+                                value += d[u];
+                                samples[(size_t)r * pitch + ser] = series_word(value, on, is_ram);
+                            }
+                        }
                     }
                 }
             }
@@ -1426,6 +1451,7 @@ struct Flow {
     // The order in which this schedules new Timeouts IS their creation order, so later ties among them are exact too.
     enum : uint32_t { GM_STEP = 0u, GM_CPU_GOT = 1u, GM_CPU_GOT_W = 2u, GM_PUT_IO = 3u, GM_PUT_END = 4u, GM_RAM_PUT = 5u, GM_RAM_GOT = 6u };
     uint32_t gm_head, gm_n;
+    uint32_t gs_rounds;   // server-station rounds of this scenario: solved at once << 16 | walked event by event (CNT_MAX_LIVE of a FEAT_GENSRV run)
     AF_CORE void gm_push(AF_PLAN_AS uint64_t* g, uint32_t kind, uint32_t slot) {
         if (gm_n >= kGsMq) {
             why |= FLOW_WHY_LIST;
@@ -1689,6 +1715,337 @@ struct Flow {
         return done;
     }
 
+    // ---- general servers, a whole ROUND at once (round 5: VERDICT r4 item 4) ---------------------------------------------------
+    // gen_servers() above is exact but one lane per server walks its events one by one: a chain of dependent LDS round trips,
+    // ~2 600 wave-cycles per server event with 2 of 64 lanes busy (LB-2).  Here a LANE IS A REQUEST -- the ones inside the servers
+    // of this pass (in the order of the pending-step ring, then of the core queue) and the round's arrivals -- and the whole window
+    // [previous horizon, `limit`) is solved at once:
+    //   * a request's timeline is a function of its own start and of the times its core acquisitions are granted (server.py:197-259:
+    //     RAM first, a core at the first CPU step of a burst, released at the next I/O step or at the end);
+    //   * a ONE-core server grants in the order of the requests' CPU.get() calls (Container FIFO), so the grant of an acquisition
+    //     that asks at r is  s = max(r, release of the acquisition that asked last before r)  -- the recurrence of servers_solve()
+    //     without the assumption that the order is the arrival order;
+    //   * relaxation: every lane walks its step program with the grants it knows (none at first), then looks up its predecessors
+    //     in the current order of the r -- all lanes against all lanes, through the crossbar -- and walks again until nothing
+    //     changes.  A fixed point satisfies the FIFO recurrence in its own order, and that recurrence has one solution (induction over
+    //     the order), so the fixed point IS the event-by-event result: the same f64 additions, request by request.
+    // Everything at or after `limit` is tentative (later arrivals can get in front of it) and only has to stay at or after
+    // `limit`: a walk stops at its first such time, which is the request's state for the next round -- exactly the state gen_servers()
+    // keeps (pending step end / place in the core queue), so either form can run any round.
+    // What the solver does not decide it leaves to gen_servers(), BEFORE touching any state (return false): more than one core, a RAM
+    // queue that is or could become non-empty, more than 64 requests in the window, step programs with more than kParBursts core
+    // acquisitions or kParSteps steps ahead, and every instant at which the ORDER of two events of a server matters -- two CPU.get()
+    // at one instant, two responses at one instant, two pending step ends at one instant (their creation order decides later
+    // ties: gs_instant).  An event that merely coincides with another of the same server without competing for the core (a step end
+    // at an arrival's instant, a release at a request's instant: the grant is at that instant either way, and the zero-length wait
+    // it may be counted for ends before any tick sees it -- a tick AT the instant is flagged by tick_index) needs no order.
+    static constexpr uint32_t kParBursts = 3u, kParSteps = 24u, kParIters = 24u;
+#if defined(AF_PAR_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
+#define AF_PAR_LEAVE(why_text) do { if (lane == 0u) std::fprintf(stderr, "par: left to gen_servers (%s), R %u limit %.9g\n", why_text, R, limit); return false; } while (0)
+#else
+#define AF_PAR_LEAVE(why_text) return false
+#endif
+    AF_CORE bool gen_servers_par(uint32_t level, double limit, uint32_t& done_any) {
+        AF_PLAN_AS uint32_t* lw = lbw();
+        const uint32_t S = A.n_servers;
+        // ---- lanes: per server of this pass its running requests, its core waiters, this round's arrivals
+        uint32_t base = 0u, sv = 0u, role = 3u, idx = 0u, my_base = 0u;
+        bool ok = true;
+        for (uint32_t k = 0u; k < S; ++k) {
+            if (kChain && level_of(k) != level) continue;
+            const AF_PLAN_AS uint64_t* gk = gs(k);
+            const uint32_t n_run = hi32(gk[GS_EV]), n_wait = hi32(gk[GS_CQ]), n_new = lw[LBW_SEG_LEN + k];
+            const uint32_t cores = (uint32_t)blob[A.off_srv + af::SREC * k + 1u] & 0xFFFFu;
+            ok = ok && cores == 1u && hi32(gk[GS_RQ]) == 0u && hi32(gk[GS_ARR]) == 0u;
+            const uint32_t n_k = n_run + n_wait + n_new;
+            if (lane >= base && lane < base + n_k) {
+                sv = k;
+                my_base = base;
+                idx = lane - base;
+                role = idx < n_run ? 0u : idx < n_run + n_wait ? 1u : 2u;
+                idx -= role == 0u ? 0u : role == 1u ? n_run : n_run + n_wait;
+            }
+            base += n_k;
+        }
+        const uint32_t R = base;
+        if (!ok || R > 64u) AF_PAR_LEAVE(!ok ? "cores / RAM queue" : "more than 64 requests");
+        const bool mine = role != 3u;
+        AF_PLAN_AS uint64_t* g = gs(sv);
+        const uint32_t s0 = A.n_edges + 3u * sv;
+        // ---- my request as gen_servers() left it, or as it arrives
+        double t_start = AF_INF, t0v = 0.0, need = 0.0;
+        uint32_t row_start = 0u, a_row = 0u;
+        bool holds0 = false, io0 = false;
+        if (role == 0u) {
+            const uint32_t p = (lo32(g[GS_EV]) + idx) & (kGsSlots - 1u), slot = gs_bytes(g, 0u)[p];
+            const uint64_t st = g[GS_STATE + slot];
+            t_start = u2d(g[GS_EVT + p]);
+            row_start = (uint32_t)st & 0xFFFFu;
+            holds0 = ((st >> 16) & 1ull) != 0ull;
+            io0 = ((st >> 17) & 1ull) != 0ull;
+            t0v = u2d(g[GS_T0 + slot]);
+            need = u2d(g[GS_NEED + slot]);
+        } else if (role == 1u) {
+            const uint32_t p = (lo32(g[GS_CQ]) + idx) & (kGsSlots - 1u), slot = gs_bytes(g, 1u)[p];
+            t_start = -(double)(64u - idx);   // asked before everything of this window, in queue order
+            row_start = (uint32_t)g[GS_STATE + slot] & 0xFFFFu;
+            t0v = u2d(g[GS_T0 + slot]);
+            need = u2d(g[GS_NEED + slot]);
+        } else if (role == 2u) {
+            const uint32_t at = lw[LBW_SEG_OFF + sv] + idx;
+            const uint64_t pre = d2u(seg(2)[at]);
+            const uint32_t epb = (uint32_t)(blob[A.off_srv + af::SREC * sv + 1u] >> 32) & 0xFFFFu;
+            t_start = seg(0)[at];
+            t0v = seg(1)[at];
+            a_row = hi32(pre);
+            need = u2d(blob[A.off_ep + af::PREC * (epb + lo32(pre))]);
+            row_start = (uint32_t)blob[A.off_ep + af::PREC * (epb + lo32(pre)) + 1u];
+        }
+        const double ram_mb = u2d(blob[A.off_srv + af::SREC * sv]);
+        bool hazard = role == 2u && need > ram_mb;   // (waits for good: FLAG_RAM_STARVED is gen_servers()'s to report)
+
+        // ---- the walk: my request from where it stands up to its first time >= limit, with the grants G[] it knows
+        double G[kParBursts], r[kParBursts], rel[kParBursts];
+#pragma unroll
+        for (uint32_t b = 0u; b < kParBursts; ++b) G[b] = -AF_INF;
+        uint32_t cls = 3u, fin_row = 0u, n_ev = 0u;   // cls: 0 left the server, 1 a step is pending at limit, 2 waits for the core at limit
+        double fin_key = AF_INF;
+        bool fin_holds = false, fin_io = false;
+        auto walk = [&](bool commit) {
+#pragma unroll
+            for (uint32_t b = 0u; b < kParBursts; ++b) {
+                r[b] = AF_INF;
+                rel[b] = AF_INF;
+            }
+            double tt = t_start;
+            uint32_t rw = row_start, nb = 0u, open = 0u;
+            bool h = holds0, io = io0, alive = mine, pending = role == 0u, queued = role == 1u;
+            n_ev = 0u;
+            cls = 3u;
+            if (holds0) {   // (the acquisition I hold was granted in an earlier round: first in the order)
+                r[0] = -1000.0;
+                nb = 1u;
+            }
+            if (commit && role == 2u && need > 0.0 && samples != nullptr) add_point(s0 + 2u, a_row, (int32_t)(need * A.ram_scale));
+            for (uint32_t step = 0u; step < kParSteps; ++step) {
+                if (!W::any(alive)) break;
+                if (alive && pending) {   // the Timeout of step rw fires at tt
+                    if (!(tt < limit)) {
+                        cls = 1u;
+                        fin_key = tt;
+                        fin_row = rw;
+                        fin_holds = h;
+                        fin_io = io;
+                        alive = false;
+                    } else {
+                        n_ev += 1u;
+                        rw += 1u;
+                        pending = false;
+                    }
+                }
+                const uint32_t kind = alive ? (uint32_t)blob[A.off_row + af::TREC * rw + 2u] : af::STEP_END;
+                const double dur = alive ? u2d(blob[A.off_row + af::TREC * rw]) : 0.0;
+                // (one tick row per step: the time the step is reached at; a grant's own row below)
+                const bool want_row = commit && alive && samples != nullptr && !queued;
+                const uint32_t rown = !want_row ? 0u : (role == 2u && step == 0u) ? a_row : tick_index(tt, true);
+                if (alive && kind == af::STEP_CPU) {
+                    if (io) {
+                        io = false;
+                        if (want_row) add_point(s0 + 1u, rown, -1);
+                    }
+                    if (!h) {
+                        if (nb >= kParBursts) {
+                            hazard = true;
+                            alive = false;
+                        } else {
+                            const double rb = tt, sg = G[nb] > rb ? G[nb] : rb;
+                            r[nb] = rb;
+                            const bool waits = queued || sg > rb;
+                            if (!(sg < limit)) {   // still in the core queue when the window ends
+                                if (commit && waits && !queued && samples != nullptr) add_point(s0, rown, 1);
+                                cls = 2u;
+                                fin_key = rb;
+                                fin_row = rw;
+                                alive = false;
+                            } else {
+                                if (commit && waits && samples != nullptr) {
+                                    if (!queued) add_point(s0, rown, 1);
+                                    add_point(s0, tick_index(sg, true), -1);
+                                }
+                                tt = sg;
+                                h = true;
+                                open = nb;
+                                nb += 1u;
+                                queued = false;
+                            }
+                        }
+                    }
+                    if (alive) {
+                        const double tn = tt + dur;
+                        hazard = hazard || !(tn > tt);
+                        tt = tn;
+                        pending = true;
+                    }
+                } else if (alive && kind == af::STEP_IO) {
+                    if (h) {
+                        rel[open] = tt;
+                        h = false;
+                    }
+                    if (!io) {
+                        io = true;
+                        if (want_row) add_point(s0 + 1u, rown, 1);
+                    }
+                    const double tn = tt + dur;
+                    hazard = hazard || !(tn > tt);
+                    tt = tn;
+                    pending = true;
+                } else if (alive) {   // the endpoint is through (server.py:257-276)
+                    if (h) rel[open] = tt;
+                    if (io && want_row) add_point(s0 + 1u, rown, -1);
+                    if (need > 0.0 && want_row) add_point(s0 + 2u, rown, -(int32_t)(need * A.ram_scale));
+                    cls = 0u;
+                    fin_key = tt;
+                    alive = false;
+                }
+            }
+            hazard = hazard || alive;   // more steps ahead than the walk takes
+        };
+
+        // ---- relaxation to the fixed point of the FIFO recurrence
+        uint32_t nb_max = 0u;
+        bool settled = false;
+        for (uint32_t it = 0u; it < kParIters && !settled; ++it) {
+            walk(false);
+            if (W::any(hazard)) AF_PAR_LEAVE("a step program outside the walk's range");
+            uint32_t mine_nb = 0u;
+#pragma unroll
+            for (uint32_t b = 0u; b < kParBursts; ++b) mine_nb += r[b] < AF_INF ? 1u : 0u;
+            nb_max = 0u;
+#pragma unroll
+            for (uint32_t b = 1u; b <= kParBursts; ++b) nb_max = W::any(mine_nb >= b) ? b : nb_max;
+            double best_r[kParBursts], best_rel[kParBursts];
+#pragma unroll
+            for (uint32_t b = 0u; b < kParBursts; ++b) {
+                best_r[b] = -AF_INF;
+                best_rel[b] = -AF_INF;
+            }
+            bool tie = false;
+            for (uint32_t o = 0u; o < R; ++o) {
+                const bool same = W::bcast32(sv, o) == sv && mine;
+#pragma unroll
+                for (uint32_t bo = 0u; bo < kParBursts; ++bo) {
+                    if (bo >= nb_max) continue;
+                    const double ro = bcast_f64(r[bo], o), relo = bcast_f64(rel[bo], o);
+#pragma unroll
+                    for (uint32_t b = 0u; b < kParBursts; ++b) {
+                        const bool before = same && ro < r[b] && ro > best_r[b];
+                        best_r[b] = before ? ro : best_r[b];
+                        best_rel[b] = before ? relo : best_rel[b];
+                        tie = tie || (same && ro == r[b] && ro < AF_INF && !(o == lane && bo == b));
+                    }
+                }
+            }
+            bool changed = false;
+#pragma unroll
+            for (uint32_t b = 0u; b < kParBursts; ++b) {
+                // (what binds is max(r, G): a predecessor that released before I asked changes nothing)
+                const double was = G[b] > r[b] ? G[b] : r[b], now = best_rel[b] > r[b] ? best_rel[b] : r[b];
+                changed = changed || (r[b] < AF_INF && was != now);
+                G[b] = best_rel[b];
+            }
+            settled = !W::any(changed);
+            if (settled && W::any(tie)) AF_PAR_LEAVE("two CPU.get() at one instant");
+        }
+        if (!settled) AF_PAR_LEAVE("no fixed point within kParIters");
+
+        // ---- where everybody stands at `limit`: places among the responses / pending step ends / core waiters of my server
+        // (RAM: every arrival must find its need at once -- the level at its instant is what the round began with, less what the
+        // arrivals before it took, plus what left before it; needs are multiples of 1/256 MB, so these sums are exact in any order)
+        uint32_t rank = 0u;
+        double need_new = 0.0, need_gone = 0.0, took_before = 0.0, back_before = 0.0;
+        bool tie = false;
+        for (uint32_t o = 0u; o < R; ++o) {
+            const bool same = W::bcast32(sv, o) == sv && mine;
+            const uint32_t co = W::bcast32(cls, o), ro = W::bcast32(role, o);
+            const double ko = bcast_f64(fin_key, o), no = bcast_f64(need, o), ao = bcast_f64(t_start, o);
+            const bool peer = same && co == cls;
+            rank += peer && ko < fin_key ? 1u : 0u;
+            tie = tie || (peer && ko == fin_key && o != lane && cls != 2u);
+            need_new += same && ro == 2u ? no : 0.0;
+            need_gone += same && co == 0u ? no : 0.0;
+            took_before += same && ro == 2u && (ao < t_start || (ao == t_start && o < lane)) ? no : 0.0;
+            back_before += same && co == 0u && ko < t_start ? no : 0.0;
+        }
+        if (W::any(tie && mine)) AF_PAR_LEAVE("two responses / two pending step ends at one instant");
+        // per server: how many leave, stay with a pending step, stay in the core queue; RAM must never have run short
+        uint32_t n_dep = 0u, n_run1 = 0u, n_wait1 = 0u;
+        bool fits = true;
+        for (uint32_t k = 0u; k < S; ++k) {
+            if (kChain && level_of(k) != level) continue;
+            const uint32_t d = popc64(W::ballot(mine && sv == k && cls == 0u)), a1 = popc64(W::ballot(mine && sv == k && cls == 1u)),
+                           w1 = popc64(W::ballot(mine && sv == k && cls == 2u));
+            fits = fits && a1 + w1 <= kGsSlots && d <= kGsDeps;
+            if (sv == k) {
+                n_dep = d;
+                n_run1 = a1;
+                n_wait1 = w1;
+            }
+        }
+        const bool ram_short = role == 2u && need > 0.0 && u2d(g[GS_RAM]) - took_before + back_before < need;
+        if (!fits || W::any(ram_short)) AF_PAR_LEAVE(!fits ? "more requests inside than slots" : "RAM could run short");
+
+        // ---- commit: series and counts of the window's events, the servers' state at `limit`, the responses in time order
+        walk(true);
+        ev += n_ev;
+        done_any = W::any(n_ev != 0u || role == 2u) ? 1u : 0u;
+        W::sync();
+        const uint32_t arrivals_k = lw[LBW_SEG_LEN + sv];
+        const double ram_now = u2d(g[GS_RAM]) - need_new + need_gone;
+        const uint32_t n_hold = popc64(W::ballot(mine && cls == 1u && fin_holds)), n_io_all = 0u;
+        (void)n_hold;
+        (void)n_io_all;
+        if (mine && cls == 0u) {
+            g[GS_DEPT + rank] = d2u(fin_key);
+            g[GS_DEPT0 + rank] = d2u(t0v);
+        } else if (mine && cls == 1u) {
+            g[GS_EVT + rank] = d2u(fin_key);
+            gs_bytes(g, 0u)[rank] = (uint8_t)rank;
+            g[GS_STATE + rank] = (uint64_t)fin_row | (fin_holds ? 1ull << 16 : 0ull) | (fin_io ? 1ull << 17 : 0ull);
+            g[GS_T0 + rank] = d2u(t0v);
+            g[GS_NEED + rank] = d2u(need);
+        } else if (mine && cls == 2u) {
+            const uint32_t slot = n_run1 + rank;
+            gs_bytes(g, 1u)[rank] = (uint8_t)slot;
+            g[GS_STATE + slot] = (uint64_t)fin_row;
+            g[GS_T0 + slot] = d2u(t0v);
+            g[GS_NEED + slot] = d2u(need);
+        }
+        for (uint32_t k = 0u; k < S; ++k) {   // the servers' scalar words, by the first lane of each server's block (or lane k for an idle server)
+            if (kChain && level_of(k) != level) continue;
+            const uint64_t in_k = W::ballot(mine && sv == k);
+            const uint32_t holders = popc64(W::ballot(mine && sv == k && cls == 1u && fin_holds)),
+                           in_io_k = popc64(W::ballot(mine && sv == k && cls == 1u && fin_io));
+            const bool writer = in_k != 0ull ? lane == (uint32_t)__builtin_ctzll(in_k) : lane == k;
+            if (writer) {
+                AF_PLAN_AS uint64_t* gk = gs(k);
+                if (in_k != 0ull) {
+                    const uint32_t inside = n_run1 + n_wait1;
+                    gk[GS_EV] = pack32(0u, n_run1);
+                    gk[GS_CQ] = pack32(0u, n_wait1);
+                    gk[GS_CPU] = pack32(1u - holders, n_wait1);
+                    gk[GS_IO] = pack32(in_io_k, inside >= 32u ? 0u : ~((1u << inside) - 1u));
+                    gk[GS_RAM] = d2u(ram_now);
+                    gk[GS_ARR] = pack32(lo32(gk[GS_ARR]) + arrivals_k, 0u);
+                    gk[GS_DEP] = pack32(n_dep, hi32(gk[GS_DEP]));
+                } else {
+                    gk[GS_DEP] = pack32(0u, hi32(gk[GS_DEP]));
+                }
+            }
+        }
+        W::sync();
+        return true;
+    }
+
     // ---- completion (client.py:62-69) -------------------------------------------------------------------
     AF_CORE void complete(bool have, uint32_t r, double t0, double now) {
         const uint32_t at = n_comp + r;
@@ -1841,12 +2198,13 @@ struct Flow {
         lb_nl = A.n_lb_edges;
         lb_magic = A.n_lb_edges ? 0xFFFFFFFFu / A.n_lb_edges + 1u : 0u;
         ev = drops = 0u;
+        gs_rounds = 0u;
         why = info = 0u;
-        run_val = 0;
+        run_val = run_val2 = 0;
         gen_done = false;
         nl0 = nl1 = nl2 = nl3 = 0u;
         h0 = h1 = h2 = h3 = 0.0;
-        h2b = h2c = 0.0;
+        h2b = h2c = h2d = h2e = 0.0;   // (kHzLds: the LDS words were zeroed with the layout)
         n_levels = 1u;
         if (kChain)
             for (uint32_t v = 0u; v < A.n_servers; ++v) n_levels = level_of(v) + 1u > n_levels ? level_of(v) + 1u : n_levels;
@@ -1863,20 +2221,26 @@ struct Flow {
             // with FEAT_FAR no station handles an event beyond it (select()): the receiving station enters the delivery of
             // a marked message at the time of that event.
             if (kFar) t_lim = (samples != nullptr && (!kHbmRing || A.L.ring_rows != 0u)) ? (double)(tick_base + A.L.win_rows) * A.sample_period : AF_INF;
-            const double h_done_before = h3;
+            const double h_done_before = H_get(3u);
             double H_in = AF_INF, h_gen = AF_INF;
             // (plan-specialised builds unroll the five stations: `st` becomes a constant in each copy -- list addresses fold,
             // the select chains over nl0..nl3 / h0..h3 and their scratch copy disappear: 58.8 -> 49.2 ms on BASELINE config 2,
             // 5 500 instructions = 36 KB of code.  The generic instantiations stay a loop: with run-time plan shapes the
             // unrolled body was 13 000 instructions and fell out of the instruction cache)
+            // (FEAT_CHAIN: the server station once per level, in level order -- stx counts the passes, st is the station; a
+            // plan-specialised build unrolls as many level passes as the plan has levels)
+#if defined(AF_FJ_N_LEVELS)
+            constexpr uint32_t kLevelPasses = AF_FJ_N_LEVELS;
+#else
+            constexpr uint32_t kLevelPasses = kMaxLevels;
+#endif
 #if defined(AF_FLOW_JIT) && !defined(AF_FLOW_LOOP_STATIONS)
 #pragma unroll
 #else
 #pragma nounroll
 #endif
-            // (FEAT_CHAIN: the server station once per level, in level order -- stx counts the passes, st is the station)
-            for (uint32_t stx = 0u; stx < (kChain ? 4u + kMaxLevels : 5u); ++stx) {
-                const uint32_t st = !kChain ? stx : stx < 3u ? stx : stx < 3u + kMaxLevels ? 3u : 4u;
+            for (uint32_t stx = 0u; stx < (kChain ? 4u + kLevelPasses : 5u); ++stx) {
+                const uint32_t st = !kChain ? stx : stx < 3u ? stx : stx < 3u + kLevelPasses ? 3u : 4u;
                 const uint32_t level = (kChain && st == 3u) ? stx - 3u : 0u;
                 if (kChain && st == 3u && level >= n_levels) continue;
                 if (st == 2u && !A.has_lb) continue;
@@ -1898,7 +2262,16 @@ struct Flow {
                 } else {
                     // (FEAT_CHAIN: what a level sends back into the server list takes the places its own selection left there,
                     // so the room that binds is the completion list's)
-                    n_sel = select(st - 1u, H_in, st == 4u ? 64u : (kBig ? cap_of(nxt) : cap) - n_list_get(nxt), key, t0, aux,
+                    uint32_t room = st == 4u ? 64u : (kBig ? cap_of(nxt) : cap) - n_list_get(nxt);
+                    if (kGen && st == 3u) {
+                        // the round-at-once solver (gen_servers_par) gives every request of the window a lane: the ones inside the
+                        // servers of this pass and the arrivals taken now -- no more arrivals than lanes are left
+                        uint32_t inside = 0u;
+                        for (uint32_t k = 0u; k < A.n_servers; ++k)
+                            if (!kChain || level_of(k) == level) inside += hi32(gs(k)[GS_EV]) + hi32(gs(k)[GS_CQ]);
+                        if (inside <= 48u && 64u - inside < room) room = 64u - inside;
+                    }
+                    n_sel = select(st - 1u, H_in, room, key, t0, aux,
                                    (kChain && st == 3u) ? level_slot(level) : st - 1u, (kChain && st == 3u) ? level : kAnyLevel);
                 }
                 if (st == 0u) prof(PROF_GEN);
@@ -1973,9 +2346,14 @@ struct Flow {
                     uint32_t done = 0u;
                     // (FEAT_CHAIN: the servers of this pass's level, up to the level's horizon; the others keep their state)
                     const bool my_pass = lane < A.n_servers && (!kChain || level_of(lane) == level);
-                    if (my_pass) done = gen_servers(lane, H_get(kChain ? level_slot(level) : 2u));
+                    // the whole round at once where the solver decides it (gen_servers_par), else event by event
+                    uint32_t par_done = 0u;
+                    const bool solved = gen_servers_par(level, H_get(kChain ? level_slot(level) : 2u), par_done);
+                    W::sync();   // (every lane has read the servers' state before a lane's gen_servers() changes it)
+                    gs_rounds += solved ? 0x10000u : 1u;   // (diagnostic: rounds solved at once | rounds walked event by event)
+                    if (!solved && my_pass) done = gen_servers(lane, H_get(kChain ? level_slot(level) : 2u));
                     W::sync();
-                    work += popc64(W::ballot(done != 0u));
+                    work += solved ? par_done : popc64(W::ballot(done != 0u));
                     prof(PROF_SERVERS);
                     // the departures the servers produced (each server's in time order), sent by the whole wave, 64 at a time
                     auto dep_cnt = [&](uint32_t k) { return (!kChain || level_of(k) == level) ? lo32(gs(k)[GS_DEP]) : 0u; };
@@ -2118,14 +2496,16 @@ struct Flow {
             }
             // ---- ticks that can no longer change
             // (a station behind a spiked edge runs AHEAD of the one that feeds it: the slowest horizon bounds what is final)
-            double h_min = h3;
+            double h_min = H_get(3u);
             if (kMarks && A.n_edge_marks != 0u) {
                 h_min = h_min < h_gen ? h_min : h_gen;
-                h_min = h_min < h0 ? h_min : h0;
-                h_min = (A.has_lb && h1 < h_min) ? h1 : h_min;
-                h_min = h_min < h2 ? h_min : h2;
-                if (kChain && n_levels > 1u) h_min = h_min < h2b ? h_min : h2b;
-                if (kChain && n_levels > 2u) h_min = h_min < h2c ? h_min : h2c;
+                h_min = h_min < H_get(0u) ? h_min : H_get(0u);
+                h_min = (A.has_lb && H_get(1u) < h_min) ? H_get(1u) : h_min;
+                h_min = h_min < H_get(2u) ? h_min : H_get(2u);
+                if (kChain)
+#pragma unroll
+                    for (uint32_t lv = 1u; lv < kMaxLevels; ++lv)
+                        if (n_levels > lv) h_min = h_min < H_get(level_slot(lv)) ? h_min : H_get(level_slot(lv));
             }
             const bool finished = gen_done && work == 0u && !(h_min < T);
             W::sync();
@@ -2133,9 +2513,9 @@ struct Flow {
             W::sync();
             prof(PROF_FLUSH);
 #if defined(AF_FLOW_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
-            if (lane == 0u) std::fprintf(stderr, "round: work %u cursor %u nl %u %u %u %u h %.6f %.6f %.6f %.6f hgen %.6f hmin %.6f moved %d tick_base %u n_comp %u why %x\n", work, cursor, nl0, nl1, nl2, nl3, h0, h1, h2, h3, h_gen, h_min, (int)moved, tick_base, n_comp, why);
+            if (lane == 0u) std::fprintf(stderr, "round: work %u cursor %u nl %u %u %u %u h %.6f %.6f %.6f %.6f hgen %.6f hmin %.6f moved %d tick_base %u n_comp %u why %x\n", work, cursor, nl0, nl1, nl2, nl3, H_get(0u), H_get(1u), H_get(2u), H_get(3u), h_gen, h_min, (int)moved, tick_base, n_comp, why);
 #endif
-            const bool stuck = work == 0u && !finished && !(kMarks ? moved : h3 > h_done_before);
+            const bool stuck = work == 0u && !finished && !(kMarks ? moved : H_get(3u) > h_done_before);
             if (stuck) why |= FLOW_WHY_LIST;   // nothing moved, no horizon advanced: a list is full of later messages
             if (finished || W::any(why != 0u)) break;
         }
@@ -2157,7 +2537,8 @@ struct Flow {
             c[af::CNT_EVENTS] = ev_all;
             c[af::CNT_TICKS] = A.n_ticks;
             c[af::CNT_FLAGS] = flags;
-            c[af::CNT_MAX_LIVE] = 0u;   // a diagnostic of the sequential kernels (peak of live requests)
+            // a diagnostic: the sequential kernels' peak of live requests; FEAT_GENSRV: how the server station's rounds were run
+            c[af::CNT_MAX_LIVE] = kGen ? ((gs_rounds >> 16 > 0xFFFFu ? 0xFFFFu : gs_rounds >> 16) << 16) | ((gs_rounds & 0xFFFFu)) : 0u;
             c[af::CNT_MARKS] = marks;
         }
         if (kProf) {

@@ -65,7 +65,8 @@ inline bool flow_needs_chain(const af_plan_t& p) {
 inline std::string flow_ineligible_reason(const af_plan_t& p) {
     if (p.n_servers == 0) return "no server";
     if (p.n_servers > kSrvSlots) return "more than 16 servers";
-    if (p.n_edges + 3u * p.n_servers > 64u) return "more than 64 sampled series";
+    if (p.n_edges > 64u) return "more than 64 edges";   // (an edge's send counter lives in the register of the edge's lane)
+    if (p.n_edges + 3u * p.n_servers > 128u) return "more than 128 sampled series";   // (a lane carries two series: flush_ticks)
     if (p.edge_target_kind[p.gen_out_edge] != AF_NODE_CLIENT) return "generator does not feed the client";
     const uint32_t ck = p.edge_target_kind[p.client_out_edge];
     if (p.has_lb) {
@@ -94,7 +95,7 @@ inline std::string flow_ineligible_reason(const af_plan_t& p) {
     if (flow_needs_chain(p)) {   // (round 4: the server station once per level -- af_flow.hpp, FEAT_CHAIN)
         const uint32_t levels = flow_server_levels(p, nullptr);
         if (levels == 0u) return "servers feed each other in a cycle";
-        if (levels > kMaxLevels) return "server chain deeper than three levels";
+        if (levels > kMaxLevels) return "server chain deeper than five levels";
     }
     if (flow_needs_general_servers(p) && p.n_endpoints + p.n_steps > 65535u) return "more step rows than a request record addresses";
     return std::string();

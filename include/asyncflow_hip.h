@@ -212,6 +212,14 @@ enum af_flag {
                                           reference raises there (simpy: ValueError "Negative delay", edge.py:107);
                                           the engine delivers at now + (transit + spike) and reports the scenario:
                                           asyncflow_amd.SimulationRunner raises the same ValueError for it */
+    ,
+    AF_FLAG_RAM_PUT_BLOCKED = 1u << 14 /* a request gave back a FRACTIONAL amount of RAM and `capacity - level >= amount`
+                                          was false by one rounding (2048 - fl(2048 - 100.3) < 100.3): in the reference the
+                                          simpy Container.put then WAITS until a later get lowers the level, and the
+                                          response leaves that much later (server.py:270-276).  The engine gives the RAM
+                                          back at once and reports the scenario: from that instant on its results are not
+                                          the reference's.  Never set for needs that are whole MB or multiples of 1/256 MB
+                                          (their sums are exact). */
 };
 
 typedef struct af_outputs {

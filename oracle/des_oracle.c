@@ -388,6 +388,9 @@ static void srv_finish(sim_t* s, int r) {
     }
     if (R->ram > 0.0) { /* `if total_ram:` */
         S->ram_in_use -= R->ram;
+        /* Container._do_put: `if self._capacity - self._level >= event.amount` -- false by one rounding for some fractional
+         * needs (2048 - fl(2048 - 100.3) < 100.3): the reference's put then waits for a later get.  Not modelled: reported. */
+        if (s->p->srv_ram_mb[R->server] - S->ram_level < R->ram) s->flags |= AF_FLAG_RAM_PUT_BLOCKED;
         S->ram_level += R->ram; /* ContainerPut.__init__ -> _do_put succeeds at once */
         sched(s, 0.0, PRIO_NORMAL, EV_RAM_PUT, r, 0);
         return;

@@ -12,6 +12,8 @@ Each fixture holds, for one (payload, seed) of oracle/scenarios.py::GOLDEN:
 * ``generated / completed / dropped / ticks / heap_events``;
 * ``clock``          float64 [completed, 2] = ClientRuntime.rqs_clock (start, finish);
 * ``samples``        uint32 [n_series, ticks] sampled series (ram rows: float32 bits);
+* ``ram_f64``        (fixtures whose endpoints need FRACTIONAL megabytes only) float64 [n_servers, ticks]: ram_in_use as the
+                     reference's collector holds it -- the engine emits the series as float32, i.e. this value rounded once;
 * ``latency_stats``  the 8 numbers of ResultsAnalyzer.get_latency_stats();
 * ``rps``            ResultsAnalyzer.get_throughput_series()[1];
 * ``glibc_log_*``    the same run WITHOUT the math.log substitution (see
@@ -50,7 +52,11 @@ def build_fixture(name: str) -> dict[str, np.ndarray]:
     raw = run_reference(payload, seed, patch_log=False)
     n = min(len(res.clock), len(raw.clock))
     delta = float(np.max(np.abs(res.clock[:n] - raw.clock[:n]))) if n else 0.0
+    extra = {}
+    if np.any(res.ram_f64 != np.floor(res.ram_f64)):
+        extra["ram_f64"] = res.ram_f64
     return {
+        **extra,
         "payload_json": np.array(json.dumps(payload, sort_keys=True)),
         "seed": np.uint64(seed),
         "generated": np.int64(res.generated),
@@ -140,7 +146,7 @@ def main() -> int:
         path = GOLDEN_DIR / f"{name}.npz"
         if args.check:
             old = np.load(path, allow_pickle=False)
-            same = all(np.array_equal(old[k], fx[k]) for k in fx)
+            same = all(k in old.files and np.array_equal(old[k], fx[k]) for k in fx)
             print(f"{name}: {'identical' if same else 'DIFFERENT'}")
             rc |= 0 if same else 1
         else:

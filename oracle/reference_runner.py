@@ -38,6 +38,7 @@ class ReferenceResult:
     edge_ids: list[str] = field(default_factory=list)
     server_ids: list[str] = field(default_factory=list)
     simpy_flavour: str = "standin"
+    ram_f64: np.ndarray = field(default_factory=lambda: np.zeros((0, 0)))   # float64 [n_servers, ticks]: ram_in_use as the reference holds it
 
 
 class _DeterministicMath(types.SimpleNamespace):
@@ -134,6 +135,11 @@ def run_reference(payload: dict, seed: int, *, patch_log: bool = True) -> Refere
     samples = np.zeros((len(rows), ticks), dtype=np.uint32)
     for i, r in enumerate(rows):
         samples[i, : len(r)] = r
+    # ram_in_use exactly as the reference's collector appended it (int | float, server.py:65): the engine emits it as f32
+    ram_f64 = np.zeros((len(servers), ticks), dtype=np.float64)
+    for i, srv in enumerate(servers):
+        vals = srv.enabled_metrics.get(SampledMetricName.RAM_IN_USE, [])
+        ram_f64[i, : len(vals)] = np.asarray(vals, dtype=np.float64)
 
     stats = {str(getattr(k, "value", k)): float(v) for k, v in analyzer.get_latency_stats().items()}
     gen = next(iter(runner._rqs_runtime.values()))  # noqa: SLF001
@@ -145,6 +151,7 @@ def run_reference(payload: dict, seed: int, *, patch_log: bool = True) -> Refere
         heap_events=heap_events,
         clock=clock,
         samples=samples,
+        ram_f64=ram_f64,
         latency_stats=stats,
         throughput=analyzer.get_throughput_series(),
         edge_ids=[e.edge_config.id for e in edges],

@@ -340,6 +340,39 @@ def server_chain(dist: str = "poisson", mean: float = 0.7, cores: int = 2, horiz
     }
 
 
+def deep_chain(depth: int = 5, users: float = 120, horizon: int = 30, fan: bool = True) -> dict:
+    """client -> [LB -> {f0, f1} ->] t1 -> t2 -> ... -> client: `depth` server levels in a row (graph.py:135-157 allows any
+    chain with one out-edge per server).  Step times and hop laws differ per tier; the last tier has two cores."""
+    servers, edges = [], [_edge("g-c", "gen", "cli", 0.003)]
+    nodes: dict = {"client": {"id": "cli"}}
+    first = ["f0", "f1"] if fan else ["f0"]
+    for name in first:
+        servers.append(_server(name, 1, 1024, [_endpoint("/in", [("initial_parsing", 0.0015), ("ram", 64), ("io_wait", 0.004)])]))
+    if fan:
+        nodes["load_balancer"] = {"id": "lb", "algorithms": "round_robin", "server_covered": first}
+        edges.append(_edge("c-lb", "cli", "lb", 0.002))
+        edges += [_edge(f"lb-{n}", "lb", n, 0.002) for n in first]
+    else:
+        edges.append(_edge("c-f0", "cli", "f0", 0.002))
+    tiers = [f"t{k}" for k in range(1, depth)]
+    for k, name in enumerate(tiers):
+        servers.append(_server(name, 2 if k == len(tiers) - 1 else 1, 2048,
+                               [_endpoint("/t", [("cpu_bound_operation", 0.001 + 0.0005 * k), ("ram", 32), ("io_db", 0.003 + 0.001 * (k % 3))])]))
+    nxt = tiers[0] if tiers else "cli"
+    for n in first:
+        edges.append(_edge(f"{n}-out", n, nxt, 0.002, "normal" if n == "f1" else "exponential", 0.0005 if n == "f1" else None))
+    for k, name in enumerate(tiers):
+        tgt = tiers[k + 1] if k + 1 < len(tiers) else "cli"
+        edges.append(_edge(f"{name}-out", name, tgt, 0.002 + 0.001 * (k % 2), "normal" if k == 1 else "exponential", 0.001 if k == 1 else None))
+    nodes["servers"] = servers
+    return {
+        "rqs_input": {"id": "gen", "avg_active_users": {"mean": users}, "avg_request_per_minute_per_user": {"mean": 60},
+                      "user_sampling_window": 10},
+        "topology_graph": {"nodes": nodes, "edges": edges},
+        "sim_settings": {"total_simulation_time": horizon, "sample_period_s": 0.05},
+    }
+
+
 def shared_backend(users: float = 200, horizon: int = 120) -> dict:
     """client -> LB -> {a1, a2} -> b (a backend both front servers call) -> client: the deterministic server-tier payload of
     the server-tier measurements (scripts/gpu_chain.py)."""
@@ -512,7 +545,23 @@ def tie_storm(rng: random.Random, horizon: int = 12) -> dict:
 
 
 #: name -> (payload builder, seed) for the committed golden fixtures
+def fractional_ram(dyadic: bool, horizon: int = 20) -> dict:
+    """LB-2 whose endpoints need fractional megabytes (schemas/topology/endpoint.py:26: necessary_ram is a PositiveFloat when
+    it is not an int; server.py:65 keeps ram_in_use as int | float).  dyadic: 100.25 / 64.5 MB -- multiples of 1/256 MB, which
+    the stage-parallel kernel's integer tick ring holds exactly; else 100.3 / 64.7 MB: next-event kernels only."""
+    p = lb_two_servers(users=300, horizon=horizon)
+    needs = (100.25, 64.5) if dyadic else (100.3, 64.7)
+    for srv, need in zip(p["topology_graph"]["nodes"]["servers"], needs):
+        srv["endpoints"][0]["steps"][1]["step_operation"] = {"necessary_ram": need}
+    return p
+
+
 GOLDEN = {
+    # ram_in_use of fractional needs: the fixtures also hold the reference's own f64 series (ram_f64)
+    "frac_ram_dyadic_t20": (lambda: fractional_ram(True), 21),
+    # NOT reproduced by the engine, on purpose (a documented deviation, AF_FLAG_RAM_PUT_BLOCKED): 2048 - fl(2048 - 100.3) < 100.3, so
+    # the reference's `yield RAM.put(100.3)` WAITS for the next get on that Container and the response leaves that much later
+    "deviation_frac_ram_t20": (lambda: fractional_ram(False), 22),
     "single_server_t30": (lambda: single_server(horizon=30), 0),
     "lb2_rr_t30": (lambda: lb_two_servers(horizon=30), 0x5EED0000),
     "lb2_lc_t20": (lambda: lb_two_servers(horizon=20, algo="least_connection"), 7),

@@ -20,4 +20,5 @@ def pytest_configure(config: pytest.Config) -> None:
 
 
 def golden_names() -> list[str]:
-    return sorted(p.stem for p in GOLDEN_DIR.glob("*.npz") if not p.stem.startswith("pooled_"))   # pooled_*: statistical fixture
+    # pooled_*: statistical fixture; deviation_*: reference behaviour the engine reports instead of reproducing (its own tests)
+    return sorted(p.stem for p in GOLDEN_DIR.glob("*.npz") if not p.stem.startswith(("pooled_", "deviation_")))

@@ -10,6 +10,7 @@
 // Built into tests/hostcheck/libaf_hostcheck.so only; never part of the product.
 #pragma once
 
+#include <execinfo.h>
 #include <stdint.h>
 #include <ucontext.h>
 
@@ -92,6 +93,8 @@ struct Exchange {
             if (w->site[i] != site) {
                 std::fprintf(stderr, "wave_emul: divergent cross-lane operations: lane %d at site %u, lane %d at site %u\n",
                              w->current, site, i, w->site[i]);
+                void* frames[24];   // (where THIS lane stands: `c++filt` the names)
+                backtrace_symbols_fd(frames, backtrace(frames, 24), 2);
                 std::abort();
             }
     }

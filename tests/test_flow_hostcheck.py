@@ -24,7 +24,7 @@ from asyncflow_amd import _abi
 from asyncflow_amd.plan import lower
 from asyncflow_amd.workloads import fanout8, lb_two_servers, lb_with_events, single_server, single_server_with_spike
 from oracle import oracle_lib as ol
-from oracle.scenarios import flow_payload, server_chain, server_tiers, stress_mixed, wide_fanout
+from oracle.scenarios import deep_chain, flow_payload, server_chain, server_tiers, stress_mixed, wide_fanout
 from tests.conftest import GOLDEN_DIR
 from tests.hostcheck import build as hc
 
@@ -318,11 +318,12 @@ def test_poisson_integer_second_latencies_run_on_the_flow_kernel():
     assert exact >= 30 and exact + back == 40
 
 
-@pytest.mark.parametrize("n_srv", [9, 12])
+@pytest.mark.parametrize("n_srv", [9, 12, 13, 16])
 def test_round_robin_fan_out_beyond_eight_servers(n_srv):
     """Round 3: 9..12 servers behind a round-robin load balancer run on the stage-parallel kernel (16 slots
-    per per-server array; the 64 sampled series of a wave's lanes bound the count: 2 + 5 S <= 64).  wide_fanout's topology
-    with ONE endpoint per server: multi-core servers, RAM, outages and a spike."""
+    per per-server array).  Round 5: 13..16 servers too -- 2 + 5 S sampled series are more than a wave has lanes, so a lane
+    carries the running values of TWO series (Flow::flush_ticks, run_val2).  wide_fanout's topology with ONE endpoint per
+    server: multi-core servers, RAM, outages and a spike."""
     from oracle.scenarios import wide_fanout
 
     payload = wide_fanout(n_srv, "round_robin", horizon=12, users=100)     # (odd servers answer over ~1-s log-normal hops)
@@ -330,10 +331,25 @@ def test_round_robin_fan_out_beyond_eight_servers(n_srv):
         s["endpoints"] = s["endpoints"][:1]
     assert _run(payload, 77, ipl=4, ring_rows=0)[0] == "exact"
     assert _run(payload, 78, ipl=4, ring_rows=128)[0] == "exact"
-    thirteen = wide_fanout(13, "round_robin", horizon=12)
-    for s in thirteen["topology_graph"]["nodes"]["servers"]:
-        s["endpoints"] = s["endpoints"][:1]
-    assert hc.flow_simulate(lower(thirteen), 1) is None and "64 sampled series" in hc.flow_reason()
+    if n_srv == 16:
+        seventeen = wide_fanout(17, "round_robin", horizon=12)
+        for s in seventeen["topology_graph"]["nodes"]["servers"]:
+            s["endpoints"] = s["endpoints"][:1]
+        assert hc.flow_simulate(lower(seventeen), 1) is None and "more than 16 servers" in hc.flow_reason()
+
+
+@pytest.mark.parametrize(("depth", "fan"), [(4, True), (5, True), (5, False)])
+def test_server_chains_of_four_and_five_levels(depth, fan):
+    """Round 5: tiers deeper than three levels.  The server station runs once per level (FEAT_CHAIN), the
+    levels' horizons are slots 4 .. 7; the generic instantiations keep them in LDS (Flow::hz) because a run-time choice among
+    eight members put the whole object in scratch.  Six levels are refused (the next-event kernels run them)."""
+    payload = deep_chain(depth, users=150, horizon=20, fan=fan)
+    for seed in (3, 4):
+        for kw in (dict(ipl=2, ring_rows=64), dict(ipl=1, ring_rows=0, robust=True, long_list_entries=512)):
+            status, why = _run(payload, seed, **kw)
+            assert status == "exact", (depth, fan, seed, kw, why)
+    if depth == 5 and fan:
+        assert hc.flow_simulate(lower(deep_chain(6, horizon=10)), 1) is None and "deeper than five levels" in hc.flow_reason()
 
 
 def test_general_servers_several_endpoints_and_core_re_entry():

@@ -768,3 +768,92 @@ def test_round_step_times_share_instants_inside_a_general_server():
     for i in (0, 7, 19, 63):
         _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])), f"scenario {i}")
     _same_batches(res, _runner(p, seeds=seeds, flow=False).run())
+
+
+# ------------------------------------------------------------------------------------------ round 5
+def test_general_servers_are_solved_a_round_at_a_time():
+    """Round 5 (VERDICT r4 item 4): the general server station solves a whole round at once (Flow::gen_servers_par: a lane is a
+    request, the one-core FIFO recurrence relaxed to its fixed point) and leaves to the event-by-event walk only what it cannot
+    decide.  Two-endpoint LB-2 -- idle to loaded -- on the generic and the plan-specialised build: nearly every round is solved
+    at once (the kernel reports rounds solved << 16 | rounds walked in counts[:, CNT_MAX_LIVE]), nothing is handed back, and
+    every result equals the next-event kernels' and the oracle's."""
+    from asyncflow_amd.workloads import lb_two_servers_two_endpoints
+
+    for users, n, T in ((400, 96, 60), (1500, 32, 20)):
+        p = lb_two_servers_two_endpoints(users=users, horizon=T)
+        seeds = 0x5EED0000 + np.arange(n, dtype=np.uint64)
+        res = _runner(p, seeds=seeds, specialise=False).run()
+        st = res.engine_stats
+        assert st.flow_scenarios == n and st.flow_to_next_event == 0, (users, st.flow_scenarios, st.flow_fallback)
+        rounds = res.counts[:, _abi.CNT_MAX_LIVE].astype(np.int64)
+        at_once, walked = int((rounds >> 16).sum()), int((rounds & 0xFFFF).sum())
+        assert at_once > 8 * walked, (users, at_once, walked)
+        plan = lower(p)
+        for i in (0, n // 2, n - 1):
+            _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])), f"users {users} scenario {i}")
+        _same_batches(res, _runner(p, seeds=seeds, flow=False).run())
+        special = _runner(p, seeds=seeds, specialise=True).run()
+        assert special.engine_stats.specialised_launches >= 1
+        _same_batches(res, special)
+
+
+def test_the_general_server_benchmark_batch_is_identical_on_both_kernel_families():
+    """`bench.py --config 6` (two-endpoint LB-2) at 2 048 replicas x 600 s: every scenario of the batch, on the device."""
+    import torch
+
+    from asyncflow_amd.results import differing_scenarios
+    from tests.test_gpu_full_batches import _oracle_picks, _sweep
+
+    flow = _sweep(6, 2048, [])
+    acc = flow.step()
+    torch.cuda.synchronize()
+    assert acc["flow_scen"] == flow.n == 2048 and acc["flow_fallback"][0] == 0
+    _oracle_picks(flow, 8)
+    seq = _sweep(6, 2048, ["--no-flow", "--generic-kernels"])
+    seq.step()
+    torch.cuda.synchronize()
+    differ = differing_scenarios(flow.counts, flow.clock, flow.samples, seq.counts, seq.clock, seq.samples)
+    assert differ.size == 0, differ[:8]
+    flow.eng.close()
+    seq.eng.close()
+
+
+@pytest.mark.parametrize("n_srv", [13, 16])
+def test_thirteen_to_sixteen_servers_behind_a_round_robin_lb(n_srv):
+    """Round 5: 2 + 5 S sampled series are more than a wave has lanes for S > 12; a lane then carries the
+    running values of two series (Flow::flush_ticks).  Generic and plan-specialised builds against the next-event kernels and
+    the oracle."""
+    from oracle.scenarios import wide_fanout
+
+    wide = wide_fanout(n_srv, "round_robin", horizon=20, users=100)
+    for s in wide["topology_graph"]["nodes"]["servers"]:
+        s["endpoints"] = s["endpoints"][:1]
+    seeds = np.arange(24, dtype=np.uint64) + 170
+    res = _runner(wide, seeds=seeds).run()
+    assert res.flow_reason == "" and res.engine_stats.flow_scenarios == 24, res.flow_reason
+    plan = lower(wide)
+    for i in (0, 23):
+        _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])), f"{n_srv}-server scenario {i}")
+    _same_batches(res, _runner(wide, seeds=seeds, flow=False).run())
+    special = _runner(wide, seeds=seeds, specialise=True).run()
+    assert special.engine_stats.specialised_launches >= 1
+    _same_batches(res, special)
+
+
+@pytest.mark.parametrize(("depth", "fan"), [(4, True), (5, True), (5, False)])
+def test_server_chains_of_four_and_five_levels_run_on_the_flow_kernel(depth, fan):
+    """Round 5: tiers deeper than three levels; the generic build (horizons in LDS: no scratch object) and
+    the plan-specialised build (as many unrolled level passes as the plan has levels) against the next-event kernels."""
+    from oracle.scenarios import deep_chain
+
+    payload = deep_chain(depth, users=150, horizon=30, fan=fan)
+    seeds = np.arange(32, dtype=np.uint64) + 11 * depth
+    res = _runner(payload, seeds=seeds, specialise=False).run()
+    assert res.flow_reason == "" and res.engine_stats.flow_scenarios == 32 and res.engine_stats.flow_to_next_event <= 2, res.flow_reason
+    plan = lower(payload)
+    for i in (0, 31):
+        _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])), f"depth {depth} scenario {i}")
+    _same_batches(res, _runner(payload, seeds=seeds, flow=False).run())
+    special = _runner(payload, seeds=seeds, specialise=True).run()
+    assert special.engine_stats.specialised_launches >= 1
+    _same_batches(res, special)
