@@ -79,7 +79,14 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         return LIB_PATH
     import fcntl
 
-    with open(CSRC / ".build.lock", "w") as lock:
+    try:
+        lock = open(CSRC / ".build.lock", "w")
+    except OSError:
+        # a read-only install: the lock lives in the temp directory (the build below then fails on its own, with hipcc's message)
+        import tempfile
+
+        lock = open(Path(tempfile.gettempdir()) / f"asyncflow_amd_build_{os.getuid()}.lock", "w")
+    with lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         if not force and not needs_build():
             return LIB_PATH

@@ -90,7 +90,7 @@ struct FlowLayout {
 };
 // FEAT_GENSRV: per-server state, in 8-byte words (Flow::gen_servers)
 constexpr uint32_t kGsSlots = 32u;   // requests inside one server at once (more: handed back)
-constexpr uint32_t kGsDeps = kGsSlots + 64u;   // departures of one round: at most what was inside plus the round's arrivals
+constexpr uint32_t kGsDeps = 64u;   // departures of one server in one round: at most what was inside plus the round's arrivals, which run() keeps within 64 (the room of the server station's select)
 enum : uint32_t { GS_CPU = 0u /* cpu_free | ready << 32 */, GS_IO = 1u /* io | free-slot mask << 32 */, GS_RAM = 2u /* f64 free RAM */,
                   GS_ARR = 3u /* arrivals | RAM queue blocked << 32 */, GS_CQ = 4u /* head | n << 32 */, GS_RQ = 5u, GS_EV = 6u, GS_DEP = 7u /* departures of this round | tie instants so far << 32 */,
                   GS_LAST = 8u /* f64 time of the server's previous event */, GS_LASTDEP = 9u /* f64 time of its previous departure */,
@@ -140,7 +140,7 @@ inline FlowLayout make_flow_layout(uint32_t cap, uint32_t ring_rows, uint32_t g_
     L.off_cnt = w; w += (n_edges + 1u) / 2u + LBW_U32 / 2u + 12u + 8u;   // u32 sends per edge; LBW_U32 u32: lb order, head, n_live, mark cursor, per-server counters; send_floor's 4 x 3 f64; 8 horizon slots (Flow::hz)
     L.off_ring = w; w += (ring_rows * L.pitch + 1u) / 2u;
     L.off_gsrv = general_servers ? w : 0u;
-    if (general_servers) w += n_servers * kGsWords;
+    if (general_servers) w += n_servers * kGsWords + 128u;   // (+ 128 words of the round-at-once solver: Flow::par_words)
     L.n_words = w;
     return L;
 }
@@ -1739,7 +1739,9 @@ struct Flow {
     // ties: gs_instant).  An event that merely coincides with another of the same server without competing for the core (a step end
     // at an arrival's instant, a release at a request's instant: the grant is at that instant either way, and the zero-length wait
     // it may be counted for ends before any tick sees it -- a tick AT the instant is flagged by tick_index) needs no order.
-    static constexpr uint32_t kParBursts = 3u, kParSteps = 24u, kParIters = 24u;
+    static constexpr uint32_t kParBursts = 2u, kParSteps = 24u, kParIters = 24u;
+    // 128 LDS words of the solver behind the servers' state (FlowLayout::off_gsrv; make_flow_layout)
+    AF_CORE AF_PLAN_AS double* par_words() const { return (AF_PLAN_AS double*)(M + A.L.off_gsrv + A.n_servers * kGsWords); }
 #if defined(AF_PAR_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
 #define AF_PAR_LEAVE(why_text) do { if (lane == 0u) std::fprintf(stderr, "par: left to gen_servers (%s), R %u limit %.9g\n", why_text, R, limit); return false; } while (0)
 #else
@@ -1749,7 +1751,7 @@ struct Flow {
         AF_PLAN_AS uint32_t* lw = lbw();
         const uint32_t S = A.n_servers;
         // ---- lanes: per server of this pass its running requests, its core waiters, this round's arrivals
-        uint32_t base = 0u, sv = 0u, role = 3u, idx = 0u, my_base = 0u;
+        uint32_t base = 0u, sv = 0u, role = 3u, idx = 0u, my_base = 0u, n_mine = 0u, blk_max = 0u;   // (blk_max: the largest server block, wave-uniform)
         bool ok = true;
         for (uint32_t k = 0u; k < S; ++k) {
             if (kChain && level_of(k) != level) continue;
@@ -1758,9 +1760,11 @@ struct Flow {
             const uint32_t cores = (uint32_t)blob[A.off_srv + af::SREC * k + 1u] & 0xFFFFu;
             ok = ok && cores == 1u && hi32(gk[GS_RQ]) == 0u && hi32(gk[GS_ARR]) == 0u;
             const uint32_t n_k = n_run + n_wait + n_new;
+            blk_max = n_k > blk_max ? n_k : blk_max;
             if (lane >= base && lane < base + n_k) {
                 sv = k;
                 my_base = base;
+                n_mine = n_k;
                 idx = lane - base;
                 role = idx < n_run ? 0u : idx < n_run + n_wait ? 1u : 2u;
                 idx -= role == 0u ? 0u : role == 1u ? n_run : n_run + n_wait;
@@ -1912,46 +1916,48 @@ struct Flow {
         };
 
         // ---- relaxation to the fixed point of the FIFO recurrence
-        uint32_t nb_max = 0u;
+        // A lane finds the predecessors of its acquisitions by RANK: every lane publishes its request times, counts the ones of
+        // its own server below each of its own (a loop over the server's block of lanes, one LDS read and four VALU operations per
+        // pair -- round 5's first form compared all lanes with all lanes through v_readlane, 14 operations per pair, 75 % of the
+        // station's time), publishes its release times at those places and reads the place in front of it.
+        AF_PLAN_AS double* keys = seg(3);                                  // [64][kParBursts]: seg(3), seg(4) are free in this station
+        AF_PLAN_AS double* sorted_rel = par_words();                       // [64][kParBursts]
+        const uint32_t e0 = kParBursts * my_base, n_e = mine ? kParBursts * n_mine : 0u;
         bool settled = false;
         for (uint32_t it = 0u; it < kParIters && !settled; ++it) {
             walk(false);
             if (W::any(hazard)) AF_PAR_LEAVE("a step program outside the walk's range");
-            uint32_t mine_nb = 0u;
+            W::sync();   // (the previous iteration's reads of keys / sorted_rel are done)
+            if (mine)
 #pragma unroll
-            for (uint32_t b = 0u; b < kParBursts; ++b) mine_nb += r[b] < AF_INF ? 1u : 0u;
-            nb_max = 0u;
+                for (uint32_t b = 0u; b < kParBursts; ++b) keys[kParBursts * lane + b] = r[b];
+            W::sync();
+            uint32_t lt[kParBursts], le[kParBursts];
 #pragma unroll
-            for (uint32_t b = 1u; b <= kParBursts; ++b) nb_max = W::any(mine_nb >= b) ? b : nb_max;
-            double best_r[kParBursts], best_rel[kParBursts];
+            for (uint32_t b = 0u; b < kParBursts; ++b) lt[b] = le[b] = 0u;
+            for (uint32_t i = 0u; i < kParBursts * blk_max; ++i) {
+                const double ko = i < n_e ? keys[e0 + i] : AF_INF;
 #pragma unroll
-            for (uint32_t b = 0u; b < kParBursts; ++b) {
-                best_r[b] = -AF_INF;
-                best_rel[b] = -AF_INF;
-            }
-            bool tie = false;
-            for (uint32_t o = 0u; o < R; ++o) {
-                const bool same = W::bcast32(sv, o) == sv && mine;
-#pragma unroll
-                for (uint32_t bo = 0u; bo < kParBursts; ++bo) {
-                    if (bo >= nb_max) continue;
-                    const double ro = bcast_f64(r[bo], o), relo = bcast_f64(rel[bo], o);
-#pragma unroll
-                    for (uint32_t b = 0u; b < kParBursts; ++b) {
-                        const bool before = same && ro < r[b] && ro > best_r[b];
-                        best_r[b] = before ? ro : best_r[b];
-                        best_rel[b] = before ? relo : best_rel[b];
-                        tie = tie || (same && ro == r[b] && ro < AF_INF && !(o == lane && bo == b));
-                    }
+                for (uint32_t b = 0u; b < kParBursts; ++b) {
+                    lt[b] += ko < r[b] ? 1u : 0u;
+                    le[b] += ko <= r[b] ? 1u : 0u;
                 }
             }
+            bool tie = false;
+#pragma unroll
+            for (uint32_t b = 0u; b < kParBursts; ++b) {
+                tie = tie || (r[b] < AF_INF && le[b] != lt[b] + 1u);   // another CPU.get() of this server at my instant
+                if (mine && r[b] < AF_INF) sorted_rel[e0 + lt[b]] = rel[b];
+            }
+            W::sync();
             bool changed = false;
 #pragma unroll
             for (uint32_t b = 0u; b < kParBursts; ++b) {
+                const double found = (mine && r[b] < AF_INF && lt[b] > 0u) ? sorted_rel[e0 + lt[b] - 1u] : -AF_INF;
                 // (what binds is max(r, G): a predecessor that released before I asked changes nothing)
-                const double was = G[b] > r[b] ? G[b] : r[b], now = best_rel[b] > r[b] ? best_rel[b] : r[b];
+                const double was = G[b] > r[b] ? G[b] : r[b], now = found > r[b] ? found : r[b];
                 changed = changed || (r[b] < AF_INF && was != now);
-                G[b] = best_rel[b];
+                G[b] = found;
             }
             settled = !W::any(changed);
             if (settled && W::any(tie)) AF_PAR_LEAVE("two CPU.get() at one instant");
@@ -1964,17 +1970,33 @@ struct Flow {
         uint32_t rank = 0u;
         double need_new = 0.0, need_gone = 0.0, took_before = 0.0, back_before = 0.0;
         bool tie = false;
-        for (uint32_t o = 0u; o < R; ++o) {
-            const bool same = W::bcast32(sv, o) == sv && mine;
-            const uint32_t co = W::bcast32(cls, o), ro = W::bcast32(role, o);
-            const double ko = bcast_f64(fin_key, o), no = bcast_f64(need, o), ao = bcast_f64(t_start, o);
-            const bool peer = same && co == cls;
-            rank += peer && ko < fin_key ? 1u : 0u;
-            tie = tie || (peer && ko == fin_key && o != lane && cls != 2u);
-            need_new += same && ro == 2u ? no : 0.0;
-            need_gone += same && co == 0u ? no : 0.0;
-            took_before += same && ro == 2u && (ao < t_start || (ao == t_start && o < lane)) ? no : 0.0;
-            back_before += same && co == 0u && ko < t_start ? no : 0.0;
+        {
+            AF_PLAN_AS double* p_key = seg(3);
+            AF_PLAN_AS double* p_need = seg(4);
+            AF_PLAN_AS double* p_start = par_words();
+            AF_PLAN_AS uint64_t* p_meta = (AF_PLAN_AS uint64_t*)(par_words() + 64);
+            W::sync();
+            if (mine) {
+                p_key[lane] = fin_key;
+                p_need[lane] = need;
+                p_start[lane] = t_start;
+                p_meta[lane] = (uint64_t)(cls | (role << 2));
+            }
+            W::sync();
+            for (uint32_t i = 0u; i < blk_max; ++i) {
+                const bool in = mine && i < n_mine;
+                const uint32_t o = my_base + (in ? i : 0u);
+                const uint32_t mo = in ? (uint32_t)p_meta[o] : 0xFu;
+                const uint32_t co = mo & 3u, ro = mo >> 2;
+                const double ko = p_key[o], no = in ? p_need[o] : 0.0, ao = p_start[o];
+                const bool peer = in && co == cls;
+                rank += peer && ko < fin_key ? 1u : 0u;
+                tie = tie || (peer && ko == fin_key && o != lane && cls != 2u);
+                need_new += ro == 2u ? no : 0.0;
+                need_gone += co == 0u ? no : 0.0;
+                took_before += ro == 2u && (ao < t_start || (ao == t_start && o < lane)) ? no : 0.0;
+                back_before += co == 0u && ko < t_start ? no : 0.0;
+            }
         }
         if (W::any(tie && mine)) AF_PAR_LEAVE("two responses / two pending step ends at one instant");
         // per server: how many leave, stay with a pending step, stay in the core queue; RAM must never have run short
@@ -2269,7 +2291,9 @@ struct Flow {
                         uint32_t inside = 0u;
                         for (uint32_t k = 0u; k < A.n_servers; ++k)
                             if (!kChain || level_of(k) == level) inside += hi32(gs(k)[GS_EV]) + hi32(gs(k)[GS_CQ]);
-                        if (inside <= 48u && 64u - inside < room) room = 64u - inside;
+                        // (the same bound keeps a server's departures of one round within kGsDeps: <= 32 inside + 8, or <= 64 in all)
+                        const uint32_t lanes_left = inside <= 56u ? 64u - inside : 8u;
+                        if (lanes_left < room) room = lanes_left;
                     }
                     n_sel = select(st - 1u, H_in, room, key, t0, aux,
                                    (kChain && st == 3u) ? level_slot(level) : st - 1u, (kChain && st == 3u) ? level : kAnyLevel);

@@ -70,15 +70,23 @@ def load_library(path: str | Path | None = None) -> C.CDLL:
             # last build -- content hash, not mtime) has none.  Without hipcc a stale library is an error as well: running
             # other code than the sources say is worse than not running.
             if not af_build.have_hipcc():
-                what = "not found" if not p.exists() else "was built from other sources than the tree holds"
-                msg = (f"{p} {what} and hipcc is not available to rebuild it (`python -m asyncflow_amd.build`, "
-                       "hipcc --offload-arch=gfx950). asyncflow_amd has no CPU fallback.")
-                raise EngineUnavailableError(msg)
-            try:
-                af_build.build()
-            except RuntimeError as exc:
-                msg = f"building {p} failed: {exc}"
-                raise EngineUnavailableError(msg) from exc
+                if p.exists() and not af_build.STAMP_PATH.exists():
+                    # a library shipped prebuilt (or built by a tree that wrote no stamp): nothing says it is stale, and nothing
+                    # here could rebuild it -- load it; the ABI version is checked below either way
+                    import warnings
+
+                    warnings.warn(f"{p} has no build stamp and hipcc is not available: loading it as it is", RuntimeWarning, stacklevel=2)
+                else:
+                    what = "not found" if not p.exists() else "was built from other sources than the tree holds"
+                    msg = (f"{p} {what} and hipcc is not available to rebuild it (`python -m asyncflow_amd.build`, "
+                           "hipcc --offload-arch=gfx950). asyncflow_amd has no CPU fallback.")
+                    raise EngineUnavailableError(msg)
+            else:
+                try:
+                    af_build.build()
+                except (RuntimeError, OSError) as exc:      # hipcc failed / a read-only tree
+                    msg = f"building {p} failed: {type(exc).__name__}: {exc}"
+                    raise EngineUnavailableError(msg) from exc
         if not p.exists():
             msg = f"{p} not found. asyncflow_amd has no CPU fallback."
             raise EngineUnavailableError(msg)

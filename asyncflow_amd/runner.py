@@ -109,7 +109,8 @@ def write_point(payload: dict, key: str, value: float) -> None:
         raise ValueError(msg)
 
 
-VALIDATE_EVERY_POINT_UP_TO = 10_000   # distinct points; the reference's model costs ~0.2 ms per payload
+VALIDATE_EVERY_POINT_UP_TO = 512      # distinct points validated row by row; the reference's model costs ~0.2 ms per payload
+_VALIDATED: dict[tuple, int] = {}       # (plan, columns) digests already validated in this process
 
 
 def validate_points(plan: DevicePlan, columns: Mapping[str, np.ndarray], n: int) -> int:
@@ -119,13 +120,20 @@ def validate_points(plan: DevicePlan, columns: Mapping[str, np.ndarray], n: int)
 
     * Up to ``VALIDATE_EVERY_POINT_UP_TO`` DISTINCT points (rows of the column table; seed replicas of one point count
       once): every one of them is validated, like the reference would.
-    * Beyond that: the points that carry every column's extremes (the scenarios holding its minimum and its maximum) plus
-      the first and the last one.  That argument covers the RANGE constraints of the schema, which are monotone in each
-      column; the constraints that are not -- integrality of the int fields -- are checked over the whole column here and in
+    * Larger sweeps (a 100 x 100 grid is 10 000 points = seconds of model validation per call, and `bench.py` resolves
+      a sweep several times): every DISTINCT VALUE of every column is validated (written into the plan's own
+      payload: the schema's field constraints are per field), then whole rows: the rows that hold every column's
+      extremes, the first and the last one, and 64 rows spread evenly over the sweep -- the schema's cross-field
+      constraints (a Gaussian's variance with its mean, the sampling window with the horizon) are monotone in each
+      column, the constraints that are not -- integrality of the int fields -- are checked over whole columns here and in
       `resolve_sweep`, and cross-column constraints of the event columns are covered exhaustively by `_event_columns`
-      (every distinct combination is lowered).
+      (every distinct combination is lowered).  The reduced coverage is logged (logger ``asyncflow_amd``).
+    * A (plan, columns) pair validated once in this process is not validated again.
     Returns the number of payloads validated; raises ``ValueError`` (pydantic's ValidationError is one)."""
     import copy
+    import hashlib
+    import json
+    import logging
 
     from .payload import normalize_payload
 
@@ -138,24 +146,46 @@ def validate_points(plan: DevicePlan, columns: Mapping[str, np.ndarray], n: int)
                 msg = f"sweep key {key!r}: an integer field of the schema, but scenario {bad} has {float(col[bad])!r}"
                 raise ValueError(msg)
     table = np.stack([np.asarray(columns[k], dtype=np.float64) for k in keys], axis=1) if keys else np.zeros((n, 0))
-    _, first = np.unique(table, axis=0, return_index=True)
-    if len(first) <= VALIDATE_EVERY_POINT_UP_TO:
-        picks = {int(i) for i in first}
-    else:
-        picks = {0, n - 1}
-        for col in columns.values():
-            picks.add(int(np.argmin(col)))
-            picks.add(int(np.argmax(col)))
-    for i in sorted(picks):
+    digest = hashlib.sha1(json.dumps(plan.payload, sort_keys=True, default=str).encode())
+    digest.update(repr(keys).encode())
+    digest.update(np.ascontiguousarray(table).tobytes())
+    memo = (digest.hexdigest(), n)
+    if memo in _VALIDATED:
+        return _VALIDATED[memo]
+
+    def check(values: Mapping[str, float], what: str) -> None:
         point = copy.deepcopy(plan.payload)
-        for key, col in columns.items():
-            write_point(point, key, col[i])
+        for key, value in values.items():
+            write_point(point, key, value)
         try:
             normalize_payload(point)
         except ValueError as exc:
-            msg = f"sweep point {i} ({ {k: float(c[i]) for k, c in columns.items()} }) is not a valid payload: {exc}"
+            msg = f"{what} ({ {k: float(v) for k, v in values.items()} }) is not a valid payload: {exc}"
             raise ValueError(msg) from exc
-    return len(picks)
+
+    _, first = np.unique(table, axis=0, return_index=True)
+    done = 0
+    if len(first) <= VALIDATE_EVERY_POINT_UP_TO:
+        picks = sorted(int(i) for i in first)
+    else:
+        for key in keys:                  # every distinct value of every column, on its own
+            for v in np.unique(columns[key]):
+                check({key: float(v)}, f"sweep value {key!r}")
+                done += 1
+        rows = {0, n - 1} | {int(i) for i in np.linspace(0, n - 1, 64).round()}
+        for col in columns.values():
+            rows.add(int(np.argmin(col)))
+            rows.add(int(np.argmax(col)))
+        picks = sorted(rows)
+        logging.getLogger("asyncflow_amd").info(
+            "sweep of %d distinct points: validated %d distinct column values one by one and %d whole rows (extremes, ends, "
+            "64 spread evenly) instead of every row", len(first), done, len(picks))
+    for i in picks:
+        check({key: col[i] for key, col in columns.items()}, f"sweep point {i}")
+    _VALIDATED[memo] = done + len(picks)
+    if len(_VALIDATED) > 64:
+        _VALIDATED.pop(next(iter(_VALIDATED)))
+    return done + len(picks)
 
 
 def resolve_sweep(plan: DevicePlan, sweep: Mapping[str, Any] | None, n: int) -> list[tuple[int, int, np.ndarray, str]]:
@@ -500,10 +530,15 @@ class SimulationRunner:
                           samples_ptr=samples.data_ptr() if samples is not None else 0, tick_capacity=ticks,
                           counts_ptr=counts.data_ptr(), draw_capacity=clock_cap)
             cols = [(c, i, v) for c, i, v, _ in overrides]
+            run_kw.update(online_hist_ptr=online_hist.data_ptr() if online_hist is not None else 0, online_hist_bins=o_bins,
+                          online_hist_max=o_max,
+                          online_rps_ptr=online_rps.data_ptr() if online_rps is not None and o_buckets else 0,
+                          online_rps_buckets=o_buckets)
             build = True
             if self.specialise is None:
-                # which kernel family this sweep runs on is the ENGINE's decision (plan range, general servers above a
-                # few scenarios, a sweep it cannot be sized for): read it off the spec it would launch
+                # which kernel family this sweep runs on is the ENGINE's decision (plan range, a sweep it cannot be sized
+                # for): read it off the spec it would launch -- asked with the very output shape of the launch, kernel-side
+                # summary included, so that the probe plans the instantiation that runs
                 on_flow_kernel = "-DAF_FLOW_JIT=1" in eng.jit_spec(self.seeds, cols, **run_kw)
                 build = self._want_specialised(n, clock_cap, on_flow_kernel)
             stats = eng.run(
@@ -512,10 +547,6 @@ class SimulationRunner:
                 **run_kw,
                 specialise=True if self.specialise is None else bool(self.specialise),
                 specialise_build=build,
-                online_hist_ptr=online_hist.data_ptr() if online_hist is not None else 0, online_hist_bins=o_bins,
-                online_hist_max=o_max,
-                online_rps_ptr=online_rps.data_ptr() if online_rps is not None and o_buckets else 0,
-                online_rps_buckets=o_buckets,
             )
             flow_reason = eng.flow_reason() if self.flow else "flow=False"
             if self.flow and not flow_reason and int(stats.flow_scenarios) == 0:

@@ -138,7 +138,7 @@ def test_invalid_points_are_rejected_by_the_payload_models():
 
 
 def test_interior_points_are_validated_too():
-    """The reference validates every payload it runs (schemas/payload.py:20-252): so does a sweep of up to 10 000 distinct
+    """The reference validates every payload it runs (schemas/payload.py:20-252): so does a sweep of up to VALIDATE_EVERY_POINT_UP_TO distinct
     points -- an invalid point between two valid extremes does not slip through (a fractional window)."""
     from asyncflow_amd import runner
 
@@ -150,8 +150,18 @@ def test_interior_points_are_validated_too():
         resolve_sweep(plan, {DOWN_T0: [18.0, 36.5, 20.0], DOWN_T1: [24.0, 41.0, 25.0]}, 3)
     cols = {"rqs_input.avg_active_users.mean": np.repeat(np.arange(1.0, 41.0), 5)}    # 40 distinct points x 5 seeds
     assert runner.validate_points(plan, {k: np.asarray(v) for k, v in cols.items()}, 200) == 40
-    many = {"rqs_input.avg_active_users.mean": np.linspace(10.0, 500.0, runner.VALIDATE_EVERY_POINT_UP_TO + 1)}
-    assert runner.validate_points(plan, many, len(many["rqs_input.avg_active_users.mean"])) == 2     # beyond: the extremes
+    # beyond VALIDATE_EVERY_POINT_UP_TO distinct points: every distinct VALUE of every column on its own, then the
+    # rows holding the extremes, the ends and 64 rows spread evenly -- a 30 x 30 grid is 60 values + < 70 rows, not 900 rows
+    a, b = np.meshgrid(np.linspace(10.0, 500.0, 30), np.linspace(0.001, 0.02, 30))
+    grid = {"rqs_input.avg_active_users.mean": a.ravel(), "topology_graph.edges[*].latency.mean": b.ravel()}
+    assert 900 > runner.VALIDATE_EVERY_POINT_UP_TO
+    done = runner.validate_points(plan, grid, 900)
+    assert 60 + 4 <= done <= 60 + 70
+    assert runner.validate_points(plan, grid, 900) == done                                # (memoised: same plan, same columns)
+    bad = {k: v.copy() for k, v in grid.items()}
+    bad["topology_graph.edges[*].latency.mean"][437] = -0.001                             # one interior value of one column
+    with pytest.raises(ValueError, match="not a valid payload|must be positive"):
+        resolve_sweep(plan, bad, 900)
     with pytest.raises(ValueError, match="integer field"):                               # ... and integrality, whole column
         resolve_sweep(plan, {WINDOW: np.where(np.arange(10_002) == 5_000, 60.5, 60.0)}, 10_002)
 
