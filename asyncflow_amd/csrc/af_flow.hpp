@@ -61,7 +61,11 @@ enum : uint32_t {
     FLOW_WHY_LIST = 1u << 10,       // more messages pending at a station than the list holds
     FLOW_WHY_RING = 1u << 11,       // an interval reaches further ahead than the tick ring
     FLOW_WHY_RAM = 1u << 12,        // a request would have to wait for RAM
-    FLOW_WHY_MASK = FLOW_WHY_TIE | FLOW_WHY_LIST | FLOW_WHY_RING | FLOW_WHY_RAM,
+    // (bits 13, 14: AF_FLAG_NEGATIVE_DELAY, AF_FLAG_RAM_PUT_BLOCKED)
+    FLOW_WHY_GEN_TIE = 1u << 15,    // the tie is one the general server station gives up on (an arrival exactly at a step end, two
+                                    // responses at one instant): the second-chance instantiation would stop at the same instant, so
+                                    // such a scenario goes straight to the next-event kernels; set together with FLOW_WHY_TIE
+    FLOW_WHY_MASK = FLOW_WHY_TIE | FLOW_WHY_LIST | FLOW_WHY_RING | FLOW_WHY_RAM | FLOW_WHY_GEN_TIE,
 };
 constexpr uint32_t kMaxServers = 8;    // least connections: in-flight counts of <= 8 servers in two 64-bit words, 8 draws in registers
 // servers behind a round-robin LB: 16 slots per per-server array of lbw() (what binds first is the 64 sampled series a wave's
@@ -1409,7 +1413,7 @@ struct Flow {
             ram_released = true;
         }
         const uint32_t nd = lo32(GR.dep);
-        if (u2d(GR.lastdep) == now) why |= FLOW_WHY_TIE;   // two responses at one instant: their order on the out-edge is SimPy's
+        if (u2d(GR.lastdep) == now) why |= FLOW_WHY_TIE | FLOW_WHY_GEN_TIE;   // two responses at one instant: their order on the out-edge is SimPy's
         GR.lastdep = d2u(now);
         g[GS_DEPT + nd] = d2u(now);
         g[GS_DEPT0 + nd] = g[GS_T0 + slot];
@@ -1461,7 +1465,7 @@ struct Flow {
         gm_n += 1u;
     }
     AF_CORE void gm_emit(AF_PLAN_AS uint64_t* g, uint32_t slot, double now, double dur) {
-        if (!(now + dur > now)) why |= FLOW_WHY_TIE;   // (a step too short to advance the f64 clock: SimPy queues it behind the instant's steps)
+        if (!(now + dur > now)) why |= FLOW_WHY_TIE | FLOW_WHY_GEN_TIE;   // (a step too short to advance the f64 clock: SimPy queues it behind the instant's steps)
         gs_schedule(g, now + dur, slot);
     }
     // Container._trigger_get of the CPU container: waiters are served FIFO while cores are free; the first n_old entries had
@@ -1639,7 +1643,7 @@ struct Flow {
 #if defined(AF_FLOW_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
                 std::fprintf(stderr, "gen tie: sv %u ta %.17g te %.17g ev_n %u\n", sv, ta, te, ev_n);
 #endif
-                why |= FLOW_WHY_TIE;   // the next-event kernels replay SimPy's event-by-event order
+                why |= FLOW_WHY_TIE | FLOW_WHY_GEN_TIE;   // the next-event kernels replay SimPy's event-by-event order
                 break;
             }
             GR.last = d2u(now);

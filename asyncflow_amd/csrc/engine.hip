@@ -377,7 +377,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) 
 // What stays a run-time argument: every pointer, the scenario count and the clock / tick / draw capacities (they
 // change with replicas and the runner's auto-grow; a key that contained them would recompile for every such change).
 #define AF_FJ_F64(bits) __builtin_bit_cast(double, (uint64_t)(bits))
-extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(((AF_FJ_FEAT) & aff::FEAT_GENSRV) ? 3 : AF_FLOW_WPE))) af_flow_jit(const aff::FlowArgs a_in) {
+// (the register budget follows the waves per SIMD the launch's LDS leaves room for -- AF_FJ_WPE, worked out by flow_jit_spec_string:
+// BASELINE config 5's 20 KB per wave admit two waves per SIMD, and with the 256-register budget of two instead of the 128 of four
+// its kernel takes 189 instead of 207 ms, round 5)
+#ifndef AF_FJ_WPE
+#define AF_FJ_WPE (((AF_FJ_FEAT) & aff::FEAT_GENSRV) ? 3 : AF_FLOW_WPE)
+#endif
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AF_FJ_WPE))) af_flow_jit(const aff::FlowArgs a_in) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (blockIdx.x >= a_in.n_scen) return;
     aff::FlowArgs a = a_in;
@@ -1419,6 +1425,14 @@ std::string flow_jit_spec_string(const af_engine* e, const FlowPlan& P, const af
     // 50 000 replicas -- but NOT for the exponential law, whose variate is inline anyway: without the call site the compiler
     // allocates 72 instead of 110 VGPRs and the kernel is 6 % SLOWER (48.5 -> 51.6 ms on config 2), five waves per SIMD included)
     if (dist_all == AF_DIST_EXPONENTIAL || std::getenv("AF_FLOW_NO_DIST_CONST")) dist_all = 255u;
+    // waves per SIMD the LDS of this launch admits (160 KB per compute unit, four SIMDs): the register budget to compile for
+    uint32_t wpe = 4u;
+    if (const char* env = std::getenv("AF_FLOW_JIT_WPE")) wpe = (uint32_t)std::atoi(env);   // (measurement hook)
+    else {
+        const uint32_t lds_alloc = (P.lds + 511u) & ~511u, per_cu = lds_alloc ? (160u * 1024u) / lds_alloc : 16u;
+        wpe = (per_cu + 3u) / 4u;
+        wpe = wpe < 2u ? 2u : wpe > 4u ? 4u : wpe;
+    }
     char buf[2048];
     std::snprintf(buf, sizeof buf,
                   "-DAF_JIT=1 -DAF_FLOW_JIT=1 -DAF_FJ_IPL=%u -DAF_FJ_FEAT=%u -DAF_FJ_TOTAL_TIME=0x%llxull -DAF_FJ_PERIOD=0x%llxull "
@@ -1427,12 +1441,12 @@ std::string flow_jit_spec_string(const af_engine* e, const FlowPlan& P, const af
                   "-DAF_FJ_LC=%u -DAF_FJ_MAX_PRE=%u -DAF_FJ_MAX_CPU=%u -DAF_FJ_MAX_POST=%u -DAF_FJ_OFF_EDGE=%u -DAF_FJ_OFF_SRV=%u "
                   "-DAF_FJ_OFF_EP=%u -DAF_FJ_OFF_ROW=%u -DAF_FJ_OFF_EMARK=%u -DAF_FJ_OFF_SMARK=%u -DAF_FJ_OFF_LB=%u -DAF_FJ_BLOB_BYTES=%u "
                   "-DAF_FJ_N_TICKS=%u -DAF_FJ_HAS_CLOCK=%d -DAF_FJ_HAS_SAMPLES=%d -DAF_FJ_HAS_ONLINE=%d -DAF_FJ_HAS_OVR=%d -DAF_FJ_DIST_ALL=%u -DAF_FJ_RAM_SCALE=%.1f "
-                  "-DAF_FJ_N_LEVELS=%u -DAF_FJ_LAYOUT=%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u",
+                  "-DAF_FJ_N_LEVELS=%u -DAF_FJ_WPE=%u -DAF_FJ_LAYOUT=%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u",
                   P.ipl, P.feat | (std::getenv("AF_FLOW_PROF") ? (uint32_t)aff::FEAT_PROF : 0u), bits(f.total_time), bits(f.sample_period), bits(f.inv_period), bits(f.tick_eps), f.metrics_mask,
                   f.gen_out_edge, f.client_out_edge, f.n_edges, f.n_servers, f.has_lb, f.n_lb_edges, f.n_edge_marks, f.n_srv_marks,
                   f.lb_least_connections, f.max_pre, f.max_cpu, f.max_post, f.off_edge, f.off_srv, f.off_ep, f.off_row, f.off_emark,
                   f.off_smark, f.off_lb, f.blob_bytes, f.n_ticks, out->clock ? 1 : 0, out->samples ? 1 : 0,
-                  (out->online_hist || out->online_rps) ? 1 : 0, has_ovr ? 1 : 0, dist_all, f.ram_scale, e->flow_levels,
+                  (out->online_hist || out->online_rps) ? 1 : 0, has_ovr ? 1 : 0, dist_all, f.ram_scale, e->flow_levels, wpe,
                   L.cap, L.ring_rows, L.win_rows, L.g_ring, L.c_ring, L.pitch, L.list_arrays, L.off_spike, L.off_list, L.off_aux, L.off_aux3,
                   L.off_out, L.off_sorted, L.off_hist, L.off_seg, L.off_fr, L.off_gr, L.off_cnt, L.off_ring, L.n_words, L.cap_of[0],
                   L.cap_of[1], L.cap_of[2], L.cap_of[3], L.off_list_of[0], L.off_list_of[1], L.off_list_of[2], L.off_list_of[3], L.off_eb, L.off_gsrv);
@@ -2070,7 +2084,9 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
             for (uint32_t i = 0; i < nc; ++i) {
                 const uint32_t fl = cnt_host[(size_t)i * AF_CNT_SLOTS + AF_CNT_FLAGS];
                 if (!(fl & aff::FLAG_FLOW_FALLBACK)) continue;
-                if ((fl & aff::FLOW_WHY_RAM) || (flow_big && !FP.gen_compact)) rest.push_back(i);   // (flow_big: that WAS the most tolerant form)
+                // (flow_big: that WAS the most tolerant form; a tie the general server station gives up on stops the second chance at
+                // the same instant: straight to the next-event kernels)
+                if ((fl & (aff::FLOW_WHY_RAM | aff::FLOW_WHY_GEN_TIE)) || (flow_big && !FP.gen_compact)) rest.push_back(i);
                 else retry.push_back(i);
             }
             if (!retry.empty()) {
