@@ -100,6 +100,10 @@ if len(sys.argv) > 3:
                                f"{c_full:.2f} cycles full rate, {c_quarter:.2f} quarter rate), / kernel cycles.  SQ_ACTIVE_INST_VALU is a COUNT of "
                                "VALU instructions (1.000 per instruction in both calibration kernels), not busy time: rounds 3-4's 'x 4' priced "
                                "every instruction at 4 cycles")
+    # what binds: the VALU when it is busy most of the launch, else the waits the resident waves do not hide
+    bj["binding"] = ("valu_issue" if busy >= 0.6 else
+                     f"latency: {bj.get('wait_any_frac_of_wave_cycles', float('nan')):.0%} of the wave cycles in s_waitcnt (dependent LDS round trips) at "
+                     f"the occupancy the launch's LDS allows; VALU busy only {busy:.0%}")
     bp.write_text(json.dumps(bj, indent=1))
     res["valu_busy_frac_calibrated"] = busy
 print(json.dumps(res, indent=1))
