@@ -24,6 +24,7 @@ def test_engine_gather_through_the_c_abi_at_world_size_one():
     eng = Engine(res.plan, 0)
     comm = EngineComm(0, 1, 0)
     try:
+        assert comm.count() == (1, 0)          # ncclCommCount / ncclCommUserRank through af_comm_count (ABI 6)
         tensors = {k: summ[k] for k in ("stats", "rps", "hist", "series_mean", "series_max")}
         got = gather_engine_summaries(eng, comm, tensors, n_max=32)          # padded shard: 24 -> 32 rows
         assert eng.stats().gather_ms > 0.0
@@ -139,3 +140,34 @@ def test_bench_rank_rows_ride_in_the_one_gather(tmp_path):
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["gather_fallback"] is False and "af_engine_gather" in line["gather_path"] and line["gather_ms"] > 0.0
     assert line["config"]["scenarios_total"] == 256 and line["parity_spot_check"]["ok"] is True
+
+
+def test_the_bench_line_of_a_launched_rank_carries_what_rccl_says(tmp_path):
+    """`bench.py` as ONE launched rank (RANK / WORLD_SIZE in the environment, backend nccl): the path the driver's
+    `torch.distributed.run --nproc-per-node N` takes.  The JSON line must carry the rank count RCCL itself reports for the
+    communicator the gather ran on, and the per-rank kernel times."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               AF_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    root = Path(__file__).resolve().parent.parent
+    res = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--scenarios", "512",
+                          "--horizon", "60", "--no-cpu-baseline", "--no-diagnostics"], env=env, capture_output=True, text=True,
+                         timeout=900, check=False)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert res.returncode == 0 and lines, res.stderr[-2000:]
+    line = json.loads(lines[-1])
+    assert line.get("error") is None, line
+    assert line["n_gpus"] == 1 and line["world_size_launcher"] == 1 and line["rccl_ranks"] == 1 and not line["gather_fallback"]
+    pr = line["per_rank"]
+    assert pr["rccl_comm_count"] == [1] and pr["rccl_comm_user_rank"] == [0] and pr["scenarios"] == [512]
+    assert pr["flow_kernel_ms"][0] > 0.0 and abs(pr["flow_kernel_ms"][0] - line["flow_kernel_ms"]) < 1e-6
+    assert line["parity_spot_check"]["ok"] is True
