@@ -1455,6 +1455,9 @@ struct Flow {
     // The order in which this schedules new Timeouts IS their creation order, so later ties among them are exact too.
     enum : uint32_t { GM_STEP = 0u, GM_CPU_GOT = 1u, GM_CPU_GOT_W = 2u, GM_PUT_IO = 3u, GM_PUT_END = 4u, GM_RAM_PUT = 5u, GM_RAM_GOT = 6u };
     uint32_t gm_head, gm_n;
+#if defined(AF_FUSED_ARRIVAL_PROBE)
+    double probe_g = 0.0, probe_s = 0.0, probe_acc = 0.0;   // (measurement build only)
+#endif
     uint32_t gs_rounds;   // server-station rounds of this scenario: solved at once << 16 | walked event by event (CNT_MAX_LIVE of a FEAT_GENSRV run)
     AF_CORE void gm_push(AF_PLAN_AS uint64_t* g, uint32_t kind, uint32_t slot) {
         if (gm_n >= kGsMq) {
@@ -2285,6 +2288,31 @@ struct Flow {
                     const uint64_t vm = W::ballot(t0 < T && t0 < t_cap);   // arrival times increase: a prefix of the lanes
                     n_sel = popc64(vm);
                     key = t0;
+#if defined(AF_FUSED_ARRIVAL_PROBE)
+                    // MEASUREMENT ONLY: the work a generator station would do if it drew its own gaps
+                    // instead of reading af_arrival_groups' rows -- per lane the Philox block and the logarithm of draw cursor + lane
+                    // and the IEEE division by lambda; then the sampler's two running sums, which are 64 DEPENDENT f64 additions
+                    // (f64 addition does not associate: lane l needs gaps 0 .. l added one by one) -- WITHOUT the window bookkeeping a
+                    // real one needs on top (draws discarded at window ends, the users draw).  The results are thrown away (the
+                    // arrivals still come from HBM, so parity holds); only the kernel time is read.
+                    {
+                        const af::U4 pr = af::draw_block(seed, af::STREAM_GENERATOR, cursor + lane + 0x40000000u, 0u);
+                        double pu = af::u53(pr.x, pr.y);
+                        pu = pu < 1e-15 ? 1e-15 : pu;
+                        const double pe = -af::af_log_unit(1.0 - pu), pdt = pe / (133.25 + probe_g * 1e-300);
+                        double pg = probe_g, ps = probe_s, mine_s = 0.0;
+#pragma unroll 8
+                        for (uint32_t j = 0u; j < 64u; ++j) {
+                            const double d = bcast_f64(pdt, j);
+                            pg = pg + d;
+                            ps = ps + d;
+                            mine_s = lane == j ? ps : mine_s;
+                        }
+                        probe_g = pg;
+                        probe_s = ps;
+                        probe_acc += mine_s;
+                    }
+#endif
                 } else {
                     // (FEAT_CHAIN: what a level sends back into the server list takes the places its own selection left there,
                     // so the room that binds is the completion list's)
@@ -2555,6 +2583,9 @@ struct Flow {
             if (n_comp > A.clock_cap && clock != nullptr) flags |= af::FLAG_CLOCK_OVERFLOW;
             if (A.n_ticks > A.tick_cap && samples != nullptr) flags |= af::FLAG_TICK_OVERFLOW;
             if (why_all != 0u) flags |= FLAG_FLOW_FALLBACK | why_all;
+#if defined(AF_FUSED_ARRIVAL_PROBE)
+            if (probe_acc == 1.2345e300) flags |= 1u << 30;   // (keeps the probe's arithmetic alive)
+#endif
             uint32_t marks = 0u;
             for (uint32_t i = 0u; i < A.n_edge_marks; ++i) marks += u2d(emark(i)[0]) < T ? 1u : 0u;
             for (uint32_t i = 0u; i < A.n_srv_marks; ++i) marks += u2d(smark(i)[0]) < T ? 1u : 0u;
