@@ -1739,14 +1739,16 @@ struct Flow {
     // Everything at or after `limit` is tentative (later arrivals can get in front of it) and only has to stay at or after
     // `limit`: a walk stops at its first such time, which is the request's state for the next round -- exactly the state gen_servers()
     // keeps (pending step end / place in the core queue), so either form can run any round.
-    // What the solver does not decide it leaves to gen_servers(), BEFORE touching any state (return false): more than one core, a RAM
+    // With c cores the grant is max(r, the c-th LATEST release among the acquisitions that asked before r) -- the k-th request of a
+    // Container FIFO is granted when fewer than c of the k - 1 before it still hold a core; c <= kParCores.
+    // What the solver does not decide it leaves to gen_servers(), BEFORE touching any state (return false): more than four cores, a RAM
     // queue that is or could become non-empty, more than 64 requests in the window, step programs with more than kParBursts core
     // acquisitions or kParSteps steps ahead, and every instant at which the ORDER of two events of a server matters -- two CPU.get()
     // at one instant, two responses at one instant, two pending step ends at one instant (their creation order decides later
     // ties: gs_instant).  An event that merely coincides with another of the same server without competing for the core (a step end
     // at an arrival's instant, a release at a request's instant: the grant is at that instant either way, and the zero-length wait
     // it may be counted for ends before any tick sees it -- a tick AT the instant is flagged by tick_index) needs no order.
-    static constexpr uint32_t kParBursts = 2u, kParSteps = 24u, kParIters = 24u;
+    static constexpr uint32_t kParBursts = 2u, kParSteps = 24u, kParIters = 24u, kParCores = 4u;
     // 128 LDS words of the solver behind the servers' state (FlowLayout::off_gsrv; make_flow_layout)
     AF_CORE AF_PLAN_AS double* par_words() const { return (AF_PLAN_AS double*)(M + A.L.off_gsrv + A.n_servers * kGsWords); }
 #if defined(AF_PAR_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
@@ -1757,15 +1759,20 @@ struct Flow {
     AF_CORE bool gen_servers_par(uint32_t level, double limit, uint32_t& done_any) {
         AF_PLAN_AS uint32_t* lw = lbw();
         const uint32_t S = A.n_servers;
+#if defined(AF_PAR_OFF)
+        return false;   // (test / measurement hook: every round by the event-by-event walk)
+#endif
         // ---- lanes: per server of this pass its running requests, its core waiters, this round's arrivals
         uint32_t base = 0u, sv = 0u, role = 3u, idx = 0u, my_base = 0u, n_mine = 0u, blk_max = 0u;   // (blk_max: the largest server block, wave-uniform)
+        uint32_t cores_max = 1u;   // the widest server of this pass (wave-uniform)
         bool ok = true;
         for (uint32_t k = 0u; k < S; ++k) {
             if (kChain && level_of(k) != level) continue;
             const AF_PLAN_AS uint64_t* gk = gs(k);
             const uint32_t n_run = hi32(gk[GS_EV]), n_wait = hi32(gk[GS_CQ]), n_new = lw[LBW_SEG_LEN + k];
             const uint32_t cores = (uint32_t)blob[A.off_srv + af::SREC * k + 1u] & 0xFFFFu;
-            ok = ok && cores == 1u && hi32(gk[GS_RQ]) == 0u && hi32(gk[GS_ARR]) == 0u;
+            ok = ok && cores <= kParCores && hi32(gk[GS_RQ]) == 0u && hi32(gk[GS_ARR]) == 0u;
+            cores_max = cores > cores_max ? cores : cores_max;
             const uint32_t n_k = n_run + n_wait + n_new;
             blk_max = n_k > blk_max ? n_k : blk_max;
             if (lane >= base && lane < base + n_k) {
@@ -1833,8 +1840,8 @@ struct Flow {
             bool h = holds0, io = io0, alive = mine, pending = role == 0u, queued = role == 1u;
             n_ev = 0u;
             cls = 3u;
-            if (holds0) {   // (the acquisition I hold was granted in an earlier round: first in the order)
-                r[0] = -1000.0;
+            if (holds0) {   // (the acquisition I hold was granted in an earlier round: first in the order, the holders among themselves in ring order)
+                r[0] = -1000.0 - (double)idx;
                 nb = 1u;
             }
             if (commit && role == 2u && need > 0.0 && samples != nullptr) add_point(s0 + 2u, a_row, (int32_t)(need * A.ram_scale));
@@ -1960,7 +1967,30 @@ struct Flow {
             bool changed = false;
 #pragma unroll
             for (uint32_t b = 0u; b < kParBursts; ++b) {
-                const double found = (mine && r[b] < AF_INF && lt[b] > 0u) ? sorted_rel[e0 + lt[b] - 1u] : -AF_INF;
+                // one core: the acquisition in front of mine releases last of all before me.  c cores (Container FIFO: the k-th
+                // request is granted when fewer than c of the k - 1 before it still run): the c-th LATEST release among them
+                double found = (mine && r[b] < AF_INF && lt[b] > 0u) ? sorted_rel[e0 + lt[b] - 1u] : -AF_INF;
+                if (cores_max > 1u) {   // (wave-uniform)
+                    double top[kParCores];
+#pragma unroll
+                    for (uint32_t c = 0u; c < kParCores; ++c) top[c] = -AF_INF;
+                    const uint32_t n_before = (mine && r[b] < AF_INF) ? lt[b] : 0u;
+                    for (uint32_t i = 0u; i < kParBursts * blk_max; ++i) {
+                        double x = i < n_before ? sorted_rel[e0 + i] : -AF_INF;
+#pragma unroll
+                        for (uint32_t c = 0u; c < kParCores; ++c) {   // insertion into the descending top-c list
+                            const bool up = x > top[c];
+                            const double t2 = up ? top[c] : x;
+                            top[c] = up ? x : top[c];
+                            x = t2;
+                        }
+                    }
+                    const uint32_t my_cores = (uint32_t)blob[A.off_srv + af::SREC * sv + 1u] & 0xFFFFu;
+                    double kth = -AF_INF;
+#pragma unroll
+                    for (uint32_t c = 0u; c < kParCores; ++c) kth = c + 1u == my_cores ? top[c] : kth;
+                    found = my_cores > 1u ? kth : found;
+                }
                 // (what binds is max(r, G): a predecessor that released before I asked changes nothing)
                 const double was = G[b] > r[b] ? G[b] : r[b], now = found > r[b] ? found : r[b];
                 changed = changed || (r[b] < AF_INF && was != now);
@@ -2061,7 +2091,7 @@ struct Flow {
                     const uint32_t inside = n_run1 + n_wait1;
                     gk[GS_EV] = pack32(0u, n_run1);
                     gk[GS_CQ] = pack32(0u, n_wait1);
-                    gk[GS_CPU] = pack32(1u - holders, n_wait1);
+                    gk[GS_CPU] = pack32(((uint32_t)blob[A.off_srv + af::SREC * k + 1u] & 0xFFFFu) - holders, n_wait1);
                     gk[GS_IO] = pack32(in_io_k, inside >= 32u ? 0u : ~((1u << inside) - 1u));
                     gk[GS_RAM] = d2u(ram_now);
                     gk[GS_ARR] = pack32(lo32(gk[GS_ARR]) + arrivals_k, 0u);
