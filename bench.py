@@ -989,6 +989,10 @@ def main() -> int:  # noqa: C901, PLR0912, PLR0915
             },
         }
         attach_binding(line["roofline"], dom_ms, sw.n_slices, args, n, wl)
+        if isinstance(line["roofline"].get("binding"), dict) and line["roofline"]["binding"].get("resource"):
+            res_name = str(line["roofline"]["binding"]["resource"])
+            line["roofline"]["bound_actual"] = ("instruction issue: the VALU is busy most of the launch (`binding.frac`)" if res_name == "valu_issue"
+                                                else res_name) + "; see `binding`"
         if base is not None:
             line["cpu_baseline"] = base
         if parity is not None:
