@@ -234,6 +234,9 @@ class Engine:
             image = jit.code_object(spec.decode(), build=build)
         except jit.JitUnavailableError as exc:      # not an error: the generic kernels do the same job
             if not build:
+                # too short a sweep to wait for the compiler: it runs on the generic kernels, and the build goes on beside it
+                # for the next sweep of this shape (asyncflow_amd/jit.py::build_in_background)
+                jit.build_in_background(spec.decode())
                 return
             warnings.warn(f"plan-specialised kernels unavailable, using the generic ones: {exc}", RuntimeWarning,
                           stacklevel=3)

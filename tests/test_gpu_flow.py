@@ -860,3 +860,24 @@ def test_server_chains_of_four_and_five_levels_run_on_the_flow_kernel(depth, fan
     special = _runner(payload, seeds=seeds, specialise=True).run()
     assert special.engine_stats.specialised_launches >= 1
     _same_batches(res, special)
+
+
+def test_a_short_sweep_gets_its_specialised_kernel_from_the_second_run_on(tmp_path, monkeypatch):
+    """`specialise=None` (the default): a sweep too short to repay a hipcc run is simulated by the generic kernels while the
+    plan-specialised kernel is built on a background thread; the next sweep of the same shape loads it from the cache.
+    Identical results either way."""
+    from asyncflow_amd import jit
+
+    monkeypatch.setattr(jit, "CACHE_DIR", tmp_path)
+    monkeypatch.setattr(jit, "_background", {})
+    payload = lb_two_servers(horizon=45)
+    seeds = np.arange(64, dtype=np.uint64) + 4242
+    first = _runner(payload, seeds=seeds).run()
+    assert first.engine_stats.flow_scenarios == 64 and first.engine_stats.specialised_launches == 0
+    assert len(jit._background) == 1                                  # noqa: SLF001
+    for t in jit._background.values():                                # noqa: SLF001
+        t.join(timeout=180)
+        assert not t.is_alive()
+    second = _runner(payload, seeds=seeds).run()
+    assert second.engine_stats.specialised_launches >= 1 and second.engine_stats.jit_fallbacks == 0
+    _same_batches(first, second)

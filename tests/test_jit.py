@@ -55,6 +55,22 @@ def test_specialised_code_object_builds_caches_and_exports_the_three_entry_point
     assert other != image and len(list(tmp_path.glob("*.hsaco"))) == 2
 
 
+def test_a_short_sweep_leaves_the_build_to_a_background_thread(tmp_path, monkeypatch):
+    """A sweep too short to repay ~4 s of hipcc runs on the generic kernels and starts the build beside it: the next sweep of the
+    same shape finds the specialised kernel in the cache (round 5; the generic form of BASELINE config 2 costs 64 instead of 38 ms)."""
+    monkeypatch.setattr(jit, "CACHE_DIR", tmp_path)
+    monkeypatch.setattr(jit, "_background", {})
+    with pytest.raises(jit.JitUnavailableError, match="not in the cache"):
+        jit.code_object(LB2_FLOW_SPEC, build=False)
+    t = jit.build_in_background(LB2_FLOW_SPEC)
+    assert t is not None and jit.build_in_background(LB2_FLOW_SPEC) is t          # once per spec
+    t.join(timeout=120)
+    assert not t.is_alive()
+    assert jit.code_object(LB2_FLOW_SPEC, build=False).startswith(b"__CLANG_OFFLOAD_BUNDLE__")
+    monkeypatch.setenv("ASYNCFLOW_JIT_BACKGROUND", "0")
+    assert jit.build_in_background(LB2_FLOW_SPEC.replace("-DAF_FJ_IPL=1", "-DAF_FJ_IPL=2")) is None
+
+
 def test_a_failing_build_is_reported_as_unavailable_not_as_a_crash(tmp_path, monkeypatch):
     monkeypatch.setattr(jit, "CACHE_DIR", tmp_path)
     with pytest.raises(jit.JitUnavailableError, match="hipcc --genco failed"):
