@@ -103,6 +103,7 @@ def code_object(spec: str, build: bool = True) -> bytes:
 
 _background: dict[str, threading.Thread] = {}
 _background_lock = threading.Lock()
+_background_one_at_a_time = threading.Semaphore(1)      # background builds take turns: one compiler beside the simulation, not twenty
 
 
 def build_in_background(spec: str) -> threading.Thread | None:
@@ -121,10 +122,11 @@ def build_in_background(spec: str) -> threading.Thread | None:
             return t
 
         def work() -> None:
-            try:
-                code_object(spec, build=True)
-            except JitUnavailableError:
-                pass
+            with _background_one_at_a_time:
+                try:
+                    code_object(spec, build=True)
+                except JitUnavailableError:
+                    pass
 
         t = threading.Thread(target=work, name="asyncflow-jit", daemon=True)
         _background[spec] = t

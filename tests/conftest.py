@@ -14,6 +14,13 @@ if str(ROOT) not in sys.path:
 GOLDEN_DIR = ROOT / "tests" / "golden"
 
 
+# the suites run hundreds of short sweeps of unlike plans: no compiler thread behind each of them (the two tests of the
+# background build switch it on for themselves)
+import os  # noqa: E402
+
+os.environ.setdefault("ASYNCFLOW_JIT_BACKGROUND", "0")
+
+
 def pytest_configure(config: pytest.Config) -> None:
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "reference: needs /root/reference (build container only)")

@@ -870,6 +870,7 @@ def test_a_short_sweep_gets_its_specialised_kernel_from_the_second_run_on(tmp_pa
 
     monkeypatch.setattr(jit, "CACHE_DIR", tmp_path)
     monkeypatch.setattr(jit, "_background", {})
+    monkeypatch.setenv("ASYNCFLOW_JIT_BACKGROUND", "1")
     payload = lb_two_servers(horizon=45)
     seeds = np.arange(64, dtype=np.uint64) + 4242
     first = _runner(payload, seeds=seeds).run()

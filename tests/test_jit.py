@@ -60,6 +60,7 @@ def test_a_short_sweep_leaves_the_build_to_a_background_thread(tmp_path, monkeyp
     same shape finds the specialised kernel in the cache (round 5; the generic form of BASELINE config 2 costs 64 instead of 38 ms)."""
     monkeypatch.setattr(jit, "CACHE_DIR", tmp_path)
     monkeypatch.setattr(jit, "_background", {})
+    monkeypatch.setenv("ASYNCFLOW_JIT_BACKGROUND", "1")
     with pytest.raises(jit.JitUnavailableError, match="not in the cache"):
         jit.code_object(LB2_FLOW_SPEC, build=False)
     t = jit.build_in_background(LB2_FLOW_SPEC)
