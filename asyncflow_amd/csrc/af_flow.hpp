@@ -287,6 +287,7 @@ struct Flow {
     // horizon slots: 0..3 = the four lists' stations; FEAT_CHAIN: 4 .. 7 = the server station of levels 1 .. 4 (level 0 is slot 2)
     double h2b, h2c, h2d, h2e;
     uint32_t n_levels;           // FEAT_CHAIN: levels the plan's servers form (wave-uniform), else 1
+    uint32_t lb_pos, lb_in_edge; // FEAT_CHAIN: the LB station runs in front of the servers of this level (0: right behind the client); the edge it receives by
     AF_CORE static constexpr uint32_t level_slot(uint32_t level) { return level == 0u ? 2u : 3u + level; }
     // The generic FEAT_CHAIN instantiations walk the stations in a LOOP, so the slot is a run-time value there -- and a select
     // over eight members of this object makes the compiler address the object indirectly, which puts ALL of it (912 B per lane)
@@ -2232,6 +2233,13 @@ struct Flow {
                 for (uint32_t pass = 0u; pass + 1u < kMaxLevels; ++pass)
                     for (uint32_t v = 0u; v < A.n_servers; ++v) {
                         const uint64_t tw = erec((uint32_t)(blob[A.off_srv + af::SREC * v + 1u] >> 16) & 0xFFFFu)[3];
+                        if (((uint32_t)tw & 0xFFu) == af::NODE_LB) {   // (round 5) a server that feeds the LB: everything behind the LB is deeper
+                            for (uint32_t i = 0u; i < A.n_lb_edges; ++i) {
+                                const uint32_t w = (uint32_t)(erec((uint32_t)blob[A.off_lb + i])[3] >> 8) & 0xFFu;
+                                if (lv[w] < lv[v] + 1u) lv[w] = (uint8_t)(lv[v] + 1u);
+                            }
+                            continue;
+                        }
                         if (((uint32_t)tw & 0xFFu) != af::NODE_SERVER) continue;
                         const uint32_t w = (uint32_t)(tw >> 8) & 0xFFu;
                         if (lv[w] < lv[v] + 1u) lv[w] = (uint8_t)(lv[v] + 1u);
@@ -2268,7 +2276,21 @@ struct Flow {
         if (kChain)
             for (uint32_t v = 0u; v < A.n_servers; ++v) n_levels = level_of(v) + 1u > n_levels ? level_of(v) + 1u : n_levels;
         const uint32_t cap = kCt ? kCap : A.L.cap;
-        const uint32_t first_srv_stage = A.has_lb ? 1u : 2u;   // where the client's out-edge leads
+        // where the client's out-edge leads: the LB's list, or the servers' (round 5: also with an LB further down the path)
+        const uint32_t first_srv_stage = (A.has_lb && ((uint32_t)erec(A.client_out_edge)[3] & 0xFFu) == af::NODE_LB) ? 1u : 2u;
+        // FEAT_CHAIN, round 5: client -> server chain -> LB -> servers -> client.  The LB station then runs BEHIND the server levels in
+        // front of it: lb_pos = the level of the servers behind the LB (0: the client feeds the LB, the classic order); lb_in_edge = the
+        // one edge the LB receives by (graph.py:135-157 allows fan-out at the LB only, so the path in front of it is one chain)
+        lb_pos = 0u;
+        lb_in_edge = A.client_out_edge;
+        if (kChain && A.has_lb)
+            for (uint32_t v = 0u; v < A.n_servers; ++v) {
+                const uint32_t oe = (uint32_t)(blob[A.off_srv + af::SREC * v + 1u] >> 16) & 0xFFFFu;
+                if (((uint32_t)erec(oe)[3] & 0xFFu) == af::NODE_LB) {
+                    lb_pos = level_of(v) + 1u;
+                    lb_in_edge = oe;
+                }
+            }
 
         // Every round walks the five stations in order.  The code of select() and of edge_send() exists ONCE
         // (the loop is not unrolled): the kernel stays small enough for the instruction cache.
@@ -2288,6 +2310,13 @@ struct Flow {
             // unrolled body was 13 000 instructions and fell out of the instruction cache)
             // (FEAT_CHAIN: the server station once per level, in level order -- stx counts the passes, st is the station; a
             // plan-specialised build unrolls as many level passes as the plan has levels)
+            // (FEAT_CHAIN: behind generator and client come kLevelPasses + 1 slots -- the server levels in order with the LB station
+            // in front of level lb_pos --, then the client's second visit)
+#if defined(AF_FJ_LB_POS)
+            const uint32_t lbp = AF_FJ_LB_POS;
+#else
+            const uint32_t lbp = lb_pos;
+#endif
 #if defined(AF_FJ_N_LEVELS)
             constexpr uint32_t kLevelPasses = AF_FJ_N_LEVELS;
 #else
@@ -2299,8 +2328,9 @@ struct Flow {
 #pragma nounroll
 #endif
             for (uint32_t stx = 0u; stx < (kChain ? 4u + kLevelPasses : 5u); ++stx) {
-                const uint32_t st = !kChain ? stx : stx < 3u ? stx : stx < 3u + kLevelPasses ? 3u : 4u;
-                const uint32_t level = (kChain && st == 3u) ? stx - 3u : 0u;
+                const uint32_t slot = stx - 2u;   // (FEAT_CHAIN, stx >= 2)
+                const uint32_t st = !kChain ? stx : stx < 2u ? stx : stx == 3u + kLevelPasses ? 4u : slot == lbp ? 2u : 3u;
+                const uint32_t level = (kChain && st == 3u) ? (slot < lbp ? slot : slot - 1u) : 0u;
                 if (kChain && st == 3u && level >= n_levels) continue;
                 if (st == 2u && !A.has_lb) continue;
                 // ---- the station's batch: lane r < n_sel holds (key = event time, t0 = start time, aux)
@@ -2347,6 +2377,10 @@ struct Flow {
                     // (FEAT_CHAIN: what a level sends back into the server list takes the places its own selection left there,
                     // so the room that binds is the completion list's)
                     uint32_t room = st == 4u ? 64u : (kBig ? cap_of(nxt) : cap) - n_list_get(nxt);
+                    if (kChain && st == 3u && A.has_lb && level < lbp) {   // a level in front of the LB sends into the LB's list
+                        const uint32_t room1 = (kBig ? cap_of(1u) : cap) - nl1;
+                        room = room1 < room ? room1 : room;
+                    }
                     if (kGen && st == 3u) {
                         // the round-at-once solver (gen_servers_par) gives every request of the window a lane: the ones inside the
                         // servers of this pass and the arrivals taken now -- no more arrivals than lanes are left
@@ -2372,10 +2406,10 @@ struct Flow {
                 if (kFar && st > 0u) t0 = __builtin_fabs(t0);
                 uint32_t row = 0u;
                 if (kFar && series_on && have && (st <= 2u || cnt_in)) row = tick_index(key, true);
-                if (kFar && cnt_in) add_point(st == 1u ? A.gen_out_edge : st == 2u ? A.client_out_edge : st == 3u ? aux >> 8 : aux, row, -1);
+                if (kFar && cnt_in) add_point(st == 1u ? A.gen_out_edge : st == 2u ? (kChain ? lb_in_edge : A.client_out_edge) : st == 3u ? aux >> 8 : aux, row, -1);
                 // ---- what the station does with it: the out-edge, the message's index on it, the send time
                 prof(PROF_SERIES_RECV);
-                bool sending = have, pre = false, to_srv = false;   // to_srv (FEAT_CHAIN): my server's out-edge leads to a server
+                bool sending = have, pre = false, to_srv = false, to_lb = false;   // to_srv / to_lb (FEAT_CHAIN): my server's out-edge leads to a server / to the LB
                 uint32_t e = 0u, idx = 0u, tgt = 0u;
                 double ts = key, pre_tr = 0.0;
                 if (st == 0u) {
@@ -2446,7 +2480,7 @@ struct Flow {
                     uint32_t total = 0u;
                     for (uint32_t k = 0u; k < A.n_servers; ++k) total += dep_cnt(k);
                     // (wave-uniform; FEAT_CHAIN: a departure goes to the completion list or back into the server list)
-                    const bool too_many = total > cap_of(3u) - nl3 || (kChain && total > cap_of(2u) - nl2);
+                    const bool too_many = total > cap_of(3u) - nl3 || (kChain && total > cap_of(2u) - nl2) || (kChain && A.has_lb && total > cap_of(1u) - nl1);
                     if (too_many) why |= FLOW_WHY_LIST;
                     for (uint32_t base = 0u; base < total && !too_many; base += 64u) {
                         const uint32_t want = base + lane;   // my departure, counted over the servers in order
@@ -2473,10 +2507,11 @@ struct Flow {
                         prof(PROF_SEND_SERIES);
                         if (kChain) {   // to the client, or to a server of a deeper level (aux: the server | the edge the message comes by)
                             const uint64_t tw = erec(oe)[3];
-                            const bool dep_to_srv = ((uint32_t)tw & 0xFFu) == af::NODE_SERVER;
+                            const bool dep_to_srv = ((uint32_t)tw & 0xFFu) == af::NODE_SERVER, dep_to_lb = ((uint32_t)tw & 0xFFu) == af::NODE_LB;
                             const uint32_t dep_tgt = (uint32_t)(tw >> 8) & 0xFFu;
-                            append(3u, ok && !dep_to_srv, k2, (kFar && counted) ? -dt0 : dt0, oe, dts);
+                            append(3u, ok && !dep_to_srv && !dep_to_lb, k2, (kFar && counted) ? -dt0 : dt0, oe, dts);
                             append(2u, ok && dep_to_srv, k2, (kFar && counted) ? -dt0 : dt0, !kFar ? dep_tgt : dep_tgt | (oe << 8), dts);
+                            if (A.has_lb) append(1u, ok && dep_to_lb, k2, (kFar && counted) ? -dt0 : dt0, 0u, dts);
                         } else {
                             append(3u, ok, k2, (kFar && counted) ? -dt0 : dt0, oe, dts);
                         }
@@ -2511,6 +2546,7 @@ struct Flow {
                             if (kChain) {
                                 const uint64_t tw = erec(e)[3];
                                 to_srv = ((uint32_t)tw & 0xFFu) == af::NODE_SERVER;
+                                to_lb = ((uint32_t)tw & 0xFFu) == af::NODE_LB;
                                 tgt = (uint32_t)(tw >> 8) & 0xFFu;
                             }
                             const uint32_t ep = (uint32_t)(meta >> 32) & 0xFFFFu;
@@ -2566,8 +2602,9 @@ struct Flow {
                     prof(PROF_SEND_SERIES);
                     // (server list: the server and the edge the message comes by; completion list: the server's out-edge)
                     if (kChain && st == 3u) {   // lane by lane: to the client, or to a server of a deeper level
-                        append(3u, ok && !to_srv, k2, (kFar && counted) ? -t0 : t0, e, ts);
+                        append(3u, ok && !to_srv && !to_lb, k2, (kFar && counted) ? -t0 : t0, e, ts);
                         append(2u, ok && to_srv, k2, (kFar && counted) ? -t0 : t0, !kFar ? tgt : tgt | (e << 8), ts);
+                        if (A.has_lb) append(1u, ok && to_lb, k2, (kFar && counted) ? -t0 : t0, 0u, ts);
                         // what the deeper levels (and the client) may touch: everything the station in front of the servers AND
                         // every level so far delivered before it (the cache of send_floor belongs to level 0's horizon)
                         const double fl = send_floor(3u, H_get(level_slot(level)), level == 0u);

@@ -30,22 +30,31 @@ inline bool flow_needs_general_servers(const af_plan_t& p) {
 }
 
 // Servers that feed servers (FEAT_CHAIN, round 4): level 0 = fed by the client / the load balancer only, level k = its deepest
-// feeding server is of level k - 1.  Returns the number of levels (1: no server feeds a server), 0 when the servers feed each
-// other in a cycle; `level` (may be null) gets each server's level.  (Flow::run works the same levels out on the device.)
+// feeding server is of level k - 1.  Round 5: a server may feed the LOAD BALANCER (client -> server chain -> LB -> servers ->
+// client): every server behind the LB is then deeper than that server.  Returns the number of levels (1: no server feeds a server),
+// 0 when the servers feed each other in a cycle; `level` (may be null) gets each server's level.  (Flow::run works the same levels
+// out on the device.)
 inline uint32_t flow_server_levels(const af_plan_t& p, uint32_t* level) {
     std::vector<uint32_t> lv(p.n_servers, 0u);
     uint32_t deepest = 0u;
+    auto raise = [&](uint32_t w, uint32_t to, bool& changed) {
+        if (lv[w] < to) {
+            lv[w] = to;
+            changed = true;
+            deepest = lv[w] > deepest ? lv[w] : deepest;
+        }
+    };
     for (uint32_t pass = 0; pass <= p.n_servers; ++pass) {
         bool changed = false;
         for (uint32_t s = 0; s < p.n_servers; ++s) {
             const int32_t e = p.srv_out_edge[s];
-            if (p.edge_target_kind[e] != AF_NODE_SERVER) continue;
-            const uint32_t w = (uint32_t)p.edge_target_idx[e];
-            if (lv[w] < lv[s] + 1u) {
-                lv[w] = lv[s] + 1u;
-                changed = true;
-                deepest = lv[w] > deepest ? lv[w] : deepest;
+            if (p.edge_target_kind[e] == AF_NODE_LB) {
+                for (uint32_t i = 0; i < p.n_lb_edges; ++i)
+                    if (p.edge_target_kind[p.lb_edges[i]] == AF_NODE_SERVER) raise((uint32_t)p.edge_target_idx[p.lb_edges[i]], lv[s] + 1u, changed);
+                continue;
             }
+            if (p.edge_target_kind[e] != AF_NODE_SERVER) continue;
+            raise((uint32_t)p.edge_target_idx[e], lv[s] + 1u, changed);
         }
         if (!changed) break;
         if (pass == p.n_servers) return 0u;   // still growing after n_servers passes: a cycle
@@ -55,9 +64,21 @@ inline uint32_t flow_server_levels(const af_plan_t& p, uint32_t* level) {
     return deepest + 1u;
 }
 inline bool flow_needs_chain(const af_plan_t& p) {
-    for (uint32_t s = 0; s < p.n_servers; ++s)
-        if (p.edge_target_kind[p.srv_out_edge[s]] == AF_NODE_SERVER) return true;
+    for (uint32_t s = 0; s < p.n_servers; ++s) {
+        const uint32_t k = p.edge_target_kind[p.srv_out_edge[s]];
+        if (k == AF_NODE_SERVER || k == AF_NODE_LB) return true;
+    }
     return false;
+}
+// the level of the servers behind the LB (Flow::lb_pos): 0 when the client feeds the LB, else 1 + the level of the server that does
+inline uint32_t flow_lb_position(const af_plan_t& p) {
+    if (!p.has_lb) return 0u;
+    std::vector<uint32_t> lv(p.n_servers, 0u);
+    if (flow_server_levels(p, lv.data()) == 0u) return 0u;
+    uint32_t pos = 0u;
+    for (uint32_t s = 0; s < p.n_servers; ++s)
+        if (p.edge_target_kind[p.srv_out_edge[s]] == AF_NODE_LB) pos = lv[s] + 1u;
+    return pos;
 }
 
 // Empty string: the plan's request path is the feed-forward chain the flow kernel implements.
@@ -69,8 +90,12 @@ inline std::string flow_ineligible_reason(const af_plan_t& p) {
     if (p.n_edges + 3u * p.n_servers > 128u) return "more than 128 sampled series";   // (a lane carries two series: flush_ticks)
     if (p.edge_target_kind[p.gen_out_edge] != AF_NODE_CLIENT) return "generator does not feed the client";
     const uint32_t ck = p.edge_target_kind[p.client_out_edge];
+    uint32_t feeds_lb = 0u;   // servers whose out-edge leads to the load balancer
+    for (uint32_t s = 0; s < p.n_servers; ++s) feeds_lb += p.edge_target_kind[p.srv_out_edge[s]] == AF_NODE_LB ? 1u : 0u;
     if (p.has_lb) {
-        if (ck != AF_NODE_LB) return "client does not feed the load balancer";
+        // (round 5) client -> LB, or client -> server chain -> LB: exactly one edge leads into the load balancer
+        if (ck == AF_NODE_LB && feeds_lb != 0u) return "the client and a server both feed the load balancer";
+        if (ck != AF_NODE_LB && (ck != AF_NODE_SERVER || feeds_lb != 1u)) return "neither the client nor exactly one server feeds the load balancer";
         if (p.n_lb_edges == 0 || p.n_lb_edges > 16u) return "load balancer fan-out outside 1..16";
         if (p.lb_algo == AF_LB_LEAST_CONNECTIONS && (p.n_lb_edges > kMaxServers || p.n_servers > kMaxServers)) return "least-connections fan-out above 8";
         for (uint32_t i = 0; i < p.n_lb_edges; ++i)
@@ -84,7 +109,7 @@ inline std::string flow_ineligible_reason(const af_plan_t& p) {
     // room: rate x 1 s messages wait at a station -- plan_flow sizes the lists for it, an overflow is handed back.
     // 150 fuzzed payloads with 1-3 Poisson edges on the wave emulator: 0 mismatches, 1 tie: tests/test_flow_hostcheck.py.)
     for (uint32_t s = 0; s < p.n_servers; ++s) {
-        if (p.edge_target_kind[p.srv_out_edge[s]] == AF_NODE_LB) return "a server feeds the load balancer";
+        if (p.edge_target_kind[p.srv_out_edge[s]] == AF_NODE_LB && !p.has_lb) return "a server feeds a load balancer the plan does not have";
         if (p.srv_cores[s] > 64u) return "more than 64 cores";
         // (the tick ring holds integer differences: RAM needs in whole MB, or in multiples of 1/256 MB -- flow_ram_scale)
         for (uint32_t ep = p.srv_ep_begin[s]; ep < p.srv_ep_begin[s + 1]; ++ep) {

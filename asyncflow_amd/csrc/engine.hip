@@ -909,6 +909,7 @@ struct af_engine {
     size_t codes_bytes = 0;
     bool flow_ok = false, flow_general_servers = false, flow_chain = false;   // flow_chain: servers feed servers (FEAT_CHAIN)
     uint32_t flow_levels = 1u;   // levels the servers form (1: no server feeds a server)
+    uint32_t flow_lb_pos = 0u;   // the LB station runs in front of the servers of this level (0: right behind the client)
     std::string flow_reason;
     uint32_t flow_mode = 0, flow_list_entries = 0, flow_ring_rows = 0;
     aff::FlowArgs fargs{};
@@ -1441,12 +1442,12 @@ std::string flow_jit_spec_string(const af_engine* e, const FlowPlan& P, const af
                   "-DAF_FJ_LC=%u -DAF_FJ_MAX_PRE=%u -DAF_FJ_MAX_CPU=%u -DAF_FJ_MAX_POST=%u -DAF_FJ_OFF_EDGE=%u -DAF_FJ_OFF_SRV=%u "
                   "-DAF_FJ_OFF_EP=%u -DAF_FJ_OFF_ROW=%u -DAF_FJ_OFF_EMARK=%u -DAF_FJ_OFF_SMARK=%u -DAF_FJ_OFF_LB=%u -DAF_FJ_BLOB_BYTES=%u "
                   "-DAF_FJ_N_TICKS=%u -DAF_FJ_HAS_CLOCK=%d -DAF_FJ_HAS_SAMPLES=%d -DAF_FJ_HAS_ONLINE=%d -DAF_FJ_HAS_OVR=%d -DAF_FJ_DIST_ALL=%u -DAF_FJ_RAM_SCALE=%.1f "
-                  "-DAF_FJ_N_LEVELS=%u -DAF_FJ_WPE=%u -DAF_FJ_LAYOUT=%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u",
+                  "-DAF_FJ_N_LEVELS=%u -DAF_FJ_LB_POS=%u -DAF_FJ_WPE=%u -DAF_FJ_LAYOUT=%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u,%u",
                   P.ipl, P.feat | (std::getenv("AF_FLOW_PROF") ? (uint32_t)aff::FEAT_PROF : 0u), bits(f.total_time), bits(f.sample_period), bits(f.inv_period), bits(f.tick_eps), f.metrics_mask,
                   f.gen_out_edge, f.client_out_edge, f.n_edges, f.n_servers, f.has_lb, f.n_lb_edges, f.n_edge_marks, f.n_srv_marks,
                   f.lb_least_connections, f.max_pre, f.max_cpu, f.max_post, f.off_edge, f.off_srv, f.off_ep, f.off_row, f.off_emark,
                   f.off_smark, f.off_lb, f.blob_bytes, f.n_ticks, out->clock ? 1 : 0, out->samples ? 1 : 0,
-                  (out->online_hist || out->online_rps) ? 1 : 0, has_ovr ? 1 : 0, dist_all, f.ram_scale, e->flow_levels, wpe,
+                  (out->online_hist || out->online_rps) ? 1 : 0, has_ovr ? 1 : 0, dist_all, f.ram_scale, e->flow_levels, e->flow_lb_pos, wpe,
                   L.cap, L.ring_rows, L.win_rows, L.g_ring, L.c_ring, L.pitch, L.list_arrays, L.off_spike, L.off_list, L.off_aux, L.off_aux3,
                   L.off_out, L.off_sorted, L.off_hist, L.off_seg, L.off_fr, L.off_gr, L.off_cnt, L.off_ring, L.n_words, L.cap_of[0],
                   L.cap_of[1], L.cap_of[2], L.cap_of[3], L.off_list_of[0], L.off_list_of[1], L.off_list_of[2], L.off_list_of[3], L.off_eb, L.off_gsrv);
@@ -1566,6 +1567,7 @@ int af_engine_create(const af_plan_t* plan, int device, const af_engine_options_
     e->flow_general_servers = e->flow_ok && aff::flow_needs_general_servers(*plan);
     e->flow_chain = e->flow_ok && aff::flow_needs_chain(*plan);
     e->flow_levels = e->flow_chain ? aff::flow_server_levels(*plan, nullptr) : 1u;
+    e->flow_lb_pos = e->flow_chain ? aff::flow_lb_position(*plan) : 0u;
     e->has_lb = plan->has_lb;
     e->gen_edge = plan->gen_out_edge;
     e->client_edge = plan->client_out_edge;

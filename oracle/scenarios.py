@@ -373,6 +373,49 @@ def deep_chain(depth: int = 5, users: float = 120, horizon: int = 30, fan: bool 
     }
 
 
+def gateway_lb(front: int = 1, algo: str = "round_robin", users: float = 150, horizon: int = 30, general: bool = False,
+               backend: bool = False, spike: bool = False) -> dict:
+    """client -> gw1 [-> gw2 ...] -> LB -> {a, b, c} [-> one shared backend] -> client: servers IN FRONT of the load balancer
+    (graph.py:135-157 gives every server one out-edge and the LB alone a fan-out, so what leads into the LB is one chain).
+    `general`: the servers behind the LB have two endpoints (one comes back to the core after I/O)."""
+    servers, edges = [], [_edge("g-c", "gen", "cli", 0.003)]
+    prev = "cli"
+    for k in range(front):
+        name = f"gw{k}"
+        servers.append(_server(name, 2, 1024, [_endpoint("/gw", [("initial_parsing", 0.0008 + 0.0002 * k), ("ram", 16), ("io_wait", 0.002)])]))
+        edges.append(_edge(f"{prev}-{name}", prev, name, 0.002, "normal" if k == 1 else "exponential", 0.0005 if k == 1 else None))
+        prev = name
+    edges.append(_edge(f"{prev}-lb", prev, "lb", 0.0015))
+    behind = ["a", "b", "c"]
+    for i, name in enumerate(behind):
+        eps = [_endpoint("/api", [("initial_parsing", 0.002 + 0.0005 * i), ("ram", 128), ("io_wait", 0.012)])]
+        if general:
+            eps.append(_endpoint("/report", [("io_db", 0.004), ("ram", 64), ("cpu_bound_operation", 0.0015), ("io_wait", 0.006),
+                                             ("cpu_bound_operation", 0.0005)]))
+        servers.append(_server(name, 1 + i % 2, 2048, eps))
+        edges.append(_edge(f"lb-{name}", "lb", name, 0.002 + 0.0005 * i, dropout=0.01))
+        edges.append(_edge(f"{name}-out", name, "be" if backend else "cli", 0.003))
+    if backend:
+        servers.append(_server("be", 2, 4096, [_endpoint("/db", [("cpu_bound_operation", 0.001), ("ram", 32), ("io_db", 0.005)])]))
+        edges.append(_edge("be-c", "be", "cli", 0.003))
+    p = {
+        "rqs_input": {"id": "gen", "avg_active_users": {"mean": users}, "avg_request_per_minute_per_user": {"mean": 60},
+                      "user_sampling_window": 10},
+        "topology_graph": {"nodes": {"client": {"id": "cli"}, "servers": servers,
+                                     "load_balancer": {"id": "lb", "algorithms": algo, "server_covered": behind}},
+                           "edges": edges},
+        "sim_settings": {"total_simulation_time": horizon, "sample_period_s": 0.05},
+    }
+    if spike:
+        p["events"] = [
+            {"event_id": "sp", "target_id": f"{prev}-lb", "start": {"kind": "network_spike_start", "t_start": 0.2 * horizon, "spike_s": 0.03},
+             "end": {"kind": "network_spike_end", "t_end": 0.5 * horizon}},
+            {"event_id": "down", "target_id": "b", "start": {"kind": "server_down", "t_start": 0.3 * horizon},
+             "end": {"kind": "server_up", "t_end": 0.7 * horizon}},
+        ]
+    return p
+
+
 def shared_backend(users: float = 200, horizon: int = 120) -> dict:
     """client -> LB -> {a1, a2} -> b (a backend both front servers call) -> client: the deterministic server-tier payload of
     the server-tier measurements (scripts/gpu_chain.py)."""

@@ -24,7 +24,7 @@ from asyncflow_amd import _abi
 from asyncflow_amd.plan import lower
 from asyncflow_amd.workloads import fanout8, lb_two_servers, lb_with_events, single_server, single_server_with_spike
 from oracle import oracle_lib as ol
-from oracle.scenarios import deep_chain, flow_payload, server_chain, server_tiers, stress_mixed, wide_fanout
+from oracle.scenarios import deep_chain, flow_payload, gateway_lb, server_chain, server_tiers, stress_mixed, wide_fanout
 from tests.conftest import GOLDEN_DIR
 from tests.hostcheck import build as hc
 
@@ -116,13 +116,11 @@ def test_small_lists_hand_the_scenario_back_instead_of_dropping_messages():
 def test_plans_outside_the_feed_forward_range_are_refused():
     odd_ram = lb_two_servers(horizon=10)
     odd_ram["topology_graph"]["nodes"]["servers"][0]["endpoints"][0]["steps"][1]["step_operation"]["necessary_ram"] = 100.1
-    feeds_lb = server_chain("exponential", 0.003)          # (servers feeding servers are in range since round 4; a server feeding the LB is not)
-    feeds_lb["topology_graph"]["nodes"]["load_balancer"] = {"id": "lb", "algorithms": "round_robin", "server_covered": ["s1"]}
-    for e in feeds_lb["topology_graph"]["edges"]:
-        if e["source"] == "s0" and e["target"] == "s1":
-            e["target"] = "lb"
-    feeds_lb["topology_graph"]["edges"].append({"id": "lb-s1", "source": "lb", "target": "s1", "latency": {"mean": 0.003, "distribution": "exponential"}})
-    for payload, word in ((odd_ram, "1/256 MB"), (wide_fanout(horizon=12), "16 servers"), (feeds_lb, "load balancer")):
+    # (servers feeding servers are in range since round 4, a server chain in front of the LB since round 5; the client AND a server
+    # feeding the LB is not)
+    feeds_lb = gateway_lb(front=1, horizon=10)
+    feeds_lb["topology_graph"]["edges"][1]["target"] = "lb"
+    for payload, word in ((odd_ram, "1/256 MB"), (wide_fanout(horizon=12), "16 servers"), (feeds_lb, "both feed the load balancer")):
         assert hc.flow_simulate(lower(payload), 1) is None
         assert word in hc.flow_reason()
 
@@ -350,6 +348,25 @@ def test_server_chains_of_four_and_five_levels(depth, fan):
             assert status == "exact", (depth, fan, seed, kw, why)
     if depth == 5 and fan:
         assert hc.flow_simulate(lower(deep_chain(6, horizon=10)), 1) is None and "deeper than five levels" in hc.flow_reason()
+
+
+@pytest.mark.parametrize("kw", [dict(front=1), dict(front=2, backend=True), dict(front=1, algo="least_connection", spike=True),
+                                dict(front=1, general=True), dict(front=2, general=True, backend=True, spike=True)],
+                         ids=["gateway", "two-gateways-backend", "least-connections-events", "general", "general-backend-events"])
+def test_servers_in_front_of_the_load_balancer(kw):
+    """Round 5 (`graph.py:135-157`): client -> server chain -> LB -> servers [-> backend] -> client.  The LB station
+    runs BEHIND the server levels in front of it (Flow::lb_pos), the front servers' responses go into the LB's list, everything behind
+    the LB is deeper than what feeds it; tandem and general servers, round robin and least connections, a spike on the edge into the LB
+    and an outage behind it.  Exact in the lean and in the second-chance form; the client AND a server feeding the LB is refused."""
+    payload = gateway_lb(users=150, horizon=15, **kw)
+    for seed in (5, 6):
+        for form in (dict(ipl=2, ring_rows=64), dict(ipl=1, ring_rows=0, robust=True, long_list_entries=512)):
+            status, why = _run(payload, seed, **form)
+            assert status == "exact", (kw, seed, form, why)
+    if kw == dict(front=1):
+        both = gateway_lb(front=1, horizon=10)
+        both["topology_graph"]["edges"][1]["target"] = "lb"          # cli -> lb as well as gw0 -> lb
+        assert hc.flow_simulate(lower(both), 1) is None and "both feed the load balancer" in hc.flow_reason()
 
 
 def test_general_servers_several_endpoints_and_core_re_entry():

@@ -882,3 +882,25 @@ def test_a_short_sweep_gets_its_specialised_kernel_from_the_second_run_on(tmp_pa
     second = _runner(payload, seeds=seeds).run()
     assert second.engine_stats.specialised_launches >= 1 and second.engine_stats.jit_fallbacks == 0
     _same_batches(first, second)
+
+
+@pytest.mark.parametrize("kw", [dict(front=1), dict(front=2, backend=True, spike=True), dict(front=1, algo="least_connection"),
+                                dict(front=2, general=True, backend=True)],
+                         ids=["gateway", "two-gateways-backend-events", "least-connections", "general-backend"])
+def test_servers_in_front_of_the_load_balancer_run_on_the_flow_kernel(kw):
+    """Round 5: client -> server chain -> LB -> servers [-> backend] -> client on the stage-parallel kernel (the
+    LB station behind the levels in front of it), generic and plan-specialised builds (`AF_FJ_LB_POS`), against the next-event
+    kernels and the oracle."""
+    from oracle.scenarios import gateway_lb
+
+    payload = gateway_lb(users=150, horizon=30, **kw)
+    seeds = np.arange(32, dtype=np.uint64) + 77
+    res = _runner(payload, seeds=seeds, specialise=False).run()
+    assert res.flow_reason == "" and res.engine_stats.flow_scenarios == 32 and res.engine_stats.flow_to_next_event <= 2, res.flow_reason
+    plan = lower(payload)
+    for i in (0, 31):
+        _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])), f"{kw} scenario {i}")
+    _same_batches(res, _runner(payload, seeds=seeds, flow=False).run())
+    special = _runner(payload, seeds=seeds, specialise=True).run()
+    assert special.engine_stats.specialised_launches >= 1
+    _same_batches(res, special)

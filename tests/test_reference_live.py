@@ -201,3 +201,12 @@ def test_reference_delays_a_response_whose_ram_put_fails_by_one_rounding_and_the
     assert ref.clock[1, 1] == res.clock[1, 1]                  # srv-2 (64.7 MB: the subtraction happens to round the other way)
     _same(dyadic, 21)
     assert not int(ol.simulate(lower(dyadic), 21).counts[_abi.CNT_FLAGS]) & _abi.FLAG_RAM_PUT_BLOCKED
+
+
+@pytest.mark.parametrize("kw", [dict(front=1), dict(front=2, algo="least_connection", backend=True, spike=True), dict(front=1, general=True)])
+def test_gateway_in_front_of_the_load_balancer_matches_reference(kw):
+    """client -> server chain -> LB -> servers [-> backend] -> client (`graph.py:100-159` validates it): the oracle against the live
+    reference, bit for bit -- the topology the stage-parallel kernel took in in round 5."""
+    from oracle.scenarios import gateway_lb
+
+    _same(gateway_lb(horizon=12, **kw), 5)
