@@ -1,4 +1,5 @@
-"""GPU fuzz of the round-4 additions to the stage-parallel kernel (FEAT_CHAIN, FEAT_GENSRV with shared instants, both together):
+"""GPU fuzz of the round-4 / round-5 additions to the stage-parallel kernel (FEAT_CHAIN, FEAT_GENSRV with shared instants and the
+round-at-once solver, both together; servers in front of the LB, deeper tiers, wider fan-outs):
 every scenario of every payload against the next-event kernels (counts, every (start, finish) pair, every sample) and two of
 them against the oracle.  Prints one JSON line of tallies (profiles/r04/gpu_fuzz_f3.json).  A mismatch raises."""
 import json
@@ -13,10 +14,33 @@ from asyncflow_amd import _abi  # noqa: E402
 from asyncflow_amd.plan import lower  # noqa: E402
 from asyncflow_amd.runner import SimulationRunner  # noqa: E402
 from oracle import oracle_lib as ol  # noqa: E402
-from oracle.scenarios import random_payload, server_tiers, tie_storm  # noqa: E402
+from oracle.scenarios import deep_chain, gateway_lb, random_payload, server_tiers, tie_storm, wide_fanout  # noqa: E402
 
 n_payloads = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+def _gateway(k: int) -> dict:
+    rng = random.Random(99000 + k)
+    return gateway_lb(front=rng.choice((1, 2)), algo=rng.choice(("round_robin", "least_connection")), users=rng.choice((60, 150, 300)),
+                      horizon=10, general=rng.random() < 0.4, backend=rng.random() < 0.5, spike=rng.random() < 0.5)
+
+
+def _deep(k: int) -> dict:
+    rng = random.Random(99500 + k)
+    return deep_chain(rng.choice((4, 5)), users=rng.choice((60, 150)), horizon=10, fan=rng.random() < 0.6)
+
+
+def _wide(k: int) -> dict:
+    rng = random.Random(99700 + k)
+    p = wide_fanout(rng.choice((13, 14, 16)), "round_robin", horizon=8, users=rng.choice((60, 100)))
+    for s in p["topology_graph"]["nodes"]["servers"]:
+        s["endpoints"] = s["endpoints"][:1]
+    return p
+
+
 families = {
+    # round 5: servers in front of the LB, four / five server levels, 13 .. 16 servers behind a round-robin LB
+    "servers in front of the LB": _gateway,
+    "four / five server levels": _deep,
+    "13 .. 16 servers behind a round-robin LB": _wide,
     "server tiers (tandem)": lambda k: server_tiers(random.Random(95000 + k), horizon=12),
     "server tiers (general servers)": lambda k: server_tiers(random.Random(96000 + k), horizon=12, general=True),
     "random topologies (general servers)": lambda k: random_payload(random.Random(97000 + k), horizon=8),
