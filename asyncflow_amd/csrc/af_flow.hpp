@@ -2276,8 +2276,6 @@ struct Flow {
         if (kChain)
             for (uint32_t v = 0u; v < A.n_servers; ++v) n_levels = level_of(v) + 1u > n_levels ? level_of(v) + 1u : n_levels;
         const uint32_t cap = kCt ? kCap : A.L.cap;
-        // where the client's out-edge leads: the LB's list, or the servers' (round 5: also with an LB further down the path)
-        const uint32_t first_srv_stage = (A.has_lb && ((uint32_t)erec(A.client_out_edge)[3] & 0xFFu) == af::NODE_LB) ? 1u : 2u;
         // FEAT_CHAIN, round 5: client -> server chain -> LB -> servers -> client.  The LB station then runs BEHIND the server levels in
         // front of it: lb_pos = the level of the servers behind the LB (0: the client feeds the LB, the classic order); lb_in_edge = the
         // one edge the LB receives by (graph.py:135-157 allows fan-out at the LB only, so the path in front of it is one chain)
@@ -2291,6 +2289,15 @@ struct Flow {
                     lb_in_edge = oe;
                 }
             }
+        // where the client's out-edge leads: the LB's list, or the servers' (round 5: also with an LB further down the path -- only the
+        // FEAT_CHAIN forms run such plans, so everywhere else this stays the constant it was: a RUN-TIME list index makes the
+        // long-list forms index FlowLayout::cap_of[] dynamically, which put the launch arguments in scratch memory and cost the
+        // general-server workload 60 %, measured)
+#if defined(AF_FJ_LB_POS)
+        const uint32_t first_srv_stage = !A.has_lb ? 2u : (kChain && AF_FJ_LB_POS != 0u) ? 2u : 1u;
+#else
+        const uint32_t first_srv_stage = !A.has_lb ? 2u : (kChain && lb_pos != 0u) ? 2u : 1u;
+#endif
 
         // Every round walks the five stations in order.  The code of select() and of edge_send() exists ONCE
         // (the loop is not unrolled): the kernel stays small enough for the instruction cache.

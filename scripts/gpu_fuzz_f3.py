@@ -30,7 +30,7 @@ def _deep(k: int) -> dict:
 
 def _wide(k: int) -> dict:
     rng = random.Random(99700 + k)
-    p = wide_fanout(rng.choice((13, 14, 16)), "round_robin", horizon=8, users=rng.choice((60, 100)))
+    p = wide_fanout(rng.choice((13, 14, 16)), "round_robin", horizon=12, users=rng.choice((60, 100)))   # (its events reach to 9.5 s)
     for s in p["topology_graph"]["nodes"]["servers"]:
         s["endpoints"] = s["endpoints"][:1]
     return p

@@ -153,3 +153,36 @@ def test_prebuild_fills_the_cache_for_every_default_bench_line(tmp_path, monkeyp
     assert jit.code_object(specs[0]).startswith(b"__CLANG_OFFLOAD_BUNDLE__")     # a cache hit needs no compiler
     with pytest.raises(jit.JitUnavailableError, match="ASYNCFLOW_NO_HIPCC"):
         jit.code_object(specs[0].replace("-DAF_FJ_IPL=1", "-DAF_FJ_IPL=2"))
+
+
+@pytest.mark.parametrize("config", [2, 6])
+def test_the_bench_kernels_keep_their_state_out_of_scratch_memory(config, tmp_path):
+    """A run-time index into a member array of the kernel's argument / state objects makes the compiler address the whole object
+    indirectly, i.e. keep it in scratch memory (round 5 met it twice: the generic server tiers at 437 instead of 102 ms, and the
+    general-server workload at 441 instead of 279 ms when the client's target list became a run-time value).  The plan-specialised
+    kernels of the bench's workloads must stay within a few call frames' worth of scratch: `-Rpass-analysis=kernel-resource-usage`."""
+    import re
+    import shlex
+    import subprocess
+
+    import numpy as np
+
+    import bench
+    from asyncflow_amd.build import CSRC, hipcc_path
+    from asyncflow_amd.engine import PLAN_ONLY, Engine
+
+    args = bench.make_parser().parse_args(["--config", str(config)])
+    args.horizon = None
+    shape = bench.rank_shape(bench.build_workload(config, 0, 1, 0, None), args)
+    eng = Engine(shape["plan"], PLAN_ONLY, **shape["engine_kw"])
+    over = [(c, i, np.ascontiguousarray(v[: shape["slice"]])) for c, i, v, _ in shape["over"]]
+    spec = eng.jit_spec(shape["seeds"][: shape["slice"]], over, clock_ptr=8, clock_capacity=shape["clock_cap"], samples_ptr=8,
+                        tick_capacity=shape["ticks"], counts_ptr=8, draw_capacity=shape["clock_cap"])
+    eng.close()
+    cmd = [hipcc_path(), *jit._FLAGS, *shlex.split(spec), "-Rpass-analysis=kernel-resource-usage", "-o", str(tmp_path / "k.hsaco"),  # noqa: SLF001
+           str(CSRC / "engine.hip")]
+    res = subprocess.run(cmd, capture_output=True, text=True, check=False)
+    assert res.returncode == 0, res.stderr[-2000:]
+    block = res.stderr[res.stderr.index("Function Name: af_flow_jit"):]
+    scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", block).group(1))
+    assert scratch <= 256, f"af_flow_jit of config {config} keeps {scratch} B per lane in scratch memory"
