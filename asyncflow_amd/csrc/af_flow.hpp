@@ -2384,7 +2384,7 @@ struct Flow {
                     // (FEAT_CHAIN: what a level sends back into the server list takes the places its own selection left there,
                     // so the room that binds is the completion list's)
                     uint32_t room = st == 4u ? 64u : (kBig ? cap_of(nxt) : cap) - n_list_get(nxt);
-                    if (kChain && st == 3u && A.has_lb && level < lbp) {   // a level in front of the LB sends into the LB's list
+                    if (kChain && st == 3u && A.has_lb && level + 1u == lbp) {   // the level in front of the LB sends into the LB's list
                         const uint32_t room1 = (kBig ? cap_of(1u) : cap) - nl1;
                         room = room1 < room ? room1 : room;
                     }
@@ -2487,7 +2487,7 @@ struct Flow {
                     uint32_t total = 0u;
                     for (uint32_t k = 0u; k < A.n_servers; ++k) total += dep_cnt(k);
                     // (wave-uniform; FEAT_CHAIN: a departure goes to the completion list or back into the server list)
-                    const bool too_many = total > cap_of(3u) - nl3 || (kChain && total > cap_of(2u) - nl2) || (kChain && A.has_lb && total > cap_of(1u) - nl1);
+                    const bool too_many = total > cap_of(3u) - nl3 || (kChain && total > cap_of(2u) - nl2) || (kChain && A.has_lb && level + 1u == lbp && total > cap_of(1u) - nl1);
                     if (too_many) why |= FLOW_WHY_LIST;
                     for (uint32_t base = 0u; base < total && !too_many; base += 64u) {
                         const uint32_t want = base + lane;   // my departure, counted over the servers in order

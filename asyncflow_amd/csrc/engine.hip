@@ -1202,11 +1202,12 @@ int plan_flow(const af_engine* e, const KArgs& a, const af_sweep_t* sweep, const
     {
         for (uint32_t s = 0; s < 4u; ++s) big_caps[s] = (s == 1u && !e->has_lb) ? 64u : 256u;   // (no LB: its list stays empty)
         for (size_t h = 0; h < hops.size(); ++h) {
-            const uint32_t s = h == 0 ? 0u : h + 1 == hops.size() ? 3u : (h == 1 && e->has_lb) ? 1u : 2u;
+            const uint32_t s = h == 0 ? 0u : h + 1 == hops.size() ? 3u : (h == 1 && e->has_lb && e->flow_lb_pos == 0u) ? 1u : 2u;
             const double want = 1.5 * pend_of[h] + 128.0;
             const uint32_t c = want < 16384.0 ? ((uint32_t)want + 63u) & ~63u : 16384u;   // any multiple of 64
             if (c > big_caps[s]) big_caps[s] = c;
         }
+        if (e->flow_lb_pos != 0u && big_caps[2] > big_caps[1]) big_caps[1] = big_caps[2];   // (servers in front of the LB: the same load passes its list)
     }
     // A list only has to leave ROOM: 64 - pending new messages fit per round.  Larger lists cost LDS (occupancy) and
     // ranking work on every round of every scenario (measured on the config-3 grid: 64 entries 122 ms, 128 entries
@@ -1314,7 +1315,7 @@ int plan_flow(const af_engine* e, const KArgs& a, const af_sweep_t* sweep, const
         // list: it takes a whole round's departures of every server at once)
         for (uint32_t s = 0; s < 4u; ++s) caps1[s] = s == 3u ? 128u : 64u;
         for (size_t h = 0; h < hops.size(); ++h) {
-            const uint32_t s = h == 0 ? 0u : h + 1 == hops.size() ? 3u : (h == 1 && e->has_lb) ? 1u : 2u;
+            const uint32_t s = h == 0 ? 0u : h + 1 == hops.size() ? 3u : (h == 1 && e->has_lb && e->flow_lb_pos == 0u) ? 1u : 2u;
             const double want = pend_of[h] <= 24.0 ? 64.0 : 1.5 * pend_of[h] + 64.0;
             const uint32_t c = want < 1024.0 ? ((uint32_t)want + 63u) & ~63u : 1024u;
             if (c > caps1[s]) caps1[s] = c;
@@ -1323,6 +1324,8 @@ int plan_flow(const af_engine* e, const KArgs& a, const af_sweep_t* sweep, const
             rows = 0u;
             win_rows = 0u;
         }
+        // (servers in front of the LB: its list takes a whole round's departures of the server that feeds it, like the completion list)
+        if (e->flow_lb_pos != 0u) caps1[1] = std::max({caps1[1], caps1[2], 128u});
         FL = aff::make_flow_layout(0u, rows, g_ring, c_ring, a.n_edges, a.n_servers, a.n_edge_marks, false, caps1, true);
     } else if (flow_big) {
         if (rows * pitch * 4u > 8u * 1024u) {   // the lists need the LDS more than the tick ring does
