@@ -2484,10 +2484,20 @@ struct Flow {
                     prof(PROF_SERVERS);
                     // the departures the servers produced (each server's in time order), sent by the whole wave, 64 at a time
                     auto dep_cnt = [&](uint32_t k) { return (!kChain || level_of(k) == level) ? lo32(gs(k)[GS_DEP]) : 0u; };
-                    uint32_t total = 0u;
-                    for (uint32_t k = 0u; k < A.n_servers; ++k) total += dep_cnt(k);
-                    // (wave-uniform; FEAT_CHAIN: a departure goes to the completion list or back into the server list)
-                    const bool too_many = total > cap_of(3u) - nl3 || (kChain && total > cap_of(2u) - nl2) || (kChain && A.has_lb && level + 1u == lbp && total > cap_of(1u) - nl1);
+                    // (wave-uniform; FEAT_CHAIN: a server's departures go to the completion list, back into the server list or -- round 5 --
+                    // into the LB's list, by the kind of node its out-edge leads to: each list must hold what is bound for it.  Round 4
+                    // checked the whole total against the completion AND the server list, which handed a third of the first launches
+                    // of tiers of general servers to the second chance for nothing.)
+                    uint32_t total = 0u, to_list[4] = {0u, 0u, 0u, 0u};
+                    for (uint32_t k = 0u; k < A.n_servers; ++k) {
+                        const uint32_t kind = !kChain ? (uint32_t)af::NODE_CLIENT
+                                                      : (uint32_t)erec((uint32_t)(blob[A.off_srv + af::SREC * k + 1u] >> 16) & 0xFFFFu)[3] & 0xFFu;
+                        total += dep_cnt(k);
+                        if (kind == af::NODE_SERVER) to_list[2] += dep_cnt(k);
+                        else if (kind == af::NODE_LB) to_list[1] += dep_cnt(k);
+                        else to_list[3] += dep_cnt(k);
+                    }
+                    const bool too_many = to_list[3] > cap_of(3u) - nl3 || to_list[2] > cap_of(2u) - nl2 || (A.has_lb && to_list[1] > cap_of(1u) - nl1);
                     if (too_many) why |= FLOW_WHY_LIST;
                     for (uint32_t base = 0u; base < total && !too_many; base += 64u) {
                         const uint32_t want = base + lane;   // my departure, counted over the servers in order

@@ -1325,6 +1325,8 @@ int plan_flow(const af_engine* e, const KArgs& a, const af_sweep_t* sweep, const
             win_rows = 0u;
         }
         // (servers in front of the LB: its list takes a whole round's departures of the server that feeds it, like the completion list)
+        // (servers that feed servers: the ONE server list holds the messages bound for every level)
+        if (e->flow_chain) caps1[2] = std::max(caps1[2], 128u);
         if (e->flow_lb_pos != 0u) caps1[1] = std::max({caps1[1], caps1[2], 128u});
         FL = aff::make_flow_layout(0u, rows, g_ring, c_ring, a.n_edges, a.n_servers, a.n_edge_marks, false, caps1, true);
     } else if (flow_big) {
