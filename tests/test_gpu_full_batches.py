@@ -12,8 +12,8 @@ and >= 32 scenarios spread over the batch are also held to the CPU oracle (the c
 fixtures).  Chain of custody: reference == oracle (tests/golden) ; oracle == next-event kernels (test_gpu_parity.py) ;
 next-event kernels == stage-parallel kernel over ALL scenarios of the benched batch (here).
 
-Config 2: 10 000 seed replicas (2 x 18 GB of outputs); config 3: the 100 x 100 users x RTT grid; config 5: 4 096 of
-the 50 000 replicas (a next-event pass over all of them would take minutes; the flow kernel's launch shape -- lists,
+Config 2: 10 000 seed replicas (2 x 18 GB of outputs); config 3: the 100 x 100 users x RTT grid; config 4: every eighth of
+its 100 000 scenarios; config 5: 4 096 of the 50 000 replicas (a next-event pass over all of them would take minutes; the flow kernel's launch shape -- lists,
 ring, FEAT -- does not depend on the replica count).
 """
 
@@ -90,6 +90,50 @@ def test_every_scenario_of_the_benched_batch_is_identical_on_both_kernel_familie
     assert not differ, f"config {config}: {len(differ)} of {flow.n} scenarios differ between the kernel families (first: {differ[:8]})"
     # the comparison looked at something: completions and ticks of the whole batch
     assert int(c[:, _abi.CNT_COMPLETED].astype(np.int64).sum()) > 1000 * flow.n and int(c[:, _abi.CNT_TICKS].min()) == 11_999
+    flow.eng.close()
+    seq.eng.close()
+
+
+def test_every_eighth_scenario_of_config_4_is_identical_on_both_kernel_families():
+    """BASELINE config 4 (the users x RTT grid x 10 seeds with event_inj_lb.yml's spikes and outages, 100 000 scenarios) is
+    benched in four slices; a next-event pass over all of it takes minutes, so this takes every eighth scenario of the BENCHED
+    batch -- same seeds, same columns, every region of the grid, 12 500 scenarios -- through both kernel families and compares
+    all of them on the device, plus 16 oracle picks."""
+    import torch
+
+    import bench
+
+    def sweep(extra):
+        args = bench.make_parser().parse_args(["--config", "4", *extra])
+        args.horizon = None
+        wl = bench.build_workload(4, 0, 1, 0, None)
+        assert wl["n"] == 100_000
+        wl["seeds"] = np.ascontiguousarray(wl["seeds"][::8])
+        wl["columns"] = {k: np.ascontiguousarray(v[::8]) for k, v in wl["columns"].items()}
+        wl["n"] = int(wl["seeds"].size)
+        sw = bench.RankSweep(wl, torch.device("cuda", 0), args)
+        sw.prepare()
+        return sw
+
+    flow = sweep([])
+    assert flow.n == 12_500 and flow.n_slices == 1 and not flow.flow_reason
+    acc = flow.step()
+    torch.cuda.synchronize()
+    assert acc["flow_scen"] == flow.n and acc["flow_fallback"][0] == 0
+    c = flow.counts.cpu().numpy().view(np.uint32)
+    assert int(np.bitwise_or.reduce(c[:, _abi.CNT_FLAGS])) & _abi.FATAL_FLAGS == 0 and int(c[:, _abi.CNT_MARKS].min()) > 0
+    _oracle_picks(flow, 16)
+    seq = sweep(["--no-flow", "--generic-kernels", "--hbm-budget-gb", "24"])
+    differ = []
+    for lo in range(0, seq.n, seq.slice):
+        hi = min(seq.n, lo + seq.slice)
+        st = seq.run_slice(lo, hi)
+        torch.cuda.synchronize()
+        assert int(st.flow_scenarios) == 0
+        d = differing_scenarios(flow.counts[lo:hi], flow.clock[lo:hi], flow.samples[lo:hi],
+                                seq.counts[lo:hi], seq.clock[: hi - lo], seq.samples[: hi - lo])
+        differ += (d + lo).tolist()
+    assert not differ, f"config 4: {len(differ)} of {flow.n} scenarios differ between the kernel families (first: {differ[:8]})"
     flow.eng.close()
     seq.eng.close()
 
