@@ -17,6 +17,7 @@ from oracle import oracle_lib as ol  # noqa: E402
 from oracle.scenarios import deep_chain, gateway_lb, random_payload, server_tiers, tie_storm, wide_fanout  # noqa: E402
 
 n_payloads = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+k0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # first payload index: a different range is a different set of payloads
 def _gateway(k: int) -> dict:
     rng = random.Random(99000 + k)
     return gateway_lb(front=rng.choice((1, 2)), algo=rng.choice(("round_robin", "least_connection")), users=rng.choice((60, 150, 300)),
@@ -49,7 +50,7 @@ families = {
 out = {}
 for name, make in families.items():
     t = {"payloads": 0, "scenarios": 0, "on_flow_kernel": 0, "handed_back_first": 0, "to_next_event": 0, "oracle_checks": 0, "not_in_range": 0}
-    for k in range(n_payloads):
+    for k in range(k0, k0 + n_payloads):
         payload = make(k)
         seeds = np.arange(8, dtype=np.uint64) + 1000 * k + 7
         res = SimulationRunner(simulation_input=payload, seeds=seeds, on_negative_delay="flag").run()
