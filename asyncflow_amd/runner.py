@@ -110,6 +110,7 @@ def write_point(payload: dict, key: str, value: float) -> None:
 
 
 VALIDATE_EVERY_POINT_UP_TO = 512      # distinct points validated row by row; the reference's model costs ~0.2 ms per payload
+MAX_ATTEMPTS = 6   # runs of one sweep while the engine reports a capacity overflow (every pool grows fourfold per attempt)
 _VALIDATED: dict[tuple, int] = {}       # (plan, columns) digests already validated in this process
 
 
@@ -501,7 +502,8 @@ class SimulationRunner:
         dev = torch.device("cuda", device)
         ticks = max(self.plan.tick_count, 1)
         t0 = time.perf_counter()
-        for attempt in range(4):
+        fifo_overflows = 0
+        for attempt in range(MAX_ATTEMPTS):
             eng = Engine(self.plan, device, request_capacity=cap, fifo_capacity=fifo,
                          force_global_state=self.force_global_state, lanes_per_wave=self.lanes_per_wave,
                          draw_memory_mb=self.draw_memory_mb, flow=self.flow,
@@ -560,7 +562,7 @@ class SimulationRunner:
                                  online_hist=online_hist, online_rps=online_rps, online_hist_max=o_max)
             res.flow_reason = flow_reason
             over = int(np.bitwise_or.reduce(res.flags)) & _abi.FATAL_FLAGS
-            if not over or attempt == 3 or not self.auto_grow:
+            if not over or attempt == MAX_ATTEMPTS - 1 or not self.auto_grow:
                 break
             # capacities are estimates (Little's law); overflow is flagged by the
             # kernel, never silent -> grow the overflowing pool and run again.  A pool that overflowed at its real
@@ -571,8 +573,11 @@ class SimulationRunner:
             if over & _abi.FLAG_POOL_OVERFLOW:
                 cap = min(_abi.MAX_REQUEST_CAPACITY, cap * 4)
             if over & _abi.FLAG_FIFO_OVERFLOW:
-                # (the wait queues hold request slots: a FIFO larger than the pool is never needed)
-                fifo = _fifo_pow2(fifo * 4)
+                # (the wait queues hold request slots: a FIFO larger than the pool is never needed -- and a queue that outgrew
+                # its estimate twice belongs to a server the estimate did not see as saturated: its backlog grows with the
+                # horizon, so go to the pool's size at once instead of re-running the sweep for every factor of four)
+                fifo_overflows += 1
+                fifo = _fifo_pow2(fifo * 4 if fifo_overflows == 1 else max(fifo * 4, cap))
                 cap = min(_abi.MAX_REQUEST_CAPACITY, max(cap, fifo))
             if over & (_abi.FLAG_CLOCK_OVERFLOW | _abi.FLAG_DRAW_OVERFLOW):
                 clock_cap *= 2

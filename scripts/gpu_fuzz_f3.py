@@ -14,7 +14,7 @@ from asyncflow_amd import _abi  # noqa: E402
 from asyncflow_amd.plan import lower  # noqa: E402
 from asyncflow_amd.runner import SimulationRunner  # noqa: E402
 from oracle import oracle_lib as ol  # noqa: E402
-from oracle.scenarios import deep_chain, gateway_lb, random_payload, server_tiers, tie_storm, wide_fanout  # noqa: E402
+from oracle.scenarios import deep_chain, flow_payload, gateway_lb, random_payload, server_tiers, tie_storm, wide_fanout  # noqa: E402
 
 n_payloads = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 k0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # first payload index: a different range is a different set of payloads
@@ -46,15 +46,24 @@ families = {
     "server tiers (general servers)": lambda k: server_tiers(random.Random(96000 + k), horizon=12, general=True),
     "random topologies (general servers)": lambda k: random_payload(random.Random(97000 + k), horizon=8),
     "tie storms": lambda k: tie_storm(random.Random(98000 + k), horizon=8),
+    # rounds 2-3: the feed-forward range itself (idle to saturated tandem servers, every latency law, dyadic step times, tight RAM,
+    # spikes, outages, least connections, both generators)
+    "feed-forward payloads (tandem servers)": lambda k: flow_payload(random.Random(94000 + k), horizon=6),
 }
+if len(sys.argv) > 3:   # only the families whose name contains the third argument
+    families = {n: f for n, f in families.items() if sys.argv[3] in n}
 out = {}
 for name, make in families.items():
-    t = {"payloads": 0, "scenarios": 0, "on_flow_kernel": 0, "handed_back_first": 0, "to_next_event": 0, "oracle_checks": 0, "not_in_range": 0}
+    t = {"payloads": 0, "scenarios": 0, "on_flow_kernel": 0, "handed_back_first": 0, "to_next_event": 0, "oracle_checks": 0, "not_in_range": 0, "overflow_raised": 0}
     for k in range(k0, k0 + n_payloads):
         payload = make(k)
         seeds = np.arange(8, dtype=np.uint64) + 1000 * k + 7
-        res = SimulationRunner(simulation_input=payload, seeds=seeds, on_negative_delay="flag").run()
-        ref = SimulationRunner(simulation_input=payload, seeds=seeds, flow=False, on_negative_delay="flag").run()
+        try:
+            res = SimulationRunner(simulation_input=payload, seeds=seeds, on_negative_delay="flag").run()
+            ref = SimulationRunner(simulation_input=payload, seeds=seeds, flow=False, on_negative_delay="flag").run()
+        except OverflowError:   # a pool at the engine's maximum: reported, never silent (runner.py)
+            t["overflow_raised"] += 1
+            continue
         st = res.engine_stats
         t["payloads"] += 1
         t["scenarios"] += 8

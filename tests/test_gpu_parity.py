@@ -310,6 +310,12 @@ def test_overflow_is_reported_and_auto_grow_recovers():
     with pytest.warns(RuntimeWarning):
         res = _runner(payload, seeds=[1, 2], request_capacity=64, fifo_capacity=16).run()
     _assert_scenario(res[1], ol.simulate(lower(payload), 2))
+    # a backlog that grows with the horizon, pools far too small: the queue goes to the pool's size on its second overflow,
+    # the pool fourfold per run -- the sweep ends within MAX_ATTEMPTS runs instead of raising with room left to grow
+    long = overload(horizon=30)
+    with pytest.warns(RuntimeWarning):
+        res = _runner(long, seeds=[3], request_capacity=16, fifo_capacity=8).run()
+    _assert_scenario(res[0], ol.simulate(lower(long), 3))
 
 
 def test_single_run_is_a_drop_in_for_the_reference_call(tmp_path):
