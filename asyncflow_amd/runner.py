@@ -110,7 +110,7 @@ def write_point(payload: dict, key: str, value: float) -> None:
 
 
 VALIDATE_EVERY_POINT_UP_TO = 512      # distinct points validated row by row; the reference's model costs ~0.2 ms per payload
-MAX_ATTEMPTS = 6   # runs of one sweep while the engine reports a capacity overflow (every pool grows fourfold per attempt)
+MAX_ATTEMPTS = 6   # runs of one sweep while the engine reports a capacity overflow (SimulationRunner.run: how the pools grow)
 _VALIDATED: dict[tuple, int] = {}       # (plan, columns) digests already validated in this process
 
 
@@ -502,7 +502,7 @@ class SimulationRunner:
         dev = torch.device("cuda", device)
         ticks = max(self.plan.tick_count, 1)
         t0 = time.perf_counter()
-        fifo_overflows = 0
+        pool_overflows = 0
         for attempt in range(MAX_ATTEMPTS):
             eng = Engine(self.plan, device, request_capacity=cap, fifo_capacity=fifo,
                          force_global_state=self.force_global_state, lanes_per_wave=self.lanes_per_wave,
@@ -570,17 +570,24 @@ class SimulationRunner:
             if (over & _abi.FLAG_POOL_OVERFLOW and cap >= _abi.MAX_REQUEST_CAPACITY) or \
                     (over & _abi.FLAG_FIFO_OVERFLOW and fifo >= _abi.MAX_FIFO_CAPACITY):
                 break
-            if over & _abi.FLAG_POOL_OVERFLOW:
-                cap = min(_abi.MAX_REQUEST_CAPACITY, cap * 4)
-            if over & _abi.FLAG_FIFO_OVERFLOW:
-                # (the wait queues hold request slots: a FIFO larger than the pool is never needed -- and a queue that outgrew
-                # its estimate twice belongs to a server the estimate did not see as saturated: its backlog grows with the
-                # horizon, so go to the pool's size at once instead of re-running the sweep for every factor of four)
-                fifo_overflows += 1
-                fifo = _fifo_pow2(fifo * 4 if fifo_overflows == 1 else max(fifo * 4, cap))
-                cap = min(_abi.MAX_REQUEST_CAPACITY, max(cap, fifo))
             if over & (_abi.FLAG_CLOCK_OVERFLOW | _abi.FLAG_DRAW_OVERFLOW):
                 clock_cap *= 2
+            if over & (_abi.FLAG_POOL_OVERFLOW | _abi.FLAG_FIFO_OVERFLOW):
+                pool_overflows += 1
+                if pool_overflows == 1:      # an estimate that was a little short: the flagged pool, fourfold
+                    if over & _abi.FLAG_POOL_OVERFLOW:
+                        cap = min(_abi.MAX_REQUEST_CAPACITY, cap * 4)
+                    if over & _abi.FLAG_FIFO_OVERFLOW:
+                        fifo = _fifo_pow2(fifo * 4)
+                else:
+                    # twice: a server the estimate did not see as saturated -- its backlog grows with the horizon.  The live
+                    # requests of a scenario never exceed its arrivals (clock_cap bounds them), the waiters of a queue never
+                    # the live requests: go to those bounds at once instead of re-running the sweep for every factor of four
+                    # (pool and queue overflow in turns: found by scripts/gpu_fuzz_sweeps.py, six runs were not enough)
+                    cap = min(_abi.MAX_REQUEST_CAPACITY, max(cap * 4, (clock_cap + 7) // 8 * 8))
+                    fifo = _fifo_pow2(cap)
+                # (the wait queues hold request slots: a FIFO larger than the pool is never needed, a pool smaller than it neither)
+                cap = min(_abi.MAX_REQUEST_CAPACITY, max(cap, fifo))
             warnings.warn(
                 f"engine capacity overflow (flags={over:#x}); retrying with request_capacity={cap}, "
                 f"fifo_capacity={fifo}, clock_capacity={clock_cap}", RuntimeWarning, stacklevel=2)
