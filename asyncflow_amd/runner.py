@@ -477,6 +477,48 @@ class SimulationRunner:
         keep = [r for r in range(k) if shards[r] is not None]
         return ShardedResults([shards[r] for r in keep], [index[r] for r in keep], time.perf_counter() - t0)
 
+    def _engine_kw(self, cap: int, fifo: int) -> dict[str, Any]:
+        return dict(request_capacity=cap, fifo_capacity=fifo, force_global_state=self.force_global_state,
+                    lanes_per_wave=self.lanes_per_wave, draw_memory_mb=self.draw_memory_mb, flow=self.flow,
+                    flow_list_entries=self.flow_list_entries, flow_ring_rows=self.flow_ring_rows,
+                    expect_shared_instants=(_SHARED_INSTANTS_SEEN.get(self._plan_key(), False)
+                                            if self.expect_shared_instants is None else bool(self.expect_shared_instants)))
+
+    def jit_spec(self) -> str:
+        """The ``-D`` flags of the plan-specialised kernels the FIRST run of this sweep launches (`asyncflow_amd/jit.py`), from a
+        planning-only engine: no GPU needed.  Of the output buffers only their presence and capacities enter, so the shape is
+        that of `run()` -- the same capacities estimate, clock / samples / kernel-side summary as this runner was set up.  Sweeps
+        the next-event kernels run (`flow=False`, plans outside the stage-parallel range) raise `EngineUnavailableError`: the
+        shape of those kernels depends on the device."""
+        from .engine import PLAN_ONLY
+
+        n = int(self.seeds.size)
+        overrides = resolve_sweep(self.plan, self.sweep, n)
+        cap, fifo, clock_cap = self._capacities(overrides)
+        o_bins = int(self.online_summary.get("hist_bins", 4096)) if self.online_summary is not None else 0
+        o_buckets = int(self.plan.total_time) if self.online_summary is not None else 0
+        eng = Engine(self.plan, PLAN_ONLY, **self._engine_kw(cap, fifo))
+        try:
+            return eng.jit_spec(self.seeds, [(c, i, v) for c, i, v, _ in overrides],
+                                clock_ptr=8 if self.collect_clock else 0, clock_capacity=clock_cap,
+                                samples_ptr=8 if self.collect_samples else 0, tick_capacity=max(self.plan.tick_count, 1), counts_ptr=8,
+                                draw_capacity=clock_cap, online_hist_ptr=8 if o_bins else 0, online_hist_bins=o_bins,
+                                online_hist_max=float(self.online_summary["hist_max"]) if o_bins else 0.0,
+                                online_rps_ptr=8 if o_buckets else 0, online_rps_buckets=o_buckets)
+        finally:
+            eng.close()
+
+    def prebuild(self) -> str:
+        """Build (or find in the cache) the plan-specialised kernel of this sweep WITHOUT a GPU: run it where hipcc is -- a build
+        machine, a container image step -- and ship `asyncflow_amd/csrc/_jit/` with the package; `run()` on a box without a
+        compiler then loads the specialised kernel instead of the library's generic one.  Returns the spec."""
+        from . import jit
+
+        spec = self.jit_spec()
+        if spec:
+            jit.code_object(spec)
+        return spec
+
     def run(self) -> BatchedResults | ScenarioResults:
         """Lower once, launch the HIP kernel over every scenario, return results."""
         import torch
@@ -504,13 +546,7 @@ class SimulationRunner:
         t0 = time.perf_counter()
         pool_overflows = 0
         for attempt in range(MAX_ATTEMPTS):
-            eng = Engine(self.plan, device, request_capacity=cap, fifo_capacity=fifo,
-                         force_global_state=self.force_global_state, lanes_per_wave=self.lanes_per_wave,
-                         draw_memory_mb=self.draw_memory_mb, flow=self.flow,
-                         flow_list_entries=self.flow_list_entries, flow_ring_rows=self.flow_ring_rows,
-                         expect_shared_instants=(_SHARED_INSTANTS_SEEN.get(self._plan_key(), False)
-                                                 if self.expect_shared_instants is None
-                                                 else bool(self.expect_shared_instants)))
+            eng = Engine(self.plan, device, **self._engine_kw(cap, fifo))
             self._engine = eng
             counts = torch.zeros((n, _abi.CNT_SLOTS), dtype=torch.int32, device=dev)
             clock = torch.empty((n, clock_cap, 2), dtype=torch.float64, device=dev) if self.collect_clock else None

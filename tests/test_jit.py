@@ -141,6 +141,31 @@ def test_a_planning_only_engine_cannot_run():
     eng.close()
 
 
+def test_a_runner_names_and_prebuilds_its_kernel_without_a_gpu(monkeypatch):
+    """SimulationRunner.jit_spec() / prebuild(): the spec of the sweep's first run from a planning-only engine -- for BASELINE
+    config 2 the very spec bench.prebuild_kernels() builds -- handed to the compiler cache; sweep columns make their own kernel."""
+    import numpy as np
+
+    import bench
+    from asyncflow_amd.runner import SimulationRunner
+    from asyncflow_amd.workloads import lb_two_servers
+
+    seeds = np.arange(64, dtype=np.uint64) + 0x5EED0000
+    runner = SimulationRunner(simulation_input=lb_two_servers(horizon=600), seeds=seeds)
+    spec = runner.jit_spec()
+    built = []
+    monkeypatch.setattr(jit, "code_object", lambda sp, build=True: built.append(sp) or b"")
+    assert bench.prebuild_kernels(configs=(2,), worlds=(1,), verbose=False) == [spec]
+    assert runner.prebuild() == spec and built == [spec, spec]
+    swept = SimulationRunner(simulation_input=lb_two_servers(horizon=600), seeds=seeds,
+                             sweep={"rqs_input.avg_active_users.mean": np.linspace(100.0, 700.0, 64)})
+    assert "-DAF_FJ_HAS_OVR=1" in swept.jit_spec() and "-DAF_FJ_HAS_OVR=0" in spec
+    from asyncflow_amd.engine import EngineUnavailableError
+
+    with pytest.raises(EngineUnavailableError, match="only sweeps of the stage-parallel kernel"):   # (their shape depends on the device)
+        SimulationRunner(simulation_input=lb_two_servers(horizon=600), seeds=seeds, flow=False).jit_spec()
+
+
 def test_prebuild_fills_the_cache_for_every_default_bench_line(tmp_path, monkeypatch):
     """`__graft_entry__.build()` calls bench.prebuild_kernels(): afterwards a box without hipcc still finds the kernels."""
     import bench
