@@ -1,6 +1,8 @@
 """GPU fuzz of the batched analyzer (af_summary_kernel / af_series_kernel, SURVEY 8 a11 + f1): random payloads of every family, six
 scenarios each -- the 8 latency statistics, the 1-s RPS series, a latency histogram with a random range and the per-series mean / max
-of `BatchedResults.summary()` against oracle/analyzer_oracle.py (numpy's own order statistics) on the downloaded outputs.
+of `BatchedResults.summary()` against oracle/analyzer_oracle.py (numpy's own order statistics) on the downloaded outputs; then the
+kernel-side summary (`online_summary=`: histogram + 1-s completion counts written by the simulation kernels, with and without the
+per-request clock) against the same functions.
 
     python scripts/gpu_fuzz_analyzer.py [payloads, default 200] [first payload index, default 0]
 
@@ -41,7 +43,7 @@ def make(k: int) -> dict:
     return p
 
 
-t = {"payloads": 0, "scenarios": 0, "empty_scenarios": 0, "overflow_raised": 0}
+t = {"payloads": 0, "scenarios": 0, "empty_scenarios": 0, "overflow_raised": 0, "online_checks": 0}
 failures: list[str] = []
 for k in range(k0, k0 + n_payloads):
     payload = make(k)
@@ -83,6 +85,34 @@ for k in range(k0, k0 + n_payloads):
             one = sc.get_latency_stats()
             if want[0] > 0:
                 assert one["p95"] == stats[i][4] and one["total_requests"] == stats[i][0], (k, i, "accessor")
+    except AssertionError as exc:
+        failures.append(str(exc)[:400])
+        print(f"DIFFERENT payload {k}: {str(exc)[:400]}", file=sys.stderr)
+    # the kernel-side summary (online_summary: histogram + 1-s completion counts written by the simulation kernels themselves, with
+    # and without the per-request clock) against the same oracle functions on the clock of the run above
+    try:
+        obins = rng.choice((64, 1024, 4096))
+        omax = rng.choice((0.016, 0.256, 2.0))
+        both = SimulationRunner(simulation_input=payload, seeds=seeds, on_negative_delay="flag", online_summary={"hist_bins": obins, "hist_max": omax}).run()
+        lean = SimulationRunner(simulation_input=payload, seeds=seeds, on_negative_delay="flag", collect_clock=False, collect_samples=False,
+                                online_summary={"hist_bins": obins, "hist_max": omax}).run()
+        oh = both.online_hist.cpu().numpy().view(np.uint32)
+        orps = both.online_rps.cpu().numpy() if T > 0 else None
+        assert np.array_equal(both.counts[:, :5], res.counts[:, :5]), (k, "online: counts")
+        assert np.array_equal(lean.counts[:, :5], res.counts[:, :5]), (k, "online, no outputs: counts")
+        assert np.array_equal(lean.online_hist.cpu().numpy(), both.online_hist.cpu().numpy()), (k, "online, no outputs: histogram")
+        if orps is not None:
+            assert np.array_equal(lean.online_rps.cpu().numpy(), both.online_rps.cpu().numpy()), (k, "online, no outputs: rps")
+        for i in range(N):
+            ck = res[i].rqs_clock
+            assert np.array_equal(oh[i], ao.latency_histogram(ck, obins, omax)), (k, i, "online histogram", obins, omax)
+            if orps is not None:
+                assert np.array_equal(orps[i].astype(np.float64), ao.throughput_series(ck, T)[1]), (k, i, "online rps")
+        t["online_checks"] += N
+        both.close()
+        lean.close()
+    except OverflowError:
+        t["overflow_raised"] += 1
     except AssertionError as exc:
         failures.append(str(exc)[:400])
         print(f"DIFFERENT payload {k}: {str(exc)[:400]}", file=sys.stderr)
