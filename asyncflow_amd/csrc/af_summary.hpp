@@ -134,7 +134,13 @@ __device__ inline void wave_select(const uint32_t* hist, int nbins, uint32_t k, 
     count = __shfl(c, src, 64);
 }
 
-__global__ __launch_bounds__(kThreads) void af_summary_kernel(SumArgs a) {
+// kWpe: waves per SIMD the register allocation aims at -- 4: 115 registers, two scenarios (workgroups) per CU; 8: 64 registers,
+// four, which is what the 35 KB of LDS admit (51 spilled registers, none of them inside the pass loops).  The kernel waits
+// most of its time (61 % of its wave cycles in s_waitcnt at two scenarios per CU: profiles/r05/binding_c2.json), residency hides
+// its HBM and LDS round trips: measured on BASELINE config 2 (profiles/r05/summary_wpe_ab.txt) 4.67 -> 4.28 ms for the
+// analyzer's two kernels (6 waves, three scenarios per CU: 4.6).  af_engine_summarize launches <8>; AF_SUMMARY_WPE=4 the other.
+template <int kWpe>
+__global__ __launch_bounds__(kThreads, kWpe) void af_summary_kernel(SumArgs a) {
     extern __shared__ uint32_t dyn[];  // [rps_buckets] then [hist_bins]
     __shared__ uint32_t exp_hist[kExpBins];
     __shared__ __attribute__((aligned(16))) uint32_t dig_hist[kRanks][kDigBins];
@@ -154,6 +160,7 @@ __global__ __launch_bounds__(kThreads) void af_summary_kernel(SumArgs a) {
     __shared__ double shift_s;      // the squared deviations of pass 1 are taken about this value (mean of the first 512 latencies)
     __shared__ uint32_t slot_code[kRanks];
 
+    constexpr int kGroup = kWpe > 4 ? kPerThread / 2 : kPerThread;   // (16-byte loads in flight per thread)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t sc = blockIdx.x;
     uint32_t n = a.counts[(size_t)sc * 8u + a.cnt_completed_slot];
@@ -206,19 +213,24 @@ __global__ __launch_bounds__(kThreads) void af_summary_kernel(SumArgs a) {
     // ---- pass 1 -----------------------------------------------------------------------------
     double s = 0.0, mn = __builtin_inf(), mx = -__builtin_inf(), sd1 = 0.0, sq1 = 0.0;
     for (uint32_t base = 0; base < n; base += kBlock) {
-        double2 c4[kPerThread];
+        // kGroup 16-byte loads in flight per thread: eight at 128 registers; the forms compiled for more waves per SIMD take
+        // the step's eight completions four at a time (half the registers, and twice the waves keep as many bytes in flight)
+        double2 c4[kGroup];
         uint32_t codes8[kPerThread / 2];
 #pragma unroll
-        for (int u = 0; u < kPerThread; ++u) {  // eight 16-byte loads in flight per thread
-            const uint32_t i = base + (uint32_t)u * kThreads + tid;
-            c4[u] = i < n ? ck[i] : double2{0.0, 0.0};
+        for (int u0 = 0; u0 < kPerThread; u0 += kGroup) {
+#pragma unroll
+        for (int v = 0; v < kGroup; ++v) {
+            const uint32_t i = base + (uint32_t)(u0 + v) * kThreads + tid;
+            c4[v] = i < n ? ck[i] : double2{0.0, 0.0};
         }
 #pragma unroll
-        for (int u = 0; u < kPerThread; ++u) {
+        for (int v = 0; v < kGroup; ++v) {
+            const int u = u0 + v;
             const uint32_t i = base + (uint32_t)u * kThreads + tid;
             const bool act = i < n;
             uint32_t code = 0u;   // (guessed bin + 1) << 10 | digit; 0 = in none of the guessed bins
-            const double2 c = c4[u];
+            const double2 c = c4[v];
             const double lat = c.y - c.x;
             if (act) {
                 s += lat;
@@ -258,6 +270,7 @@ __global__ __launch_bounds__(kThreads) void af_summary_kernel(SumArgs a) {
                 const uint32_t b = bf >= (double)(a.hist_bins - 1u) ? a.hist_bins - 1u : (uint32_t)bf;
                 atomicAdd(&hist_l[b], 1u);
             }
+        }
         }
         // the thread's eight codes side by side: one 16-byte store (position base + 8 tid + u holds completion base + 512 u + tid)
         if (cd) *reinterpret_cast<uint4*>(cd + base + 8u * (uint32_t)tid) = uint4{codes8[0], codes8[1], codes8[2], codes8[3]};

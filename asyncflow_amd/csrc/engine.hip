@@ -2292,6 +2292,8 @@ int af_engine_set_kernels(af_engine_t* e, const char* spec, const void* image, s
     return AF_OK;
 }
 
+constexpr int kSummaryWpe = 8;   // (af_summary.hpp: kWpe; BASELINE config 2, 10 000 scenarios: 4.67 -> 4.28 ms for the analyzer's pair of kernels)
+
 int af_engine_summarize(af_engine_t* e, const af_outputs_t* out, const af_summary_t* sum) {
     if (!e || !out || !sum) return fail(AF_ERR_INVALID, "NULL argument");
     if (e->plan_only) return fail(AF_ERR_NO_DEVICE, "planning-only engine (AF_DEVICE_PLAN_ONLY)");
@@ -2310,6 +2312,9 @@ int af_engine_summarize(af_engine_t* e, const af_outputs_t* out, const af_summar
     if (dyn_bytes > 96u * 1024u) return fail(AF_ERR_CAPACITY, "rps_buckets + hist_bins exceed the LDS budget (24576 words)");
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
+    // (Measured, round 5: the series kernel on a second stream beside the latency kernel gains nothing -- 4.68 vs 4.65 ms for the
+    // pair, both are HBM-bound -- and neither does the analyzer of a finished part of a sweep under the stage-parallel kernel of the
+    // next part: every part pays the arrival chain's 5 ms again.  profiles/r05/summary_wpe_ab.txt, overlap_probe.log.)
     if (want_lat) {
         afs::SumArgs s{};
         s.clock = out->clock;
@@ -2336,9 +2341,14 @@ int af_engine_summarize(af_engine_t* e, const af_outputs_t* out, const af_summar
             }
             s.codes = e->codes_bytes >= code_bytes ? static_cast<uint16_t*>(e->d_codes) : nullptr;
         }
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(afs::af_summary_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes));
-        hipLaunchKernelGGL(afs::af_summary_kernel, dim3(sum->n_scenarios), dim3(afs::kThreads), dyn_bytes, e->stream, s);
+        // register budget of the latency kernel (af_summary.hpp: kWpe); AF_SUMMARY_WPE=4|8: measurements
+        int wpe = kSummaryWpe;
+        if (const char* env = std::getenv("AF_SUMMARY_WPE")) wpe = std::atoi(env);
+        const void* fn = wpe == 8 ? reinterpret_cast<const void*>(afs::af_summary_kernel<8>)
+                                  : reinterpret_cast<const void*>(afs::af_summary_kernel<4>);
+        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes));
+        void* kargs[] = {&s};
+        HIP_TRY(hipLaunchKernel(fn, dim3(sum->n_scenarios), dim3(afs::kThreads), kargs, dyn_bytes, e->stream));
         HIP_TRY(hipGetLastError());
     }
     if (want_series) {
