@@ -627,7 +627,19 @@ struct Flow {
         const AF_PLAN_AS uint64_t* r = erec(e);
         const double mean = u2d(r[0]), sigma = u2d(r[1]);
         const uint32_t stream = af::stream_edge(e);
+#if defined(__HIP_DEVICE_COMPILE__) && defined(AF_FJ_KEYS_PER_CALL)
+        // The seed is the wave's (one scenario per wave), so Philox's key schedule -- seed + r x the Weyl constants -- is scalar
+        // work.  Left alone the compiler makes twenty loop-invariant scalar registers of it, more than it has: part of them live
+        // in the lanes of a vector register and come back through v_readlane, a VALU slot each, in a kernel bound by VALU issue.
+        // The empty asm makes the seed opaque at every call site: ten pairs of s_add per draw instead (config 2: 63 -> 45
+        // v_readlane, 1 903 -> 1 869 VALU instructions).  A plan-specialised build asks for it where it was measured to pay
+        // (engine.hip: flow_jit_spec_string); the register allocation of this kernel is chaotic, and it does not everywhere.
+        uint32_t sd_lo = (uint32_t)seed, sd_hi = (uint32_t)(seed >> 32);
+        asm volatile("" : "+s"(sd_lo), "+s"(sd_hi));
+        const af::U4 rr = af::draw_block(((uint64_t)sd_hi << 32) | sd_lo, stream, idx, 0u);
+#else
         const af::U4 rr = af::draw_block(seed, stream, idx, 0u);
+#endif
         // dropped (edge.py:78-86)?  u < dropout_rate with u = k x 2^-53, k the draw's 53 bits: the same test on integers,
         // k < ceil(dropout x 2^53) -- run() turned the blob's dropout word into that threshold -- without the two u32 -> f64
         // conversions, the multiply-add and the scaling of af::u53 (round 4)

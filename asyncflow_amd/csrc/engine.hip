@@ -1430,7 +1430,7 @@ std::string flow_jit_spec_string(const af_engine* e, const FlowPlan& P, const af
     // (measured, round 3: the constant pays for the laws behind the call -- BASELINE config 5, log-normal: 245.4 -> 235.5 ms per
     // 50 000 replicas -- but NOT for the exponential law, whose variate is inline anyway: without the call site the compiler
     // allocates 72 instead of 110 VGPRs and the kernel is 6 % SLOWER (48.5 -> 51.6 ms on config 2), five waves per SIMD included)
-    if (dist_all == AF_DIST_EXPONENTIAL || std::getenv("AF_FLOW_NO_DIST_CONST")) dist_all = 255u;
+    if ((dist_all == AF_DIST_EXPONENTIAL && !std::getenv("AF_FLOW_DIST_CONST_EXP")) || std::getenv("AF_FLOW_NO_DIST_CONST")) dist_all = 255u;
     // waves per SIMD the LDS of this launch admits (160 KB per compute unit, four SIMDs): the register budget to compile for
     uint32_t wpe = 4u;
     if (const char* env = std::getenv("AF_FLOW_JIT_WPE")) wpe = (uint32_t)std::atoi(env);   // (measurement hook)
@@ -1456,7 +1456,13 @@ std::string flow_jit_spec_string(const af_engine* e, const FlowPlan& P, const af
                   L.cap, L.ring_rows, L.win_rows, L.g_ring, L.c_ring, L.pitch, L.list_arrays, L.off_spike, L.off_list, L.off_aux, L.off_aux3,
                   L.off_out, L.off_sorted, L.off_hist, L.off_seg, L.off_fr, L.off_gr, L.off_cnt, L.off_ring, L.n_words, L.cap_of[0],
                   L.cap_of[1], L.cap_of[2], L.cap_of[3], L.off_list_of[0], L.off_list_of[1], L.off_list_of[2], L.off_list_of[3], L.off_eb, L.off_gsrv);
-    return buf;
+    std::string spec(buf);
+    // Philox's key schedule per call site instead of hoisted (af_flow.hpp: Flow::edge_draw) where it was measured to pay -- the
+    // lean form and the forms with timeline marks (configs 2 / 4: 38.2 -> 37.9, 670 -> 653 ms); it costs on the others (FAR alone,
+    // config 3: 55.7 -> 56.4; general servers, config 6: 281 -> 293; config 5: nothing): profiles/r05/philox_keys_ab.txt
+    const bool keys = (P.feat == 0u || (P.feat & aff::FEAT_MARKS) != 0u) && (P.feat & aff::FEAT_GENSRV) == 0u;
+    if (keys && !std::getenv("AF_FLOW_KEYS_HOISTED")) spec += " -DAF_FJ_KEYS_PER_CALL=1";
+    return spec;
 }
 }  // namespace
 
