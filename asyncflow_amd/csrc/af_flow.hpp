@@ -634,7 +634,7 @@ struct Flow {
         // The empty asm makes the seed opaque at every call site: ten pairs of s_add per draw instead (config 2: 63 -> 45
         // v_readlane, 1 903 -> 1 869 VALU instructions).  A plan-specialised build asks for it where it was measured to pay
         // (engine.hip: flow_jit_spec_string); the register allocation of this kernel is chaotic, and it does not everywhere.
-        uint32_t sd_lo = (uint32_t)seed, sd_hi = (uint32_t)(seed >> 32);
+        uint32_t sd_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)seed), sd_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(seed >> 32));
         asm volatile("" : "+s"(sd_lo), "+s"(sd_hi));
         const af::U4 rr = af::draw_block(((uint64_t)sd_hi << 32) | sd_lo, stream, idx, 0u);
 #else
