@@ -77,14 +77,19 @@ def _summarize_synthetic(lats_list, starts_list=None, total_time=50, hist_bins=0
     return clocks, stats.cpu().numpy(), rps.cpu().numpy(), hist.cpu().numpy().view(np.uint32)
 
 
-@pytest.fixture(params=["codes", "clock_again"])
+@pytest.fixture(params=["codes", "clock_again", "codes_four_waves"])
 def last_pass(request, monkeypatch):
-    """Both forms of the analyzer's last pass: candidates found through the 16-bit codes pass 1 left in the engine's scratch
-    array (round 3; the default), or by reading the clock again (no scratch memory: AF_SUMMARY_NO_CODES)."""
+    """The forms of the analyzer's latency kernel: candidates found through the 16-bit codes pass 1 left in the engine's scratch
+    array (round 3; the default) or by reading the clock again (no scratch memory: AF_SUMMARY_NO_CODES), compiled for eight
+    waves per SIMD (four scenarios per CU, the default since round 5) or for four (AF_SUMMARY_WPE=4: `af_summary_kernel<4>`)."""
     if request.param == "clock_again":
         monkeypatch.setenv("AF_SUMMARY_NO_CODES", "1")
     else:
         monkeypatch.delenv("AF_SUMMARY_NO_CODES", raising=False)
+    if request.param == "codes_four_waves":
+        monkeypatch.setenv("AF_SUMMARY_WPE", "4")
+    else:
+        monkeypatch.delenv("AF_SUMMARY_WPE", raising=False)
     return request.param
 
 

@@ -3,6 +3,7 @@ code objects without a GPU; loading and running them is covered by tests/test_gp
 
 from __future__ import annotations
 
+import numpy as np
 import pytest
 
 from asyncflow_amd import jit
@@ -211,3 +212,44 @@ def test_the_bench_kernels_keep_their_state_out_of_scratch_memory(config, tmp_pa
     block = res.stderr[res.stderr.index("Function Name: af_flow_jit"):]
     scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", block).group(1))
     assert scratch <= 256, f"af_flow_jit of config {config} keeps {scratch} B per lane in scratch memory"
+
+
+def test_key_schedule_per_call_is_asked_for_where_it_was_measured_to_pay():
+    """Round 5: Philox's key schedule on the scalar unit at every call site (`-DAF_FJ_KEYS_PER_CALL`, af_flow.hpp: Flow::edge_draw)
+    is part of the spec of the lean form and of the forms with timeline marks -- BASELINE configs 2 and 4, where it is faster -- and
+    of no other (configs 3, 5 and the general-server workload: profiles/r05/philox_keys_ab.txt)."""
+    import bench
+
+    from asyncflow_amd.engine import PLAN_ONLY, Engine
+
+    asked = {}
+    for cfg in (2, 3, 4, 5, 6):
+        args = bench.make_parser().parse_args(["--config", str(cfg)])
+        args.horizon = None
+        shape = bench.rank_shape(bench.build_workload(cfg, 0, 1, 0, None), args)
+        eng = Engine(shape["plan"], PLAN_ONLY, **shape["engine_kw"])
+        hi = min(shape["slice"], shape["n"])
+        over = [(c, i, np.ascontiguousarray(v[:hi])) for c, i, v, _ in shape["over"]]
+        spec = eng.jit_spec(shape["seeds"][:hi], over, clock_ptr=8, clock_capacity=shape["clock_cap"], samples_ptr=8,
+                            tick_capacity=shape["ticks"], counts_ptr=8, draw_capacity=shape["clock_cap"])
+        eng.close()
+        asked[cfg] = "-DAF_FJ_KEYS_PER_CALL=1" in spec
+    assert asked == {2: True, 3: False, 4: True, 5: False, 6: False}
+
+
+def test_second_chance_tier_form_builds_with_the_key_schedule_per_call(tmp_path, monkeypatch):
+    """The first form of that change (an `asm` constraint on the seed without a `v_readfirstlane` in front) crashed the compiler
+    on a FEAT_CHAIN instantiation with timeline marks (the GPU suite's specialised-build test found it): the build of such a
+    plan is part of the CPU suite now."""
+    import random
+
+    from asyncflow_amd.runner import SimulationRunner
+    from oracle.scenarios import server_tiers
+
+    monkeypatch.setattr(jit, "CACHE_DIR", tmp_path)
+    runner = SimulationRunner(simulation_input=server_tiers(random.Random(91001), horizon=12), seeds=np.arange(8, dtype=np.uint64) + 50,
+                              specialise=True, on_negative_delay="flag")
+    spec = runner.prebuild()
+    assert "-DAF_FJ_KEYS_PER_CALL=1" in spec and "-DAF_FJ_FEAT=607" in spec
+    assert len(list(tmp_path.glob("*.hsaco"))) == 1
+
