@@ -9,11 +9,11 @@ from __future__ import annotations
 
 import ctypes as C
 
-AF_ABI_VERSION = 6
+AF_ABI_VERSION = 7
 
 # af_status
 MAX_REQUEST_CAPACITY = 65535   # include/asyncflow_hip.h AF_MAX_REQUEST_CAPACITY
-MAX_FIFO_CAPACITY = 16384      # AF_MAX_FIFO_CAPACITY
+MAX_FIFO_CAPACITY = 1 << 20    # AF_MAX_FIFO_CAPACITY (rounds 1-5: 16 384)
 COMM_ID_BYTES = 128            # AF_COMM_ID_BYTES
 AF_OK = 0
 AF_ERR_INVALID = -1
@@ -69,18 +69,16 @@ FLAG_RAM_STARVED = 16
 FLAG_TIME_TIE = 32
 FLAG_DRAW_OVERFLOW = 64
 FLAG_NEGATIVE_DELAY = 1 << 13
-FLAG_RAM_PUT_BLOCKED = 1 << 14
 FLAG_NAMES = {
     FLAG_POOL_OVERFLOW: "request pool overflow (raise request_capacity)",
     FLAG_FIFO_OVERFLOW: "server wait-queue overflow (raise fifo_capacity)",
     FLAG_CLOCK_OVERFLOW: "rqs_clock capacity overflow (raise clock_capacity)",
     FLAG_TICK_OVERFLOW: "sample capacity overflow",
-    FLAG_RAM_STARVED: "a request needs more RAM than the server owns (queue blocked, as in the reference)",
+    FLAG_RAM_STARVED: "a server's RAM queue is blocked for good, as in the reference: a request needs more RAM than the server owns, "
+                      "or a refused fractional RAM put faces a waiter that does not fit",
     FLAG_TIME_TIE: "a zero-delay timeout was created in the middle of a zero-time cascade (SimPy may order the pending steps differently)",
     FLAG_DRAW_OVERFLOW: "more arrivals than draw_capacity (raise clock_capacity)",
     FLAG_NEGATIVE_DELAY: "a message was sent with transit + spike < 0 (the reference raises ValueError 'Negative delay')",
-    FLAG_RAM_PUT_BLOCKED: "a fractional RAM need: `capacity - level >= amount` failed by one rounding when a request gave its RAM back -- "
-                          "the reference's simpy Container.put waits there, the engine does not (results differ from that instant on)",
 }
 FATAL_FLAGS = (
     FLAG_POOL_OVERFLOW | FLAG_FIFO_OVERFLOW | FLAG_CLOCK_OVERFLOW | FLAG_TICK_OVERFLOW | FLAG_DRAW_OVERFLOW

@@ -63,7 +63,6 @@ enum : uint32_t {
     FLAG_DRAW_OVERFLOW = 1u << 6,
     FLAG_SHARED_INSTANT = 1u << 7,  // internal: never visible in the outputs of af_engine_run
     FLAG_NEGATIVE_DELAY = 1u << 13, // transit + spike < 0 at a send (the reference raises "Negative delay")
-    FLAG_RAM_PUT_BLOCKED = 1u << 14, // capacity - level < amount at a RAM put by one rounding: simpy's Container.put would wait (AF_FLAG_RAM_PUT_BLOCKED)
 };
 enum : uint32_t {
     CNT_GENERATED = 0, CNT_COMPLETED, CNT_DROPPED, CNT_EVENTS, CNT_TICKS, CNT_FLAGS, CNT_MAX_LIVE, CNT_MARKS, CNT_SLOTS
@@ -125,23 +124,26 @@ AF_HD uint64_t d2u(double d) { return __builtin_bit_cast(uint64_t, d); }
 //   heap K/A/B [cap] each; edge [E][2] = {conn[0:15] | ring_ahead[16:23] | sends<<32, spike};
 //   draw rings [1+E][RING] (stream 0 = arrival times, 1+e = edge e transit times, staged
 //   from the pre-generated HBM arrays); optional per-scenario step-time column; server
-//   [S][5] = {cpu_free | ready<<32, io | arrivals<<32, ram_free, ram_in_use,
-//   cq_head | cq_n<<16 | rq_head<<32 | rq_n<<48 | blocked<<63}; wait queues
+//   [S][6] = {cpu_free | ready<<32, io | arrivals<<32, ram_free, ram_in_use,
+//   cq_head | cq_n<<32, rq_head | rq_n<<32 | blocked<<63}; wait queues
 //   [S][fcap][2] = {start time, state}; LB order [n_lb] (only used when n_lb > 8).
+//   (round 6: a queue word per queue -- rounds 1-5 packed both into one, 16- and 15-bit counts, which capped a server's
+//   queue at 16 384 waiters where the reference's simpy Container queue has no bound, server.py:146-149, 210-227)
 struct Layout {
     uint32_t cap;       // pending timed events (== requests in flight) per scenario
-    uint32_t fcap;      // per-server wait-queue capacity (power of two, <= 16384: rq_n is a 15-bit field)
+    uint32_t fcap;      // per-server wait-queue capacity (power of two, <= AF_MAX_FIFO_CAPACITY = 2^20)
     uint32_t ovr_mask;  // bit p set: af_param class p is overridden per scenario
     uint32_t hk, ha, hb, edge, ring, stime, srv, cq, rq, lb, n_words;
     uint32_t srvram, marks;   // per-scenario ram_mb [S] / timeline marks [MREC n_emarks + NREC n_smarks] (only when overridden)
     // per-scenario HBM scratch of the shared-timestamp path (64-bit words, plain array):
-    //   zero-time event FIFO [tcap][2] | node inbox items [tcap][2] | forwarder-busy bits
+    //   zero-time event FIFO [tcap][2] | node inbox items [tcap][2] | refused RAM puts [tcap][2] (they outlive the instant:
+    //   Lane::pb_n) | forwarder-busy bits
     uint32_t tcap, tie_words;
 };
 #ifndef AF_RING_LOW
 #define AF_RING_LOW 1
 #endif
-enum : uint32_t { LEDGE = 2, LSRV = 5, RING = 4, RING_LOW = AF_RING_LOW };
+enum : uint32_t { LEDGE = 2, LSRV = 6, RING = 4, RING_LOW = AF_RING_LOW };
 
 AF_HD Layout make_layout(uint32_t cap, uint32_t fcap, uint32_t n_edges, uint32_t n_servers, uint32_t n_lb,
                          uint32_t n_rows, uint32_t ovr_mask, uint32_t n_emarks = 0u, uint32_t n_smarks = 0u) {
@@ -166,7 +168,7 @@ AF_HD Layout make_layout(uint32_t cap, uint32_t fcap, uint32_t n_edges, uint32_t
     uint32_t tc = 16u;
     while (tc < 2u * cap + 8u) tc <<= 1;
     L.tcap = tc;
-    L.tie_words = 4u * tc + (2u + n_servers + 63u) / 64u + 17u;  // + Lane::PARK_WORDS at the end
+    L.tie_words = 6u * tc + (2u + n_servers + 63u) / 64u + 17u;  // + Lane::PARK_WORDS at the end
     return L;
 }
 AF_HD uint64_t layout_bytes_per_lane(const Layout& L) { return 8ull * L.n_words; }
@@ -292,6 +294,7 @@ struct LaneRegs {
     uint32_t fl;
     uint32_t heap_n, seq, live, max_live, lb_n, emark_i, smark_i;
     uint32_t n_gen, n_comp, n_drop, n_events, n_ticks, n_marks, flags;
+    uint32_t pb_n;       // RAM puts simpy's Container refused and that still wait (micro_mode; 0 unless needs are fractional)
 };
 
 template <bool kFaithful> struct RoundType { using type = uint32_t; };
@@ -460,7 +463,12 @@ struct Lane : LaneRegs {
     }
 
     // ---- server wait queues: rings of (start time, state) ---------------------------
-    // q word: cq_head[0:15] | cq_n[16:31] | rq_head[32:47] | rq_n[48:62] | ram_blocked[63]
+    // queue words: [4] cq_head[0:31] | cq_n[32:63]; [5] rq_head[0:31] | rq_n[32:62] | ram_blocked[63]
+    AF_CORE static uint32_t q_head(uint64_t q) { return (uint32_t)q; }
+    AF_CORE static uint32_t q_n(uint64_t q) { return (uint32_t)(q >> 32) & 0x7FFFFFFFu; }
+    AF_CORE uint64_t q_popped(uint64_t q) const {   // head + 1 (ring), n - 1; bit 63 stays
+        return (q & (1ull << 63)) | (uint64_t)((q_head(q) + 1u) & (L.fcap - 1u)) | ((uint64_t)(q_n(q) - 1u) << 32);
+    }
     AF_CORE bool q_push(uint32_t base, uint32_t sv, uint32_t head, uint32_t n, uint64_t a, uint32_t state) {
         if (n >= L.fcap) {
             flags |= FLAG_FIFO_OVERFLOW;
@@ -565,15 +573,12 @@ struct Lane : LaneRegs {
     AF_CORE void cpu_release(uint32_t sv) {
         const uint32_t at = L.srv + LSRV * sv;
         const uint64_t q = M.ld(at + 4u);
-        const uint32_t cqn = (uint32_t)(q >> 16) & 0xFFFFu;
-        if (cqn > 0u) {
-            const uint32_t head = (uint32_t)q & 0xFFFFu;
-            const uint32_t from = L.cq + 2u * (sv * L.fcap + head);
+        if (q_n(q) > 0u) {
+            const uint32_t from = L.cq + 2u * (sv * L.fcap + q_head(q));
             grant_a = M.ld(from);
             grant_st = (uint32_t)M.ld(from + 1u);
             fl |= F_GRANT;
-            const uint64_t nq = (q & ~0xFFFFFFFFull) | ((head + 1u) & (L.fcap - 1u)) | ((uint64_t)(cqn - 1u) << 16);
-            M.st(at + 4u, nq);
+            M.st(at + 4u, q_popped(q));
         } else {
             M.st(at, M.ld(at) + 1ull);  // cpu_free += 1
         }
@@ -589,12 +594,12 @@ struct Lane : LaneRegs {
             if (!core_locked) {
                 const uint64_t w0 = M.ld(at);  // cpu_free | ready<<32
                 const uint64_t q = M.ld(at + 4u);
-                const uint32_t cqn = (uint32_t)(q >> 16) & 0xFFFFu;
+                const uint32_t cqn = q_n(q);
                 if (cqn == 0u && (uint32_t)w0 > 0u) {
                     M.st(at, w0 - 1ull);  // granted at once: not in the ready queue
                 } else {
-                    if (q_push(L.cq, sv, (uint32_t)q & 0xFFFFu, cqn, a, st_pack(RK_WAIT, sv, hops, 0u, step))) {
-                        M.st(at + 4u, q + (1ull << 16));
+                    if (q_push(L.cq, sv, q_head(q), cqn, a, st_pack(RK_WAIT, sv, hops, 0u, step))) {
+                        M.st(at + 4u, q + (1ull << 32));
                         M.st(at, w0 + (1ull << 32));  // ready += 1
                     }
                     return;
@@ -615,9 +620,11 @@ struct Lane : LaneRegs {
         const double ram = u2d(P.row[TREC * step + 1u]);
         if (ram > 0.0) {
             M.st(at + 3u, d2u(u2d(M.ld(at + 3u)) - ram));  // ram_in_use
-            if (ram_cap(sv) - u2d(M.ld(at + 2u)) < ram) flags |= FLAG_RAM_PUT_BLOCKED;   // (Container._do_put: the reference would wait)
+            // Container._do_put (`if capacity - level >= amount`) cannot refuse here: plans whose needs are not multiples
+            // of 1/256 MB -- the only ones whose sums round -- run every request event through micro_mode
+            // (af_plan_pack.hpp::every_event_in_order), which models the waiting put (m_srv_finish).
             M.st(at + 2u, d2u(u2d(M.ld(at + 2u)) + ram));  // ram container level
-            if (((M.ld(at + 4u) >> 48) & 0x7FFFu) > 0u) fu_ram_sv = (int32_t)sv;
+            if (q_n(M.ld(at + 5u)) > 0u) fu_ram_sv = (int32_t)sv;
         }
         // with RAM to give back, `yield RAM.put` lets the CPU waiter resume first (server.py:273-276);
         // without, transport() runs in the same step and its Timeout is created first
@@ -631,14 +638,12 @@ struct Lane : LaneRegs {
     AF_CORE void ram_stage() {
         const uint32_t sv = (uint32_t)fu_ram_sv;
         const uint32_t at = L.srv + LSRV * sv;
-        const uint64_t q = M.ld(at + 4u);
-        const uint32_t rqn = (uint32_t)(q >> 48) & 0x7FFFu;
-        if (rqn == 0u) {
+        const uint64_t q = M.ld(at + 5u);
+        if (q_n(q) == 0u) {
             fu_ram_sv = -1;
             return;
         }
-        const uint32_t head = (uint32_t)(q >> 32) & 0xFFFFu;
-        const uint32_t from = L.rq + 2u * (sv * L.fcap + head);
+        const uint32_t from = L.rq + 2u * (sv * L.fcap + q_head(q));
         const uint64_t a = M.ld(from);
         const uint32_t st = (uint32_t)M.ld(from + 1u);
         const uint32_t step = st_step(st);
@@ -648,9 +653,7 @@ struct Lane : LaneRegs {
             fu_ram_sv = -1;
             return;
         }
-        const uint64_t nq = (q & ~(0x7FFFFFFFull << 32)) | ((uint64_t)((head + 1u) & (L.fcap - 1u)) << 32) |
-                            ((uint64_t)(rqn - 1u) << 48);
-        M.st(at + 4u, nq);
+        M.st(at + 5u, q_popped(q));
         M.st(at + 2u, d2u(free_ram - need));
         M.st(at + 3u, d2u(u2d(M.ld(at + 3u)) + need));
         fl = (fl & ~(F_ADV_CORE | F_ADV_IO)) | F_ADV;  // keep fu_ram_sv: the queue is looked at again after this waiter
@@ -674,23 +677,23 @@ struct Lane : LaneRegs {
         const double ram = u2d(P.ep[PREC * ep]);
         const uint32_t step0 = (uint32_t)P.ep[PREC * ep + 1u];
         if (ram > 0.0) {  // server.py:146-149
-            const uint64_t q = M.ld(at + 4u);
+            const uint64_t q = M.ld(at + 5u);
             if (ram > ram_cap(sv) || (q >> 63)) {
                 // can never be served: it (and everything queued behind it) waits
                 // forever in the reference, observable nowhere -> dropped here.
                 flags |= FLAG_RAM_STARVED;
-                M.st(at + 4u, q | (1ull << 63));
+                M.st(at + 5u, q | (1ull << 63));
                 live -= 1u;
                 return;
             }
             const double free_ram = u2d(M.ld(at + 2u));
-            const uint32_t rqn = (uint32_t)(q >> 48) & 0x7FFFu;
+            const uint32_t rqn = q_n(q);
             if (rqn == 0u && free_ram >= ram) {
                 M.st(at + 2u, d2u(free_ram - ram));
                 M.st(at + 3u, d2u(u2d(M.ld(at + 3u)) + ram));
             } else {
-                if (q_push(L.rq, sv, (uint32_t)(q >> 32) & 0xFFFFu, rqn, a, st_pack(RK_WAIT, sv, hops, 0u, step0)))
-                    M.st(at + 4u, q + (1ull << 48));
+                if (q_push(L.rq, sv, q_head(q), rqn, a, st_pack(RK_WAIT, sv, hops, 0u, step0)))
+                    M.st(at + 5u, q + (1ull << 32));
                 return;
             }
         }
@@ -925,9 +928,9 @@ struct Lane : LaneRegs {
         return false;
     }
     // forwarder of a node is between `box.get()` succeeding and its next `box.get()`
-    AF_CORE bool busy(uint32_t node) const { return (D.tie[4u * L.tcap + (node >> 6)] >> (node & 63u)) & 1ull; }
+    AF_CORE bool busy(uint32_t node) const { return (D.tie[6u * L.tcap + (node >> 6)] >> (node & 63u)) & 1ull; }
     AF_CORE void set_busy(uint32_t node, bool v) {
-        uint64_t& w = D.tie[4u * L.tcap + (node >> 6)];
+        uint64_t& w = D.tie[6u * L.tcap + (node >> 6)];
         w = v ? (w | (1ull << (node & 63u))) : (w & ~(1ull << (node & 63u)));
     }
     AF_CORE void m_urgent(uint32_t k, uint64_t a, uint32_t idx, uint32_t hops) {
@@ -977,12 +980,10 @@ struct Lane : LaneRegs {
         uint64_t w0 = M.ld(at);
         uint64_t q = M.ld(at + 4u);
         uint32_t g = 0u;
-        while (((uint32_t)(q >> 16) & 0xFFFFu) > 0u && (uint32_t)w0 > 0u) {
-            const uint32_t head = (uint32_t)q & 0xFFFFu;
-            const uint32_t cqn = (uint32_t)(q >> 16) & 0xFFFFu;
-            const uint32_t from = L.cq + 2u * (sv * L.fcap + head);
+        while (q_n(q) > 0u && (uint32_t)w0 > 0u) {
+            const uint32_t from = L.cq + 2u * (sv * L.fcap + q_head(q));
             mq_push(MK_CPU_GOT, M.ld(from), (uint32_t)M.ld(from + 1u), 0u, g < n_old ? 1u : 0u);
-            q = (q & ~0xFFFFFFFFull) | ((head + 1u) & (L.fcap - 1u)) | ((uint64_t)(cqn - 1u) << 16);
+            q = q_popped(q);
             w0 -= 1ull;  // level -= 1
             g += 1u;
         }
@@ -993,20 +994,73 @@ struct Lane : LaneRegs {
     AF_CORE void m_ram_trigger(uint32_t sv) {  // head-of-line blocking FIFO
         const uint32_t at = L.srv + LSRV * sv;
         for (;;) {
-            const uint64_t q = M.ld(at + 4u);
-            const uint32_t rqn = (uint32_t)(q >> 48) & 0x7FFFu;
-            if (rqn == 0u) break;
-            const uint32_t head = (uint32_t)(q >> 32) & 0xFFFFu;
-            const uint32_t from = L.rq + 2u * (sv * L.fcap + head);
+            const uint64_t q = M.ld(at + 5u);
+            if (q_n(q) == 0u) break;
+            const uint32_t from = L.rq + 2u * (sv * L.fcap + q_head(q));
             const uint64_t a = M.ld(from);
             const uint32_t st = (uint32_t)M.ld(from + 1u);
             const double need = u2d(P.row[TREC * st_step(st) + 1u]);
             const double free_ram = u2d(M.ld(at + 2u));
             if (free_ram < need) break;
-            M.st(at + 4u, (q & ~(0x7FFFFFFFull << 32)) | ((uint64_t)((head + 1u) & (L.fcap - 1u)) << 32) |
-                              ((uint64_t)(rqn - 1u) << 48));
+            M.st(at + 5u, q_popped(q));
             M.st(at + 2u, d2u(free_ram - need));
             mq_push(MK_RAM_GOT, a, st);
+        }
+    }
+    // ---- the RAM container's PUT queue (simpy BaseResource.put_queue; only ever non-empty with fractional needs) ----
+    // `Container._do_put` succeeds `if capacity - level >= amount`.  In exact arithmetic capacity - level is the sum of what is
+    // held and the test cannot fail; with a need like 100.3 MB it fails by ONE ROUNDING (2048 - fl(2048 - 100.3) < 100.3) and
+    // `yield RAM.put(total_ram)` (server.py:273) WAITS: the put stays in the queue, every later put of that server queues
+    // behind it (`_trigger_put` walks from the head and stops at the first refusal), and the queue is walked again by every
+    // new put and when a RAM get of that server is PROCESSED (`_trigger_put` is the get's first callback) -- the level that
+    // get took lets the put through, and the response leaves then.  Entries: (start time, state) of the request, all servers
+    // in ONE list in arrival order (a server's subsequence is its FIFO), in the scenario's HBM scratch.
+    AF_CORE bool pb_has(uint32_t sv) const {
+        for (uint32_t i = 0u; i < pb_n; ++i)
+            if (st_idx((uint32_t)D.tie[4u * L.tcap + 2u * i + 1u]) == sv) return true;
+        return false;
+    }
+    // BaseResource._trigger_put of server sv's RAM container
+    AF_CORE void m_put_trigger(uint32_t sv) {
+        if (pb_n == 0u) return;
+        const uint32_t at = L.srv + LSRV * sv;
+        const uint32_t base = 4u * L.tcap;
+        uint32_t i = 0u;
+        while (i < pb_n) {
+            const uint32_t st = (uint32_t)D.tie[base + 2u * i + 1u];
+            if (st_idx(st) != sv) {
+                i += 1u;
+                continue;
+            }
+            const double amount = u2d(P.row[TREC * st_step(st) + 1u]);
+            const double level = u2d(M.ld(at + 2u));
+            if (!(ram_cap(sv) - level >= amount)) break;  // `if not proceed: break` (head-of-line)
+            M.st(at + 2u, d2u(level + amount));
+            mq_push(MK_RAM_PUT, D.tie[base + 2u * i], st);  // event.succeed()
+            for (uint32_t k = i + 1u; k < pb_n; ++k) {
+                D.tie[base + 2u * (k - 1u)] = D.tie[base + 2u * k];
+                D.tie[base + 2u * (k - 1u) + 1u] = D.tie[base + 2u * k + 1u];
+            }
+            pb_n -= 1u;
+        }
+    }
+    // A refused put at the head of the put queue AND a waiter at the head of the get queue that does not fit: the level can
+    // never change again (puts and gets are both head-of-line blocked, and nothing else moves it), so every later RAM request
+    // of this server waits for good, like behind a starved one -- same bit, same report; they need not be kept.
+    AF_CORE void m_ram_deadlock_check(uint32_t sv) {
+        const uint32_t at = L.srv + LSRV * sv;
+        const uint64_t q = M.ld(at + 5u);
+        if ((q >> 63) || q_n(q) == 0u || pb_n == 0u) return;
+        const double level = u2d(M.ld(at + 2u));
+        const uint32_t hst = (uint32_t)M.ld(L.rq + 2u * (sv * L.fcap + q_head(q)) + 1u);
+        if (level >= u2d(P.row[TREC * st_step(hst) + 1u])) return;   // the get at the head fits (it is served when a put is processed)
+        for (uint32_t i = 0u; i < pb_n; ++i) {
+            const uint32_t st = (uint32_t)D.tie[4u * L.tcap + 2u * i + 1u];
+            if (st_idx(st) != sv) continue;
+            if (ram_cap(sv) - level >= u2d(P.row[TREC * st_step(st) + 1u])) return;   // the put at the head goes through at the next walk
+            flags |= FLAG_RAM_STARVED;
+            M.st(at + 5u, q | (1ull << 63));
+            return;
         }
     }
     // tail of _handle_request once the core is back (server.py:261-276)
@@ -1016,8 +1070,21 @@ struct Lane : LaneRegs {
         const double ram = u2d(P.row[TREC * step + 1u]);
         if (ram > 0.0) {
             M.st(at + 3u, d2u(u2d(M.ld(at + 3u)) - ram));
-            if (ram_cap(sv) - u2d(M.ld(at + 2u)) < ram) flags |= FLAG_RAM_PUT_BLOCKED;
-            M.st(at + 2u, d2u(u2d(M.ld(at + 2u)) + ram));  // ContainerPut succeeds at once (unless the flag says otherwise)
+            // ContainerPut.__init__: append to the put queue, _trigger_put(None)
+            const double level = u2d(M.ld(at + 2u));
+            if ((pb_n != 0u && pb_has(sv)) || !(ram_cap(sv) - level >= ram)) {
+                if (pb_n >= L.tcap) {
+                    flags |= FLAG_POOL_OVERFLOW;
+                    return;
+                }
+                D.tie[4u * L.tcap + 2u * pb_n] = a;
+                D.tie[4u * L.tcap + 2u * pb_n + 1u] = (uint64_t)st_pack(RK_WAIT, sv, hops, 0u, step);
+                pb_n += 1u;
+                m_put_trigger(sv);   // (the walk a new put starts: the head may fit by now)
+                m_ram_deadlock_check(sv);
+                return;
+            }
+            M.st(at + 2u, d2u(level + ram));
             mq_push(MK_RAM_PUT, a, st_pack(RK_WAIT, sv, hops, 0u, step));
             return;
         }
@@ -1031,9 +1098,9 @@ struct Lane : LaneRegs {
             if (in_io) M.st(at + 1u, M.ld(at + 1u) - 1ull);
             if (!core_locked) {  // cpu_req = CPU.get(1): append, trigger, `if not cpu_req.triggered`
                 const uint64_t q = M.ld(at + 4u);
-                const uint32_t cqn = (uint32_t)(q >> 16) & 0xFFFFu;
-                if (!q_push(L.cq, sv, (uint32_t)q & 0xFFFFu, cqn, a, st_pack(RK_WAIT, sv, hops, 0u, step))) return;
-                M.st(at + 4u, q + (1ull << 16));
+                const uint32_t cqn = q_n(q);
+                if (!q_push(L.cq, sv, q_head(q), cqn, a, st_pack(RK_WAIT, sv, hops, 0u, step))) return;
+                M.st(at + 4u, q + (1ull << 32));
                 if (m_cpu_trigger(sv, cqn) <= cqn) M.st(at, M.ld(at) + (1ull << 32));  // still queued: ready += 1
                 return;
             }
@@ -1071,17 +1138,17 @@ struct Lane : LaneRegs {
         const double ram = u2d(P.ep[PREC * ep]);
         const uint32_t step0 = (uint32_t)P.ep[PREC * ep + 1u];
         if (ram > 0.0) {
-            const uint64_t q = M.ld(at + 4u);
+            const uint64_t q = M.ld(at + 5u);
             if (ram > ram_cap(sv) || (q >> 63)) {  // same treatment as server_arrival
                 flags |= FLAG_RAM_STARVED;
-                M.st(at + 4u, q | (1ull << 63));
+                M.st(at + 5u, q | (1ull << 63));
                 live -= 1u;
                 return;
             }
-            if (q_push(L.rq, sv, (uint32_t)(q >> 32) & 0xFFFFu, (uint32_t)(q >> 48) & 0x7FFFu, a,
-                       st_pack(RK_WAIT, sv, hops, 0u, step0))) {
-                M.st(at + 4u, q + (1ull << 48));
+            if (q_push(L.rq, sv, q_head(q), q_n(q), a, st_pack(RK_WAIT, sv, hops, 0u, step0))) {
+                M.st(at + 5u, q + (1ull << 32));
                 m_ram_trigger(sv);
+                m_ram_deadlock_check(sv);
             }
             return;  // yield RAM.get(total_ram)
         }
@@ -1188,7 +1255,8 @@ struct Lane : LaneRegs {
                     break;
                 }
                 case MK_CBOX_PUT: m_forwarder_get(0u); break;
-                case MK_RAM_GOT: {  // server.py:149-150
+                case MK_RAM_GOT: {  // server.py:149-150; the get's first callback is the container's _trigger_put
+                    m_put_trigger(sv);
                     const uint32_t at = L.srv + LSRV * sv;
                     M.st(at + 3u, d2u(u2d(M.ld(at + 3u)) + u2d(P.row[TREC * step + 1u])));
                     m_srv_continue(ra, sv, step, hops, false, false);
@@ -1247,7 +1315,8 @@ struct Lane : LaneRegs {
         q_gen = 2u;
         q_tick = 3u;
         seq = 4u;
-        for (uint32_t i = 0u; i < (2u + P.n_servers + 63u) / 64u; ++i) D.tie[4u * L.tcap + i] = 0ull;
+        for (uint32_t i = 0u; i < (2u + P.n_servers + 63u) / 64u; ++i) D.tie[6u * L.tcap + i] = 0ull;
+        pb_n = 0u;
         flags = D.flags_in;
         fl = 0u;
         pend_count = 0u;
@@ -1265,6 +1334,7 @@ struct Lane : LaneRegs {
             M.st(at + 2u, P.srv[SREC * v]);  // RAM level = ram_mb
             M.st(at + 3u, d2u(0.0));
             M.st(at + 4u, 0ull);
+            M.st(at + 5u, 0ull);
         }
         lb_n = P.n_lb_edges;
         lb_list = 0ull;
@@ -1463,7 +1533,7 @@ struct Lane : LaneRegs {
         dst[13] = n_gen | ((uint64_t)n_comp << 32);
         dst[14] = n_drop | ((uint64_t)n_events << 32);
         dst[15] = n_ticks | ((uint64_t)n_marks << 32);
-        dst[16] = flags;
+        dst[16] = flags | ((uint64_t)pb_n << 32);
     }
     AF_CORE void unpark_regs(const volatile uint64_t* src) {
         now = u2d(src[0]); t_gen = u2d(src[1]); t_tick = u2d(src[2]); t_emark = u2d(src[3]); t_smark = u2d(src[4]);
@@ -1480,7 +1550,8 @@ struct Lane : LaneRegs {
         n_gen = (uint32_t)w13; n_comp = (uint32_t)(w13 >> 32);
         n_drop = (uint32_t)w14; n_events = (uint32_t)(w14 >> 32);
         n_ticks = (uint32_t)w15; n_marks = (uint32_t)(w15 >> 32);
-        flags = (uint32_t)src[16];
+        const uint64_t w16 = src[16];
+        flags = (uint32_t)w16; pb_n = (uint32_t)(w16 >> 32);
         pend_count = 0u;
         fu_ram_sv = -1;
     }

@@ -61,7 +61,7 @@ enum : uint32_t {
     FLOW_WHY_LIST = 1u << 10,       // more messages pending at a station than the list holds
     FLOW_WHY_RING = 1u << 11,       // an interval reaches further ahead than the tick ring
     FLOW_WHY_RAM = 1u << 12,        // a request would have to wait for RAM
-    // (bits 13, 14: AF_FLAG_NEGATIVE_DELAY, AF_FLAG_RAM_PUT_BLOCKED)
+    // (bit 13: AF_FLAG_NEGATIVE_DELAY)
     FLOW_WHY_GEN_TIE = 1u << 15,    // the tie is one the general server station gives up on (an arrival exactly at a step end, two
                                     // responses at one instant): the second-chance instantiation would stop at the same instant, so
                                     // such a scenario goes straight to the next-event kernels; set together with FLOW_WHY_TIE
@@ -2489,7 +2489,9 @@ struct Flow {
                     uint32_t par_done = 0u;
                     const bool solved = gen_servers_par(level, H_get(kChain ? level_slot(level) : 2u), par_done);
                     W::sync();   // (every lane has read the servers' state before a lane's gen_servers() changes it)
-                    gs_rounds += solved ? 0x10000u : 1u;   // (diagnostic: rounds solved at once | rounds walked event by event)
+                    // (diagnostic: rounds solved at once << 16 | rounds walked event by event; each half saturates on its own)
+                    if (solved) gs_rounds += (gs_rounds >> 16) < 0xFFFFu ? 0x10000u : 0u;
+                    else gs_rounds += (gs_rounds & 0xFFFFu) < 0xFFFFu ? 1u : 0u;
                     if (!solved && my_pass) done = gen_servers(lane, H_get(kChain ? level_slot(level) : 2u));
                     W::sync();
                     work += solved ? par_done : popc64(W::ballot(done != 0u));
@@ -2693,7 +2695,7 @@ struct Flow {
             c[af::CNT_TICKS] = A.n_ticks;
             c[af::CNT_FLAGS] = flags;
             // a diagnostic: the sequential kernels' peak of live requests; FEAT_GENSRV: how the server station's rounds were run
-            c[af::CNT_MAX_LIVE] = kGen ? ((gs_rounds >> 16 > 0xFFFFu ? 0xFFFFu : gs_rounds >> 16) << 16) | ((gs_rounds & 0xFFFFu)) : 0u;
+            c[af::CNT_MAX_LIVE] = kGen ? gs_rounds : 0u;
             c[af::CNT_MARKS] = marks;
         }
         if (kProf) {

@@ -92,7 +92,19 @@ inline std::string pack_plan(const af_plan_t& p, PackedPlan& out) {
 // delivery is queued between the zero-time steps of the sending server's cascade, which the inline
 // cascades cannot express.  Such plans (none of the reference's own examples) run every request event
 // through the SimPy-order path.
+// So do plans with a RAM need that is not a multiple of 1/256 MB (100.3, 64.7): the f64 sums of such needs round, simpy's
+// `Container._do_put` (`if capacity - level >= amount`) can then refuse a put by one rounding, and the response waits for the
+// next RAM get of that server (server.py:270-276) -- modelled by the SimPy-order path only (af_core.hpp::m_srv_finish).  Whole
+// megabytes and multiples of 1/256 MB (every example of the reference) have exact sums and never meet it.
 inline bool every_event_in_order(const af_plan_t& p) {
+    for (uint32_t ep = 0; ep < p.n_endpoints; ++ep) {
+        const double fine = p.ep_ram[ep] * 256.0;
+        if (fine != (double)(int64_t)fine || p.ep_ram[ep] > 4194304.0) return true;
+    }
+    for (uint32_t s = 0; s < p.n_servers; ++s) {
+        const double fine = p.srv_ram_mb[s] * 256.0;
+        if (fine != (double)(int64_t)fine) return true;
+    }
     for (uint32_t s = 0; s < p.n_servers; ++s) {
         const int32_t e = p.srv_out_edge[s];
         if (e < 0) continue;

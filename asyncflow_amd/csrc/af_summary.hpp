@@ -5,24 +5,31 @@
 // (/root/reference src/asyncflow/metrics/analyzer.py:83-126):
 //   latencies = finish - start;  total, np.mean, np.median, np.std, np.percentile(95 / 99),
 //   np.min, np.max;  RPS windows (k-1, k] for k = 1..floor(total_simulation_time).
-// Order statistics are EXACT (bit-equal to numpy's partition + linear interpolation, including
-// its "t >= 0.5" lerp branch); mean/std are deterministic tree sums (numpy sums pairwise, so those
-// two agree to ~1e-13 relative, not bit for bit).
+// EVERY statistic is bit-equal to numpy's: the order statistics (partition + linear interpolation, including its "t >= 0.5"
+// lerp branch) since round 2, mean and standard deviation since round 6 -- the kernel adds in numpy's own order:
+//   np.add.reduce over a contiguous f64 array calls DOUBLE_add's reduce loop on pieces of at most 8 192 elements (the ufunc
+//   buffer size) and adds the pieces' sums one after the other onto the identity; a piece is summed by DOUBLE_pairwise_sum
+//   (numpy/_core/src/umath/loops_utils.h.src): n < 8: one after the other; n <= 128: eight running sums r[j] over the elements
+//   j, j + 8, j + 16, ..., then ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)), then the n % 8 elements left over one by one;
+//   larger: the first n2 = (n / 2) - (n / 2) % 8 elements and the rest, recursively, added.
+//   np.mean = that sum / n; np.std = sqrt(the same sum over (x - mean)^2, / n)   (_methods.py::_mean / _var).
+// A full piece is therefore a PERFECT tree over 64 leaves of 128 elements (16 rows of 8): one piece per step of the
+// workgroup, an 8-lane group per leaf, a lane per running sum -- every load instruction of a group is one full 128-byte line --
+// and the tree is six butterfly exchanges plus eight values through LDS.  The last, partial piece has leaves of 64 .. 128
+// elements found by walking the recursion down from every 64-th element; its sums meet in 128 LDS slots (a leaf of depth d
+// with path p sits at p << (7 - d); absent slots are skipped, so the additions are exactly the recursion's).
 //
-// HBM-bound: one workgroup per scenario streams that scenario's rqs_clock rows (16 B per
-// completed request) TWICE in the common case (three times in round 1):
+// HBM-bound: one workgroup per scenario streams that scenario's rqs_clock rows (16 B per completed request) TWICE:
 //   pass 1  sum / min / max / RPS buckets / histogram of the f64 exponent field -- and, for the (<= 3)
 //           exponent bins in which the first 512 latencies put the wanted ranks, already the next 10 key
 //           bits: when the guess covers every wanted rank (latencies of one scenario span 2-3 binades)
 //           the first radix level costs no pass of its own
 //   pass 2+ (only while a wanted rank still has > kCand candidates) 10 more key bits per pass,
 //           MSB-first radix select, all wanted ranks at once
-//   last    gather the <= kCand candidates of every wanted rank into LDS, accumulate the squared
-//           deviations, then select by counting
-// Round 3: with a scratch array of one 16-bit code per completion (SumArgs::codes: which guessed exponent bin, which of its
-// 1 024 digit bins) pass 1 leaves behind what the last pass needs to FIND the candidates, and carries the squared deviations
-// itself (about a shift taken from the first 512 latencies): the last pass then reads 2 bytes per completion instead of 16
-// and fetches only the candidates' rows -- 1.25 reads of the clock's bytes instead of 2.
+//   last    the squared deviations about the mean (which only exists after pass 1: numpy's two-pass variance cannot be had
+//           in one), and on the way the <= kCand candidates of every wanted rank into LDS; then select by counting
+// (Round 3 - 5 had a scratch array of 16-bit codes instead of the second read, and a one-pass shifted variance that agreed
+// with numpy to 1e-13: 1.25 reads of the clock's bytes instead of 2.  Bit-equality costs the other 0.75.)
 // No sort, no atomics on floating point (results are run-to-run deterministic).
 #pragma once
 
@@ -36,8 +43,10 @@ constexpr int kThreads = 512;   // (1 024 threads, two scenarios per CU, in the 
 constexpr int kWaves = kThreads / 64;
 constexpr int kRanks = 6;       // median lo/hi, p95 lo/hi, p99 lo/hi
 constexpr int kCand = 512;      // candidates per rank resolved in LDS
-constexpr int kPerThread = 8;   // completions per thread and step of pass 1
-constexpr uint32_t kBlock = kThreads * kPerThread;   // ... per workgroup: the codes of one step are stored thread by thread
+constexpr uint32_t kPiece = 8192;   // numpy's reduction buffer: elements per call of the pairwise sum = per step of a workgroup
+constexpr int kLeafRows = 16;       // a full piece's leaf: 128 elements = 16 rows of 8
+constexpr int kTailSlots = 128;     // leaves of the partial piece (64 .. 128 elements each, < 8 192 together)
+constexpr unsigned long long kAbsent = 0xFFF8DEADBEEF0000ull;   // an LDS slot no leaf was written to (a NaN no sum can be)
 constexpr int kExpBins = 2048;  // level 0: bits 62..52 (latencies are >= +0.0, the sign bit is clear)
 constexpr int kDigBits = 10;    // deeper levels: 10 key bits each
 constexpr int kDigBins = 1 << kDigBits;
@@ -53,8 +62,6 @@ struct SumArgs {
     uint32_t* hist;  // [n][hist_bins] or null
     uint32_t hist_bins;
     double hist_scale;  // hist_bins / hist_max
-    uint16_t* codes;      // [n][code_pitch] scratch or null (then the last pass reads the clock again)
-    uint32_t code_pitch;  // multiple of kBlock
 };
 
 __device__ inline double wave_sum(double v) {
@@ -97,6 +104,111 @@ __device__ inline double block_sum(double v, double* scratch /* [kWaves] */) {
     double r = 0.0;
     for (int w = 0; w < kWaves; ++w) r += scratch[w];
     return r;
+}
+
+// The 8 lanes of a group hold 8 consecutive completions -- nearly always one 1-s window: one LDS atomic per group instead
+// of one per lane (64 lanes on one LDS word serialise; round 3 found pass 1 LDS-bound on exactly that).  Called by every
+// lane of the wave from uniform control flow; a group's first lane is active whenever any of its lanes is.
+__device__ inline void group_agg_add(uint32_t* base, uint32_t idx, bool active) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t lead = (uint32_t)__shfl((int)idx, lane & ~7, 64);
+    const bool same = active && idx == lead;
+    const uint32_t grp = (uint32_t)(__ballot(same) >> (lane & ~7)) & 0xFFu;
+    if ((lane & 7) == 0 && grp != 0u) atomicAdd(&base[lead], (uint32_t)__popc(grp));
+    if (active && !same) atomicAdd(&base[idx], 1u);
+}
+
+__device__ inline double xor_add(double v, int m) { return v + __shfl_xor(v, m, 64); }   // (a + b == b + a bit for bit)
+
+// numpy's np.add.reduce over the n values elem(row i) of a scenario, in numpy's own order (the head of this file).  `elem`
+// is called once per completion by the lane that owns it -- and by every other lane of the wave with act = false (it may
+// hold wave-wide operations) -- and returns the value to be added.  wsum: [2][kWaves] doubles, slots: [kTailSlots] doubles.
+template <int kLoads, class Elem>
+__device__ __forceinline__ double numpy_sum(const double2* ck, uint32_t n, double* wsum, double* slots, Elem&& elem) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t j = (uint32_t)tid & 7u, g = (uint32_t)tid >> 3;
+    double tot = 0.0;   // the reduction starts from the identity
+    const uint32_t n_full = n / kPiece;
+    for (uint32_t c = 0; c < n_full; ++c) {   // a full piece: leaf g = elements [128 g, 128 g + 128), lane j its running sum r[j]
+        const double2* p = ck + (size_t)c * kPiece + g * 128u + j;
+        double acc = -0.0;   // (-0.0 + x == x for every x: the first row needs no case of its own)
+#pragma unroll 1
+        for (int r0 = 0; r0 < kLeafRows; r0 += kLoads) {
+            double2 cc[kLoads];
+#pragma unroll
+            for (int v = 0; v < kLoads; ++v) cc[v] = p[(r0 + v) * 8];
+#pragma unroll
+            for (int v = 0; v < kLoads; ++v) acc = acc + elem(cc[v], true);
+        }
+        acc = xor_add(acc, 1); acc = xor_add(acc, 2); acc = xor_add(acc, 4);      // ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7))
+        acc = xor_add(acc, 8); acc = xor_add(acc, 16); acc = xor_add(acc, 32);    // the wave's eight leaves, pairwise
+        double* ws = wsum + (c & 1u) * kWaves;   // (two buffers: one barrier per piece)
+        if (lane == 0) ws[wave] = acc;
+        __syncthreads();
+        tot = tot + (((ws[0] + ws[1]) + (ws[2] + ws[3])) + ((ws[4] + ws[5]) + (ws[6] + ws[7])));
+    }
+    const uint32_t m = n - n_full * kPiece;
+    if (m == 0u) return tot;
+    // the partial piece: the recursion's leaves hold 64 .. 128 elements (or all m <= 128), so every leaf holds a multiple of
+    // 64; group g walks the recursion down to the leaf of element 64 g (and 64 (g + 64)) and takes it if it is the first there
+    const double2* q = ck + (size_t)n_full * kPiece;
+    if (tid < kTailSlots) slots[tid] = __longlong_as_double((long long)kAbsent);
+    __syncthreads();
+    const uint32_t n_cand = (m + 63u) / 64u;
+    for (uint32_t k0 = 0; k0 < n_cand; k0 += (uint32_t)kThreads / 8u) {
+        const uint32_t k = k0 + g, e = 64u * k;
+        uint32_t o = 0u, len = m, path = 0u, depth = 0u;
+        bool mine = k < n_cand;
+        if (mine) {
+            while (len > 128u) {
+                const uint32_t n2 = (len >> 1) & ~7u;
+                if (e - o < n2) { len = n2; path <<= 1; }
+                else { o += n2; len -= n2; path = (path << 1) | 1u; }
+                depth += 1u;
+            }
+            if (k > 0u && e - 64u >= o) mine = false;   // (the candidate before this one lies in the same leaf)
+        }
+        const uint32_t rows = mine ? len >> 3 : 0u, rem = mine ? len & 7u : 0u;
+        double acc = -0.0;
+#pragma unroll 1
+        for (int r0 = 0; r0 < kLeafRows; r0 += kLoads) {   // (<= 16 rows; the trip count is uniform, the rows are not)
+            double2 cc[kLoads];
+#pragma unroll
+            for (int v = 0; v < kLoads; ++v) cc[v] = (uint32_t)(r0 + v) < rows ? q[o + (uint32_t)(r0 + v) * 8u + j] : double2{0.0, 0.0};
+#pragma unroll
+            for (int v = 0; v < kLoads; ++v) {
+                const bool act = (uint32_t)(r0 + v) < rows;
+                const double x = elem(cc[v], act);
+                if (act) acc = acc + x;
+            }
+        }
+        double leaf = xor_add(acc, 1);
+        leaf = xor_add(leaf, 2);
+        leaf = xor_add(leaf, 4);
+        if (rows == 0u) leaf = -0.0;   // n < 8: one after the other, from -0.0
+        {   // the len % 8 elements left over (the piece's last leaf only), one by one
+            const bool act = j < rem;
+            const double2 cc = act ? q[o + 8u * rows + j] : double2{0.0, 0.0};
+            const double x = elem(cc, act);
+#pragma unroll
+            for (int t = 0; t < 7; ++t) {
+                const double xt = __shfl(x, (lane & ~7) + t, 64);
+                if ((uint32_t)t < rem) leaf = leaf + xt;
+            }
+        }
+        if (mine && j == 0u) slots[path << (7u - depth)] = leaf;   // (depth <= 7: a node of depth 7 holds < 8 192 / 128 + 15 elements)
+    }
+    __syncthreads();
+    for (uint32_t st = 1u; st < (uint32_t)kTailSlots; st <<= 1) {   // the recursion's additions, bottom up; an absent right half = a leaf higher up
+        if ((uint32_t)tid < (uint32_t)kTailSlots && ((uint32_t)tid & (2u * st - 1u)) == 0u) {
+            const double r = slots[(uint32_t)tid + st];
+            if ((unsigned long long)__double_as_longlong(r) != kAbsent) slots[tid] = slots[tid] + r;
+        }
+        __syncthreads();
+    }
+    tot = tot + slots[0];
+    __syncthreads();   // (the slots are the next call's)
+    return tot;
 }
 
 // One wave finds the bin holding rank k of a histogram: bin, #elements below it, its count.
@@ -157,10 +269,10 @@ __global__ __launch_bounds__(kThreads, kWpe) void af_summary_kernel(SumArgs a) {
     __shared__ double val[kRanks];
     __shared__ uint32_t g_pfx[3];   // exponent bins guessed from the first 512 latencies
     __shared__ uint32_t g_n, g_hit;
-    __shared__ double shift_s;      // the squared deviations of pass 1 are taken about this value (mean of the first 512 latencies)
-    __shared__ uint32_t slot_code[kRanks];
+    __shared__ double wsum[2 * kWaves];
+    __shared__ double tail_slots[kTailSlots];
 
-    constexpr int kGroup = kWpe > 4 ? kPerThread / 2 : kPerThread;   // (16-byte loads in flight per thread)
+    constexpr int kLoads = kWpe > 4 ? 4 : 8;   // (16-byte loads in flight per thread: eight at 128 registers, four at 64)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t sc = blockIdx.x;
     uint32_t n = a.counts[(size_t)sc * 8u + a.cnt_completed_slot];
@@ -177,14 +289,10 @@ __global__ __launch_bounds__(kThreads, kWpe) void af_summary_kernel(SumArgs a) {
     // ---- guess: in which exponent bins do the first 512 latencies put the median / p95 / p99? ------------
     {
         const uint32_t m = n < (uint32_t)kThreads ? n : (uint32_t)kThreads;
-        double first = 0.0;
         if ((uint32_t)tid < m) {
             const double2 c = ck[tid];
-            first = c.y - c.x;
-            atomicAdd(&exp_hist[((unsigned long long)__double_as_longlong(first) >> 52) & (kExpBins - 1)], 1u);
+            atomicAdd(&exp_hist[((unsigned long long)__double_as_longlong(c.y - c.x) >> 52) & (kExpBins - 1)], 1u);
         }
-        const double first_sum = block_sum(first, scratch);
-        if (tid == 0) shift_s = m ? first_sum / (double)m : 0.0;
         __syncthreads();
         if (wave < 3 && m > 0u) {
             const uint32_t k = wave == 0 ? m / 2u : wave == 1 ? (uint32_t)((double)(m - 1u) * 0.95) : (uint32_t)((double)(m - 1u) * 0.99);
@@ -207,83 +315,42 @@ __global__ __launch_bounds__(kThreads, kWpe) void af_summary_kernel(SumArgs a) {
         __syncthreads();
     }
     const uint32_t gn = g_n, gp0 = g_pfx[0], gp1 = g_pfx[1], gp2 = g_pfx[2];
-    const double shift_v = shift_s;
-    uint16_t* cd = a.codes ? a.codes + (size_t)sc * a.code_pitch : nullptr;
 
     // ---- pass 1 -----------------------------------------------------------------------------
-    double s = 0.0, mn = __builtin_inf(), mx = -__builtin_inf(), sd1 = 0.0, sq1 = 0.0;
-    for (uint32_t base = 0; base < n; base += kBlock) {
-        // kGroup 16-byte loads in flight per thread: eight at 128 registers; the forms compiled for more waves per SIMD take
-        // the step's eight completions four at a time (half the registers, and twice the waves keep as many bytes in flight)
-        double2 c4[kGroup];
-        uint32_t codes8[kPerThread / 2];
-#pragma unroll
-        for (int u0 = 0; u0 < kPerThread; u0 += kGroup) {
-#pragma unroll
-        for (int v = 0; v < kGroup; ++v) {
-            const uint32_t i = base + (uint32_t)(u0 + v) * kThreads + tid;
-            c4[v] = i < n ? ck[i] : double2{0.0, 0.0};
+    double mn = __builtin_inf(), mx = -__builtin_inf();
+    const double total = numpy_sum<kLoads>(ck, n, wsum, tail_slots, [&](const double2 c, const bool act) -> double {
+        const double lat = c.y - c.x;
+        const unsigned long long key = (unsigned long long)__double_as_longlong(lat);
+        const uint32_t ebin = (uint32_t)(key >> 52) & (kExpBins - 1);
+        if (act) {
+            mn = fmin(mn, lat);
+            mx = fmax(mx, lat);
+            const uint32_t dig = (uint32_t)(key >> (52 - kDigBits)) & (kDigBins - 1);
+            if (gn > 0u && ebin == gp0) atomicAdd(&dig_hist[0][dig], 1u);
+            else if (gn > 1u && ebin == gp1) atomicAdd(&dig_hist[1][dig], 1u);
+            else if (gn > 2u && ebin == gp2) atomicAdd(&dig_hist[2][dig], 1u);
+            else atomicAdd(&exp_hist[ebin], 1u);   // (rare: the guessed bins hold nearly everything, and THEIR counts are the sums of their digit bins, below)
         }
-#pragma unroll
-        for (int v = 0; v < kGroup; ++v) {
-            const int u = u0 + v;
-            const uint32_t i = base + (uint32_t)u * kThreads + tid;
-            const bool act = i < n;
-            uint32_t code = 0u;   // (guessed bin + 1) << 10 | digit; 0 = in none of the guessed bins
-            const double2 c = c4[v];
-            const double lat = c.y - c.x;
-            if (act) {
-                s += lat;
-                mn = fmin(mn, lat);
-                mx = fmax(mx, lat);
-                const double d = lat - shift_v;
-                sd1 += d;
-                sq1 += d * d;
-            }
-            const unsigned long long key = (unsigned long long)__double_as_longlong(lat);
-            const uint32_t ebin = (uint32_t)(key >> 52) & (kExpBins - 1);
-            if (act) {
-                const uint32_t dig = (uint32_t)(key >> (52 - kDigBits)) & (kDigBins - 1);
-                if (gn > 0u && ebin == gp0) {
-                    atomicAdd(&dig_hist[0][dig], 1u);
-                    code = (1u << kDigBits) | dig;
-                } else if (gn > 1u && ebin == gp1) {
-                    atomicAdd(&dig_hist[1][dig], 1u);
-                    code = (2u << kDigBits) | dig;
-                } else if (gn > 2u && ebin == gp2) {
-                    atomicAdd(&dig_hist[2][dig], 1u);
-                    code = (3u << kDigBits) | dig;
-                } else {
-                    atomicAdd(&exp_hist[ebin], 1u);   // (rare: the guessed bins hold nearly everything, and THEIR counts are the sums of their digit bins, below)
-                }
-            }
-            if (u & 1) codes8[u >> 1] |= code << 16;
-            else codes8[u >> 1] = code;
-            if (a.rps) {
-                // window (k-1, k]; a finish at exactly 0 belongs to the first window (analyzer.py:112-121)
-                const double kf = ceil(c.y);
-                const uint32_t k = kf < 1.0 ? 1u : (kf > 4.0e9 ? 0xFFFFFFFFu : (uint32_t)kf);
-                wave_agg_add(rps_l, k - 1u, act && k <= a.rps_buckets);
-            }
-            if (a.hist && act) {
-                const double bf = lat * a.hist_scale;
-                const uint32_t b = bf >= (double)(a.hist_bins - 1u) ? a.hist_bins - 1u : (uint32_t)bf;
-                atomicAdd(&hist_l[b], 1u);
-            }
+        if (a.rps) {
+            // window (k-1, k]; a finish at exactly 0 belongs to the first window (analyzer.py:112-121)
+            const double kf = ceil(c.y);
+            const uint32_t k = kf < 1.0 ? 1u : (kf > 4.0e9 ? 0xFFFFFFFFu : (uint32_t)kf);
+            group_agg_add(rps_l, k - 1u, act && k <= a.rps_buckets);
         }
+        if (a.hist && act) {
+            const double bf = lat * a.hist_scale;
+            const uint32_t b = bf >= (double)(a.hist_bins - 1u) ? a.hist_bins - 1u : (uint32_t)bf;
+            atomicAdd(&hist_l[b], 1u);
         }
-        // the thread's eight codes side by side: one 16-byte store (position base + 8 tid + u holds completion base + 512 u + tid)
-        if (cd) *reinterpret_cast<uint4*>(cd + base + 8u * (uint32_t)tid) = uint4{codes8[0], codes8[1], codes8[2], codes8[3]};
-    }
-    const double total = block_sum(s, scratch);   // (its barriers also close pass 1's histogram updates)
+        return lat;
+    });
+    __syncthreads();   // (closes pass 1's histogram updates)
     if ((uint32_t)wave < gn) {   // exponent bin q of the guess: as many as its digit bins hold together
         uint32_t c = 0;
         for (int j = lane; j < kDigBins; j += 64) c += dig_hist[wave][j];
         for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
         if (lane == 0) exp_hist[g_pfx[wave]] = c;
     }
-    const double sd1_total = block_sum(sd1, scratch);
-    const double sq1_total = block_sum(sq1, scratch);
     mn = wave_min(mn);
     mx = wave_max(mx);
     __syncthreads();
@@ -419,77 +486,27 @@ __global__ __launch_bounds__(kThreads, kWpe) void af_summary_kernel(SumArgs a) {
         shift = new_shift;
     }
 
-    // ---- last pass: gather candidates + squared deviations -----------------------------------------
+    // ---- last pass: the squared deviations in numpy's order (x - mean, squared, summed like the latencies), candidates on the way
     if (tid < kRanks) cand_n[tid] = 0u;
     __syncthreads();
     const uint32_t ns = n_slots;
-    double sq = 0.0;
-    // every wanted rank sits in a guessed exponent bin and its digit bin is small enough: the codes of pass 1 say which
-    // completions are candidates, and only their rows are read again
-    const bool by_code = cd != nullptr && g_hit != 0u && shift == 52 - kDigBits;
-    if (by_code) {
-        if ((uint32_t)tid < ns) {
-            const uint32_t ebin = (uint32_t)(slot_pfx[tid] >> kDigBits), dig = (uint32_t)slot_pfx[tid] & (kDigBins - 1);
-            uint32_t j = 0;
-            for (uint32_t q = 0; q < g_n; ++q)
-                if (g_pfx[q] == ebin) j = q;
-            slot_code[tid] = ((j + 1u) << kDigBits) | dig;
-        }
-        __syncthreads();
-        uint32_t sc_q[kRanks];
+    unsigned long long sp[kRanks];
 #pragma unroll
-        for (int q = 0; q < kRanks; ++q) sc_q[q] = (uint32_t)q < ns ? slot_code[q] : 0xFFFFFFFFu;
-        const uint4* cd4 = reinterpret_cast<const uint4*>(cd);
-        for (uint32_t base = 0; base < n; base += kBlock) {   // (every position of a started step was written: no completion, code 0)
-            const uint4 w = cd4[(base >> 3) + (uint32_t)tid];
-            const uint32_t word[4] = {w.x, w.y, w.z, w.w};
+    for (int q = 0; q < kRanks; ++q) sp[q] = (uint32_t)q < ns ? slot_pfx[q] : ~0ull;   // (a prefix no key >> shift can equal: latencies are >= +0.0)
+    const double sq_total = numpy_sum<kLoads>(ck, n, wsum, tail_slots, [&](const double2 c, const bool act) -> double {
+        const double lat = c.y - c.x;
+        const double d = lat - mean;
+        if (act && shift > 0) {
+            const unsigned long long hi = (unsigned long long)__double_as_longlong(lat) >> shift;
 #pragma unroll
-            for (int h = 0; h < 8; ++h) {
-                const uint32_t i = base + (uint32_t)h * kThreads + (uint32_t)tid;
-                const uint32_t code = (word[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
-                if (code == 0u) continue;
-#pragma unroll
-                for (int q = 0; q < kRanks; ++q)
-                    if (code == sc_q[q]) {
-                        const double2 c = ck[i];
-                        const uint32_t pos = atomicAdd(&cand_n[q], 1u);
-                        if (pos < (uint32_t)kCand) cand[q][pos] = c.y - c.x;
-                    }
-            }
+            for (int q = 0; q < kRanks; ++q)
+                if (hi == sp[q]) {
+                    const uint32_t pos = atomicAdd(&cand_n[q], 1u);
+                    if (pos < (uint32_t)kCand) cand[q][pos] = lat;
+                }
         }
-    } else {
-        // (back to front: the rows pass 1 read last are the ones most likely still in the Infinity Cache -- 1 024 scenarios in
-        // flight x 1.2 MB is five times its 256 MB, so the tail of each scenario's clock is what survives)
-        const uint32_t n_blocks = (n + kThreads * 4u - 1u) / (kThreads * 4u);
-        for (uint32_t blk = n_blocks; blk-- > 0u;) {
-            const uint32_t base = blk * kThreads * 4u;
-            double2 c4[4];
-    #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t i = base + (uint32_t)u * kThreads + tid;
-                c4[u] = i < n ? ck[i] : double2{0.0, 0.0};
-            }
-    #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t i = base + (uint32_t)u * kThreads + tid;
-                if (i >= n) continue;
-                const double lat = c4[u].y - c4[u].x;
-                const double d = lat - mean;
-                sq += d * d;
-                const unsigned long long hi = (unsigned long long)__double_as_longlong(lat) >> shift;
-                for (uint32_t q = 0; q < ns; ++q)
-                    if (hi == slot_pfx[q]) {
-                        const uint32_t pos = atomicAdd(&cand_n[q], 1u);
-                        if (pos < (uint32_t)kCand) cand[q][pos] = lat;
-                    }
-            }
-        }
-    }
-    double sq_total = block_sum(sq, scratch);
-    if (by_code) {   // sum (x - mean)^2 = sum d^2 - (sum d)^2 / n with d = x - shift (shift ~ mean: no cancellation to speak of)
-        sq_total = sq1_total - sd1_total * sd1_total / (double)n;
-        if (!(sq_total > 0.0)) sq_total = 0.0;
-    }
+        return d * d;
+    });
     __syncthreads();
     for (int r = 0; r < kRanks; ++r) {
         const uint32_t q = slot_of[r];

@@ -905,8 +905,6 @@ struct af_engine {
     std::vector<uint32_t> row_of_step;
     af_stats_t stats{};
     // stage-parallel kernel (af_flow.hpp)
-    void* d_codes = nullptr;   // analyzer scratch (af_engine_summarize)
-    size_t codes_bytes = 0;
     bool flow_ok = false, flow_general_servers = false, flow_chain = false;   // flow_chain: servers feed servers (FEAT_CHAIN)
     uint32_t flow_levels = 1u;   // levels the servers form (1: no server feeds a server)
     uint32_t flow_lb_pos = 0u;   // the LB station runs in front of the servers of this level (0: right behind the client)
@@ -1433,11 +1431,16 @@ std::string flow_jit_spec_string(const af_engine* e, const FlowPlan& P, const af
     if ((dist_all == AF_DIST_EXPONENTIAL && !std::getenv("AF_FLOW_DIST_CONST_EXP")) || std::getenv("AF_FLOW_NO_DIST_CONST")) dist_all = 255u;
     // waves per SIMD the LDS of this launch admits (160 KB per compute unit, four SIMDs): the register budget to compile for
     uint32_t wpe = 4u;
-    if (const char* env = std::getenv("AF_FLOW_JIT_WPE")) wpe = (uint32_t)std::atoi(env);   // (measurement hook)
-    else {
+    if (const char* env = std::getenv("AF_FLOW_JIT_WPE")) {   // (measurement hook; anything outside 1..8 is ignored)
+        const int v = std::atoi(env);
+        if (v >= 1 && v <= 8) wpe = (uint32_t)v;
+    } else {
         const uint32_t lds_alloc = (P.lds + 511u) & ~511u, per_cu = lds_alloc ? (160u * 1024u) / lds_alloc : 16u;
         wpe = (per_cu + 3u) / 4u;
         wpe = wpe < 2u ? 2u : wpe > 4u ? 4u : wpe;
+        // general servers: the kernel also holds gen_servers_par's walk and top-c arrays -- 128 registers (four waves) would
+        // spill them; the generic instantiation and round 4's measurements are at three
+        if ((P.feat & (uint32_t)aff::FEAT_GENSRV) != 0u && wpe > 3u) wpe = 3u;
     }
     char buf[2048];
     std::snprintf(buf, sizeof buf,
@@ -1555,10 +1558,11 @@ int af_engine_create(const af_plan_t* plan, int device, const af_engine_options_
         return fail(AF_ERR_INVALID, "lanes_per_wave must be 0 (auto) or a power of two <= 64");
     }
     if (e->lanes_per_wave > 64u) e->lanes_per_wave = 64u;
-    // (the RAM wait-queue count is a 15-bit field next to the 'starved' bit, af_core.hpp: 16384 keeps it clear)
+    // (a server's wait queues have a 32-bit word each since round 6: the cap is what a scenario's state may cost in HBM --
+    // 32 bytes per waiter slot and server and queue pair; af_engine_run sizes its pieces by it)
     if (e->request_capacity > 65535u || e->fifo_capacity > AF_MAX_FIFO_CAPACITY) {
         delete e;
-        return fail(AF_ERR_CAPACITY, "request_capacity must be <= 65535 and fifo_capacity <= 16384");
+        return fail(AF_ERR_CAPACITY, "request_capacity must be <= 65535 and fifo_capacity <= 1048576");
     }
     if (a.blob_bytes > kLdsLimit / 2) {
         delete e;
@@ -1843,8 +1847,11 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
     auto run_sequential = [&](uint32_t count, const uint32_t* h_map, const KArgs& chunk_args) -> int {
         size_t mf = 0, mt = 0;
         HIP_TRY(hipMemGetInfo(&mf, &mt));
-        uint32_t piece = chunk_size(e, count, draw_bytes_per_scen, mf);
-        if (piece == 0) return fail(AF_ERR_CAPACITY, "draw_capacity too large for the device memory budget");
+        // (per scenario: its draws, its scratch of the SimPy-order path and -- when the state does not fit the LDS: long wait
+        // queues -- its state words in HBM)
+        const size_t state_hbm = bytes_per_lane > 48u * 1024u ? (size_t)bytes_per_lane : 0u;
+        uint32_t piece = chunk_size(e, count, draw_bytes_per_scen + tie_words * 8u + state_hbm, mf);
+        if (piece == 0) return fail(AF_ERR_CAPACITY, "draw_capacity / fifo_capacity too large for the device memory budget");
         if (const char* env = std::getenv("AF_SEQ_PIECE")) {   // test hook: force a whole chunk to run in pieces
             const uint32_t v = (uint32_t)std::atoi(env);
             if (v != 0u && v < piece) piece = v;
@@ -2333,20 +2340,6 @@ int af_engine_summarize(af_engine_t* e, const af_outputs_t* out, const af_summar
         s.hist = sum->hist;
         s.hist_bins = sum->hist ? sum->hist_bins : 0u;
         s.hist_scale = sum->hist ? (double)sum->hist_bins / sum->hist_max : 0.0;
-        // scratch for the analyzer's 16-bit codes (af_summary.hpp): kept for the engine's later calls; without it (no memory,
-        // AF_SUMMARY_NO_CODES) the last pass reads the clock again
-        s.code_pitch = (out->clock_capacity + afs::kBlock - 1u) / afs::kBlock * afs::kBlock;
-        const size_t code_bytes = (size_t)sum->n_scenarios * s.code_pitch * sizeof(uint16_t);
-        if (std::getenv("AF_SUMMARY_NO_CODES") == nullptr) {
-            if (e->codes_bytes < code_bytes) {
-                if (e->d_codes) (void)hipFree(e->d_codes);
-                e->d_codes = nullptr;
-                e->codes_bytes = 0;
-                if (hipMalloc(&e->d_codes, code_bytes) == hipSuccess) e->codes_bytes = code_bytes;
-                else (void)hipGetLastError();
-            }
-            s.codes = e->codes_bytes >= code_bytes ? static_cast<uint16_t*>(e->d_codes) : nullptr;
-        }
         // register budget of the latency kernel (af_summary.hpp: kWpe); AF_SUMMARY_WPE=4|8: measurements
         int wpe = kSummaryWpe;
         if (const char* env = std::getenv("AF_SUMMARY_WPE")) wpe = std::atoi(env);
@@ -2396,7 +2389,6 @@ void af_engine_destroy(af_engine_t* e) {
     }
     (void)hipSetDevice(e->device);
     if (e->d_blob) (void)hipFree(e->d_blob);
-    if (e->d_codes) (void)hipFree(e->d_codes);
     if (e->d_state) (void)hipFree(e->d_state);
     if (e->d_sweep) (void)hipFree(e->d_sweep);
     if (e->ev0) (void)hipEventDestroy(e->ev0);

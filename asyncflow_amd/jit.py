@@ -101,6 +101,37 @@ def code_object(spec: str, build: bool = True) -> bytes:
         raise JitUnavailableError(f"{type(exc).__name__}: {exc}") from exc
 
 
+def _sweep_stale_tmp_files(older_than_s: float = 600.0) -> None:
+    """Temporary files of builds that never finished (a process that exited under its compiler): removed once they are older
+    than any build could be."""
+    import time
+
+    now = time.time()
+    for cand in (CACHE_DIR, _FALLBACK_CACHE_DIR):
+        try:
+            for f in cand.glob("*.tmp"):
+                if now - f.stat().st_mtime > older_than_s:
+                    f.unlink(missing_ok=True)
+        except OSError:
+            continue
+
+
+def _wait_for_background_builds() -> None:
+    """atexit: give the background builds a few seconds to land in the cache (see `build_in_background`)."""
+    import time
+
+    try:
+        budget = float(os.environ.get("ASYNCFLOW_JIT_EXIT_WAIT_S", "8"))
+    except ValueError:
+        budget = 8.0
+    deadline = time.monotonic() + max(budget, 0.0)
+    for t in list(_background.values()):
+        left = deadline - time.monotonic()
+        if left <= 0.0:
+            break
+        t.join(left)
+
+
 _background: dict[str, threading.Thread] = {}
 _background_lock = threading.Lock()
 _background_one_at_a_time = threading.Semaphore(1)      # background builds take turns: one compiler beside the simulation, not twenty
@@ -112,14 +143,22 @@ def build_in_background(spec: str) -> threading.Thread | None:
     For sweeps too short to repay a synchronous hipcc run (~4 s): the sweep at hand runs on the library's generic kernels
     -- BASELINE config 2 takes 64 instead of 38 ms per 10 000 replicas on them -- while the compiler works beside it, and the NEXT
     sweep of the same shape (the usual Monte-Carlo loop: same plan, other seeds) finds the specialised kernel in the cache.
-    ``ASYNCFLOW_JIT_BACKGROUND=0`` turns it off.  Failures are silent (the generic kernels do the same job); a process that
-    exits mid-build leaves at most a ``*.tmp`` file, never a truncated code object (the cache entry is renamed into place)."""
+    ``ASYNCFLOW_JIT_BACKGROUND=0`` turns it off.  Failures are silent (the generic kernels do the same job).  A process that
+    finishes its sweep before the compiler does (~4 s) waits for the build at exit, at most ``ASYNCFLOW_JIT_EXIT_WAIT_S``
+    seconds (default 8; 0: do not wait) -- otherwise a short script would never leave its kernel in the cache and its next run
+    would be as slow; a build cut off anyway leaves at most a ``*.tmp`` file, never a truncated code object (the
+    cache entry is renamed into place), and stale ``*.tmp`` files are swept when the next background build starts."""
     if os.environ.get("ASYNCFLOW_JIT_BACKGROUND", "1") == "0":
         return None
     with _background_lock:
         t = _background.get(spec)
         if t is not None:
             return t
+        if not _background:
+            import atexit
+
+            atexit.register(_wait_for_background_builds)
+            _sweep_stale_tmp_files()
 
         def work() -> None:
             with _background_one_at_a_time:

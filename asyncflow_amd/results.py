@@ -390,8 +390,9 @@ class BatchedResults:
         for name, slot in (("generated", _abi.CNT_GENERATED), ("completed", _abi.CNT_COMPLETED),
                            ("dropped", _abi.CNT_DROPPED), ("request_events", _abi.CNT_EVENTS),
                            ("ticks", _abi.CNT_TICKS), ("flags", _abi.CNT_FLAGS)):
-            # (counts[CNT_MAX_LIVE] is a diagnostic of the next-event kernels only -- the stage-parallel kernel writes 0 --
-            # and is not part of the on-disk summary: one sweep may mix both paths)
+            # (counts[CNT_MAX_LIVE] is a diagnostic -- the next-event kernels' high-water mark of live requests; the stage-parallel
+            # kernel writes 0, or for general servers its rounds solved at once << 16 | walked event by event, each half
+            # saturating at 65 535 -- and is not part of the on-disk summary: one sweep may mix both paths)
             cols[name] = self.counts[:, slot].copy()
         stats = summ["stats"].cpu().numpy()
         for j, k in enumerate(LATENCY_KEYS):

@@ -122,8 +122,9 @@ def validate_points(plan: DevicePlan, columns: Mapping[str, np.ndarray], n: int)
     * Up to ``VALIDATE_EVERY_POINT_UP_TO`` DISTINCT points (rows of the column table; seed replicas of one point count
       once): every one of them is validated, like the reference would.
     * Larger sweeps (a 100 x 100 grid is 10 000 points = seconds of model validation per call, and `bench.py` resolves
-      a sweep several times): every DISTINCT VALUE of every column is validated (written into the plan's own
-      payload: the schema's field constraints are per field), then whole rows: the rows that hold every column's
+      a sweep several times): every DISTINCT VALUE of every column is validated inside the first row of the
+      sweep that holds it (the schema's field constraints are per field; its cross-field constraints see the row's own
+      values), and so are the rows that hold every column's
       extremes, the first and the last one, and 64 rows spread evenly over the sweep -- the schema's cross-field
       constraints (a Gaussian's variance with its mean, the sampling window with the horizon) are monotone in each
       column, the constraints that are not -- integrality of the int fields -- are checked over whole columns here and in
@@ -169,18 +170,23 @@ def validate_points(plan: DevicePlan, columns: Mapping[str, np.ndarray], n: int)
     if len(first) <= VALIDATE_EVERY_POINT_UP_TO:
         picks = sorted(int(i) for i in first)
     else:
-        for key in keys:                  # every distinct value of every column, on its own
-            for v in np.unique(columns[key]):
-                check({key: float(v)}, f"sweep value {key!r}")
-                done += 1
-        rows = {0, n - 1} | {int(i) for i in np.linspace(0, n - 1, 64).round()}
+        # every distinct value of every column -- inside a row of the sweep that holds it (the first one), not on its own in
+        # the plan's base payload: the schema's cross-field constraints (an event's t_start < t_end, an event inside the
+        # horizon, a Gaussian's variance with its mean) relate a row's OWN values, and a value that is valid in its rows can
+        # be invalid beside the base payload's (t_start = 160.07 against the base t_end = 160)
+        rows: set[int] = set()
+        for key in keys:
+            _, at = np.unique(columns[key], return_index=True)
+            rows.update(int(i) for i in at)
+        done = 0
+        rows |= {0, n - 1} | {int(i) for i in np.linspace(0, n - 1, 64).round()}
         for col in columns.values():
             rows.add(int(np.argmin(col)))
             rows.add(int(np.argmax(col)))
         picks = sorted(rows)
         logging.getLogger("asyncflow_amd").info(
-            "sweep of %d distinct points: validated %d distinct column values one by one and %d whole rows (extremes, ends, "
-            "64 spread evenly) instead of every row", len(first), done, len(picks))
+            "sweep of %d distinct points: validated %d whole rows (the first row holding every distinct value of every column, "
+            "the columns' extremes, both ends, 64 spread evenly) instead of every row", len(first), len(picks))
     for i in picks:
         check({key: col[i] for key, col in columns.items()}, f"sweep point {i}")
     _VALIDATED[memo] = done + len(picks)
@@ -619,10 +625,13 @@ class SimulationRunner:
                     # twice: a server the estimate did not see as saturated -- its backlog grows with the horizon.  The live
                     # requests of a scenario never exceed its arrivals (clock_cap bounds them), the waiters of a queue never
                     # the live requests: go to those bounds at once instead of re-running the sweep for every factor of four
-                    # (pool and queue overflow in turns: found by scripts/gpu_fuzz_sweeps.py, six runs were not enough)
+                    # (pool and queue overflow in turns: found by scripts/gpu_fuzz_sweeps.py, six runs were not enough).
+                    # Round 6: a wait queue may hold up to 2^20 requests (the reference's simpy queues have no bound at all,
+                    # server.py:146-149, 210-227) -- 32 bytes of HBM per slot, server and queue pair; the engine runs a sweep
+                    # whose state does not fit the device in pieces.
                     cap = min(_abi.MAX_REQUEST_CAPACITY, max(cap * 4, (clock_cap + 7) // 8 * 8))
-                    fifo = _fifo_pow2(cap)
-                # (the wait queues hold request slots: a FIFO larger than the pool is never needed, a pool smaller than it neither)
+                    fifo = _fifo_pow2(max(fifo * 4, clock_cap))
+                # (a request waits in a queue or for a timed event: the pool need not hold more than 65 535 of the latter)
                 cap = min(_abi.MAX_REQUEST_CAPACITY, max(cap, fifo))
             warnings.warn(
                 f"engine capacity overflow (flags={over:#x}); retrying with request_capacity={cap}, "

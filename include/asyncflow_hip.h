@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define AF_ABI_VERSION 6
+#define AF_ABI_VERSION 7
 
 /* ---- status codes ------------------------------------------------------ */
 enum af_status {
@@ -192,9 +192,12 @@ enum af_flag {
     AF_FLAG_FIFO_OVERFLOW = 1u << 1,   /* a CPU/RAM wait queue exceeded fifo_capacity */
     AF_FLAG_CLOCK_OVERFLOW = 1u << 2,  /* more completions than clock_capacity     */
     AF_FLAG_TICK_OVERFLOW = 1u << 3,   /* more ticks than tick_capacity            */
-    AF_FLAG_RAM_STARVED = 1u << 4,     /* a request needs more RAM than ram_mb: that
-                                          server's RAM queue is blocked for good
-                                          (same as the reference; informational) */
+    AF_FLAG_RAM_STARVED = 1u << 4,     /* a server's RAM queue is blocked for good: a request needs more RAM than
+                                          ram_mb (server.py:146-149), or -- fractional needs only -- a RAM put that
+                                          simpy refuses by one rounding faces a waiter that does not fit, so that
+                                          neither can ever move.  The engine does what the reference does (every
+                                          later RAM request of that server waits for ever; tests/golden/ram_starved_t30,
+                                          ram_put_deadlock_t20 are the reference's own output); informational */
     AF_FLAG_TIME_TIE = 1u << 5,        /* a zero-delay Timeout that is not a delivery to the
                                           client was created while other zero-time steps were
                                           pending: SimPy may order those steps differently.
@@ -212,14 +215,7 @@ enum af_flag {
                                           reference raises there (simpy: ValueError "Negative delay", edge.py:107);
                                           the engine delivers at now + (transit + spike) and reports the scenario:
                                           asyncflow_amd.SimulationRunner raises the same ValueError for it */
-    ,
-    AF_FLAG_RAM_PUT_BLOCKED = 1u << 14 /* a request gave back a FRACTIONAL amount of RAM and `capacity - level >= amount`
-                                          was false by one rounding (2048 - fl(2048 - 100.3) < 100.3): in the reference the
-                                          simpy Container.put then WAITS until a later get lowers the level, and the
-                                          response leaves that much later (server.py:270-276).  The engine gives the RAM
-                                          back at once and reports the scenario: from that instant on its results are not
-                                          the reference's.  Never set for needs that are whole MB or multiples of 1/256 MB
-                                          (their sums are exact). */
+    /* (bit 14 was AF_FLAG_RAM_PUT_BLOCKED in ABI 6: simpy's waiting Container.put is modelled since ABI 7, never reported) */
 };
 
 typedef struct af_outputs {
@@ -253,7 +249,10 @@ typedef struct af_outputs {
 } af_outputs_t;
 
 #define AF_MAX_REQUEST_CAPACITY 65535u
-#define AF_MAX_FIFO_CAPACITY 16384u   /* rounded up to a power of two by the engine */
+#define AF_MAX_FIFO_CAPACITY 1048576u /* rounded up to a power of two by the engine.  (ABI <= 6: 16 384.  The reference's simpy
+                                         Container queues have no bound -- server.py:146-149, 210-227 --; a saturated server's
+                                         backlog grows with the horizon, and 2^20 waiters per server queue is what a scenario
+                                         may cost in HBM: 32 B per slot and server and queue pair) */
 
 typedef struct af_engine_options {
     uint32_t request_capacity;  /* live requests per scenario (0 = engine default, <= AF_MAX_REQUEST_CAPACITY) */

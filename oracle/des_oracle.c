@@ -164,6 +164,7 @@ typedef struct { /* ServerRuntime + ServerContainers (server.py, server_containe
     int ready, io;       /* _el_ready_queue_len, _el_io_queue_len */
     double ram_in_use;   /* _ram_in_use              */
     fifo_t cpu_q, ram_q; /* Container.get_queue      */
+    fifo_t ram_pq;       /* RAM Container.put_queue: puts that `_do_put` refused (fractional needs, see ram_trigger_put) */
     uint32_t arrivals;
 } srv_t;
 
@@ -184,7 +185,7 @@ typedef struct {
     uint32_t emark_i, smark_i;
     /* outputs */
     uint64_t n_generated, n_completed, n_dropped, n_events, n_ticks, n_marks, flags;
-    uint64_t n_heap_events, n_ties;
+    uint64_t n_heap_events, n_ties, n_put_waits;
     double* clock; uint64_t clock_cap;
     uint32_t* samples; uint64_t tick_cap; uint32_t n_series;
 } sim_t;
@@ -374,6 +375,37 @@ static void ram_trigger_get(sim_t* s, int sv) {
     }
 }
 
+/* BaseResource._trigger_put for the RAM container: walk the put queue from its head, stop at the first put that
+ * `Container._do_put` refuses (`if self._capacity - self._level >= event.amount`) -- head-of-line blocking, like the gets.
+ * With whole-MB needs the test never fails (capacity - level IS the sum of what is held).  With a fractional need it can
+ * fail by ONE ROUNDING: 2048 - fl(2048 - 100.3) < 100.3, so `yield RAM.put(100.3)` of the only holder WAITS.  The queue is
+ * walked again (a) by every later ContainerPut.__init__ and (b) when a RAM get is PROCESSED (`_trigger_put` is the first
+ * callback Get.__init__ registers, before the process's own resume): the level that get took lets the put through, and
+ * the response leaves then (server.py:270-276). */
+static void ram_trigger_put(sim_t* s, int sv) {
+    srv_t* S = &s->srv[sv];
+    while (S->ram_pq.n > 0) {
+        int w = fifo_front(&S->ram_pq);
+        double amount = s->reqs[w].ram;
+        if (!(s->p->srv_ram_mb[sv] - S->ram_level >= amount)) break; /* _do_put returns None: `if not proceed: break` */
+        fifo_pop(&S->ram_pq);
+        S->ram_level += amount;
+        sched(s, 0.0, PRIO_NORMAL, EV_RAM_PUT, w, 0); /* event.succeed() */
+    }
+}
+
+/* Informational, like the starved case below: a refused put at the head of the put queue facing a waiter at the head of
+ * the get queue that does not fit -- neither queue can ever move again (both are head-of-line blocked and nothing else
+ * changes the level), so the server's RAM is dead-locked for good in the reference.  Nothing is changed here: the queues
+ * simply never move; the engine reports the same flag (and stops keeping what queues up behind). */
+static void ram_deadlock_check(sim_t* s, int sv) {
+    srv_t* S = &s->srv[sv];
+    if (S->ram_pq.n == 0 || S->ram_q.n == 0) return;
+    if (S->ram_level >= s->reqs[fifo_front(&S->ram_q)].ram) return;
+    if (s->p->srv_ram_mb[sv] - S->ram_level >= s->reqs[fifo_front(&S->ram_pq)].ram) return;
+    s->flags |= AF_FLAG_RAM_STARVED;
+}
+
 /* tail of _handle_request after the core was given back (server.py:261-276) */
 static void srv_finish(sim_t* s, int r) {
     req_t* R = &s->reqs[r];
@@ -388,12 +420,11 @@ static void srv_finish(sim_t* s, int r) {
     }
     if (R->ram > 0.0) { /* `if total_ram:` */
         S->ram_in_use -= R->ram;
-        /* Container._do_put: `if self._capacity - self._level >= event.amount` -- false by one rounding for some fractional
-         * needs (2048 - fl(2048 - 100.3) < 100.3): the reference's put then waits for a later get.  Not modelled: reported. */
-        if (s->p->srv_ram_mb[R->server] - S->ram_level < R->ram) s->flags |= AF_FLAG_RAM_PUT_BLOCKED;
-        S->ram_level += R->ram; /* ContainerPut.__init__ -> _do_put succeeds at once */
-        sched(s, 0.0, PRIO_NORMAL, EV_RAM_PUT, r, 0);
-        return;
+        fifo_push(&S->ram_pq, r); /* ContainerPut.__init__: append, then _trigger_put(None) */
+        ram_trigger_put(s, R->server);
+        if (S->ram_pq.n > 0) s->n_put_waits += 1; /* diagnostics: this put (or one ahead of it) was refused */
+        ram_deadlock_check(s, R->server);
+        return; /* yield RAM.put(total_ram): resumes at EV_RAM_PUT */
     }
     transport(s, r, s->p->srv_out_edge[R->server]);
 }
@@ -472,6 +503,7 @@ static void srv_init(sim_t* s, int r) {
         if (R->ram > p->srv_ram_mb[sv]) s->flags |= AF_FLAG_RAM_STARVED;
         fifo_push(&S->ram_q, r); /* ContainerGet.__init__ */
         ram_trigger_get(s, sv);
+        ram_deadlock_check(s, sv);
         return; /* yield RAM.get(total_ram): resumes at EV_RAM_GOT */
     }
     srv_continue(s, r);
@@ -594,7 +626,8 @@ static void sample_tick(sim_t* s) {
 }
 
 /* ------------------------------------------------------------- top level */
-static uint64_t g_last_ties, g_last_heap_events;
+static uint64_t g_last_ties, g_last_heap_events, g_last_put_waits;
+uint64_t orc_last_put_waits(void) { return g_last_put_waits; } /* RAM puts that had to wait (tests: proves a case is in that regime) */
 uint64_t orc_last_ties(void) { return g_last_ties; }
 uint64_t orc_last_heap_events(void) { return g_last_heap_events; }
 
@@ -681,8 +714,9 @@ int orc_simulate(const af_plan_t* plan, uint64_t seed, uint64_t clock_cap, doubl
             case EV_STORE_GET: store_get_processed(s, ev.a, ev.b); break;
             case EV_CBOX_PUT: forwarder_get(s, BOX_CLIENT); break; /* client.py:46-48 loop */
             case EV_SRV_INIT: srv_init(s, ev.a); break;
-            case EV_RAM_GOT: { /* server.py:149 */
+            case EV_RAM_GOT: { /* server.py:149; the get's first callback is the container's _trigger_put */
                 req_t* R = &s->reqs[ev.a];
+                ram_trigger_put(s, R->server);
                 s->srv[R->server].ram_in_use += R->ram;
                 srv_continue(s, ev.a);
                 break;
@@ -742,9 +776,11 @@ int orc_simulate(const af_plan_t* plan, uint64_t seed, uint64_t clock_cap, doubl
     }
     g_last_ties = s->n_ties;
     g_last_heap_events = s->n_heap_events;
+    g_last_put_waits = s->n_put_waits;
     for (uint32_t v = 0; v < plan->n_servers; ++v) {
         free(s->srv[v].cpu_q.a);
         free(s->srv[v].ram_q.a);
+        free(s->srv[v].ram_pq.a);
     }
     for (uint32_t b = 0; b < 2 + plan->n_servers; ++b) free(s->box[b].items.a);
     free(s->box);

@@ -59,6 +59,8 @@ def lib() -> C.CDLL:
         L.orc_last_ties.restype = C.c_uint64
         L.orc_last_heap_events.argtypes = []
         L.orc_last_heap_events.restype = C.c_uint64
+        L.orc_last_put_waits.argtypes = []
+        L.orc_last_put_waits.restype = C.c_uint64
         L.orc_tick_count.argtypes = [C.c_double, C.c_double]
         L.orc_tick_count.restype = C.c_uint32
         _lib = L
@@ -85,6 +87,7 @@ class OracleResult:
     samples: np.ndarray  # uint32[n_series, n_ticks] raw words (ram rows are float32 bits)
     ties: int = 0        # timed events popped at the timestamp of the previous one
     heap_events: int = 0 # SimPy-equivalent heap pushes
+    put_waits: int = 0   # RAM puts that simpy's Container refused at first (fractional needs; des_oracle.c::ram_trigger_put)
 
     @property
     def generated(self) -> int:
@@ -180,6 +183,7 @@ def simulate(
         samples=samples[:, : int(counts[_abi.CNT_TICKS])].copy() if samples is not None else np.zeros((0, 0), np.uint32),
         ties=int(L.orc_last_ties()),
         heap_events=int(L.orc_last_heap_events()),
+        put_waits=int(L.orc_last_put_waits()),
     )
 
 

@@ -587,6 +587,31 @@ def tie_storm(rng: random.Random, horizon: int = 12) -> dict:
     return copy.deepcopy(p)
 
 
+def fractional_ram_fuzz(rng: random.Random, horizon: int = 10) -> dict:
+    """Random payloads whose RAM needs are DECIMAL fractions of a megabyte (100.3, 64.7, 0.1 ...: not multiples of 1/256 MB) on
+    tight RAM budgets -- the regime in which simpy's `Container._do_put` (`if capacity - level >= amount`) refuses a put by one
+    rounding: the response waits for the next RAM get of that server to be processed (server.py:270-276), several puts can queue
+    behind a refused one (head-of-line), and a refused put facing a RAM waiter that does not fit dead-locks the server's RAM for
+    good.  Half of the cases use dyadic step times and Poisson hops (shared instants by the thousand) on top."""
+    storm = rng.random() < 0.5
+    base = tie_storm(rng, horizon) if storm else random_payload(rng, horizon)
+    fr = [100.3, 64.7, 0.1, 33.33, 250.9, 17.2, 199.99, 12.6, 77.7, 150.15, 0.7, 300.3]
+    for srv in base["topology_graph"]["nodes"]["servers"]:
+        srv["server_resources"]["ram_mb"] = rng.choice([256, 300, 320, 512])
+        for ep in srv["endpoints"]:
+            had = False
+            for st in ep["steps"]:
+                if "necessary_ram" in st["step_operation"]:
+                    st["step_operation"]["necessary_ram"] = rng.choice(fr)
+                    had = True
+            if not had and rng.random() < 0.6:
+                ep["steps"].insert(rng.randrange(len(ep["steps"]) + 1),
+                                   {"kind": "ram", "step_operation": {"necessary_ram": rng.choice(fr)}})
+    if not storm:
+        base["rqs_input"]["avg_active_users"]["mean"] = rng.choice([5, 20, 60, 150, 300])
+    return base
+
+
 #: name -> (payload builder, seed) for the committed golden fixtures
 def fractional_ram(dyadic: bool, horizon: int = 20) -> dict:
     """LB-2 whose endpoints need fractional megabytes (schemas/topology/endpoint.py:26: necessary_ram is a PositiveFloat when
@@ -599,12 +624,38 @@ def fractional_ram(dyadic: bool, horizon: int = 20) -> dict:
     return p
 
 
+def ram_put_deadlock(horizon: int = 20) -> dict:
+    """One server of 1024 MB, endpoints needing 300.3 MB and 800 MB.  1024 - fl(1024 - 300.3) < 300.3: a /a request that is the
+    only holder has its `RAM.put` refused by simpy (`Container._do_put`) and its response waits for the next RAM get of the
+    server to be processed (server.py:270-276) -- until a /b request (800 MB > the 723.7 left) queues up behind such a holder:
+    the put waits for a get, the get for a put, and the server's RAM is dead-locked for the rest of the run (every later
+    request of the server waits for good; requests of /c, which needs no RAM, still go through)."""
+    eps = [
+        _endpoint("/a", [("initial_parsing", 0.002), ("ram", 300.3), ("io_wait", 0.05)]),
+        _endpoint("/b", [("initial_parsing", 0.001), ("ram", 800), ("io_db", 0.02)]),
+        _endpoint("/c", [("cpu_bound_operation", 0.001), ("io_cache", 0.004)]),
+    ]
+    p = single_server(users=6, rpm=60, horizon=horizon, period=0.02)
+    p["topology_graph"]["nodes"]["servers"] = [_server("srv-1", 2, 1024, eps)]
+    return p
+
+
+def ram_starved(horizon: int = 30) -> dict:
+    """stress_mixed with one endpoint that needs more RAM than its server owns (server.py:146-149): the request waits in
+    `RAM.get()` for good and -- the container's gets being FIFO -- so does every later RAM request of that server."""
+    p = stress_mixed(horizon)
+    p["topology_graph"]["nodes"]["servers"][2]["endpoints"][1]["steps"][1]["step_operation"]["necessary_ram"] = 5000
+    return p
+
+
 GOLDEN = {
     # ram_in_use of fractional needs: the fixtures also hold the reference's own f64 series (ram_f64)
     "frac_ram_dyadic_t20": (lambda: fractional_ram(True), 21),
-    # NOT reproduced by the engine, on purpose (a documented deviation, AF_FLAG_RAM_PUT_BLOCKED): 2048 - fl(2048 - 100.3) < 100.3, so
-    # the reference's `yield RAM.put(100.3)` WAITS for the next get on that Container and the response leaves that much later
-    "deviation_frac_ram_t20": (lambda: fractional_ram(False), 22),
+    # 2048 - fl(2048 - 100.3) < 100.3: the reference's `yield RAM.put(100.3)` WAITS for the next get on that Container and the
+    # response leaves that much later (round 5 reported this, round 6 reproduces it: des_oracle.c::ram_trigger_put)
+    "frac_ram_waiting_put_t20": (lambda: fractional_ram(False), 22),
+    "ram_put_deadlock_t20": (lambda: ram_put_deadlock(20), 4),
+    "ram_starved_t30": (lambda: ram_starved(30), 1),
     "single_server_t30": (lambda: single_server(horizon=30), 0),
     "lb2_rr_t30": (lambda: lb_two_servers(horizon=30), 0x5EED0000),
     "lb2_lc_t20": (lambda: lb_two_servers(horizon=20, algo="least_connection"), 7),

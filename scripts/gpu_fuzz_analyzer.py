@@ -71,9 +71,9 @@ for k in range(k0, k0 + n_payloads):
             t["scenarios"] += 1
             t["empty_scenarios"] += int(want[0] == 0)
             assert np.array_equal(stats[i][EXACT].view(np.uint64), want[EXACT].view(np.uint64)), (k, i, "order statistics", stats[i].tolist(), want.tolist())
-            if want[0] > 0:
-                assert np.allclose(stats[i][1], want[1], rtol=1e-12, atol=0.0), (k, i, "mean", stats[i][1], want[1])
-                assert np.allclose(stats[i][3], want[3], rtol=1e-12, atol=1e-13 * want[7]), (k, i, "std", stats[i][3], want[3])
+            if want[0] > 0:      # (round 6: mean and std_dev bit-equal to numpy's too)
+                assert stats[i][1] == want[1], (k, i, "mean", stats[i][1], want[1])
+                assert stats[i][3] == want[3], (k, i, "std", stats[i][3], want[3])
             else:
                 assert np.isnan(stats[i][1:]).all(), (k, i, "empty", stats[i].tolist())
             if rps is not None:

@@ -16,8 +16,6 @@ from asyncflow_amd.runner import SimulationRunner  # noqa: E402
 from oracle import oracle_lib as ol  # noqa: E402
 from oracle.scenarios import deep_chain, flow_payload, gateway_lb, random_payload, server_tiers, tie_storm, wide_fanout  # noqa: E402
 
-n_payloads = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-k0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # first payload index: a different range is a different set of payloads
 def _gateway(k: int) -> dict:
     rng = random.Random(99000 + k)
     return gateway_lb(front=rng.choice((1, 2)), algo=rng.choice(("round_robin", "least_connection")), users=rng.choice((60, 150, 300)),
@@ -50,40 +48,50 @@ families = {
     # spikes, outages, least connections, both generators)
     "feed-forward payloads (tandem servers)": lambda k: flow_payload(random.Random(94000 + k), horizon=6),
 }
-if len(sys.argv) > 3:   # only the families whose name contains the third argument
-    families = {n: f for n, f in families.items() if sys.argv[3] in n}
-out = {}
-for name, make in families.items():
-    t = {"payloads": 0, "scenarios": 0, "on_flow_kernel": 0, "handed_back_first": 0, "to_next_event": 0, "oracle_checks": 0, "not_in_range": 0, "overflow_raised": 0}
-    for k in range(k0, k0 + n_payloads):
-        payload = make(k)
-        seeds = np.arange(8, dtype=np.uint64) + 1000 * k + 7
-        try:
-            res = SimulationRunner(simulation_input=payload, seeds=seeds, on_negative_delay="flag").run()
-            ref = SimulationRunner(simulation_input=payload, seeds=seeds, flow=False, on_negative_delay="flag").run()
-        except OverflowError:   # a pool at the engine's maximum: reported, never silent (runner.py)
-            t["overflow_raised"] += 1
-            continue
-        st = res.engine_stats
-        t["payloads"] += 1
-        t["scenarios"] += 8
-        if res.flow_reason:
-            t["not_in_range"] += 1
-        t["on_flow_kernel"] += int(st.flow_scenarios)
-        t["handed_back_first"] += int(st.flow_fallback)
-        t["to_next_event"] += int(st.flow_to_next_event)
-        assert np.array_equal(res.counts[:, :6], ref.counts[:, :6]), (name, k)
-        assert np.array_equal(res.counts[:, _abi.CNT_MARKS], ref.counts[:, _abi.CNT_MARKS]), (name, k)
-        for i in range(8):
-            assert np.array_equal(res[i].rqs_clock.view(np.uint64), ref[i].rqs_clock.view(np.uint64)), (name, k, i)
-            assert np.array_equal(res[i]._samples, ref[i]._samples), (name, k, i)  # noqa: SLF001
-        plan = lower(payload)
-        for i in (0, 7):
-            want = ol.simulate(plan, int(seeds[i]))
-            assert np.array_equal(res[i].counts[:5].astype(np.uint64), want.counts[:5]), (name, k, i)
-            assert np.array_equal(res[i].rqs_clock.view(np.uint64), want.clock.view(np.uint64)), (name, k, i)
-            assert np.array_equal(res[i]._samples, want.samples), (name, k, i)  # noqa: SLF001
-            t["oracle_checks"] += 1
-    out[name] = t
-out["different"] = 0
-print(json.dumps(out))
+
+
+def run(n_payloads: int = 40, k0: int = 0, only: str | None = None, oracle_every: bool = False) -> dict:
+    """`n_payloads` payloads per family from index `k0` on (a different range is a different set of payloads), eight scenarios
+    each; `only`: the families whose name contains it; `oracle_every`: all eight scenarios against the oracle (default: two).
+    A mismatch raises."""
+    fams = {n: f for n, f in families.items() if only is None or only in n}
+    out = {}
+    for name, make in fams.items():
+        t = {"payloads": 0, "scenarios": 0, "on_flow_kernel": 0, "handed_back_first": 0, "to_next_event": 0, "oracle_checks": 0, "not_in_range": 0, "overflow_raised": 0}
+        for k in range(k0, k0 + n_payloads):
+            payload = make(k)
+            seeds = np.arange(8, dtype=np.uint64) + 1000 * k + 7
+            try:
+                res = SimulationRunner(simulation_input=payload, seeds=seeds, on_negative_delay="flag").run()
+                ref = SimulationRunner(simulation_input=payload, seeds=seeds, flow=False, on_negative_delay="flag").run()
+            except OverflowError:   # a pool at the engine's maximum: reported, never silent (runner.py)
+                t["overflow_raised"] += 1
+                continue
+            st = res.engine_stats
+            t["payloads"] += 1
+            t["scenarios"] += 8
+            if res.flow_reason:
+                t["not_in_range"] += 1
+            t["on_flow_kernel"] += int(st.flow_scenarios)
+            t["handed_back_first"] += int(st.flow_fallback)
+            t["to_next_event"] += int(st.flow_to_next_event)
+            assert np.array_equal(res.counts[:, :6], ref.counts[:, :6]), (name, k)
+            assert np.array_equal(res.counts[:, _abi.CNT_MARKS], ref.counts[:, _abi.CNT_MARKS]), (name, k)
+            for i in range(8):
+                assert np.array_equal(res[i].rqs_clock.view(np.uint64), ref[i].rqs_clock.view(np.uint64)), (name, k, i)
+                assert np.array_equal(res[i]._samples, ref[i]._samples), (name, k, i)  # noqa: SLF001
+            plan = lower(payload)
+            for i in (range(8) if oracle_every else (0, 7)):
+                want = ol.simulate(plan, int(seeds[i]))
+                assert np.array_equal(res[i].counts[:5].astype(np.uint64), want.counts[:5]), (name, k, i)
+                assert np.array_equal(res[i].rqs_clock.view(np.uint64), want.clock.view(np.uint64)), (name, k, i)
+                assert np.array_equal(res[i]._samples, want.samples), (name, k, i)  # noqa: SLF001
+                t["oracle_checks"] += 1
+        out[name] = t
+    out["different"] = 0
+    return out
+
+
+if __name__ == "__main__":
+    print(json.dumps(run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 0,
+                         sys.argv[3] if len(sys.argv) > 3 else None)))

@@ -20,8 +20,6 @@ from asyncflow_amd.runner import SimulationRunner, write_point  # noqa: E402
 from oracle import oracle_lib as ol  # noqa: E402
 from oracle.scenarios import flow_payload, lb_with_events  # noqa: E402
 
-n_payloads = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-k0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 N = 6
 
 
@@ -71,52 +69,58 @@ def columns(payload: dict, rng: random.Random) -> dict[str, np.ndarray]:
     return cols
 
 
-t = {"payloads": 0, "scenarios": 0, "columns": 0, "on_flow_kernel": 0, "to_next_event": 0, "oracle_checks": 0, "overflow_raised": 0, "invalid_points": 0,
-     "paths": {}}
-failures: list[str] = []
-for k in range(k0, k0 + n_payloads):
-    rng = random.Random(77000 + k)
-    payload = flow_payload(rng, horizon=6) if k % 4 else lb_with_events(users=rng.choice((60, 120, 300)), horizon=30, scale=0.05)
-    cols = columns(payload, rng)
-    seeds = np.arange(N, dtype=np.uint64) + 1000 * k + 11
-    try:
-        res = SimulationRunner(simulation_input=payload, seeds=seeds, sweep=cols, on_negative_delay="flag").run()
-        ref = SimulationRunner(simulation_input=payload, seeds=seeds, sweep=cols, flow=False, on_negative_delay="flag").run()
-    except OverflowError as exc:   # a pool at the engine's maximum: reported, never silent
-        t["overflow_raised"] += 1
-        print(f"payload {k}: OverflowError: {str(exc)[:200]}", file=sys.stderr)
-        continue
-    except ValueError as exc:   # a point the payload models refuse (e.g. an event window that no longer fits)
-        t["invalid_points"] += 1
-        print(f"payload {k}: {str(exc)[:200]}", file=sys.stderr)
-        continue
-    st = res.engine_stats
-    t["payloads"] += 1
-    t["scenarios"] += N
-    t["columns"] += len(cols)
-    for key in cols:
-        short = key.split("[")[0] + ("[..]" + key.split("]")[-1] if "[" in key else "")
-        t["paths"][short] = t["paths"].get(short, 0) + 1
-    t["on_flow_kernel"] += int(st.flow_scenarios)
-    t["to_next_event"] += int(st.flow_to_next_event)
-    try:
-        assert np.array_equal(res.counts[:, :6], ref.counts[:, :6]), (k, list(cols))
-        assert np.array_equal(res.counts[:, _abi.CNT_MARKS], ref.counts[:, _abi.CNT_MARKS]), (k, list(cols))
-        base = lower(payload).payload   # (normalised: what write_point expects)
-        for i in range(N):
-            assert np.array_equal(res[i].rqs_clock.view(np.uint64), ref[i].rqs_clock.view(np.uint64)), (k, i, list(cols))
-            assert np.array_equal(res[i]._samples, ref[i]._samples), (k, i, list(cols))  # noqa: SLF001
-            point = copy.deepcopy(base)
-            for key, col in cols.items():
-                write_point(point, key, col[i])
-            want = ol.simulate(lower(point), int(seeds[i]))
-            assert np.array_equal(res[i].counts[:5].astype(np.uint64), want.counts[:5]), (k, i, list(cols), res[i].counts[:5], want.counts[:5])
-            assert np.array_equal(res[i].rqs_clock.view(np.uint64), want.clock.view(np.uint64)), (k, i, list(cols))
-            assert np.array_equal(res[i]._samples, want.samples), (k, i, list(cols))  # noqa: SLF001
-            t["oracle_checks"] += 1
-    except AssertionError as exc:   # (keep going: every differing payload is worth knowing)
-        failures.append(str(exc)[:400])
-        print(f"DIFFERENT payload {k}: {str(exc)[:400]}", file=sys.stderr)
-t["different"] = len(failures)
-t["failures"] = failures[:10]
-print(json.dumps(t))
+def run(n_payloads: int = 100, k0: int = 0) -> dict:
+    """Tallies of `n_payloads` payloads from index `k0` on; `different`: payloads with any difference."""
+    t = {"payloads": 0, "scenarios": 0, "columns": 0, "on_flow_kernel": 0, "to_next_event": 0, "oracle_checks": 0, "overflow_raised": 0, "invalid_points": 0,
+         "paths": {}}
+    failures: list[str] = []
+    for k in range(k0, k0 + n_payloads):
+        rng = random.Random(77000 + k)
+        payload = flow_payload(rng, horizon=6) if k % 4 else lb_with_events(users=rng.choice((60, 120, 300)), horizon=30, scale=0.05)
+        cols = columns(payload, rng)
+        seeds = np.arange(N, dtype=np.uint64) + 1000 * k + 11
+        try:
+            res = SimulationRunner(simulation_input=payload, seeds=seeds, sweep=cols, on_negative_delay="flag").run()
+            ref = SimulationRunner(simulation_input=payload, seeds=seeds, sweep=cols, flow=False, on_negative_delay="flag").run()
+        except OverflowError as exc:   # a pool at the engine's maximum: reported, never silent
+            t["overflow_raised"] += 1
+            print(f"payload {k}: OverflowError: {str(exc)[:200]}", file=sys.stderr)
+            continue
+        except ValueError as exc:   # a point the payload models refuse (e.g. an event window that no longer fits)
+            t["invalid_points"] += 1
+            print(f"payload {k}: {str(exc)[:200]}", file=sys.stderr)
+            continue
+        st = res.engine_stats
+        t["payloads"] += 1
+        t["scenarios"] += N
+        t["columns"] += len(cols)
+        for key in cols:
+            short = key.split("[")[0] + ("[..]" + key.split("]")[-1] if "[" in key else "")
+            t["paths"][short] = t["paths"].get(short, 0) + 1
+        t["on_flow_kernel"] += int(st.flow_scenarios)
+        t["to_next_event"] += int(st.flow_to_next_event)
+        try:
+            assert np.array_equal(res.counts[:, :6], ref.counts[:, :6]), (k, list(cols))
+            assert np.array_equal(res.counts[:, _abi.CNT_MARKS], ref.counts[:, _abi.CNT_MARKS]), (k, list(cols))
+            base = lower(payload).payload   # (normalised: what write_point expects)
+            for i in range(N):
+                assert np.array_equal(res[i].rqs_clock.view(np.uint64), ref[i].rqs_clock.view(np.uint64)), (k, i, list(cols))
+                assert np.array_equal(res[i]._samples, ref[i]._samples), (k, i, list(cols))  # noqa: SLF001
+                point = copy.deepcopy(base)
+                for key, col in cols.items():
+                    write_point(point, key, col[i])
+                want = ol.simulate(lower(point), int(seeds[i]))
+                assert np.array_equal(res[i].counts[:5].astype(np.uint64), want.counts[:5]), (k, i, list(cols), res[i].counts[:5], want.counts[:5])
+                assert np.array_equal(res[i].rqs_clock.view(np.uint64), want.clock.view(np.uint64)), (k, i, list(cols))
+                assert np.array_equal(res[i]._samples, want.samples), (k, i, list(cols))  # noqa: SLF001
+                t["oracle_checks"] += 1
+        except AssertionError as exc:   # (keep going: every differing payload is worth knowing)
+            failures.append(str(exc)[:400])
+            print(f"DIFFERENT payload {k}: {str(exc)[:400]}", file=sys.stderr)
+    t["different"] = len(failures)
+    t["failures"] = failures[:10]
+    return t
+
+
+if __name__ == "__main__":
+    print(json.dumps(run(int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 0)))

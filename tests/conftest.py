@@ -27,5 +27,5 @@ def pytest_configure(config: pytest.Config) -> None:
 
 
 def golden_names() -> list[str]:
-    # pooled_*: statistical fixture; deviation_*: reference behaviour the engine reports instead of reproducing (its own tests)
-    return sorted(p.stem for p in GOLDEN_DIR.glob("*.npz") if not p.stem.startswith(("pooled_", "deviation_")))
+    # pooled_*: statistical fixture (round 5's deviation_* fixture is an ordinary parity fixture since round 6)
+    return sorted(p.stem for p in GOLDEN_DIR.glob("*.npz") if not p.stem.startswith("pooled_"))

@@ -37,7 +37,7 @@ extern "C" int hc_simulate(const af_plan_t* p, uint64_t seed, uint32_t n_ovr, co
                            uint32_t clock_cap, double* clock, uint32_t tick_cap, uint32_t* samples,
                            uint32_t* counts, uint32_t draw_cap) {
     if (!p || p->abi_version != AF_ABI_VERSION || p->struct_size != sizeof(af_plan_t)) return AF_ERR_ABI;
-    if (fcap == 0 || (fcap & (fcap - 1)) != 0 || fcap > 32768) return AF_ERR_INVALID;
+    if (fcap == 0 || (fcap & (fcap - 1)) != 0 || fcap > AF_MAX_FIFO_CAPACITY) return AF_ERR_INVALID;
     af::PackedPlan pk;
     if (!af::pack_plan(*p, pk).empty()) return AF_ERR_INVALID;
     af::PlanView V{};

@@ -374,8 +374,7 @@ def test_full_horizon_properties_and_statistical_parity_with_simpy():
         clock = s.rqs_clock
         assert np.all(np.diff(clock[:, 1]) >= 0) and np.all(clock[:, 1] >= clock[:, 0]) and clock[:, 1].max() < 600.0
         host = s.get_latency_stats()
-        assert np.allclose([host[k] for k in ("mean", "median", "std_dev", "p95", "p99", "min", "max")],
-                           stats[i, 1:], rtol=1e-9, atol=0)
+        assert [host[k] for k in ("mean", "median", "std_dev", "p95", "p99", "min", "max")] == stats[i, 1:].tolist()   # numpy on the host == the HIP analyzer, bit for bit
         sm = s.get_sampled_metrics()
         assert max(sm["ram_in_use"]["srv-1"]) <= 2048 and min(sm["edge_concurrent_connection"]["lb-srv1"]) >= 0
         assert np.array_equal(clock, ol.simulate(lower(payload), int(res.seeds[i])).clock)

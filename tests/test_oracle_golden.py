@@ -94,22 +94,25 @@ def test_ram_in_use_is_the_references_f64_value_rounded_once_to_f32(name):
         assert np.array_equal(decoded, f64)
 
 
-def test_a_blocking_ram_put_is_reported_not_reproduced():
-    """Documented deviation (AF_FLAG_RAM_PUT_BLOCKED).  simpy's `Container._do_put` succeeds only `if
-    self._capacity - self._level >= event.amount`; for a fractional need that is false by ONE ROUNDING -- 2048 - fl(2048 - 100.3)
-    < 100.3 -- so in the reference the request that gives 100.3 MB back waits until the next get on that Container, and its
-    response leaves that much later (server.py:270-276).  The fixture holds what the unmodified reference did; the oracle (and
-    the engine) give the RAM back at once, report the scenario, and differ from the fixture exactly from the first such put on.
-    Whole-MB needs and multiples of 1/256 MB never set the flag (their sums are exact): frac_ram_dyadic_t20 is a parity fixture."""
+def test_a_waiting_ram_put_is_reproduced():
+    """simpy's `Container._do_put` succeeds only `if self._capacity - self._level >= event.amount`; for a fractional need that is
+    false by ONE ROUNDING -- 2048 - fl(2048 - 100.3) < 100.3 -- so in the reference the request that gives 100.3 MB back waits
+    until the next RAM get of that server is processed, and its response leaves that much later (server.py:270-276).  Round 5
+    reported such scenarios (AF_FLAG_RAM_PUT_BLOCKED); since round 6 oracle and engine model the put queue
+    (des_oracle.c::ram_trigger_put, af_core.hpp::m_put_trigger) and the reference's outputs are ordinary parity fixtures:
+    frac_ram_waiting_put_t20 (586 waiting puts) and ram_put_deadlock_t20 (a waiting put facing a waiter that does not fit:
+    the server's RAM is dead for the rest of the run, AF_FLAG_RAM_STARVED like the starved case of ram_starved_t30)."""
     from asyncflow_amd import _abi
 
-    fx = load_fixture("deviation_frac_ram_t20")
-    plan = lower(json.loads(str(fx["payload_json"])))
     assert 2048.0 - (2048.0 - 100.3) < 100.3 and not 2048.0 - (2048.0 - 64.7) < 64.7          # the rounding itself
-    res = ol.simulate(plan, int(fx["seed"]))
-    assert int(res.counts[_abi.CNT_FLAGS]) & _abi.FLAG_RAM_PUT_BLOCKED
-    assert res.generated == int(fx["generated"])                                  # arrivals do not depend on the servers
-    assert not np.array_equal(res.clock[:8], fx["clock"][:8])                     # ... the first response of srv-1 already does
-    assert np.array_equal(res.clock[1], fx["clock"][1])                           # a request served by srv-2 (64.7 MB) is untouched
-    ok = ol.simulate(lower(json.loads(str(load_fixture("frac_ram_dyadic_t20")["payload_json"]))), 21)
-    assert not int(ok.counts[_abi.CNT_FLAGS]) & _abi.FLAG_RAM_PUT_BLOCKED
+    assert not hasattr(_abi, "FLAG_RAM_PUT_BLOCKED")
+    seen = {}
+    for name in ("frac_ram_waiting_put_t20", "ram_put_deadlock_t20", "ram_starved_t30", "frac_ram_dyadic_t20"):
+        fx = load_fixture(name)
+        res = ol.simulate(lower(json.loads(str(fx["payload_json"]))), int(fx["seed"]))
+        assert np.array_equal(res.clock, fx["clock"]) and np.array_equal(res.samples, fx["samples"])
+        seen[name] = (res.put_waits, int(res.counts[_abi.CNT_FLAGS]))
+    assert seen["frac_ram_waiting_put_t20"][0] > 100 and seen["frac_ram_waiting_put_t20"][1] == 0
+    assert seen["ram_put_deadlock_t20"][0] >= 2 and seen["ram_put_deadlock_t20"][1] == _abi.FLAG_RAM_STARVED
+    assert seen["ram_starved_t30"] == (0, _abi.FLAG_RAM_STARVED)
+    assert seen["frac_ram_dyadic_t20"] == (0, 0)          # multiples of 1/256 MB: exact sums, no put ever waits

@@ -150,13 +150,13 @@ def test_interior_points_are_validated_too():
         resolve_sweep(plan, {DOWN_T0: [18.0, 36.5, 20.0], DOWN_T1: [24.0, 41.0, 25.0]}, 3)
     cols = {"rqs_input.avg_active_users.mean": np.repeat(np.arange(1.0, 41.0), 5)}    # 40 distinct points x 5 seeds
     assert runner.validate_points(plan, {k: np.asarray(v) for k, v in cols.items()}, 200) == 40
-    # beyond VALIDATE_EVERY_POINT_UP_TO distinct points: every distinct VALUE of every column on its own, then the
-    # rows holding the extremes, the ends and 64 rows spread evenly -- a 30 x 30 grid is 60 values + < 70 rows, not 900 rows
+    # beyond VALIDATE_EVERY_POINT_UP_TO distinct points: every distinct VALUE of every column inside the first row
+    # that holds it, then the rows holding the extremes, the ends and 64 rows spread evenly -- a 30 x 30 grid is 60 + < 70 rows, not 900
     a, b = np.meshgrid(np.linspace(10.0, 500.0, 30), np.linspace(0.001, 0.02, 30))
     grid = {"rqs_input.avg_active_users.mean": a.ravel(), "topology_graph.edges[*].latency.mean": b.ravel()}
     assert 900 > runner.VALIDATE_EVERY_POINT_UP_TO
     done = runner.validate_points(plan, grid, 900)
-    assert 60 + 4 <= done <= 60 + 70
+    assert 59 + 4 <= done <= 60 + 70
     assert runner.validate_points(plan, grid, 900) == done                                # (memoised: same plan, same columns)
     bad = {k: v.copy() for k, v in grid.items()}
     bad["topology_graph.edges[*].latency.mean"][437] = -0.001                             # one interior value of one column
@@ -164,6 +164,18 @@ def test_interior_points_are_validated_too():
         resolve_sweep(plan, bad, 900)
     with pytest.raises(ValueError, match="integer field"):                               # ... and integrality, whole column
         resolve_sweep(plan, {WINDOW: np.where(np.arange(10_002) == 5_000, 60.5, 60.0)}, 10_002)
+    # columns that share a cross-field constraint.  1 000 points over a spike's start AND end, t_end = t_start + 5 in
+    # every row: each row is a valid payload, although most t_start values lie behind the BASE payload's t_end -- a distinct value
+    # is validated inside a row that holds it, never alone beside the base payload's other fields
+    ev = {e["event_id"]: e for e in plan.payload["events"]}
+    t0 = ev["ev-spike-1"]["start"]["t_start"] + np.linspace(0.0, 20.0, 1_000)
+    moving = {"events[ev-spike-1].start.t_start": t0, "events[ev-spike-1].end.t_end": t0 + 5.0}
+    assert t0[-1] > ev["ev-spike-1"]["end"]["t_end"] and 1_000 > runner.VALIDATE_EVERY_POINT_UP_TO
+    assert runner.validate_points(plan, moving, 1_000) >= 1_000          # (every value is distinct here: every row is checked)
+    crossed = {k: v.copy() for k, v in moving.items()}
+    crossed["events[ev-spike-1].end.t_end"][613] = t0[613] - 0.5         # ONE interior row ends before it starts
+    with pytest.raises(ValueError, match="not a valid payload"):
+        runner.validate_points(plan, crossed, 1_000)
 
 
 @pytest.mark.parametrize("kernel", ["next-event", "flow"])
