@@ -805,13 +805,13 @@ def test_the_general_server_benchmark_batch_is_identical_on_both_kernel_families
     import torch
 
     from asyncflow_amd.results import differing_scenarios
-    from tests.test_gpu_full_batches import _oracle_picks, _sweep
+    from tests.test_gpu_full_batches import _oracle_bulk, _sweep
 
     flow = _sweep(6, 2048, [])
     acc = flow.step()
     torch.cuda.synchronize()
     assert acc["flow_scen"] == flow.n == 2048 and acc["flow_fallback"][0] == 0
-    _oracle_picks(flow, 8)
+    assert _oracle_bulk(flow, 256) == 256          # (round 5: 8 picks) every eighth scenario against the oracle itself
     seq = _sweep(6, 2048, ["--no-flow", "--generic-kernels"])
     seq.step()
     torch.cuda.synchronize()
