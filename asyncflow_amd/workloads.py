@@ -193,3 +193,19 @@ def grid_users_rtt(side: int = 100, users_max: float = 1000.0, hop_mean_max: flo
 
 
 BASELINE_SEED_BASE = {1: 0, 2: 0x5EED0000, 3: 0xC0F30000, 4: 0xC0F40000, 5: 0xFA085000, 6: 0x5EED0000}
+
+
+def reference_examples() -> dict[str, dict]:
+    """The reference's five example inputs (examples/yaml_input/data/*.yml), value for value (pinned on the YAML files by
+    tests/test_reference_live.py::test_baseline_workloads_equal_the_reference_yaml) -- plus the README quickstart
+    (README.md:109-155: 100 users x 100 rpm, 300 s).  `SimulationRunner.prebuild_reference_examples()` builds their
+    plan-specialised kernels where a compiler is, so that a user who runs the reference's own examples on a box without one
+    gets the specialised kernel on the first sweep."""
+    return {
+        "single_server.yml": single_server(horizon=500),
+        "two_servers_lb.yml": lb_two_servers(),
+        "event_inj_lb.yml": lb_with_events(users=120, horizon=600),
+        "event_inj_single_server.yml": single_server_with_spike(),
+        "heavy_inj_single_server.yml": single_server_with_spike(heavy=True),
+        "README quickstart": single_server(users=100, rpm=100, horizon=300),
+    }

@@ -253,3 +253,21 @@ def test_second_chance_tier_form_builds_with_the_key_schedule_per_call(tmp_path,
     assert "-DAF_FJ_KEYS_PER_CALL=1" in spec and "-DAF_FJ_FEAT=607" in spec
     assert len(list(tmp_path.glob("*.hsaco"))) == 1
 
+
+def test_the_references_own_examples_find_their_kernel_in_the_shipped_cache():
+    """a user's FIRST sweep ran on the generic kernels (64 instead of 38 ms per 10 000 replicas of
+    two_servers_lb.yml) unless it was long enough to repay a hipcc run.  The kernel a sweep launches does not depend on its
+    replica count, so `__graft_entry__.build()` now builds ONE kernel per example input of the reference
+    (`SimulationRunner.prebuild_reference_examples`): whoever runs the reference's examples -- the first thing a user of the
+    reference does -- loads a specialised kernel from the cache that ships with the package, with no compiler in reach."""
+    from asyncflow_amd import jit, workloads
+    from asyncflow_amd.runner import SimulationRunner
+
+    specs = SimulationRunner.prebuild_reference_examples()
+    assert set(specs) == set(workloads.reference_examples()) and len(specs) == 6
+    for name, payload in workloads.reference_examples().items():
+        for replicas in (1, 250, 10_000):
+            spec = SimulationRunner(simulation_input=payload, replicas=replicas).jit_spec()
+            assert spec == specs[name], (name, replicas)                 # one shape, whatever the number of replicas
+        assert "-DAF_FLOW_JIT=1" in specs[name]                          # every example is in the stage-parallel kernel's range
+        assert len(jit.code_object(specs[name], build=False)) > 10_000    # ... and its code object is in the cache
