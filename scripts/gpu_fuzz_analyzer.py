@@ -6,7 +6,8 @@ per-request clock) against the same functions.
 
     python scripts/gpu_fuzz_analyzer.py [payloads, default 200] [first payload index, default 0]
 
-Order statistics, RPS, histogram, series: bit-exact; mean / std: 1e-12 relative (different summation order).  One JSON line."""
+Every number bit-exact -- order statistics, RPS, histogram, series, and since round 6 mean / std too (numpy's own summation order).
+One JSON line."""
 import json
 import random
 import sys
