@@ -213,7 +213,8 @@ class AfStats(C.Structure):
         ("jit_fallbacks", C.c_uint32),
         ("gather_ms", C.c_double),
         ("pregen_group", C.c_uint32),
-        ("reserved0", C.c_uint32),
+        ("summary_overlapped", C.c_uint32),
+        ("summary_beside_ms", C.c_double),
     ]
 
 
@@ -239,6 +240,7 @@ EXPORTED_SYMBOLS = (
     "af_engine_create",
     "af_engine_run",
     "af_engine_summarize",
+    "af_engine_run_summarized",
     "af_engine_jit_spec",
     "af_engine_set_kernels",
     "af_engine_stats",
@@ -270,6 +272,8 @@ def declare(lib: C.CDLL) -> C.CDLL:
     lib.af_engine_run.restype = C.c_int
     lib.af_engine_summarize.argtypes = [C.c_void_p, C.POINTER(AfOutputs), C.POINTER(AfSummary)]
     lib.af_engine_summarize.restype = C.c_int
+    lib.af_engine_run_summarized.argtypes = [C.c_void_p, C.POINTER(AfSweep), C.POINTER(AfOutputs), C.POINTER(AfSummary)]
+    lib.af_engine_run_summarized.restype = C.c_int
     lib.af_engine_jit_spec.argtypes = [C.c_void_p, C.POINTER(AfSweep), C.POINTER(AfOutputs), C.c_char_p, C.c_size_t]
     lib.af_engine_jit_spec.restype = C.c_int
     lib.af_engine_set_kernels.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]

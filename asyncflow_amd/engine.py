@@ -172,18 +172,31 @@ class Engine:
             clock_ptr: int, clock_capacity: int, samples_ptr: int, tick_capacity: int, counts_ptr: int,
             draw_capacity: int = 0, specialise: bool = False, online_hist_ptr: int = 0, online_hist_bins: int = 0,
             online_hist_max: float = 0.0, online_rps_ptr: int = 0, online_rps_buckets: int = 0,
-            specialise_build: bool = True) -> _abi.AfStats:
+            specialise_build: bool = True, summary: dict | None = None) -> _abi.AfStats:
         """Launch the sweep; output pointers are DEVICE addresses owned by the caller.
 
         ``specialise``: build (or fetch from the cache) kernels with this plan's shape as compile-time
         constants and use them for this sweep (asyncflow_amd/jit.py; worth it for long sweeps);
         ``specialise_build=False``: only from the cache, never a hipcc run.
+        ``summary``: the keyword arguments of :meth:`summarize` that name its outputs (``stats_ptr``, ``rps_ptr``,
+        ``rps_buckets``, ``hist_ptr``, ``hist_bins``, ``hist_max``, ``series_mean_ptr``, ``series_max_ptr``): run and
+        analyzer in ONE call (``af_engine_run_summarized``) -- the same results as ``run`` then ``summarize``, with the
+        analyzer of the stage-parallel kernel's full residency rounds hidden beside its last, partial one.
         """
         sweep, out, _keep = self._sweep_structs(seeds, overrides, clock_ptr, clock_capacity, samples_ptr, tick_capacity,
                                                 counts_ptr, draw_capacity, online_hist_ptr, online_hist_bins,
                                                 online_hist_max, online_rps_ptr, online_rps_buckets)
         if specialise:
             self._specialise(sweep, out, build=specialise_build)
+        if summary is not None:
+            summ = _abi.AfSummary(int(seeds.shape[0]) if hasattr(seeds, "shape") else len(seeds), int(summary.get("rps_buckets", 0)),
+                                  int(summary.get("hist_bins", 0)), float(summary.get("hist_max", 0.0)),
+                                  C.c_void_p(summary.get("stats_ptr") or None), C.c_void_p(summary.get("rps_ptr") or None),
+                                  C.c_void_p(summary.get("hist_ptr") or None), C.c_void_p(summary.get("series_mean_ptr") or None),
+                                  C.c_void_p(summary.get("series_max_ptr") or None))
+            _check(self._lib, self._lib.af_engine_run_summarized(self._h, C.byref(sweep), C.byref(out), C.byref(summ)),
+                   "af_engine_run_summarized")
+            return self.stats()
         _check(self._lib, self._lib.af_engine_run(self._h, C.byref(sweep), C.byref(out)), "af_engine_run")
         return self.stats()
 

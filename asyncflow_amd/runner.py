@@ -28,7 +28,7 @@ from . import _abi
 from .engine import Engine
 from .payload import load_yaml, normalize_payload
 from .plan import DevicePlan, estimate_capacities, lower
-from .results import BatchedResults, ScenarioResults
+from .results import LATENCY_KEYS, BatchedResults, ScenarioResults
 
 DEFAULT_SEED_BASE = 0x5EED0000  # BASELINE config 2: scenario i uses Philox key 0x5EED0000 + i
 
@@ -350,8 +350,13 @@ class SimulationRunner:
         flow_ring_rows: int = 0,
         devices: Sequence[int] | None = None,
         on_negative_delay: str = "raise",
+        summary: Mapping[str, Any] | bool | None = None,
     ) -> None:
         self.env = env  # accepted for signature compatibility; unused
+        #: the keyword arguments of `BatchedResults.summary()` (True: its defaults): run() then makes ONE engine call for simulation
+        #: and analyzer (`af_engine_run_summarized`: the analyzer of the stage-parallel kernel's full residency rounds runs beside
+        #: its last, partial one) and `results.summary(**the same arguments)` returns what that call wrote
+        self.summary_kw: dict[str, Any] | None = ({} if summary is True else dict(summary)) if summary else None
         self.simulation_input = simulation_input
         self.payload = normalize_payload(simulation_input)
         self.plan: DevicePlan = lower(self.payload)
@@ -410,7 +415,7 @@ class SimulationRunner:
                                  collect_samples=collect_samples, force_global_state=force_global_state, auto_grow=auto_grow,
                                  lanes_per_wave=lanes_per_wave, draw_memory_mb=draw_memory_mb,
                                  expect_shared_instants=expect_shared_instants, specialise=specialise,
-                                 online_summary=online_summary, flow=flow, flow_list_entries=flow_list_entries,
+                                 online_summary=online_summary, flow=flow, flow_list_entries=flow_list_entries, summary=summary,
                                  flow_ring_rows=flow_ring_rows, on_negative_delay=on_negative_delay)
         self._single = seeds is None and int(replicas) == 1 and not self.sweep
         self._engine: Engine | None = None
@@ -595,6 +600,28 @@ class SimulationRunner:
                           online_hist_max=o_max,
                           online_rps_ptr=online_rps.data_ptr() if online_rps is not None and o_buckets else 0,
                           online_rps_buckets=o_buckets)
+            summ_out: dict[str, Any] | None = None
+            summ_ptrs: dict[str, Any] | None = None
+            if self.summary_kw is not None and clock is not None:
+                kw = {"rps": True, "hist_bins": 0, "hist_max": 0.0, "series": False, **self.summary_kw}
+                if not (kw["series"] and samples is None):
+                    T_s = int(self.plan.total_time)
+                    summ_out = {"stats": torch.empty((n, 8), dtype=torch.float64, device=dev), "keys": LATENCY_KEYS}
+                    if kw["rps"] and T_s > 0:
+                        summ_out["rps"] = torch.empty((n, T_s), dtype=torch.float32, device=dev)
+                    if kw["hist_bins"]:
+                        summ_out["hist"] = torch.empty((n, int(kw["hist_bins"])), dtype=torch.int32, device=dev)
+                    if kw["series"]:
+                        summ_out["series_mean"] = torch.empty((n, self.plan.n_series), dtype=torch.float64, device=dev)
+                        summ_out["series_max"] = torch.empty((n, self.plan.n_series), dtype=torch.int32, device=dev)
+                    summ_ptrs = dict(stats_ptr=summ_out["stats"].data_ptr(),
+                                     rps_ptr=summ_out["rps"].data_ptr() if "rps" in summ_out else 0, rps_buckets=T_s if "rps" in summ_out else 0,
+                                     hist_ptr=summ_out["hist"].data_ptr() if "hist" in summ_out else 0, hist_bins=int(kw["hist_bins"]),
+                                     hist_max=float(kw["hist_max"]),
+                                     series_mean_ptr=summ_out["series_mean"].data_ptr() if kw["series"] else 0,
+                                     series_max_ptr=summ_out["series_max"].data_ptr() if kw["series"] else 0)
+                    summ_out["_kw"] = kw
+            torch.cuda.synchronize(dev)
             build = True
             if self.specialise is None:
                 # which kernel family this sweep runs on is the ENGINE's decision (plan range, a sweep it cannot be sized
@@ -608,6 +635,7 @@ class SimulationRunner:
                 **run_kw,
                 specialise=True if self.specialise is None else bool(self.specialise),
                 specialise_build=build,
+                summary=summ_ptrs,
             )
             flow_reason = eng.flow_reason() if self.flow else "flow=False"
             if self.flow and not flow_reason and int(stats.flow_scenarios) == 0:
@@ -620,6 +648,9 @@ class SimulationRunner:
                                  time.perf_counter() - t0, user_cols,
                                  online_hist=online_hist, online_rps=online_rps, online_hist_max=o_max)
             res.flow_reason = flow_reason
+            if summ_out is not None:
+                summ_out["summary_ms"] = float(stats.summary_ms)
+                res._summary_from_run = summ_out  # noqa: SLF001
             over = int(np.bitwise_or.reduce(res.flags)) & _abi.FATAL_FLAGS
             if not over or attempt == MAX_ATTEMPTS - 1 or not self.auto_grow:
                 break
@@ -653,7 +684,7 @@ class SimulationRunner:
             warnings.warn(
                 f"engine capacity overflow (flags={over:#x}); retrying with request_capacity={cap}, "
                 f"fifo_capacity={fifo}, clock_capacity={clock_cap}", RuntimeWarning, stacklevel=2)
-            del counts, clock, samples, res, online_hist, online_rps
+            del counts, clock, samples, res, online_hist, online_rps, summ_out
         res.raise_on_overflow()
         if self.on_negative_delay == "raise":
             res.raise_on_negative_delay()

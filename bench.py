@@ -591,21 +591,30 @@ class RankSweep:
             self.eng.prepare(seeds, over, **kw)     # hipcc run or cache hit: never inside the timed region
             self.jit_build_s = time.perf_counter() - t0
 
-    def run_slice(self, lo: int, hi: int):
-        """af_engine_run over scenarios [lo, hi) of the rank's batch into the (reused) output buffers."""
+    def _summary_args(self, lo: int, hi: int) -> dict:
+        return dict(stats_ptr=self.s_stats[lo:hi].data_ptr(), rps_ptr=self.s_rps[lo:hi].data_ptr(), rps_buckets=self.T,
+                    hist_ptr=self.s_hist[lo:hi].data_ptr(), hist_bins=256, hist_max=self.hist_max,
+                    series_mean_ptr=self.s_mean[lo:hi].data_ptr() if self.s_mean is not None else 0,
+                    series_max_ptr=self.s_max[lo:hi].data_ptr() if self.s_max is not None else 0)
+
+    def run_slice(self, lo: int, hi: int, summarize: bool = False):
+        """af_engine_run over scenarios [lo, hi) of the rank's batch into the (reused) output buffers; `summarize`: the analyzer
+        too, in the same call (af_engine_run_summarized: the same results, the analyzer of the stage-parallel kernel's full
+        residency rounds beside its last, partial one)."""
         seeds, over, kw = self._slice_args(lo, hi)
         if self.online:
             self.o_hist.zero_()
             self.o_rps.zero_()
-        return self.eng.run(seeds, over, specialise=self.specialise, **kw)
+        return self.eng.run(seeds, over, specialise=self.specialise, summary=self._summary_args(lo, hi) if summarize else None, **kw)
 
     def step(self) -> dict:
         """One pass over the rank's batch; returns the engine's own timings summed over the slices."""
         acc = {"kernel_ms": 0.0, "pregen_ms": 0.0, "summary_ms": 0.0, "shared": 0, "jit": 0, "flow_ms": 0.0, "flow_scen": 0,
-               "flow_fallback": [0, 0, 0, 0, 0], "jit_fallbacks": 0}
+               "flow_fallback": [0, 0, 0, 0, 0], "jit_fallbacks": 0, "summary_beside_ms": 0.0, "summary_overlapped": 0}
+        fused = not self.online and not getattr(self.args, "separate_summary", False)
         for lo in range(0, self.n, self.slice):
             hi = min(self.n, lo + self.slice)
-            st = self.run_slice(lo, hi)
+            st = self.run_slice(lo, hi, summarize=fused)
             acc["kernel_ms"] += float(st.kernel_ms)
             acc["pregen_ms"] += float(st.pregen_ms)
             acc["shared"] += int(st.shared_instant_scenarios)
@@ -621,6 +630,12 @@ class RankSweep:
                               "waves": int(st.waves), "request_capacity": int(st.request_capacity),
                               "state_bytes_per_scenario": int(st.state_bytes_per_scenario), "draw_bytes": int(st.draw_bytes)}
             if self.online:      # the kernel-side summary IS the analyzer step of this mode
+                self.last_stats = st
+                continue
+            if fused:            # run + analyzer were ONE call
+                acc["summary_ms"] += float(st.summary_ms)
+                acc["summary_beside_ms"] += float(st.summary_beside_ms)
+                acc["summary_overlapped"] += int(st.summary_overlapped)
                 self.last_stats = st
                 continue
             st = self.eng.summarize(hi - lo, clock_ptr=self.clock.data_ptr(), clock_capacity=self.clock_cap,
@@ -718,6 +733,9 @@ def make_parser() -> argparse.ArgumentParser:
                          "histogram and the 1-s completion counts per scenario (19 KB instead of 1.9 MB per LB-2 scenario), "
                          "so that sweeps far beyond the BASELINE sizes fit (e.g. --scenarios 131072)")
     ap.add_argument("--no-flow", action="store_true", help="next-event kernels only (no stage-parallel kernel)")
+    ap.add_argument("--separate-summary", action="store_true",
+                    help="af_engine_run, then af_engine_summarize (rounds 2-5) instead of the one call af_engine_run_summarized, which "
+                         "hides the analyzer of the stage-parallel kernel's full residency rounds beside its last, partial one")
     ap.add_argument("--flow-list-entries", type=int, default=0, choices=[0, 64, 128, 256])
     ap.add_argument("--flow-ring-rows", type=int, default=0, help="rows of the LDS tick ring (0 = auto, -1 = keep the differences in HBM)")
     ap.add_argument("--hbm-budget-gb", type=float, default=96.0, help="HBM for the output buffers of one slice")
@@ -941,9 +959,15 @@ def main() -> int:  # noqa: C901, PLR0912, PLR0915
             "summary": {
                 "kernels": "af_summary_kernel + af_series_kernel (inside the timed step)",
                 "ms": summary_ms,
-                # one read of every rqs_clock row and sample word is the algorithmic minimum
-                "algorithmic_bytes": out_bytes,
-                "achieved_GBps": out_bytes / max(summary_ms, 1e-9) / 1e6,
+                # af_engine_run_summarized: `ms` is what ran AFTER the simulation kernels; `beside_ms` the analyzer kernels that ran on
+                # the second stream beside the stage-parallel kernel's last residency round, over `overlapped_scenarios` scenarios
+                "call": "af_engine_run, then af_engine_summarize" if args.separate_summary else "af_engine_run_summarized (one call)",
+                "beside_ms": float(np.mean([a["summary_beside_ms"] for a in accs])),
+                "overlapped_scenarios": int(accs[-1]["summary_overlapped"]),
+                # numpy's two-pass variance needs the finished mean: TWO reads of every rqs_clock row (round 6: mean / std_dev bit-equal
+                # to numpy's), one of every sample word
+                "algorithmic_bytes": out_bytes + 16.0 * completed_rank,
+                "achieved_GBps": (out_bytes + 16.0 * completed_rank) / max(summary_ms + float(np.mean([a["summary_beside_ms"] for a in accs])), 1e-9) / 1e6,
             },
             "gather_ms": gather_ms,
             "gather_path": gather_path,

@@ -326,7 +326,9 @@ typedef struct af_stats {
     double gather_ms;              /* last af_engine_gather (HIP events around the grouped all-gather)        */
     uint32_t pregen_group;         /* arrival pre-generation of the stage-parallel path: scenarios per workgroup of
                                       af_arrival_groups, 0 = the row kernel                                   */
-    uint32_t reserved0;
+    uint32_t summary_overlapped;   /* af_engine_run_summarized: scenarios whose analyzer ran on a second stream beside the
+                                      last residency round of the stage-parallel kernel (0: everything after the run) */
+    double summary_beside_ms;      /* ... HIP-event time of those analyzer kernels; summary_ms is then what was NOT hidden */
 } af_stats_t;
 
 typedef struct af_engine af_engine_t;
@@ -376,6 +378,14 @@ typedef struct af_summary_t {
 /* `out` is the af_outputs_t the run filled (clock + counts are required, samples only for the
  * series outputs).  Synchronous like af_engine_run. */
 int af_engine_summarize(af_engine_t* engine, const af_outputs_t* out, const af_summary_t* summary);
+
+/* af_engine_run followed by af_engine_summarize, in one call and with the same results (replaces SimulationRunner.run +
+ * ResultsAnalyzer.process_all_metrics, simulation_runner.py:349-376 + analyzer.py:75-81, for the whole sweep).
+ * summary->n_scenarios must equal sweep->n_scenarios.  Where the sweep is ONE launch sequence of the stage-parallel kernel over
+ * alike scenarios, the analyzer of the scenarios of the kernel's full residency rounds runs on a second stream beside its last,
+ * partial round (af_stats_t.summary_overlapped / summary_beside_ms); everywhere else it runs after the simulation, as the two
+ * separate calls would.  AF_NO_SUMMARY_OVERLAP=1 in the environment: always the latter (measurements). */
+int af_engine_run_summarized(af_engine_t* engine, const af_sweep_t* sweep, const af_outputs_t* out, const af_summary_t* summary);
 
 /* ---- the one collective of a multi-GPU sweep ---------------------------------------------
  * Scenarios shard over the GPUs of a node with no exchange during simulation; at the end every rank

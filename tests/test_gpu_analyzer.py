@@ -233,3 +233,55 @@ def test_kernel_side_summary_without_the_per_request_clock():
     assert np.all(approx[:, 6] <= exact[:, 6]) and np.all(exact[:, 6] - approx[:, 6] <= width)
     assert np.all(approx[:, 7] >= exact[:, 7]) and np.all(approx[:, 7] - exact[:, 7] <= width)
     assert np.array_equal(summ["rps"].cpu().numpy(), rps.astype(np.float32))
+
+
+def _summary_tensors_equal(a: dict, b: dict) -> None:
+    import torch
+
+    for key in ("stats", "rps", "hist", "series_mean", "series_max"):
+        assert (key in a) == (key in b), key
+        if key in a:
+            x, y = a[key], b[key]
+            if x.dtype.is_floating_point:       # bit patterns: NaN rows (no completion) compare equal too
+                x, y = x.view(torch.int64 if x.dtype == torch.float64 else torch.int32), y.view(torch.int64 if y.dtype == torch.float64 else torch.int32)
+            assert torch.equal(x, y), key
+
+
+def test_run_and_analyzer_in_one_call_give_what_the_two_calls_give():
+    """`af_engine_run_summarized` (round 6): the stage-parallel kernel is launched in two parts -- the scenarios of its full residency
+    rounds, then the rest -- and the analyzer of the first part runs on a second stream beside the second.  Same sweep through
+    `SimulationRunner(summary=...)` (one call) and through `run()` + `summary()` (two): every summary tensor bit-equal; with
+    10 000 replicas the overlap is really taken (8 192 scenarios = two rounds of 4 096 resident waves)."""
+    from asyncflow_amd.runner import SimulationRunner
+    from oracle.scenarios import tie_storm
+    import random
+
+    kw = dict(rps=True, hist_bins=64, hist_max=0.25, series=True)
+    payload = lb_two_servers(horizon=30)
+    seeds = np.arange(10_000, dtype=np.uint64) + 77
+    two = SimulationRunner(simulation_input=payload, seeds=seeds, specialise=True).run()
+    one = SimulationRunner(simulation_input=payload, seeds=seeds, specialise=True, summary=kw).run()
+    assert int(one.engine_stats.flow_scenarios) == 10_000 and int(one.engine_stats.flow_fallback) == 0
+    assert int(one.engine_stats.summary_overlapped) == 8_192 and float(one.engine_stats.summary_beside_ms) > 0.0
+    assert np.array_equal(one.counts, two.counts)
+    assert one.summary(**kw)["stats"].data_ptr() == one._summary_from_run["stats"].data_ptr()          # noqa: SLF001  (no second launch)
+    _summary_tensors_equal(one.summary(**kw), two.summary(**kw))
+    i = 9_999                                                                                           # ... and against numpy
+    assert np.array_equal(one.summary(**kw)["stats"][i].cpu().numpy().view(np.uint64), ao.latency_stats(two[i].rqs_clock).view(np.uint64))
+    # the generic kernels (no plan-specialised build) split the same way
+    gen = SimulationRunner(simulation_input=payload, seeds=seeds[:9_000], specialise=False, summary=kw).run()
+    assert int(gen.engine_stats.summary_overlapped) in (4_096, 8_192) and int(gen.engine_stats.specialised_launches) == 0
+    _summary_tensors_equal(gen.summary(**kw), SimulationRunner(simulation_input=payload, seeds=seeds[:9_000], specialise=False).run().summary(**kw))
+    # scenarios the kernel hands back are simulated again after the first part was analysed: the sweep is summarised again
+    storm = tie_storm(random.Random(777_003), horizon=12)
+    s_seeds = np.arange(6_000, dtype=np.uint64) + 5
+    s_one = SimulationRunner(simulation_input=storm, seeds=s_seeds, summary=kw).run()
+    s_two = SimulationRunner(simulation_input=storm, seeds=s_seeds).run()
+    assert int(s_one.engine_stats.summary_overlapped) == 0 or int(s_one.engine_stats.flow_fallback) == 0
+    _summary_tensors_equal(s_one.summary(**kw), s_two.summary(**kw))
+    # a sweep over the load is launched heaviest first (an order array): no split, the analyzer after the run
+    users = np.linspace(20.0, 400.0, 6_000)
+    g_one = SimulationRunner(simulation_input=payload, seeds=s_seeds, sweep={"rqs_input.avg_active_users.mean": users}, summary=kw).run()
+    g_two = SimulationRunner(simulation_input=payload, seeds=s_seeds, sweep={"rqs_input.avg_active_users.mean": users}).run()
+    assert int(g_one.engine_stats.summary_overlapped) == 0
+    _summary_tensors_equal(g_one.summary(**kw), g_two.summary(**kw))
