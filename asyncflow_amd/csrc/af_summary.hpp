@@ -62,7 +62,29 @@ struct SumArgs {
     uint32_t* hist;  // [n][hist_bins] or null
     uint32_t hist_bins;
     double hist_scale;  // hist_bins / hist_max
+    // af_engine_run_summarized (engine.hip): the analyzer running BESIDE the simulation kernel's last residency round
+    const uint32_t* done_flags;  // [n] or null: scenario's outputs are in memory (set by its wave, device-scope release)
+    uint32_t* retry;             // [1 + n]: count, then the scenarios this kernel met unfinished (a later launch takes them: scen_map)
+    const uint32_t* scen_map;    // null, or workgroup j analyses scenario scen_map[j]
 };
+
+// Which scenario is this workgroup's, and may it be analysed yet?  (message passing: the simulation wave stores its outputs,
+// fences at device scope and sets the flag with release semantics; an acquire load of the flag followed by a device-scope
+// acquire fence in every thread makes those outputs visible here, also across the XCDs' L2 caches)
+__device__ inline bool claim_scenario(const uint32_t* done_flags, uint32_t* retry, const uint32_t* scen_map, uint32_t& sc) {
+    sc = scen_map ? scen_map[blockIdx.x] : blockIdx.x;
+    if (done_flags == nullptr) return true;
+    __shared__ uint32_t go;
+    if (threadIdx.x == 0) {
+        const uint32_t f = __hip_atomic_load(done_flags + sc, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if (!f) retry[1u + atomicAdd(retry, 1u)] = sc;
+        go = f;
+    }
+    __syncthreads();
+    if (!go) return false;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return true;
+}
 
 __device__ inline double wave_sum(double v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -274,7 +296,8 @@ __global__ __launch_bounds__(kThreads, kWpe) void af_summary_kernel(SumArgs a) {
 
     constexpr int kLoads = kWpe > 4 ? 4 : 8;   // (16-byte loads in flight per thread: eight at 128 registers, four at 64)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t sc = blockIdx.x;
+    uint32_t sc;
+    if (!claim_scenario(a.done_flags, a.retry, a.scen_map, sc)) return;
     uint32_t n = a.counts[(size_t)sc * 8u + a.cnt_completed_slot];
     if (n > a.clock_cap) n = a.clock_cap;
     const double2* ck = reinterpret_cast<const double2*>(a.clock) + (size_t)sc * a.clock_cap;
@@ -557,6 +580,9 @@ struct SeriesArgs {
     uint32_t tick_cap, pitch, n_series, cnt_ticks_slot, n_edges;
     double* mean;    // [n][n_series]
     uint32_t* maxv;  // [n][n_series]
+    const uint32_t* done_flags;  // (as in SumArgs)
+    uint32_t* retry;
+    const uint32_t* scen_map;
 };
 
 constexpr int kSeriesThreads = 256;
@@ -571,7 +597,8 @@ __global__ __launch_bounds__(kSeriesThreads) void af_series_kernel(SeriesArgs a)
     __shared__ unsigned long long part_sum[kSeriesThreads][4];
     __shared__ uint32_t part_max[kSeriesThreads][4];
     const int tid = threadIdx.x;
-    const uint32_t sc = blockIdx.x;
+    uint32_t sc;
+    if (!claim_scenario(a.done_flags, a.retry, a.scen_map, sc)) return;
     uint32_t ticks = a.counts[(size_t)sc * 8u + a.cnt_ticks_slot];
     if (ticks > a.tick_cap) ticks = a.tick_cap;
     const uint32_t pq = a.pitch / 4u;                       // 16-byte groups per row

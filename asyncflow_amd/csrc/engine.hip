@@ -303,6 +303,17 @@ struct WaveHip {
         return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     static __device__ __forceinline__ void global_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); }
+    // the scenario's outputs are in memory (every lane's stores: a device-scope release fence per lane, then the wave barrier that
+    // orders the lanes), then the flag (release, device scope) and the count (release, SYSTEM scope: host-coherent memory the
+    // analyzer's stream waits on with hipStreamWaitValue32)
+    static __device__ __forceinline__ void signal_done(uint32_t* flag, uint32_t* count) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_wave_barrier();
+        if (threadIdx.x == 0u) {
+            __hip_atomic_store(flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            (void)__hip_atomic_fetch_add(count, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
     static __device__ __forceinline__ double rcp(double x) { return __builtin_amdgcn_rcp(x); }
     static __device__ __forceinline__ double fract(double x) { return __builtin_amdgcn_fract(x); }   // v_fract_f64: x - floor(x), exact for x >= 0
     static __device__ __forceinline__ uint32_t bcast32(uint32_t v, uint32_t src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src); }
@@ -896,11 +907,15 @@ struct af_engine {
     const af_summary_t* fused_sum = nullptr;   // non-null while af_engine_run works for af_engine_run_summarized
     const af_outputs_t* fused_out = nullptr;
     hipStream_t stream2 = nullptr;
-    hipEvent_t ev_a = nullptr, ev_s0 = nullptr, ev_s1 = nullptr;
-    uint32_t fused_done = 0;                   // scenarios [0, fused_done) of the sweep have their summary already
-    uint32_t* d_tail_map = nullptr;            // scenario indices of the partial round
-    size_t tail_map_cap = 0;
-    std::vector<uint32_t> tail_host;
+    hipEvent_t ev_s0 = nullptr, ev_s1 = nullptr;
+    bool fused_done = false;                   // the sweep's summary was written during af_engine_run (but for the retry lists)
+    uint32_t* d_done_flags = nullptr;          // [n] set by a wave of the stage-parallel kernel when its scenario's outputs are in memory
+    size_t done_flags_cap = 0;
+    uint32_t* h_done_count = nullptr;          // pinned, host-coherent: finished scenarios (the second stream waits on it: hipStreamWaitValue32)
+    uint32_t* d_done_count = nullptr;          // ... its device address
+    uint32_t* d_retry = nullptr;               // [2][n + 1]: count, then the scenarios the latency / the series kernel met unfinished
+    size_t retry_cap = 0;
+    int wait_value_ok = -1;                    // hipDeviceAttributeCanUseStreamWaitValue (-1: not asked yet)
     bool shared_instants_likely = false;
     hipModule_t jit_module = nullptr;  // plan-specialised kernels (af_engine_set_kernels), valid for jit_spec only
     hipFunction_t jit_lean = nullptr, jit_order3 = nullptr, jit_order2 = nullptr;
@@ -1705,8 +1720,13 @@ static int check_summary_request(const af_engine_t* e, const af_outputs_t* out, 
 }
 
 // The analyzer's two kernels over scenarios [sc0, sc0 + count) of `out` / `sum`, enqueued on `stream` (no synchronisation).
-static int launch_summary_kernels(af_engine_t* e, const af_outputs_t* out, const af_summary_t* sum, uint32_t sc0, uint32_t count, hipStream_t stream) {
+// `done_flags` / `retry` ([2][n + 1]: count + scenarios, latency kernel then series kernel): workgroups check their scenario's flag
+// and put an unfinished one on their kernel's retry list; `map_lat` / `map_ser` + their counts: the retry launch over such a list.
+static int launch_summary_kernels(af_engine_t* e, const af_outputs_t* out, const af_summary_t* sum, uint32_t sc0, uint32_t count, hipStream_t stream,
+                                  const uint32_t* done_flags = nullptr, uint32_t* retry = nullptr, const uint32_t* map_lat = nullptr, uint32_t n_map_lat = 0u,
+                                  const uint32_t* map_ser = nullptr, uint32_t n_map_ser = 0u) {
     if (count == 0u) return AF_OK;
+    const bool by_map = map_lat != nullptr || map_ser != nullptr;
     const bool want_lat = sum->stats || sum->rps || sum->hist;
     const bool want_series = sum->series_mean || sum->series_max;
     const uint32_t rps_buckets = sum->rps ? sum->rps_buckets : 0u;
@@ -1724,6 +1744,9 @@ static int launch_summary_kernels(af_engine_t* e, const af_outputs_t* out, const
         s.hist = sum->hist ? sum->hist + (size_t)sc0 * sum->hist_bins : nullptr;
         s.hist_bins = sum->hist ? sum->hist_bins : 0u;
         s.hist_scale = sum->hist ? (double)sum->hist_bins / sum->hist_max : 0.0;
+        s.done_flags = done_flags;
+        s.retry = retry;
+        s.scen_map = map_lat;
         // register budget of the latency kernel (af_summary.hpp: kWpe); AF_SUMMARY_WPE=4|8: measurements
         int wpe = kSummaryWpe;
         if (const char* env = std::getenv("AF_SUMMARY_WPE")) wpe = std::atoi(env);
@@ -1731,7 +1754,8 @@ static int launch_summary_kernels(af_engine_t* e, const af_outputs_t* out, const
                                   : reinterpret_cast<const void*>(afs::af_summary_kernel<4>);
         HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes));
         void* kargs[] = {&s};
-        HIP_TRY(hipLaunchKernel(fn, dim3(count), dim3(afs::kThreads), kargs, dyn_bytes, stream));
+        const uint32_t grid = by_map ? n_map_lat : count;
+        if (grid != 0u) HIP_TRY(hipLaunchKernel(fn, dim3(grid), dim3(afs::kThreads), kargs, dyn_bytes, stream));
         HIP_TRY(hipGetLastError());
     }
     if (want_series) {
@@ -1745,7 +1769,11 @@ static int launch_summary_kernels(af_engine_t* e, const af_outputs_t* out, const
         s.n_edges = e->args.n_edges;
         s.mean = sum->series_mean ? sum->series_mean + (size_t)sc0 * n_series : nullptr;
         s.maxv = sum->series_max ? sum->series_max + (size_t)sc0 * n_series : nullptr;
-        hipLaunchKernelGGL(afs::af_series_kernel, dim3(count), dim3(afs::kSeriesThreads), 0, stream, s);
+        s.done_flags = done_flags;
+        s.retry = retry ? retry + (size_t)count + 1u : nullptr;
+        s.scen_map = map_ser;
+        const uint32_t grid = by_map ? n_map_ser : count;
+        if (grid != 0u) hipLaunchKernelGGL(afs::af_series_kernel, dim3(grid), dim3(afs::kSeriesThreads), 0, stream, s);
         HIP_TRY(hipGetLastError());
     }
     return AF_OK;
@@ -2136,17 +2164,20 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
             const void* fn = jit ? nullptr : flow_kernel_for(FP.ipl, FP.feat);
             if (!jit && fn == nullptr) return fail(AF_ERR_INVALID, "no stage-parallel instantiation for this launch");
             if (!jit && flow_lds_launch > 48u * 1024u) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flow_lds_launch));
-            auto launch_flow = [&](uint32_t count) -> int {
-                f.n_scen = count;
-                if (jit) HIP_TRY(hipModuleLaunchKernel(e->flow_jit_fn, count, 1, 1, kWave, 1, 1, flow_lds_launch, e->stream, kargs, nullptr));
-                else HIP_TRY(hipLaunchKernel(fn, dim3(count), dim3(kWave), kargs, flow_lds_launch, e->stream));
-                return AF_OK;
-            };
-            // af_engine_run_summarized, ONE launch sequence over alike scenarios: the scenarios of the kernel's full residency
-            // rounds first, their analyzer on the second stream beside the rest (the partial last round leaves the chip mostly
-            // idle, and the analyzer is HBM-bound where this kernel is VALU-bound)
-            uint32_t n_first = nc;
-            if (e->fused_sum != nullptr && lo == 0u && nc == n && !ordered && d_prof == nullptr) {
+            // af_engine_run_summarized: the analyzer starts on a second stream once the scenarios of the kernel's full residency rounds
+            // have finished (hipStreamWaitValue32 on a counter its waves bump) and runs beside the last, partial round, which leaves
+            // most of the chip idle; the analyzer is HBM-bound where this kernel is VALU-bound.  A workgroup of the analyzer that
+            // meets a scenario still being simulated (its done flag is clear) puts it on a retry list and leaves.
+            // (Measured first, round 6: the kernel launched in two parts with the analyzer of the first beside the second --
+            // 51.9 instead of 48.4 ms per step on BASELINE config 2: the second part cannot start before the LAST wave of the first
+            // has ended and then lasts a whole scenario at low occupancy, 11 ms against the 7 ms of the natural tail.)
+            uint32_t gate = 0u;
+            if (e->fused_sum != nullptr && lo == 0u && nc == n && d_prof == nullptr) {
+                if (e->wait_value_ok < 0) {
+                    int v = 0;
+                    if (hipDeviceGetAttribute(&v, hipDeviceAttributeCanUseStreamWaitValue, e->device) != hipSuccess) { (void)hipGetLastError(); v = 0; }
+                    e->wait_value_ok = v;
+                }
                 int per_cu = 0;
                 hipDeviceProp_t prop;
                 HIP_TRY(hipGetDeviceProperties(&prop, e->device));
@@ -2155,36 +2186,49 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
                 const uint32_t resident = (uint32_t)(per_cu > 0 ? per_cu : 0) * (uint32_t)prop.multiProcessorCount;
                 const uint32_t rem = resident ? nc % resident : 0u;
                 // (a tail of more than three quarters of a round leaves no room for the analyzer's workgroups; no tail, nothing to fill)
-                if (resident != 0u && nc > resident && rem != 0u && rem * 4u <= resident * 3u) n_first = nc - rem;
-                if (std::getenv("AF_DEBUG")) std::fprintf(stderr, "[af] flow launch in two parts: %u resident waves, %u + %u scenarios\n", resident, n_first, nc - n_first);
+                if (e->wait_value_ok > 0 && resident != 0u && nc > resident && rem != 0u && rem * 4u <= resident * 3u) gate = nc - rem;
+                if (std::getenv("AF_DEBUG")) std::fprintf(stderr, "[af] analyzer beside the last round: %u resident waves, gate at %u of %u scenarios\n", resident, gate, nc);
             }
-            if (n_first == nc) {
-                if (int rc = launch_flow(nc)) return rc;
-            } else {
+            if (gate != 0u) {
                 if (e->stream2 == nullptr) {
                     HIP_TRY(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
-                    HIP_TRY(hipEventCreate(&e->ev_a));
                     HIP_TRY(hipEventCreate(&e->ev_s0));
                     HIP_TRY(hipEventCreate(&e->ev_s1));
+                    HIP_TRY(hipHostMalloc((void**)&e->h_done_count, 64, hipHostMallocCoherent | hipHostMallocMapped));
+                    HIP_TRY(hipHostGetDevicePointer((void**)&e->d_done_count, e->h_done_count, 0));
                 }
-                const uint32_t n_tail = nc - n_first;
-                e->tail_host.resize(n_tail);   // (a member: the copy below may read it after this block is left)
-                for (uint32_t i = 0; i < n_tail; ++i) e->tail_host[i] = n_first + i;
-                if (int rc = grow((void**)&e->d_tail_map, e->tail_map_cap, (size_t)n_tail * 4u)) return rc;
-                HIP_TRY(hipMemcpyAsync(e->d_tail_map, e->tail_host.data(), (size_t)n_tail * 4u, hipMemcpyHostToDevice, e->stream));
-                if (int rc = launch_flow(n_first)) return rc;
-                HIP_TRY(hipEventRecord(e->ev_a, e->stream));
-                HIP_TRY(hipStreamWaitEvent(e->stream2, e->ev_a, 0));
-                HIP_TRY(hipEventRecord(e->ev_s0, e->stream2));
-                if (int rc = launch_summary_kernels(e, e->fused_out, e->fused_sum, 0u, n_first, e->stream2)) return rc;
-                HIP_TRY(hipEventRecord(e->ev_s1, e->stream2));
-                f.scen_map = e->d_tail_map;   // wave j of the second part simulates scenario n_first + j
-                if (int rc = launch_flow(n_tail)) return rc;
-                f.scen_map = nullptr;
-                f.n_scen = nc;
+                if (int rc = grow((void**)&e->d_done_flags, e->done_flags_cap, (size_t)nc * 4u)) return rc;
+                if (int rc = grow((void**)&e->d_retry, e->retry_cap, 2u * ((size_t)nc + 1u) * 4u)) return rc;
+                *e->h_done_count = 0u;   // (nothing of this engine is in flight: af_engine_run is synchronous)
+                HIP_TRY(hipMemsetAsync(e->d_done_flags, 0, (size_t)nc * 4u, e->stream));
+                HIP_TRY(hipMemsetAsync(e->d_retry, 0, 2u * ((size_t)nc + 1u) * 4u, e->stream));
+                f.done_flags = e->d_done_flags;
+                f.done_count = e->d_done_count;
             }
-            if (jit) n_jit += 1u;
-            fused_first = n_first == nc ? 0u : n_first;
+            f.n_scen = nc;
+            if (jit) {
+                HIP_TRY(hipModuleLaunchKernel(e->flow_jit_fn, nc, 1, 1, kWave, 1, 1, flow_lds_launch, e->stream, kargs, nullptr));
+                n_jit += 1u;
+            } else {
+                HIP_TRY(hipLaunchKernel(fn, dim3(nc), dim3(kWave), kargs, flow_lds_launch, e->stream));
+            }
+            if (gate != 0u) {
+                // (from here on the second stream waits for the counter: whatever goes wrong below must still let it through)
+                auto release_side = [&]() { *e->h_done_count = 0xFFFFFFFFu; };
+                hipError_t err = hipStreamWaitValue32(e->stream2, e->d_done_count, gate, hipStreamWaitValueGte, 0xFFFFFFFFu);
+                if (err == hipSuccess) err = hipEventRecord(e->ev_s0, e->stream2);
+                int rc = AF_OK;
+                if (err == hipSuccess) rc = launch_summary_kernels(e, e->fused_out, e->fused_sum, 0u, nc, e->stream2, e->d_done_flags, e->d_retry, nullptr, 0u);
+                if (err == hipSuccess && rc == AF_OK) err = hipEventRecord(e->ev_s1, e->stream2);
+                if (err != hipSuccess || rc != AF_OK) {
+                    release_side();
+                    (void)hipStreamSynchronize(e->stream);
+                    (void)hipStreamSynchronize(e->stream2);
+                    if (rc != AF_OK) return rc;
+                    HIP_TRY(err);
+                }
+            }
+            fused_first = gate;
         }
         HIP_TRY(hipEventRecord(e->ev4, e->stream));
         uint32_t fb[5] = {0, 0, 0, 0, 0};
@@ -2196,7 +2240,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
             HIP_TRY(hipEventElapsedTime(&ms_s, e->ev_s0, e->ev_s1));
             e->stats.summary_beside_ms = ms_s;
             // (a scenario handed back is simulated again below and its outputs change: the sweep is then summarised again, in full)
-            e->fused_done = fb[0] == 0u ? fused_first : 0u;
+            e->fused_done = fb[0] == 0u;
         }
         if (d_prof != nullptr) {
             std::vector<unsigned long long> hp((size_t)nc * aff::kProfSections);
@@ -2248,6 +2292,8 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
                 f2.n_scen = (uint32_t)retry.size();
                 f2.scen_map = e->d_map;
                 f2.n_fallback = e->d_fb + 5;
+                f2.done_flags = nullptr;   // (nobody waits for the second chance: the sweep is summarised again after it)
+                f2.done_count = nullptr;
                 const uint32_t lds2 = a.blob_bytes + f2.L.n_words * 8u;
                 if (lds2 > kLdsLimit) return fail(AF_ERR_CAPACITY, "flow kernel layout exceeds the LDS of a compute unit");
                 if (a.online_hist || a.online_rps) {
@@ -2466,21 +2512,31 @@ int af_engine_run_summarized(af_engine_t* e, const af_sweep_t* sweep, const af_o
     if (!sweep || sum->n_scenarios != sweep->n_scenarios) return fail(AF_ERR_INVALID, "summary.n_scenarios must equal sweep.n_scenarios");
     e->fused_sum = std::getenv("AF_NO_SUMMARY_OVERLAP") ? nullptr : sum;
     e->fused_out = out;
-    e->fused_done = 0u;
+    e->fused_done = false;
     e->stats.summary_beside_ms = 0.0;
     const int rc = af_engine_run(e, sweep, out);
     e->fused_sum = nullptr;
     e->fused_out = nullptr;
     if (rc != AF_OK) return rc;
-    const uint32_t done = e->fused_done;
+    const uint32_t n = sum->n_scenarios;
+    uint32_t n_lat = 0u, n_ser = 0u;
+    if (e->fused_done) {   // what the analyzer beside the kernel met unfinished
+        HIP_TRY(hipMemcpy(&n_lat, e->d_retry, 4u, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&n_ser, e->d_retry + (size_t)n + 1u, 4u, hipMemcpyDeviceToHost));
+    }
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
-    if (int rc2 = launch_summary_kernels(e, out, sum, done, sum->n_scenarios - done, e->stream)) return rc2;
+    if (e->fused_done) {
+        if (int rc2 = launch_summary_kernels(e, out, sum, 0u, n, e->stream, nullptr, nullptr, e->d_retry + 1u, n_lat, e->d_retry + (size_t)n + 2u, n_ser)) return rc2;
+    } else {
+        if (int rc2 = launch_summary_kernels(e, out, sum, 0u, n, e->stream)) return rc2;
+    }
     HIP_TRY(hipEventRecord(e->ev1, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
     e->stats.summary_ms = ms;                 // the part of the analyzer that was NOT hidden
-    e->stats.summary_overlapped = done;
+    const bool want_lat = sum->stats || sum->rps || sum->hist;
+    e->stats.summary_overlapped = e->fused_done ? n - (want_lat ? n_lat : n_ser) : 0u;
     return AF_OK;
 }
 
@@ -2507,11 +2563,12 @@ void af_engine_destroy(af_engine_t* e) {
     if (e->ev2) (void)hipEventDestroy(e->ev2);
     if (e->ev3) (void)hipEventDestroy(e->ev3);
     if (e->ev4) (void)hipEventDestroy(e->ev4);
-    if (e->ev_a) (void)hipEventDestroy(e->ev_a);
     if (e->ev_s0) (void)hipEventDestroy(e->ev_s0);
     if (e->ev_s1) (void)hipEventDestroy(e->ev_s1);
     if (e->stream2) (void)hipStreamDestroy(e->stream2);
-    if (e->d_tail_map) (void)hipFree(e->d_tail_map);
+    if (e->d_done_flags) (void)hipFree(e->d_done_flags);
+    if (e->d_retry) (void)hipFree(e->d_retry);
+    if (e->h_done_count) (void)hipHostFree(e->h_done_count);
     if (e->d_draws) (void)hipFree(e->d_draws);
     if (e->d_pre_flags) (void)hipFree(e->d_pre_flags);
     if (e->d_tie) (void)hipFree(e->d_tie);

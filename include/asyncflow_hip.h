@@ -381,10 +381,11 @@ int af_engine_summarize(af_engine_t* engine, const af_outputs_t* out, const af_s
 
 /* af_engine_run followed by af_engine_summarize, in one call and with the same results (replaces SimulationRunner.run +
  * ResultsAnalyzer.process_all_metrics, simulation_runner.py:349-376 + analyzer.py:75-81, for the whole sweep).
- * summary->n_scenarios must equal sweep->n_scenarios.  Where the sweep is ONE launch sequence of the stage-parallel kernel over
- * alike scenarios, the analyzer of the scenarios of the kernel's full residency rounds runs on a second stream beside its last,
- * partial round (af_stats_t.summary_overlapped / summary_beside_ms); everywhere else it runs after the simulation, as the two
- * separate calls would.  AF_NO_SUMMARY_OVERLAP=1 in the environment: always the latter (measurements). */
+ * summary->n_scenarios must equal sweep->n_scenarios.  Where the sweep is ONE launch of the stage-parallel kernel, the analyzer
+ * starts on a second stream as soon as the scenarios of the kernel's full residency rounds have finished (a counter the kernel's
+ * waves bump; hipStreamWaitValue32) and runs beside its last, partial round (af_stats_t.summary_overlapped / summary_beside_ms);
+ * scenarios it meets unfinished, and everything else, are analysed after the simulation, as the two separate calls would.
+ * AF_NO_SUMMARY_OVERLAP=1 in the environment: always the latter (measurements). */
 int af_engine_run_summarized(af_engine_t* engine, const af_sweep_t* sweep, const af_outputs_t* out, const af_summary_t* summary);
 
 /* ---- the one collective of a multi-GPU sweep ---------------------------------------------

@@ -248,10 +248,11 @@ def _summary_tensors_equal(a: dict, b: dict) -> None:
 
 
 def test_run_and_analyzer_in_one_call_give_what_the_two_calls_give():
-    """`af_engine_run_summarized` (round 6): the stage-parallel kernel is launched in two parts -- the scenarios of its full residency
-    rounds, then the rest -- and the analyzer of the first part runs on a second stream beside the second.  Same sweep through
-    `SimulationRunner(summary=...)` (one call) and through `run()` + `summary()` (two): every summary tensor bit-equal; with
-    10 000 replicas the overlap is really taken (8 192 scenarios = two rounds of 4 096 resident waves)."""
+    """`af_engine_run_summarized` (round 6): the analyzer starts on a second stream once the scenarios of the stage-parallel kernel's
+    full residency rounds have finished (a counter its waves bump; `hipStreamWaitValue32`) and runs beside the last, partial round;
+    a workgroup that meets a scenario still being simulated (done flag clear) leaves it to a retry launch after the kernel.  Same
+    sweep through `SimulationRunner(summary=...)` (one call) and through `run()` + `summary()` (two): every summary tensor
+    bit-equal; with 10 000 replicas the overlap is really taken (~8 192 scenarios = two rounds of 4 096 resident waves)."""
     from asyncflow_amd.runner import SimulationRunner
     from oracle.scenarios import tie_storm
     import random
@@ -262,7 +263,7 @@ def test_run_and_analyzer_in_one_call_give_what_the_two_calls_give():
     two = SimulationRunner(simulation_input=payload, seeds=seeds, specialise=True).run()
     one = SimulationRunner(simulation_input=payload, seeds=seeds, specialise=True, summary=kw).run()
     assert int(one.engine_stats.flow_scenarios) == 10_000 and int(one.engine_stats.flow_fallback) == 0
-    assert int(one.engine_stats.summary_overlapped) == 8_192 and float(one.engine_stats.summary_beside_ms) > 0.0
+    assert 8_000 <= int(one.engine_stats.summary_overlapped) <= 10_000 and float(one.engine_stats.summary_beside_ms) > 0.0
     assert np.array_equal(one.counts, two.counts)
     assert one.summary(**kw)["stats"].data_ptr() == one._summary_from_run["stats"].data_ptr()          # noqa: SLF001  (no second launch)
     _summary_tensors_equal(one.summary(**kw), two.summary(**kw))
@@ -270,7 +271,7 @@ def test_run_and_analyzer_in_one_call_give_what_the_two_calls_give():
     assert np.array_equal(one.summary(**kw)["stats"][i].cpu().numpy().view(np.uint64), ao.latency_stats(two[i].rqs_clock).view(np.uint64))
     # the generic kernels (no plan-specialised build) split the same way
     gen = SimulationRunner(simulation_input=payload, seeds=seeds[:9_000], specialise=False, summary=kw).run()
-    assert int(gen.engine_stats.summary_overlapped) in (4_096, 8_192) and int(gen.engine_stats.specialised_launches) == 0
+    assert 4_000 <= int(gen.engine_stats.summary_overlapped) <= 9_000 and int(gen.engine_stats.specialised_launches) == 0
     _summary_tensors_equal(gen.summary(**kw), SimulationRunner(simulation_input=payload, seeds=seeds[:9_000], specialise=False).run().summary(**kw))
     # scenarios the kernel hands back are simulated again after the first part was analysed: the sweep is summarised again
     storm = tie_storm(random.Random(777_003), horizon=12)
@@ -279,9 +280,8 @@ def test_run_and_analyzer_in_one_call_give_what_the_two_calls_give():
     s_two = SimulationRunner(simulation_input=storm, seeds=s_seeds).run()
     assert int(s_one.engine_stats.summary_overlapped) == 0 or int(s_one.engine_stats.flow_fallback) == 0
     _summary_tensors_equal(s_one.summary(**kw), s_two.summary(**kw))
-    # a sweep over the load is launched heaviest first (an order array): no split, the analyzer after the run
+    # a sweep over the load is launched heaviest first (an order array): whatever is finished when the gate opens, in any order
     users = np.linspace(20.0, 400.0, 6_000)
     g_one = SimulationRunner(simulation_input=payload, seeds=s_seeds, sweep={"rqs_input.avg_active_users.mean": users}, summary=kw).run()
     g_two = SimulationRunner(simulation_input=payload, seeds=s_seeds, sweep={"rqs_input.avg_active_users.mean": users}).run()
-    assert int(g_one.engine_stats.summary_overlapped) == 0
     _summary_tensors_equal(g_one.summary(**kw), g_two.summary(**kw))
