@@ -193,7 +193,8 @@ struct FlowArgs {
     const uint32_t* scen_map;  // second-chance launch: wave j simulates scenario scen_map[j] (null = j)
     unsigned long long* prof;  // FEAT_PROF builds: [n_scen][kProfSections] shader-clock cycles per section of run()
     // af_engine_run_summarized: a wave that has written all of its scenario's outputs says so -- done_flags[scenario] = 1 and
-    // *done_count += 1 (the analyzer's stream waits on the count and its workgroups check the flag); null: nobody is waiting
+    // *done_count += 1 (the analyzer's stream waits on the count and its workgroups check the flag); null: nobody is waiting.
+    // (Read by the kernel's entry point after run(), engine.hip: WaveHip::signal_done)
     uint32_t* done_flags;
     uint32_t* done_count;
 };
@@ -213,7 +214,6 @@ enum : uint32_t { PROF_SETUP, PROF_GEN, PROF_SELECT, PROF_SERIES_RECV, PROF_STAT
 //   W::rcp(x)                       ~1/x (only ever used where the exact value does not matter)
 //   W::scan_incl_u32(v)             inclusive prefix sum over the lanes (DPP row shifts / broadcasts on the device)
 //   W::bcast32 / bcast64(v, lane)   value of a WAVE-UNIFORM lane (v_readlane on the device)
-//   W::signal_done(flag, count)     every global store of the wave is in memory; then *flag = 1 (release) and *count += 1
 // Every W:: call is made by all 64 lanes from wave-uniform control flow.
 // IPL = list entries per lane (list capacity = 64 * IPL).
 // FEAT = features compiled in (the host picks the leanest instantiation that covers the launch: every
@@ -2703,7 +2703,6 @@ struct Flow {
             c[af::CNT_MAX_LIVE] = kGen ? gs_rounds : 0u;
             c[af::CNT_MARKS] = marks;
         }
-        if (A.done_flags != nullptr) W::signal_done(A.done_flags + sc, A.done_count);
         if (kProf) {
             prof(PROF_SETUP);
             if (lane == 0u && A.prof != nullptr)

@@ -358,6 +358,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FEAT &
     const uint32_t sc = a.scen_map ? a.scen_map[blockIdx.x] : blockIdx.x;
     aff::Flow<WaveHip, IPL, FEAT> f(a);
     f.run((LDS_AS uint64_t*)smem, sc);
+    if (a.done_flags != nullptr) WaveHip::signal_done(a.done_flags + sc, a.done_count);
     if (threadIdx.x == 0u && a.n_fallback) {
         const uint32_t flags = a.counts[(size_t)sc * af::CNT_SLOTS + af::CNT_FLAGS];
         if (flags & aff::FLAG_FLOW_FALLBACK) {
@@ -434,6 +435,9 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
     const uint32_t sc = a.scen_map ? a.scen_map[blockIdx.x] : blockIdx.x;
     aff::Flow<WaveHip, AF_FJ_IPL, AF_FJ_FEAT> f(a);
     f.run((LDS_AS uint64_t*)smem, sc);
+    // (read from the kernel arguments HERE, not carried through run() in two more scalar register pairs: the general-server form
+    // paid 5 % for that, measured)
+    if (a_in.done_flags != nullptr) WaveHip::signal_done(a_in.done_flags + sc, a_in.done_count);
     if (threadIdx.x == 0u && a.n_fallback) {
         const uint32_t flags = a.counts[(size_t)sc * af::CNT_SLOTS + af::CNT_FLAGS];
         if (flags & aff::FLAG_FLOW_FALLBACK) {
@@ -2186,7 +2190,10 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
                 const uint32_t resident = (uint32_t)(per_cu > 0 ? per_cu : 0) * (uint32_t)prop.multiProcessorCount;
                 const uint32_t rem = resident ? nc % resident : 0u;
                 // (a tail of more than three quarters of a round leaves no room for the analyzer's workgroups; no tail, nothing to fill)
-                if (e->wait_value_ok > 0 && resident != 0u && nc > resident && rem != 0u && rem * 4u <= resident * 3u) gate = nc - rem;
+                // (and only where the partial round is a good part of the launch -- at most six rounds --: the analyzer of a sweep of
+                // many rounds needs longer than the tail lasts, and beside a FULL round it only takes the kernel's slots: BASELINE
+                // config 5, 12.2 rounds, 227 instead of 223 ms per step, measured)
+                if (e->wait_value_ok > 0 && resident != 0u && nc > resident && nc <= 6u * resident && rem != 0u && rem * 4u <= resident * 3u) gate = nc - rem;
                 if (std::getenv("AF_DEBUG")) std::fprintf(stderr, "[af] analyzer beside the last round: %u resident waves, gate at %u of %u scenarios\n", resident, gate, nc);
             }
             if (gate != 0u) {

@@ -129,12 +129,6 @@ struct WaveEmu {
     static void global_add(uint32_t* p, uint32_t v) { *p += v; }
     static uint32_t global_load(const uint32_t* p) { return *p; }
     static void global_fence() {}
-    static void signal_done(uint32_t* flag, uint32_t* count) {
-        if (lane() == 0u) {
-            *flag = 1u;
-            *count += 1u;
-        }
-    }
     static double rcp(double x) { return 1.0 / x; }
     static double fract(double x) { return x - __builtin_floor(x); }   // (x >= 0: exact, like v_fract_f64)
     static uint32_t bcast32(uint32_t v, uint32_t src) { return shfl32(v, src); }
