@@ -192,11 +192,6 @@ struct FlowArgs {
     uint32_t* n_fallback;   // [5]: scenarios handed over, then by reason (tie, list, ring, ram)
     const uint32_t* scen_map;  // second-chance launch: wave j simulates scenario scen_map[j] (null = j)
     unsigned long long* prof;  // FEAT_PROF builds: [n_scen][kProfSections] shader-clock cycles per section of run()
-    // af_engine_run_summarized: a wave that has written all of its scenario's outputs says so -- done_flags[scenario] = 1 and
-    // *done_count += 1 (the analyzer's stream waits on the count and its workgroups check the flag); null: nobody is waiting.
-    // (Read by the kernel's entry point after run(), engine.hip: WaveHip::signal_done)
-    uint32_t* done_flags;
-    uint32_t* done_count;
 };
 // FEAT_PROF: where a wave's time goes (measurement builds only: AF_FLOW_PROF)
 enum : uint32_t { PROF_SETUP, PROF_GEN, PROF_SELECT, PROF_SERIES_RECV, PROF_STATION, PROF_SERVERS, PROF_SERVER_SERIES, PROF_DRAW, PROF_SEND_SERIES,

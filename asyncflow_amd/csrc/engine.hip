@@ -343,6 +343,17 @@ struct WaveHip {
     static __device__ __forceinline__ unsigned long long clock() { return __builtin_amdgcn_s_memtime(); }   // shader cycles
 };
 
+// af_engine_run_summarized: the engine's counter block (FlowArgs::n_fallback) holds, at word kDoneWords, the addresses of the done
+// flags and of the done counter, or zeros.  Read HERE, after run(), through a pointer the kernel keeps anyway: as two more
+// kernel arguments they were two more scalar register pairs live across the whole kernel (general servers: 280 -> 295 ms).
+constexpr uint32_t kDoneWords = 16u;
+static __device__ __forceinline__ void signal_scenario_done(const uint32_t* counter_block, uint32_t sc) {
+    if (counter_block == nullptr) return;
+    const uint64_t* sig = reinterpret_cast<const uint64_t*>(counter_block + kDoneWords);
+    uint32_t* flags = reinterpret_cast<uint32_t*>(sig[0]);
+    if (flags != nullptr) WaveHip::signal_done(flags + sc, reinterpret_cast<uint32_t*>(sig[1]));
+}
+
 // Register budget as waves per SIMD (measured on MI355X, profiles/r02: see DESIGN.md section 4e).
 #ifndef AF_FLOW_WPE
 #define AF_FLOW_WPE 4
@@ -358,7 +369,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((FEAT &
     const uint32_t sc = a.scen_map ? a.scen_map[blockIdx.x] : blockIdx.x;
     aff::Flow<WaveHip, IPL, FEAT> f(a);
     f.run((LDS_AS uint64_t*)smem, sc);
-    if (a.done_flags != nullptr) WaveHip::signal_done(a.done_flags + sc, a.done_count);
+    signal_scenario_done(a.n_fallback, sc);
     if (threadIdx.x == 0u && a.n_fallback) {
         const uint32_t flags = a.counts[(size_t)sc * af::CNT_SLOTS + af::CNT_FLAGS];
         if (flags & aff::FLAG_FLOW_FALLBACK) {
@@ -435,9 +446,7 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
     const uint32_t sc = a.scen_map ? a.scen_map[blockIdx.x] : blockIdx.x;
     aff::Flow<WaveHip, AF_FJ_IPL, AF_FJ_FEAT> f(a);
     f.run((LDS_AS uint64_t*)smem, sc);
-    // (read from the kernel arguments HERE, not carried through run() in two more scalar register pairs: the general-server form
-    // paid 5 % for that, measured)
-    if (a_in.done_flags != nullptr) WaveHip::signal_done(a_in.done_flags + sc, a_in.done_count);
+    signal_scenario_done(a.n_fallback, sc);
     if (threadIdx.x == 0u && a.n_fallback) {
         const uint32_t flags = a.counts[(size_t)sc * af::CNT_SLOTS + af::CNT_FLAGS];
         if (flags & aff::FLAG_FLOW_FALLBACK) {
@@ -920,6 +929,7 @@ struct af_engine {
     uint32_t* d_retry = nullptr;               // [2][n + 1]: count, then the scenarios the latency / the series kernel met unfinished
     size_t retry_cap = 0;
     int wait_value_ok = -1;                    // hipDeviceAttributeCanUseStreamWaitValue (-1: not asked yet)
+    uint64_t done_ptrs[2] = {0, 0};            // host copy of d_fb[kDoneWords ..] (a member: an asynchronous copy reads it)
     bool shared_instants_likely = false;
     hipModule_t jit_module = nullptr;  // plan-specialised kernels (af_engine_set_kernels), valid for jit_spec only
     hipFunction_t jit_lean = nullptr, jit_order3 = nullptr, jit_order2 = nullptr;
@@ -946,7 +956,9 @@ struct af_engine {
     size_t arr_cap = 0;
     uint32_t* d_arr_flags = nullptr;
     size_t arr_flags_cap = 0;
-    uint32_t* d_fb = nullptr;      // [10] hand-over counters of the first and of the second-chance launch
+    uint32_t* d_fb = nullptr;      // [32]: [0..9] hand-over counters of the first and of the second-chance launch; [16..19] two 64-bit
+                                   // words: af_engine_run_summarized's done flags / done counter (kDoneWords), 0 = nobody waits;
+                                   // [21..24], what the second chance (d_fb + 5) finds at that offset: always 0
     uint32_t* d_slot = nullptr;    // draw slots of a second pass over a subset
     size_t slot_cap = 0;
     // host copy of what the layout heuristics need
@@ -1681,7 +1693,7 @@ int af_engine_create(const af_plan_t* plan, int device, const af_engine_options_
     if (err == hipSuccess && e->flow_ok) err = hipMalloc((void**)&e->d_tick, (e->tick.t.size() + 1u) * 8u);
     if (err == hipSuccess && e->flow_ok && !e->tick.t.empty())
         err = hipMemcpy(e->d_tick, e->tick.t.data(), e->tick.t.size() * 8u, hipMemcpyHostToDevice);
-    if (err == hipSuccess) err = hipMalloc((void**)&e->d_fb, 10u * 4u);
+    if (err == hipSuccess) err = hipMalloc((void**)&e->d_fb, 32u * 4u);
     if (err == hipSuccess) err = hipEventCreate(&e->ev0);
     if (err == hipSuccess) err = hipEventCreate(&e->ev1);
     if (err == hipSuccess) err = hipEventCreate(&e->ev2);
@@ -2144,7 +2156,7 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
         f.online_rps_buckets = a.online_rps_buckets;
         f.online_hist_scale = a.online_hist_scale;
         f.n_fallback = e->d_fb;
-        HIP_TRY(hipMemsetAsync(e->d_fb, 0, 10u * 4u, e->stream));
+        HIP_TRY(hipMemsetAsync(e->d_fb, 0, 32u * 4u, e->stream));
         // measurement hook (AF_FLOW_PROF=<file>, plan-specialised builds only): shader-clock time per section of Flow::run
         unsigned long long* d_prof = nullptr;
         const char* prof_path = std::getenv("AF_FLOW_PROF");
@@ -2209,8 +2221,11 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
                 *e->h_done_count = 0u;   // (nothing of this engine is in flight: af_engine_run is synchronous)
                 HIP_TRY(hipMemsetAsync(e->d_done_flags, 0, (size_t)nc * 4u, e->stream));
                 HIP_TRY(hipMemsetAsync(e->d_retry, 0, 2u * ((size_t)nc + 1u) * 4u, e->stream));
-                f.done_flags = e->d_done_flags;
-                f.done_count = e->d_done_count;
+                // (where the kernel's entry point finds them: behind the hand-over counters it already has a pointer to -- two more
+                // kernel arguments cost the general-server form 5 %, measured: its register allocation answers small changes chaotically)
+                e->done_ptrs[0] = reinterpret_cast<uint64_t>(e->d_done_flags);
+                e->done_ptrs[1] = reinterpret_cast<uint64_t>(e->d_done_count);
+                HIP_TRY(hipMemcpyAsync(e->d_fb + kDoneWords, e->done_ptrs, 16u, hipMemcpyHostToDevice, e->stream));
             }
             f.n_scen = nc;
             if (jit) {
@@ -2299,8 +2314,6 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
                 f2.n_scen = (uint32_t)retry.size();
                 f2.scen_map = e->d_map;
                 f2.n_fallback = e->d_fb + 5;
-                f2.done_flags = nullptr;   // (nobody waits for the second chance: the sweep is summarised again after it)
-                f2.done_count = nullptr;
                 const uint32_t lds2 = a.blob_bytes + f2.L.n_words * 8u;
                 if (lds2 > kLdsLimit) return fail(AF_ERR_CAPACITY, "flow kernel layout exceeds the LDS of a compute unit");
                 if (a.online_hist || a.online_rps) {
