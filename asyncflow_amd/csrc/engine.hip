@@ -2530,7 +2530,11 @@ int af_engine_summarize(af_engine_t* e, const af_outputs_t* out, const af_summar
 int af_engine_run_summarized(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* out, const af_summary_t* sum) {
     if (int rc = check_summary_request(e, out, sum)) return rc;
     if (!sweep || sum->n_scenarios != sweep->n_scenarios) return fail(AF_ERR_INVALID, "summary.n_scenarios must equal sweep.n_scenarios");
-    e->fused_sum = std::getenv("AF_NO_SUMMARY_OVERLAP") ? nullptr : sum;
+    // (a profiler that collects counters runs the kernels of a process ONE AT A TIME -- rocprofv3 --pmc sets
+    // ROCPROF_COUNTER_COLLECTION --: nothing can run beside anything, and a dispatch held back behind a stream wait can stall
+    // the tool's serialiser.  There, and with AF_NO_SUMMARY_OVERLAP set, the analyzer runs after the simulation.)
+    const bool serialised = std::getenv("AF_NO_SUMMARY_OVERLAP") != nullptr || std::getenv("ROCPROF_COUNTER_COLLECTION") != nullptr;
+    e->fused_sum = serialised ? nullptr : sum;
     e->fused_out = out;
     e->fused_done = false;
     e->stats.summary_beside_ms = 0.0;

@@ -23,16 +23,16 @@ for step in "$@"; do
     cal)
       hipcc --offload-arch=gfx950 -O2 -o /tmp/valu_calibration scripts/microbench/valu_calibration.hip 2> /dev/null
       /tmp/valu_calibration > $OUT/cal_stdout.json
-      rm -rf /tmp/pcal; timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE --output-format csv -d /tmp/pcal -o c -- /tmp/valu_calibration > $OUT/cal_under_pmc.log 2>&1
+      rm -rf /tmp/pcal; timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE --output-format csv -d /tmp/pcal -o c -- /tmp/valu_calibration > $OUT/cal_under_pmc.log 2>&1
       cp $(find /tmp/pcal -name "*counter_collection.csv" | head -1) $OUT/cal_counters.csv
       python scripts/make_valu_calibration.py $OUT | tail -14 ;;
     c2|c3|c4|c5|gensrv)
       L=$step; C=$(cfg_of $L); B="python bench.py --config $C --no-cpu-baseline --no-diagnostics"
       $B --steps 3 --warmup 1 > $OUT/bench_unprofiled_$L.log 2>&1
-      rm -rf /tmp/pt; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt -o t -- $B --steps 3 --warmup 1 --no-parity-check > $OUT/bench_under_trace_$L.log 2>&1
+      rm -rf /tmp/pt; timeout -k 10 420 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt -o t -- $B --steps 3 --warmup 1 --no-parity-check > $OUT/bench_under_trace_$L.log 2>&1
       cp $(find /tmp/pt -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_trace_$L.csv
       f=$(find /tmp/pt -name "*kernel_trace.csv" | head -1); head -1 $f > $OUT/kernel_trace_af_$L.csv; grep -E "$KERN" $f >> $OUT/kernel_trace_af_$L.csv
-      pass() { i=$1; shift; rm -rf /tmp/pp$i; timeout 600 rocprofv3 --pmc "$@" --output-format csv -d /tmp/pp$i -o p -- $B --steps 1 --warmup 0 --no-parity-check > $OUT/bench_under_pmc${i}_$L.log 2>&1; f=$(find /tmp/pp$i -name "*counter_collection.csv" | head -1); head -1 $f > $OUT/pmc${i}_$L.csv; grep -E "$KERN" $f >> $OUT/pmc${i}_$L.csv; }
+      pass() { i=$1; shift; rm -rf /tmp/pp$i; timeout -k 10 420 rocprofv3 --pmc "$@" --output-format csv -d /tmp/pp$i -o p -- $B --steps 1 --warmup 0 --no-parity-check > $OUT/bench_under_pmc${i}_$L.log 2>&1; f=$(find /tmp/pp$i -name "*counter_collection.csv" | head -1); head -1 $f > $OUT/pmc${i}_$L.csv; grep -E "$KERN" $f >> $OUT/pmc${i}_$L.csv; }
       pass 1 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVES SQ_WAVE_CYCLES
       pass 2 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_THREAD_CYCLES_VALU
       pass 3 FETCH_SIZE
