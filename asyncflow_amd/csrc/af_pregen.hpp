@@ -200,6 +200,9 @@ struct ArrivalArgs {
     uint32_t group;    // scenarios per workgroup (<= 64)
     const uint64_t* seeds;
     const uint32_t* scen_map;   // slot j holds scenario scen_map[j] (null: j)
+    const uint32_t* group_order;   // workgroup j works on group group_order[j] (null: j): sweeps over the load start their HEAVIEST
+                                   // groups first -- workgroups are dispatched in index order, a group lasts as long as its heaviest
+                                   // scenario's chain, and a users-major grid would otherwise start its longest groups last
     uint32_t n_ovr;
     const uint32_t* ovr_param;
     const uint32_t* ovr_index;
@@ -317,7 +320,7 @@ __global__ void __launch_bounds__(kGroupThreads) af_arrival_groups(const Arrival
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const bool chain = tid < 64u;
     const uint32_t ptid = tid - 64u;   // (producers)
-    const uint32_t slot0 = blockIdx.x * a.group;
+    const uint32_t slot0 = (a.group_order ? a.group_order[blockIdx.x] : blockIdx.x) * a.group;
     const uint32_t n_here = a.n_scen - slot0 < a.group ? a.n_scen - slot0 : a.group;
     const double T = a.total_time;
     double* rows = a.out + (size_t)slot0 * a.stride;

@@ -57,7 +57,9 @@ def run(n_payloads: int = 40, k0: int = 0, only: str | None = None, oracle_every
     fams = {n: f for n, f in families.items() if only is None or only in n}
     out = {}
     for name, make in fams.items():
-        t = {"payloads": 0, "scenarios": 0, "on_flow_kernel": 0, "handed_back_first": 0, "to_next_event": 0, "oracle_checks": 0, "not_in_range": 0, "overflow_raised": 0}
+        t = {"payloads": 0, "scenarios": 0, "on_flow_kernel": 0, "handed_back_first": 0, "to_next_event": 0, "oracle_checks": 0, "not_in_range": 0, "overflow_raised": 0,
+             # where the default run's kernel time went (VERDICT r5 item 7 asks for the split): stage-parallel kernel (both launches) / next-event kernels
+             "flow_kernel_ms": 0.0, "next_event_kernel_ms": 0.0}
         for k in range(k0, k0 + n_payloads):
             payload = make(k)
             seeds = np.arange(8, dtype=np.uint64) + 1000 * k + 7
@@ -75,6 +77,8 @@ def run(n_payloads: int = 40, k0: int = 0, only: str | None = None, oracle_every
             t["on_flow_kernel"] += int(st.flow_scenarios)
             t["handed_back_first"] += int(st.flow_fallback)
             t["to_next_event"] += int(st.flow_to_next_event)
+            t["flow_kernel_ms"] += float(st.flow_kernel_ms)
+            t["next_event_kernel_ms"] += float(st.kernel_ms) - float(st.flow_kernel_ms)
             assert np.array_equal(res.counts[:, :6], ref.counts[:, :6]), (name, k)
             assert np.array_equal(res.counts[:, _abi.CNT_MARKS], ref.counts[:, _abi.CNT_MARKS]), (name, k)
             for i in range(8):
