@@ -720,7 +720,7 @@ static uint32_t pregen_group_width(uint32_t n) {
 }
 
 static int launch_pregen_arrivals(const KArgs& a, uint32_t n, uint32_t stride, bool uniform_load, hipStream_t stream,
-                                  bool grouped = false, uint32_t* group_out = nullptr, const uint32_t* d_group_order = nullptr) {
+                                  bool grouped = false, uint32_t* group_out = nullptr, const uint32_t* d_heaviest_first = nullptr) {
     if (grouped) {
         afp::ArrivalArgs g{};
         g.total_time = a.total_time;
@@ -733,10 +733,13 @@ static int launch_pregen_arrivals(const KArgs& a, uint32_t n, uint32_t stride, b
         g.n_draw = a.n_draw;
         g.stride = stride;
         g.group = pregen_group_width(n);
-        g.group_order = d_group_order;
         if (group_out) *group_out = g.group;
         g.seeds = a.seeds;
         g.scen_map = a.scen_map;
+        if (d_heaviest_first != nullptr) {   // slot j = scenario d_heaviest_first[j], its arrival times to that scenario's row
+            g.scen_map = d_heaviest_first;
+            g.rows_by_scenario = 1u;
+        }
         g.n_ovr = a.n_ovr;
         g.ovr_param = a.ovr_param;
         g.ovr_index = a.ovr_index;
@@ -921,9 +924,6 @@ struct af_engine {
     size_t map_cap = 0;
     uint32_t* d_order = nullptr;   // launch order of the stage-parallel kernel for sweeps over the load (heaviest scenario first)
     size_t order_cap = 0;
-    uint32_t* d_group_order = nullptr;   // ... and of af_arrival_groups' workgroups (heaviest group first)
-    size_t group_order_cap = 0;
-    std::vector<uint32_t> group_order_host;   // (a member: an asynchronous copy reads it)
     // af_engine_run_summarized: the analyzer of the scenarios of the stage-parallel kernel's FULL residency rounds runs on a
     // second stream beside the kernel's last, partial round (round 6)
     const af_summary_t* fused_sum = nullptr;   // non-null while af_engine_run works for af_engine_run_summarized
@@ -1136,27 +1136,6 @@ static std::vector<uint32_t> heaviest_first(const af_engine_t* e, const af_sweep
     for (uint32_t i = 0; i < nc; ++i) load[i] = (users ? users[i] : e->users_mean) * (rpm ? rpm[i] : e->rpm_mean);
     std::vector<uint32_t> order(nc);
     for (uint32_t i = 0; i < nc; ++i) order[i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return load[x] > load[y]; });
-    return order;
-}
-// af_arrival_groups over a sweep of unlike loads: the groups (consecutive scenarios) by the load of their heaviest scenario,
-// heaviest first
-static std::vector<uint32_t> groups_heaviest_first(const af_engine_t* e, const af_sweep_t* sweep, uint32_t lo, uint32_t nc, uint32_t group) {
-    const double* users = nullptr;
-    const double* rpm = nullptr;
-    for (uint32_t k = 0; k < sweep->n_overrides; ++k) {
-        const af_override_t& o = sweep->overrides[k];
-        if (o.param == AF_PARAM_GEN_USERS_MEAN) users = o.values + lo;
-        else if (o.param == AF_PARAM_GEN_RPM_MEAN) rpm = o.values + lo;
-    }
-    const uint32_t n_groups = (nc + group - 1u) / group;
-    std::vector<double> load(n_groups, 0.0);
-    for (uint32_t i = 0; i < nc; ++i) {
-        const double l = (users ? users[i] : e->users_mean) * (rpm ? rpm[i] : e->rpm_mean);
-        if (l > load[i / group]) load[i / group] = l;
-    }
-    std::vector<uint32_t> order(n_groups);
-    for (uint32_t i = 0; i < n_groups; ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return load[x] > load[y]; });
     return order;
 }
@@ -2158,17 +2137,12 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
             HIP_TRY(hipMemcpyAsync(e->d_order, order.data(), (size_t)nc * 4u, hipMemcpyHostToDevice, e->stream));
             HIP_TRY(hipStreamSynchronize(e->stream));   // (`order` leaves scope; 40 KB, before anything of this chunk is enqueued)
         }
-        const uint32_t* d_group_order = nullptr;
-        if (grouped && hetero_load && std::getenv("AF_PREGEN_ORDER_OFF") == nullptr) {
-            // (round 6: BASELINE config 4's users-major slices of 25 000 scenarios are 391 groups on 256 CUs -- in index order the
-            // heaviest groups, 12.8 ms of chain each, start last: 21 ms per launch)
-            e->group_order_host = groups_heaviest_first(e, sweep, lo, nc, pregen_group_width(nc));
-            if (int rc = grow((void**)&e->d_group_order, e->group_order_cap, e->group_order_host.size() * 4u)) return rc;
-            HIP_TRY(hipMemcpyAsync(e->d_group_order, e->group_order_host.data(), e->group_order_host.size() * 4u, hipMemcpyHostToDevice, e->stream));
-            d_group_order = e->d_group_order;
-        }
+        // (round 6) a sweep over the load hands its scenarios to af_arrival_groups in the order the simulation kernel is launched
+        // in -- heaviest first --: a workgroup lasts as long as its heaviest scenario's chain, and BASELINE config 4's slices are
+        // dealt by load (every group of 64 consecutive scenarios held a heavy one: 391 groups x 12.8 ms on 256 CUs)
+        const uint32_t* d_heaviest_first = (grouped && ordered && std::getenv("AF_PREGEN_ORDER_OFF") == nullptr) ? e->d_order : nullptr;
         HIP_TRY(hipEventRecord(e->ev2, e->stream));
-        if (launch_pregen_arrivals(a, nc, n_draw, !hetero_load, e->stream, grouped, &pregen_group, d_group_order)) return fail(AF_ERR_HIP, "af_arrival_groups: LDS attribute");
+        if (launch_pregen_arrivals(a, nc, n_draw, !hetero_load, e->stream, grouped, &pregen_group, d_heaviest_first)) return fail(AF_ERR_HIP, "af_arrival_groups: LDS attribute");
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(e->ev3, e->stream));
         aff::FlowArgs f = e->fargs;
@@ -2648,7 +2622,6 @@ void af_engine_destroy(af_engine_t* e) {
     if (e->d_arr) (void)hipFree(e->d_arr);
     if (e->d_arr_flags) (void)hipFree(e->d_arr_flags);
     if (e->d_fb) (void)hipFree(e->d_fb);
-    if (e->d_group_order) (void)hipFree(e->d_group_order);
     if (e->d_slot) (void)hipFree(e->d_slot);
     if (e->jit_module) (void)hipModuleUnload(e->jit_module);
     if (e->flow_jit_module) (void)hipModuleUnload(e->flow_jit_module);

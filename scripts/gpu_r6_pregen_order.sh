@@ -9,3 +9,4 @@ for c in 4 3; do
     AF_PREGEN_ORDER_OFF=1 python bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline --no-diagnostics > $OUT/bench_c${c}_index_order_$rep.log 2>&1; line $OUT/bench_c${c}_index_order_$rep.log "config $c index order         "
   done
 done
+( time timeout 1500 python -m pytest tests/test_gpu_full_batches.py tests/test_gpu_parity.py -m gpu -q -k "config_4 or arrival or grid or sweep" ) > $OUT/gputests_grids.log 2>&1; tail -6 $OUT/gputests_grids.log
