@@ -628,7 +628,8 @@ class RankSweep:
                               "flow_lds_bytes": int(st.flow_lds_bytes), "state_in_lds": int(st.state_in_lds),
                               "lds_bytes_per_wave": int(st.lds_bytes_per_wave), "lanes_per_wave": int(st.lanes_per_wave),
                               "waves": int(st.waves), "request_capacity": int(st.request_capacity),
-                              "state_bytes_per_scenario": int(st.state_bytes_per_scenario), "draw_bytes": int(st.draw_bytes)}
+                              "state_bytes_per_scenario": int(st.state_bytes_per_scenario), "draw_bytes": int(st.draw_bytes),
+                              "pregen_group": int(st.pregen_group)}
             if self.online:      # the kernel-side summary IS the analyzer step of this mode
                 self.last_stats = st
                 continue
@@ -955,6 +956,7 @@ def main() -> int:  # noqa: C901, PLR0912, PLR0915
             "pregen_ms": float(np.mean([a["pregen_ms"] for a in accs])),
             "flow_kernel_ms": float(np.mean([a["flow_ms"] for a in accs])),
             "draw_bytes": rs["draw_bytes"],
+            "pregen_group": rs.get("pregen_group"),      # scenarios per workgroup of af_arrival_groups; 0: the row kernel (af_pregen_arrivals_rows)
             "summary_ms": summary_ms,
             "summary": {
                 "kernels": "af_summary_kernel + af_series_kernel (inside the timed step)",
