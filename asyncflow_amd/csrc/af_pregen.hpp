@@ -200,9 +200,6 @@ struct ArrivalArgs {
     uint32_t group;    // scenarios per workgroup (<= 64)
     const uint64_t* seeds;
     const uint32_t* scen_map;   // slot j holds scenario scen_map[j] (null: j)
-    uint32_t rows_by_scenario;  // 0: slot j's arrival times go to row j of `out` (and pre_flags[j]); 1: to the row of scenario
-                                // scen_map[j] -- sweeps over the load hand in their scenarios HEAVIEST FIRST (round 6): a workgroup lasts
-                                // as long as its heaviest scenario's chain, so alike scenarios share a workgroup and the longest start first
     uint32_t n_ovr;
     const uint32_t* ovr_param;
     const uint32_t* ovr_index;
@@ -254,7 +251,6 @@ struct GroupLds {
     uint32_t d0[64];                   // draw index at which the scenario's current window began; kIdle: it does not run
     uint32_t sums_k[2][64], sums_n[2][64];   // where the round's arrival times go in the scenario's row, how many they are
     uint32_t k_final[64];
-    uint32_t row_of[64];               // row of `out` the scenario's arrival times go to
     uint32_t run[2];                   // [round parity] a lane still runs after the round
     uint32_t window[2];                // [window parity] 0: every scenario is done, 1: nobody runs in this window, 2: rounds follow
 };
@@ -271,14 +267,13 @@ __device__ __forceinline__ void group_produce(GroupLds& M, uint32_t buf, uint32_
         M.in[buf][s][j] = unit_variate(((uint64_t)hi << 32) | lo, d0 + round * kChunk + j);
     }
 }
-__device__ __forceinline__ void group_store(const GroupLds& M, uint32_t buf, double* out, uint32_t stride, uint32_t n_here,
+__device__ __forceinline__ void group_store(const GroupLds& M, uint32_t buf, double* rows, uint32_t stride, uint32_t n_here,
                                             uint32_t ptid) {
     const uint32_t j = ptid & 63u;
     for (uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ptid >> 6)); s < n_here; s += kProducers) {
         const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)M.sums_n[buf][s]);
         const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)M.sums_k[buf][s]);
-        const uint32_t row = (uint32_t)__builtin_amdgcn_readfirstlane((int)M.row_of[s]);
-        if (j < n) out[(size_t)row * stride + k + j] = M.sums[buf][s][j];
+        if (j < n) rows[(size_t)s * stride + k + j] = M.sums[buf][s][j];
     }
 }
 template <bool FAST_DIV>
@@ -325,6 +320,7 @@ __global__ void __launch_bounds__(kGroupThreads) af_arrival_groups(const Arrival
     const uint32_t slot0 = blockIdx.x * a.group;
     const uint32_t n_here = a.n_scen - slot0 < a.group ? a.n_scen - slot0 : a.group;
     const double T = a.total_time;
+    double* rows = a.out + (size_t)slot0 * a.stride;
     // the chain wave's lanes: their scenarios
     const bool valid = chain && lane < n_here;
     const uint32_t slot = slot0 + (valid ? lane : 0u);
@@ -341,7 +337,6 @@ __global__ void __launch_bounds__(kGroupThreads) af_arrival_groups(const Arrival
         rps_per_user = arrival_param(a, af::PARAM_GEN_RPM_MEAN, scen, a.rpm) / 60.0;
         if (valid) L.state = LANE_WAIT;
         M.seed[lane] = seed;
-        M.row_of[lane] = a.rows_by_scenario ? scen : slot;
         // (the chain wave is the critical path of the workgroup: it issues before the producers it shares its SIMD with)
         __builtin_amdgcn_s_setprio(3);
     }
@@ -371,22 +366,22 @@ __global__ void __launch_bounds__(kGroupThreads) af_arrival_groups(const Arrival
                 if (lane == 0u) M.run[b] = any_run ? 1u : 0u;
             } else {
                 group_produce(M, b ^ 1u, r + 1u, n_here, ptid);
-                if (r > 0u) group_store(M, b ^ 1u, a.out, a.stride, n_here, ptid);
+                if (r > 0u) group_store(M, b ^ 1u, rows, a.stride, n_here, ptid);
             }
             __syncthreads();
             ++r;
             if (M.run[b] == 0u) break;
         }
-        if (!chain) group_store(M, (r - 1u) & 1u, a.out, a.stride, n_here, ptid);   // the last round's
+        if (!chain) group_store(M, (r - 1u) & 1u, rows, a.stride, n_here, ptid);   // the last round's
     }
     // behind the last arrival: +inf
     if (chain) {
         M.k_final[lane] = L.k;
-        if (valid) a.pre_flags[a.rows_by_scenario ? scen : slot] = L.flags;
+        if (valid) a.pre_flags[slot] = L.flags;
     }
     __syncthreads();
     for (uint32_t s = 0u; s < n_here; ++s) {
-        double* o = a.out + (size_t)M.row_of[s] * a.stride;
+        double* o = rows + (size_t)s * a.stride;
         for (uint32_t i = M.k_final[s] + tid; i < a.n_draw; i += kGroupThreads) o[i] = af::AF_INF;
     }
 }

@@ -720,7 +720,7 @@ static uint32_t pregen_group_width(uint32_t n) {
 }
 
 static int launch_pregen_arrivals(const KArgs& a, uint32_t n, uint32_t stride, bool uniform_load, hipStream_t stream,
-                                  bool grouped = false, uint32_t* group_out = nullptr, const uint32_t* d_heaviest_first = nullptr) {
+                                  bool grouped = false, uint32_t* group_out = nullptr) {
     if (grouped) {
         afp::ArrivalArgs g{};
         g.total_time = a.total_time;
@@ -736,10 +736,6 @@ static int launch_pregen_arrivals(const KArgs& a, uint32_t n, uint32_t stride, b
         if (group_out) *group_out = g.group;
         g.seeds = a.seeds;
         g.scen_map = a.scen_map;
-        if (d_heaviest_first != nullptr) {   // slot j = scenario d_heaviest_first[j], its arrival times to that scenario's row
-            g.scen_map = d_heaviest_first;
-            g.rows_by_scenario = 1u;
-        }
         g.n_ovr = a.n_ovr;
         g.ovr_param = a.ovr_param;
         g.ovr_index = a.ovr_index;
@@ -2137,12 +2133,8 @@ int af_engine_run(af_engine_t* e, const af_sweep_t* sweep, const af_outputs_t* o
             HIP_TRY(hipMemcpyAsync(e->d_order, order.data(), (size_t)nc * 4u, hipMemcpyHostToDevice, e->stream));
             HIP_TRY(hipStreamSynchronize(e->stream));   // (`order` leaves scope; 40 KB, before anything of this chunk is enqueued)
         }
-        // (round 6) a sweep over the load hands its scenarios to af_arrival_groups in the order the simulation kernel is launched
-        // in -- heaviest first --: a workgroup lasts as long as its heaviest scenario's chain, and BASELINE config 4's slices are
-        // dealt by load (every group of 64 consecutive scenarios held a heavy one: 391 groups x 12.8 ms on 256 CUs)
-        const uint32_t* d_heaviest_first = (grouped && ordered && std::getenv("AF_PREGEN_ORDER_OFF") == nullptr) ? e->d_order : nullptr;
         HIP_TRY(hipEventRecord(e->ev2, e->stream));
-        if (launch_pregen_arrivals(a, nc, n_draw, !hetero_load, e->stream, grouped, &pregen_group, d_heaviest_first)) return fail(AF_ERR_HIP, "af_arrival_groups: LDS attribute");
+        if (launch_pregen_arrivals(a, nc, n_draw, !hetero_load, e->stream, grouped, &pregen_group)) return fail(AF_ERR_HIP, "af_arrival_groups: LDS attribute");
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(e->ev3, e->stream));
         aff::FlowArgs f = e->fargs;
