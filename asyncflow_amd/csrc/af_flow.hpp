@@ -136,7 +136,7 @@ inline FlowLayout make_flow_layout(uint32_t cap, uint32_t ring_rows, uint32_t g_
     L.off_out = w; w += 64u * 2u + 32u;
     L.off_sorted = w; w += tiebreak ? 2u * cap : cap;   // bucket-sorted keys [, their send times]
     L.off_hist = w; w += 32u + 32u + 8u;
-    L.off_eb = w; w += caps4 ? (cap + 1u) / 2u : 0u;    // FEAT_BIGLIST: u32 per entry (bucket | slot, then rank)
+    L.off_eb = w; w += caps4 ? ((cap + 1u) / 2u > 64u || !general_servers ? (cap + 1u) / 2u : 64u) : 0u;    // FEAT_BIGLIST: u32 per entry (bucket | slot, then rank); FEAT_GENSRV: also the solver's 128 place ids (gen_servers_par)
     L.off_seg = scratch0;
     if (w < scratch0 + 5u * 64u) w = scratch0 + 5u * 64u;
     L.off_fr = w; w += n_servers * c_ring;
@@ -195,7 +195,8 @@ struct FlowArgs {
 };
 // FEAT_PROF: where a wave's time goes (measurement builds only: AF_FLOW_PROF)
 enum : uint32_t { PROF_SETUP, PROF_GEN, PROF_SELECT, PROF_SERIES_RECV, PROF_STATION, PROF_SERVERS, PROF_SERVER_SERIES, PROF_DRAW, PROF_SEND_SERIES,
-                  PROF_APPEND, PROF_COMPLETE, PROF_FLUSH, kProfSections = 16u };
+                  PROF_APPEND, PROF_COMPLETE, PROF_FLUSH, PROF_PAR_SETUP, PROF_PAR_WALK, PROF_PAR_RANK, PROF_PAR_FINAL,
+                  PROF_N_PAR_ROUNDS /* counts, not cycles */, PROF_N_PAR_ITERS, PROF_N_PAR_LANES, PROF_N_WALKED_ROUNDS, PROF_PAR_STANDING, PROF_PAR_COMMIT_WALK, kProfSections = 22u };
 
 // ---- the algorithm, written against a wave backend W ---------------------------------------------
 //   W::lane()                       0..63
@@ -1762,6 +1763,7 @@ struct Flow {
     // at an arrival's instant, a release at a request's instant: the grant is at that instant either way, and the zero-length wait
     // it may be counted for ends before any tick sees it -- a tick AT the instant is flagged by tick_index) needs no order.
     static constexpr uint32_t kParBursts = 2u, kParSteps = 24u, kParIters = 24u, kParCores = 4u;
+    static constexpr uint32_t kPairU = 8u;   // keys of the all-pairs loops in flight at once
     // 128 LDS words of the solver behind the servers' state (FlowLayout::off_gsrv; make_flow_layout)
     AF_CORE AF_PLAN_AS double* par_words() const { return (AF_PLAN_AS double*)(M + A.L.off_gsrv + A.n_servers * kGsWords); }
 #if defined(AF_PAR_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
@@ -1834,6 +1836,7 @@ struct Flow {
         }
         const double ram_mb = u2d(blob[A.off_srv + af::SREC * sv]);
         bool hazard = role == 2u && need > ram_mb;   // (waits for good: FLAG_RAM_STARVED is gen_servers()'s to report)
+        prof(PROF_PAR_SETUP);
 
         // ---- the walk: my request from where it stands up to its first time >= limit, with the grants G[] it knows
         double G[kParBursts], r[kParBursts], rel[kParBursts];
@@ -1842,6 +1845,12 @@ struct Flow {
         uint32_t cls = 3u, fin_row = 0u, n_ev = 0u;   // cls: 0 left the server, 1 a step is pending at limit, 2 waits for the core at limit
         double fin_key = AF_INF;
         bool fin_holds = false, fin_io = false;
+        // (round 6: ONE straight line per step.  A lane is a request, so in every step some lanes stand before a CPU step, some
+        // before an I/O step and some at the end of their endpoint: as nested branches the wave ran all of them one after the
+        // other with the lane-varying booleans kept as scalar masks that every join merges -- ~200 instructions per step, most of
+        // them scalar, the two words of the step row fetched one after the other.  Here every lane evaluates the three cases'
+        // predicates and the state moves on through selects; only the series' entries sit in divergent regions.)
+        const int32_t need_w = (int32_t)(need * A.ram_scale);
         auto walk = [&](bool commit) {
 #pragma unroll
             for (uint32_t b = 0u; b < kParBursts; ++b) {
@@ -1857,87 +1866,73 @@ struct Flow {
                 r[0] = -1000.0 - (double)idx;
                 nb = 1u;
             }
-            if (commit && role == 2u && need > 0.0 && samples != nullptr) add_point(s0 + 2u, a_row, (int32_t)(need * A.ram_scale));
+            const bool ser = commit && samples != nullptr;   // (wave-uniform)
+            if (ser && role == 2u && need > 0.0) add_point(s0 + 2u, a_row, need_w);
             for (uint32_t step = 0u; step < kParSteps; ++step) {
                 if (!W::any(alive)) break;
-                if (alive && pending) {   // the Timeout of step rw fires at tt
-                    if (!(tt < limit)) {
-                        cls = 1u;
-                        fin_key = tt;
-                        fin_row = rw;
-                        fin_holds = h;
-                        fin_io = io;
-                        alive = false;
-                    } else {
-                        n_ev += 1u;
-                        rw += 1u;
-                        pending = false;
-                    }
-                }
-                const uint32_t kind = alive ? (uint32_t)blob[A.off_row + af::TREC * rw + 2u] : af::STEP_END;
-                const double dur = alive ? u2d(blob[A.off_row + af::TREC * rw]) : 0.0;
+                // the Timeout of step rw fires at tt: beyond the window it is the request's state for the next round
+                const bool fire = alive && pending, in_win = tt < limit;
+                const bool stop1 = fire && !in_win, adv = fire && in_win;
+                cls = stop1 ? 1u : cls;
+                fin_key = stop1 ? tt : fin_key;
+                fin_row = stop1 ? rw : fin_row;
+                fin_holds = stop1 ? h : fin_holds;
+                fin_io = stop1 ? io : fin_io;
+                alive = alive && !stop1;
+                n_ev += adv ? 1u : 0u;
+                rw += adv ? 1u : 0u;
+                pending = pending && !adv;
+                // (both words of the row at once, by every lane: a lane that is through reads the row it stopped at)
+                const uint32_t kind = (uint32_t)blob[A.off_row + af::TREC * rw + 2u];
+                const double dur = u2d(blob[A.off_row + af::TREC * rw]);
                 // (one tick row per step: the time the step is reached at; a grant's own row below)
-                const bool want_row = commit && alive && samples != nullptr && !queued;
-                const uint32_t rown = !want_row ? 0u : (role == 2u && step == 0u) ? a_row : tick_index(tt, true);
-                if (alive && kind == af::STEP_CPU) {
-                    if (io) {
-                        io = false;
-                        if (want_row) add_point(s0 + 1u, rown, -1);
-                    }
-                    if (!h) {
-                        if (nb >= kParBursts) {
-                            hazard = true;
-                            alive = false;
-                        } else {
-                            const double rb = tt, sg = G[nb] > rb ? G[nb] : rb;
-                            r[nb] = rb;
-                            const bool waits = queued || sg > rb;
-                            if (!(sg < limit)) {   // still in the core queue when the window ends
-                                if (commit && waits && !queued && samples != nullptr) add_point(s0, rown, 1);
-                                cls = 2u;
-                                fin_key = rb;
-                                fin_row = rw;
-                                alive = false;
-                            } else {
-                                if (commit && waits && samples != nullptr) {
-                                    if (!queued) add_point(s0, rown, 1);
-                                    add_point(s0, tick_index(sg, true), -1);
-                                }
-                                tt = sg;
-                                h = true;
-                                open = nb;
-                                nb += 1u;
-                                queued = false;
-                            }
-                        }
-                    }
-                    if (alive) {
-                        const double tn = tt + dur;
-                        hazard = hazard || !(tn > tt);
-                        tt = tn;
-                        pending = true;
-                    }
-                } else if (alive && kind == af::STEP_IO) {
-                    if (h) {
-                        rel[open] = tt;
-                        h = false;
-                    }
-                    if (!io) {
-                        io = true;
-                        if (want_row) add_point(s0 + 1u, rown, 1);
-                    }
-                    const double tn = tt + dur;
-                    hazard = hazard || !(tn > tt);
-                    tt = tn;
-                    pending = true;
-                } else if (alive) {   // the endpoint is through (server.py:257-276)
-                    if (h) rel[open] = tt;
-                    if (io && want_row) add_point(s0 + 1u, rown, -1);
-                    if (need > 0.0 && want_row) add_point(s0 + 2u, rown, -(int32_t)(need * A.ram_scale));
-                    cls = 0u;
-                    fin_key = tt;
-                    alive = false;
+                const bool want_row = ser && alive && !queued;
+                uint32_t rown = 0u;
+                if (want_row) rown = (role == 2u && step == 0u) ? a_row : tick_index(tt, true);
+                const bool is_cpu = alive && kind == af::STEP_CPU, is_io = alive && kind == af::STEP_IO, is_end = alive && !is_cpu && !is_io;
+                // a CPU step of a request that does not hold the core: CPU.get() at rb, granted at max(rb, what it knows of its predecessor)
+                const bool need_core = is_cpu && !h;
+                const bool hz = need_core && nb >= kParBursts, acq = need_core && nb < kParBursts;
+                double Gn = G[0];
+#pragma unroll
+                for (uint32_t b = 1u; b < kParBursts; ++b) Gn = nb == b ? G[b] : Gn;
+                const double rb = tt, sg = Gn > rb ? Gn : rb;
+#pragma unroll
+                for (uint32_t b = 0u; b < kParBursts; ++b) r[b] = (acq && nb == b) ? rb : r[b];
+                const bool waits = queued || sg > rb, sg_in = sg < limit;
+                const bool stay = acq && !sg_in, got = acq && sg_in;   // stay: still in the core queue when the window ends
+                if (ser) {
+                    const bool io_down = (is_cpu || is_end) && io, io_up = is_io && !io;
+                    add_point(s0 + 1u, rown, io_up ? 1 : -1, want_row && (io_down || io_up));
+                    add_point(s0, rown, 1, want_row && acq && waits);   // (want_row: not a waiter of an earlier round, whose +1 was entered then)
+                    if (got && waits) add_point(s0, tick_index(sg, true), -1);
+                    add_point(s0 + 2u, rown, -need_w, want_row && is_end && need > 0.0);
                 }
+                cls = stay ? 2u : cls;
+                fin_key = stay ? rb : fin_key;
+                fin_row = stay ? rw : fin_row;
+                hazard = hazard || hz;
+                alive = alive && !stay && !hz;
+                tt = got ? sg : tt;
+                open = got ? nb : open;
+                nb += got ? 1u : 0u;
+                queued = queued && !got;
+                // an I/O step or the end of the endpoint gives the core back (server.py:239-259)
+                const bool give = (is_io || is_end) && h;
+#pragma unroll
+                for (uint32_t b = 0u; b < kParBursts; ++b) rel[b] = (give && open == b) ? tt : rel[b];
+                h = (h || got) && !is_io;
+                io = is_cpu ? false : is_io ? true : io;
+                // the step's own Timeout
+                const bool timed = (is_cpu && alive) || is_io;
+                const double tn = tt + dur;
+                hazard = hazard || (timed && !(tn > tt));
+                tt = timed ? tn : tt;
+                pending = pending || timed;
+                // the endpoint is through (server.py:257-276)
+                cls = is_end ? 0u : cls;
+                fin_key = is_end ? tt : fin_key;
+                alive = alive && !is_end;
             }
             hazard = hazard || alive;   // more steps ahead than the walk takes
         };
@@ -1949,35 +1944,48 @@ struct Flow {
         // station's time), publishes its release times at those places and reads the place in front of it.
         AF_PLAN_AS double* keys = seg(3);                                  // [64][kParBursts]: seg(3), seg(4) are free in this station
         AF_PLAN_AS double* sorted_rel = par_words();                       // [64][kParBursts]
+        AF_PLAN_AS uint32_t* place_id = eb();                              // [64][kParBursts]: select_big()'s per-entry words are free in this station
         const uint32_t e0 = kParBursts * my_base, n_e = mine ? kParBursts * n_mine : 0u;
         bool settled = false;
         for (uint32_t it = 0u; it < kParIters && !settled; ++it) {
             walk(false);
+            prof(PROF_PAR_WALK);
+            if (kProf) prof_acc[PROF_N_PAR_ITERS] += 1ull;
             if (W::any(hazard)) AF_PAR_LEAVE("a step program outside the walk's range");
             W::sync();   // (the previous iteration's reads of keys / sorted_rel are done)
             if (mine)
 #pragma unroll
                 for (uint32_t b = 0u; b < kParBursts; ++b) keys[kParBursts * lane + b] = r[b];
             W::sync();
-            uint32_t lt[kParBursts], le[kParBursts];
+            uint32_t lt[kParBursts];
 #pragma unroll
-            for (uint32_t b = 0u; b < kParBursts; ++b) lt[b] = le[b] = 0u;
-            for (uint32_t i = 0u; i < kParBursts * blk_max; ++i) {
-                const double ko = i < n_e ? keys[e0 + i] : AF_INF;
+            for (uint32_t b = 0u; b < kParBursts; ++b) lt[b] = 0u;
+            // (round 6: kPairU keys fetched before the first of them is compared -- the loads are unconditional, what lies behind
+            // the block is masked by the comparison of the index -- instead of one masked LDS read, a wait and eight VALU
+            // operations per trip; and only the keys BELOW mine are counted: two acquisitions with one request time get the same
+            // place, which the place's id shows -- each writes its own, one of them reads the other's back)
+            for (uint32_t i0 = 0u; i0 < kParBursts * blk_max; i0 += kPairU) {
+                double kq[kPairU];
 #pragma unroll
-                for (uint32_t b = 0u; b < kParBursts; ++b) {
-                    lt[b] += ko < r[b] ? 1u : 0u;
-                    le[b] += ko <= r[b] ? 1u : 0u;
+                for (uint32_t u = 0u; u < kPairU; ++u) kq[u] = keys[(e0 + i0 + u) & (64u * kParBursts - 1u)];   // (inside the array whatever the lane's block)
+#pragma unroll
+                for (uint32_t u = 0u; u < kPairU; ++u) {
+                    const double ko = i0 + u < n_e ? kq[u] : AF_INF;
+#pragma unroll
+                    for (uint32_t b = 0u; b < kParBursts; ++b) lt[b] += ko < r[b] ? 1u : 0u;
                 }
             }
-            bool tie = false;
 #pragma unroll
-            for (uint32_t b = 0u; b < kParBursts; ++b) {
-                tie = tie || (r[b] < AF_INF && le[b] != lt[b] + 1u);   // another CPU.get() of this server at my instant
-                if (mine && r[b] < AF_INF) sorted_rel[e0 + lt[b]] = rel[b];
-            }
+            for (uint32_t b = 0u; b < kParBursts; ++b)
+                if (mine && r[b] < AF_INF) {
+                    sorted_rel[e0 + lt[b]] = rel[b];
+                    place_id[e0 + lt[b]] = kParBursts * lane + b;
+                }
             W::sync();
-            bool changed = false;
+            bool changed = false, tie = false;
+#pragma unroll
+            for (uint32_t b = 0u; b < kParBursts; ++b)   // another CPU.get() of this server at my instant took my place (or I took its)
+                tie = tie || (mine && r[b] < AF_INF && place_id[e0 + lt[b]] != kParBursts * lane + b);
 #pragma unroll
             for (uint32_t b = 0u; b < kParBursts; ++b) {
                 // one core: the acquisition in front of mine releases last of all before me.  c cores (Container FIFO: the k-th
@@ -1988,14 +1996,20 @@ struct Flow {
 #pragma unroll
                     for (uint32_t c = 0u; c < kParCores; ++c) top[c] = -AF_INF;
                     const uint32_t n_before = (mine && r[b] < AF_INF) ? lt[b] : 0u;
-                    for (uint32_t i = 0u; i < kParBursts * blk_max; ++i) {
-                        double x = i < n_before ? sorted_rel[e0 + i] : -AF_INF;
+                    for (uint32_t i0 = 0u; i0 < kParBursts * blk_max; i0 += kPairU) {   // (loads first: see the rank loop)
+                        double xq[kPairU];
 #pragma unroll
-                        for (uint32_t c = 0u; c < kParCores; ++c) {   // insertion into the descending top-c list
-                            const bool up = x > top[c];
-                            const double t2 = up ? top[c] : x;
-                            top[c] = up ? x : top[c];
-                            x = t2;
+                        for (uint32_t u = 0u; u < kPairU; ++u) xq[u] = sorted_rel[(e0 + i0 + u) & (64u * kParBursts - 1u)];
+#pragma unroll
+                        for (uint32_t u = 0u; u < kPairU; ++u) {
+                            double x = i0 + u < n_before ? xq[u] : -AF_INF;
+#pragma unroll
+                            for (uint32_t c = 0u; c < kParCores; ++c) {   // insertion into the descending top-c list
+                                const bool up = x > top[c];
+                                const double t2 = up ? top[c] : x;
+                                top[c] = up ? x : top[c];
+                                x = t2;
+                            }
                         }
                     }
                     const uint32_t my_cores = (uint32_t)blob[A.off_srv + af::SREC * sv + 1u] & 0xFFFFu;
@@ -2010,6 +2024,7 @@ struct Flow {
                 G[b] = found;
             }
             settled = !W::any(changed);
+            prof(PROF_PAR_RANK);
             if (settled && W::any(tie)) AF_PAR_LEAVE("two CPU.get() at one instant");
         }
         if (!settled) AF_PAR_LEAVE("no fixed point within kParIters");
@@ -2017,37 +2032,48 @@ struct Flow {
         // ---- where everybody stands at `limit`: places among the responses / pending step ends / core waiters of my server
         // (RAM: every arrival must find its need at once -- the level at its instant is what the round began with, less what the
         // arrivals before it took, plus what left before it; needs are multiples of 1/256 MB, so these sums are exact in any order)
-        uint32_t rank = 0u;
-        double need_new = 0.0, need_gone = 0.0, took_before = 0.0, back_before = 0.0;
+        // (round 6: two words per peer -- its time, and class | role | RAM need in units of 1 / ram_scale MB in one u32 -- fetched
+        // kPairU peers ahead; what the arrivals before mine took and the servers' totals are prefix sums over the lanes: a server's
+        // block is contiguous and its arrivals stand in it in time order.  Round 5's loop read four words per peer one peer at a
+        // time and kept four f64 sums.)
+        uint32_t rank = 0u, back_u = 0u;
         bool tie = false;
-        {
-            AF_PLAN_AS double* p_key = seg(3);
-            AF_PLAN_AS double* p_need = seg(4);
-            AF_PLAN_AS double* p_start = par_words();
-            AF_PLAN_AS uint64_t* p_meta = (AF_PLAN_AS uint64_t*)(par_words() + 64);
-            W::sync();
-            if (mine) {
-                p_key[lane] = fin_key;
-                p_need[lane] = need;
-                p_start[lane] = t_start;
-                p_meta[lane] = (uint64_t)(cls | (role << 2));
+        AF_PLAN_AS double* p_key = seg(3);
+        AF_PLAN_AS uint32_t* p_meta = place_id;   // (the relaxation is over)
+        const double need_s = need * A.ram_scale;
+        const uint32_t need_u = (mine && need_s < 16777216.0) ? (uint32_t)need_s : 0u;
+        if (W::any(mine && (double)need_u != need_s)) AF_PAR_LEAVE("a RAM need that is not a small multiple of the unit");
+        W::sync();
+        if (mine) {
+            p_key[lane] = fin_key;
+            p_meta[lane] = cls | (role << 2) | (need_u << 4);
+        }
+        W::sync();
+        for (uint32_t i0 = 0u; i0 < blk_max; i0 += kPairU) {   // (loads first: see the rank loop)
+            uint32_t mq[kPairU];
+            double kq[kPairU];
+#pragma unroll
+            for (uint32_t u = 0u; u < kPairU; ++u) {
+                const uint32_t o = (my_base + i0 + u) & 63u;   // (lanes past my block read somebody's words: masked below)
+                mq[u] = p_meta[o];
+                kq[u] = p_key[o];
             }
-            W::sync();
-            for (uint32_t i = 0u; i < blk_max; ++i) {
-                const bool in = mine && i < n_mine;
-                const uint32_t o = my_base + (in ? i : 0u);
-                const uint32_t mo = in ? (uint32_t)p_meta[o] : 0xFu;
-                const uint32_t co = mo & 3u, ro = mo >> 2;
-                const double ko = p_key[o], no = in ? p_need[o] : 0.0, ao = p_start[o];
-                const bool peer = in && co == cls;
-                rank += peer && ko < fin_key ? 1u : 0u;
-                tie = tie || (peer && ko == fin_key && o != lane && cls != 2u);
-                need_new += ro == 2u ? no : 0.0;
-                need_gone += co == 0u ? no : 0.0;
-                took_before += ro == 2u && (ao < t_start || (ao == t_start && o < lane)) ? no : 0.0;
-                back_before += co == 0u && ko < t_start ? no : 0.0;
+#pragma unroll
+            for (uint32_t u = 0u; u < kPairU; ++u) {
+                const bool in = mine && i0 + u < n_mine;
+                const bool peer = in && (mq[u] & 3u) == cls;
+                rank += peer && kq[u] < fin_key ? 1u : 0u;
+                tie = tie || (peer && kq[u] == fin_key && my_base + i0 + u != lane && cls != 2u);
+                back_u += (in && (mq[u] & 3u) == 0u && kq[u] < t_start) ? mq[u] >> 4 : 0u;   // RAM that came back before my arrival
             }
         }
+        const uint32_t last = (my_base + (n_mine ? n_mine - 1u : 0u)) & 63u;
+        const uint32_t new_u = role == 2u ? need_u : 0u, gone_u = (mine && cls == 0u) ? need_u : 0u;
+        const uint32_t new_incl = W::scan_incl_u32(new_u), gone_incl = W::scan_incl_u32(gone_u);
+        const uint32_t new_base = W::shfl32(new_incl - new_u, my_base), gone_base = W::shfl32(gone_incl - gone_u, my_base);
+        const double took_before = (double)(new_incl - new_u - new_base) * A.ram_unit, back_before = (double)back_u * A.ram_unit;
+        const double need_new = (double)(W::shfl32(new_incl, last) - new_base) * A.ram_unit;
+        const double need_gone = (double)(W::shfl32(gone_incl, last) - gone_base) * A.ram_unit;
         if (W::any(tie && mine)) AF_PAR_LEAVE("two responses / two pending step ends at one instant");
         // per server: how many leave, stay with a pending step, stay in the core queue; RAM must never have run short
         uint32_t n_dep = 0u, n_run1 = 0u, n_wait1 = 0u;
@@ -2065,9 +2091,11 @@ struct Flow {
         }
         const bool ram_short = role == 2u && need > 0.0 && u2d(g[GS_RAM]) - took_before + back_before < need;
         if (!fits || W::any(ram_short)) AF_PAR_LEAVE(!fits ? "more requests inside than slots" : "RAM could run short");
+        prof(PROF_PAR_STANDING);
 
         // ---- commit: series and counts of the window's events, the servers' state at `limit`, the responses in time order
         walk(true);
+        prof(PROF_PAR_COMMIT_WALK);
         ev += n_ev;
         done_any = W::any(n_ev != 0u || role == 2u) ? 1u : 0u;
         W::sync();
@@ -2115,6 +2143,11 @@ struct Flow {
             }
         }
         W::sync();
+        prof(PROF_PAR_FINAL);
+        if (kProf) {
+            prof_acc[PROF_N_PAR_ROUNDS] += 1ull;
+            prof_acc[PROF_N_PAR_LANES] += R;
+        }
         return true;
     }
 
@@ -2492,6 +2525,7 @@ struct Flow {
                     // (diagnostic: rounds solved at once << 16 | rounds walked event by event; each half saturates on its own)
                     if (solved) gs_rounds += (gs_rounds >> 16) < 0xFFFFu ? 0x10000u : 0u;
                     else gs_rounds += (gs_rounds & 0xFFFFu) < 0xFFFFu ? 1u : 0u;
+                    if (kProf && !solved) prof_acc[PROF_N_WALKED_ROUNDS] += 1ull;
                     if (!solved && my_pass) done = gen_servers(lane, H_get(kChain ? level_slot(level) : 2u));
                     W::sync();
                     work += solved ? par_done : popc64(W::ballot(done != 0u));

@@ -67,6 +67,8 @@ def lib() -> C.CDLL:
         L.hc_arrivals.argtypes = [C.c_int, C.c_uint64, C.c_uint32] + [C.c_double] * 5 + [C.c_uint32, C.POINTER(C.c_double),
                                   C.POINTER(C.c_uint32)]
         L.hc_arrivals.restype = C.c_int64
+        L.hc_math.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_uint64]
+        L.hc_math.restype = None
         _lib = L
     return _lib
 
@@ -165,3 +167,11 @@ def flow_reason() -> str:
 def set_test_quantum(bits: int) -> None:
     """TEST-ONLY tie generator of the host builds (asyncflow_amd/csrc/af_math.hpp::test_quant)."""
     lib().hc_set_test_quantum(int(bits))
+
+
+def math(kind: int, x: np.ndarray) -> np.ndarray:
+    """af_math.hpp's elementary functions as the host compiles them (1 log, 2 exp, 3 normal quantile, 7 log on (0, 1])."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    lib().hc_math(kind, x.ctypes.data_as(C.POINTER(C.c_double)), out.ctypes.data_as(C.POINTER(C.c_double)), x.size)
+    return out

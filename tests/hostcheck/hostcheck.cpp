@@ -324,6 +324,13 @@ extern "C" uint64_t hc_flow_lds_bytes(const af_plan_t* p, uint32_t ipl, uint32_t
     return 8ull * (pk.words.size() + aff::choose_flow_layout(*p, ipl, ring_rows).n_words);
 }
 
+// ---- elementary functions of af_math.hpp on the host (the device build of the same header is probed by af_probe_math) ----
+// kind 1 log, 2 exp, 3 normal quantile, 7 log of a normal number in (0, 1]
+extern "C" void hc_math(int kind, const double* in, double* out, uint64_t n) {
+    for (uint64_t i = 0; i < n; ++i)
+        out[i] = kind == 1 ? af::af_log(in[i]) : kind == 2 ? af::af_exp(in[i]) : kind == 3 ? af::af_norminv(in[i]) : af::af_log_unit(in[i]);
+}
+
 // ---- the arrival sampler (af_pregen.hpp) ------------------------------------------------------------------------------
 // which = 0: af::gen_next_gap, the sequential statement (what the oracle follows); which = 1 / 2: the per-lane functions of
 // af_arrival_groups driven the way the kernel drives ONE lane (window_start, then steps of eight unit variates), with the

@@ -63,6 +63,26 @@ def test_norminv_matches_scipy():
     assert L.orc_x_norminv(0.5) == 0.0
 
 
+def test_engine_header_math_equals_the_oracle_bit_for_bit():
+    """af_math.hpp (host build of the header the kernels compile) against oracle_rng.h, bit patterns: normal quantile (the
+    boundaries of AS 241's three regions included), logarithm, exponential."""
+    from tests.hostcheck import build as hc
+
+    L = ol.lib()
+    rng = np.random.default_rng(5)
+    edge = np.array([0.075, 0.925, np.nextafter(0.075, 0), np.nextafter(0.075, 1), np.nextafter(0.925, 0), np.nextafter(0.925, 1),
+                     0.5, np.nextafter(0.5, 0), np.nextafter(0.5, 1), 2.0 ** -53, 1 - 2.0 ** -53, 1.3887943864964021e-11,
+                     1.4e-11, 1.38e-11, 1 - 1.4e-11, 1e-300, 5e-324, 0.0, 1.0])
+    ps = np.concatenate([rng.random(200000), rng.random(20000) * 0.075, 1 - rng.random(20000) * 0.075,
+                         np.exp(rng.uniform(np.log(1e-300), np.log(1e-3), 20000)), (rng.integers(0, 2 ** 53, 20000) / 2.0 ** 53), edge])
+    want = np.array([L.orc_x_norminv(float(p)) for p in ps])
+    assert np.array_equal(hc.math(3, ps).view(np.uint64), want.view(np.uint64))
+    xs = np.concatenate([rng.random(50000), np.exp(rng.uniform(-700, 700, 5000))])
+    assert np.array_equal(hc.math(1, xs).view(np.uint64), np.array([L.orc_x_log(float(x)) for x in xs]).view(np.uint64))
+    es = np.concatenate([rng.uniform(-20, 20, 50000), rng.uniform(-700, 700, 5000)])
+    assert np.array_equal(hc.math(2, es).view(np.uint64), np.array([L.orc_x_exp(float(x)) for x in es]).view(np.uint64))
+
+
 @pytest.mark.parametrize("mean", [0.003, 0.7, 4.0, 16.0, 40.0, 400.0, 1000.0])
 def test_poisson_moments(mean):
     L = ol.lib()
