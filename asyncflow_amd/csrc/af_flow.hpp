@@ -790,8 +790,26 @@ struct Flow {
                 // by exactly one (me) unless another message of the station shares my instant
                 if (!kTieBreak) {
                     uint32_t c = p0;
+                    // (round 6: the first kAhead keys of my bucket fetched at once -- 64 buckets for ~60 messages: the fullest holds
+                    // three or four, and the wave walked it one LDS round trip per key; what lies behind the bucket is masked.
+                    // Interleaved A/B, 0 / 2 / 4 ahead: config 2 37.75 / 37.50 / 37.06 ms, config 3 55.3 / 55.0 / 54.25, config 5
+                    // 189.2 / 187.7 / 187.5: profiles/r06/ab_select_bucket_ahead.txt)
+#if defined(AF_SELECT_BUCKET_AHEAD)
+                    constexpr uint32_t kAhead = AF_SELECT_BUCKET_AHEAD;
+#else
+                    constexpr uint32_t kAhead = 4u;
+#endif
+                    double kq[kAhead > 0u ? kAhead : 1u];
+#pragma unroll
+                    for (uint32_t u = 0u; u < kAhead; ++u) kq[u] = sorted()[p0 + u];
+#pragma unroll
+                    for (uint32_t u = 0u; u < kAhead; ++u) {
+                        const bool in = u < bc[q];
+                        r += in && kq[u] < k[q] ? 1u : 0u;
+                        c += in && kq[u] <= k[q] ? 1u : 0u;
+                    }
 #pragma nounroll
-                    for (uint32_t p = p0; p < p1; ++p) {
+                    for (uint32_t p = p0 + kAhead; p < p1; ++p) {
                         const double kk = sorted()[p];
                         r += kk < k[q] ? 1u : 0u;
                         c += kk <= k[q] ? 1u : 0u;
@@ -1205,7 +1223,36 @@ struct Flow {
     };
     // (the loops run to the plan-wide maxima with the lane's own counts as predicates: wave-uniform loop control
     // instead of three per-lane while loops)
-    AF_CORE SrvTimes srv_program(uint32_t row0, uint32_t counts, double arrival, double g_prev, double f_prev) const {
+    // (round 6: the step times of my request's program in REGISTERS while the relaxation runs -- every pass read them again
+    // from the plan blob, one LDS round trip per step and pass in a chain of dependent additions; programs of up to kStepRegs
+    // leading-I/O, CPU and trailing-I/O steps, which is every example of the reference; longer ones keep reading the blob)
+    static constexpr uint32_t kStepRegs = 2u;
+    struct StepDur {
+        double pre[kStepRegs], cpu[kStepRegs], post[kStepRegs];
+    };
+#if defined(AF_NO_STEP_REGS)
+    AF_CORE bool step_regs_ok() const { return false; }   // (measurement hook)
+#else
+    AF_CORE bool step_regs_ok() const { return A.max_pre <= kStepRegs && A.max_cpu <= kStepRegs && A.max_post <= kStepRegs; }
+#endif
+    AF_CORE StepDur step_durations(uint32_t row0, uint32_t counts) const {
+        StepDur d;
+        const uint32_t n_pre = counts & 0xFFu, n_cpu = (counts >> 8) & 0xFFu;
+#pragma unroll
+        for (uint32_t i = 0u; i < kStepRegs; ++i) {   // (a row past my own program's is read and never used)
+            d.pre[i] = i < A.max_pre ? u2d(blob[A.off_row + af::TREC * (row0 + i)]) : 0.0;
+            d.cpu[i] = i < A.max_cpu ? u2d(blob[A.off_row + af::TREC * (row0 + n_pre + i)]) : 0.0;
+            d.post[i] = i < A.max_post ? u2d(blob[A.off_row + af::TREC * (row0 + n_pre + n_cpu + i)]) : 0.0;
+        }
+        return d;
+    }
+    AF_CORE static double reg_step(const double (&v)[kStepRegs], uint32_t i) {
+        double x = v[0];
+#pragma unroll
+        for (uint32_t u = 1u; u < kStepRegs; ++u) x = i == u ? v[u] : x;
+        return x;
+    }
+    AF_CORE SrvTimes srv_program(uint32_t row0, uint32_t counts, double arrival, double g_prev, double f_prev, bool regs, const StepDur& d) const {
         SrvTimes r;
         const double T = A.total_time;
         const uint32_t n_pre = counts & 0xFFu, n_cpu = (counts >> 8) & 0xFFu, n_post = (counts >> 16) & 0xFFu;
@@ -1214,7 +1261,7 @@ struct Flow {
         uint32_t e_cnt = 0u;
         for (uint32_t i = 0u; i < A.max_pre; ++i)   // leading I/O steps
             if (i < n_pre) {
-                t = t + u2d(blob[A.off_row + af::TREC * (row0 + i)]);
+                t = t + (regs ? reg_step(d.pre, i) : u2d(blob[A.off_row + af::TREC * (row0 + i)]));
                 e_cnt += t < T ? 1u : 0u;
             }
         r.b = t;
@@ -1222,13 +1269,13 @@ struct Flow {
         r.s = t;
         for (uint32_t i = 0u; i < A.max_cpu; ++i)
             if (i < n_cpu) {
-                t = t + u2d(blob[A.off_row + af::TREC * (row0 + n_pre + i)]);
+                t = t + (regs ? reg_step(d.cpu, i) : u2d(blob[A.off_row + af::TREC * (row0 + n_pre + i)]));
                 e_cnt += t < T ? 1u : 0u;
             }
         r.f = t;
         for (uint32_t i = 0u; i < A.max_post; ++i)  // trailing I/O steps
             if (i < n_post) {
-                t = t + u2d(blob[A.off_row + af::TREC * (row0 + n_pre + n_cpu + i)]);
+                t = t + (regs ? reg_step(d.post, i) : u2d(blob[A.off_row + af::TREC * (row0 + n_pre + n_cpu + i)]));
                 e_cnt += t < T ? 1u : 0u;
             }
         r.g = t;
@@ -1269,7 +1316,10 @@ struct Flow {
             }
         }
         const uint32_t prog = lw[LBW_PROG + sv];
-        SrvTimes r = srv_program(row0, prog, a, g_prev, f_prev);
+        const bool regs = step_regs_ok();   // (wave-uniform; a constant of a plan-specialised build)
+        StepDur sd{};
+        if (regs) sd = step_durations(row0, prog);
+        SrvTimes r = srv_program(row0, prog, a, g_prev, f_prev, regs, sd);
         for (;;) {
             if (have) {
                 seg(3)[pos] = r.f;
@@ -1283,7 +1333,7 @@ struct Flow {
                 if (gp != g_prev || fp != f_prev) {
                     g_prev = gp;
                     f_prev = fp;
-                    const SrvTimes n = srv_program(row0, prog, a, g_prev, f_prev);
+                    const SrvTimes n = srv_program(row0, prog, a, g_prev, f_prev, regs, sd);
                     changed = n.f != r.f || n.g != r.g;
                     r = n;
                 }
