@@ -1220,6 +1220,8 @@ struct Flow {
     struct SrvTimes {
         double adm, b, s, f, g;
         uint32_t events;   // step ends before the horizon
+        uint32_t out_edge; // servers_solve(): the server's out-edge and its endpoint's RAM need (read there anyway)
+        double ram;
     };
     // (the loops run to the plan-wide maxima with the lane's own counts as predicates: wave-uniform loop control
     // instead of three per-lane while loops)
@@ -1291,34 +1293,38 @@ struct Flow {
         // A server whose endpoint needs more RAM than the server has never admits anybody: the first request blocks in
         // RAM.get() for good and everything behind it queues up (server.py:146-149; Container gets are FIFO).  Such
         // arrivals are timed events and nothing else.
-        const bool have = arrived && lw[LBW_SLOTS + sv] != 0u;
+        // (round 6: three LDS round trips instead of seven -- what is indexed by the server first, every lane, no conditions (a
+        // lane without an arrival reads server 0's words and uses none of them); then the endpoint's two words; then the ring
+        // entries and the step times.  The station was a chain of dependent, conditional reads.)
+        const uint32_t slots = lw[LBW_SLOTS + sv];   // requests that fit the RAM at once
+        const uint32_t arrivals0 = lw[LBW_ARRIVALS + sv], prog = lw[LBW_PROG + sv];
+        const uint64_t meta = blob[A.off_srv + af::SREC * sv + 1u];
+        const bool have = arrived && slots != 0u;
         const uint32_t off = have ? seg_off : 0u, n_k = have ? seg_len : 0u;
         const uint32_t li = pos - off;                         // my index among this window's arrivals of my server
-        const uint32_t j = have ? lw[LBW_ARRIVALS + sv] + li : 0u;      // ... and among all of them
-        const uint64_t meta = blob[A.off_srv + af::SREC * sv + 1u];
+        const uint32_t j = have ? arrivals0 + li : 0u;         // ... and among all of them
         const uint32_t cores = (uint32_t)meta & 0xFFFFu;
         const uint32_t ep = (uint32_t)(meta >> 32) & 0xFFFFu;
         const double ram = u2d(blob[A.off_ep + af::PREC * ep]);
         const uint32_t row0 = (uint32_t)blob[A.off_ep + af::PREC * ep + 1u];
         const uint32_t G = A.L.g_ring;
-        const uint32_t slots = lw[LBW_SLOTS + sv];   // requests that fit the RAM at once
         // where my predecessors' times come from: this window's segment, or the rings of earlier windows
         const bool ram_gate = have && ram > 0.0 && slots != 0u && slots <= G && j >= slots;
         const bool core_gate = have && j >= cores;
         const bool g_in_seg = ram_gate && li >= slots, f_in_seg = core_gate && li >= cores;
-        double g_prev = -AF_INF, f_prev = -AF_INF;
-        if (ram_gate && !g_in_seg) g_prev = gr(sv)[(j - slots) & (G - 1u)];
-        if (core_gate && !f_in_seg) f_prev = fr(sv)[(j - cores) & (A.L.c_ring - 1u)];   // (the release `cores` requests earlier: c_ring >= cores slots)
+        // (the ring entries are read by every lane -- masked indices stay inside the rings -- and used where the gates say so)
+        const double g_ring_v = gr(sv)[(j - slots) & (G - 1u)], f_ring_v = fr(sv)[(j - cores) & (A.L.c_ring - 1u)];   // (the release `cores` requests earlier: c_ring >= cores slots)
+        const bool regs = step_regs_ok();   // (wave-uniform; a constant of a plan-specialised build)
+        StepDur sd{};
+        if (regs) sd = step_durations(row0, prog);
+        double g_prev = (ram_gate && !g_in_seg) ? g_ring_v : -AF_INF;
+        double f_prev = (core_gate && !f_in_seg) ? f_ring_v : -AF_INF;
         if (have && ram > 0.0) {
             if (slots > G && j >= G) {         // more slots than the ring remembers: fine while fewer than G requests are inside
                 const double gq = li >= G ? AF_INF : gr(sv)[(j - G) & (G - 1u)];   // (li >= G: G arrivals of one server in one window)
                 if (!(gq < a)) why |= FLOW_WHY_RAM;
             }
         }
-        const uint32_t prog = lw[LBW_PROG + sv];
-        const bool regs = step_regs_ok();   // (wave-uniform; a constant of a plan-specialised build)
-        StepDur sd{};
-        if (regs) sd = step_durations(row0, prog);
         SrvTimes r = srv_program(row0, prog, a, g_prev, f_prev, regs, sd);
         for (;;) {
             if (have) {
@@ -1355,7 +1361,9 @@ struct Flow {
             ev += r.events;
         }
         W::sync();
-        if (lane < A.n_servers) lw[LBW_ARRIVALS + lane] += srv_cnt;
+        if (lane < A.n_servers) (void)W::lds_add(lw + LBW_ARRIVALS + lane, srv_cnt);   // (no value comes back: nothing to wait for)
+        r.out_edge = (uint32_t)(meta >> 16) & 0xFFFFu;
+        r.ram = ram;
         if (arrived && !have) {   // never admitted (the sequential kernels and the oracle report the same, informational, flag)
             r.adm = r.b = r.s = r.f = r.g = AF_INF;
             info |= af::FLAG_RAM_STARVED;
@@ -2656,16 +2664,14 @@ struct Flow {
                         const SrvTimes r = servers_solve(have, sv, pos, key, seg_off, seg_len, srv_cnt);
                         prof(PROF_SERVERS);
                         if (have) {
-                            const uint64_t meta = blob[A.off_srv + af::SREC * sv + 1u];
-                            e = (uint32_t)(meta >> 16) & 0xFFFFu;
+                            e = r.out_edge;   // (round 6: server words that servers_solve() read are not read again)
                             if (kChain) {
                                 const uint64_t tw = erec(e)[3];
                                 to_srv = ((uint32_t)tw & 0xFFu) == af::NODE_SERVER;
                                 to_lb = ((uint32_t)tw & 0xFFu) == af::NODE_LB;
                                 tgt = (uint32_t)(tw >> 8) & 0xFFu;
                             }
-                            const uint32_t ep = (uint32_t)(meta >> 32) & 0xFFFFu;
-                            const double ram = u2d(blob[A.off_ep + af::PREC * ep]);
+                            const double ram = r.ram;
                             const uint32_t s0 = A.n_edges + 3u * sv;
                             ts = r.g;
                             // ready queue: waited for a core (server.py:215-225); leading / trailing I/O steps; RAM held from
