@@ -525,24 +525,40 @@ struct Flow {
                     int32_t& value = half == 0u ? run_val : run_val2;
                     bool on, is_ram;
                     series_kind(ser, on, is_ram);
-                    for (uint32_t r0 = tick_base; r0 < stop; r0 += kRows) {
+                    // (round 6: whole chunks first, with the row numbers in SCALAR registers and one divergent region per chunk -- the
+                    // rows' own `r < stop` tests were vector compares and a branch each: ~23 instructions per row of config 5's 44
+                    // series, 14 % of that kernel)
+                    uint32_t r0 = W::bcast32(tick_base, 0u);
+                    const uint32_t stop_u = W::bcast32(stop, 0u);
+                    for (; r0 + kRows <= stop_u; r0 += kRows) {
+                        if (ser < pitch) {
+                            int32_t d[kRows];
+#pragma unroll
+                            for (uint32_t u = 0u; u < kRows; ++u)
+                                d[u] = in_hbm ? (int32_t)W::global_load(samples + (size_t)(r0 + u) * pitch + ser) : ring()[((r0 + u) & (R - 1u)) * pitch + ser];
+#pragma unroll
+                            for (uint32_t u = 0u; u < kRows; ++u) {
+                                if (!in_hbm) ring()[((r0 + u) & (R - 1u)) * pitch + ser] = 0;
+                                value += d[u];
+                                samples[(size_t)(r0 + u) * pitch + ser] = series_word(value, on, is_ram);
+                            }
+                        }
+                    }
+                    if (r0 < stop_u && ser < pitch) {   // (the rows left over: fewer than kRows, a scalar test each)
+                        const uint32_t n_left = stop_u - r0;
                         int32_t d[kRows];
 #pragma unroll
                         for (uint32_t u = 0u; u < kRows; ++u) {
-                            const uint32_t r = r0 + u;
                             d[u] = 0;
-                            if (ser < pitch && r < stop)
-                                d[u] = in_hbm ? (int32_t)W::global_load(samples + (size_t)r * pitch + ser) : ring()[(r & (R - 1u)) * pitch + ser];
+                            if (u < n_left) d[u] = in_hbm ? (int32_t)W::global_load(samples + (size_t)(r0 + u) * pitch + ser) : ring()[((r0 + u) & (R - 1u)) * pitch + ser];
                         }
 #pragma unroll
-                        for (uint32_t u = 0u; u < kRows; ++u) {
-                            const uint32_t r = r0 + u;
-                            if (ser < pitch && r < stop) {
-                                if (!in_hbm) ring()[(r & (R - 1u)) * pitch + ser] = 0;
+                        for (uint32_t u = 0u; u < kRows; ++u)
+                            if (u < n_left) {
+                                if (!in_hbm) ring()[((r0 + u) & (R - 1u)) * pitch + ser] = 0;
                                 value += d[u];
-                                samples[(size_t)r * pitch + ser] = series_word(value, on, is_ram);
+                                samples[(size_t)(r0 + u) * pitch + ser] = series_word(value, on, is_ram);
                             }
-                        }
                     }
                 }
             }
