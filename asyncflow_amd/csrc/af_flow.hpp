@@ -1026,6 +1026,9 @@ struct Flow {
     // index of each lane's message on its edge: sends[e] + (messages of lower lanes on the same edge).
     // Candidate edges: the LB's out-edges (payload order) or the servers' out-edges; the lane that holds a candidate's
     // counter advances it.
+    // (round 6, measured and dropped: the edges PRESENT in the batch taken from the lanes one after the other -- first lane left, its
+    // edge through v_readlane, everybody on it by ballot -- instead of the walk over the candidates, whose edge numbers are LDS reads
+    // at wave-uniform addresses: config 5 177.0 -> 181.1 ms, config 2 36.1 -> 36.6.  The candidates' reads do not wait for each other.)
     AF_CORE uint32_t claim_send_index(bool have, uint32_t e, bool server_edges) {
         const uint32_t n_cand = server_edges ? A.n_servers : A.n_lb_edges;
         uint32_t idx = 0u;
