@@ -349,6 +349,7 @@ struct Flow {
     // -2 % -- configs 3, 4, 5 --, the plain lean one +0.6 % with 224 instead of 153 static v_readlanes: it keeps loading.)
     static constexpr bool kCt = !kBig && !kTieBreak && FEAT != 0u;
     static constexpr uint32_t kCap = 64u * IPL, kAuxW = (kCap + 3u) / 4u;
+    static constexpr uint32_t kBigRegIpl = 2u;   // FEAT_BIGLIST: lists of up to 128 entries are ranked out of registers (select_big)
     AF_CORE uint32_t o_list() const { return (kCt && !kMarks) ? 0u : A.L.off_list; }   // (no marks: no spike table in front)
     AF_CORE uint32_t o_aux() const { return kCt ? o_list() + 8u * kCap : A.L.off_aux; }
     AF_CORE uint32_t o_aux3() const { return kCt ? o_aux() + kAuxW : A.L.off_aux3; }
@@ -729,6 +730,12 @@ struct Flow {
     // `level` != kAnyLevel: only the entries of the server list whose target server is of that level.
     AF_CORE uint32_t select(uint32_t s, double H_in, uint32_t room, double& okey, double& ot0, uint32_t& oaux, uint32_t hs, uint32_t level = kAnyLevel) {
         if (kBig) return select_big(s, H_in, room, okey, ot0, oaux, hs, level);
+        return select_regs<IPL>(s, H_in, room, okey, ot0, oaux, hs, level);
+    }
+    // (IPLx entries per lane in registers: the class's own IPL for the register-resident lists; round 6: also what select_big()
+    // hands a list of at most 64 x kBigRegIpl entries to)
+    template <uint32_t IPLx>
+    AF_CORE uint32_t select_regs(uint32_t s, double H_in, uint32_t room, double& okey, double& ot0, uint32_t& oaux, uint32_t hs, uint32_t level) {
         W::sync();   // appends of the previous station are visible
         const double lo = H_get(hs);
         const double hi_t = H_in < A.total_time ? H_in : A.total_time, hi = (kFar && t_lim < hi_t) ? t_lim : hi_t;   // (t_lim: run())
@@ -752,16 +759,16 @@ struct Flow {
         hist()[lane] = 0u;   // (zeroing them in front of the entry sync instead -- one sync less -- measured: no gain)
         W::sync();
         // my (up to 4) entries; bucket counts
-        double k[IPL], t[IPL], sent[IPL];
-        uint32_t a[IPL], b[IPL], slot[IPL];
-        bool valid[IPL], elig[IPL];
+        double k[IPLx], t[IPLx], sent[IPLx];
+        uint32_t a[IPLx], b[IPLx], slot[IPLx];
+        bool valid[IPLx], elig[IPLx];
 #pragma unroll
-        for (uint32_t q = 0u; q < IPL; ++q) {
+        for (uint32_t q = 0u; q < IPLx; ++q) {
             valid[q] = elig[q] = false;
             k[q] = t[q] = sent[q] = 0.0;
             a[q] = b[q] = slot[q] = 0u;
             {
-                // (entries past the list's end are read too -- the arrays hold 64 x IPL -- and masked by `valid`: the loads and
+                // (entries past the list's end are read too -- the arrays hold 64 x IPLx -- and masked by `valid`: the loads and
                 // the bucket arithmetic run for every lane, only the atomic sits in a divergent region)
                 const uint32_t i = q * 64u + lane;
                 valid[q] = i < n;
@@ -782,22 +789,22 @@ struct Flow {
         const uint32_t base = excl_scan(cnt, E);
         // a lane's bucket start and count straight from the bucket's lane (two ds_bpermute) instead of an LDS array written,
         // synchronised and read back (round 4: -0.4 %)
-        uint32_t bb[IPL], bc[IPL];
+        uint32_t bb[IPLx], bc[IPLx];
 #pragma unroll
-        for (uint32_t q = 0u; q < IPL; ++q) {
+        for (uint32_t q = 0u; q < IPLx; ++q) {
             bb[q] = W::shfl32(base, b[q]);
             bc[q] = W::shfl32(cnt, b[q]);
         }
 #pragma unroll
-        for (uint32_t q = 0u; q < IPL; ++q)
+        for (uint32_t q = 0u; q < IPLx; ++q)
             if (elig[q]) {
                 sorted()[bb[q] + slot[q]] = k[q];
                 if (kTieBreak) sorted_ts()[bb[q] + slot[q]] = sent[q];
             }
         W::sync();
-        uint32_t rank[IPL];
+        uint32_t rank[IPLx];
 #pragma unroll
-        for (uint32_t q = 0u; q < IPL; ++q) {
+        for (uint32_t q = 0u; q < IPLx; ++q) {
             rank[q] = 0u;
             if (elig[q]) {
                 const uint32_t p0 = bb[q], p1 = p0 + bc[q], me = p0 + slot[q];
@@ -855,14 +862,14 @@ struct Flow {
         double h_left = 0.0;   // the first message left behind bounds the horizon: its key straight from the lane that
         if (n_sel < E) {       // holds it (ballot + v_readlane), not through LDS (round 4)
 #pragma unroll
-            for (uint32_t q = 0u; q < IPL; ++q) {
+            for (uint32_t q = 0u; q < IPLx; ++q) {
                 const uint64_t mb = W::ballot(elig[q] && rank[q] == n_sel);
                 if (mb != 0ull) h_left = bcast_f64(k[q], (uint32_t)__builtin_ctzll(mb));
             }
         }
         uint32_t kept = 0u;
 #pragma unroll
-        for (uint32_t q = 0u; q < IPL; ++q) {
+        for (uint32_t q = 0u; q < IPLx; ++q) {
             {
                 const bool sel = elig[q] && rank[q] < n_sel;
                 const bool keep = valid[q] && !sel;
@@ -912,6 +919,12 @@ struct Flow {
             H_set(hs, hi);
             return 0u;
         }
+#if !defined(AF_BIG_NO_REGS)
+        // (round 6: a list that fits kBigRegIpl entries per lane is ranked out of registers like the short lists -- one pass and
+        // five LDS round trips instead of four passes over u32 words per entry; the general servers' first launch, whose lists
+        // hold 64 .. 128 entries, spent a fifth of its time here)
+        if (n <= 64u * kBigRegIpl) return select_regs<kBigRegIpl>(s, H_in, room, okey, ot0, oaux, hs, level);
+#endif
         AF_PLAN_AS double* K = list_key(s);
         AF_PLAN_AS double* T0 = list_t0(s);
         AF_PLAN_AS double* TS = list_ts(s);
