@@ -237,8 +237,12 @@ __device__ __noinline__ double users_draw_call(uint32_t dist, double mean, doubl
 //
 // 10 000 scenarios = 250 workgroups of 40 (one per CU): the producers' ~110 instructions per variate are spread over the
 // whole chip, the chain wave's round (~1 400 cycles) is what a round takes.
+// (round 6: 15 producers -- four waves per SIMD, the workgroup's 1 024 threads -- instead of 11: the producers' Philox + logarithm
+// are what a round takes, and a fourth wave per SIMD fills more of its issue slots.  Library variants on one box, 10 000 LB-2
+// replicas, 7 / 11 / 15 producers: 6.25 / 5.15 / 4.97 ms at 40 scenarios per workgroup, - / 7.58 / 6.90 ms at 64:
+// profiles/r06/ab_pregen_producers.txt)
 #if !defined(AF_PREGEN_PRODUCERS)
-#define AF_PREGEN_PRODUCERS 11   /* measurement builds: -DAF_PREGEN_PRODUCERS=n (<= 15: a workgroup is at most 16 waves) */
+#define AF_PREGEN_PRODUCERS 15   /* measurement builds: -DAF_PREGEN_PRODUCERS=n (<= 15: a workgroup is at most 16 waves) */
 #endif
 constexpr uint32_t kProducers = AF_PREGEN_PRODUCERS;
 constexpr uint32_t kGroupThreads = 64u * (1u + kProducers);
