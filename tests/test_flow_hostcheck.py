@@ -273,6 +273,17 @@ def test_second_long_spikes_of_the_reference_examples(heavy):
             assert got.completed > (2500 if heavy else 500)
 
 
+def test_long_lists_on_both_sides_of_the_register_ranked_length():
+    """select_big() ranks a list of up to 128 entries out of registers (round 6) and walks a longer one in chunks: hops of
+    0.3 / 0.9 / 2 s at 133 requests per second keep ~40 / ~120 / ~270 messages pending per station, so the lists cross that
+    length in both directions inside one run."""
+    for hop, seed in ((0.3, 5), (0.9, 6), (2.0, 7)):
+        p = lb_two_servers(horizon=30)
+        for e in p["topology_graph"]["edges"]:
+            e["latency"]["mean"] = hop
+        assert _run(p, seed, ipl=1, ring_rows=0, robust=True, long_list_entries=1024)[0] == "exact", hop
+
+
 def test_long_list_instantiation_matches_the_register_resident_one():
     """FEAT_BIGLIST changes how a list is walked, not what is selected: same outputs on workloads both can run."""
     for payload, seed in ((lb_two_servers(horizon=30), 7), (lb_with_events(users=300, horizon=60, scale=0.1), 42), (fanout8(horizon=20), 11)):
