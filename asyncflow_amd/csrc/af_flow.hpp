@@ -67,7 +67,8 @@ enum : uint32_t {
                                     // such a scenario goes straight to the next-event kernels; set together with FLOW_WHY_TIE
     FLOW_WHY_MASK = FLOW_WHY_TIE | FLOW_WHY_LIST | FLOW_WHY_RING | FLOW_WHY_RAM | FLOW_WHY_GEN_TIE,
 };
-constexpr uint32_t kMaxServers = 8;    // least connections: in-flight counts of <= 8 servers in two 64-bit words, 8 draws in registers
+constexpr uint32_t kMaxServers = 16;   // least connections: 16-bit in-flight counts of <= 16 servers in 64-bit words and their draws in registers (round 6: 8;
+                                       // Flow::lb_pick_lc_n<8> still serves fan-outs of up to 8 with two words and eight draws)
 // servers behind a round-robin LB: 16 slots per per-server array of lbw() (what binds first is the 64 sampled series a wave's
 // lanes carry: 2 + 5 S series -> S <= 12)
 constexpr uint32_t kSrvSlots = 16;
@@ -1133,13 +1134,22 @@ struct Flow {
     // time; what does not depend on them is done first and in parallel: the next 64 draws of every out-edge.
     // Returns lane r's out-edge; `tr` = its transit time (< 0: dropped).
     AF_CORE uint32_t lb_pick_lc(uint32_t n_sel, double my_key, double& tr) {
+        // (the narrow form where the fan-out allows it: half the draws and half the count words in registers; wave-uniform,
+        // a constant of a plan-specialised build)
+        if (A.n_lb_edges <= 8u && A.n_servers <= 8u) return lb_pick_lc_n<8u>(n_sel, my_key, tr);
+        return lb_pick_lc_n<kMaxServers>(n_sel, my_key, tr);
+    }
+    template <uint32_t NS>
+    AF_CORE uint32_t lb_pick_lc_n(uint32_t n_sel, double my_key, double& tr) {
+        static_assert(NS % 4u == 0u && NS <= kMaxServers, "four 16-bit counts per word");
+        constexpr uint32_t NW = NS / 4u;
         AF_PLAN_AS uint32_t* lw = lbw();
         // xs[c]: my lane's draw on the c-th out-edge (payload order) = the transit time of the (lane+1)-th message this
         // batch sends there (< 0: dropped).  Registers, not LDS: the walk below reads one of them per message, and an
         // LDS round trip per message would be most of its time.
-        double xs[kMaxServers];
+        double xs[NS];
 #pragma unroll
-        for (uint32_t c = 0u; c < kMaxServers; ++c) {
+        for (uint32_t c = 0u; c < NS; ++c) {
             xs[c] = -1.0;
             if (c < A.n_lb_edges) {
                 const uint32_t e = (uint32_t)blob[A.off_lb + c];
@@ -1149,11 +1159,13 @@ struct Flow {
         }
         // What does not depend on the picks either: how many entries of the server list are still in flight towards
         // each server at MY message's time -- every lane walks the list (the same entry in all lanes: LDS broadcasts)
-        // and keeps eight 16-bit counts in two words (<= kMaxServers servers, <= 16 384 entries).
+        // and keeps NS 16-bit counts in NS / 4 words (<= 16 384 entries).
         const AF_PLAN_AS double* K2 = list_key(2u);
         const AF_PLAN_AS uint16_t* AX = list_aux();
         const uint32_t n2 = n_list_get(2u);
-        uint64_t b_lo = 0ull, b_hi = 0ull;
+        uint64_t bw[NW];
+#pragma unroll
+        for (uint32_t w = 0u; w < NW; ++w) bw[w] = 0ull;
         uint64_t lb_edges = 0ull;   // FEAT_CHAIN: the server list also holds what servers send to servers -- not in flight on an LB edge
         if (kChain)
             for (uint32_t c = 0u; c < A.n_lb_edges; ++c) lb_edges |= 1ull << ((uint32_t)blob[A.off_lb + c] & 63u);
@@ -1162,8 +1174,8 @@ struct Flow {
             const uint32_t axw = W::bcast32(AX[i2], 0u), ax = axw & 0xFFu;
             const bool by_lb = !kChain || ((lb_edges >> ((axw >> 8) & 63u)) & 1ull) != 0ull;
             const uint64_t inc = (by_lb && k > my_key) ? 1ull << (16u * (ax & 3u)) : 0ull;
-            if (ax < 4u) b_lo += inc;
-            else b_hi += inc;
+#pragma unroll
+            for (uint32_t w = 0u; w < NW; ++w) bw[w] += (ax >> 2) == w ? inc : 0ull;   // (ax is wave-uniform: one scalar test per word)
             if (k == my_key) why |= FLOW_WHY_TIE;   // a delivery by the LB's edges at the very instant of a decision
         }
         // the candidates in the LB's current order: lane i < n_live holds (out-edge, its server, its place in the payload order)
@@ -1207,11 +1219,16 @@ struct Flow {
                 W::sync();
                 load_live();
             }
-            const uint64_t blo = W::bcast64(b_lo, r), bhi = W::bcast64(b_hi, r);
+            uint64_t br[NW];   // message r's counts
+#pragma unroll
+            for (uint32_t w = 0u; w < NW; ++w) br[w] = W::bcast64(bw[w], r);
             uint32_t best = 0xFFFFFFFFu, best_e = 0u, best_i = 0u;
             for (uint32_t i = 0u; i < nl; ++i) {
                 const uint32_t e = W::bcast32(live_e, i), srv = W::bcast32(live_srv, i);
-                uint32_t cnt = (uint32_t)((srv < 4u ? blo : bhi) >> (16u * (srv & 3u))) & 0xFFFFu;
+                uint64_t word = br[0];
+#pragma unroll
+                for (uint32_t w = 1u; w < NW; ++w) word = (srv >> 2) == w ? br[w] : word;
+                uint32_t cnt = (uint32_t)(word >> (16u * (srv & 3u))) & 0xFFFFu;
                 const bool earlier = lane < r && my_e == e;
                 cnt += popc64(W::ballot(earlier && my_k2 > t));
                 if (earlier && my_k2 == t) why |= FLOW_WHY_TIE;
@@ -1226,7 +1243,7 @@ struct Flow {
             const uint32_t c_of = W::bcast32(live_c, best_i);
             double x = -1.0;
 #pragma unroll
-            for (uint32_t c = 0u; c < kMaxServers; ++c)
+            for (uint32_t c = 0u; c < NS; ++c)
                 if (c == c_of) x = bcast_f64(xs[c], k_on_edge);
             const double sp = (kMarks && A.n_edge_marks != 0u) ? spike_at(best_e, t) : 0.0;
             if (lane == r) {

@@ -97,7 +97,7 @@ inline std::string flow_ineligible_reason(const af_plan_t& p) {
         if (ck == AF_NODE_LB && feeds_lb != 0u) return "the client and a server both feed the load balancer";
         if (ck != AF_NODE_LB && (ck != AF_NODE_SERVER || feeds_lb != 1u)) return "neither the client nor exactly one server feeds the load balancer";
         if (p.n_lb_edges == 0 || p.n_lb_edges > 16u) return "load balancer fan-out outside 1..16";
-        if (p.lb_algo == AF_LB_LEAST_CONNECTIONS && (p.n_lb_edges > kMaxServers || p.n_servers > kMaxServers)) return "least-connections fan-out above 8";
+        if (p.lb_algo == AF_LB_LEAST_CONNECTIONS && (p.n_lb_edges > kMaxServers || p.n_servers > kMaxServers)) return "least-connections fan-out above 16";
         for (uint32_t i = 0; i < p.n_lb_edges; ++i)
             if (p.edge_target_kind[p.lb_edges[i]] != AF_NODE_SERVER) return "load balancer edge does not lead to a server";
     } else if (ck != AF_NODE_SERVER) {

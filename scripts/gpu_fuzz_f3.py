@@ -35,7 +35,18 @@ def _wide(k: int) -> dict:
     return p
 
 
+def _wide_lc(k: int) -> dict:
+    rng = random.Random(99900 + k)
+    p = wide_fanout(rng.choice((9, 11, 12, 14, 16)), "least_connection", horizon=12, users=rng.choice((60, 100, 200)))
+    if rng.random() < 0.7:   # (else: both endpoints -- general servers behind least connections)
+        for s in p["topology_graph"]["nodes"]["servers"]:
+            s["endpoints"] = s["endpoints"][:1]
+    return p
+
+
 families = {
+    # round 6: 9 .. 16 servers behind a least-connections LB (Flow::lb_pick_lc_n<16>)
+    "9 .. 16 servers behind a least-connections LB": _wide_lc,
     # round 5: servers in front of the LB, four / five server levels, 13 .. 16 servers behind a round-robin LB
     "servers in front of the LB": _gateway,
     "four / five server levels": _deep,

@@ -347,6 +347,27 @@ def test_round_robin_fan_out_beyond_eight_servers(n_srv):
         assert hc.flow_simulate(lower(seventeen), 1) is None and "more than 16 servers" in hc.flow_reason()
 
 
+@pytest.mark.parametrize("n_srv", [9, 12, 16])
+def test_least_connections_fan_out_beyond_eight_servers(n_srv):
+    """Round 6: a least-connections load balancer in front of 9 .. 16 servers runs on the stage-parallel kernel (the walk keeps
+    16-bit in-flight counts of sixteen servers in four words and sixteen prepared draws per lane: Flow::lb_pick_lc_n<16>;
+    lb_algorithms.py:10-20).  wide_fanout's topology with ONE endpoint per server: multi-core servers, RAM, two outages and a
+    spike; then with both endpoints (general servers behind least connections)."""
+    from oracle.scenarios import wide_fanout
+
+    payload = wide_fanout(n_srv, "least_connection", horizon=10, users=100)
+    both = copy.deepcopy(payload)
+    for s in payload["topology_graph"]["nodes"]["servers"]:
+        s["endpoints"] = s["endpoints"][:1]
+    assert _run(payload, 81, ipl=4, ring_rows=0)[0] == "exact"
+    assert _run(payload, 82, ipl=4, ring_rows=128)[0] == "exact"
+    status, _ = _run(both, 83, ipl=1, ring_rows=0, robust=True, long_list_entries=1024)
+    assert status in ("exact", "fallback")
+    if n_srv == 16:
+        seventeen = wide_fanout(17, "least_connection", horizon=10)
+        assert hc.flow_simulate(lower(seventeen), 1) is None
+
+
 @pytest.mark.parametrize(("depth", "fan"), [(4, True), (5, True), (5, False)])
 def test_server_chains_of_four_and_five_levels(depth, fan):
     """Round 5: tiers deeper than three levels.  The server station runs once per level (FEAT_CHAIN), the

@@ -643,6 +643,28 @@ def test_poisson_latencies_and_wide_round_robin_fan_out_run_on_the_flow_kernel()
     _same_batches(res, special)
 
 
+@pytest.mark.parametrize("n_srv", [9, 16])
+def test_least_connections_over_nine_to_sixteen_servers_run_on_the_flow_kernel(n_srv):
+    """Round 6: least connections in front of 9 .. 16 servers is inside the stage-parallel kernel's range (Flow::lb_pick_lc_n<16>:
+    sixteen 16-bit in-flight counts in four words, sixteen prepared draws per lane; rounds 2-5: eight, wider fan-outs went to the
+    next-event kernels).  Against the oracle, against the next-event kernels, generic and plan-specialised builds."""
+    from oracle.scenarios import wide_fanout
+
+    wide = wide_fanout(n_srv, "least_connection", horizon=16, users=100)
+    for s in wide["topology_graph"]["nodes"]["servers"]:
+        s["endpoints"] = s["endpoints"][:1]
+    seeds = np.arange(24, dtype=np.uint64) + 170 + n_srv
+    res = _runner(wide, seeds=seeds).run()
+    assert res.flow_reason == "" and res.engine_stats.flow_scenarios == 24, res.flow_reason
+    plan = lower(wide)
+    for i in (0, 9, 23):
+        _assert_scenario(res[i], ol.simulate(plan, int(seeds[i])), f"{n_srv}-server least-connections scenario {i}")
+    _same_batches(res, _runner(wide, seeds=seeds, flow=False).run())
+    special = _runner(wide, seeds=seeds, specialise=True).run()
+    assert special.engine_stats.specialised_launches >= 1
+    _same_batches(res, special)
+
+
 def test_servers_that_feed_servers_run_on_the_flow_kernel():
     """Round 4: server -> server edges are inside the stage-parallel kernel's range (FEAT_CHAIN: the servers in
     levels, the server station once per level and round over the one server list, each level with its own horizon).
