@@ -17,4 +17,4 @@ for c in 3 4 5 6; do
   python bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline --no-diagnostics --separate-summary > $OUT/bench_c${c}_two_calls.log 2>&1
   grep '^{' $OUT/bench_c${c}_two_calls.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('config $c two calls', 'ms/step %.2f' % d['ms_per_step'], 'flow %.2f' % d['flow_kernel_ms'], 'value %.4g' % d['value'])"
 done
-bash scripts/gpu_r6_fuzz.sh 20000
+bash scripts/gpu_r6_fuzz.sh ${1:-20000}

@@ -45,8 +45,8 @@ def test_feed_forward_payloads_every_scenario_against_the_oracle():
 def test_round_4_and_5_families_every_scenario_against_the_oracle():
     out = _script("gpu_fuzz_f3").run(4, 300_000, oracle_every=True)
     fams = [v for k, v in out.items() if k != "different"]
-    assert out["different"] == 0 and len(fams) == 8
-    assert sum(t["scenarios"] + 8 * t["overflow_raised"] for t in fams) == 8 * 4 * 8
+    assert out["different"] == 0 and len(fams) == 9             # round 6: + least connections over 9 .. 16 servers
+    assert sum(t["scenarios"] + 8 * t["overflow_raised"] for t in fams) == 9 * 4 * 8
     assert sum(t["oracle_checks"] for t in fams) == sum(t["scenarios"] for t in fams) >= 200
     assert sum(t["on_flow_kernel"] for t in fams) >= 100          # (random topologies and tie storms mostly go to the next-event kernels)
 
