@@ -929,3 +929,44 @@ def test_servers_in_front_of_the_load_balancer_run_on_the_flow_kernel(kw):
     special = _runner(payload, seeds=seeds, specialise=True).run()
     assert special.engine_stats.specialised_launches >= 1
     _same_batches(res, special)
+
+
+# ------------------------------------------------------------------------------------------------ sweeps in flight
+def test_sweeps_in_flight_on_host_threads_equal_their_lone_runs():
+    """Several sweeps at once on one GPU: every engine has its own HIP streams, counter block and buffers, the error string is
+    per thread and ctypes releases the GIL inside `af_engine_run_summarized`, so runners called from host threads overlap on
+    the device (the next sweep's pre-generation and first waves beside the previous sweep's last residency round:
+    scripts/gpu_two_sweeps_in_flight.py measures it).  Three different payloads -- stage-parallel kernel with the analyzer in
+    the same call, general servers, next-event kernels only -- each twice in flight, equal their lone runs and the oracle."""
+    import threading
+
+    cases = [(lb_two_servers(horizon=60), dict(seeds=np.arange(700, dtype=np.uint64) + 11, summary=True)),
+             (fanout8(horizon=30), dict(seeds=np.arange(300, dtype=np.uint64) + 5)),
+             (single_server(horizon=120), dict(seeds=np.arange(500, dtype=np.uint64) + 3, flow=False))]
+    lone = [_runner(p, **kw).run() for p, kw in cases]
+    got: dict[int, object] = {}
+    errors: list[BaseException] = []
+
+    def work(slot: int) -> None:
+        try:
+            p, kw = cases[slot % len(cases)]
+            got[slot] = _runner(copy.deepcopy(p), **kw).run()
+        except BaseException as exc:  # noqa: BLE001
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(s,)) for s in range(2 * len(cases))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for slot in range(2 * len(cases)):
+        want = lone[slot % len(cases)]
+        _same_batches(got[slot], want)
+        if cases[slot % len(cases)][1].get("summary"):
+            a, b = got[slot].summary()["stats"].cpu().numpy(), want.summary()["stats"].cpu().numpy()
+            assert np.array_equal(a.view(np.uint64), b.view(np.uint64))      # (the analyzer of the same call: bit patterns)
+    for k, (p, kw) in enumerate(cases):
+        plan = lower(p)
+        for i in (0, len(kw["seeds"]) - 1):
+            _assert_scenario(got[k][i], ol.simulate(plan, int(kw["seeds"][i])), f"case {k} scenario {i}")
