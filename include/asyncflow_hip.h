@@ -22,8 +22,13 @@
  *    (e.g. torch tensors); the engine never allocates or frees output buffers;
  *  - all entry points return 0 on success, a negative af_status otherwise, and
  *    leave a thread-local message retrievable through af_last_error();
- *  - one host thread per engine; calls are synchronous with respect to the
- *    returned buffers (one internal HIP stream, synchronised before return);
+ *  - one host thread per engine AT A TIME; calls are synchronous with respect to the
+ *    returned buffers (the engine's own HIP streams, synchronised before return);
+ *    different engines may be called from different host threads at once: an
+ *    engine owns its streams, counter block and scratch buffers, the library keeps
+ *    no mutable global state besides the RCCL symbol table af_comm_load fills, and
+ *    the error message is per thread (tests/test_gpu_flow.py::
+ *    test_sweeps_in_flight_on_host_threads_equal_their_lone_runs);
  *  - capacity overflow is reported per scenario in counts[AF_CNT_FLAGS] and is
  *    never a silent drop.
  */
